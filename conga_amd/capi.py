@@ -1,0 +1,254 @@
+"""ctypes binding of the C-ABI in include/conga_hip.h (conga_amd/libconga_hip.so).
+
+The shared library is the product; this module only marshals numpy arrays through its plain-C
+entry points.  There is no CPU fallback: if the library is missing, or no HIP device is present,
+the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libconga_hip.so")
+
+CONGA_OK = 0
+CONGA_ERR_INVALID = -1
+CONGA_ERR_NO_DEVICE = -2
+CONGA_ERR_HIP = -3
+CONGA_ERR_NOMEM = -4
+CONGA_ERR_UNSORTED = -5
+CONGA_ERR_RANGE = -6
+
+FLAG_READS_UNSORTED = 0x1
+FLAG_PROFILE = 0x2
+
+DELETION = "D"
+DUPLICATION = "E"
+
+KERNEL_NAMES = ("ingest", "depth_tile", "expected_table", "paint", "interval_reduce", "interval_score")
+
+# every symbol include/conga_hip.h declares
+EXPORTS = (
+    "conga_create", "conga_destroy", "conga_strerror", "conga_last_error", "conga_abi_version",
+    "conga_device_count", "conga_chrom_begin", "conga_reads_staging", "conga_reads_commit",
+    "conga_mappability", "conga_intervals", "conga_split_support", "conga_chrom_compute",
+    "conga_chrom_fetch", "conga_chrom_finish", "conga_results_device", "conga_stream", "conga_sync",
+    "conga_copy_read_depth", "conga_copy_mappability", "conga_host_repeat_add_f32",
+)
+
+
+class Opts(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("mq_threshold", C.c_int32), ("gc_step", C.c_int32),
+                ("flags", C.c_uint32), ("reserved", C.c_int32 * 4)]
+
+
+class ReadStaging(C.Structure):
+    _fields_ = [("pos", C.POINTER(C.c_int32)), ("mapq", C.POINTER(C.c_uint8)), ("capacity", C.c_size_t)]
+
+
+class ChromStats(C.Structure):
+    _fields_ = [("reads_committed", C.c_int64), ("reads_counted", C.c_int64),
+                ("reads_out_of_range", C.c_int64), ("rd_sum", C.c_int64), ("mean", C.c_float),
+                ("n_kernels", C.c_int32), ("rd_per_gc", C.c_int64 * 101), ("window_per_gc", C.c_int64 * 101),
+                ("kernel_ms", C.c_double * 8)]
+
+
+RESULT_DTYPE = np.dtype([
+    ("observed", "<i4"), ("expected", "<f4"), ("lhomo", "<f8"), ("lhetero", "<f8"), ("lnone", "<f8"),
+    ("score", "<f8"), ("cn", "<i4"), ("rp", "<i4"), ("border_rp", "<i4"), ("reserved", "<i4"),
+    ("mappability", "<f8"),
+])
+assert RESULT_DTYPE.itemsize == 64
+
+
+class CongaError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("conga status %d: %s" % (status, msg))
+        self.status = status
+
+
+_lib = None
+
+
+def load():
+    """dlopen the HIP library.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(conga_amd has no CPU path)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i64, sz = C.c_void_p, C.c_int64, C.c_size_t
+    L.conga_create.restype = vp
+    L.conga_create.argtypes = [C.c_int, C.POINTER(Opts), C.POINTER(C.c_int)]
+    L.conga_destroy.restype = None
+    L.conga_destroy.argtypes = [vp]
+    L.conga_strerror.restype = C.c_char_p
+    L.conga_strerror.argtypes = [C.c_int]
+    L.conga_last_error.restype = C.c_char_p
+    L.conga_last_error.argtypes = [vp]
+    L.conga_abi_version.restype = C.c_int
+    L.conga_device_count.restype = C.c_int
+    L.conga_chrom_begin.restype = C.c_int
+    L.conga_chrom_begin.argtypes = [vp, i64, vp, vp, i64]
+    L.conga_reads_staging.restype = C.c_int
+    L.conga_reads_staging.argtypes = [vp, C.POINTER(ReadStaging)]
+    L.conga_reads_commit.restype = C.c_int
+    L.conga_reads_commit.argtypes = [vp, sz]
+    L.conga_mappability.restype = C.c_int
+    L.conga_mappability.argtypes = [vp, vp, vp, vp, sz]
+    L.conga_intervals.restype = C.c_int
+    L.conga_intervals.argtypes = [vp, C.c_char, vp, vp, sz]
+    L.conga_split_support.restype = C.c_int
+    L.conga_split_support.argtypes = [vp, C.c_char, vp, sz]
+    L.conga_chrom_compute.restype = C.c_int
+    L.conga_chrom_compute.argtypes = [vp]
+    L.conga_chrom_fetch.restype = C.c_int
+    L.conga_chrom_fetch.argtypes = [vp, vp, vp, vp, C.POINTER(ChromStats)]
+    L.conga_chrom_finish.restype = C.c_int
+    L.conga_chrom_finish.argtypes = [vp, vp, vp, vp, C.POINTER(ChromStats)]
+    L.conga_results_device.restype = C.c_int
+    L.conga_results_device.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]
+    L.conga_stream.restype = vp
+    L.conga_stream.argtypes = [vp]
+    L.conga_sync.restype = C.c_int
+    L.conga_sync.argtypes = [vp]
+    L.conga_copy_read_depth.restype = C.c_int
+    L.conga_copy_read_depth.argtypes = [vp, vp, i64]
+    L.conga_copy_mappability.restype = C.c_int
+    L.conga_copy_mappability.argtypes = [vp, vp, i64]
+    L.conga_host_repeat_add_f32.restype = C.c_float
+    L.conga_host_repeat_add_f32.argtypes = [C.c_float, C.c_float, C.c_uint32]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One conga_ctx: one GPU, one stream, one chromosome in flight."""
+
+    def __init__(self, device=0, mq_threshold=-1, gc_step=100, flags=0):
+        self._lib = load()
+        opts = Opts(C.sizeof(Opts), mq_threshold, gc_step, flags)
+        st = C.c_int(0)
+        self._h = self._lib.conga_create(device, C.byref(opts), C.byref(st))
+        if not self._h:
+            raise CongaError(st.value, self._lib.conga_strerror(st.value).decode())
+        self.gc_step = gc_step
+        self.n_dels = self.n_dups = 0
+        self.chrom_len = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.conga_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        if rc != CONGA_OK:
+            raise CongaError(rc, "%s: %s" % (self._lib.conga_strerror(rc).decode(),
+                                             self._lib.conga_last_error(self._h).decode()))
+
+    # -- one chromosome ------------------------------------------------------------------
+    def chrom_begin(self, chrom_len, gc_hist_w, gc_like_w=None):
+        gh = np.ascontiguousarray(gc_hist_w, dtype=np.uint8)
+        gl = gh if gc_like_w is None else np.ascontiguousarray(gc_like_w, dtype=np.uint8)
+        if len(gl) != len(gh):
+            raise ValueError("gc_hist_w and gc_like_w differ in length")
+        self._check(self._lib.conga_chrom_begin(self._h, chrom_len, _p(gh), _p(gl), len(gh)))
+        self.n_dels = self.n_dups = 0
+        self.chrom_len = chrom_len
+
+    def reads(self, pos, mapq):
+        """Streams (pos, mapq) through the pinned staging ring, like the BAM loop would."""
+        pos = np.ascontiguousarray(pos, dtype=np.int32)
+        mapq = np.ascontiguousarray(mapq, dtype=np.uint8)
+        if len(pos) != len(mapq):
+            raise ValueError("pos and mapq differ in length")
+        n, off = len(pos), 0
+        stg = ReadStaging()
+        while off < n or (n == 0 and off == 0):
+            self._check(self._lib.conga_reads_staging(self._h, C.byref(stg)))
+            k = min(stg.capacity, n - off)
+            if k:
+                C.memmove(stg.pos, pos[off:].ctypes.data, k * 4)
+                C.memmove(stg.mapq, mapq[off:].ctypes.data, k)
+            self._check(self._lib.conga_reads_commit(self._h, k))
+            off += k
+            if n == 0:
+                break
+
+    def mappability(self, start, end, val):
+        s = np.ascontiguousarray(start, dtype=np.int32)
+        e = np.ascontiguousarray(end, dtype=np.int32)
+        v = np.ascontiguousarray(val, dtype=np.float32)
+        self._check(self._lib.conga_mappability(self._h, _p(s), _p(e), _p(v), len(s)))
+
+    def intervals(self, sv_type, start, end):
+        s = np.ascontiguousarray(start, dtype=np.int32)
+        e = np.ascontiguousarray(end, dtype=np.int32)
+        self._check(self._lib.conga_intervals(self._h, sv_type.encode()[:1], _p(s), _p(e), len(s)))
+        if sv_type == DELETION:
+            self.n_dels = len(s)
+        else:
+            self.n_dups = len(s)
+
+    def split_support(self, sv_type, support):
+        s = np.ascontiguousarray(support, dtype=np.int32)
+        self._check(self._lib.conga_split_support(self._h, sv_type.encode()[:1], _p(s), len(s)))
+
+    def compute(self):
+        self._check(self._lib.conga_chrom_compute(self._h))
+
+    def fetch(self):
+        """-> (dels RESULT_DTYPE[n_dels], dups RESULT_DTYPE[n_dups], E float32[101], ChromStats)"""
+        dels = np.zeros(self.n_dels, dtype=RESULT_DTYPE)
+        dups = np.zeros(self.n_dups, dtype=RESULT_DTYPE)
+        E = np.zeros(101, dtype=np.float32)
+        st = ChromStats()
+        self._check(self._lib.conga_chrom_fetch(self._h, _p(dels) if self.n_dels else None,
+                                                _p(dups) if self.n_dups else None, _p(E), C.byref(st)))
+        return dels, dups, E, st
+
+    def finish(self):
+        self.compute()
+        return self.fetch()
+
+    def sync(self):
+        self._check(self._lib.conga_sync(self._h))
+
+    def stream(self):
+        return self._lib.conga_stream(self._h)
+
+    def results_device(self):
+        """-> (device pointer (int), n_dels, n_dups)"""
+        p, nd, nu = C.c_void_p(), C.c_size_t(), C.c_size_t()
+        self._check(self._lib.conga_results_device(self._h, C.byref(p), C.byref(nd), C.byref(nu)))
+        return p.value or 0, nd.value, nu.value
+
+    def read_depth(self):
+        out = np.empty(self.chrom_len, dtype=np.int16)
+        self._check(self._lib.conga_copy_read_depth(self._h, _p(out), len(out)))
+        return out
+
+    def mappability_track(self):
+        out = np.empty(self.chrom_len, dtype=np.float32)
+        self._check(self._lib.conga_copy_mappability(self._h, _p(out), len(out)))
+        return out
+
+
+def host_repeat_add_f32(s, c, k):
+    return np.float32(load().conga_host_repeat_add_f32(C.c_float(float(s)), C.c_float(float(c)), int(k)))

@@ -1,0 +1,189 @@
+/*
+ * conga_hip.h -- C-ABI of the MI355X (gfx950) read-depth / likelihood engine.
+ *
+ * This is the drop-in seam for CONGA's per-chromosome hot path.  The reference is one
+ * executable with no FFI; the seam sits where its BAM loop hands over to the depth model:
+ *
+ *   producer  count_reads_bam            /root/reference/bam_data.c:192-221
+ *   consumers init_rd_per_chr            /root/reference/read_distribution.c:12-18
+ *             calc_mean_per_chr          /root/reference/read_distribution.c:49-84
+ *             init_mappability_per_chr   /root/reference/read_distribution.c:20-24
+ *             load_mappability_regions   /root/reference/svs.c:317-377 (paint loop :363-371)
+ *             find_depths / calculate_likelihood_CNV / lpoisson
+ *                                        /root/reference/likelihood.c:96-169,290-308
+ *   state     bam_info.read_depth / mappability / expected_read_depth
+ *                                        /root/reference/common.h:88-104
+ *             svs                        /root/reference/svs.h:10-28
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 (CONGA_OK) or a negative
+ * conga_status and never calls exit(); the caller owns all host buffers it passes in; the library
+ * owns device memory and the pinned staging buffers.  A context belongs to one GPU and must be
+ * driven by one host thread at a time (the reference is single-threaded and keeps this state in
+ * globals: likelihood.c:10-15).  There is no CPU fallback: without a usable HIP device
+ * conga_create() fails.
+ */
+#ifndef CONGA_HIP_H_
+#define CONGA_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CONGA_ABI_VERSION 1
+
+typedef struct conga_ctx conga_ctx;
+
+typedef enum conga_status {
+	CONGA_OK = 0,
+	CONGA_ERR_INVALID = -1,     /* bad argument or call order */
+	CONGA_ERR_NO_DEVICE = -2,   /* no HIP device / device index out of range */
+	CONGA_ERR_HIP = -3,         /* a HIP runtime call failed; see conga_last_error() */
+	CONGA_ERR_NOMEM = -4,       /* host or device allocation failed */
+	CONGA_ERR_UNSORTED = -5,    /* committed reads are not sorted by position (and CONGA_FLAG_READS_UNSORTED not set) */
+	CONGA_ERR_RANGE = -6        /* an interval or mappability row lies outside what the engine can address */
+} conga_status;
+
+/* conga_opts.flags */
+#define CONGA_FLAG_READS_UNSORTED 0x1u /* reads may arrive in any order: depth uses global atomics */
+#define CONGA_FLAG_PROFILE 0x2u        /* bracket every kernel with HIP events; conga_chrom_stats.kernel_ms is filled */
+
+/* SV types, as the reference's DELETION / DUPLICATION (common.h:12-13) */
+#define CONGA_DELETION 'D'
+#define CONGA_DUPLICATION 'E'
+
+typedef struct conga_opts {
+	uint32_t struct_size;    /* sizeof(conga_opts), for forward compatibility */
+	int32_t mq_threshold;    /* params->mq_threshold (cmdline.c:188-194): a read counts iff mapq > this; -1 = all */
+	int32_t gc_step;         /* WINDOWSLIDE (read_distribution.h:8): bases per GC byte; 0 -> 100 */
+	uint32_t flags;          /* CONGA_FLAG_* */
+	int32_t reserved[4];
+} conga_opts;
+
+/* Pinned host buffers the BAM loop fills (structure of arrays).  Replaces the fields of
+ * bam1_core_t that count_reads_bam reads (bam_data.c:203-213): core.pos and core.qual. */
+typedef struct conga_read_staging {
+	int32_t *pos;    /* 0-based leftmost coordinate (bam1_core_t.pos) */
+	uint8_t *mapq;   /* bam1_core_t.qual */
+	size_t capacity; /* records that fit before the next conga_reads_commit() */
+} conga_read_staging;
+
+/* Output fields of one `svs` record (svs.h:10-28).  64 bytes, no padding holes. */
+typedef struct conga_result {
+	int32_t observed;    /* observed_rd_sv */
+	float expected;      /* expected_rd_sv (serial float32 sum, bit-exact) */
+	double lhomo;
+	double lhetero;
+	double lnone;
+	double score;        /* likelihood_score */
+	int32_t copy_number; /* 2 -> "1/1", else "0/1" */
+	int32_t rp;          /* split-read support (dups); copied through from conga_split_support() */
+	int32_t border_rp;   /* split-read support (dels) */
+	int32_t reserved;
+	double mappability;  /* mean mappability over [start, end); 0 when no track was given */
+} conga_result;
+
+enum {
+	CONGA_K_INGEST = 0,   /* sortedness / range check + tile index over the read tuples */
+	CONGA_K_DEPTH,        /* LDS-tiled depth build + GC histogram (K1 + K2) */
+	CONGA_K_EXPECTED,     /* expected_read_depth[101] */
+	CONGA_K_PAINT,        /* mappability paint (K3) */
+	CONGA_K_REDUCE,       /* per-interval integer depth sum + mappability sum (K4, memory side) */
+	CONGA_K_SCORE,        /* serial-float expected chain + likelihoods + CN (K4 chain + K5) */
+	CONGA_K_COUNT
+};
+
+typedef struct conga_chrom_stats {
+	int64_t reads_committed;    /* tuples handed over for this chromosome */
+	int64_t reads_counted;      /* bam_info.total_read_count_unfiltered (bam_data.c:214) */
+	int64_t reads_out_of_range; /* pos outside [0, L): skipped (undefined behaviour in the reference) */
+	int64_t rd_sum;             /* rd_cnt of calc_mu_per_chr (read_distribution.c:35) */
+	float mean;                 /* bam_info.mean (read_distribution.c:39) */
+	int32_t n_kernels;          /* CONGA_K_COUNT */
+	int64_t rd_per_gc[101];     /* rd_per_gc_unfiltered (read_distribution.c:52) */
+	int64_t window_per_gc[101]; /* window_per_gc (read_distribution.c:51) */
+	double kernel_ms[8];        /* per-kernel device time of the last compute (CONGA_FLAG_PROFILE), else 0 */
+} conga_chrom_stats;
+
+/* ---- lifetime -------------------------------------------------------------------------- */
+
+/* Creates a context on HIP device `device`.  Returns NULL on failure; *status (may be NULL)
+ * receives the reason.  opts may be NULL (defaults: mq_threshold -1, gc_step 100, flags 0). */
+conga_ctx *conga_create(int device, const conga_opts *opts, int *status);
+void conga_destroy(conga_ctx *ctx);
+const char *conga_strerror(int status);
+/* Text of the most recent failure on this context ("" if none). */
+const char *conga_last_error(const conga_ctx *ctx);
+int conga_abi_version(void);
+int conga_device_count(void);
+
+/* ---- one chromosome --------------------------------------------------------------------- */
+
+/* init_rd_per_chr + the GC side of calc_mean_per_chr / calculate_likelihood_CNV.
+ * chrom_len = sonic->chromosome_lengths[chr_index].  gc_hist_w[w] is the rounded GC% (0..100) that
+ * `sonic_get_gc_content(chr, i, min(i + step, L))` yields for bases i in window w (loop of
+ * read_distribution.c:63-73); gc_like_w[w] the one `sonic_get_gc_content(chr, i, i + step)` yields
+ * (likelihood.c:117).  They may be the same pointer.  n_win must be ceil(chrom_len / gc_step).
+ * Resets all per-chromosome state (reads, intervals, mappability, split support). */
+int conga_chrom_begin(conga_ctx *ctx, int64_t chrom_len, const uint8_t *gc_hist_w, const uint8_t *gc_like_w,
+		int64_t n_win);
+
+/* count_reads_bam, producer side: get a pinned buffer, fill pos[0..n) / mapq[0..n) in BAM order,
+ * commit.  Commit starts an asynchronous copy into HBM and returns; the next conga_reads_staging()
+ * hands out the other buffer of the ring.  May be repeated any number of times per chromosome. */
+int conga_reads_staging(conga_ctx *ctx, conga_read_staging *out);
+int conga_reads_commit(conga_ctx *ctx, size_t n);
+
+/* load_mappability_regions: rows of this chromosome in FILE ORDER (later rows overwrite earlier
+ * ones, end inclusive: svs.c:368).  Copies the arrays; call at most once per chromosome.
+ * Not calling it means "no --mappability" (conga_result.mappability = 0). */
+int conga_mappability(conga_ctx *ctx, const int32_t *start, const int32_t *end, const float *val, size_t m);
+
+/* load_known_SVs + qsort output for this chromosome: rows already filtered
+ * (end - start >= min_sv_size) and sorted by (start, end) (likelihood.c:324-328), type
+ * CONGA_DELETION or CONGA_DUPLICATION.  Copies the arrays; once per type per chromosome. */
+int conga_intervals(conga_ctx *ctx, char type, const int32_t *start, const int32_t *end, size_t n);
+
+/* count_ReadPairs result for this chromosome (likelihood.c:41-94): per-interval split-read support
+ * in the order of conga_intervals(); copied through to conga_result.rp (dups) / border_rp (dels). */
+int conga_split_support(conga_ctx *ctx, char type, const int32_t *support, size_t n);
+
+/* calc_mean_per_chr + find_depths: enqueue every kernel for this chromosome on the context's
+ * stream and return without waiting.  May be called again on the same resident inputs
+ * (it recomputes everything from the committed tuples). */
+int conga_chrom_compute(conga_ctx *ctx);
+
+/* Waits for the last conga_chrom_compute() and copies results out.  dels / dups receive one record
+ * per interval in the order given to conga_intervals() (NULL allowed when that type has no
+ * intervals); expected_rd receives bam_info.expected_read_depth; stats may be NULL. */
+int conga_chrom_fetch(conga_ctx *ctx, conga_result *dels, conga_result *dups, float expected_rd[101],
+		conga_chrom_stats *stats);
+
+/* conga_chrom_compute() followed by conga_chrom_fetch(). */
+int conga_chrom_finish(conga_ctx *ctx, conga_result *dels, conga_result *dups, float expected_rd[101],
+		conga_chrom_stats *stats);
+
+/* ---- device-side access (multi-GPU gather, profiling, tests) ------------------------------ */
+
+/* Device pointer to the result records of the last compute: n_dels records then n_dups records,
+ * valid until the next conga_chrom_begin().  Used to gather results over RCCL without a host hop. */
+int conga_results_device(conga_ctx *ctx, void **dev_ptr, size_t *n_dels, size_t *n_dups);
+/* hipStream_t of this context (as void*), e.g. to record HIP events around conga_chrom_compute(). */
+void *conga_stream(conga_ctx *ctx);
+/* Blocks until the context's stream is idle. */
+int conga_sync(conga_ctx *ctx);
+/* Test hooks: copy bam_info.read_depth (int16[chrom_len]) / bam_info.mappability (float[chrom_len])
+ * of the last compute back to the host. */
+int conga_copy_read_depth(conga_ctx *ctx, int16_t *out, int64_t n);
+int conga_copy_mappability(conga_ctx *ctx, float *out, int64_t n);
+
+/* Host-callable build of the device routine that advances the serial float32 accumulator of
+ * likelihood.c:119 by k equal addends in O(1) (used by CPU tests to check it against k real adds). */
+float conga_host_repeat_add_f32(float s, float c, uint32_t k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONGA_HIP_H_ */
