@@ -8,8 +8,9 @@
 // real add.  The result is bit-identical to k hardware adds (checked exhaustively-by-property in
 // tests/test_serial_f32.py against the literal loop).
 //
-// Preconditions: s >= 0, c >= 0, both finite (expected_read_depth is a non-negative table,
-// read_distribution.c:75-83).  Sub-normal s or c fall back to real adds.
+// Operands must be finite.  The fast path needs s and c of equal sign (expected_read_depth is a
+// non-negative table unless a depth counter wrapped, read_distribution.c:75-83); sub-normal or
+// mixed-sign operands fall back to real adds.
 #pragma once
 #include <stdint.h>
 
@@ -80,8 +81,8 @@ CONGA_HD conga_step conga_step_for(uint32_t es, uint32_t bits_c)
 	return st;
 }
 
-// s after `k` repetitions of s = fl32(s + c).
-CONGA_HD float conga_repeat_add_f32(float s, float c, uint32_t k)
+// s after `k` repetitions of s = fl32(s + c), for s >= 0 and c >= 0.
+CONGA_HD float conga_repeat_add_nonneg_f32(float s, float c, uint32_t k)
 {
 	const uint32_t bc = conga_f32_bits(c);
 	while (k) {
@@ -102,6 +103,26 @@ CONGA_HD float conga_repeat_add_f32(float s, float c, uint32_t k)
 		ms += n * st.delta; // <= 2^24
 		k -= n;
 		s = (ms == 0x1000000u) ? conga_bits_f32((es + 1u) << 23) : conga_bits_f32((es << 23) | (ms & 0x7FFFFFu));
+	}
+	return s;
+}
+
+// Any finite operands.  expected_read_depth can only go negative when a `short` depth counter has
+// wrapped (more than 32767 read starts on one base); round-to-nearest-even is symmetric, so equal
+// signs reuse the non-negative routine and mixed signs fall back to literal adds.
+CONGA_HD float conga_repeat_add_f32(float s, float c, uint32_t k)
+{
+	while (k) {
+		const uint32_t bs = conga_f32_bits(s), bc = conga_f32_bits(c);
+		const bool s_neg = (bs >> 31) != 0, c_neg = (bc >> 31) != 0;
+		if (!s_neg && !c_neg)
+			return conga_repeat_add_nonneg_f32(s, c, k);
+		if (s_neg && c_neg)
+			return -conga_repeat_add_nonneg_f32(-s, -c, k);
+		if ((bc << 1) == 0)
+			return s + c; // +-0 addend: one add settles the sign of a zero accumulator, later ones change nothing
+		s = s + c;    // opposite signs (or a signed zero accumulator): one literal add, then look again
+		--k;
 	}
 	return s;
 }
