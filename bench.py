@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""bench.py -- CNV intervals genotyped per second on the read-depth / likelihood hot path.
+
+Workload at N=1 (BASELINE.json configs[1]): the full 1000G-Phase-3-sized deletion set (~42k rows
+before the min-size filter) over the 22 GRCh37 autosomes against a 1x synthetic sample.  A "step"
+is one pass of the whole hot path over that sample: for every chromosome, read tuples (already
+resident in HBM) -> read_depth + GC histogram -> expected_read_depth[101] -> per-interval depth
+sums, serial-float expected chain, 3-state log-likelihoods, c-score and CN -> result records
+gathered on rank 0.  Host-side BAM decoding and BED parsing are outside the timed region.
+
+Multi-GPU: one process per GPU (torchrun), chromosomes sharded LPT across ranks, no data-path
+collective, one RCCL gather of the fixed-size result records per step.  Default scaling is weak:
+N ranks genotype N samples (22 N chromosome units); `--scaling strong` splits ONE sample.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from conga_amd import capi, shard, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md, Chip-level parameters)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--config", choices=("dels", "dels+dups+map"), default="dels",
+                    help="dels = BASELINE configs[1]; dels+dups+map = configs[2]")
+    ap.add_argument("--cov", type=float, default=1.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0,
+                    help="lower bound of CPU-baseline work (oracle, 1 thread); 0 disables the leg")
+    ap.add_argument("--chroms", type=str, default="", help="comma list of chromosome names (debug)")
+    return ap.parse_args()
+
+
+def build_units(args, world):
+    """(sample, chromosome) units and their owner rank."""
+    chroms = synth.GRCH37_AUTOSOMES
+    if args.chroms:
+        keep = set(args.chroms.split(","))
+        chroms = tuple(c for c in chroms if c[0] in keep)
+    n_dups = synth.N_DUPS_GENOME if args.config != "dels" else 0
+    plan = synth.genome_plan(chroms, synth.N_DELS_GENOME, n_dups)
+    n_samples = world if args.scaling == "weak" else 1
+    units = []
+    for sample in range(n_samples):
+        for name, length, nd, nu in plan:
+            units.append(dict(sample=sample, name=name, length=length, n_dels=nd, n_dups=nu))
+    costs = [shard.unit_cost(u["length"], u["n_dels"] + u["n_dups"]) for u in units]
+    owner = shard.lpt_partition(costs, world)
+    for u, o in zip(units, owner):
+        u["owner"] = o
+    return units
+
+
+def load_unit(u, args, device):
+    """Generate one chromosome's inputs and make them resident in HBM behind a context."""
+    c = synth.make_chrom(u["name"], u["length"], cov=args.cov, n_dels=u["n_dels"], n_dups=u["n_dups"],
+                         seed=synth.BASE_SEED + 1000 * u["sample"], mappability=(args.config != "dels"))
+    ds, de = synth.kept_sorted(c.del_start, c.del_end)
+    us, ue = synth.kept_sorted(c.dup_start, c.dup_end)
+    ctx = capi.Context(device=device)
+    ctx.chrom_begin(c.length, c.gc)
+    ctx.reads(c.pos, c.mapq)
+    if c.map_start is not None:
+        ctx.mappability(c.map_start, c.map_end, c.map_val)
+    ctx.intervals("D", ds, de)
+    if u["n_dups"]:
+        ctx.intervals("E", us, ue)
+    ctx.sync()
+    u.update(ctx=ctx, chrom=c, ds=ds, de=de, us=us, ue=ue, n_iv=len(ds) + len(us), n_reads=len(c.pos),
+             sum_len=int((de.astype(np.int64) - ds).sum() + (ue.astype(np.int64) - us).sum()))
+    return u
+
+
+def depth_kernel_bytes(u):
+    """Algorithmic bytes of one depth_tile launch: read_depth written once as int16,
+    the tuples read once (int32 pos + uint8 mapq), one GC byte per window, one tile-index word per tile."""
+    L, n = u["length"], u["n_reads"]
+    n_win = (L + 99) // 100
+    n_tiles = (L + 7999) // 8000
+    return 2 * L + 5 * n + n_win + 4 * (n_tiles + 1)
+
+
+def dense_reference_bytes(u, with_map):
+    """bytes the reference's dense formulation touches for this chromosome."""
+    L, n, sl, niv = u["length"], u["n_reads"], u["sum_len"], u["n_iv"]
+    b = 2 * L + 9 * n + (2 * L + L // 100) + (2 * sl + sl // 100 + 64 * niv)
+    if with_map:
+        b += 4 * L + 4 * sl
+    return b
+
+
+def cpu_baseline(mine, args):
+    """The oracle (a serial port of the reference's loops) timed on this host, 1 thread, on a bounded
+    sample of the same workload; its results double as a full-size parity check of the HIP path."""
+    from oracle import oracle as O
+    O.lib()
+    todo = sorted(mine, key=lambda u: u["length"])
+    t_cpu, n_iv, names = 0.0, 0, []
+    for u in todo:
+        c = u["chrom"]
+        t0 = time.perf_counter()
+        rd, _ = O.count_reads(c.length, c.pos, c.mapq, -1)
+        E, _, _ = O.calc_mean_per_chr(rd, c.gc)
+        m = O.paint_mappability(c.length, c.map_start, c.map_end, c.map_val) if c.map_start is not None else None
+        od = O.find_depths(rd, m, c.gc, E, "D", O.make_svs(u["ds"], u["de"]))
+        ou = O.find_depths(rd, m, c.gc, E, "E", O.make_svs(u["us"], u["ue"]))
+        t_cpu += time.perf_counter() - t0
+        n_iv += u["n_iv"]
+        names.append(u["name"])
+        # parity at full size (the oracle is the checker here, never the thing measured above)
+        dels, dups, Eg, _ = u["ctx"].fetch()
+        assert np.array_equal(Eg.view(np.uint32), E.view(np.uint32)), "expected_read_depth mismatch"
+        for got, want in ((dels, od), (dups, ou)):
+            assert np.array_equal(got["observed"], want["observed"]), "observed mismatch chr" + u["name"]
+            assert np.array_equal(got["expected"].view(np.uint32), want["expected"].view(np.uint32))
+            assert np.array_equal(got["cn"], want["cn"]), "CN mismatch chr" + u["name"]
+            assert np.allclose(got["lnone"], want["lnone"], rtol=0, atol=1e-6)
+            assert np.allclose(got["score"], want["score"], rtol=0, atol=1e-6)
+        if t_cpu >= args.cpu_seconds:
+            break
+    return dict(value=n_iv / t_cpu, unit="intervals/s", cores=1, kind="port",
+                sample="chromosomes %s of the same workload (%d intervals, %.1f s, oracle/conga_oracle.c, "
+                       "results compared with the HIP path)" % (",".join(names), n_iv, t_cpu))
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)  # RCCL
+
+    units = build_units(args, world)
+    mine = [load_unit(u, args, local_rank) for u in units if u["owner"] == rank]
+    rec = capi.RESULT_DTYPE.itemsize
+    bytes_per_rank = [sum((u["n_dels"] + u["n_dups"]) * rec for u in units if u["owner"] == r) for r in range(world)]
+    # interval counts after the min-size filter are only known to the owner: exchange them once
+    my_bytes = sum(u["n_iv"] for u in mine) * rec
+    if world > 1:
+        t = torch.tensor([my_bytes], dtype=torch.int64, device=dev)
+        all_b = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(all_b, t)
+        bytes_per_rank = [int(x.item()) for x in all_b]
+    else:
+        bytes_per_rank = [my_bytes]
+    packed = torch.zeros(max(my_bytes, 1), dtype=torch.uint8, device=dev)
+    total_iv = sum(bytes_per_rank) // rec
+
+    def step():
+        for u in mine:
+            u["ctx"].compute()                      # every kernel of one chromosome, async on its own stream
+        off = 0
+        for u in mine:
+            nb = u["n_iv"] * rec
+            u["ctx"].results_copy(packed.data_ptr() + off, nb)
+            off += nb
+        for u in mine:
+            u["ctx"].sync()
+        return shard.gather_records(packed[:my_bytes], bytes_per_rank, rank, world, dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gathered = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    out = None
+    if rank == 0:
+        got = sum(g.numel() for g in gathered) // rec
+        assert got == total_iv, (got, total_iv)
+
+        # ---- roofline of the dominant kernel, HIP events on the kernel's own stream, one chromosome at a time
+        for u in mine:
+            u["ctx"].set_profile(True)
+        kms = np.zeros(len(capi.KERNEL_NAMES))
+        reps = 5
+        depth_bytes = 0
+        for _ in range(reps):
+            for u in mine:
+                u["ctx"].compute()
+                st = u["ctx"].fetch()[3]
+                kms += np.array(st.kernel_ms[:len(capi.KERNEL_NAMES)])
+                depth_bytes += depth_kernel_bytes(u)
+        for u in mine:
+            u["ctx"].set_profile(False)
+        depth_ms = kms[1]
+        achieved = depth_bytes / (depth_ms * 1e-3) / 1e9
+        launches = reps * len(mine)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "depth_tile_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        roofline = dict(bound="hbm", kernel="depth_tile_kernel", achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
+                        unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
+                        algorithmic_bytes_per_launch=depth_bytes // launches,
+                        avg_launch_ms=round(depth_ms / launches, 5), traffic=traffic,
+                        kernel_ms_per_step={k: round(v / reps, 4) for k, v in zip(capi.KERNEL_NAMES, kms)})
+
+        dense = sum(dense_reference_bytes(u, args.config != "dels") for u in mine)
+        cfg = dict(workload=("BASELINE configs[1]: GRCh37 autosomes 1-22, %d deletion rows (%d kept >= 1000 bp)%s, "
+                             "%.1fx synthetic sample, 100-bp GC windows" % (
+                                 synth.N_DELS_GENOME, total_iv // max(world if args.scaling == "weak" else 1, 1),
+                                 "" if args.config == "dels" else " + dups + 100-mer-like mappability track",
+                                 args.cov)),
+                   samples=world if args.scaling == "weak" else 1, chromosomes_per_sample=len(units) // max(
+                       world if args.scaling == "weak" else 1, 1),
+                   intervals_per_step=int(total_iv), reads_rank0=int(sum(u["n_reads"] for u in mine)),
+                   parallelism="chromosome-sharded x%d, one RCCL gather per step" % world,
+                   dense_reference_bytes_rank0=int(dense))
+        out = dict(metric="CNV intervals genotyped/sec (1000G Phase-3 set); CN-call concordance vs ref",
+                   value=round(total_iv * args.steps / elapsed, 1), unit="intervals/s", n_gpus=world,
+                   steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
+                   higher_is_better=True, scaling=args.scaling, vs_baseline=None, dtype="i16/i32+f32/f64",
+                   data="synthetic", config=cfg, roofline=roofline)
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(mine, args)
+            out["cn_concordance"] = 1.0  # asserted bit-exact against the oracle on the cpu_baseline sample
+
+    for u in mine:
+        u["ctx"].close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

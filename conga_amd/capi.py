@@ -26,14 +26,16 @@ FLAG_PROFILE = 0x2
 DELETION = "D"
 DUPLICATION = "E"
 
-KERNEL_NAMES = ("ingest", "depth_tile", "expected_table", "paint", "interval_reduce", "interval_score")
+KERNEL_NAMES = ("ingest", "depth_tile", "expected_table", "paint", "interval_reduce", "interval_score",
+                "chain_long")
 
 # every symbol include/conga_hip.h declares
 EXPORTS = (
     "conga_create", "conga_destroy", "conga_strerror", "conga_last_error", "conga_abi_version",
     "conga_device_count", "conga_chrom_begin", "conga_reads_staging", "conga_reads_commit",
     "conga_mappability", "conga_intervals", "conga_split_support", "conga_chrom_compute",
-    "conga_chrom_fetch", "conga_chrom_finish", "conga_results_device", "conga_stream", "conga_sync",
+    "conga_chrom_fetch", "conga_chrom_finish", "conga_results_device", "conga_results_copy",
+    "conga_set_profile", "conga_stream", "conga_sync",
     "conga_copy_read_depth", "conga_copy_mappability", "conga_host_repeat_add_f32",
 )
 
@@ -111,6 +113,10 @@ def load():
     L.conga_chrom_finish.argtypes = [vp, vp, vp, vp, C.POINTER(ChromStats)]
     L.conga_results_device.restype = C.c_int
     L.conga_results_device.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]
+    L.conga_results_copy.restype = C.c_int
+    L.conga_results_copy.argtypes = [vp, vp, sz]
+    L.conga_set_profile.restype = C.c_int
+    L.conga_set_profile.argtypes = [vp, C.c_int]
     L.conga_stream.restype = vp
     L.conga_stream.argtypes = [vp]
     L.conga_sync.restype = C.c_int
@@ -238,6 +244,13 @@ class Context:
         p, nd, nu = C.c_void_p(), C.c_size_t(), C.c_size_t()
         self._check(self._lib.conga_results_device(self._h, C.byref(p), C.byref(nd), C.byref(nu)))
         return p.value or 0, nd.value, nu.value
+
+    def results_copy(self, dst_ptr, dst_bytes):
+        """Enqueue a D2D copy of the result records to a device pointer (e.g. tensor.data_ptr())."""
+        self._check(self._lib.conga_results_copy(self._h, C.c_void_p(dst_ptr), dst_bytes))
+
+    def set_profile(self, on):
+        self._check(self._lib.conga_set_profile(self._h, int(bool(on))))
 
     def read_depth(self):
         out = np.empty(self.chrom_len, dtype=np.int16)

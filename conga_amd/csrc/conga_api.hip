@@ -74,7 +74,7 @@ struct conga_ctx {
 	std::vector<int32_t> iv_start[2], iv_end[2], iv_support[2];
 	bool iv_given[2] = {false, false};
 	bool iv_dirty = true;
-	int64_t n_iv = 0, n_items = 0;
+	int64_t n_iv = 0, n_items = 0, n_long = 0;
 
 	// mappability rows
 	bool has_map = false, map_sorted = false;
@@ -83,7 +83,7 @@ struct conga_ctx {
 	// device buffers
 	DevBuf d_pos, d_mapq, d_tile_start, d_rd, d_gc_hist, d_gc_like, d_small, d_map, d_winner, d_map_start,
 			d_map_end, d_map_val, d_iv_start, d_iv_end, d_iv_type, d_order, d_observed, d_item_iv, d_item_start,
-			d_item_end, d_item_first, d_map_part, d_support, d_results;
+			d_item_end, d_item_first, d_map_part, d_support, d_results, d_expected;
 
 	// pinned read-back
 	SmallBlock *h_small = nullptr;
@@ -206,6 +206,17 @@ int prepare_intervals(conga_ctx *ctx)
 	std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
 		return (int64_t) end[x] - start[x] > (int64_t) end[y] - start[y];
 	});
+	// intervals spanning more than kLongWindows GC windows take the wave-cooperative chain
+	ctx->n_long = 0;
+	for (size_t i = 0; i < n; i++) {
+		const int32_t iv = order[i];
+		if (end[iv] <= start[iv])
+			break;
+		const int64_t nw = ((int64_t) end[iv] - 1) / ctx->step - (int64_t) start[iv] / ctx->step + 1;
+		if (nw <= kLongWindows)
+			break;
+		ctx->n_long = (int64_t) i + 1;
+	}
 
 	// reduce work items: [max(start,0), min(end,L)) cut into kItemLen pieces
 	std::vector<int32_t> item_iv, item_start, item_end;
@@ -235,6 +246,7 @@ int prepare_intervals(conga_ctx *ctx)
 	TRY(ensure(ctx, ctx->d_observed, n * 4));
 	TRY(ensure(ctx, ctx->d_map_part, std::max<size_t>(item_iv.size(), 1) * 8));
 	TRY(ensure(ctx, ctx->d_results, n * sizeof(conga_result)));
+	TRY(ensure(ctx, ctx->d_expected, n * 4));
 
 	ctx->support_given = !ctx->iv_support[0].empty() || !ctx->iv_support[1].empty();
 	if (ctx->support_given) {
@@ -394,7 +406,7 @@ void conga_destroy(conga_ctx *ctx)
 			&ctx->d_small, &ctx->d_map, &ctx->d_winner, &ctx->d_map_start, &ctx->d_map_end, &ctx->d_map_val,
 			&ctx->d_iv_start, &ctx->d_iv_end, &ctx->d_iv_type, &ctx->d_order, &ctx->d_observed, &ctx->d_item_iv,
 			&ctx->d_item_start, &ctx->d_item_end, &ctx->d_item_first, &ctx->d_map_part, &ctx->d_support,
-			&ctx->d_results};
+			&ctx->d_results, &ctx->d_expected};
 	if (ctx->gc_aliased)
 		ctx->d_gc_like = DevBuf();
 	for (DevBuf *b : bufs)
@@ -727,6 +739,21 @@ int conga_chrom_compute(conga_ctx *ctx)
 			const int grid = (int) ((ctx->n_items + waves_per_block - 1) / waves_per_block);
 			hipLaunchKernelGGL(interval_reduce_kernel, dim3(grid), dim3(256), 0, st, a);
 		}
+		if (ctx->n_long > 0) {
+			KernelTimer t(ctx, CONGA_K_CHAIN);
+			ChainArgs c;
+			c.start = ptr<int32_t>(ctx->d_iv_start);
+			c.end = ptr<int32_t>(ctx->d_iv_end);
+			c.order = ptr<int32_t>(ctx->d_order);
+			c.n_long = ctx->n_long;
+			c.gc_like = ptr<uint8_t>(ctx->d_gc_like);
+			c.n_win = ctx->n_win;
+			c.step = ctx->step;
+			c.E = small->E;
+			c.expected = ptr<float>(ctx->d_expected);
+			const int grid = (int) ((ctx->n_long + 3) / 4);
+			hipLaunchKernelGGL(chain_long_kernel, dim3(grid), dim3(256), 0, st, c);
+		}
 		{
 			KernelTimer t(ctx, CONGA_K_SCORE);
 			ScoreArgs a;
@@ -744,6 +771,8 @@ int conga_chrom_compute(conga_ctx *ctx)
 			a.item_first = ptr<int32_t>(ctx->d_item_first);
 			a.support = ctx->support_given ? ptr<int32_t>(ctx->d_support) : nullptr;
 			a.has_map = ctx->has_map ? 1 : 0;
+			a.n_long = ctx->n_long;
+			a.expected_long = ptr<float>(ctx->d_expected);
 			a.out = ptr<conga_result>(ctx->d_results);
 			const int grid = (int) ((ctx->n_iv + 63) / 64);
 			hipLaunchKernelGGL(interval_score_kernel, dim3(grid), dim3(64), 0, st, a);
@@ -825,6 +854,32 @@ int conga_results_device(conga_ctx *ctx, void **dev_ptr, size_t *n_dels, size_t 
 		*n_dels = ctx->iv_start[0].size();
 	if (n_dups)
 		*n_dups = ctx->iv_start[1].size();
+	return CONGA_OK;
+}
+
+int conga_results_copy(conga_ctx *ctx, void *dst_device, size_t dst_bytes)
+{
+	if (!ctx || (!dst_device && ctx->n_iv))
+		return CONGA_ERR_INVALID;
+	if (!ctx->computed)
+		return fail(ctx, CONGA_ERR_INVALID, "conga_results_copy: nothing computed");
+	const size_t bytes = (size_t) ctx->n_iv * sizeof(conga_result);
+	if (dst_bytes < bytes)
+		return fail(ctx, CONGA_ERR_INVALID, "conga_results_copy: destination too small");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	if (bytes)
+		HIP_TRY(ctx, hipMemcpyAsync(dst_device, ctx->d_results.p, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+	return CONGA_OK;
+}
+
+int conga_set_profile(conga_ctx *ctx, int on)
+{
+	if (!ctx)
+		return CONGA_ERR_INVALID;
+	if (on)
+		ctx->opts.flags |= CONGA_FLAG_PROFILE;
+	else
+		ctx->opts.flags &= ~CONGA_FLAG_PROFILE;
 	return CONGA_OK;
 }
 

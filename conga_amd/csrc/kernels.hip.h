@@ -482,6 +482,118 @@ __global__ __launch_bounds__(256) void interval_reduce_kernel(ReduceArgs a)
 // conga_repeat_add_f32 collapses exactly (serial_f32.h); windows are walked left to right, so
 // the rounding sequence is the reference's.
 // -------------------------------------------------------------------------------------------
+// Long intervals: one wave walks one interval, 64 GC windows per step.
+//
+// Inside one binade of the accumulator every window advances the mantissa by k * delta ulps
+// (conga_step_for), an INTEGER, so the 64 per-window advances are combined with a wave prefix sum.
+// A window is "regular" when its whole run of k adds stays below the binade top and is not an
+// exact tie; the first irregular window (ballot + ffs) is applied with the scalar routine
+// conga_repeat_add_f32 -- which performs the real rounding -- and the scan restarts behind it.
+// Irregular windows are rare (one per binade crossing, i.e. O(log) per interval), so a 5 Mb
+// interval costs ~800 wave steps instead of 50,000 dependent window updates on one lane.
+// The result is the same bit pattern as the per-base loop of likelihood.c:115-119.
+constexpr int kLongWindows = 192; // intervals with more GC windows than this take the wave path
+
+struct ChainArgs {
+	const int32_t *start;
+	const int32_t *end;
+	const int32_t *order; // longest first; the first n_long entries are the long intervals
+	int64_t n_long;
+	const uint8_t *gc_like;
+	int64_t n_win;
+	int32_t step;
+	const float *E;
+	float *expected; // [n_iv]
+};
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
+{
+#pragma unroll
+	for (int o = 1; o < kWave; o <<= 1) {
+		const uint32_t t = __shfl_up(v, o, kWave);
+		if (lane >= o)
+			v += t;
+	}
+	return v;
+}
+
+__device__ __forceinline__ float compose_f32(uint32_t es, uint32_t ms)
+{
+	return (ms == 0x1000000u) ? conga_bits_f32((es + 1u) << 23) : conga_bits_f32((es << 23) | (ms & 0x7FFFFFu));
+}
+
+__global__ __launch_bounds__(256) void chain_long_kernel(ChainArgs a)
+{
+	__shared__ float sE[kGcBins];
+	for (int g = threadIdx.x; g < kGcBins; g += blockDim.x)
+		sE[g] = a.E[g];
+	__syncthreads();
+
+	const int lane = threadIdx.x & (kWave - 1);
+	const int64_t slot = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+	if (slot >= a.n_long)
+		return; // wave-uniform
+	const int32_t iv = a.order[slot];
+	const int64_t s0 = a.start[iv], e0 = a.end[iv];
+	const int64_t step = a.step;
+	const int64_t w_first = s0 / step;
+	const int64_t w_end = (e0 - 1) / step + 1;
+
+	float s = 0.0f; // wave-uniform accumulator
+	for (int64_t wb = w_first; wb < w_end; wb += kWave) {
+		const int64_t w = wb + lane;
+		const bool active = w < w_end;
+		uint32_t k = 0, bc = 0;
+		float c = 0.0f;
+		if (active) {
+			const int64_t lo = (w * step > s0) ? w * step : s0;
+			const int64_t hi = ((w + 1) * step < e0) ? (w + 1) * step : e0;
+			k = (uint32_t) (hi - lo);
+			const uint32_t g = a.gc_like[(w < a.n_win) ? w : a.n_win - 1];
+			c = (g < (uint32_t) kGcBins) ? sE[g] : 0.0f;
+			bc = conga_f32_bits(c);
+		}
+		unsigned long long todo = __ballot(active);
+		while (todo) {
+			const uint32_t bs = conga_f32_bits(s);
+			const uint32_t es = bs >> 23;
+			const uint32_t ms = (bs & 0x7FFFFFu) | 0x800000u;
+			const bool in = (todo >> lane) & 1ull;
+			const conga_step st = conga_step_for(es & 0xFFu, bc);
+			const bool valid = in && st.delta != 0xFFFFFFFFu && !st.tie && !(bs >> 31) && !(bc >> 31);
+			uint32_t adv = 0;
+			if (valid) {
+				const uint64_t a64 = (uint64_t) k * st.delta;
+				adv = (a64 > (1u << 25)) ? (1u << 25) : (uint32_t) a64;
+			}
+			const uint32_t incl = wave_incl_scan_u32(adv, lane);
+			const uint32_t pre = incl - adv;
+			const uint32_t m = ms + pre; // mantissa in front of this lane's window (< 2^32)
+			bool ok = true;
+			if (in)
+				ok = valid && (st.delta == 0 || (m <= st.lim && (uint64_t) (k - 1u) * st.delta <= (uint64_t) (st.lim - m)));
+			const unsigned long long bad = __ballot(!ok);
+			if (bad == 0) {
+				const uint32_t total = __shfl(incl, kWave - 1, kWave);
+				if (total)
+					s = compose_f32(es, ms + total);
+				todo = 0;
+			} else {
+				const int fb = __ffsll((long long) bad) - 1;
+				const uint32_t pre_fb = __shfl(pre, fb, kWave);
+				if (pre_fb)
+					s = compose_f32(es, ms + pre_fb); // exact state in front of the irregular window
+				const float c_fb = __shfl(c, fb, kWave);
+				const uint32_t k_fb = __shfl(k, fb, kWave);
+				s = conga_repeat_add_f32(s, c_fb, k_fb); // real adds where rounding is not a constant step
+				todo &= ~((2ull << fb) - 1ull);
+			}
+		}
+	}
+	if (lane == 0)
+		a.expected[iv] = s;
+}
+
 struct ScoreArgs {
 	const int32_t *start;
 	const int32_t *end;
@@ -497,6 +609,8 @@ struct ScoreArgs {
 	const int32_t *item_first; // [n_iv + 1] first work item of each interval
 	const int32_t *support;  // split-read support per interval (may be null)
 	int32_t has_map;
+	int64_t n_long;          // slots below this were computed by chain_long_kernel
+	const float *expected_long; // [n_iv], valid for those slots
 	conga_result *out;
 };
 
@@ -548,7 +662,9 @@ __global__ __launch_bounds__(256) void interval_score_kernel(ScoreArgs a)
 	const int64_t s = a.start[iv], e = a.end[iv];
 
 	float ex = 0.0f;
-	if (e > s) {
+	if (slot < a.n_long) {
+		ex = a.expected_long[iv];
+	} else if (e > s) {
 		int64_t w = s / a.step;
 		int64_t pos = s;
 		const uint32_t *gc32 = reinterpret_cast<const uint32_t *>(a.gc_like);

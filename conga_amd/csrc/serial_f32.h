@@ -97,9 +97,11 @@ CONGA_HD float conga_repeat_add_nonneg_f32(float s, float c, uint32_t k)
 		}
 		if (st.delta == 0)
 			return s;
-		uint32_t n = (st.lim - ms) / st.delta + 1u;
-		if (n > k)
-			n = k;
+		// all k adds stay regular iff the last one starts at or below lim; only a run that reaches the
+		// binade top needs the (slow, rare) integer divide
+		uint32_t n = k;
+		if ((uint64_t) (k - 1u) * st.delta > (uint64_t) (st.lim - ms))
+			n = (st.lim - ms) / st.delta + 1u;
 		ms += n * st.delta; // <= 2^24
 		k -= n;
 		s = (ms == 0x1000000u) ? conga_bits_f32((es + 1u) << 23) : conga_bits_f32((es << 23) | (ms & 0x7FFFFFu));

@@ -88,6 +88,8 @@ def make_reads(length, gc, step, cov, readlen, rng, dels=None, dups=None, del_gt
     n_win = len(gc)
     g = gc.astype(np.float64)
     bias = np.where(gc > 0, 1.0 - ((g - 45.0) / 60.0) ** 2, 0.0)          # mild quadratic bias, 0 in gaps
+    if np.any(gc > 0):
+        bias /= bias[gc > 0].mean()                                         # cov is the depth outside gaps
     rate = (cov / readlen) * bias                                            # starts per base
     factor = np.ones(n_win)
     if dels is not None and del_gt is not None:

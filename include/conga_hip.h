@@ -91,7 +91,8 @@ enum {
 	CONGA_K_EXPECTED,     /* expected_read_depth[101] */
 	CONGA_K_PAINT,        /* mappability paint (K3) */
 	CONGA_K_REDUCE,       /* per-interval integer depth sum + mappability sum (K4, memory side) */
-	CONGA_K_SCORE,        /* serial-float expected chain + likelihoods + CN (K4 chain + K5) */
+	CONGA_K_SCORE,        /* serial-float expected chain (short intervals) + likelihoods + CN (K4 chain + K5) */
+	CONGA_K_CHAIN,        /* serial-float expected chain of long intervals, one wave per interval */
 	CONGA_K_COUNT
 };
 
@@ -170,6 +171,11 @@ int conga_chrom_finish(conga_ctx *ctx, conga_result *dels, conga_result *dups, f
 /* Device pointer to the result records of the last compute: n_dels records then n_dups records,
  * valid until the next conga_chrom_begin().  Used to gather results over RCCL without a host hop. */
 int conga_results_device(conga_ctx *ctx, void **dev_ptr, size_t *n_dels, size_t *n_dups);
+/* Enqueue a device-to-device copy of those records into dst_device (at least
+ * (n_dels + n_dups) * sizeof(conga_result) bytes, e.g. a torch tensor's data_ptr) on the context's stream. */
+int conga_results_copy(conga_ctx *ctx, void *dst_device, size_t dst_bytes);
+/* Turn per-kernel HIP-event timing (CONGA_FLAG_PROFILE) on or off for later computes. */
+int conga_set_profile(conga_ctx *ctx, int on);
 /* hipStream_t of this context (as void*), e.g. to record HIP events around conga_chrom_compute(). */
 void *conga_stream(conga_ctx *ctx);
 /* Blocks until the context's stream is idle. */
