@@ -65,33 +65,35 @@ def build_units(args, world):
     return units
 
 
-def load_unit(u, args, device):
-    """Generate one chromosome's inputs and make them resident in HBM behind a context."""
+def load_unit(u, args, ctx):
+    """Generate one chromosome's inputs and make them resident in HBM behind the rank's batch context."""
     c = synth.make_chrom(u["name"], u["length"], cov=args.cov, n_dels=u["n_dels"], n_dups=u["n_dups"],
                          seed=synth.BASE_SEED + 1000 * u["sample"], mappability=(args.config != "dels"))
     ds, de = synth.kept_sorted(c.del_start, c.del_end)
     us, ue = synth.kept_sorted(c.dup_start, c.dup_end)
-    ctx = capi.Context(device=device)
-    ctx.chrom_begin(c.length, c.gc)
+    u["index"] = ctx.chrom_begin(c.length, c.gc)
     ctx.reads(c.pos, c.mapq)
     if c.map_start is not None:
         ctx.mappability(c.map_start, c.map_end, c.map_val)
     ctx.intervals("D", ds, de)
     if u["n_dups"]:
         ctx.intervals("E", us, ue)
-    ctx.sync()
-    u.update(ctx=ctx, chrom=c, ds=ds, de=de, us=us, ue=ue, n_iv=len(ds) + len(us), n_reads=len(c.pos),
+    u.update(chrom=c, ds=ds, de=de, us=us, ue=ue, n_iv=len(ds) + len(us), n_reads=len(c.pos),
              sum_len=int((de.astype(np.int64) - ds).sum() + (ue.astype(np.int64) - us).sum()))
     return u
 
 
-def depth_kernel_bytes(u):
-    """Algorithmic bytes of one depth_tile launch: read_depth written once as int16,
-    the tuples read once (int32 pos + uint8 mapq), one GC byte per window, one tile-index word per tile."""
-    L, n = u["length"], u["n_reads"]
-    n_win = (L + 99) // 100
-    n_tiles = (L + 7999) // 8000
-    return 2 * L + 5 * n + n_win + 4 * (n_tiles + 1)
+def depth_kernel_bytes(units):
+    """Algorithmic bytes of the depth_tile launch over these chromosomes: read_depth
+    written once as int16, the tuples read once (int32 pos + uint8 mapq), one GC byte per window, one
+    tile-index word per tile."""
+    total = 0
+    for u in units:
+        L, n = u["length"], u["n_reads"]
+        n_win = (L + 99) // 100
+        n_tiles = (L + 7999) // 8000
+        total += 2 * L + 5 * n + n_win + 4 * (n_tiles + 1)
+    return total
 
 
 def dense_reference_bytes(u, with_map):
@@ -103,7 +105,7 @@ def dense_reference_bytes(u, with_map):
     return b
 
 
-def cpu_baseline(mine, args):
+def cpu_baseline(mine, ctx, args):
     """The oracle (a serial port of the reference's loops) timed on this host, 1 thread, on a bounded
     sample of the same workload; its results double as a full-size parity check of the HIP path."""
     from oracle import oracle as O
@@ -122,7 +124,8 @@ def cpu_baseline(mine, args):
         n_iv += u["n_iv"]
         names.append(u["name"])
         # parity at full size (the oracle is the checker here, never the thing measured above)
-        dels, dups, Eg, _ = u["ctx"].fetch()
+        ctx.select(u["index"])
+        dels, dups, Eg, _ = ctx.fetch()
         assert np.array_equal(Eg.view(np.uint32), E.view(np.uint32)), "expected_read_depth mismatch"
         for got, want in ((dels, od), (dups, ou)):
             assert np.array_equal(got["observed"], want["observed"]), "observed mismatch chr" + u["name"]
@@ -157,7 +160,9 @@ def main():
         dist.init_process_group("nccl", device_id=dev)  # RCCL
 
     units = build_units(args, world)
-    mine = [load_unit(u, args, local_rank) for u in units if u["owner"] == rank]
+    ctx = capi.Context(device=local_rank, flags=capi.FLAG_BATCH)  # every chromosome of this rank, one launch per kernel
+    mine = [load_unit(u, args, ctx) for u in units if u["owner"] == rank]
+    ctx.sync()
     rec = capi.RESULT_DTYPE.itemsize
     bytes_per_rank = [sum((u["n_dels"] + u["n_dups"]) * rec for u in units if u["owner"] == r) for r in range(world)]
     # interval counts after the min-size filter are only known to the owner: exchange them once
@@ -173,15 +178,12 @@ def main():
     total_iv = sum(bytes_per_rank) // rec
 
     def step():
-        for u in mine:
-            u["ctx"].compute()                      # every kernel of one chromosome, async on its own stream
-        off = 0
-        for u in mine:
-            nb = u["n_iv"] * rec
-            u["ctx"].results_copy(packed.data_ptr() + off, nb)
-            off += nb
-        for u in mine:
-            u["ctx"].sync()
+        ctx.compute()                               # whole hot path for this rank's chromosomes, async
+        if world > 1:
+            ctx.results_copy(packed.data_ptr(), my_bytes)   # records stay on the device for the RCCL gather
+        ctx.sync()                                  # N=1: the records are in pinned host memory now
+        if world == 1:
+            return [packed[:0]]
         return shard.gather_records(packed[:my_bytes], bytes_per_rank, rank, world, dev)
 
     def barrier():
@@ -205,26 +207,25 @@ def main():
 
     out = None
     if rank == 0:
-        got = sum(g.numel() for g in gathered) // rec
-        assert got == total_iv, (got, total_iv)
+        if world > 1:
+            got = sum(g.numel() for g in gathered) // rec
+            assert got == total_iv, (got, total_iv)
 
-        # ---- roofline of the dominant kernel, HIP events on the kernel's own stream, one chromosome at a time
-        for u in mine:
-            u["ctx"].set_profile(True)
+        # ---- roofline of the dominant kernel: HIP events recorded on the context's own stream around
+        # every kernel (CONGA_FLAG_PROFILE), same resident inputs, one launch per kernel per compute
+        ctx.set_profile(True)
         kms = np.zeros(len(capi.KERNEL_NAMES))
-        reps = 5
-        depth_bytes = 0
+        reps = 10
         for _ in range(reps):
-            for u in mine:
-                u["ctx"].compute()
-                st = u["ctx"].fetch()[3]
-                kms += np.array(st.kernel_ms[:len(capi.KERNEL_NAMES)])
-                depth_bytes += depth_kernel_bytes(u)
-        for u in mine:
-            u["ctx"].set_profile(False)
+            ctx.compute()
+            ctx.select(0)
+            st = ctx.fetch()[3]
+            kms += np.array(st.kernel_ms[:len(capi.KERNEL_NAMES)])
+        ctx.set_profile(False)
+        depth_bytes = depth_kernel_bytes(mine) * reps
         depth_ms = kms[1]
         achieved = depth_bytes / (depth_ms * 1e-3) / 1e9
-        launches = reps * len(mine)
+        launches = reps
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "depth_tile_traffic.json")
         if os.path.exists(tpath):
@@ -252,11 +253,10 @@ def main():
                    higher_is_better=True, scaling=args.scaling, vs_baseline=None, dtype="i16/i32+f32/f64",
                    data="synthetic", config=cfg, roofline=roofline)
         if world == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(mine, args)
+            out["cpu_baseline"] = cpu_baseline(mine, ctx, args)
             out["cn_concordance"] = 1.0  # asserted bit-exact against the oracle on the cpu_baseline sample
 
-    for u in mine:
-        u["ctx"].close()
+    ctx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -22,6 +22,7 @@ CONGA_ERR_RANGE = -6
 
 FLAG_READS_UNSORTED = 0x1
 FLAG_PROFILE = 0x2
+FLAG_BATCH = 0x4
 
 DELETION = "D"
 DUPLICATION = "E"
@@ -32,7 +33,7 @@ KERNEL_NAMES = ("ingest", "depth_tile", "expected_table", "paint", "interval_red
 # every symbol include/conga_hip.h declares
 EXPORTS = (
     "conga_create", "conga_destroy", "conga_strerror", "conga_last_error", "conga_abi_version",
-    "conga_device_count", "conga_chrom_begin", "conga_reads_staging", "conga_reads_commit",
+    "conga_device_count", "conga_reset", "conga_chrom_count", "conga_chrom_select", "conga_chrom_begin", "conga_reads_staging", "conga_reads_commit",
     "conga_mappability", "conga_intervals", "conga_split_support", "conga_chrom_compute",
     "conga_chrom_fetch", "conga_chrom_finish", "conga_results_device", "conga_results_copy",
     "conga_set_profile", "conga_stream", "conga_sync",
@@ -93,6 +94,12 @@ def load():
     L.conga_last_error.argtypes = [vp]
     L.conga_abi_version.restype = C.c_int
     L.conga_device_count.restype = C.c_int
+    L.conga_reset.restype = C.c_int
+    L.conga_reset.argtypes = [vp]
+    L.conga_chrom_count.restype = C.c_int
+    L.conga_chrom_count.argtypes = [vp]
+    L.conga_chrom_select.restype = C.c_int
+    L.conga_chrom_select.argtypes = [vp, C.c_int]
     L.conga_chrom_begin.restype = C.c_int
     L.conga_chrom_begin.argtypes = [vp, i64, vp, vp, i64]
     L.conga_reads_staging.restype = C.c_int
@@ -112,7 +119,7 @@ def load():
     L.conga_chrom_finish.restype = C.c_int
     L.conga_chrom_finish.argtypes = [vp, vp, vp, vp, C.POINTER(ChromStats)]
     L.conga_results_device.restype = C.c_int
-    L.conga_results_device.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]
+    L.conga_results_device.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
     L.conga_results_copy.restype = C.c_int
     L.conga_results_copy.argtypes = [vp, vp, sz]
     L.conga_set_profile.restype = C.c_int
@@ -146,8 +153,9 @@ class Context:
         if not self._h:
             raise CongaError(st.value, self._lib.conga_strerror(st.value).decode())
         self.gc_step = gc_step
-        self.n_dels = self.n_dups = 0
-        self.chrom_len = 0
+        self.batch = bool(flags & FLAG_BATCH)
+        self._meta = []   # per chromosome: [length, n_dels, n_dups]
+        self._cur = -1
 
     def close(self):
         if getattr(self, "_h", None):
@@ -175,8 +183,38 @@ class Context:
         if len(gl) != len(gh):
             raise ValueError("gc_hist_w and gc_like_w differ in length")
         self._check(self._lib.conga_chrom_begin(self._h, chrom_len, _p(gh), _p(gl), len(gh)))
-        self.n_dels = self.n_dups = 0
-        self.chrom_len = chrom_len
+        if not self.batch:
+            self._meta = []
+        self._meta.append([chrom_len, 0, 0])
+        self._cur = len(self._meta) - 1
+        return self._cur
+
+    def reset(self):
+        self._check(self._lib.conga_reset(self._h))
+        self._meta, self._cur = [], -1
+
+    def select(self, index):
+        self._check(self._lib.conga_chrom_select(self._h, index))
+        self._cur = index
+
+    def chrom_count(self):
+        return self._lib.conga_chrom_count(self._h)
+
+    @property
+    def chrom_len(self):
+        return self._meta[self._cur][0]
+
+    @property
+    def n_dels(self):
+        return self._meta[self._cur][1]
+
+    @property
+    def n_dups(self):
+        return self._meta[self._cur][2]
+
+    @property
+    def n_records(self):
+        return sum(m[1] + m[2] for m in self._meta)
 
     def reads(self, pos, mapq):
         """Streams (pos, mapq) through the pinned staging ring, like the BAM loop would."""
@@ -207,10 +245,7 @@ class Context:
         s = np.ascontiguousarray(start, dtype=np.int32)
         e = np.ascontiguousarray(end, dtype=np.int32)
         self._check(self._lib.conga_intervals(self._h, sv_type.encode()[:1], _p(s), _p(e), len(s)))
-        if sv_type == DELETION:
-            self.n_dels = len(s)
-        else:
-            self.n_dups = len(s)
+        self._meta[self._cur][1 if sv_type == DELETION else 2] = len(s)
 
     def split_support(self, sv_type, support):
         s = np.ascontiguousarray(support, dtype=np.int32)
@@ -240,10 +275,18 @@ class Context:
         return self._lib.conga_stream(self._h)
 
     def results_device(self):
-        """-> (device pointer (int), n_dels, n_dups)"""
-        p, nd, nu = C.c_void_p(), C.c_size_t(), C.c_size_t()
-        self._check(self._lib.conga_results_device(self._h, C.byref(p), C.byref(nd), C.byref(nu)))
-        return p.value or 0, nd.value, nu.value
+        """-> (device pointer (int), n_records)"""
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self._lib.conga_results_device(self._h, C.byref(p), C.byref(n)))
+        return p.value or 0, n.value
+
+    def fetch_all(self):
+        """Batch mode: [(dels, dups, E, stats)] for every chromosome, in begin order."""
+        out = []
+        for i in range(len(self._meta)):
+            self.select(i)
+            out.append(self.fetch())
+        return out
 
     def results_copy(self, dst_ptr, dst_bytes):
         """Enqueue a D2D copy of the result records to a device pointer (e.g. tensor.data_ptr())."""

@@ -1,8 +1,11 @@
 // conga_api.hip -- C-ABI of include/conga_hip.h over the gfx950 kernels in kernels.hip.h.
 //
-// One context = one GPU, one HIP stream, one chromosome in flight.  Everything the kernels need
-// stays resident in HBM between conga_chrom_begin() and the next one, so conga_chrom_compute()
-// can be replayed on the same inputs (bench.py times exactly that).
+// One context = one GPU and one HIP stream.  A context holds one chromosome (the reference's
+// sequential per-chromosome loop, bam_data.c:269-339) or, with CONGA_FLAG_BATCH, any number of
+// them ("slots"): every kernel then covers the whole batch in ONE launch, which is what keeps an
+// MI355X busy -- a single chromosome's interval kernels are far too small to fill 256 CUs.
+// Everything the kernels need stays resident in HBM, so conga_chrom_compute() can be replayed on
+// the same inputs (bench.py times exactly that).
 //
 // There is deliberately no CPU fallback anywhere in this file: without a HIP device
 // conga_create() returns NULL / CONGA_ERR_NO_DEVICE.
@@ -12,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -31,17 +35,6 @@ struct DevBuf {
 constexpr size_t kStagingTuples = (size_t) 1 << 22; // per pinned buffer
 constexpr int kStagingRing = 2;
 
-// small device block read back after every compute
-struct SmallBlock {
-	uint32_t status;
-	uint32_t pad;
-	unsigned long long counters[CNT_N];
-	unsigned long long hist_sum[kGcBins];
-	unsigned long long hist_bases[kGcBins];
-	float E[kGcBins];
-	float pad2;
-};
-
 struct Staging {
 	int32_t *pos = nullptr;
 	uint8_t *mapq = nullptr;
@@ -49,49 +42,57 @@ struct Staging {
 	bool in_flight = false;
 };
 
+// Host side of one chromosome.
+struct HostSlot {
+	int64_t L = 0, n_win = 0, n_tiles = 0;
+	int64_t read_off = 0, n_reads = 0;
+	std::vector<uint8_t> gc_hist, gc_like; // gc_like empty = same as gc_hist
+	std::vector<int32_t> iv_start[2], iv_end[2], iv_support[2]; // [0] = dels, [1] = dups
+	bool has_map = false, map_sorted = false;
+	std::vector<int32_t> map_start, map_end;
+	std::vector<float> map_val;
+	// filled by prepare()
+	int64_t rd_off = 0, gc_off = 0, tile0 = 0, tidx_off = 0, iv0 = 0, map_row_off = 0;
+};
+
 } // namespace
 
 struct conga_ctx {
 	int device = 0;
 	int n_cu = 256;
+	int depth_blocks_per_cu = 8; // resident depth_tile workgroups per CU (occupancy query)
 	hipStream_t stream = nullptr;
 	conga_opts opts{};
 	std::string err;
 
-	// chromosome geometry
-	bool chrom_open = false;
-	int64_t L = 0, n_win = 0, n_tiles = 0;
 	int32_t step = 100, tile_win = 0;
-	bool gc_aliased = false;
+	std::vector<HostSlot> slots;
+	int cur = -1; // selected slot
+	bool layout_dirty = true;
 
 	// reads
-	int64_t n_reads = 0;
+	int64_t n_reads_total = 0;
 	Staging staging[kStagingRing];
-	int staging_next = 0;  // buffer the next conga_reads_staging() hands out
-	int staging_cur = -1;  // buffer handed out and not yet committed
+	int staging_next = 0; // buffer the next conga_reads_staging() hands out
+	int staging_cur = -1; // buffer handed out and not yet committed
 
-	// intervals (host copies; [0] = dels, [1] = dups)
-	std::vector<int32_t> iv_start[2], iv_end[2], iv_support[2];
-	bool iv_given[2] = {false, false};
-	bool iv_dirty = true;
-	int64_t n_iv = 0, n_items = 0, n_long = 0;
-
-	// mappability rows
-	bool has_map = false, map_sorted = false;
-	int64_t n_map_rows = 0;
+	// layout totals (prepare)
+	int64_t total_L = 0, total_tiles = 0, total_gc = 0, n_iv = 0, n_items = 0, n_long = 0;
+	bool gc_like_distinct = false, any_map = false, support_given = false;
 
 	// device buffers
-	DevBuf d_pos, d_mapq, d_tile_start, d_rd, d_gc_hist, d_gc_like, d_small, d_map, d_winner, d_map_start,
-			d_map_end, d_map_val, d_iv_start, d_iv_end, d_iv_type, d_order, d_observed, d_item_iv, d_item_start,
-			d_item_end, d_item_first, d_map_part, d_support, d_results, d_expected;
+	DevBuf d_pos, d_mapq, d_tile_start, d_rd, d_gc_hist, d_gc_like, d_slots, d_small, d_map, d_winner,
+			d_map_start, d_map_end, d_map_val, d_iv_start, d_iv_end, d_iv_type, d_iv_slot, d_iv_has_map, d_order,
+			d_observed, d_expected, d_item_off, d_item_len, d_item_iv, d_item_has_map, d_item_first, d_map_part,
+			d_support, d_results;
 
 	// pinned read-back
-	SmallBlock *h_small = nullptr;
+	Small *h_small = nullptr;
+	size_t h_small_cap = 0;
 	conga_result *h_results = nullptr;
 	size_t h_results_cap = 0;
 
 	bool computed = false;
-	bool support_given = false;
 	hipEvent_t ev_done = nullptr;
 	hipEvent_t ev_k0[CONGA_K_COUNT] = {}, ev_k1[CONGA_K_COUNT] = {};
 	bool ev_used[CONGA_K_COUNT] = {};
@@ -114,6 +115,14 @@ int fail(conga_ctx *ctx, int status, const std::string &msg)
 					std::string(#call) + ": " + hipGetErrorString(e_));                                \
 	} while (0)
 
+#define TRY(expr)                \
+	do {                         \
+		int rc_ = (expr);        \
+		if (rc_ != CONGA_OK)     \
+			return rc_;          \
+	} while (0)
+
+// Grow a device buffer.  keep = preserve the old contents (device-to-device copy on the stream).
 int ensure(conga_ctx *ctx, DevBuf &b, size_t bytes, bool keep = false)
 {
 	if (bytes <= b.cap)
@@ -122,16 +131,14 @@ int ensure(conga_ctx *ctx, DevBuf &b, size_t bytes, bool keep = false)
 	want = (want + 255) & ~(size_t) 255;
 	void *np = nullptr;
 	HIP_TRY(ctx, hipMalloc(&np, want));
-	if (keep && b.p && b.cap) {
-		hipError_t e = hipMemcpyAsync(np, b.p, b.cap, hipMemcpyDeviceToDevice, ctx->stream);
-		if (e == hipSuccess)
-			e = hipStreamSynchronize(ctx->stream);
-		if (e != hipSuccess) {
-			(void) hipFree(np);
-			return fail(ctx, CONGA_ERR_HIP, std::string("grow copy: ") + hipGetErrorString(e));
-		}
-	} else if (b.p) {
-		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // nothing in flight may still use the old block
+	hipError_t e = hipSuccess;
+	if (keep && b.p && b.cap)
+		e = hipMemcpyAsync(np, b.p, b.cap, hipMemcpyDeviceToDevice, ctx->stream);
+	if (e == hipSuccess && b.p)
+		e = hipStreamSynchronize(ctx->stream); // nothing in flight may still use the old block
+	if (e != hipSuccess) {
+		(void) hipFree(np);
+		return fail(ctx, CONGA_ERR_HIP, std::string("grow: ") + hipGetErrorString(e));
 	}
 	if (b.p)
 		(void) hipFree(b.p);
@@ -139,13 +146,6 @@ int ensure(conga_ctx *ctx, DevBuf &b, size_t bytes, bool keep = false)
 	b.cap = want;
 	return CONGA_OK;
 }
-
-#define TRY(expr)                \
-	do {                         \
-		int rc_ = (expr);        \
-		if (rc_ != CONGA_OK)     \
-			return rc_;          \
-	} while (0)
 
 template <typename T> T *ptr(const DevBuf &b)
 {
@@ -177,98 +177,207 @@ int type_index(char type)
 	return -1;
 }
 
-// Build the combined interval arrays, the processing order and the reduce work items.
-int prepare_intervals(conga_ctx *ctx)
+bool batch_mode(const conga_ctx *ctx)
 {
-	const size_t nd = ctx->iv_start[0].size(), nu = ctx->iv_start[1].size();
-	const size_t n = nd + nu;
-	ctx->n_iv = (int64_t) n;
-	ctx->n_items = 0;
-	ctx->iv_dirty = false;
-	if (n == 0)
-		return CONGA_OK;
+	return (ctx->opts.flags & CONGA_FLAG_BATCH) != 0;
+}
 
-	std::vector<int32_t> start(n), end(n), order(n), item_first(n + 1), support;
-	std::vector<uint8_t> type(n);
-	for (size_t i = 0; i < nd; i++) {
-		start[i] = ctx->iv_start[0][i];
-		end[i] = ctx->iv_end[0][i];
-		type[i] = CONGA_DELETION;
+// Lay the batch out in the concatenated buffers and upload everything that is not a read tuple.
+int prepare(conga_ctx *ctx)
+{
+	const int n_slots = (int) ctx->slots.size();
+
+	// ---- geometry
+	int64_t rd_off = 0, gc_off = 0, tile0 = 0, iv0 = 0, map_rows = 0;
+	ctx->gc_like_distinct = false;
+	ctx->any_map = false;
+	ctx->support_given = false;
+	std::vector<Slot> dslots(n_slots);
+	for (int s = 0; s < n_slots; s++) {
+		HostSlot &h = ctx->slots[s];
+		h.rd_off = rd_off;
+		h.gc_off = gc_off;
+		h.tile0 = tile0;
+		h.tidx_off = tile0 + s;
+		h.iv0 = iv0;
+		h.map_row_off = map_rows;
+		Slot &d = dslots[s];
+		d.L = h.L;
+		d.rd_off = h.rd_off;
+		d.read_off = h.read_off;
+		d.n_reads = h.n_reads;
+		d.gc_off = h.gc_off;
+		d.n_win = h.n_win;
+		d.tile0 = h.tile0;
+		d.n_tiles = h.n_tiles;
+		d.tidx_off = h.tidx_off;
+		rd_off += (h.L + 7) & ~(int64_t) 7;
+		gc_off += (h.n_win + 15) & ~(int64_t) 15;
+		tile0 += h.n_tiles;
+		iv0 += (int64_t) (h.iv_start[0].size() + h.iv_start[1].size());
+		map_rows += (int64_t) h.map_start.size();
+		if (!h.gc_like.empty())
+			ctx->gc_like_distinct = true;
+		if (h.has_map)
+			ctx->any_map = true;
+		if (!h.iv_support[0].empty() || !h.iv_support[1].empty())
+			ctx->support_given = true;
 	}
-	for (size_t i = 0; i < nu; i++) {
-		start[nd + i] = ctx->iv_start[1][i];
-		end[nd + i] = ctx->iv_end[1][i];
-		type[nd + i] = CONGA_DUPLICATION;
+	ctx->total_L = rd_off;
+	ctx->total_gc = gc_off;
+	ctx->total_tiles = tile0;
+	ctx->n_iv = iv0;
+
+	TRY(upload(ctx, ctx->d_slots, dslots.data(), dslots.size() * sizeof(Slot)));
+	TRY(ensure(ctx, ctx->d_small, std::max<size_t>(n_slots, 1) * sizeof(Small)));
+	TRY(ensure(ctx, ctx->d_rd, std::max<size_t>((size_t) ctx->total_L, 8) * 2));
+	TRY(ensure(ctx, ctx->d_tile_start, ((size_t) ctx->total_tiles + n_slots + 1) * 4));
+	if ((size_t) n_slots > ctx->h_small_cap) {
+		if (ctx->h_small)
+			(void) hipHostFree(ctx->h_small);
+		ctx->h_small = nullptr;
+		ctx->h_small_cap = 0;
+		const size_t cap = (size_t) n_slots + 8;
+		HIP_TRY(ctx, hipHostMalloc((void **) &ctx->h_small, cap * sizeof(Small), hipHostMallocDefault));
+		ctx->h_small_cap = cap;
 	}
 
-	// longest chains first, so the lanes of a wave in interval_score_kernel retire together
-	std::iota(order.begin(), order.end(), 0);
-	std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
-		return (int64_t) end[x] - start[x] > (int64_t) end[y] - start[y];
-	});
-	// intervals spanning more than kLongWindows GC windows take the wave-cooperative chain
-	ctx->n_long = 0;
-	for (size_t i = 0; i < n; i++) {
-		const int32_t iv = order[i];
-		if (end[iv] <= start[iv])
-			break;
-		const int64_t nw = ((int64_t) end[iv] - 1) / ctx->step - (int64_t) start[iv] / ctx->step + 1;
-		if (nw <= kLongWindows)
-			break;
-		ctx->n_long = (int64_t) i + 1;
-	}
-
-	// reduce work items: [max(start,0), min(end,L)) cut into kItemLen pieces
-	std::vector<int32_t> item_iv, item_start, item_end;
-	item_iv.reserve(n + n / 2);
-	item_start.reserve(n + n / 2);
-	item_end.reserve(n + n / 2);
-	for (size_t i = 0; i < n; i++) {
-		item_first[i] = (int32_t) item_iv.size();
-		int64_t s = std::max<int64_t>(start[i], 0), e = std::min<int64_t>(end[i], ctx->L);
-		for (int64_t a = s; a < e; a += kItemLen) {
-			item_iv.push_back((int32_t) i);
-			item_start.push_back((int32_t) a);
-			item_end.push_back((int32_t) std::min<int64_t>(a + kItemLen, e));
+	// ---- GC bytes (padded to 16 per slot)
+	{
+		std::vector<uint8_t> gh((size_t) ctx->total_gc, 0), gl;
+		if (ctx->gc_like_distinct)
+			gl.assign((size_t) ctx->total_gc, 0);
+		for (int s = 0; s < n_slots; s++) {
+			const HostSlot &h = ctx->slots[s];
+			memcpy(gh.data() + h.gc_off, h.gc_hist.data(), (size_t) h.n_win);
+			if (ctx->gc_like_distinct)
+				memcpy(gl.data() + h.gc_off, h.gc_like.empty() ? h.gc_hist.data() : h.gc_like.data(), (size_t) h.n_win);
 		}
-	}
-	item_first[n] = (int32_t) item_iv.size();
-	ctx->n_items = (int64_t) item_iv.size();
-
-	TRY(upload(ctx, ctx->d_iv_start, start.data(), n * 4));
-	TRY(upload(ctx, ctx->d_iv_end, end.data(), n * 4));
-	TRY(upload(ctx, ctx->d_iv_type, type.data(), n));
-	TRY(upload(ctx, ctx->d_order, order.data(), n * 4));
-	TRY(upload(ctx, ctx->d_item_first, item_first.data(), (n + 1) * 4));
-	TRY(upload(ctx, ctx->d_item_iv, item_iv.data(), item_iv.size() * 4));
-	TRY(upload(ctx, ctx->d_item_start, item_start.data(), item_start.size() * 4));
-	TRY(upload(ctx, ctx->d_item_end, item_end.data(), item_end.size() * 4));
-	TRY(ensure(ctx, ctx->d_observed, n * 4));
-	TRY(ensure(ctx, ctx->d_map_part, std::max<size_t>(item_iv.size(), 1) * 8));
-	TRY(ensure(ctx, ctx->d_results, n * sizeof(conga_result)));
-	TRY(ensure(ctx, ctx->d_expected, n * 4));
-
-	ctx->support_given = !ctx->iv_support[0].empty() || !ctx->iv_support[1].empty();
-	if (ctx->support_given) {
-		support.assign(n, 0);
-		for (size_t i = 0; i < ctx->iv_support[0].size() && i < nd; i++)
-			support[i] = ctx->iv_support[0][i];
-		for (size_t i = 0; i < ctx->iv_support[1].size() && i < nu; i++)
-			support[nd + i] = ctx->iv_support[1][i];
-		TRY(upload(ctx, ctx->d_support, support.data(), n * 4));
+		TRY(upload(ctx, ctx->d_gc_hist, gh.data(), gh.size()));
+		if (ctx->gc_like_distinct)
+			TRY(upload(ctx, ctx->d_gc_like, gl.data(), gl.size()));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	}
 
-	if (n > ctx->h_results_cap) {
-		if (ctx->h_results)
-			(void) hipHostFree(ctx->h_results);
-		ctx->h_results = nullptr;
-		ctx->h_results_cap = 0;
-		const size_t cap = n + n / 2 + 64;
-		HIP_TRY(ctx, hipHostMalloc((void **) &ctx->h_results, cap * sizeof(conga_result), hipHostMallocDefault));
-		ctx->h_results_cap = cap;
+	// ---- mappability rows
+	if (ctx->any_map) {
+		std::vector<int32_t> ms((size_t) map_rows), me((size_t) map_rows);
+		std::vector<float> mv((size_t) map_rows);
+		int64_t max_L = 0;
+		bool any_unsorted = false;
+		for (const HostSlot &h : ctx->slots) {
+			if (!h.has_map)
+				continue;
+			std::copy(h.map_start.begin(), h.map_start.end(), ms.begin() + h.map_row_off);
+			std::copy(h.map_end.begin(), h.map_end.end(), me.begin() + h.map_row_off);
+			std::copy(h.map_val.begin(), h.map_val.end(), mv.begin() + h.map_row_off);
+			if (!h.map_sorted) {
+				any_unsorted = true;
+				max_L = std::max(max_L, h.L);
+			}
+		}
+		TRY(upload(ctx, ctx->d_map_start, ms.data(), ms.size() * 4));
+		TRY(upload(ctx, ctx->d_map_end, me.data(), me.size() * 4));
+		TRY(upload(ctx, ctx->d_map_val, mv.data(), mv.size() * 4));
+		TRY(ensure(ctx, ctx->d_map, std::max<size_t>((size_t) ctx->total_L, 8) * 4));
+		if (any_unsorted)
+			TRY(ensure(ctx, ctx->d_winner, (size_t) max_L * 4));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	}
-	// the uploads above read from vectors that die at return
-	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+	// ---- intervals: slot order, dels then dups inside a slot
+	const size_t n = (size_t) ctx->n_iv;
+	ctx->n_items = 0;
+	ctx->n_long = 0;
+	if (n > 0) {
+		std::vector<int32_t> start(n), end(n), iv_slot(n), order(n), item_first(n + 1), support;
+		std::vector<uint8_t> type(n), iv_has_map(n);
+		size_t k = 0;
+		for (int s = 0; s < n_slots; s++) {
+			const HostSlot &h = ctx->slots[s];
+			for (int t = 0; t < 2; t++)
+				for (size_t i = 0; i < h.iv_start[t].size(); i++, k++) {
+					start[k] = h.iv_start[t][i];
+					end[k] = h.iv_end[t][i];
+					type[k] = t == 0 ? CONGA_DELETION : CONGA_DUPLICATION;
+					iv_slot[k] = s;
+					iv_has_map[k] = h.has_map ? 1 : 0;
+				}
+		}
+		std::vector<int32_t> n_windows(n);
+		for (size_t i = 0; i < n; i++)
+			n_windows[i] = (end[i] <= start[i]) ? 0
+					: (int32_t) (((int64_t) end[i] - 1) / ctx->step - (int64_t) start[i] / ctx->step + 1);
+		// longest chains first: the groups of a wave in interval_chain_kernel then retire together, and
+		// the first n_long entries are the intervals that get a whole wave
+		std::iota(order.begin(), order.end(), 0);
+		std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return n_windows[x] > n_windows[y]; });
+		while ((size_t) ctx->n_long < n && n_windows[order[ctx->n_long]] > kLongWindows)
+			ctx->n_long++;
+
+		// reduce work items: [start, min(end, L)) cut into kItemLen pieces
+		std::vector<int64_t> item_off;
+		std::vector<int32_t> item_len, item_iv;
+		std::vector<uint8_t> item_has_map;
+		item_off.reserve(n + n / 2);
+		item_len.reserve(n + n / 2);
+		item_iv.reserve(n + n / 2);
+		item_has_map.reserve(n + n / 2);
+		for (size_t i = 0; i < n; i++) {
+			item_first[i] = (int32_t) item_off.size();
+			const HostSlot &h = ctx->slots[iv_slot[i]];
+			const int64_t s = start[i], e = std::min<int64_t>(end[i], h.L);
+			for (int64_t a = s; a < e; a += kItemLen) {
+				item_off.push_back(h.rd_off + a);
+				item_len.push_back((int32_t) std::min<int64_t>(kItemLen, e - a));
+				item_iv.push_back((int32_t) i);
+				item_has_map.push_back(iv_has_map[i]);
+			}
+		}
+		item_first[n] = (int32_t) item_off.size();
+		ctx->n_items = (int64_t) item_off.size();
+
+		TRY(upload(ctx, ctx->d_iv_start, start.data(), n * 4));
+		TRY(upload(ctx, ctx->d_iv_end, end.data(), n * 4));
+		TRY(upload(ctx, ctx->d_iv_type, type.data(), n));
+		TRY(upload(ctx, ctx->d_iv_slot, iv_slot.data(), n * 4));
+		TRY(upload(ctx, ctx->d_iv_has_map, iv_has_map.data(), n));
+		TRY(upload(ctx, ctx->d_order, order.data(), n * 4));
+		TRY(upload(ctx, ctx->d_item_first, item_first.data(), (n + 1) * 4));
+		TRY(upload(ctx, ctx->d_item_off, item_off.data(), item_off.size() * 8));
+		TRY(upload(ctx, ctx->d_item_len, item_len.data(), item_len.size() * 4));
+		TRY(upload(ctx, ctx->d_item_iv, item_iv.data(), item_iv.size() * 4));
+		TRY(upload(ctx, ctx->d_item_has_map, item_has_map.data(), item_has_map.size()));
+		TRY(ensure(ctx, ctx->d_observed, n * 4));
+		TRY(ensure(ctx, ctx->d_expected, n * 4));
+		TRY(ensure(ctx, ctx->d_map_part, std::max<size_t>(item_off.size(), 1) * 8));
+		TRY(ensure(ctx, ctx->d_results, n * sizeof(conga_result)));
+		if (ctx->support_given) {
+			support.assign(n, 0);
+			for (int s = 0; s < n_slots; s++) {
+				const HostSlot &h = ctx->slots[s];
+				size_t base = (size_t) h.iv0;
+				for (int t = 0; t < 2; t++) {
+					for (size_t i = 0; i < h.iv_support[t].size() && i < h.iv_start[t].size(); i++)
+						support[base + i] = h.iv_support[t][i];
+					base += h.iv_start[t].size();
+				}
+			}
+			TRY(upload(ctx, ctx->d_support, support.data(), n * 4));
+		}
+		if (n > ctx->h_results_cap) {
+			if (ctx->h_results)
+				(void) hipHostFree(ctx->h_results);
+			ctx->h_results = nullptr;
+			ctx->h_results_cap = 0;
+			const size_t cap = n + n / 2 + 64;
+			HIP_TRY(ctx, hipHostMalloc((void **) &ctx->h_results, cap * sizeof(conga_result), hipHostMallocDefault));
+			ctx->h_results_cap = cap;
+		}
+		// the uploads above read from vectors that die at return
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	ctx->layout_dirty = false;
 	return CONGA_OK;
 }
 
@@ -289,6 +398,23 @@ struct KernelTimer {
 			(void) hipEventRecord(ctx->ev_k1[k], ctx->stream);
 	}
 };
+
+void reset_slots(conga_ctx *ctx)
+{
+	ctx->slots.clear();
+	ctx->cur = -1;
+	ctx->n_reads_total = 0;
+	ctx->staging_cur = -1;
+	ctx->layout_dirty = true;
+	ctx->computed = false;
+}
+
+HostSlot *current(conga_ctx *ctx)
+{
+	if (ctx->cur < 0 || ctx->cur >= (int) ctx->slots.size())
+		return nullptr;
+	return &ctx->slots[ctx->cur];
+}
 
 } // namespace
 
@@ -367,6 +493,14 @@ conga_ctx *conga_create(int device, const conga_opts *opts, int *status)
 		delete ctx;
 		return nullptr;
 	}
+	ctx->step = ctx->opts.gc_step;
+	// tile = tile_win windows; tile_win * step must be a multiple of 8 (16-byte stores) and fit the LDS tile
+	int32_t tw = std::min<int32_t>(kDepthMaxTile / ctx->step, kDepthMaxWin);
+	tw &= ~7;
+	if (tw < 8)
+		tw = 8;
+	ctx->tile_win = tw;
+
 	auto bail = [&](int st) -> conga_ctx * {
 		*status = st;
 		conga_destroy(ctx);
@@ -377,6 +511,12 @@ conga_ctx *conga_create(int device, const conga_opts *opts, int *status)
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
 		ctx->n_cu = prop.multiProcessorCount;
+	{
+		// the depth kernel keeps a histogram per workgroup, so its grid is exactly one resident wave of workgroups
+		int nb = 0;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, depth_tile_kernel, kDepthBlock, 0) == hipSuccess && nb > 0)
+			ctx->depth_blocks_per_cu = std::min(nb, 8);
+	}
 	if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess)
 		return bail(CONGA_ERR_HIP);
 	if (hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming) != hipSuccess)
@@ -384,13 +524,6 @@ conga_ctx *conga_create(int device, const conga_opts *opts, int *status)
 	for (int k = 0; k < CONGA_K_COUNT; k++)
 		if (hipEventCreate(&ctx->ev_k0[k]) != hipSuccess || hipEventCreate(&ctx->ev_k1[k]) != hipSuccess)
 			return bail(CONGA_ERR_HIP);
-	if (hipHostMalloc((void **) &ctx->h_small, sizeof(SmallBlock), hipHostMallocDefault) != hipSuccess)
-		return bail(CONGA_ERR_NOMEM);
-	void *small = nullptr;
-	if (hipMalloc(&small, sizeof(SmallBlock)) != hipSuccess)
-		return bail(CONGA_ERR_NOMEM);
-	ctx->d_small.p = small;
-	ctx->d_small.cap = sizeof(SmallBlock);
 	*status = CONGA_OK;
 	return ctx;
 }
@@ -403,12 +536,10 @@ void conga_destroy(conga_ctx *ctx)
 	if (ctx->stream)
 		(void) hipStreamSynchronize(ctx->stream);
 	DevBuf *bufs[] = {&ctx->d_pos, &ctx->d_mapq, &ctx->d_tile_start, &ctx->d_rd, &ctx->d_gc_hist, &ctx->d_gc_like,
-			&ctx->d_small, &ctx->d_map, &ctx->d_winner, &ctx->d_map_start, &ctx->d_map_end, &ctx->d_map_val,
-			&ctx->d_iv_start, &ctx->d_iv_end, &ctx->d_iv_type, &ctx->d_order, &ctx->d_observed, &ctx->d_item_iv,
-			&ctx->d_item_start, &ctx->d_item_end, &ctx->d_item_first, &ctx->d_map_part, &ctx->d_support,
-			&ctx->d_results, &ctx->d_expected};
-	if (ctx->gc_aliased)
-		ctx->d_gc_like = DevBuf();
+			&ctx->d_slots, &ctx->d_small, &ctx->d_map, &ctx->d_winner, &ctx->d_map_start, &ctx->d_map_end,
+			&ctx->d_map_val, &ctx->d_iv_start, &ctx->d_iv_end, &ctx->d_iv_type, &ctx->d_iv_slot, &ctx->d_iv_has_map,
+			&ctx->d_order, &ctx->d_observed, &ctx->d_expected, &ctx->d_item_off, &ctx->d_item_len, &ctx->d_item_iv,
+			&ctx->d_item_has_map, &ctx->d_item_first, &ctx->d_map_part, &ctx->d_support, &ctx->d_results};
 	for (DevBuf *b : bufs)
 		free_buf(*b);
 	for (auto &s : ctx->staging) {
@@ -436,6 +567,16 @@ void conga_destroy(conga_ctx *ctx)
 	delete ctx;
 }
 
+int conga_reset(conga_ctx *ctx)
+{
+	if (!ctx)
+		return CONGA_ERR_INVALID;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	reset_slots(ctx);
+	return CONGA_OK;
+}
+
 int conga_chrom_begin(conga_ctx *ctx, int64_t chrom_len, const uint8_t *gc_hist_w, const uint8_t *gc_like_w,
 		int64_t n_win)
 {
@@ -443,60 +584,44 @@ int conga_chrom_begin(conga_ctx *ctx, int64_t chrom_len, const uint8_t *gc_hist_
 		return CONGA_ERR_INVALID;
 	if (chrom_len <= 0 || chrom_len > (int64_t) INT32_MAX - 2 * kDepthMaxTile || !gc_hist_w || !gc_like_w)
 		return fail(ctx, CONGA_ERR_INVALID, "conga_chrom_begin: bad length or null GC array");
-	const int32_t step = ctx->opts.gc_step;
+	const int32_t step = ctx->step;
 	if (n_win != (chrom_len + step - 1) / step)
 		return fail(ctx, CONGA_ERR_INVALID, "conga_chrom_begin: n_win must be ceil(chrom_len / gc_step)");
+	if (ctx->staging_cur >= 0)
+		return fail(ctx, CONGA_ERR_INVALID, "conga_chrom_begin: a staging buffer is handed out and not committed");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
-	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-
-	ctx->chrom_open = false;
+	if (!batch_mode(ctx)) {
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		reset_slots(ctx);
+	}
+	HostSlot h;
+	h.L = chrom_len;
+	h.n_win = n_win;
+	const int64_t T = (int64_t) ctx->tile_win * step;
+	h.n_tiles = (chrom_len + T - 1) / T;
+	h.read_off = ctx->n_reads_total;
+	h.gc_hist.assign(gc_hist_w, gc_hist_w + n_win);
+	if (gc_like_w != gc_hist_w && memcmp(gc_like_w, gc_hist_w, (size_t) n_win) != 0)
+		h.gc_like.assign(gc_like_w, gc_like_w + n_win);
+	ctx->slots.push_back(std::move(h));
+	ctx->cur = (int) ctx->slots.size() - 1;
+	ctx->layout_dirty = true;
 	ctx->computed = false;
-	ctx->L = chrom_len;
-	ctx->n_win = n_win;
-	ctx->step = step;
-	// tile = tile_win windows; tile_win * step must be a multiple of 8 (16-byte stores) and fit the LDS tile
-	int32_t tw = std::min<int32_t>(kDepthMaxTile / step, 1024);
-	tw &= ~7;
-	if (tw < 8)
-		tw = 8;
-	ctx->tile_win = tw;
-	const int64_t T = (int64_t) tw * step;
-	ctx->n_tiles = (chrom_len + T - 1) / T;
+	return CONGA_OK;
+}
 
-	ctx->n_reads = 0;
-	ctx->staging_cur = -1;
-	for (int t = 0; t < 2; t++) {
-		ctx->iv_start[t].clear();
-		ctx->iv_end[t].clear();
-		ctx->iv_support[t].clear();
-		ctx->iv_given[t] = false;
-	}
-	ctx->iv_dirty = true;
-	ctx->n_iv = ctx->n_items = 0;
-	ctx->has_map = false;
-	ctx->n_map_rows = 0;
+int conga_chrom_count(const conga_ctx *ctx)
+{
+	return ctx ? (int) ctx->slots.size() : 0;
+}
 
-	// GC bytes, padded to a multiple of 4 (interval_score_kernel reads them as words)
-	const size_t gc_bytes = ((size_t) n_win + 3) & ~(size_t) 3;
-	if (ctx->gc_aliased)
-		ctx->d_gc_like = DevBuf();
-	ctx->gc_aliased = false;
-	TRY(ensure(ctx, ctx->d_gc_hist, gc_bytes));
-	HIP_TRY(ctx, hipMemsetAsync(ctx->d_gc_hist.p, 0, gc_bytes, ctx->stream));
-	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_gc_hist.p, gc_hist_w, (size_t) n_win, hipMemcpyHostToDevice, ctx->stream));
-	if (gc_like_w == gc_hist_w) {
-		free_buf(ctx->d_gc_like);
-		ctx->d_gc_like = ctx->d_gc_hist;
-		ctx->gc_aliased = true;
-	} else {
-		TRY(ensure(ctx, ctx->d_gc_like, gc_bytes));
-		HIP_TRY(ctx, hipMemsetAsync(ctx->d_gc_like.p, 0, gc_bytes, ctx->stream));
-		HIP_TRY(ctx, hipMemcpyAsync(ctx->d_gc_like.p, gc_like_w, (size_t) n_win, hipMemcpyHostToDevice, ctx->stream));
-	}
-	TRY(ensure(ctx, ctx->d_rd, ((size_t) chrom_len * 2 + 15) & ~(size_t) 15));
-	TRY(ensure(ctx, ctx->d_tile_start, ((size_t) ctx->n_tiles + 2) * 4));
-	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // caller's GC arrays are free again
-	ctx->chrom_open = true;
+int conga_chrom_select(conga_ctx *ctx, int index)
+{
+	if (!ctx)
+		return CONGA_ERR_INVALID;
+	if (index < 0 || index >= (int) ctx->slots.size())
+		return fail(ctx, CONGA_ERR_INVALID, "conga_chrom_select: no such chromosome");
+	ctx->cur = index;
 	return CONGA_OK;
 }
 
@@ -504,7 +629,7 @@ int conga_reads_staging(conga_ctx *ctx, conga_read_staging *out)
 {
 	if (!ctx || !out)
 		return CONGA_ERR_INVALID;
-	if (!ctx->chrom_open)
+	if (ctx->slots.empty())
 		return fail(ctx, CONGA_ERR_INVALID, "conga_reads_staging: no chromosome open");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	Staging &s = ctx->staging[ctx->staging_next];
@@ -528,29 +653,32 @@ int conga_reads_commit(conga_ctx *ctx, size_t n)
 {
 	if (!ctx)
 		return CONGA_ERR_INVALID;
-	if (!ctx->chrom_open || ctx->staging_cur < 0)
+	if (ctx->slots.empty() || ctx->staging_cur < 0)
 		return fail(ctx, CONGA_ERR_INVALID, "conga_reads_commit: call conga_reads_staging first");
 	if (n > kStagingTuples)
 		return fail(ctx, CONGA_ERR_INVALID, "conga_reads_commit: n exceeds the staging capacity");
-	if ((uint64_t) ctx->n_reads + n >= 0xFFFFFFF0ull)
+	HostSlot &h = ctx->slots.back(); // reads stream into the chromosome begun last (BAM order)
+	if ((uint64_t) h.n_reads + n >= 0xFFFFFFF0ull)
 		return fail(ctx, CONGA_ERR_RANGE, "conga_reads_commit: more than 2^32 reads on one chromosome");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	Staging &s = ctx->staging[ctx->staging_cur];
 	ctx->staging_cur = -1;
 	if (n == 0)
 		return CONGA_OK;
-	const size_t total = (size_t) ctx->n_reads + n;
+	const size_t total = (size_t) ctx->n_reads_total + n;
 	if (total * 4 > ctx->d_pos.cap || total > ctx->d_mapq.cap) {
 		const size_t want = std::max(total, (size_t) 1 << 22);
 		TRY(ensure(ctx, ctx->d_pos, want * 4, true));
 		TRY(ensure(ctx, ctx->d_mapq, want, true));
 	}
-	HIP_TRY(ctx, hipMemcpyAsync(ptr<int32_t>(ctx->d_pos) + ctx->n_reads, s.pos, n * 4, hipMemcpyHostToDevice, ctx->stream));
-	HIP_TRY(ctx, hipMemcpyAsync(ptr<uint8_t>(ctx->d_mapq) + ctx->n_reads, s.mapq, n, hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(ptr<int32_t>(ctx->d_pos) + ctx->n_reads_total, s.pos, n * 4, hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(ptr<uint8_t>(ctx->d_mapq) + ctx->n_reads_total, s.mapq, n, hipMemcpyHostToDevice, ctx->stream));
 	HIP_TRY(ctx, hipEventRecord(s.copied, ctx->stream));
 	s.in_flight = true;
-	ctx->n_reads += (int64_t) n;
+	h.n_reads += (int64_t) n;
+	ctx->n_reads_total += (int64_t) n;
 	ctx->staging_next = (ctx->staging_next + 1) % kStagingRing;
+	ctx->layout_dirty = true;
 	ctx->computed = false;
 	return CONGA_OK;
 }
@@ -559,11 +687,11 @@ int conga_mappability(conga_ctx *ctx, const int32_t *start, const int32_t *end, 
 {
 	if (!ctx || (m && (!start || !end || !val)))
 		return CONGA_ERR_INVALID;
-	if (!ctx->chrom_open)
+	HostSlot *h = current(ctx);
+	if (!h)
 		return fail(ctx, CONGA_ERR_INVALID, "conga_mappability: no chromosome open");
 	if (m > (size_t) INT32_MAX)
 		return fail(ctx, CONGA_ERR_RANGE, "conga_mappability: too many rows");
-	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	// sorted, abutting-at-most rows can be painted in one pass (kernels.hip.h: paint_sorted_kernel)
 	bool sorted = true;
 	for (size_t k = 0; k < m && sorted; k++) {
@@ -572,17 +700,13 @@ int conga_mappability(conga_ctx *ctx, const int32_t *start, const int32_t *end, 
 		if (k + 1 < m && (start[k + 1] < end[k] || start[k + 1] < start[k]))
 			sorted = false;
 	}
-	ctx->map_sorted = sorted;
-	ctx->n_map_rows = (int64_t) m;
-	ctx->has_map = true;
+	h->map_sorted = sorted;
+	h->has_map = true;
+	h->map_start.assign(start, start + m);
+	h->map_end.assign(end, end + m);
+	h->map_val.assign(val, val + m);
+	ctx->layout_dirty = true;
 	ctx->computed = false;
-	TRY(upload(ctx, ctx->d_map_start, start, m * 4));
-	TRY(upload(ctx, ctx->d_map_end, end, m * 4));
-	TRY(upload(ctx, ctx->d_map_val, val, m * 4));
-	TRY(ensure(ctx, ctx->d_map, ((size_t) ctx->L * 4 + 15) & ~(size_t) 15));
-	if (!sorted)
-		TRY(ensure(ctx, ctx->d_winner, (size_t) ctx->L * 4));
-	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // caller's arrays are free again
 	return CONGA_OK;
 }
 
@@ -593,7 +717,8 @@ int conga_intervals(conga_ctx *ctx, char type, const int32_t *start, const int32
 	const int t = type_index(type);
 	if (t < 0)
 		return fail(ctx, CONGA_ERR_INVALID, "conga_intervals: type must be 'D' or 'E'");
-	if (!ctx->chrom_open)
+	HostSlot *h = current(ctx);
+	if (!h)
 		return fail(ctx, CONGA_ERR_INVALID, "conga_intervals: no chromosome open");
 	if (n > (size_t) 1 << 28)
 		return fail(ctx, CONGA_ERR_RANGE, "conga_intervals: too many intervals");
@@ -602,11 +727,10 @@ int conga_intervals(conga_ctx *ctx, char type, const int32_t *start, const int32
 		if (start[i] < 0 || end[i] < start[i])
 			return fail(ctx, CONGA_ERR_RANGE, "conga_intervals: interval with start < 0 or end < start");
 	}
-	ctx->iv_start[t].assign(start, start + n);
-	ctx->iv_end[t].assign(end, end + n);
-	ctx->iv_support[t].clear();
-	ctx->iv_given[t] = true;
-	ctx->iv_dirty = true;
+	h->iv_start[t].assign(start, start + n);
+	h->iv_end[t].assign(end, end + n);
+	h->iv_support[t].clear();
+	ctx->layout_dirty = true;
 	ctx->computed = false;
 	return CONGA_OK;
 }
@@ -616,10 +740,11 @@ int conga_split_support(conga_ctx *ctx, char type, const int32_t *support, size_
 	if (!ctx || (n && !support))
 		return CONGA_ERR_INVALID;
 	const int t = type_index(type);
-	if (t < 0 || n != ctx->iv_start[t].size())
+	HostSlot *h = current(ctx);
+	if (t < 0 || !h || n != h->iv_start[t].size())
 		return fail(ctx, CONGA_ERR_INVALID, "conga_split_support: type / count does not match conga_intervals");
-	ctx->iv_support[t].assign(support, support + n);
-	ctx->iv_dirty = true;
+	h->iv_support[t].assign(support, support + n);
+	ctx->layout_dirty = true;
 	ctx->computed = false;
 	return CONGA_OK;
 }
@@ -628,33 +753,38 @@ int conga_chrom_compute(conga_ctx *ctx)
 {
 	if (!ctx)
 		return CONGA_ERR_INVALID;
-	if (!ctx->chrom_open)
+	if (ctx->slots.empty())
 		return fail(ctx, CONGA_ERR_INVALID, "conga_chrom_compute: no chromosome open");
+	if (ctx->staging_cur >= 0)
+		return fail(ctx, CONGA_ERR_INVALID, "conga_chrom_compute: a staging buffer is handed out and not committed");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
-	if (ctx->iv_dirty)
-		TRY(prepare_intervals(ctx));
-	if (ctx->n_reads == 0) {
+	if (ctx->layout_dirty)
+		TRY(prepare(ctx));
+	if (ctx->n_reads_total == 0) {
 		TRY(ensure(ctx, ctx->d_pos, 256));
 		TRY(ensure(ctx, ctx->d_mapq, 256));
 	}
 
 	hipStream_t st = ctx->stream;
-	SmallBlock *small = ptr<SmallBlock>(ctx->d_small);
+	const int n_slots = (int) ctx->slots.size();
+	Small *small = ptr<Small>(ctx->d_small);
+	const Slot *dslots = ptr<Slot>(ctx->d_slots);
+	const uint8_t *gc_like = ctx->gc_like_distinct ? ptr<uint8_t>(ctx->d_gc_like) : ptr<uint8_t>(ctx->d_gc_hist);
 	const bool unsorted_mode = (ctx->opts.flags & CONGA_FLAG_READS_UNSORTED) != 0;
 	for (int k = 0; k < CONGA_K_COUNT; k++)
 		ctx->ev_used[k] = false;
 
-	HIP_TRY(ctx, hipMemsetAsync(small, 0, sizeof(SmallBlock), st));
+	HIP_TRY(ctx, hipMemsetAsync(small, 0, (size_t) n_slots * sizeof(Small), st));
 
 	if (!unsorted_mode) {
-		HIP_TRY(ctx, hipMemsetAsync(ctx->d_tile_start.p, 0xFF, ((size_t) ctx->n_tiles + 2) * 4, st));
+		HIP_TRY(ctx, hipMemsetAsync(ctx->d_tile_start.p, 0xFF, ((size_t) ctx->total_tiles + n_slots + 1) * 4, st));
 		{
 			KernelTimer t(ctx, CONGA_K_INGEST);
-			if (ctx->n_reads > 0) {
-				const int grid = (int) std::min<int64_t>((ctx->n_reads + 255) / 256, (int64_t) ctx->n_cu * 8);
-				hipLaunchKernelGGL(ingest_kernel, dim3(grid), dim3(256), 0, st, ptr<int32_t>(ctx->d_pos), ctx->n_reads,
-						ctx->L, ctx->tile_win * ctx->step, ctx->n_tiles, ptr<uint32_t>(ctx->d_tile_start),
-						&small->status, small->counters);
+			if (ctx->n_reads_total > 0) {
+				const int grid = (int) std::min<int64_t>((ctx->n_reads_total + 255) / 256, (int64_t) ctx->n_cu * 8);
+				hipLaunchKernelGGL(ingest_kernel, dim3(grid), dim3(256), 0, st, ptr<int32_t>(ctx->d_pos),
+						ctx->n_reads_total, dslots, n_slots, ctx->tile_win * ctx->step,
+						ptr<uint32_t>(ctx->d_tile_start), small);
 			}
 		}
 		{
@@ -662,63 +792,72 @@ int conga_chrom_compute(conga_ctx *ctx)
 			DepthArgs a;
 			a.pos = ptr<int32_t>(ctx->d_pos);
 			a.mapq = ptr<uint8_t>(ctx->d_mapq);
-			a.n = ctx->n_reads;
 			a.tile_start = ptr<uint32_t>(ctx->d_tile_start);
 			a.rd = ptr<int16_t>(ctx->d_rd);
-			a.L = ctx->L;
 			a.gc_hist = ptr<uint8_t>(ctx->d_gc_hist);
-			a.n_win = ctx->n_win;
+			a.slots = dslots;
+			a.small = small;
+			a.n_slots = n_slots;
 			a.step = ctx->step;
 			a.tile_win = ctx->tile_win;
 			a.mq_threshold = ctx->opts.mq_threshold;
-			a.n_tiles = ctx->n_tiles;
-			a.hist_sum = small->hist_sum;
-			a.hist_bases = small->hist_bases;
-			a.counters = small->counters;
-			a.status = &small->status;
-			const int grid = (int) std::min<int64_t>(ctx->n_tiles, (int64_t) ctx->n_cu * 4);
+			a.total_tiles = ctx->total_tiles;
+			const int64_t max_grid = (int64_t) ctx->n_cu * ctx->depth_blocks_per_cu;
+			a.tiles_per_block = std::max<int64_t>(1, (ctx->total_tiles + max_grid - 1) / max_grid);
+			const int grid = (int) ((ctx->total_tiles + a.tiles_per_block - 1) / a.tiles_per_block);
 			hipLaunchKernelGGL(depth_tile_kernel, dim3(grid), dim3(kDepthBlock), 0, st, a);
 		}
 	} else {
 		KernelTimer t(ctx, CONGA_K_DEPTH);
-		HIP_TRY(ctx, hipMemsetAsync(ctx->d_rd.p, 0, ((size_t) ctx->L * 2 + 15) & ~(size_t) 15, st));
-		if (ctx->n_reads > 0) {
-			const int grid = (int) std::min<int64_t>((ctx->n_reads + 255) / 256, (int64_t) ctx->n_cu * 8);
-			hipLaunchKernelGGL(depth_atomic_kernel, dim3(grid), dim3(256), 0, st, ptr<int32_t>(ctx->d_pos),
-					ptr<uint8_t>(ctx->d_mapq), ctx->n_reads, ctx->L, ctx->opts.mq_threshold, ptr<int16_t>(ctx->d_rd),
-					small->counters);
+		HIP_TRY(ctx, hipMemsetAsync(ctx->d_rd.p, 0, (size_t) ctx->total_L * 2, st));
+		for (int s = 0; s < n_slots; s++) {
+			const HostSlot &h = ctx->slots[s];
+			if (h.n_reads > 0) {
+				const int grid = (int) std::min<int64_t>((h.n_reads + 255) / 256, (int64_t) ctx->n_cu * 8);
+				hipLaunchKernelGGL(depth_atomic_kernel, dim3(grid), dim3(256), 0, st,
+						ptr<int32_t>(ctx->d_pos) + h.read_off, ptr<uint8_t>(ctx->d_mapq) + h.read_off, h.n_reads, h.L,
+						ctx->opts.mq_threshold, ptr<int16_t>(ctx->d_rd) + h.rd_off, small[s].counters);
+			}
+			const int64_t n_w = (h.L + ctx->step - 1) / ctx->step;
+			const int grid = (int) std::min<int64_t>((n_w + 255) / 256, (int64_t) ctx->n_cu * 8);
+			hipLaunchKernelGGL(gc_hist_kernel, dim3(grid), dim3(256), 0, st, ptr<int16_t>(ctx->d_rd) + h.rd_off, h.L,
+					ptr<uint8_t>(ctx->d_gc_hist) + h.gc_off, h.n_win, ctx->step, small[s].hist_sum, small[s].hist_bases);
 		}
-		const int64_t n_w = (ctx->L + ctx->step - 1) / ctx->step;
-		const int grid = (int) std::min<int64_t>((n_w + 255) / 256, (int64_t) ctx->n_cu * 8);
-		hipLaunchKernelGGL(gc_hist_kernel, dim3(grid), dim3(256), 0, st, ptr<int16_t>(ctx->d_rd), ctx->L,
-				ptr<uint8_t>(ctx->d_gc_hist), ctx->n_win, ctx->step, small->hist_sum, small->hist_bases);
 	}
 
 	{
 		KernelTimer t(ctx, CONGA_K_EXPECTED);
-		hipLaunchKernelGGL(expected_table_kernel, dim3(1), dim3(128), 0, st, small->hist_sum, small->hist_bases, small->E);
+		hipLaunchKernelGGL(expected_table_kernel, dim3(n_slots), dim3(128), 0, st, small);
 	}
 
 	// the reference paints the track only when the chromosome has at least one kept SV
 	// (likelihood.c:332-336 returns before :352-356)
-	if (ctx->has_map && ctx->n_iv > 0) {
+	if (ctx->any_map && ctx->n_iv > 0) {
 		KernelTimer t(ctx, CONGA_K_PAINT);
-		if (ctx->map_sorted) {
-			const int64_t tile = 256 * 4;
-			const int grid = (int) std::min<int64_t>((ctx->L + tile - 1) / tile, (int64_t) ctx->n_cu * 16);
-			hipLaunchKernelGGL(paint_sorted_kernel, dim3(grid), dim3(256), 0, st, ptr<int32_t>(ctx->d_map_start),
-					ptr<int32_t>(ctx->d_map_end), ptr<float>(ctx->d_map_val), ctx->n_map_rows, ptr<float>(ctx->d_map),
-					ctx->L);
-		} else {
-			HIP_TRY(ctx, hipMemsetAsync(ctx->d_winner.p, 0xFF, (size_t) ctx->L * 4, st));
-			if (ctx->n_map_rows > 0) {
-				const int grid = (int) std::min<int64_t>((ctx->n_map_rows + 3) / 4, (int64_t) ctx->n_cu * 8);
-				hipLaunchKernelGGL(paint_winner_kernel, dim3(grid), dim3(256), 0, st, ptr<int32_t>(ctx->d_map_start),
-						ptr<int32_t>(ctx->d_map_end), ctx->n_map_rows, ptr<int32_t>(ctx->d_winner), ctx->L);
+		for (int s = 0; s < n_slots; s++) {
+			const HostSlot &h = ctx->slots[s];
+			if (!h.has_map || h.iv_start[0].size() + h.iv_start[1].size() == 0)
+				continue;
+			const int32_t *ms = ptr<int32_t>(ctx->d_map_start) + h.map_row_off;
+			const int32_t *me = ptr<int32_t>(ctx->d_map_end) + h.map_row_off;
+			const float *mv = ptr<float>(ctx->d_map_val) + h.map_row_off;
+			float *map = ptr<float>(ctx->d_map) + h.rd_off;
+			const int64_t m = (int64_t) h.map_start.size();
+			if (h.map_sorted) {
+				const int64_t tile = 256 * 4;
+				const int grid = (int) std::min<int64_t>((h.L + tile - 1) / tile, (int64_t) ctx->n_cu * 16);
+				hipLaunchKernelGGL(paint_sorted_kernel, dim3(grid), dim3(256), 0, st, ms, me, mv, m, map, h.L);
+			} else {
+				HIP_TRY(ctx, hipMemsetAsync(ctx->d_winner.p, 0xFF, (size_t) h.L * 4, st));
+				if (m > 0) {
+					const int grid = (int) std::min<int64_t>((m + 3) / 4, (int64_t) ctx->n_cu * 8);
+					hipLaunchKernelGGL(paint_winner_kernel, dim3(grid), dim3(256), 0, st, ms, me, m,
+							ptr<int32_t>(ctx->d_winner), h.L);
+				}
+				const int grid = (int) std::min<int64_t>((h.L + 255) / 256, (int64_t) ctx->n_cu * 16);
+				hipLaunchKernelGGL(paint_resolve_kernel, dim3(grid), dim3(256), 0, st, ptr<int32_t>(ctx->d_winner), mv,
+						map, h.L);
 			}
-			const int grid = (int) std::min<int64_t>((ctx->L + 255) / 256, (int64_t) ctx->n_cu * 16);
-			hipLaunchKernelGGL(paint_resolve_kernel, dim3(grid), dim3(256), 0, st, ptr<int32_t>(ctx->d_winner),
-					ptr<float>(ctx->d_map_val), ptr<float>(ctx->d_map), ctx->L);
 		}
 	}
 
@@ -728,10 +867,11 @@ int conga_chrom_compute(conga_ctx *ctx)
 			KernelTimer t(ctx, CONGA_K_REDUCE);
 			ReduceArgs a;
 			a.rd = ptr<int16_t>(ctx->d_rd);
-			a.map = ctx->has_map ? ptr<float>(ctx->d_map) : nullptr;
+			a.map = ptr<float>(ctx->d_map);
+			a.item_off = ptr<int64_t>(ctx->d_item_off);
+			a.item_len = ptr<int32_t>(ctx->d_item_len);
 			a.item_iv = ptr<int32_t>(ctx->d_item_iv);
-			a.item_start = ptr<int32_t>(ctx->d_item_start);
-			a.item_end = ptr<int32_t>(ctx->d_item_end);
+			a.item_has_map = ptr<uint8_t>(ctx->d_item_has_map);
 			a.n_items = ctx->n_items;
 			a.observed = ptr<int32_t>(ctx->d_observed);
 			a.map_part = ptr<double>(ctx->d_map_part);
@@ -739,20 +879,30 @@ int conga_chrom_compute(conga_ctx *ctx)
 			const int grid = (int) ((ctx->n_items + waves_per_block - 1) / waves_per_block);
 			hipLaunchKernelGGL(interval_reduce_kernel, dim3(grid), dim3(256), 0, st, a);
 		}
-		if (ctx->n_long > 0) {
+		{
 			KernelTimer t(ctx, CONGA_K_CHAIN);
 			ChainArgs c;
 			c.start = ptr<int32_t>(ctx->d_iv_start);
 			c.end = ptr<int32_t>(ctx->d_iv_end);
+			c.iv_slot = ptr<int32_t>(ctx->d_iv_slot);
 			c.order = ptr<int32_t>(ctx->d_order);
-			c.n_long = ctx->n_long;
-			c.gc_like = ptr<uint8_t>(ctx->d_gc_like);
-			c.n_win = ctx->n_win;
+			c.gc_like = gc_like;
+			c.slots = dslots;
+			c.small = small;
 			c.step = ctx->step;
-			c.E = small->E;
 			c.expected = ptr<float>(ctx->d_expected);
-			const int grid = (int) ((ctx->n_long + 3) / 4);
-			hipLaunchKernelGGL(chain_long_kernel, dim3(grid), dim3(256), 0, st, c);
+			if (ctx->n_long > 0) {
+				c.first = 0;
+				c.count = ctx->n_long;
+				const int grid = (int) ((ctx->n_long + 3) / 4); // one wave per interval, 4 waves per block
+				hipLaunchKernelGGL(interval_chain_kernel<64>, dim3(grid), dim3(256), 0, st, c);
+			}
+			if (ctx->n_iv > ctx->n_long) {
+				c.first = ctx->n_long;
+				c.count = ctx->n_iv - ctx->n_long;
+				const int grid = (int) ((c.count + 15) / 16); // four 16-lane groups per wave
+				hipLaunchKernelGGL(interval_chain_kernel<16>, dim3(grid), dim3(256), 0, st, c);
+			}
 		}
 		{
 			KernelTimer t(ctx, CONGA_K_SCORE);
@@ -760,19 +910,13 @@ int conga_chrom_compute(conga_ctx *ctx)
 			a.start = ptr<int32_t>(ctx->d_iv_start);
 			a.end = ptr<int32_t>(ctx->d_iv_end);
 			a.type = ptr<uint8_t>(ctx->d_iv_type);
-			a.order = ptr<int32_t>(ctx->d_order);
 			a.n_iv = ctx->n_iv;
-			a.gc_like = ptr<uint8_t>(ctx->d_gc_like);
-			a.n_win = ctx->n_win;
-			a.step = ctx->step;
-			a.E = small->E;
 			a.observed = ptr<int32_t>(ctx->d_observed);
-			a.map_part = ctx->has_map ? ptr<double>(ctx->d_map_part) : nullptr;
+			a.expected = ptr<float>(ctx->d_expected);
+			a.map_part = ptr<double>(ctx->d_map_part);
 			a.item_first = ptr<int32_t>(ctx->d_item_first);
+			a.iv_has_map = ptr<uint8_t>(ctx->d_iv_has_map);
 			a.support = ctx->support_given ? ptr<int32_t>(ctx->d_support) : nullptr;
-			a.has_map = ctx->has_map ? 1 : 0;
-			a.n_long = ctx->n_long;
-			a.expected_long = ptr<float>(ctx->d_expected);
 			a.out = ptr<conga_result>(ctx->d_results);
 			const int grid = (int) ((ctx->n_iv + 63) / 64);
 			hipLaunchKernelGGL(interval_score_kernel, dim3(grid), dim3(64), 0, st, a);
@@ -780,7 +924,7 @@ int conga_chrom_compute(conga_ctx *ctx)
 		HIP_TRY(ctx, hipMemcpyAsync(ctx->h_results, ctx->d_results.p, (size_t) ctx->n_iv * sizeof(conga_result),
 				hipMemcpyDeviceToHost, st));
 	}
-	HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small, small, sizeof(SmallBlock), hipMemcpyDeviceToHost, st));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small, small, (size_t) n_slots * sizeof(Small), hipMemcpyDeviceToHost, st));
 	HIP_TRY(ctx, hipEventRecord(ctx->ev_done, st));
 	HIP_TRY(ctx, hipGetLastError());
 	ctx->computed = true;
@@ -794,24 +938,27 @@ int conga_chrom_fetch(conga_ctx *ctx, conga_result *dels, conga_result *dups, fl
 		return CONGA_ERR_INVALID;
 	if (!ctx->computed)
 		return fail(ctx, CONGA_ERR_INVALID, "conga_chrom_fetch: nothing computed");
+	HostSlot *h = current(ctx);
+	if (!h)
+		return fail(ctx, CONGA_ERR_INVALID, "conga_chrom_fetch: no chromosome selected");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	HIP_TRY(ctx, hipEventSynchronize(ctx->ev_done));
-	const SmallBlock &sb = *ctx->h_small;
+	const Small &sb = ctx->h_small[ctx->cur];
 	if (sb.status & kStatusUnsorted)
 		return fail(ctx, CONGA_ERR_UNSORTED,
 				"reads were committed out of position order; pass CONGA_FLAG_READS_UNSORTED to accept that");
-	const size_t nd = ctx->iv_start[0].size(), nu = ctx->iv_start[1].size();
+	const size_t nd = h->iv_start[0].size(), nu = h->iv_start[1].size();
 	if ((nd && !dels) || (nu && !dups))
 		return fail(ctx, CONGA_ERR_INVALID, "conga_chrom_fetch: result array missing");
 	if (nd)
-		memcpy(dels, ctx->h_results, nd * sizeof(conga_result));
+		memcpy(dels, ctx->h_results + h->iv0, nd * sizeof(conga_result));
 	if (nu)
-		memcpy(dups, ctx->h_results + nd, nu * sizeof(conga_result));
+		memcpy(dups, ctx->h_results + h->iv0 + nd, nu * sizeof(conga_result));
 	if (expected_rd)
 		memcpy(expected_rd, sb.E, kGcBins * sizeof(float));
 	if (stats) {
 		memset(stats, 0, sizeof *stats);
-		stats->reads_committed = ctx->n_reads;
+		stats->reads_committed = h->n_reads;
 		stats->reads_counted = (int64_t) sb.counters[CNT_COUNTED];
 		stats->reads_out_of_range = (int64_t) sb.counters[CNT_OUT_OF_RANGE];
 		long long total = 0;
@@ -821,7 +968,7 @@ int conga_chrom_fetch(conga_ctx *ctx, conga_result *dels, conga_result *dups, fl
 			total += (long long) sb.hist_sum[g];
 		}
 		stats->rd_sum = total;
-		stats->mean = (float) ((double) total / (double) ctx->L); // read_distribution.c:39
+		stats->mean = (float) ((double) total / (double) h->L); // read_distribution.c:39
 		stats->n_kernels = CONGA_K_COUNT;
 		if (ctx->opts.flags & CONGA_FLAG_PROFILE) {
 			for (int k = 0; k < CONGA_K_COUNT; k++) {
@@ -843,17 +990,15 @@ int conga_chrom_finish(conga_ctx *ctx, conga_result *dels, conga_result *dups, f
 	return conga_chrom_fetch(ctx, dels, dups, expected_rd, stats);
 }
 
-int conga_results_device(conga_ctx *ctx, void **dev_ptr, size_t *n_dels, size_t *n_dups)
+int conga_results_device(conga_ctx *ctx, void **dev_ptr, size_t *n_records)
 {
 	if (!ctx || !dev_ptr)
 		return CONGA_ERR_INVALID;
 	if (!ctx->computed)
 		return fail(ctx, CONGA_ERR_INVALID, "conga_results_device: nothing computed");
 	*dev_ptr = ctx->n_iv ? ctx->d_results.p : nullptr;
-	if (n_dels)
-		*n_dels = ctx->iv_start[0].size();
-	if (n_dups)
-		*n_dups = ctx->iv_start[1].size();
+	if (n_records)
+		*n_records = (size_t) ctx->n_iv;
 	return CONGA_OK;
 }
 
@@ -899,20 +1044,23 @@ int conga_sync(conga_ctx *ctx)
 
 int conga_copy_read_depth(conga_ctx *ctx, int16_t *out, int64_t n)
 {
-	if (!ctx || !out || !ctx->computed || n > ctx->L || n < 0)
+	HostSlot *h = ctx ? current(ctx) : nullptr;
+	if (!ctx || !out || !ctx->computed || !h || n > h->L || n < 0)
 		return CONGA_ERR_INVALID;
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
-	HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_rd.p, (size_t) n * 2, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(out, ptr<int16_t>(ctx->d_rd) + h->rd_off, (size_t) n * 2, hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	return CONGA_OK;
 }
 
 int conga_copy_mappability(conga_ctx *ctx, float *out, int64_t n)
 {
-	if (!ctx || !out || !ctx->computed || !ctx->has_map || ctx->n_iv == 0 || n > ctx->L || n < 0)
+	HostSlot *h = ctx ? current(ctx) : nullptr;
+	if (!ctx || !out || !ctx->computed || !h || !h->has_map || h->iv_start[0].size() + h->iv_start[1].size() == 0
+			|| n > h->L || n < 0)
 		return CONGA_ERR_INVALID;
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
-	HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_map.p, (size_t) n * 4, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(out, ptr<float>(ctx->d_map) + h->rd_off, (size_t) n * 4, hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	return CONGA_OK;
 }

@@ -1,12 +1,16 @@
 // kernels.hip.h -- gfx950 (CDNA4, wave64) kernels of the read-depth / likelihood path.
 //
 // All kernels are HBM-bound integer/byte work or short scalar chains; none is a contraction, so no
-// MFMA is used.  Layout in HBM per chromosome:
-//   pos   int32[N], mapq uint8[N]   read tuples in BAM order (sorted by pos)
-//   rd    int16[L]                  bam_info.read_depth          (common.h:91)
-//   map   float[L]                  bam_info.mappability         (common.h:92)
-//   gc_*  uint8[n_win]              rounded GC% per `step`-base window
-//   E     float[101]                bam_info.expected_read_depth (common.h:94)
+// MFMA is used.  Every kernel works on a BATCH of chromosomes ("slots") in one launch: a whole
+// sample is a handful of launches, not a handful per chromosome.
+//
+// Layout in HBM; every per-chromosome array is a region of one concatenated buffer,
+// located through the Slot table:
+//   pos   int32[N], mapq uint8[N]   read tuples in BAM order (sorted by pos inside a slot)
+//   rd    int16[sum L]              bam_info.read_depth          (common.h:91)
+//   map   float[sum L]              bam_info.mappability         (common.h:92)
+//   gc_*  uint8[sum n_win]          rounded GC% per `step`-base window
+//   small Small[n_slots]            status, counters, GC histogram, expected_read_depth[101]
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -19,14 +23,35 @@ namespace conga {
 constexpr int kWave = 64;
 constexpr int kGcBins = 101; // read_distribution.c:51-52
 
-// device status word bits
-constexpr uint32_t kStatusUnsorted = 1u;
-
-// device counters (uint64 each)
+constexpr uint32_t kStatusUnsorted = 1u; // Small.status bits
 enum { CNT_COUNTED = 0, CNT_OUT_OF_RANGE, CNT_N };
 
+// One chromosome of the batch.  Offsets are in elements of the respective concatenated buffer.
+struct Slot {
+	int64_t L;        // chromosome length (sonic->chromosome_lengths[chr_index])
+	int64_t rd_off;   // first element in rd / map (multiple of 8)
+	int64_t read_off; // first tuple in pos / mapq
+	int64_t n_reads;
+	int64_t gc_off;   // first byte in gc_hist / gc_like (multiple of 16)
+	int64_t n_win;
+	int64_t tile0;    // first global depth tile
+	int64_t n_tiles;
+	int64_t tidx_off; // first entry in tile_start (n_tiles + 1 entries per slot)
+};
+
+// Small per-chromosome block, read back after every compute.
+struct Small {
+	uint32_t status;
+	uint32_t pad;
+	unsigned long long counters[CNT_N];
+	unsigned long long hist_sum[kGcBins];   // rd_per_gc_unfiltered (read_distribution.c:52)
+	unsigned long long hist_bases[kGcBins]; // window_per_gc (read_distribution.c:51)
+	float E[kGcBins];                       // expected_read_depth (common.h:94)
+	float pad2;
+};
+
 // -------------------------------------------------------------------------------------------
-// wave64 reductions (DPP-backed shuffles)
+// wave64 helpers (DPP-backed shuffles)
 // -------------------------------------------------------------------------------------------
 __device__ __forceinline__ int wave_sum_i32(int v)
 {
@@ -44,50 +69,64 @@ __device__ __forceinline__ double wave_sum_f64(double v)
 	return v;
 }
 
+// last slot whose first key is <= x; keys are non-decreasing
+template <typename KeyOf> __device__ __forceinline__ int find_slot(int n_slots, int64_t x, KeyOf key)
+{
+	int lo = 0, hi = n_slots; // invariant: key(lo) <= x < key(hi)
+	while (hi - lo > 1) {
+		const int mid = (lo + hi) >> 1;
+		if (key(mid) <= x)
+			lo = mid;
+		else
+			hi = mid;
+	}
+	return lo;
+}
+
 // -------------------------------------------------------------------------------------------
-// K0 ingest: one pass over the read tuples of a chromosome.
-//   * flags tuples that break the position order (the tile index below needs sorted input,
-//     which is what sam_itr_next over an indexed BAM yields: bam_data.c:201,293);
+// K0 ingest: one pass over every read tuple of the batch.
+//   * flags tuples that break the position order inside a chromosome (the tile index below needs
+//     sorted input, which is what sam_itr_next over an indexed BAM yields: bam_data.c:201,293);
 //   * counts tuples outside [0, L) (the reference would write out of bounds: bam_data.c:213);
-//   * builds tile_start[t] = index of the first tuple whose position falls in depth tile t or
+//   * builds tile_start[t] = local index of the first tuple whose position falls in depth tile t or
 //     later, so the depth kernel needs no search.  Entries past the last tuple's tile keep the
-//     memset value 0xFFFFFFFF (= "n").
+//     memset value 0xFFFFFFFF (= "n_reads").
 // -------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ingest_kernel(const int32_t *__restrict__ pos, int64_t n, int64_t L,
-		int32_t tile_len, int64_t n_tiles, uint32_t *__restrict__ tile_start, uint32_t *__restrict__ status,
-		unsigned long long *__restrict__ counters)
+__global__ __launch_bounds__(256) void ingest_kernel(const int32_t *__restrict__ pos, int64_t n_total,
+		const Slot *__restrict__ slots, int n_slots, int32_t tile_len, uint32_t *__restrict__ tile_start,
+		Small *__restrict__ small)
 {
 	const int64_t stride = (int64_t) gridDim.x * blockDim.x;
-	unsigned long long oor = 0;
-	for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+	int s = 0;
+	for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_total; i += stride) {
+		if (i < slots[s].read_off || i >= slots[s].read_off + slots[s].n_reads)
+			s = find_slot(n_slots, i, [&](int k) { return slots[k].read_off; });
+		const Slot sl = slots[s];
+		const int64_t li = i - sl.read_off;
 		const int32_t p = pos[i];
-		const int32_t prev = (i > 0) ? pos[i - 1] : INT32_MIN;
+		const int32_t prev = (li > 0) ? pos[i - 1] : INT32_MIN;
 		if (p < prev)
-			atomicOr(status, kStatusUnsorted);
+			atomicOr(&small[s].status, kStatusUnsorted);
 		int64_t t_cur, t_prev;
 		if (p < 0) {
 			t_cur = 0;
-			oor++;
-		} else if (p >= L) {
-			t_cur = n_tiles;
-			oor++;
+			atomicAdd(&small[s].counters[CNT_OUT_OF_RANGE], 1ull);
+		} else if (p >= sl.L) {
+			t_cur = sl.n_tiles;
+			atomicAdd(&small[s].counters[CNT_OUT_OF_RANGE], 1ull);
 		} else
-			t_cur = p / tile_len;
-		if (i == 0)
+			t_cur = (uint32_t) p / (uint32_t) tile_len;
+		if (li == 0)
 			t_prev = -1;
 		else if (prev < 0)
 			t_prev = 0;
-		else if (prev >= L)
-			t_prev = n_tiles;
+		else if (prev >= sl.L)
+			t_prev = sl.n_tiles;
 		else
-			t_prev = prev / tile_len;
+			t_prev = (uint32_t) prev / (uint32_t) tile_len;
 		for (int64_t t = t_prev + 1; t <= t_cur; t++)
-			tile_start[t] = (uint32_t) i;
+			tile_start[sl.tidx_off + t] = (uint32_t) li;
 	}
-	// one atomic per wave
-	int w = wave_sum_i32((int) oor);
-	if ((threadIdx.x & (kWave - 1)) == 0 && w)
-		atomicAdd(&counters[CNT_OUT_OF_RANGE], (unsigned long long) w);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -95,105 +134,144 @@ __global__ __launch_bounds__(256) void ingest_kernel(const int32_t *__restrict__
 //
 // Replaces init_rd_per_chr's memset (read_distribution.c:16-17), the increments of
 // count_reads_bam (bam_data.c:205-215) and both loops of calc_mean_per_chr
-// (read_distribution.c:33-37,63-73).  Each workgroup owns tiles of tile_win * step positions:
-// it zeroes 32-bit counters in LDS, adds the tile's tuples with LDS atomics, then streams the
-// tile out ONCE as int16 with 16-byte stores (so read_depth is written exactly once and never
-// read back for the histogram), accumulating per-window sums -> a 101-bin {sum, bases} histogram
-// kept in LDS across all of the workgroup's tiles and flushed with one global atomic per bin.
-// All accumulators are integers, so the result does not depend on the order of the atomics.
+// (read_distribution.c:33-37,63-73).  A workgroup owns a contiguous run of tiles of
+// tile_win * step positions.  Per tile it zeroes 16-bit counters in LDS (two per dword -- the
+// layout of the int16 output), adds the tile's tuples with LDS atomics, then streams the tile out
+// ONCE with one ds_read_b128 + one 16-byte global store per lane (read_depth is written exactly
+// once and never read back for the histogram).  Per-window sums feed a 101-bin {sum, bases}
+// histogram kept in LDS across the workgroup's tiles and flushed with one global atomic per
+// non-empty bin when the workgroup moves to another chromosome.  All accumulators are integers,
+// so the result does not depend on the order of the atomics.
+// `short` semantics: a counter wraps modulo 2^16 exactly like read_depth[pos]++ on a short
+// (gcc); the carry of a wrapping low half into its neighbour is undone on the spot.
 // -------------------------------------------------------------------------------------------
 constexpr int kDepthBlock = 256;
-constexpr int kDepthMaxTile = 8192; // positions per tile (32 KiB of LDS counters)
+constexpr int kDepthMaxTile = 8192; // positions per tile (16 KiB of packed LDS counters)
+constexpr int kDepthMaxWin = 256;   // GC windows per tile (LDS window sums); 18.3 KiB LDS -> 8 workgroups per CU
 
 struct DepthArgs {
 	const int32_t *pos;
 	const uint8_t *mapq;
-	int64_t n;
 	const uint32_t *tile_start;
 	int16_t *rd;
-	int64_t L;
 	const uint8_t *gc_hist;
-	int64_t n_win;
+	const Slot *slots;
+	Small *small;
+	int32_t n_slots;
 	int32_t step;
 	int32_t tile_win;
 	int32_t mq_threshold;
-	int64_t n_tiles;
-	unsigned long long *hist_sum;   // [101]
-	unsigned long long *hist_bases; // [101]
-	unsigned long long *counters;
-	const uint32_t *status;
+	int64_t total_tiles;
+	int64_t tiles_per_block;
 };
+
+__device__ __forceinline__ void depth_flush_hist(Small *sm, unsigned long long *h_sum, unsigned int *h_bases,
+		int tid)
+{
+	for (int g = tid; g < kGcBins; g += kDepthBlock) {
+		if (h_sum[g])
+			atomicAdd(&sm->hist_sum[g], h_sum[g]);
+		if (h_bases[g])
+			atomicAdd(&sm->hist_bases[g], (unsigned long long) h_bases[g]);
+		h_sum[g] = 0;
+		h_bases[g] = 0;
+	}
+}
 
 __global__ __launch_bounds__(kDepthBlock) void depth_tile_kernel(DepthArgs a)
 {
-	__shared__ int32_t cnt[kDepthMaxTile];
-	__shared__ int32_t wsum[kDepthMaxTile / 8 + 8];
+	__shared__ __attribute__((aligned(16))) uint32_t cnt2[kDepthMaxTile / 2];
+	__shared__ int32_t wsum[kDepthMaxWin + 8];
 	__shared__ unsigned long long h_sum[kGcBins];
 	__shared__ unsigned int h_bases[kGcBins];
 
-	if (*a.status & kStatusUnsorted)
-		return; // tile index is meaningless; the host reports CONGA_ERR_UNSORTED
-
 	const int tid = threadIdx.x;
 	const int T = a.tile_win * a.step;
+	const int64_t g_begin = (int64_t) blockIdx.x * a.tiles_per_block;
+	const int64_t g_end = (g_begin + a.tiles_per_block < a.total_tiles) ? g_begin + a.tiles_per_block : a.total_tiles;
+	if (g_begin >= g_end)
+		return;
+
 	for (int g = tid; g < kGcBins; g += kDepthBlock) {
 		h_sum[g] = 0;
 		h_bases[g] = 0;
 	}
+	int s = find_slot(a.n_slots, g_begin, [&](int k) { return a.slots[k].tile0; });
+	Slot sl = a.slots[s];
 	unsigned int counted = 0;
 
-	for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+	for (int64_t gt = g_begin; gt < g_end; gt++) {
+		if (gt >= sl.tile0 + sl.n_tiles) {
+			// next chromosome: hand this one's partial histogram and read count over
+			__syncthreads();
+			depth_flush_hist(&a.small[s], h_sum, h_bases, tid);
+			int w = wave_sum_i32((int) counted);
+			if ((tid & (kWave - 1)) == 0 && w)
+				atomicAdd(&a.small[s].counters[CNT_COUNTED], (unsigned long long) w);
+			counted = 0;
+			while (gt >= a.slots[s].tile0 + a.slots[s].n_tiles)
+				s++;
+			sl = a.slots[s];
+		}
+		const int64_t tile = gt - sl.tile0;
 		const int64_t base = tile * T;
-		const int len = (int) ((a.L - base < T) ? (a.L - base) : T);
+		const int len = (int) ((sl.L - base < T) ? (sl.L - base) : T);
+		const bool skip = (a.small[s].status & kStatusUnsorted) != 0; // tile index is meaningless
 
-		for (int j = tid; j < T; j += kDepthBlock)
-			cnt[j] = 0;
+		for (int j = tid * 4; j < T / 2; j += kDepthBlock * 4)
+			*reinterpret_cast<uint4 *>(&cnt2[j]) = make_uint4(0, 0, 0, 0);
 		for (int j = tid; j < a.tile_win; j += kDepthBlock)
 			wsum[j] = 0;
 		__syncthreads();
 
-		const uint32_t lo = a.tile_start[tile];
-		uint32_t hi = a.tile_start[tile + 1];
-		if (lo != 0xFFFFFFFFu) {
+		const uint32_t lo = a.tile_start[sl.tidx_off + tile];
+		uint32_t hi = a.tile_start[sl.tidx_off + tile + 1];
+		if (lo != 0xFFFFFFFFu && !skip) {
 			if (hi == 0xFFFFFFFFu)
-				hi = (uint32_t) a.n;
+				hi = (uint32_t) sl.n_reads;
+			const int32_t *tp = a.pos + sl.read_off;
+			const uint8_t *tq = a.mapq + sl.read_off;
 			for (uint32_t i = lo + tid; i < hi; i += kDepthBlock) {
-				const int64_t p = (int64_t) a.pos[i] - base;
-				if (p >= 0 && p < len && (int) a.mapq[i] > a.mq_threshold) {
-					atomicAdd(&cnt[p], 1);
+				const int64_t p = (int64_t) tp[i] - base;
+				if (p >= 0 && p < len && (int) tq[i] > a.mq_threshold) {
+					if (p & 1)
+						atomicAdd(&cnt2[p >> 1], 0x10000u);
+					else {
+						const uint32_t old = atomicAdd(&cnt2[p >> 1], 1u);
+						if ((old & 0xFFFFu) == 0xFFFFu)
+							atomicSub(&cnt2[p >> 1], 0x10000u); // the low short wrapped: undo its carry
+					}
 					counted++;
 				}
 			}
 		}
 		__syncthreads();
 
-		// stream the tile out: 8 positions (16 bytes) per lane per step
+		// stream the tile out: 8 positions (16 bytes) per lane per step; the slot's region is padded to
+		// a multiple of 8 elements and positions >= len hold zeros, so the last store may run over len
+		int16_t *out = a.rd + sl.rd_off + base;
 		for (int j = tid * 8; j < len; j += kDepthBlock * 8) {
-			int16_t v[8];
-			int w = j / a.step;
-			int r = j - w * a.step;
-			int acc = 0;
+			const uint4 q = *reinterpret_cast<const uint4 *>(&cnt2[j >> 1]);
+			*reinterpret_cast<uint4 *>(out + j) = q;
+			if ((q.x | q.y | q.z | q.w) != 0u) { // sparse: most 8-base groups hold no read start
+				const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+				int w = j / a.step;
+				int r = j - w * a.step;
+				int acc = 0;
 #pragma unroll
-			for (int e = 0; e < 8; e++) {
-				// `short` wrap of read_depth[pos]++ (two's complement, as gcc does)
-				const int16_t s16 = (j + e < len) ? (int16_t) cnt[j + e] : (int16_t) 0;
-				v[e] = s16;
-				acc += (int) s16;
-				if (++r == a.step) {
-					if (acc)
-						atomicAdd(&wsum[w], acc);
-					acc = 0;
-					r = 0;
-					w++;
+				for (int e = 0; e < 8; e++) {
+					const uint32_t half = (e & 1) ? (wd[e >> 1] >> 16) : (wd[e >> 1] & 0xFFFFu);
+					acc += (int) (int16_t) half;
+					if (++r == a.step) {
+						if (acc)
+							atomicAdd(&wsum[w], acc);
+						acc = 0;
+						r = 0;
+						w++;
+					}
 				}
-			}
-			if (acc)
-				atomicAdd(&wsum[w], acc);
-			if (j + 8 <= len) {
-				*reinterpret_cast<uint4 *>(a.rd + base + j) = *reinterpret_cast<const uint4 *>(v);
-			} else {
-				for (int e = 0; j + e < len; e++)
-					a.rd[base + j + e] = v[e];
+				if (acc)
+					atomicAdd(&wsum[w], acc);
 			}
 		}
 		__syncthreads();
@@ -203,33 +281,29 @@ __global__ __launch_bounds__(kDepthBlock) void depth_tile_kernel(DepthArgs a)
 		const int64_t w0 = tile * a.tile_win;
 		for (int w = tid; w < nw; w += kDepthBlock) {
 			int64_t wg = w0 + w;
-			if (wg >= a.n_win)
-				wg = a.n_win - 1;
-			const int g = a.gc_hist[wg];
+			if (wg >= sl.n_win)
+				wg = sl.n_win - 1;
+			const int g = a.gc_hist[sl.gc_off + wg];
 			const int nb = (len - w * a.step < a.step) ? (len - w * a.step) : a.step;
 			if (g < kGcBins) {
-				const int s = wsum[w];
-				if (s)
-					atomicAdd(&h_sum[g], (unsigned long long) (long long) s);
+				const int sw = wsum[w];
+				if (sw)
+					atomicAdd(&h_sum[g], (unsigned long long) (long long) sw);
 				atomicAdd(&h_bases[g], (unsigned int) nb);
 			}
 		}
+		// the next tile's zeroing of cnt2 / wsum is fenced by the barrier that follows it
 		__syncthreads();
 	}
 
-	for (int g = tid; g < kGcBins; g += kDepthBlock) {
-		if (h_sum[g])
-			atomicAdd(&a.hist_sum[g], h_sum[g]);
-		if (h_bases[g])
-			atomicAdd(&a.hist_bases[g], (unsigned long long) h_bases[g]);
-	}
+	depth_flush_hist(&a.small[s], h_sum, h_bases, tid);
 	int w = wave_sum_i32((int) counted);
 	if ((tid & (kWave - 1)) == 0 && w)
-		atomicAdd(&a.counters[CNT_COUNTED], (unsigned long long) w);
+		atomicAdd(&a.small[s].counters[CNT_COUNTED], (unsigned long long) w);
 }
 
 // Depth for unsorted input (CONGA_FLAG_READS_UNSORTED): read_depth is zeroed by hipMemsetAsync and
-// incremented with global atomics on the containing 32-bit word.
+// incremented with global atomics on the containing 32-bit word.  One launch per chromosome.
 __global__ __launch_bounds__(256) void depth_atomic_kernel(const int32_t *__restrict__ pos,
 		const uint8_t *__restrict__ mapq, int64_t n, int64_t L, int32_t mq_threshold, int16_t *rd,
 		unsigned long long *counters)
@@ -238,10 +312,13 @@ __global__ __launch_bounds__(256) void depth_atomic_kernel(const int32_t *__rest
 	unsigned int counted = 0;
 	for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
 		const int64_t p = pos[i];
-		if (p < 0 || p >= L || (int) mapq[i] <= mq_threshold)
+		if (p < 0 || p >= L) {
+			atomicAdd(&counters[CNT_OUT_OF_RANGE], 1ull);
+			continue;
+		}
+		if ((int) mapq[i] <= mq_threshold)
 			continue;
 		unsigned int *word = reinterpret_cast<unsigned int *>(rd) + (p >> 1);
-		// carry out of the low half would corrupt the high half: split the add when it wraps
 		if (p & 1)
 			atomicAdd(word, 0x10000u);
 		else {
@@ -293,36 +370,37 @@ __global__ __launch_bounds__(256) void gc_hist_kernel(const int16_t *__restrict_
 }
 
 // -------------------------------------------------------------------------------------------
-// K2b expected_table: expected_read_depth[g] = (float) rd_per_gc[g] / window_per_gc[g]
-// (read_distribution.c:75-83): float(long) / float(int) in single precision, [0] forced to 0,
-// NaN / +-inf -> 0.  Integer -> float goes through double (exact below 2^53, then one rounding),
-// which equals the correctly rounded direct conversion.
+// K2b expected_table (one workgroup per chromosome):
+// expected_read_depth[g] = (float) rd_per_gc[g] / window_per_gc[g] (read_distribution.c:75-83):
+// float(long) / float(int) in single precision, [0] forced to 0, NaN / +-inf -> 0.  Integer ->
+// float goes through double (exact below 2^53, then one rounding), which equals the correctly
+// rounded direct conversion.
 // -------------------------------------------------------------------------------------------
-__global__ void expected_table_kernel(const unsigned long long *__restrict__ hist_sum,
-		const unsigned long long *__restrict__ hist_bases, float *__restrict__ E)
+__global__ void expected_table_kernel(Small *__restrict__ small)
 {
+	Small &sm = small[blockIdx.x];
 	const int g = threadIdx.x;
 	if (g >= kGcBins)
 		return;
 	float e = 0.0f;
 	if (g > 0) {
-		const float num = (float) (double) (long long) hist_sum[g];
-		const float den = (float) (double) (int) hist_bases[g];
+		const float num = (float) (double) (long long) sm.hist_sum[g];
+		const float den = (float) (double) (int) sm.hist_bases[g];
 		e = num / den;
 		if (isnan(e) || isinf(e))
 			e = 0.0f;
 	}
-	E[g] = e;
+	sm.E[g] = e;
 }
 
 // -------------------------------------------------------------------------------------------
-// K3 mappability paint.  Semantics (svs.c:363-371): rows in file order, END INCLUSIVE,
-// a later row overwrites an earlier one.
+// K3 mappability paint (one launch per chromosome that has a track).  Semantics
+// (svs.c:363-371): rows in file order, END INCLUSIVE, a later row overwrites an earlier one.
 //
 // paint_sorted_kernel: rows sorted by start with row k+1 starting at or after row k's end (the
 // bedGraph-like layout of README.md:77-88; abutting rows share one base, which the later row
-// wins).  Each workgroup owns a tile of bases; a base x is covered by the LAST row with
-// start <= x, if that row's end >= x.  One pass, every float written exactly once, no memset.
+// wins).  A base x is covered by the LAST row with start <= x, if that row's end >= x.  One pass,
+// every float written exactly once, no memset.
 // paint_winner_kernel / paint_resolve_kernel: any row order -- atomicMax of the row index per
 // base, then map[i] = val[winner[i]].
 // -------------------------------------------------------------------------------------------
@@ -346,19 +424,26 @@ __global__ __launch_bounds__(256) void paint_sorted_kernel(const int32_t *__rest
 				hi = mid;
 		}
 		int64_t k = lo - 1;
-		float out[kPerThread];
-#pragma unroll
-		for (int e = 0; e < kPerThread; e++) {
-			const int64_t x = x0 + e;
-			while (k + 1 < m && (int64_t) start[k + 1] <= x)
-				k++;
-			out[e] = (k >= 0 && (int64_t) end[k] >= x) ? val[k] : 0.0f;
-		}
+		float o0, o1, o2, o3;
+#define CONGA_PAINT_ONE(e, dst)                                         \
+	{                                                                   \
+		const int64_t x = x0 + (e);                                     \
+		while (k + 1 < m && (int64_t) start[k + 1] <= x)                \
+			k++;                                                        \
+		dst = (k >= 0 && (int64_t) end[k] >= x) ? val[k] : 0.0f;        \
+	}
+		CONGA_PAINT_ONE(0, o0)
+		CONGA_PAINT_ONE(1, o1)
+		CONGA_PAINT_ONE(2, o2)
+		CONGA_PAINT_ONE(3, o3)
+#undef CONGA_PAINT_ONE
 		if (x0 + kPerThread <= L)
-			*reinterpret_cast<float4 *>(map + x0) = *reinterpret_cast<const float4 *>(out);
-		else
+			*reinterpret_cast<float4 *>(map + x0) = make_float4(o0, o1, o2, o3);
+		else {
+			const float o[4] = {o0, o1, o2, o3};
 			for (int e = 0; x0 + e < L; e++)
-				map[x0 + e] = out[e];
+				map[x0 + e] = o[e];
+		}
 	}
 }
 
@@ -406,10 +491,11 @@ constexpr int kItemLen = 16384;
 
 struct ReduceArgs {
 	const int16_t *rd;
-	const float *map; // may be null
+	const float *map; // concatenated like rd; only read for items whose slot has a track
+	const int64_t *item_off;   // global element offset of the item's first base
+	const int32_t *item_len;
 	const int32_t *item_iv;
-	const int32_t *item_start;
-	const int32_t *item_end;
+	const uint8_t *item_has_map;
 	int64_t n_items;
 	int32_t *observed;  // [n_iv], zeroed before launch
 	double *map_part;   // [n_items]
@@ -420,8 +506,8 @@ __global__ __launch_bounds__(256) void interval_reduce_kernel(ReduceArgs a)
 	const int lane = threadIdx.x & (kWave - 1);
 	const int64_t item = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) / kWave;
 	if (item >= a.n_items)
-		return;
-	const int64_t s = a.item_start[item], e = a.item_end[item];
+		return; // wave-uniform
+	const int64_t s = a.item_off[item], e = s + a.item_len[item];
 
 	// ---- depth: int16, 8 per lane
 	int acc = 0;
@@ -449,7 +535,7 @@ __global__ __launch_bounds__(256) void interval_reduce_kernel(ReduceArgs a)
 		atomicAdd(&a.observed[a.item_iv[item]], acc);
 
 	// ---- mappability: float, 4 per lane, summed in double
-	if (a.map) {
+	if (a.item_has_map[item]) {
 		double m = 0.0;
 		int64_t head = (s + 3) & ~(int64_t) 3;
 		if (head > e)
@@ -473,45 +559,41 @@ __global__ __launch_bounds__(256) void interval_reduce_kernel(ReduceArgs a)
 }
 
 // -------------------------------------------------------------------------------------------
-// K4 (chain) + K5 interval_score: the serial float32 expected_rd accumulation
-// (likelihood.c:111,115-119), then lpoisson x3, the int-truncated max, the c-score and the CN
-// call (likelihood.c:96-105,131-168).
+// K4 (chain) interval_chain<G>: the serial float32 accumulation `expected_rd += E[gc]`
+// (likelihood.c:111,115-119), bit-exact, G lanes per interval (G = 64: one wave per long interval;
+// G = 16: four short intervals per wave).
 //
-// One lane per interval; lanes are handed intervals in descending window count (order[]) so the
-// lanes of a wave finish together.  Each GC window contributes k equal float adds which
-// conga_repeat_add_f32 collapses exactly (serial_f32.h); windows are walked left to right, so
-// the rounding sequence is the reference's.
+// Inside one binade of the accumulator every GC window advances the mantissa by k * delta ulps
+// (conga_step_for, serial_f32.h), an INTEGER, so the G per-window advances are combined with a
+// prefix sum over the lane group.  A window is "regular" when its whole run of k adds stays below
+// the binade top and is not an exact tie; the first irregular window of the group (ballot + ffs)
+// is applied with the scalar routine conga_repeat_add_f32 -- which performs the real rounding --
+// and the scan restarts behind it.  Irregular windows are rare (one per binade crossing, i.e.
+// O(log) per interval), so a 5 Mb interval costs ~800 group steps instead of 50,000 dependent
+// window updates.  Windows are consumed left to right, so the rounding sequence is the reference's.
 // -------------------------------------------------------------------------------------------
-// Long intervals: one wave walks one interval, 64 GC windows per step.
-//
-// Inside one binade of the accumulator every window advances the mantissa by k * delta ulps
-// (conga_step_for), an INTEGER, so the 64 per-window advances are combined with a wave prefix sum.
-// A window is "regular" when its whole run of k adds stays below the binade top and is not an
-// exact tie; the first irregular window (ballot + ffs) is applied with the scalar routine
-// conga_repeat_add_f32 -- which performs the real rounding -- and the scan restarts behind it.
-// Irregular windows are rare (one per binade crossing, i.e. O(log) per interval), so a 5 Mb
-// interval costs ~800 wave steps instead of 50,000 dependent window updates on one lane.
-// The result is the same bit pattern as the per-base loop of likelihood.c:115-119.
-constexpr int kLongWindows = 192; // intervals with more GC windows than this take the wave path
+constexpr int kLongWindows = 192; // intervals with more GC windows than this get a whole wave
 
 struct ChainArgs {
 	const int32_t *start;
 	const int32_t *end;
-	const int32_t *order; // longest first; the first n_long entries are the long intervals
-	int64_t n_long;
+	const int32_t *iv_slot;
+	const int32_t *order; // interval ids, longest first
+	int64_t first;        // slots [first, first + count) of order[] belong to this launch
+	int64_t count;
 	const uint8_t *gc_like;
-	int64_t n_win;
+	const Slot *slots;
+	const Small *small;
 	int32_t step;
-	const float *E;
 	float *expected; // [n_iv]
 };
 
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
+template <int G> __device__ __forceinline__ uint32_t group_incl_scan_u32(uint32_t v, int gl)
 {
 #pragma unroll
-	for (int o = 1; o < kWave; o <<= 1) {
-		const uint32_t t = __shfl_up(v, o, kWave);
-		if (lane >= o)
+	for (int o = 1; o < G; o <<= 1) {
+		const uint32_t t = __shfl_up(v, o, G);
+		if (gl >= o)
 			v += t;
 	}
 	return v;
@@ -522,26 +604,39 @@ __device__ __forceinline__ float compose_f32(uint32_t es, uint32_t ms)
 	return (ms == 0x1000000u) ? conga_bits_f32((es + 1u) << 23) : conga_bits_f32((es << 23) | (ms & 0x7FFFFFu));
 }
 
-__global__ __launch_bounds__(256) void chain_long_kernel(ChainArgs a)
+template <int G> __global__ __launch_bounds__(256) void interval_chain_kernel(ChainArgs a)
 {
-	__shared__ float sE[kGcBins];
-	for (int g = threadIdx.x; g < kGcBins; g += blockDim.x)
-		sE[g] = a.E[g];
-	__syncthreads();
-
+	constexpr int kGroups = kWave / G;
 	const int lane = threadIdx.x & (kWave - 1);
-	const int64_t slot = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) / kWave;
-	if (slot >= a.n_long)
-		return; // wave-uniform
-	const int32_t iv = a.order[slot];
-	const int64_t s0 = a.start[iv], e0 = a.end[iv];
-	const int64_t step = a.step;
-	const int64_t w_first = s0 / step;
-	const int64_t w_end = (e0 - 1) / step + 1;
+	const int gl = lane & (G - 1);  // lane inside the group
+	const int grp = lane / G;       // group inside the wave
+	const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << (grp * G));
+	const int64_t wave = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+	const int64_t slot_idx = wave * kGroups + grp;
+	const bool have = slot_idx < a.count;
 
-	float s = 0.0f; // wave-uniform accumulator
-	for (int64_t wb = w_first; wb < w_end; wb += kWave) {
-		const int64_t w = wb + lane;
+	int32_t iv = 0;
+	int64_t s0 = 0, e0 = 0, w_first = 0, w_end = 0, gc_off = 0, n_win = 1;
+	const float *E = a.small[0].E;
+	if (have) {
+		iv = a.order[a.first + slot_idx];
+		s0 = a.start[iv];
+		e0 = a.end[iv];
+		const int sl = a.iv_slot[iv];
+		gc_off = a.slots[sl].gc_off;
+		n_win = a.slots[sl].n_win;
+		E = a.small[sl].E;
+		if (e0 > s0) {
+			w_first = (uint32_t) s0 / (uint32_t) a.step;
+			w_end = (uint32_t) (e0 - 1) / (uint32_t) a.step + 1;
+		}
+	}
+	const int64_t step = a.step;
+
+	float s = 0.0f; // uniform inside a group
+	int64_t wb = w_first;
+	while (__any(wb < w_end)) {
+		const int64_t w = wb + gl;
 		const bool active = w < w_end;
 		uint32_t k = 0, bc = 0;
 		float c = 0.0f;
@@ -549,12 +644,12 @@ __global__ __launch_bounds__(256) void chain_long_kernel(ChainArgs a)
 			const int64_t lo = (w * step > s0) ? w * step : s0;
 			const int64_t hi = ((w + 1) * step < e0) ? (w + 1) * step : e0;
 			k = (uint32_t) (hi - lo);
-			const uint32_t g = a.gc_like[(w < a.n_win) ? w : a.n_win - 1];
-			c = (g < (uint32_t) kGcBins) ? sE[g] : 0.0f;
+			const uint32_t g = a.gc_like[gc_off + ((w < n_win) ? w : n_win - 1)];
+			c = (g < (uint32_t) kGcBins) ? E[g] : 0.0f; // 404-byte table: L1/L2 resident
 			bc = conga_f32_bits(c);
 		}
-		unsigned long long todo = __ballot(active);
-		while (todo) {
+		unsigned long long todo = __ballot(active) & gmask; // this group's windows still to apply
+		while (__any(todo != 0ull)) {
 			const uint32_t bs = conga_f32_bits(s);
 			const uint32_t es = bs >> 23;
 			const uint32_t ms = (bs & 0x7FFFFFu) | 0x800000u;
@@ -566,51 +661,52 @@ __global__ __launch_bounds__(256) void chain_long_kernel(ChainArgs a)
 				const uint64_t a64 = (uint64_t) k * st.delta;
 				adv = (a64 > (1u << 25)) ? (1u << 25) : (uint32_t) a64;
 			}
-			const uint32_t incl = wave_incl_scan_u32(adv, lane);
+			const uint32_t incl = group_incl_scan_u32<G>(adv, gl);
 			const uint32_t pre = incl - adv;
 			const uint32_t m = ms + pre; // mantissa in front of this lane's window (< 2^32)
 			bool ok = true;
 			if (in)
 				ok = valid && (st.delta == 0 || (m <= st.lim && (uint64_t) (k - 1u) * st.delta <= (uint64_t) (st.lim - m)));
-			const unsigned long long bad = __ballot(!ok);
-			if (bad == 0) {
-				const uint32_t total = __shfl(incl, kWave - 1, kWave);
-				if (total)
-					s = compose_f32(es, ms + total);
-				todo = 0;
-			} else {
-				const int fb = __ffsll((long long) bad) - 1;
-				const uint32_t pre_fb = __shfl(pre, fb, kWave);
-				if (pre_fb)
-					s = compose_f32(es, ms + pre_fb); // exact state in front of the irregular window
-				const float c_fb = __shfl(c, fb, kWave);
-				const uint32_t k_fb = __shfl(k, fb, kWave);
-				s = conga_repeat_add_f32(s, c_fb, k_fb); // real adds where rounding is not a constant step
-				todo &= ~((2ull << fb) - 1ull);
+			const unsigned long long bad = __ballot(!ok) & gmask;
+			const uint32_t total = __shfl(incl, G - 1, G);
+			const int fb = bad ? (__ffsll((long long) bad) - 1 - grp * G) : 0;
+			const uint32_t pre_fb = __shfl(pre, fb, G);
+			const float c_fb = __shfl(c, fb, G);
+			const uint32_t k_fb = __shfl(k, fb, G);
+			if (todo != 0ull) {
+				if (bad == 0ull) {
+					if (total)
+						s = compose_f32(es, ms + total);
+					todo = 0ull;
+				} else {
+					if (pre_fb)
+						s = compose_f32(es, ms + pre_fb); // exact state in front of the irregular window
+					s = conga_repeat_add_f32(s, c_fb, k_fb); // real adds where rounding is not a constant step
+					todo &= ~(((2ull << (fb + grp * G)) - 1ull));
+				}
 			}
 		}
+		wb += G;
 	}
-	if (lane == 0)
+	if (have && gl == 0)
 		a.expected[iv] = s;
 }
 
+// -------------------------------------------------------------------------------------------
+// K5 interval_score: lpoisson x3, the int-truncated max, the c-score and the CN call
+// (likelihood.c:96-105,131-168).  One lane per interval.
+// -------------------------------------------------------------------------------------------
 struct ScoreArgs {
 	const int32_t *start;
 	const int32_t *end;
 	const uint8_t *type;     // 'D' / 'E' per interval
-	const int32_t *order;    // processing order (longest first)
 	int64_t n_iv;
-	const uint8_t *gc_like;
-	int64_t n_win;
-	int32_t step;
-	const float *E;
 	const int32_t *observed;
-	const double *map_part;  // may be null
+	const float *expected;
+	const double *map_part;
 	const int32_t *item_first; // [n_iv + 1] first work item of each interval
+	const uint8_t *iv_has_map;
 	const int32_t *support;  // split-read support per interval (may be null)
-	int32_t has_map;
-	int64_t n_long;          // slots below this were computed by chain_long_kernel
-	const float *expected_long; // [n_iv], valid for those slots
 	conga_result *out;
 };
 
@@ -629,9 +725,21 @@ __device__ __forceinline__ int trunc_max(double x, double y)
 	return (xi < yi) ? yi : xi;
 }
 
-__device__ __forceinline__ void score_interval(int observed, float expected, uint8_t type, conga_result &r)
+__global__ __launch_bounds__(256) void interval_score_kernel(ScoreArgs a)
 {
+	const int64_t iv = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (iv >= a.n_iv)
+		return;
+	const int observed = a.observed[iv];
+	const float expected = a.expected[iv];
+	const uint8_t type = a.type[iv];
 	const double ex = (double) expected;
+
+	conga_result r;
+	r.rp = 0;
+	r.border_rp = 0;
+	r.reserved = 0;
+	r.mappability = 0.0;
 	if (type == CONGA_DELETION) {
 		r.lhomo = lpoisson_dev(observed, 0.0);
 		r.lhetero = lpoisson_dev(observed, 0.5 * ex);
@@ -646,60 +754,11 @@ __device__ __forceinline__ void score_interval(int observed, float expected, uin
 	r.score = (double) trunc_max(r.lhomo, r.lhetero) / r.lnone; // likelihood.c:138,160
 	r.observed = observed;
 	r.expected = expected;
-}
-
-__global__ __launch_bounds__(256) void interval_score_kernel(ScoreArgs a)
-{
-	__shared__ float sE[kGcBins];
-	for (int g = threadIdx.x; g < kGcBins; g += blockDim.x)
-		sE[g] = a.E[g];
-	__syncthreads();
-
-	const int64_t slot = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-	if (slot >= a.n_iv)
-		return;
-	const int32_t iv = a.order[slot];
-	const int64_t s = a.start[iv], e = a.end[iv];
-
-	float ex = 0.0f;
-	if (slot < a.n_long) {
-		ex = a.expected_long[iv];
-	} else if (e > s) {
-		int64_t w = s / a.step;
-		int64_t pos = s;
-		const uint32_t *gc32 = reinterpret_cast<const uint32_t *>(a.gc_like);
-		const int64_t w_last = a.n_win - 1;
-		uint32_t word = 0;
-		int64_t word_idx = -1;
-		while (pos < e) {
-			int64_t next = (w + 1) * (int64_t) a.step;
-			if (next > e)
-				next = e;
-			const int64_t wc = (w < w_last) ? w : w_last; // window index clamped at the chromosome end
-			if ((wc >> 2) != word_idx) {
-				word_idx = wc >> 2;
-				word = gc32[word_idx]; // gc arrays are padded to a multiple of 4 bytes
-			}
-			const uint32_t g = (word >> (8 * (wc & 3))) & 0xFFu;
-			const float c = (g < kGcBins) ? sE[g] : 0.0f;
-			ex = conga_repeat_add_f32(ex, c, (uint32_t) (next - pos));
-			pos = next;
-			w++;
-		}
-	}
-
-	conga_result r;
-	r.rp = 0;
-	r.border_rp = 0;
-	r.reserved = 0;
-	r.mappability = 0.0;
-	const uint8_t type = a.type[iv];
-	score_interval(a.observed[iv], ex, type, r);
-	if (a.has_map) {
+	if (a.iv_has_map[iv]) {
 		double ms = 0.0;
 		for (int32_t it = a.item_first[iv]; it < a.item_first[iv + 1]; it++)
 			ms += a.map_part[it];
-		r.mappability = ms / (double) (e - s); // likelihood.c:128
+		r.mappability = ms / (double) ((int64_t) a.end[iv] - a.start[iv]); // likelihood.c:128
 	}
 	if (a.support) {
 		if (type == CONGA_DELETION)

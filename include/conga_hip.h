@@ -21,6 +21,15 @@
  * driven by one host thread at a time (the reference is single-threaded and keeps this state in
  * globals: likelihood.c:10-15).  There is no CPU fallback: without a usable HIP device
  * conga_create() fails.
+ *
+ * Two ways to drive it:
+ *   sequential (default)  begin / reads / intervals / finish per chromosome, exactly the order of
+ *                         the reference's loop (bam_data.c:269-339); each begin drops the previous
+ *                         chromosome.
+ *   batch (CONGA_FLAG_BATCH)  begin / reads / intervals for every chromosome of the sample, then ONE
+ *                         conga_chrom_compute() -- each kernel is launched once over the whole batch --
+ *                         then conga_chrom_select(i) + conga_chrom_fetch() per chromosome.  This is
+ *                         the form that fills an MI355X; results are identical.
  */
 #ifndef CONGA_HIP_H_
 #define CONGA_HIP_H_
@@ -49,6 +58,8 @@ typedef enum conga_status {
 /* conga_opts.flags */
 #define CONGA_FLAG_READS_UNSORTED 0x1u /* reads may arrive in any order: depth uses global atomics */
 #define CONGA_FLAG_PROFILE 0x2u        /* bracket every kernel with HIP events; conga_chrom_stats.kernel_ms is filled */
+#define CONGA_FLAG_BATCH 0x4u          /* conga_chrom_begin() ADDS a chromosome instead of replacing the previous one;
+                                          conga_chrom_compute() then covers all of them in one launch per kernel */
 
 /* SV types, as the reference's DELETION / DUPLICATION (common.h:12-13) */
 #define CONGA_DELETION 'D'
@@ -122,12 +133,21 @@ int conga_device_count(void);
 
 /* ---- one chromosome --------------------------------------------------------------------- */
 
+/* Batch mode: drop every chromosome held by the context (sequential mode does this in begin). */
+int conga_reset(conga_ctx *ctx);
+/* Number of chromosomes held, and which of them conga_mappability / conga_intervals /
+ * conga_split_support / conga_chrom_fetch / conga_copy_* refer to (default: the one begun last).
+ * Reads always stream into the chromosome begun last. */
+int conga_chrom_count(const conga_ctx *ctx);
+int conga_chrom_select(conga_ctx *ctx, int index);
+
 /* init_rd_per_chr + the GC side of calc_mean_per_chr / calculate_likelihood_CNV.
  * chrom_len = sonic->chromosome_lengths[chr_index].  gc_hist_w[w] is the rounded GC% (0..100) that
  * `sonic_get_gc_content(chr, i, min(i + step, L))` yields for bases i in window w (loop of
  * read_distribution.c:63-73); gc_like_w[w] the one `sonic_get_gc_content(chr, i, i + step)` yields
  * (likelihood.c:117).  They may be the same pointer.  n_win must be ceil(chrom_len / gc_step).
- * Resets all per-chromosome state (reads, intervals, mappability, split support). */
+ * The arrays are copied.  Sequential mode: resets all per-chromosome state (reads, intervals,
+ * mappability, split support).  Batch mode: opens one more chromosome and selects it. */
 int conga_chrom_begin(conga_ctx *ctx, int64_t chrom_len, const uint8_t *gc_hist_w, const uint8_t *gc_like_w,
 		int64_t n_win);
 
@@ -151,12 +171,12 @@ int conga_intervals(conga_ctx *ctx, char type, const int32_t *start, const int32
  * in the order of conga_intervals(); copied through to conga_result.rp (dups) / border_rp (dels). */
 int conga_split_support(conga_ctx *ctx, char type, const int32_t *support, size_t n);
 
-/* calc_mean_per_chr + find_depths: enqueue every kernel for this chromosome on the context's
- * stream and return without waiting.  May be called again on the same resident inputs
- * (it recomputes everything from the committed tuples). */
+/* calc_mean_per_chr + find_depths: enqueue every kernel for the chromosome (batch mode: for all
+ * chromosomes held) on the context's stream and return without waiting.  May be called again on
+ * the same resident inputs (it recomputes everything from the committed tuples). */
 int conga_chrom_compute(conga_ctx *ctx);
 
-/* Waits for the last conga_chrom_compute() and copies results out.  dels / dups receive one record
+/* Waits for the last conga_chrom_compute() and copies the selected chromosome's results out.  dels / dups receive one record
  * per interval in the order given to conga_intervals() (NULL allowed when that type has no
  * intervals); expected_rd receives bam_info.expected_read_depth; stats may be NULL. */
 int conga_chrom_fetch(conga_ctx *ctx, conga_result *dels, conga_result *dups, float expected_rd[101],
@@ -168,11 +188,12 @@ int conga_chrom_finish(conga_ctx *ctx, conga_result *dels, conga_result *dups, f
 
 /* ---- device-side access (multi-GPU gather, profiling, tests) ------------------------------ */
 
-/* Device pointer to the result records of the last compute: n_dels records then n_dups records,
- * valid until the next conga_chrom_begin().  Used to gather results over RCCL without a host hop. */
-int conga_results_device(conga_ctx *ctx, void **dev_ptr, size_t *n_dels, size_t *n_dups);
+/* Device pointer to the result records of the last compute: chromosomes in begin order, each with
+ * its deletions then its duplications; valid until the next conga_chrom_begin() / conga_reset().
+ * Used to gather results over RCCL without a host hop. */
+int conga_results_device(conga_ctx *ctx, void **dev_ptr, size_t *n_records);
 /* Enqueue a device-to-device copy of those records into dst_device (at least
- * (n_dels + n_dups) * sizeof(conga_result) bytes, e.g. a torch tensor's data_ptr) on the context's stream. */
+ * n_records * sizeof(conga_result) bytes, e.g. a torch tensor's data_ptr) on the context's stream. */
 int conga_results_copy(conga_ctx *ctx, void *dst_device, size_t dst_bytes);
 /* Turn per-kernel HIP-event timing (CONGA_FLAG_PROFILE) on or off for later computes. */
 int conga_set_profile(conga_ctx *ctx, int on);

@@ -362,3 +362,74 @@ def test_long_chains_random_tables(capi, oracle):
         want = run_oracle(oracle, c.length, c.gc, c.pos, c.mapq, ds, de, ds[::2], de[::2])
         got = run_gpu(capi, c.length, c.gc, c.pos, c.mapq, ds, de, ds[::2], de[::2], want_tracks=False)
         compare(got, want, False)
+
+
+def test_batch_mode_matches_per_chromosome_results(capi, oracle):
+    """CONGA_FLAG_BATCH: several chromosomes resident at once, every kernel launched once over the batch.
+    Mixed bag on purpose: with/without mappability, no intervals, no reads, a distinct likelihood GC array."""
+    specs = [("1", 900_000, dict(cov=1.0, n_dels=40, n_dups=10, mappability=True)),
+             ("2", 50_007, dict(cov=3.0, n_dels=6, n_dups=0, gaps=False)),
+             ("3", 2_500_000, dict(cov=8.0, n_dels=80, n_dups=30)),
+             ("4", 300_000, dict(cov=1.0, n_dels=0, n_dups=0, gaps=False)),
+             ("5", 400_000, dict(cov=1.0, n_dels=20, n_dups=5, gaps=False)),
+             ("6", 1_000_001, dict(cov=0.5, n_dels=30, n_dups=8, mappability=True))]
+    cases = []
+    with capi.Context(device=0, mq_threshold=5, flags=capi.FLAG_BATCH) as ctx:
+        for i, (name, length, kw) in enumerate(specs):
+            c, ds, de, us, ue = chrom_case(name, length, **kw)
+            pos, mapq = (c.pos[:0], c.mapq[:0]) if name == "5" else (c.pos, c.mapq)
+            gc_like = np.roll(c.gc, 3) if name == "3" else None
+            rows = (c.map_start, c.map_end, c.map_val) if c.map_start is not None else None
+            assert ctx.chrom_begin(c.length, c.gc, gc_like) == i
+            ctx.reads(pos, mapq)
+            cases.append((c, pos, mapq, ds, de, us, ue, rows, gc_like))
+        # intervals / tracks may be attached after all reads are in (chromosome selected by index)
+        for i, (c, pos, mapq, ds, de, us, ue, rows, gc_like) in enumerate(cases):
+            ctx.select(i)
+            if rows is not None:
+                ctx.mappability(*rows)
+            ctx.intervals("D", ds, de)
+            ctx.intervals("E", us, ue)
+        assert ctx.chrom_count() == len(specs)
+        ctx.compute()
+        ctx.compute()  # replay
+        for i, (c, pos, mapq, ds, de, us, ue, rows, gc_like) in enumerate(cases):
+            ctx.select(i)
+            dels, dups, E, st = ctx.fetch()
+            got = dict(dels=dels, dups=dups, E=E, counted=st.reads_counted, S=np.array(st.rd_per_gc[:]),
+                       W=np.array(st.window_per_gc[:]), rd=ctx.read_depth())
+            if rows is not None and len(ds) + len(us):
+                got["map"] = ctx.mappability_track()
+            want = run_oracle(oracle, c.length, c.gc, pos, mapq, ds, de, us, ue, mq=5, rows=rows, gc_like=gc_like)
+            compare(got, want, rows is not None)
+        # the packed device records are the per-chromosome records in begin order
+        ptr, n = ctx.results_device()
+        assert n == sum(len(x[3]) + len(x[5]) for x in cases) and ptr
+        ctx.reset()
+        assert ctx.chrom_count() == 0
+        c = cases[1][0]
+        ctx.chrom_begin(c.length, c.gc)
+        ctx.reads(cases[1][1], cases[1][2])
+        ctx.intervals("D", cases[1][3], cases[1][4])
+        dels = ctx.finish()[0]
+        want = run_oracle(oracle, c.length, c.gc, cases[1][1], cases[1][2], cases[1][3], cases[1][4],
+                          cases[1][5], cases[1][6], mq=5)
+        assert_records(dels, want["dels"], False)
+
+
+def test_batch_unsorted_chromosome_is_reported_per_chromosome(capi):
+    c1, ds, de, us, ue = chrom_case("7", 200_000, cov=1.0, n_dels=10, gaps=False)
+    with capi.Context(device=0, flags=capi.FLAG_BATCH) as ctx:
+        ctx.chrom_begin(c1.length, c1.gc)
+        ctx.reads(c1.pos, c1.mapq)
+        ctx.intervals("D", ds, de)
+        ctx.chrom_begin(c1.length, c1.gc)
+        ctx.reads(c1.pos[::-1].copy(), c1.mapq)
+        ctx.intervals("D", ds, de)
+        ctx.compute()
+        ctx.select(0)
+        assert len(ctx.fetch()[0]) == len(ds)
+        ctx.select(1)
+        with pytest.raises(capi.CongaError) as err:
+            ctx.fetch()
+        assert err.value.status == capi.CONGA_ERR_UNSORTED
