@@ -84,7 +84,7 @@ struct conga_ctx {
 	DevBuf d_pos, d_mapq, d_tile_start, d_rd, d_gc_hist, d_gc_like, d_slots, d_small, d_map, d_winner,
 			d_map_start, d_map_end, d_map_val, d_iv_start, d_iv_end, d_iv_type, d_iv_slot, d_iv_has_map, d_order,
 			d_observed, d_expected, d_item_off, d_item_len, d_item_iv, d_item_has_map, d_item_first, d_map_part,
-			d_support, d_results;
+			d_support, d_results, d_bases;
 
 	// pinned read-back
 	Small *h_small = nullptr;
@@ -231,7 +231,7 @@ int prepare(conga_ctx *ctx)
 	TRY(upload(ctx, ctx->d_slots, dslots.data(), dslots.size() * sizeof(Slot)));
 	TRY(ensure(ctx, ctx->d_small, std::max<size_t>(n_slots, 1) * sizeof(Small)));
 	TRY(ensure(ctx, ctx->d_rd, std::max<size_t>((size_t) ctx->total_L, 8) * 2));
-	TRY(ensure(ctx, ctx->d_tile_start, ((size_t) ctx->total_tiles + n_slots + 1) * 4));
+	TRY(ensure(ctx, ctx->d_tile_start, ((size_t) ctx->total_tiles + 2) * 4));
 	if ((size_t) n_slots > ctx->h_small_cap) {
 		if (ctx->h_small)
 			(void) hipHostFree(ctx->h_small);
@@ -256,6 +256,11 @@ int prepare(conga_ctx *ctx)
 		TRY(upload(ctx, ctx->d_gc_hist, gh.data(), gh.size()));
 		if (ctx->gc_like_distinct)
 			TRY(upload(ctx, ctx->d_gc_like, gl.data(), gl.size()));
+		// window_per_gc depends on the annotation only: computed once per layout
+		TRY(ensure(ctx, ctx->d_bases, (size_t) n_slots * kGcBins * 8));
+		HIP_TRY(ctx, hipMemsetAsync(ctx->d_bases.p, 0, (size_t) n_slots * kGcBins * 8, ctx->stream));
+		hipLaunchKernelGGL(gc_bases_kernel, dim3(64, n_slots), dim3(256), 0, ctx->stream, ptr<uint8_t>(ctx->d_gc_hist),
+				ptr<Slot>(ctx->d_slots), n_slots, ctx->step, ptr<unsigned long long>(ctx->d_bases));
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	}
 
@@ -496,9 +501,15 @@ conga_ctx *conga_create(int device, const conga_opts *opts, int *status)
 	ctx->step = ctx->opts.gc_step;
 	// tile = tile_win windows; tile_win * step must be a multiple of 8 (16-byte stores) and fit the LDS tile
 	int32_t tw = std::min<int32_t>(kDepthMaxTile / ctx->step, kDepthMaxWin);
-	tw &= ~7;
-	if (tw < 8)
-		tw = 8;
+	while (tw > 1 && ((int64_t) tw * ctx->step) % 8 != 0)
+		tw--;
+	if (((int64_t) tw * ctx->step) % 8 != 0 || tw < 1)
+		tw = 8; // step > 256 and odd: 8 windows still fit (8 * 1024 = kDepthMaxTile * 4 is checked below)
+	if ((int64_t) tw * ctx->step > kDepthMaxTile) {
+		*status = CONGA_ERR_INVALID; // gc_step too large for the LDS tile
+		delete ctx;
+		return nullptr;
+	}
 	ctx->tile_win = tw;
 
 	auto bail = [&](int st) -> conga_ctx * {
@@ -539,7 +550,8 @@ void conga_destroy(conga_ctx *ctx)
 			&ctx->d_slots, &ctx->d_small, &ctx->d_map, &ctx->d_winner, &ctx->d_map_start, &ctx->d_map_end,
 			&ctx->d_map_val, &ctx->d_iv_start, &ctx->d_iv_end, &ctx->d_iv_type, &ctx->d_iv_slot, &ctx->d_iv_has_map,
 			&ctx->d_order, &ctx->d_observed, &ctx->d_expected, &ctx->d_item_off, &ctx->d_item_len, &ctx->d_item_iv,
-			&ctx->d_item_has_map, &ctx->d_item_first, &ctx->d_map_part, &ctx->d_support, &ctx->d_results};
+			&ctx->d_item_has_map, &ctx->d_item_first, &ctx->d_map_part, &ctx->d_support, &ctx->d_results,
+			&ctx->d_bases};
 	for (DevBuf *b : bufs)
 		free_buf(*b);
 	for (auto &s : ctx->staging) {
@@ -658,8 +670,8 @@ int conga_reads_commit(conga_ctx *ctx, size_t n)
 	if (n > kStagingTuples)
 		return fail(ctx, CONGA_ERR_INVALID, "conga_reads_commit: n exceeds the staging capacity");
 	HostSlot &h = ctx->slots.back(); // reads stream into the chromosome begun last (BAM order)
-	if ((uint64_t) h.n_reads + n >= 0xFFFFFFF0ull)
-		return fail(ctx, CONGA_ERR_RANGE, "conga_reads_commit: more than 2^32 reads on one chromosome");
+	if ((uint64_t) ctx->n_reads_total + n >= 0xFFFFFFF0ull)
+		return fail(ctx, CONGA_ERR_RANGE, "conga_reads_commit: more than 2^32 reads in one context");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	Staging &s = ctx->staging[ctx->staging_cur];
 	ctx->staging_cur = -1;
@@ -777,7 +789,7 @@ int conga_chrom_compute(conga_ctx *ctx)
 	HIP_TRY(ctx, hipMemsetAsync(small, 0, (size_t) n_slots * sizeof(Small), st));
 
 	if (!unsorted_mode) {
-		HIP_TRY(ctx, hipMemsetAsync(ctx->d_tile_start.p, 0xFF, ((size_t) ctx->total_tiles + n_slots + 1) * 4, st));
+		HIP_TRY(ctx, hipMemsetAsync(ctx->d_tile_start.p, 0xFF, ((size_t) ctx->total_tiles + 2) * 4, st));
 		{
 			KernelTimer t(ctx, CONGA_K_INGEST);
 			if (ctx->n_reads_total > 0) {
@@ -792,19 +804,23 @@ int conga_chrom_compute(conga_ctx *ctx)
 			DepthArgs a;
 			a.pos = ptr<int32_t>(ctx->d_pos);
 			a.mapq = ptr<uint8_t>(ctx->d_mapq);
-			a.tile_start = ptr<uint32_t>(ctx->d_tile_start);
+			a.tile_first = ptr<uint32_t>(ctx->d_tile_start);
+			a.n_total = (uint32_t) ctx->n_reads_total;
 			a.rd = ptr<int16_t>(ctx->d_rd);
 			a.gc_hist = ptr<uint8_t>(ctx->d_gc_hist);
 			a.slots = dslots;
 			a.small = small;
 			a.n_slots = n_slots;
 			a.step = ctx->step;
+			a.step_magic = (uint32_t) (0x100000000ull / (uint64_t) ctx->step) + 1u;
 			a.tile_win = ctx->tile_win;
 			a.mq_threshold = ctx->opts.mq_threshold;
 			a.total_tiles = ctx->total_tiles;
-			const int64_t max_grid = (int64_t) ctx->n_cu * ctx->depth_blocks_per_cu;
-			a.tiles_per_block = std::max<int64_t>(1, (ctx->total_tiles + max_grid - 1) / max_grid);
-			const int grid = (int) ((ctx->total_tiles + a.tiles_per_block - 1) / a.tiles_per_block);
+			// one resident set of waves, each with a contiguous run of tiles
+			const int64_t max_waves = (int64_t) ctx->n_cu * ctx->depth_blocks_per_cu * kDepthWaves;
+			a.tiles_per_wave = std::max<int64_t>(1, (ctx->total_tiles + max_waves - 1) / max_waves);
+			const int64_t n_waves = (ctx->total_tiles + a.tiles_per_wave - 1) / a.tiles_per_wave;
+			const int grid = (int) ((n_waves + kDepthWaves - 1) / kDepthWaves);
 			hipLaunchKernelGGL(depth_tile_kernel, dim3(grid), dim3(kDepthBlock), 0, st, a);
 		}
 	} else {
@@ -827,7 +843,8 @@ int conga_chrom_compute(conga_ctx *ctx)
 
 	{
 		KernelTimer t(ctx, CONGA_K_EXPECTED);
-		hipLaunchKernelGGL(expected_table_kernel, dim3(n_slots), dim3(128), 0, st, small);
+		hipLaunchKernelGGL(expected_table_kernel, dim3(n_slots), dim3(128), 0, st, small,
+				ptr<unsigned long long>(ctx->d_bases));
 	}
 
 	// the reference paints the track only when the chromosome has at least one kept SV

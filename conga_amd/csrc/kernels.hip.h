@@ -88,12 +88,25 @@ template <typename KeyOf> __device__ __forceinline__ int find_slot(int n_slots, 
 //   * flags tuples that break the position order inside a chromosome (the tile index below needs
 //     sorted input, which is what sam_itr_next over an indexed BAM yields: bam_data.c:201,293);
 //   * counts tuples outside [0, L) (the reference would write out of bounds: bam_data.c:213);
-//   * builds tile_start[t] = local index of the first tuple whose position falls in depth tile t or
-//     later, so the depth kernel needs no search.  Entries past the last tuple's tile keep the
-//     memset value 0xFFFFFFFF (= "n_reads").
+//   * builds tile_first[t] = index (into the concatenated tuple arrays) of the first tuple whose
+//     position falls in GLOBAL depth tile t or later, so the depth kernel needs no search: the tuples
+//     of tile t are [tile_first[t], tile_first[t + 1]).  Chromosomes are concatenated in begin order
+//     and sorted inside, so the global tile number never decreases along the tuple array.  Entries
+//     past the last tuple's tile keep the memset value 0xFFFFFFFF (= "n_total").  Out-of-range
+//     tuples are filed under their chromosome's first / last tile, where the depth kernel's range
+//     check drops them.
 // -------------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t global_tile_of(const Slot &sl, int32_t p, uint32_t tile_len)
+{
+	if (p < 0)
+		return sl.tile0;
+	if (p >= sl.L)
+		return sl.tile0 + sl.n_tiles - 1;
+	return sl.tile0 + (uint32_t) p / tile_len;
+}
+
 __global__ __launch_bounds__(256) void ingest_kernel(const int32_t *__restrict__ pos, int64_t n_total,
-		const Slot *__restrict__ slots, int n_slots, int32_t tile_len, uint32_t *__restrict__ tile_start,
+		const Slot *__restrict__ slots, int n_slots, int32_t tile_len, uint32_t *__restrict__ tile_first,
 		Small *__restrict__ small)
 {
 	const int64_t stride = (int64_t) gridDim.x * blockDim.x;
@@ -102,160 +115,209 @@ __global__ __launch_bounds__(256) void ingest_kernel(const int32_t *__restrict__
 		if (i < slots[s].read_off || i >= slots[s].read_off + slots[s].n_reads)
 			s = find_slot(n_slots, i, [&](int k) { return slots[k].read_off; });
 		const Slot sl = slots[s];
-		const int64_t li = i - sl.read_off;
 		const int32_t p = pos[i];
-		const int32_t prev = (li > 0) ? pos[i - 1] : INT32_MIN;
-		if (p < prev)
-			atomicOr(&small[s].status, kStatusUnsorted);
-		int64_t t_cur, t_prev;
-		if (p < 0) {
-			t_cur = 0;
+		if (p < 0 || p >= sl.L)
 			atomicAdd(&small[s].counters[CNT_OUT_OF_RANGE], 1ull);
-		} else if (p >= sl.L) {
-			t_cur = sl.n_tiles;
-			atomicAdd(&small[s].counters[CNT_OUT_OF_RANGE], 1ull);
-		} else
-			t_cur = (uint32_t) p / (uint32_t) tile_len;
-		if (li == 0)
-			t_prev = -1;
-		else if (prev < 0)
-			t_prev = 0;
-		else if (prev >= sl.L)
-			t_prev = sl.n_tiles;
-		else
-			t_prev = (uint32_t) prev / (uint32_t) tile_len;
+		const int64_t t_cur = global_tile_of(sl, p, (uint32_t) tile_len);
+		int64_t t_prev = -1;
+		if (i > 0) {
+			const int32_t prev = pos[i - 1];
+			if (i > sl.read_off) { // same chromosome
+				if (p < prev)
+					atomicOr(&small[s].status, kStatusUnsorted);
+				t_prev = global_tile_of(sl, prev, (uint32_t) tile_len);
+			} else {
+				// first tuple of this chromosome: the previous tuple belongs to an earlier one
+				const int sp = find_slot(n_slots, i - 1, [&](int k) { return slots[k].read_off; });
+				t_prev = global_tile_of(slots[sp], prev, (uint32_t) tile_len);
+			}
+		}
 		for (int64_t t = t_prev + 1; t <= t_cur; t++)
-			tile_start[sl.tidx_off + t] = (uint32_t) li;
+			tile_first[t] = (uint32_t) i;
 	}
 }
 
 // -------------------------------------------------------------------------------------------
-// K1 + K2 depth_tile: builds read_depth and the GC-stratified sums in one pass.
+// K1 + K2 depth_tile: builds read_depth and the GC-stratified depth sums in one pass.
 //
 // Replaces init_rd_per_chr's memset (read_distribution.c:16-17), the increments of
-// count_reads_bam (bam_data.c:205-215) and both loops of calc_mean_per_chr
-// (read_distribution.c:33-37,63-73).  A workgroup owns a contiguous run of tiles of
-// tile_win * step positions.  Per tile it zeroes 16-bit counters in LDS (two per dword -- the
-// layout of the int16 output), adds the tile's tuples with LDS atomics, then streams the tile out
-// ONCE with one ds_read_b128 + one 16-byte global store per lane (read_depth is written exactly
-// once and never read back for the histogram).  Per-window sums feed a 101-bin {sum, bases}
-// histogram kept in LDS across the workgroup's tiles and flushed with one global atomic per
-// non-empty bin when the workgroup moves to another chromosome.  All accumulators are integers,
-// so the result does not depend on the order of the atomics.
+// count_reads_bam (bam_data.c:205-215) and the depth side of both loops of calc_mean_per_chr
+// (read_distribution.c:33-37,63-73).
+//
+// Every WAVE is an independent worker (no workgroup barrier anywhere): it owns a contiguous run of
+// tiles of tile_win * step positions and a private LDS area.  Per tile it zeroes 16-bit counters
+// in LDS (two per dword -- the layout of the int16 output), adds the tile's tuples with LDS
+// atomics, then streams the tile out ONCE with one ds_read_b128 + one 16-byte global store per lane
+// (1 KiB per wave-instruction; read_depth is written exactly once and never read back for the
+// histogram).  Per-window sums feed a private 101-bin histogram that is flushed with one global
+// atomic per non-empty bin when the wave moves to another chromosome.  LDS operations of one wave
+// execute in order, so the phases need no barrier; 28 such waves per CU hide each other's
+// tile-index / tuple / GC-byte load latencies.  All accumulators are integers, so the result does
+// not depend on the order of the atomics.
 // `short` semantics: a counter wraps modulo 2^16 exactly like read_depth[pos]++ on a short
 // (gcc); the carry of a wrapping low half into its neighbour is undone on the spot.
 // -------------------------------------------------------------------------------------------
 constexpr int kDepthBlock = 256;
-constexpr int kDepthMaxTile = 8192; // positions per tile (16 KiB of packed LDS counters)
-constexpr int kDepthMaxWin = 256;   // GC windows per tile (LDS window sums); 18.3 KiB LDS -> 8 workgroups per CU
+constexpr int kDepthWaves = kDepthBlock / kWave;
+constexpr int kDepthMaxTile = 2048; // positions per wave tile (4 KiB of packed LDS counters)
+constexpr int kDepthMaxWin = 64;    // GC windows per wave tile
 
 struct DepthArgs {
 	const int32_t *pos;
 	const uint8_t *mapq;
-	const uint32_t *tile_start;
+	const uint32_t *tile_first; // [total_tiles + 1], global tuple indices (ingest_kernel)
 	int16_t *rd;
 	const uint8_t *gc_hist;
 	const Slot *slots;
 	Small *small;
 	int32_t n_slots;
 	int32_t step;
+	uint32_t step_magic; // floor(2^32 / step) + 1: j / step == umulhi(j, magic) for j * step < 2^32
 	int32_t tile_win;
 	int32_t mq_threshold;
+	uint32_t n_total;    // tuples in the batch
 	int64_t total_tiles;
-	int64_t tiles_per_block;
+	int64_t tiles_per_wave;
 };
 
-__device__ __forceinline__ void depth_flush_hist(Small *sm, unsigned long long *h_sum, unsigned int *h_bases,
-		int tid)
+__device__ __forceinline__ void depth_flush(Small *sm, unsigned long long *h_sum, unsigned int counted, int lane)
 {
-	for (int g = tid; g < kGcBins; g += kDepthBlock) {
+	for (int g = lane; g < kGcBins; g += kWave) {
 		if (h_sum[g])
 			atomicAdd(&sm->hist_sum[g], h_sum[g]);
-		if (h_bases[g])
-			atomicAdd(&sm->hist_bases[g], (unsigned long long) h_bases[g]);
 		h_sum[g] = 0;
-		h_bases[g] = 0;
 	}
+	const int w = wave_sum_i32((int) counted);
+	if (lane == 0 && w)
+		atomicAdd(&sm->counters[CNT_COUNTED], (unsigned long long) w);
 }
+
+constexpr int kDepthPrefetch = 2; // tuples per lane fetched one tile ahead (128 per 2000-base tile = 6x coverage)
 
 __global__ __launch_bounds__(kDepthBlock) void depth_tile_kernel(DepthArgs a)
 {
-	__shared__ __attribute__((aligned(16))) uint32_t cnt2[kDepthMaxTile / 2];
-	__shared__ int32_t wsum[kDepthMaxWin + 8];
-	__shared__ unsigned long long h_sum[kGcBins];
-	__shared__ unsigned int h_bases[kGcBins];
+	__shared__ __attribute__((aligned(16))) uint32_t cnt2_all[kDepthWaves][kDepthMaxTile / 2];
+	__shared__ int32_t wsum_all[kDepthWaves][kDepthMaxWin + 8];
+	__shared__ unsigned long long h_sum_all[kDepthWaves][kGcBins];
 
-	const int tid = threadIdx.x;
+	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+	const int lane = threadIdx.x & (kWave - 1);
+	uint32_t *cnt2 = cnt2_all[wv];
+	int32_t *wsum = wsum_all[wv];
+	unsigned long long *h_sum = h_sum_all[wv];
+
 	const int T = a.tile_win * a.step;
-	const int64_t g_begin = (int64_t) blockIdx.x * a.tiles_per_block;
-	const int64_t g_end = (g_begin + a.tiles_per_block < a.total_tiles) ? g_begin + a.tiles_per_block : a.total_tiles;
+	const int64_t wave_id = (int64_t) blockIdx.x * kDepthWaves + wv;
+	const int64_t g_begin = wave_id * a.tiles_per_wave;
+	const int64_t g_end = (g_begin + a.tiles_per_wave < a.total_tiles) ? g_begin + a.tiles_per_wave : a.total_tiles;
 	if (g_begin >= g_end)
-		return;
+		return; // wave-uniform; the kernel has no workgroup barrier
 
-	for (int g = tid; g < kGcBins; g += kDepthBlock) {
+	for (int g = lane; g < kGcBins; g += kWave)
 		h_sum[g] = 0;
-		h_bases[g] = 0;
-	}
+
+	auto first_of = [&](int64_t t) -> uint32_t {
+		const uint32_t v = a.tile_first[(t < a.total_tiles) ? t : a.total_tiles];
+		return (v == 0xFFFFFFFFu) ? a.n_total : v;
+	};
+	auto gc_of = [&](const Slot &sl_, int64_t gt_) -> uint32_t {
+		// GC byte of window `lane` of global tile gt_ (only lanes < tile_win matter)
+		int64_t wg = (gt_ - sl_.tile0) * a.tile_win + lane;
+		if (wg >= sl_.n_win)
+			wg = sl_.n_win - 1;
+		return a.gc_hist[sl_.gc_off + wg];
+	};
+
+	// ---- software pipeline: everything tile gt + 1 needs from HBM is requested while tile gt is
+	// processed (tile index two tiles ahead), so no wave ever waits on a dependent load chain
 	int s = find_slot(a.n_slots, g_begin, [&](int k) { return a.slots[k].tile0; });
 	Slot sl = a.slots[s];
+	int s_n = s;
+	Slot sl_n = sl;
+	bool skip = (a.small[s].status & kStatusUnsorted) != 0; // then this chromosome's tile index is meaningless
 	unsigned int counted = 0;
+
+	uint32_t c_lo = first_of(g_begin), c_hi = first_of(g_begin + 1), n_hi = first_of(g_begin + 2);
+	int32_t c_pos[kDepthPrefetch];
+	int c_mq[kDepthPrefetch];
+#pragma unroll
+	for (int k = 0; k < kDepthPrefetch; k++) {
+		const uint32_t i = c_lo + k * kWave + lane;
+		c_pos[k] = (i < c_hi) ? a.pos[i] : INT32_MIN; // INT32_MIN: no tuple (fails the range check below)
+		c_mq[k] = (i < c_hi) ? (int) a.mapq[i] : 0;
+	}
+	uint32_t c_gc = (lane < a.tile_win) ? gc_of(sl, g_begin) : 0;
 
 	for (int64_t gt = g_begin; gt < g_end; gt++) {
 		if (gt >= sl.tile0 + sl.n_tiles) {
 			// next chromosome: hand this one's partial histogram and read count over
-			__syncthreads();
-			depth_flush_hist(&a.small[s], h_sum, h_bases, tid);
-			int w = wave_sum_i32((int) counted);
-			if ((tid & (kWave - 1)) == 0 && w)
-				atomicAdd(&a.small[s].counters[CNT_COUNTED], (unsigned long long) w);
+			depth_flush(&a.small[s], h_sum, counted, lane);
 			counted = 0;
-			while (gt >= a.slots[s].tile0 + a.slots[s].n_tiles)
-				s++;
-			sl = a.slots[s];
+			s = s_n;
+			sl = sl_n;
+			skip = (a.small[s].status & kStatusUnsorted) != 0;
 		}
+		// ---- requests for tile gt + 1 (and the tile index of gt + 2)
+		const bool have_next = gt + 1 < g_end;
+		if (have_next && gt + 1 >= sl_n.tile0 + sl_n.n_tiles) {
+			while (gt + 1 >= a.slots[s_n].tile0 + a.slots[s_n].n_tiles)
+				s_n++;
+			sl_n = a.slots[s_n];
+		}
+		const uint32_t nn_hi = first_of(gt + 3);
+		int32_t n_pos[kDepthPrefetch];
+		int n_mq[kDepthPrefetch];
+#pragma unroll
+		for (int k = 0; k < kDepthPrefetch; k++) {
+			const uint32_t i = c_hi + k * kWave + lane;
+			const bool ok = have_next && i < n_hi;
+			n_pos[k] = ok ? a.pos[i] : INT32_MIN;
+			n_mq[k] = ok ? (int) a.mapq[i] : 0;
+		}
+		const uint32_t n_gc = (have_next && lane < a.tile_win) ? gc_of(sl_n, gt + 1) : 0;
+
+		// ---- tile gt
 		const int64_t tile = gt - sl.tile0;
 		const int64_t base = tile * T;
 		const int len = (int) ((sl.L - base < T) ? (sl.L - base) : T);
-		const bool skip = (a.small[s].status & kStatusUnsorted) != 0; // tile index is meaningless
 
-		for (int j = tid * 4; j < T / 2; j += kDepthBlock * 4)
+		for (int j = lane * 4; j < T / 2; j += kWave * 4)
 			*reinterpret_cast<uint4 *>(&cnt2[j]) = make_uint4(0, 0, 0, 0);
-		for (int j = tid; j < a.tile_win; j += kDepthBlock)
-			wsum[j] = 0;
-		__syncthreads();
+		if (lane < a.tile_win)
+			wsum[lane] = 0;
+		__builtin_amdgcn_wave_barrier();
 
-		const uint32_t lo = a.tile_start[sl.tidx_off + tile];
-		uint32_t hi = a.tile_start[sl.tidx_off + tile + 1];
-		if (lo != 0xFFFFFFFFu && !skip) {
-			if (hi == 0xFFFFFFFFu)
-				hi = (uint32_t) sl.n_reads;
-			const int32_t *tp = a.pos + sl.read_off;
-			const uint8_t *tq = a.mapq + sl.read_off;
-			for (uint32_t i = lo + tid; i < hi; i += kDepthBlock) {
-				const int64_t p = (int64_t) tp[i] - base;
-				if (p >= 0 && p < len && (int) tq[i] > a.mq_threshold) {
-					if (p & 1)
-						atomicAdd(&cnt2[p >> 1], 0x10000u);
-					else {
-						const uint32_t old = atomicAdd(&cnt2[p >> 1], 1u);
-						if ((old & 0xFFFFu) == 0xFFFFu)
-							atomicSub(&cnt2[p >> 1], 0x10000u); // the low short wrapped: undo its carry
-					}
-					counted++;
+		auto add_tuple = [&](int32_t pp, int mq) {
+			const int64_t p = (int64_t) pp - base;
+			if (p >= 0 && p < len && mq > a.mq_threshold) {
+				if (p & 1)
+					atomicAdd(&cnt2[p >> 1], 0x10000u);
+				else {
+					const uint32_t old = atomicAdd(&cnt2[p >> 1], 1u);
+					if ((old & 0xFFFFu) == 0xFFFFu)
+						atomicSub(&cnt2[p >> 1], 0x10000u); // the low short wrapped: undo its carry
 				}
+				counted++;
 			}
+		};
+		if (!skip) {
+#pragma unroll
+			for (int k = 0; k < kDepthPrefetch; k++)
+				add_tuple(c_pos[k], c_mq[k]); // lanes past c_hi carry INT32_MIN and fail the range check
+			for (uint32_t i = c_lo + kDepthPrefetch * kWave + lane; i < c_hi; i += kWave) // deep tiles: direct loads
+				add_tuple(a.pos[i], (int) a.mapq[i]);
 		}
-		__syncthreads();
+		__builtin_amdgcn_wave_barrier();
 
 		// stream the tile out: 8 positions (16 bytes) per lane per step; the slot's region is padded to
 		// a multiple of 8 elements and positions >= len hold zeros, so the last store may run over len
 		int16_t *out = a.rd + sl.rd_off + base;
-		for (int j = tid * 8; j < len; j += kDepthBlock * 8) {
+		for (int j = lane * 8; j < len; j += kWave * 8) {
 			const uint4 q = *reinterpret_cast<const uint4 *>(&cnt2[j >> 1]);
 			*reinterpret_cast<uint4 *>(out + j) = q;
 			if ((q.x | q.y | q.z | q.w) != 0u) { // sparse: most 8-base groups hold no read start
 				const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
-				int w = j / a.step;
+				int w = (a.step == 1) ? j : (int) __umulhi((uint32_t) j, a.step_magic);
 				int r = j - w * a.step;
 				int acc = 0;
 #pragma unroll
@@ -274,32 +336,54 @@ __global__ __launch_bounds__(kDepthBlock) void depth_tile_kernel(DepthArgs a)
 					atomicAdd(&wsum[w], acc);
 			}
 		}
-		__syncthreads();
+		__builtin_amdgcn_wave_barrier();
 
-		// per-window sums -> GC bins (read_distribution.c:70-72)
-		const int nw = (len + a.step - 1) / a.step;
-		const int64_t w0 = tile * a.tile_win;
-		for (int w = tid; w < nw; w += kDepthBlock) {
-			int64_t wg = w0 + w;
-			if (wg >= sl.n_win)
-				wg = sl.n_win - 1;
-			const int g = a.gc_hist[sl.gc_off + wg];
-			const int nb = (len - w * a.step < a.step) ? (len - w * a.step) : a.step;
-			if (g < kGcBins) {
-				const int sw = wsum[w];
-				if (sw)
-					atomicAdd(&h_sum[g], (unsigned long long) (long long) sw);
-				atomicAdd(&h_bases[g], (unsigned int) nb);
-			}
+		// per-window depth sums -> GC bins (read_distribution.c:70-71)
+		const int nw = (a.step == 1) ? len : (int) __umulhi((uint32_t) (len + a.step - 1), a.step_magic);
+		if (lane < nw) {
+			const int sw = wsum[lane];
+			if (sw && c_gc < (uint32_t) kGcBins)
+				atomicAdd(&h_sum[c_gc], (unsigned long long) (long long) sw);
 		}
-		// the next tile's zeroing of cnt2 / wsum is fenced by the barrier that follows it
-		__syncthreads();
-	}
+		__builtin_amdgcn_wave_barrier();
 
-	depth_flush_hist(&a.small[s], h_sum, h_bases, tid);
-	int w = wave_sum_i32((int) counted);
-	if ((tid & (kWave - 1)) == 0 && w)
-		atomicAdd(&a.small[s].counters[CNT_COUNTED], (unsigned long long) w);
+		// ---- rotate the pipeline
+		c_lo = c_hi;
+		c_hi = n_hi;
+		n_hi = nn_hi;
+#pragma unroll
+		for (int k = 0; k < kDepthPrefetch; k++) {
+			c_pos[k] = n_pos[k];
+			c_mq[k] = n_mq[k];
+		}
+		c_gc = n_gc;
+	}
+	depth_flush(&a.small[s], h_sum, counted, lane);
+}
+
+// window_per_gc (read_distribution.c:72) depends on the annotation only: one thread per GC window,
+// run once per layout (not per compute).
+__global__ __launch_bounds__(256) void gc_bases_kernel(const uint8_t *__restrict__ gc_hist,
+		const Slot *__restrict__ slots, int n_slots, int32_t step, unsigned long long *__restrict__ bases /* [n_slots][101] */)
+{
+	__shared__ unsigned int h[kGcBins];
+	const int s = blockIdx.y;
+	const Slot sl = slots[s];
+	for (int g = threadIdx.x; g < kGcBins; g += blockDim.x)
+		h[g] = 0;
+	__syncthreads();
+	const int64_t n_w = (sl.L + step - 1) / step;
+	for (int64_t w = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; w < n_w; w += (int64_t) gridDim.x * blockDim.x) {
+		const int64_t b = w * step;
+		const int nb = (int) ((sl.L - b < step) ? (sl.L - b) : step);
+		const int g = gc_hist[sl.gc_off + ((w < sl.n_win) ? w : sl.n_win - 1)];
+		if (g < kGcBins)
+			atomicAdd(&h[g], (unsigned int) nb);
+	}
+	__syncthreads();
+	for (int g = threadIdx.x; g < kGcBins; g += blockDim.x)
+		if (h[g])
+			atomicAdd(&bases[(int64_t) s * kGcBins + g], (unsigned long long) h[g]);
 }
 
 // Depth for unsorted input (CONGA_FLAG_READS_UNSORTED): read_depth is zeroed by hipMemsetAsync and
@@ -376,12 +460,14 @@ __global__ __launch_bounds__(256) void gc_hist_kernel(const int16_t *__restrict_
 // float goes through double (exact below 2^53, then one rounding), which equals the correctly
 // rounded direct conversion.
 // -------------------------------------------------------------------------------------------
-__global__ void expected_table_kernel(Small *__restrict__ small)
+__global__ void expected_table_kernel(Small *__restrict__ small, const unsigned long long *__restrict__ bases)
 {
 	Small &sm = small[blockIdx.x];
 	const int g = threadIdx.x;
 	if (g >= kGcBins)
 		return;
+	if (bases)
+		sm.hist_bases[g] = bases[(int64_t) blockIdx.x * kGcBins + g];
 	float e = 0.0f;
 	if (g > 0) {
 		const float num = (float) (double) (long long) sm.hist_sum[g];
