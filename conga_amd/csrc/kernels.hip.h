@@ -110,11 +110,17 @@ __global__ __launch_bounds__(256) void ingest_kernel(const int32_t *__restrict__
 		Small *__restrict__ small)
 {
 	const int64_t stride = (int64_t) gridDim.x * blockDim.x;
-	int s = 0;
+	// the few Slot fields this kernel needs, refreshed only when the tuple index leaves the chromosome
+	int s = -1;
+	int64_t r0 = 0, r1 = 0;
+	Slot sl;
 	for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_total; i += stride) {
-		if (i < slots[s].read_off || i >= slots[s].read_off + slots[s].n_reads)
+		if (i < r0 || i >= r1) {
 			s = find_slot(n_slots, i, [&](int k) { return slots[k].read_off; });
-		const Slot sl = slots[s];
+			sl = slots[s];
+			r0 = sl.read_off;
+			r1 = sl.read_off + sl.n_reads;
+		}
 		const int32_t p = pos[i];
 		if (p < 0 || p >= sl.L)
 			atomicAdd(&small[s].counters[CNT_OUT_OF_RANGE], 1ull);
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(256) void ingest_kernel(const int32_t *__restrict__
 		int64_t t_prev = -1;
 		if (i > 0) {
 			const int32_t prev = pos[i - 1];
-			if (i > sl.read_off) { // same chromosome
+			if (i > r0) { // same chromosome
 				if (p < prev)
 					atomicOr(&small[s].status, kStatusUnsorted);
 				t_prev = global_tile_of(sl, prev, (uint32_t) tile_len);
@@ -132,8 +138,9 @@ __global__ __launch_bounds__(256) void ingest_kernel(const int32_t *__restrict__
 				t_prev = global_tile_of(slots[sp], prev, (uint32_t) tile_len);
 			}
 		}
-		for (int64_t t = t_prev + 1; t <= t_cur; t++)
-			tile_first[t] = (uint32_t) i;
+		if (t_prev != t_cur)
+			for (int64_t t = t_prev + 1; t <= t_cur; t++)
+				tile_first[t] = (uint32_t) i;
 	}
 }
 

@@ -1,0 +1,139 @@
+"""Binary containers the `conga` command line reads, and their Python writers/readers.
+
+Neither htslib nor SONIC exists in this image (both are empty submodules of the reference), so:
+  * `--sonic` takes this implementation's own annotation container (.cga): chromosome table, one rounded
+    GC% byte per gc_step-bp window, satellite intervals;
+  * `--input` takes a BAM (conga_amd/host/bam_reader.cpp, when built) or a read-tuple container (.ctp) holding
+    exactly the fields of bam1_core_t that the path reads (pos, qual; flag and l_qseq for --rp).
+All integers are little-endian.
+"""
+import struct
+
+import numpy as np
+
+ANNOT_MAGIC = b"CONGAAN1"
+TUPLE_MAGIC = b"CONGATP1"
+
+
+def write_annotation(path, chroms, gc_step=100):
+    """chroms: list of (name, length, gc uint8[n_win], sat_start int32[], sat_end int32[])."""
+    with open(path, "wb") as f:
+        f.write(ANNOT_MAGIC)
+        f.write(struct.pack("<ii", gc_step, len(chroms)))
+        for name, length, gc, ss, se in chroms:
+            nb = name.encode()
+            n_win = (length + gc_step - 1) // gc_step
+            assert len(gc) == n_win, (name, len(gc), n_win)
+            f.write(struct.pack("<H", len(nb)) + nb)
+            f.write(struct.pack("<qqq", length, n_win, len(ss)))
+        for name, length, gc, ss, se in chroms:
+            f.write(np.ascontiguousarray(gc, dtype=np.uint8).tobytes())
+            f.write(np.ascontiguousarray(ss, dtype="<i4").tobytes())
+            f.write(np.ascontiguousarray(se, dtype="<i4").tobytes())
+
+
+def read_annotation(path):
+    with open(path, "rb") as f:
+        assert f.read(8) == ANNOT_MAGIC
+        gc_step, n = struct.unpack("<ii", f.read(8))
+        table = []
+        for _ in range(n):
+            (ln,) = struct.unpack("<H", f.read(2))
+            name = f.read(ln).decode()
+            length, n_win, n_sat = struct.unpack("<qqq", f.read(24))
+            table.append((name, length, n_win, n_sat))
+        out = []
+        for name, length, n_win, n_sat in table:
+            gc = np.frombuffer(f.read(n_win), dtype=np.uint8)
+            ss = np.frombuffer(f.read(4 * n_sat), dtype="<i4")
+            se = np.frombuffer(f.read(4 * n_sat), dtype="<i4")
+            out.append((name, length, gc, ss, se))
+    return gc_step, out
+
+
+def write_tuples(path, sample, chroms):
+    """chroms: list of (name, length, pos int32[n] sorted, mapq uint8[n][, flag uint16[n], l_qseq int32[n]])."""
+    with open(path, "wb") as f:
+        f.write(TUPLE_MAGIC)
+        sb = sample.encode()
+        f.write(struct.pack("<H", len(sb)) + sb)
+        f.write(struct.pack("<i", len(chroms)))
+        for c in chroms:
+            nb = c[0].encode()
+            f.write(struct.pack("<H", len(nb)) + nb)
+            f.write(struct.pack("<qqB", c[1], len(c[2]), 1 if len(c) > 4 else 0))
+        for c in chroms:
+            f.write(np.ascontiguousarray(c[2], dtype="<i4").tobytes())
+            f.write(np.ascontiguousarray(c[3], dtype=np.uint8).tobytes())
+            if len(c) > 4:
+                f.write(np.ascontiguousarray(c[4], dtype="<u2").tobytes())
+                f.write(np.ascontiguousarray(c[5], dtype="<i4").tobytes())
+
+
+# ------------------------------------------------------------------------------------------------
+# Minimal BAM writer (BGZF + BAM records per the SAM/BAM specification) for synthetic inputs and tests.
+# ------------------------------------------------------------------------------------------------
+import zlib
+
+_BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def _bgzf_block(data):
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    cdata = co.compress(data) + co.flush()
+    bsize = len(cdata) + 25  # 12 header + 6 extra + cdata + 8 trailer - 1
+    return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize)
+            + cdata + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+
+
+def _reg2bin(beg, end):
+    end -= 1
+    for shift, off in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        if beg >> shift == end >> shift:
+            return off + (beg >> shift)
+    return 0
+
+
+def write_bam(path, sample, chroms, read_len=100, unplaced=0, block_payload=60000):
+    """chroms: list of (name, length, pos int32[n] sorted, mapq uint8[n][, flag uint16[n]]).
+    Every record gets a `read_len`M CIGAR, an all-A sequence and quality 30; `unplaced` unmapped records
+    (refID -1) are appended at the end, as in a real coordinate-sorted BAM."""
+    text = "@HD\tVN:1.6\tSO:coordinate\n"
+    for c in chroms:
+        text += "@SQ\tSN:%s\tLN:%d\n" % (c[0], c[1])
+    text += "@RG\tID:rg1\tSM:%s\tPL:ILLUMINA\n" % sample
+    tb = text.encode()
+    out = bytearray()
+    out += b"BAM\x01" + struct.pack("<i", len(tb)) + tb + struct.pack("<i", len(chroms))
+    for c in chroms:
+        nb = c[0].encode() + b"\x00"
+        out += struct.pack("<i", len(nb)) + nb + struct.pack("<i", c[1])
+    l_seq = read_len
+    seq = bytes([0x11]) * ((l_seq + 1) // 2)
+    qual = bytes([30]) * l_seq
+    cigar = struct.pack("<I", (read_len << 4) | 0)
+    k = 0
+    with open(path, "wb") as f:
+        def flush(final=False):
+            nonlocal out
+            while len(out) >= block_payload or (final and len(out)):
+                f.write(_bgzf_block(bytes(out[:block_payload])))
+                out = out[block_payload:]
+        for tid, c in enumerate(chroms):
+            pos, mapq = np.asarray(c[2]), np.asarray(c[3])
+            flag = np.asarray(c[4]) if len(c) > 4 else np.zeros(len(pos), np.uint16)
+            for p, q, fl in zip(pos.tolist(), mapq.tolist(), flag.tolist()):
+                name = ("r%d" % k).encode() + b"\x00"
+                k += 1
+                body = struct.pack("<iiBBHHHiiii", tid, p, len(name), q, _reg2bin(p, p + read_len), 1, fl, l_seq,
+                                   -1, -1, 0) + name + cigar + seq + qual
+                out += struct.pack("<i", len(body)) + body
+                if len(out) >= block_payload:
+                    flush()
+        for _ in range(unplaced):
+            name = ("u%d" % k).encode() + b"\x00"
+            k += 1
+            body = struct.pack("<iiBBHHHiiii", -1, -1, len(name), 0, 4680, 0, 4, l_seq, -1, -1, 0) + name + seq + qual
+            out += struct.pack("<i", len(body)) + body
+        flush(final=True)
+        f.write(_BGZF_EOF)

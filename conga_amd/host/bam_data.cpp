@@ -1,0 +1,230 @@
+// bam_data.cpp -- read_bam / count_reads_bam / find_SVs re-hosted on the C-ABI of include/conga_hip.h.
+//
+// Order of work differs from the reference on purpose: all chromosomes are handed to ONE batch context
+// (CONGA_FLAG_BATCH) and computed by a single conga_chrom_compute(), then written out in annotation order.
+// Outputs are byte-identical to doing begin / finish per chromosome; the GPU just gets launches that fill it.
+#include "bam_data.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/conga_hip.h"
+#include "likelihood.h"
+#include "reads.h"
+#include "svs.h"
+
+namespace conga_host {
+
+FILE *logFile = nullptr;
+
+namespace {
+
+// print_error (common.c:102-108)
+[[noreturn]] void print_error(const std::string &msg)
+{
+	fprintf(stderr, "\n%s\n", msg.c_str());
+	fprintf(stderr, "Invoke parameter -h for help.\n");
+	exit(CONGA_EXIT_COMMON);
+}
+
+// safe_fopen (common.c:111-125)
+FILE *safe_fopen(const std::string &path, const char *mode)
+{
+	FILE *f = fopen(path.c_str(), mode);
+	if (!f)
+		print_error("[CONGA INPUT ERROR] Unable to open file " + path + " in " + (mode[0] == 'w' ? "write" : "read") + " mode.");
+	return f;
+}
+
+void engine_check(conga_ctx *ctx, int rc, const char *what)
+{
+	if (rc != CONGA_OK) {
+		fprintf(stderr, "\n[CONGA ENGINE ERROR] %s: %s (%s)\n", what, conga_strerror(rc), conga_last_error(ctx));
+		exit(CONGA_EXIT_COMMON);
+	}
+}
+
+// count_reads_bam (bam_data.c:192-221), producer side: records go straight into the pinned staging ring.
+int64_t count_reads_bam(conga_ctx *ctx, read_source *src, int chr_index_bam, int64_t chrom_len)
+{
+	std::string err;
+	if (!src->begin(chr_index_bam, chrom_len, &err)) {
+		fprintf(stderr, "Error: Iterator cannot be loaded (bam_itr_queryi)\n");
+		exit(1);
+	}
+	int64_t cnt = 0;
+	for (;;) {
+		conga_read_staging stg;
+		engine_check(ctx, conga_reads_staging(ctx, &stg), "conga_reads_staging");
+		read_batch b;
+		if (!src->next(stg.capacity, &b, &err))
+			print_error("[CONGA INPUT ERROR] " + err);
+		if (b.n) {
+			memcpy(stg.pos, b.pos, b.n * sizeof(int32_t));
+			memcpy(stg.mapq, b.mapq, b.n);
+		}
+		engine_check(ctx, conga_reads_commit(ctx, b.n), "conga_reads_commit");
+		cnt += (int64_t) b.n;
+		if (b.n < stg.capacity)
+			break;
+	}
+	return cnt;
+}
+
+} // namespace
+
+int read_bam(parameters *params, sonic *this_sonic)
+{
+	FILE *fpDel = nullptr, *fpDup = nullptr, *fpSVs = nullptr;
+
+	// ---- output files and headers (bam_data.c:232-250)
+	const std::string svfile = params->outdir + params->outprefix + "_svs.bed";
+	fprintf(stderr, "\nOutput SV file: %s\n", svfile.c_str());
+	fpSVs = safe_fopen(svfile, "w");
+	fprintf(fpSVs, "#CHR\tSTART_SV\tEND_SV\tSV_TYPE\tCOPY_NUMBER\tLIKELIHOOD\tREAD_PAIR\tMAPPABILITY\n");
+	if (params->have_dels) {
+		const std::string f = params->outdir + params->outprefix + "_dels.bed";
+		fprintf(stderr, "Output Del file: %s\n", f.c_str());
+		fpDel = safe_fopen(f, "w");
+		fprintf(fpDel, "#CHR\tSTART_SV\tEND_SV\tCOPY_NUMBER\tLIKELIHOOD\tREAD_PAIR\tMAPPABILITY\tOBSERVED_READS\tEXPECTED_READS\n");
+	}
+	if (params->have_dups) {
+		const std::string f = params->outdir + params->outprefix + "_dups.bed";
+		fprintf(stderr, "Output DUP file: %s\n", f.c_str());
+		fpDup = safe_fopen(f, "w");
+		fprintf(fpDup, "#CHR\tSTART_SV\tEND_SV\tCOPY_NUMBER\tLIKELIHOOD\tREAD_PAIR\tMAPPABILITY\tOBSERVED_READS\tEXPECTED_READS\n");
+	}
+
+	// ---- inputs (bam_data.c:253-267); the BED files are parsed once instead of once per chromosome
+	std::string err;
+	std::unique_ptr<read_source> src(open_reads(params->bam_file, &err));
+	if (!src)
+		print_error(err);
+	bed_index dels_bed, dups_bed, map_bed;
+	if (params->have_dels && !load_bed(params->del_file, false, &dels_bed))
+		print_error("[CONGA INPUT ERROR] Unable to open file " + params->del_file + " in read mode.");
+	if (params->have_dups && !load_bed(params->dup_file, false, &dups_bed))
+		print_error("[CONGA INPUT ERROR] Unable to open file " + params->dup_file + " in read mode.");
+	if (params->have_map && !load_bed(params->mappability_file, true, &map_bed))
+		print_error("[CONGA INPUT ERROR] Unable to open file " + params->mappability_file + " in read mode.");
+
+	conga_opts opts;
+	memset(&opts, 0, sizeof opts);
+	opts.struct_size = sizeof opts;
+	opts.mq_threshold = params->mq_threshold;
+	opts.gc_step = this_sonic->gc_step;
+	opts.flags = CONGA_FLAG_BATCH;
+	int status = 0;
+	conga_ctx *ctx = conga_create(params->device, &opts, &status);
+	if (!ctx) {
+		fprintf(stderr, "\n[CONGA ENGINE ERROR] cannot create a context on HIP device %d: %s\n", params->device,
+				conga_strerror(status));
+		return CONGA_EXIT_COMMON;
+	}
+
+	// ---- chromosome loop (bam_data.c:269-339)
+	std::vector<chrom_svs> work;
+	for (int chr_index = 0; chr_index < this_sonic->number_of_chromosomes; chr_index++) {
+		if (chr_index < params->first_chrom)
+			chr_index = params->first_chrom;
+		if (chr_index > params->last_chrom || chr_index >= this_sonic->number_of_chromosomes)
+			break;
+		const std::string &name = this_sonic->chromosome_names[chr_index];
+		if (name.find('X') != std::string::npos || name.find('Y') != std::string::npos)
+			continue; // strstr(name, "X") / "Y" (bam_data.c:280)
+		const int chr_index_bam = find_chr_index_bam(name, *src);
+		if (chr_index_bam == -1) {
+			fprintf(stderr, "\nCannot find chromosome name %s in BAM/CRAM %s", name.c_str(), src->sample_name().c_str());
+			continue;
+		}
+		const int64_t L = this_sonic->chromosome_lengths[chr_index];
+		fprintf(stderr, "\n");
+		fprintf(stderr, "Reading BAM [%s] - Chromosome: %s", src->sample_name().c_str(), src->target_name(chr_index_bam).c_str());
+
+		// init_rd_per_chr + the GC side of calc_mean_per_chr (read_distribution.c:12-18,63-73)
+		std::vector<uint8_t> gc_hist_w, gc_like_w;
+		gc_window_arrays(this_sonic, chr_index, &gc_hist_w, &gc_like_w);
+		engine_check(ctx, conga_chrom_begin(ctx, L, gc_hist_w.data(), gc_like_w.data(), (int64_t) gc_hist_w.size()),
+				"conga_chrom_begin");
+
+		fprintf(stderr, "\n-->counting reads");
+		const int64_t cnt_reads = count_reads_bam(ctx, src.get(), chr_index_bam, L);
+		fprintf(stderr, " (%lld reads, %ld split-reads)\n", (long long) cnt_reads, 0L);
+
+		// find_SVs, loading half (likelihood.c:319-336): BED rows are matched against the BAM's target name
+		chrom_svs cs;
+		cs.chr_name = src->target_name(chr_index_bam);
+		fprintf(stderr, "\nLoading known SVs");
+		if (params->have_dels)
+			cs.dels = known_SVs_for(dels_bed, cs.chr_name, params->min_sv_size);
+		if (params->have_dups)
+			cs.dups = known_SVs_for(dups_bed, cs.chr_name, params->min_sv_size);
+		fprintf(stderr, "(%d DELS, %d DUPS in chromosome %s - larger than the threshold %d)\n", (int) cs.dels.size(),
+				(int) cs.dups.size(), cs.chr_name.c_str(), params->min_sv_size);
+		std::vector<int32_t> s, e;
+		auto hand_over = [&](char type, const std::vector<sv_row> &rows) {
+			s.resize(rows.size());
+			e.resize(rows.size());
+			for (size_t i = 0; i < rows.size(); i++) {
+				s[i] = rows[i].start;
+				e[i] = rows[i].end;
+			}
+			engine_check(ctx, conga_intervals(ctx, type, s.data(), e.data(), rows.size()), "conga_intervals");
+		};
+		hand_over(CONGA_DELETION, cs.dels);
+		hand_over(CONGA_DUPLICATION, cs.dups);
+		if (params->have_map && cs.dels.size() + cs.dups.size() > 0) {
+			// load_mappability_regions (svs.c:317-377) runs only for chromosomes that have SVs (likelihood.c:332-356)
+			fprintf(stderr, "Finding mappability for each region\n");
+			auto it = map_bed.rows.find(cs.chr_name);
+			std::vector<int32_t> ms, me;
+			std::vector<float> mv;
+			if (it != map_bed.rows.end()) {
+				ms.resize(it->second.size());
+				me.resize(it->second.size());
+				for (size_t i = 0; i < it->second.size(); i++) {
+					ms[i] = it->second[i].start;
+					me[i] = it->second[i].end;
+				}
+				mv = map_bed.values[cs.chr_name];
+			}
+			engine_check(ctx, conga_mappability(ctx, ms.data(), me.data(), mv.data(), ms.size()), "conga_mappability");
+		}
+		work.push_back(std::move(cs));
+	}
+
+	// ---- calc_mean_per_chr + find_depths for every chromosome at once, then output in loop order
+	if (!work.empty()) {
+		fprintf(stderr, "\nCalculating Likelihoods\n");
+		engine_check(ctx, conga_chrom_compute(ctx), "conga_chrom_compute");
+		for (size_t i = 0; i < work.size(); i++) {
+			chrom_svs &cs = work[i];
+			cs.del_res.resize(cs.dels.size());
+			cs.dup_res.resize(cs.dups.size());
+			float expected_rd[101];
+			conga_chrom_stats st;
+			engine_check(ctx, conga_chrom_select(ctx, (int) i), "conga_chrom_select");
+			engine_check(ctx, conga_chrom_fetch(ctx, cs.del_res.data(), cs.dup_res.data(), expected_rd, &st), "conga_chrom_fetch");
+			// calc_mu_per_chr's log line (read_distribution.c:41)
+			fprintf(logFile, "Read Count:%li  Window count:%li mean=%f\n", (long) st.rd_sum,
+					(long) this_sonic->chromosome_lengths[sonic_refind_chromosome_index(this_sonic, cs.chr_name)], st.mean);
+			if (cs.dels.size() + cs.dups.size() == 0)
+				continue; // find_SVs returns before output_SVs when the chromosome has no SV (likelihood.c:332-336)
+			output_SVs(params, cs, fpSVs, fpDel, fpDup);
+		}
+	}
+	conga_destroy(ctx);
+
+	fprintf(stderr, "\n");
+	if (fpDel)
+		fclose(fpDel);
+	if (fpDup)
+		fclose(fpDup);
+	fclose(fpSVs);
+	return 0;
+}
+
+} // namespace conga_host

@@ -1,0 +1,388 @@
+// bam_reader.cpp -- minimal coordinate-sorted BAM source (BGZF + BAM records, optional .bai seek).
+//
+// htslib is an un-vendored submodule of the reference and absent from this image, so the BAM side of
+// count_reads_bam (bam_data.c:192-221) is re-implemented from the SAM/BAM specification: only the fixed
+// 32-byte record core is decoded (refID, pos, mapq, flag, l_seq) -- the depth path reads nothing else.
+// Record set (parity unpinned): all records with refID == tid and 0 <= pos < L, in
+// file order, which is what sam_itr_queryi(idx, tid, 0, L) + sam_itr_next yield (bam_data.c:293,201).
+// CRAM is not supported.  Inflate is zlib, single-threaded.
+#include <zlib.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "reads.h"
+
+namespace conga_host {
+
+namespace {
+
+class bgzf_reader {
+public:
+	~bgzf_reader()
+	{
+		if (f_)
+			fclose(f_);
+	}
+	bgzf_reader() {}
+	bgzf_reader(const bgzf_reader &) = delete;
+	bgzf_reader &operator=(const bgzf_reader &) = delete;
+	bool open(const std::string &path)
+	{
+		if (f_)
+			fclose(f_);
+		f_ = fopen(path.c_str(), "rb");
+		block_.clear();
+		at_ = 0;
+		eof_ = false;
+		err_.clear();
+		return f_ != nullptr;
+	}
+	// virtual offset = compressed block offset << 16 | offset inside the inflated block
+	bool seek(uint64_t voffset)
+	{
+		if (fseeko(f_, (off_t) (voffset >> 16), SEEK_SET) != 0)
+			return false;
+		block_.clear();
+		at_ = 0;
+		eof_ = false;
+		if (!load_block())
+			return false;
+		at_ = (size_t) (voffset & 0xFFFF);
+		return at_ <= block_.size();
+	}
+	// read exactly n bytes; false on EOF / error
+	bool read(void *dst, size_t n)
+	{
+		uint8_t *d = (uint8_t *) dst;
+		while (n) {
+			if (at_ == block_.size()) {
+				if (!load_block() || block_.empty())
+					return false;
+			}
+			const size_t k = std::min(n, block_.size() - at_);
+			memcpy(d, block_.data() + at_, k);
+			at_ += k;
+			d += k;
+			n -= k;
+		}
+		return true;
+	}
+	bool skip(size_t n)
+	{
+		while (n) {
+			if (at_ == block_.size()) {
+				if (!load_block() || block_.empty())
+					return false;
+			}
+			const size_t k = std::min(n, block_.size() - at_);
+			at_ += k;
+			n -= k;
+		}
+		return true;
+	}
+	bool at_eof()
+	{
+		while (at_ == block_.size()) {
+			if (eof_)
+				return true;
+			if (!load_block())
+				return true;
+		}
+		return false;
+	}
+	const std::string &error() const { return err_; }
+
+private:
+	bool load_block()
+	{
+		block_.clear();
+		at_ = 0;
+		for (;;) { // skip empty blocks (the EOF marker is one)
+			uint8_t h[12];
+			const size_t got = fread(h, 1, 12, f_);
+			if (got == 0) {
+				eof_ = true;
+				return true;
+			}
+			if (got != 12 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) {
+				err_ = "not a BGZF block";
+				return false;
+			}
+			const unsigned xlen = h[10] | (h[11] << 8);
+			std::vector<uint8_t> extra(xlen);
+			if (fread(extra.data(), 1, xlen, f_) != xlen) {
+				err_ = "truncated BGZF header";
+				return false;
+			}
+			int bsize = -1;
+			for (unsigned i = 0; i + 4 <= xlen;) {
+				const unsigned slen = extra[i + 2] | (extra[i + 3] << 8);
+				if (extra[i] == 'B' && extra[i + 1] == 'C' && slen == 2 && i + 6 <= xlen)
+					bsize = extra[i + 4] | (extra[i + 5] << 8);
+				i += 4 + slen;
+			}
+			if (bsize < 0) {
+				err_ = "BGZF block without BC field";
+				return false;
+			}
+			const int cdata = bsize - (int) xlen - 19; // total block = bsize + 1; header 12 + xlen; trailer 8
+			if (cdata < 0) {
+				err_ = "bad BGZF block size";
+				return false;
+			}
+			cbuf_.resize((size_t) cdata + 8);
+			if (fread(cbuf_.data(), 1, cbuf_.size(), f_) != cbuf_.size()) {
+				err_ = "truncated BGZF block";
+				return false;
+			}
+			uint32_t isize;
+			memcpy(&isize, cbuf_.data() + cdata + 4, 4);
+			if (isize == 0)
+				continue;
+			block_.resize(isize);
+			z_stream zs;
+			memset(&zs, 0, sizeof zs);
+			if (inflateInit2(&zs, -15) != Z_OK) {
+				err_ = "zlib init failed";
+				return false;
+			}
+			zs.next_in = cbuf_.data();
+			zs.avail_in = (uInt) cdata;
+			zs.next_out = block_.data();
+			zs.avail_out = isize;
+			const int rc = inflate(&zs, Z_FINISH);
+			inflateEnd(&zs);
+			if (rc != Z_STREAM_END || zs.avail_out != 0) {
+				err_ = "BGZF inflate failed";
+				return false;
+			}
+			return true;
+		}
+	}
+	FILE *f_ = nullptr;
+	std::vector<uint8_t> block_, cbuf_;
+	size_t at_ = 0;
+	bool eof_ = false;
+	std::string err_;
+};
+
+class bam_file : public read_source {
+public:
+	bool open(const std::string &path, std::string *err)
+	{
+		path_ = path;
+		if (!bgzf_.open(path) || !read_header(err)) {
+			if (err->empty())
+				*err = "[CONGA INPUT ERROR] Unable to open file " + path + " in read mode.";
+			return false;
+		}
+		load_bai(path + ".bai");
+		return true;
+	}
+	int n_targets() const override { return (int) names_.size(); }
+	const std::string &target_name(int tid) const override { return names_[tid]; }
+	const std::string &sample_name() const override { return sample_; }
+
+	bool begin(int tid, int64_t chrom_len, std::string *err) override
+	{
+		tid_ = tid;
+		len_ = chrom_len;
+		done_ = false;
+		if (tid < (int) ref_beg_.size() && ref_beg_[tid] != 0) {
+			if (!bgzf_.seek(ref_beg_[tid])) {
+				*err = "BAM seek failed";
+				return false;
+			}
+			have_pending_ = false;
+			last_ref_ = -2;
+		} else if (last_ref_ > tid || last_ref_ == -1) {
+			// no index and the file position is already past this target: start over
+			have_pending_ = false;
+			if (!bgzf_.open(path_) || !read_header(err))
+				return false;
+		}
+		// otherwise keep scanning forward; a record already read for a later target stays pending
+		return true;
+	}
+
+	bool next(size_t max_n, read_batch *out, std::string *err) override
+	{
+		pos_.clear();
+		mapq_.clear();
+		while (!done_ && pos_.size() < max_n) {
+			core c;
+			if (have_pending_) {
+				c = pending_;
+				have_pending_ = false;
+			} else if (!read_core(&c, err)) {
+				if (!err->empty())
+					return false;
+				done_ = true; // end of file
+				break;
+			}
+			last_ref_ = c.ref_id;
+			if (c.ref_id >= 0 && c.ref_id < tid_)
+				continue; // earlier target (sequential scan without an index)
+			if (c.ref_id != tid_) {
+				// sorted file: a later target (or the unplaced tail, refID -1) ends this one
+				pending_ = c;
+				have_pending_ = true;
+				done_ = true;
+				break;
+			}
+			if (c.pos < 0)
+				continue;
+			if (c.pos >= len_) {
+				done_ = true;
+				break;
+			}
+			pos_.push_back(c.pos);
+			mapq_.push_back(c.mapq);
+		}
+		out->pos = pos_.data();
+		out->mapq = mapq_.data();
+		out->n = pos_.size();
+		return true;
+	}
+
+private:
+	struct core {
+		int32_t ref_id, pos;
+		uint8_t mapq;
+		uint16_t flag;
+		int32_t l_seq;
+	};
+
+	bool read_header(std::string *err)
+	{
+		char magic[4];
+		int32_t l_text, n_ref;
+		if (!bgzf_.read(magic, 4) || memcmp(magic, "BAM\1", 4) != 0 || !bgzf_.read(&l_text, 4) || l_text < 0) {
+			*err = path_ + ": not a BAM file" + (bgzf_.error().empty() ? "" : " (" + bgzf_.error() + ")");
+			return false;
+		}
+		std::string text((size_t) l_text, '\0');
+		if (!bgzf_.read(&text[0], (size_t) l_text) || !bgzf_.read(&n_ref, 4) || n_ref < 0) {
+			*err = path_ + ": truncated BAM header";
+			return false;
+		}
+		names_.clear();
+		for (int i = 0; i < n_ref; i++) {
+			int32_t l_name, l_ref;
+			if (!bgzf_.read(&l_name, 4) || l_name <= 0) {
+				*err = path_ + ": truncated BAM header";
+				return false;
+			}
+			std::string name((size_t) l_name, '\0');
+			if (!bgzf_.read(&name[0], (size_t) l_name) || !bgzf_.read(&l_ref, 4)) {
+				*err = path_ + ": truncated BAM header";
+				return false;
+			}
+			name.resize(strlen(name.c_str()));
+			names_.push_back(name);
+		}
+		// get_sample_name (common.c:325-352): first token (split on tab / newline) that starts with "SM"
+		sample_.clear();
+		size_t i = 0;
+		while (i < text.size()) {
+			size_t j = text.find_first_of("\t\n", i);
+			if (j == std::string::npos)
+				j = text.size();
+			if (j - i >= 3 && text[i] == 'S' && text[i + 1] == 'M') {
+				sample_ = text.substr(i + 3, j - i - 3);
+				break;
+			}
+			i = j + 1;
+		}
+		last_ref_ = -2;
+		return true;
+	}
+
+	// next record's fixed core; false with empty *err at end of file
+	bool read_core(core *c, std::string *err)
+	{
+		if (bgzf_.at_eof()) {
+			if (!bgzf_.error().empty())
+				*err = bgzf_.error();
+			return false;
+		}
+		int32_t block_size;
+		uint8_t b[32];
+		if (!bgzf_.read(&block_size, 4) || block_size < 32 || !bgzf_.read(b, 32)) {
+			*err = "truncated BAM record";
+			return false;
+		}
+		memcpy(&c->ref_id, b, 4);
+		memcpy(&c->pos, b + 4, 4);
+		c->mapq = b[9];
+		memcpy(&c->flag, b + 14, 2);
+		memcpy(&c->l_seq, b + 16, 4);
+		if (!bgzf_.skip((size_t) block_size - 32)) {
+			*err = "truncated BAM record";
+			return false;
+		}
+		return true;
+	}
+
+	// .bai: only the smallest chunk start per reference is kept (whole-chromosome queries)
+	void load_bai(const std::string &path)
+	{
+		FILE *f = fopen(path.c_str(), "rb");
+		if (!f)
+			return;
+		char magic[4];
+		int32_t n_ref;
+		std::vector<uint64_t> beg;
+		bool ok = fread(magic, 1, 4, f) == 4 && memcmp(magic, "BAI\1", 4) == 0 && fread(&n_ref, 4, 1, f) == 1 && n_ref >= 0;
+		for (int r = 0; ok && r < n_ref; r++) {
+			int32_t n_bin;
+			uint64_t first = 0;
+			ok = fread(&n_bin, 4, 1, f) == 1 && n_bin >= 0;
+			for (int b = 0; ok && b < n_bin; b++) {
+				uint32_t bin;
+				int32_t n_chunk;
+				ok = fread(&bin, 4, 1, f) == 1 && fread(&n_chunk, 4, 1, f) == 1 && n_chunk >= 0;
+				for (int k = 0; ok && k < n_chunk; k++) {
+					uint64_t ce[2];
+					ok = fread(ce, 8, 2, f) == 2;
+					if (ok && bin != 37450 && (first == 0 || ce[0] < first))
+						first = ce[0];
+				}
+			}
+			int32_t n_intv;
+			ok = ok && fread(&n_intv, 4, 1, f) == 1 && n_intv >= 0 && fseeko(f, (off_t) n_intv * 8, SEEK_CUR) == 0;
+			beg.push_back(first);
+		}
+		fclose(f);
+		if (ok && (int) beg.size() == n_targets())
+			ref_beg_ = beg;
+	}
+
+	std::string path_, sample_;
+	bgzf_reader bgzf_;
+	std::vector<std::string> names_;
+	std::vector<uint64_t> ref_beg_;
+	std::vector<int32_t> pos_;
+	std::vector<uint8_t> mapq_;
+	int tid_ = -1, last_ref_ = -2;
+	int64_t len_ = 0;
+	bool done_ = false, have_pending_ = false;
+	core pending_{};
+};
+
+} // namespace
+
+read_source *open_bam(const std::string &path, std::string *err)
+{
+	bam_file *b = new bam_file();
+	if (!b->open(path, err)) {
+		delete b;
+		return nullptr;
+	}
+	return b;
+}
+
+} // namespace conga_host

@@ -1,0 +1,178 @@
+#include "reads.h"
+
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <fcntl.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstring>
+
+namespace conga_host {
+
+read_source *open_bam(const std::string &path, std::string *err); // bam_reader.cpp
+
+namespace {
+
+// Memory-mapped CONGATP1 container (layout: conga_amd/formats.py write_tuples).
+class tuple_file : public read_source {
+public:
+	~tuple_file() override
+	{
+		if (map_ && map_ != MAP_FAILED)
+			munmap(map_, size_);
+		if (fd_ >= 0)
+			close(fd_);
+	}
+	bool open(const std::string &path, std::string *err)
+	{
+		fd_ = ::open(path.c_str(), O_RDONLY);
+		struct stat st;
+		if (fd_ < 0 || fstat(fd_, &st) != 0) {
+			*err = "cannot open " + path;
+			return false;
+		}
+		size_ = (size_t) st.st_size;
+		map_ = mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0);
+		if (map_ == MAP_FAILED) {
+			*err = "cannot map " + path;
+			return false;
+		}
+		const uint8_t *p = (const uint8_t *) map_, *end = p + size_;
+		auto need = [&](size_t n) { return (size_t) (end - p) >= n; };
+		if (!need(8) || memcmp(p, "CONGATP1", 8) != 0) {
+			*err = path + ": not a CONGATP1 read-tuple container";
+			return false;
+		}
+		p += 8;
+		uint16_t ln;
+		if (!need(2))
+			return trunc(err);
+		memcpy(&ln, p, 2);
+		p += 2;
+		if (!need(ln))
+			return trunc(err);
+		sample_.assign((const char *) p, ln);
+		p += ln;
+		int32_t n;
+		if (!need(4))
+			return trunc(err);
+		memcpy(&n, p, 4);
+		p += 4;
+		if (n < 0)
+			return trunc(err);
+		for (int c = 0; c < n; c++) {
+			if (!need(2))
+				return trunc(err);
+			memcpy(&ln, p, 2);
+			p += 2;
+			if (!need((size_t) ln + 17))
+				return trunc(err);
+			entry e;
+			e.name.assign((const char *) p, ln);
+			p += ln;
+			memcpy(&e.length, p, 8);
+			memcpy(&e.n, p + 8, 8);
+			e.ext = p[16];
+			p += 17;
+			if (e.n < 0)
+				return trunc(err);
+			chroms_.push_back(e);
+		}
+		for (entry &e : chroms_) {
+			const size_t bytes = (size_t) e.n * (5 + (e.ext ? 6 : 0));
+			if (!need(bytes))
+				return trunc(err);
+			e.pos = (const int32_t *) p;
+			e.mapq = p + (size_t) e.n * 4;
+			p += bytes;
+		}
+		return true;
+	}
+	int n_targets() const override { return (int) chroms_.size(); }
+	const std::string &target_name(int tid) const override { return chroms_[tid].name; }
+	const std::string &sample_name() const override { return sample_; }
+	bool begin(int tid, int64_t chrom_len, std::string *err) override
+	{
+		if (tid < 0 || tid >= (int) chroms_.size()) {
+			*err = "bad target id";
+			return false;
+		}
+		cur_ = tid;
+		off_ = 0;
+		len_ = chrom_len;
+		return true;
+	}
+	bool next(size_t max_n, read_batch *out, std::string *) override
+	{
+		const entry &e = chroms_[cur_];
+		// records are coordinate-sorted: skip pos < 0, stop at the first pos >= L (region [0, L))
+		while (off_ < e.n && e.pos[off_] < 0)
+			off_++;
+		size_t n = 0;
+		while (off_ + (int64_t) n < e.n && n < max_n && e.pos[off_ + n] < len_)
+			n++;
+		out->pos = e.pos + off_;
+		out->mapq = e.mapq + off_;
+		out->n = n;
+		off_ += (int64_t) n;
+		return true;
+	}
+
+private:
+	struct entry {
+		std::string name;
+		int64_t length = 0, n = 0;
+		int ext = 0;
+		const int32_t *pos = nullptr;
+		const uint8_t *mapq = nullptr;
+	};
+	bool trunc(std::string *err)
+	{
+		*err = "truncated read-tuple container";
+		return false;
+	}
+	int fd_ = -1;
+	void *map_ = nullptr;
+	size_t size_ = 0;
+	std::string sample_;
+	std::vector<entry> chroms_;
+	int cur_ = -1;
+	int64_t off_ = 0, len_ = 0;
+};
+
+} // namespace
+
+read_source *open_reads(const std::string &path, std::string *err)
+{
+	FILE *f = fopen(path.c_str(), "rb");
+	if (!f) {
+		*err = "[CONGA INPUT ERROR] Unable to open file " + path + " in read mode.";
+		return nullptr;
+	}
+	unsigned char magic[8] = {0};
+	const size_t got = fread(magic, 1, 8, f);
+	fclose(f);
+	if (got == 8 && memcmp(magic, "CONGATP1", 8) == 0) {
+		tuple_file *t = new tuple_file();
+		if (!t->open(path, err)) {
+			delete t;
+			return nullptr;
+		}
+		return t;
+	}
+	if (got >= 2 && magic[0] == 0x1f && magic[1] == 0x8b) // gzip member: BGZF-compressed BAM
+		return open_bam(path, err);
+	*err = path + ": neither a BAM nor a CONGATP1 read-tuple container (CRAM is not supported)";
+	return nullptr;
+}
+
+int find_chr_index_bam(const std::string &chromosome_name, const read_source &src)
+{
+	for (int i = 0; i < src.n_targets(); i++)
+		if (src.target_name(i) == chromosome_name)
+			return i;
+	return -1;
+}
+
+} // namespace conga_host

@@ -1,0 +1,33 @@
+// reads.h -- the record source of count_reads_bam (bam_data.c:192-221).
+// Two containers are understood: this implementation's read-tuple container (.ctp, conga_amd/formats.py)
+// and coordinate-sorted BAM (bam_reader.cpp; needs the .bai only for random access, not used here).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace conga_host {
+
+struct read_batch {
+	const int32_t *pos;
+	const uint8_t *mapq;
+	size_t n;
+};
+
+class read_source {
+public:
+	virtual ~read_source() {}
+	// header: bam_hdr_t.n_targets / target_name (find_chr_index_bam, common.c:289-300)
+	virtual int n_targets() const = 0;
+	virtual const std::string &target_name(int tid) const = 0;
+	virtual const std::string &sample_name() const = 0; // @RG SM (get_sample_name, common.c:325-352)
+	// Iterate the records of target `tid` with 0 <= pos < chrom_len, in file order, at most max_n at a time
+	// (the analogue of sam_itr_queryi(idx, tid, 0, L) + sam_itr_next: bam_data.c:293,201).
+	virtual bool begin(int tid, int64_t chrom_len, std::string *err) = 0;
+	virtual bool next(size_t max_n, read_batch *out, std::string *err) = 0;
+};
+
+read_source *open_reads(const std::string &path, std::string *err);
+int find_chr_index_bam(const std::string &chromosome_name, const read_source &src); // common.c:289-300
+
+} // namespace conga_host

@@ -1,0 +1,178 @@
+"""The `conga` command line (conga_amd/host): flags, messages and exit codes of the reference
+(cmdline.c, svdepth.c), its BED / BAM / annotation readers, and -- on the GPU -- the three output files
+byte for byte against the oracle's writer (likelihood.c:172-288, bam_data.c:235-249)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conga_amd import formats, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONGA = os.path.join(ROOT, "conga_amd", "host", "conga")
+
+
+def run(args, cwd):
+    return subprocess.run([CONGA] + args, cwd=cwd, capture_output=True, text=True, timeout=600)
+
+
+def make_inputs(d, with_bam=True):
+    specs = [("1", 400_000, 30, 8), ("2", 250_000, 20, 5), ("X", 100_000, 5, 0), ("3", 90_000, 0, 0), ("4", 300_000, 25, 6)]
+    cs = [synth.make_chrom(n, L, cov=2.0, n_dels=nd, n_dups=nu, mappability=True, gaps=False) for n, L, nd, nu in specs]
+    formats.write_annotation(os.path.join(d, "a.cga"), [(c.name, c.length, c.gc, [], []) for c in cs])
+    in_bam = [c for c in cs if c.name != "4"]          # chromosome 4 is missing from the alignment file
+    formats.write_tuples(os.path.join(d, "r.ctp"), "NA00001", [(c.name, c.length, c.pos, c.mapq) for c in in_bam])
+    if with_bam:
+        formats.write_bam(os.path.join(d, "r.bam"), "NA00001", [(c.name, c.length, c.pos, c.mapq) for c in in_bam], unplaced=5)
+    rows_d, rows_u, rows_m = [], [], []
+    rng = np.random.default_rng(1)
+    for c in cs:
+        rows_d += [(c.name, s, e) for s, e in zip(c.del_start, c.del_end)]
+        rows_u += [(c.name, s, e) for s, e in zip(c.dup_start, c.dup_end)]
+        rows_m += [(c.name, s, e, "%g" % v) for s, e, v in zip(c.map_start, c.map_end, c.map_val)]
+    rng.shuffle(rows_d)                                   # the reference sorts per chromosome
+    synth.write_bed(os.path.join(d, "dels.bed"), [("#chr", "start", "end")] + rows_d)
+    synth.write_bed(os.path.join(d, "dups.bed"), rows_u)
+    synth.write_bed(os.path.join(d, "map.bed"), rows_m)
+    return cs, in_bam
+
+
+def test_help_version_and_required_options(tmp_path):
+    d = str(tmp_path)
+    r = run([], d)
+    assert r.returncode == 0 and "--dels [BED file]" in r.stdout and "--mapability [BED file]" in r.stdout
+    r = run(["--help"], d)
+    assert r.returncode == 0 and "CONGA (COpy Number variation Genotyping in Ancient genomes)" in r.stdout
+    r = run(["--version"], d)
+    assert r.returncode == 0 and "CONGA Version" in r.stderr
+    r = run(["-i", "x.bam", "--ref", "r.fa"], d)
+    assert r.returncode == 1 and "[CONGA CMDLINE ERROR] Please enter the output file name prefix using the --out option." in r.stderr
+    r = run(["-i", "x.bam", "--out", "o"], d)
+    assert r.returncode == 1 and "Please enter reference genome file (FASTA) using the --ref option." in r.stderr
+    assert os.path.exists(os.path.join(d, "conga.log"))  # always created in the working directory (svdepth.c:30)
+
+
+def test_missing_files_exit_like_print_error(tmp_path):
+    d = str(tmp_path)
+    r = run(["-i", "nope.bam", "--out", "o", "--ref", "r.fa", "--sonic", "nope.sonic"], d)
+    assert r.returncode == 1 and "Invoke parameter -h for help." in r.stderr
+
+
+def test_defaults_are_announced_and_out_is_split(tmp_path):
+    d = str(tmp_path)
+    make_inputs(d, with_bam=False)
+    os.mkdir(os.path.join(d, "res"))
+    r = run(["-i", "r.ctp", "--out", "res/sampleA", "--ref", "r.fa", "--sonic", "a.cga", "--dels", "dels.bed",
+             "--dump-intervals", "1"], d)
+    assert r.returncode == 0
+    assert "Minimum size of an SV is set to 1000" in r.stderr and "Minimum size of a read is set to 60" in r.stderr
+    assert "[CONGA INFO] Working directory: res/" in r.stderr and "prefix: sampleA" in r.stderr
+
+
+def test_interval_loading_matches_the_oracle(tmp_path, oracle):
+    d = str(tmp_path)
+    make_inputs(d, with_bam=False)
+    for chrom in ("1", "2", "X", "9"):
+        for minsize in (None, 3000):
+            args = ["-i", "r.ctp", "--out", "o", "--ref", "r.fa", "--sonic", "a.cga", "--dels", "dels.bed", "--dups",
+                    "dups.bed", "--dump-intervals", chrom] + (["--min-sv-size", str(minsize)] if minsize else [])
+            r = run(args, d)
+            assert r.returncode == 0
+            got = [tuple(l.split("\t")) for l in r.stdout.splitlines() if l.startswith(("DEL", "DUP"))]
+            want = []
+            for tag, f in (("DEL", "dels.bed"), ("DUP", "dups.bed")):
+                svs = oracle.sort_svs(oracle.load_known_SVs(os.path.join(d, f), chrom, minsize or 1000))
+                want += [(tag, chrom, str(s), str(e)) for s, e in zip(svs["start"], svs["end"])]
+            assert got == want
+
+
+def test_bam_and_tuple_readers_yield_the_same_records(tmp_path):
+    d = str(tmp_path)
+    cs, in_bam = make_inputs(d)
+    outs = []
+    for inp in ("r.ctp", "r.bam"):
+        r = run(["-i", inp, "--out", "o", "--ref", "r.fa", "--sonic", "a.cga", "--dump-reads"], d)
+        assert r.returncode == 0, r.stderr
+        outs.append([l for l in r.stdout.splitlines() if "\t" in l and not l.startswith(("BAM", "Ref", "SONIC"))])
+    assert outs[0] == outs[1]
+    lines = dict(l.split("\t", 1) for l in outs[0])
+    assert lines["sample"] == "NA00001"
+    assert lines["4"] == "missing" and "X" not in lines
+    for c in in_bam:
+        if c.name != "X":
+            assert lines[c.name] == "%d\t%d\t%d" % (len(c.pos), c.pos.astype(np.int64).sum(), c.mapq.astype(np.int64).sum())
+
+
+def test_reads_past_the_annotated_length_are_not_returned(tmp_path):
+    """sam_itr_queryi(idx, tid, 0, L) yields only pos < L (L from the annotation, not the BAM header)."""
+    d = str(tmp_path)
+    pos = np.array([5, 10, 999, 1000, 1500], np.int32)
+    mapq = np.array([1, 2, 3, 4, 5], np.uint8)
+    formats.write_annotation(os.path.join(d, "a.cga"), [("1", 1000, np.full(10, 40, np.uint8), [], [])])
+    formats.write_bam(os.path.join(d, "r.bam"), "s", [("1", 2000, pos, mapq)])
+    r = run(["-i", "r.bam", "--out", "o", "--ref", "r.fa", "--sonic", "a.cga", "--dump-reads"], d)
+    assert "1\t3\t1014\t6" in r.stdout
+
+
+def _oracle_files(oracle, d, cs, in_bam, *, dels, dups, with_map, mq, c_score=0.5):
+    paths = [os.path.join(d, "want_%s.bed" % k) for k in ("svs", "dels", "dups")]
+    first = True
+    names_in_bam = {c.name for c in in_bam}
+    any_rows = False
+    for c in cs:
+        if "X" in c.name or "Y" in c.name or c.name not in names_in_bam:
+            continue
+        ds = oracle.sort_svs(oracle.load_known_SVs(os.path.join(d, "dels.bed"), c.name, 1000)) if dels else None
+        us = oracle.sort_svs(oracle.load_known_SVs(os.path.join(d, "dups.bed"), c.name, 1000)) if dups else None
+        if (0 if ds is None else len(ds)) + (0 if us is None else len(us)) == 0:
+            continue
+        rd, _ = oracle.count_reads(c.length, c.pos, c.mapq, mq)
+        E, _, _ = oracle.calc_mean_per_chr(rd, c.gc)
+        m = oracle.load_mappability_regions(os.path.join(d, "map.bed"), c.name, c.length)[0] if with_map else None
+        if ds is not None:
+            oracle.find_depths(rd, m, c.gc, E, "D", ds)
+        if us is not None:
+            oracle.find_depths(rd, m, c.gc, E, "E", us)
+        oracle.output_svs(c.name, ds, us, paths[0], paths[1] if dels else None, paths[2] if dups else None,
+                          have_mappability=with_map, c_score=c_score, write_headers=first)
+        first = False
+        any_rows = True
+    assert any_rows
+    return paths
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("inp,dels,dups,with_map,mq,c_score", [
+    ("r.ctp", True, True, True, -1, None),
+    ("r.bam", True, False, False, -1, None),
+    ("r.bam", True, True, False, 30, "0.3"),
+    ("r.ctp", False, True, True, 0, None),
+])
+def test_cli_outputs_are_byte_identical_to_the_oracle(tmp_path, oracle, inp, dels, dups, with_map, mq, c_score):
+    d = str(tmp_path)
+    cs, in_bam = make_inputs(d)
+    args = ["-i", inp, "--out", "got", "--ref", "r.fa", "--sonic", "a.cga"]
+    if dels:
+        args += ["--dels", "dels.bed"]
+    if dups:
+        args += ["--dups", "dups.bed"]
+    if with_map:
+        args += ["--mappability", "map.bed"]
+    if mq >= 0:
+        args += ["--min-mapq", str(mq)]
+    if c_score:
+        args += ["--c-score", c_score]
+    r = run(args, d)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Cannot find chromosome name 4 in BAM/CRAM NA00001" in r.stderr
+    assert "Thank you" in r.stderr and "Hope to see you again..." in r.stderr
+    want = _oracle_files(oracle, d, cs, in_bam, dels=dels, dups=dups, with_map=with_map, mq=mq,
+                         c_score=float(np.float32(c_score)) if c_score else 0.5)
+    for k, have, w in (("svs", True, want[0]), ("dels", dels, want[1]), ("dups", dups, want[2])):
+        got_path = os.path.join(d, "got_%s.bed" % k)
+        assert os.path.exists(got_path) == have
+        if have:
+            assert open(got_path, "rb").read() == open(w, "rb").read(), k
+    log = open(os.path.join(d, "conga.log")).read()
+    assert "#CreationDate=" in log and "Read Count:" in log and "mean=" in log
