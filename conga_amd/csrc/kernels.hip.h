@@ -96,51 +96,107 @@ template <typename KeyOf> __device__ __forceinline__ int find_slot(int n_slots, 
 //     tuples are filed under their chromosome's first / last tile, where the depth kernel's range
 //     check drops them.
 // -------------------------------------------------------------------------------------------
-__device__ __forceinline__ int64_t global_tile_of(const Slot &sl, int32_t p, uint32_t tile_len)
+// p / tile_len in 32-bit arithmetic: a float estimate is at most 1 off (relative error 2^-23 on a quotient
+// below 2^21), and one multiply-subtract settles it.
+__device__ __forceinline__ uint32_t div_tile(uint32_t p, uint32_t tile_len, float inv_tile_len)
+{
+	uint32_t q = (uint32_t) ((float) p * inv_tile_len);
+	const int32_t r = (int32_t) (p - q * tile_len);
+	if (r < 0)
+		q--;
+	else if ((uint32_t) r >= tile_len)
+		q++;
+	return q;
+}
+
+struct IngestSlot { // the fields of a Slot this kernel needs, in 32 bits
+	uint32_t r0, r1;   // tuple index range
+	int32_t L;
+	uint32_t tile0, last_tile;
+};
+
+__device__ __forceinline__ IngestSlot ingest_slot(const Slot &sl)
+{
+	IngestSlot o;
+	o.r0 = (uint32_t) sl.read_off;
+	o.r1 = (uint32_t) (sl.read_off + sl.n_reads);
+	o.L = (int32_t) sl.L;
+	o.tile0 = (uint32_t) sl.tile0;
+	o.last_tile = (uint32_t) (sl.tile0 + sl.n_tiles - 1);
+	return o;
+}
+
+__device__ __forceinline__ uint32_t global_tile_of(const IngestSlot &sl, int32_t p, uint32_t tile_len, float inv_tile_len)
 {
 	if (p < 0)
 		return sl.tile0;
 	if (p >= sl.L)
-		return sl.tile0 + sl.n_tiles - 1;
-	return sl.tile0 + (uint32_t) p / tile_len;
+		return sl.last_tile;
+	return sl.tile0 + div_tile((uint32_t) p, tile_len, inv_tile_len);
 }
 
-__global__ __launch_bounds__(256) void ingest_kernel(const int32_t *__restrict__ pos, int64_t n_total,
-		const Slot *__restrict__ slots, int n_slots, int32_t tile_len, uint32_t *__restrict__ tile_first,
+__global__ __launch_bounds__(256) void ingest_kernel(const int32_t *__restrict__ pos, int64_t n_total64,
+		const Slot *__restrict__ slots, int n_slots, int32_t tile_len_, uint32_t *__restrict__ tile_first,
 		Small *__restrict__ small)
 {
-	const int64_t stride = (int64_t) gridDim.x * blockDim.x;
-	// the few Slot fields this kernel needs, refreshed only when the tuple index leaves the chromosome
+	const uint32_t n_total = (uint32_t) n_total64; // < 2^32 - 16 (conga_reads_commit)
+	const uint32_t tile_len = (uint32_t) tile_len_;
+	const float inv_T = 1.0f / (float) tile_len;
+	const uint64_t stride = (uint64_t) gridDim.x * blockDim.x * 4;
 	int s = -1;
-	int64_t r0 = 0, r1 = 0;
-	Slot sl;
-	for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_total; i += stride) {
-		if (i < r0 || i >= r1) {
-			s = find_slot(n_slots, i, [&](int k) { return slots[k].read_off; });
-			sl = slots[s];
-			r0 = sl.read_off;
-			r1 = sl.read_off + sl.n_reads;
+	IngestSlot sl = {1, 0, 0, 0, 0}; // empty range: the first tuple refreshes it
+	// four tuples (one 16-byte load) per lane per step: the kernel is bound by bytes in flight
+	for (uint64_t i0 = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) * 4; i0 < n_total; i0 += stride) {
+		int32_t p4[4];
+		if (i0 + 4 <= n_total) {
+			const int4 q = *reinterpret_cast<const int4 *>(pos + i0);
+			p4[0] = q.x;
+			p4[1] = q.y;
+			p4[2] = q.z;
+			p4[3] = q.w;
+		} else {
+			for (int e = 0; e < 4; e++)
+				p4[e] = (i0 + e < n_total) ? pos[i0 + e] : 0;
 		}
-		const int32_t p = pos[i];
-		if (p < 0 || p >= sl.L)
-			atomicAdd(&small[s].counters[CNT_OUT_OF_RANGE], 1ull);
-		const int64_t t_cur = global_tile_of(sl, p, (uint32_t) tile_len);
-		int64_t t_prev = -1;
-		if (i > 0) {
-			const int32_t prev = pos[i - 1];
-			if (i > r0) { // same chromosome
-				if (p < prev)
-					atomicOr(&small[s].status, kStatusUnsorted);
-				t_prev = global_tile_of(sl, prev, (uint32_t) tile_len);
-			} else {
-				// first tuple of this chromosome: the previous tuple belongs to an earlier one
-				const int sp = find_slot(n_slots, i - 1, [&](int k) { return slots[k].read_off; });
-				t_prev = global_tile_of(slots[sp], prev, (uint32_t) tile_len);
+		int32_t prev = (i0 > 0) ? pos[i0 - 1] : 0;
+		uint32_t t_prev = 0;
+		bool t_prev_known = false; // t_prev is the global tile of `prev`, which lies in the same chromosome
+#pragma unroll
+		for (int e = 0; e < 4; e++) {
+			const uint32_t i = (uint32_t) i0 + e;
+			if (i >= n_total)
+				break;
+			if (i < sl.r0 || i >= sl.r1) {
+				s = find_slot(n_slots, (int64_t) i, [&](int k) { return slots[k].read_off; });
+				sl = ingest_slot(slots[s]);
+				t_prev_known = false;
 			}
+			const int32_t p = p4[e];
+			if (p < 0 || p >= sl.L)
+				atomicAdd(&small[s].counters[CNT_OUT_OF_RANGE], 1ull);
+			const uint32_t t_cur = global_tile_of(sl, p, tile_len, inv_T);
+			int64_t first_fill;
+			if (i == 0)
+				first_fill = 0;
+			else {
+				if (i > sl.r0) { // `prev` is in the same chromosome
+					if (p < prev)
+						atomicOr(&small[s].status, kStatusUnsorted);
+					if (!t_prev_known)
+						t_prev = global_tile_of(sl, prev, tile_len, inv_T);
+				} else {
+					// first tuple of this chromosome: the previous tuple belongs to an earlier one
+					const int sp = find_slot(n_slots, (int64_t) i - 1, [&](int k) { return slots[k].read_off; });
+					t_prev = global_tile_of(ingest_slot(slots[sp]), prev, tile_len, inv_T);
+				}
+				first_fill = (int64_t) t_prev + 1;
+			}
+			for (int64_t t = first_fill; t <= (int64_t) t_cur; t++)
+				tile_first[t] = i;
+			prev = p;
+			t_prev = t_cur;
+			t_prev_known = true;
 		}
-		if (t_prev != t_cur)
-			for (int64_t t = t_prev + 1; t <= t_cur; t++)
-				tile_first[t] = (uint32_t) i;
 	}
 }
 
@@ -681,14 +737,26 @@ struct ChainArgs {
 	float *expected; // [n_iv]
 };
 
+// Inclusive prefix sum over a lane group through DPP (no LDS crossbar): row_shr 1/2/4/8 inside each
+// 16-lane row, then row_bcast:15 / row_bcast:31 to carry row totals across the wave (gfx9 wave64).
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_add(uint32_t v)
+{
+	// lanes without a source (shifted in from outside the row / masked rows) add 0
+	return v + (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, CTRL, ROW_MASK, 0xF, false);
+}
+
 template <int G> __device__ __forceinline__ uint32_t group_incl_scan_u32(uint32_t v, int gl)
 {
-#pragma unroll
-	for (int o = 1; o < G; o <<= 1) {
-		const uint32_t t = __shfl_up(v, o, G);
-		if (gl >= o)
-			v += t;
+	static_assert(G == 16 || G == 64, "lane groups are one DPP row or the whole wave");
+	v = dpp_add<0x111, 0xF>(v); // row_shr:1
+	v = dpp_add<0x112, 0xF>(v); // row_shr:2
+	v = dpp_add<0x114, 0xF>(v); // row_shr:4
+	v = dpp_add<0x118, 0xF>(v); // row_shr:8
+	if (G == 64) {
+		v = dpp_add<0x142, 0xA>(v); // row_bcast:15 -> rows 1 and 3
+		v = dpp_add<0x143, 0xC>(v); // row_bcast:31 -> rows 2 and 3
 	}
+	(void) gl;
 	return v;
 }
 
@@ -700,6 +768,9 @@ __device__ __forceinline__ float compose_f32(uint32_t es, uint32_t ms)
 template <int G> __global__ __launch_bounds__(256) void interval_chain_kernel(ChainArgs a)
 {
 	constexpr int kGroups = kWave / G;
+	constexpr int kBlockGroups = 256 / G;
+	__shared__ float sE[kBlockGroups][kGcBins + 3]; // one expected_read_depth table per lane group
+
 	const int lane = threadIdx.x & (kWave - 1);
 	const int gl = lane & (G - 1);  // lane inside the group
 	const int grp = lane / G;       // group inside the wave
@@ -707,38 +778,45 @@ template <int G> __global__ __launch_bounds__(256) void interval_chain_kernel(Ch
 	const int64_t wave = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) / kWave;
 	const int64_t slot_idx = wave * kGroups + grp;
 	const bool have = slot_idx < a.count;
+	float *E = sE[threadIdx.x / G];
 
 	int32_t iv = 0;
-	int64_t s0 = 0, e0 = 0, w_first = 0, w_end = 0, gc_off = 0, n_win = 1;
-	const float *E = a.small[0].E;
+	int64_t s0 = 0, e0 = 0, w_first = 0, w_end = 0, n_win = 1;
+	const uint8_t *gc = a.gc_like;
 	if (have) {
 		iv = a.order[a.first + slot_idx];
 		s0 = a.start[iv];
 		e0 = a.end[iv];
 		const int sl = a.iv_slot[iv];
-		gc_off = a.slots[sl].gc_off;
+		gc = a.gc_like + a.slots[sl].gc_off;
 		n_win = a.slots[sl].n_win;
-		E = a.small[sl].E;
+		const float *Eg = a.small[sl].E;
+		for (int g = gl; g < kGcBins; g += G)
+			E[g] = Eg[g];
 		if (e0 > s0) {
 			w_first = (uint32_t) s0 / (uint32_t) a.step;
 			w_end = (uint32_t) (e0 - 1) / (uint32_t) a.step + 1;
 		}
 	}
+	__builtin_amdgcn_wave_barrier(); // the table is written and read by lanes of the same wave: LDS ops stay in order
 	const int64_t step = a.step;
 
 	float s = 0.0f; // uniform inside a group
 	int64_t wb = w_first;
+	// the GC byte of this lane's window in the NEXT step is requested one step ahead
+	uint32_t g_cur = (wb + gl < w_end) ? gc[(wb + gl < n_win) ? wb + gl : n_win - 1] : 0;
 	while (__any(wb < w_end)) {
 		const int64_t w = wb + gl;
 		const bool active = w < w_end;
+		const int64_t wn = w + G;
+		const uint32_t g_next = (wn < w_end) ? gc[(wn < n_win) ? wn : n_win - 1] : 0;
 		uint32_t k = 0, bc = 0;
 		float c = 0.0f;
 		if (active) {
 			const int64_t lo = (w * step > s0) ? w * step : s0;
 			const int64_t hi = ((w + 1) * step < e0) ? (w + 1) * step : e0;
 			k = (uint32_t) (hi - lo);
-			const uint32_t g = a.gc_like[gc_off + ((w < n_win) ? w : n_win - 1)];
-			c = (g < (uint32_t) kGcBins) ? E[g] : 0.0f; // 404-byte table: L1/L2 resident
+			c = (g_cur < (uint32_t) kGcBins) ? E[g_cur] : 0.0f;
 			bc = conga_f32_bits(c);
 		}
 		unsigned long long todo = __ballot(active) & gmask; // this group's windows still to apply
@@ -760,12 +838,28 @@ template <int G> __global__ __launch_bounds__(256) void interval_chain_kernel(Ch
 			bool ok = true;
 			if (in)
 				ok = valid && (st.delta == 0 || (m <= st.lim && (uint64_t) (k - 1u) * st.delta <= (uint64_t) (st.lim - m)));
-			const unsigned long long bad = __ballot(!ok) & gmask;
-			const uint32_t total = __shfl(incl, G - 1, G);
+			const unsigned long long bad_all = __ballot(!ok);
+			const unsigned long long bad = bad_all & gmask;
+			uint32_t total, pre_fb = 0, k_fb = 0;
+			float c_fb = 0.0f;
 			const int fb = bad ? (__ffsll((long long) bad) - 1 - grp * G) : 0;
-			const uint32_t pre_fb = __shfl(pre, fb, G);
-			const float c_fb = __shfl(c, fb, G);
-			const uint32_t k_fb = __shfl(k, fb, G);
+			if (G == 64) {
+				// one group = the wave: everything is wave-uniform, so scalar lane reads do
+				total = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
+				if (bad_all) {
+					const int fbu = __builtin_amdgcn_readfirstlane(fb);
+					pre_fb = (uint32_t) __builtin_amdgcn_readlane((int) pre, fbu);
+					c_fb = conga_bits_f32((uint32_t) __builtin_amdgcn_readlane((int) bc, fbu));
+					k_fb = (uint32_t) __builtin_amdgcn_readlane((int) k, fbu);
+				}
+			} else {
+				total = __shfl(incl, G - 1, G);
+				if (bad_all) { // some group of this wave has an irregular window
+					pre_fb = __shfl(pre, fb, G);
+					c_fb = __shfl(c, fb, G);
+					k_fb = __shfl(k, fb, G);
+				}
+			}
 			if (todo != 0ull) {
 				if (bad == 0ull) {
 					if (total)
@@ -780,6 +874,7 @@ template <int G> __global__ __launch_bounds__(256) void interval_chain_kernel(Ch
 			}
 		}
 		wb += G;
+		g_cur = g_next;
 	}
 	if (have && gl == 0)
 		a.expected[iv] = s;

@@ -35,6 +35,20 @@ template <bool NT> __global__ __launch_bounds__(256) void fill_wave_runs(uint4 *
 	}
 }
 
+// tiles dealt round-robin over the waves in runs of `run` consecutive tiles
+__global__ __launch_bounds__(256) void fill_round_robin(uint4 *p, size_t n_tiles, int tile16, int run)
+{
+	const int lane = threadIdx.x & 63;
+	const size_t n_waves = (size_t) gridDim.x * 4;
+	const size_t wave = ((size_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	for (size_t t0 = wave * run; t0 < n_tiles; t0 += n_waves * run)
+		for (size_t t = t0; t < t0 + run && t < n_tiles; t++) {
+			uint4 *q = p + t * tile16;
+			for (int j = lane; j < tile16; j += 64)
+				q[j] = make_uint4(0, 0, 0, 0);
+		}
+}
+
 int main()
 {
 	const size_t bytes = 5762066572ull / 16 * 16;
@@ -71,5 +85,12 @@ int main()
 		snprintf(nm, sizeof nm, "wave runs 4000 B nt, %d blocks/CU", per_cu);
 		time(nm, [&] { hipLaunchKernelGGL(fill_wave_runs<true>, dim3(256 * per_cu), dim3(256), 0, st, (uint4 *) buf, n_tiles, tpw, 250); });
 	}
+	for (int tile_bytes : {4000, 4096, 6400, 8192})
+		for (int run : {1, 4, 16}) {
+			const size_t n_tiles = bytes / tile_bytes;
+			char nm[64];
+			snprintf(nm, sizeof nm, "round-robin %d B x%d, 7 blk/CU", tile_bytes, run);
+			time(nm, [&] { hipLaunchKernelGGL(fill_round_robin, dim3(256 * 7), dim3(256), 0, st, (uint4 *) buf, n_tiles, tile_bytes / 16, run); });
+		}
 	return 0;
 }
