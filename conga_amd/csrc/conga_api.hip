@@ -52,7 +52,7 @@ struct HostSlot {
 	std::vector<int32_t> map_start, map_end;
 	std::vector<float> map_val;
 	// filled by prepare()
-	int64_t rd_off = 0, gc_off = 0, tile0 = 0, tidx_off = 0, iv0 = 0, map_row_off = 0;
+	int64_t rd_off = 0, gc_off = 0, tile0 = 0, tidx_off = 0, iv0 = 0, map_row_off = 0, row_tile_off = 0;
 };
 
 } // namespace
@@ -84,7 +84,7 @@ struct conga_ctx {
 	DevBuf d_pos, d_mapq, d_tile_start, d_rd, d_gc_hist, d_gc_like, d_slots, d_small, d_map, d_winner,
 			d_map_start, d_map_end, d_map_val, d_iv_start, d_iv_end, d_iv_type, d_iv_slot, d_iv_has_map, d_order,
 			d_observed, d_expected, d_item_off, d_item_len, d_item_iv, d_item_has_map, d_item_first, d_map_part,
-			d_support, d_results, d_bases;
+			d_support, d_results, d_bases, d_row_tile;
 
 	// pinned read-back
 	Small *h_small = nullptr;
@@ -287,6 +287,24 @@ int prepare(conga_ctx *ctx)
 		TRY(ensure(ctx, ctx->d_map, std::max<size_t>((size_t) ctx->total_L, 8) * 4));
 		if (any_unsorted)
 			TRY(ensure(ctx, ctx->d_winner, (size_t) max_L * 4));
+		// per-tile first-row index of every sorted track (rows do not change between computes)
+		int64_t rt = 0;
+		for (HostSlot &h : ctx->slots) {
+			h.row_tile_off = rt;
+			if (h.has_map && h.map_sorted)
+				rt += (h.L + kPaintTile - 1) / kPaintTile + 2;
+		}
+		TRY(ensure(ctx, ctx->d_row_tile, std::max<size_t>((size_t) rt, 1) * 4));
+		HIP_TRY(ctx, hipMemsetAsync(ctx->d_row_tile.p, 0xFF, std::max<size_t>((size_t) rt, 1) * 4, ctx->stream));
+		for (const HostSlot &h : ctx->slots) {
+			if (!h.has_map || !h.map_sorted || h.map_start.empty())
+				continue;
+			const int64_t mrows = (int64_t) h.map_start.size();
+			const int grid = (int) std::min<int64_t>((mrows + 255) / 256, (int64_t) ctx->n_cu * 8);
+			hipLaunchKernelGGL(row_tile_index_kernel, dim3(grid), dim3(256), 0, ctx->stream,
+					ptr<int32_t>(ctx->d_map_start) + h.map_row_off, mrows, kPaintTile, (h.L + kPaintTile - 1) / kPaintTile,
+					ptr<uint32_t>(ctx->d_row_tile) + h.row_tile_off);
+		}
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	}
 
@@ -551,7 +569,7 @@ void conga_destroy(conga_ctx *ctx)
 			&ctx->d_map_val, &ctx->d_iv_start, &ctx->d_iv_end, &ctx->d_iv_type, &ctx->d_iv_slot, &ctx->d_iv_has_map,
 			&ctx->d_order, &ctx->d_observed, &ctx->d_expected, &ctx->d_item_off, &ctx->d_item_len, &ctx->d_item_iv,
 			&ctx->d_item_has_map, &ctx->d_item_first, &ctx->d_map_part, &ctx->d_support, &ctx->d_results,
-			&ctx->d_bases};
+			&ctx->d_bases, &ctx->d_row_tile};
 	for (DevBuf *b : bufs)
 		free_buf(*b);
 	for (auto &s : ctx->staging) {
@@ -861,9 +879,10 @@ int conga_chrom_compute(conga_ctx *ctx)
 			float *map = ptr<float>(ctx->d_map) + h.rd_off;
 			const int64_t m = (int64_t) h.map_start.size();
 			if (h.map_sorted) {
-				const int64_t tile = 256 * 4;
-				const int grid = (int) std::min<int64_t>((h.L + tile - 1) / tile, (int64_t) ctx->n_cu * 16);
-				hipLaunchKernelGGL(paint_sorted_kernel, dim3(grid), dim3(256), 0, st, ms, me, mv, m, map, h.L);
+				const int64_t n_pt = (h.L + kPaintTile - 1) / kPaintTile;
+				const int grid = (int) std::min<int64_t>((n_pt + 3) / 4, (int64_t) ctx->n_cu * 8);
+				hipLaunchKernelGGL(paint_sorted_kernel, dim3(grid), dim3(256), 0, st, ms, me, mv, m,
+						ptr<uint32_t>(ctx->d_row_tile) + h.row_tile_off, map, h.L);
 			} else {
 				HIP_TRY(ctx, hipMemsetAsync(ctx->d_winner.p, 0xFF, (size_t) h.L * 4, st));
 				if (m > 0) {

@@ -553,46 +553,112 @@ __global__ void expected_table_kernel(Small *__restrict__ small, const unsigned 
 // paint_winner_kernel / paint_resolve_kernel: any row order -- atomicMax of the row index per
 // base, then map[i] = val[winner[i]].
 // -------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void paint_sorted_kernel(const int32_t *__restrict__ start,
-		const int32_t *__restrict__ end, const float *__restrict__ val, int64_t m, float *__restrict__ map,
-		int64_t L)
+// row_tile_first[t] = first row whose start lies in paint tile t or later (rows sorted by start); entries past
+// the last row keep the memset value 0xFFFFFFFF (= "m").  Built once per layout.
+__global__ __launch_bounds__(256) void row_tile_index_kernel(const int32_t *__restrict__ start, int64_t m,
+		int32_t tile_len, int64_t n_tiles, uint32_t *__restrict__ row_tile_first)
 {
-	constexpr int kPerThread = 4;
-	const int64_t tile = (int64_t) blockDim.x * kPerThread;
-	for (int64_t base = (int64_t) blockIdx.x * tile; base < L; base += (int64_t) gridDim.x * tile) {
-		const int64_t x0 = base + (int64_t) threadIdx.x * kPerThread;
-		if (x0 >= L)
-			continue;
-		// last row with start <= x0 (upper_bound - 1)
-		int64_t lo = 0, hi = m;
-		while (lo < hi) {
-			const int64_t mid = (lo + hi) >> 1;
-			if ((int64_t) start[mid] <= x0)
-				lo = mid + 1;
-			else
-				hi = mid;
-		}
-		int64_t k = lo - 1;
-		float o0, o1, o2, o3;
-#define CONGA_PAINT_ONE(e, dst)                                         \
-	{                                                                   \
-		const int64_t x = x0 + (e);                                     \
-		while (k + 1 < m && (int64_t) start[k + 1] <= x)                \
-			k++;                                                        \
-		dst = (k >= 0 && (int64_t) end[k] >= x) ? val[k] : 0.0f;        \
+	const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+	for (int64_t k = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; k < m; k += stride) {
+		int64_t t_cur = (start[k] < 0) ? 0 : (int64_t) start[k] / tile_len;
+		int64_t t_prev = (k == 0) ? -1 : ((start[k - 1] < 0) ? 0 : (int64_t) start[k - 1] / tile_len);
+		if (t_cur > n_tiles)
+			t_cur = n_tiles;
+		if (t_prev > n_tiles)
+			t_prev = n_tiles;
+		for (int64_t t = t_prev + 1; t <= t_cur; t++)
+			row_tile_first[t] = (uint32_t) k;
 	}
-		CONGA_PAINT_ONE(0, o0)
-		CONGA_PAINT_ONE(1, o1)
-		CONGA_PAINT_ONE(2, o2)
-		CONGA_PAINT_ONE(3, o3)
-#undef CONGA_PAINT_ONE
-		if (x0 + kPerThread <= L)
-			*reinterpret_cast<float4 *>(map + x0) = make_float4(o0, o1, o2, o3);
-		else {
-			const float o[4] = {o0, o1, o2, o3};
-			for (int e = 0; x0 + e < L; e++)
-				map[x0 + e] = o[e];
+}
+
+// One wave paints one 1024-base tile: row starts are marked in LDS (atomicMax of the row index, so the later
+// of two rows with equal starts wins), a running maximum over the marks gives every base the LAST row that
+// starts at or before it, and that row covers the base iff its end >= base (rows abut at most, so no earlier
+// row can reach further).  16 consecutive bases per lane; a DPP max-scan carries the running row across lanes.
+constexpr int kPaintTile = 1024;
+
+__device__ __forceinline__ int wave_excl_scan_max_i32(int v, int carry)
+{
+	// inclusive max-scan through DPP, then shift by one lane
+#define CONGA_DPP_MAX(ctrl, rows) { const int t = __builtin_amdgcn_update_dpp(INT32_MIN, v, ctrl, rows, 0xF, false); v = (t > v) ? t : v; }
+	CONGA_DPP_MAX(0x111, 0xF)
+	CONGA_DPP_MAX(0x112, 0xF)
+	CONGA_DPP_MAX(0x114, 0xF)
+	CONGA_DPP_MAX(0x118, 0xF)
+	CONGA_DPP_MAX(0x142, 0xA)
+	CONGA_DPP_MAX(0x143, 0xC)
+#undef CONGA_DPP_MAX
+	int up = __shfl_up(v, 1, kWave);
+	if ((threadIdx.x & (kWave - 1)) == 0)
+		up = INT32_MIN;
+	return (up > carry) ? up : carry;
+}
+
+__global__ __launch_bounds__(256) void paint_sorted_kernel(const int32_t *__restrict__ start,
+		const int32_t *__restrict__ end, const float *__restrict__ val, int64_t m,
+		const uint32_t *__restrict__ row_tile_first, float *__restrict__ map, int64_t L)
+{
+	__shared__ __attribute__((aligned(16))) int32_t mark_all[4][kPaintTile];
+	const int wv = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+	int32_t *mark = mark_all[wv];
+	const int64_t n_tiles = (L + kPaintTile - 1) / kPaintTile;
+	const int64_t n_waves = (int64_t) gridDim.x * 4;
+	for (int64_t tile = (int64_t) blockIdx.x * 4 + wv; tile < n_tiles; tile += n_waves) {
+		const int64_t base = tile * kPaintTile;
+		uint32_t k0 = row_tile_first[tile], k1 = row_tile_first[tile + 1];
+		if (k0 == 0xFFFFFFFFu)
+			k0 = (uint32_t) m;
+		if (k1 == 0xFFFFFFFFu)
+			k1 = (uint32_t) m;
+		for (int j = lane * 4; j < kPaintTile; j += kWave * 4)
+			*reinterpret_cast<int4 *>(&mark[j]) = make_int4(-1, -1, -1, -1);
+		__builtin_amdgcn_wave_barrier();
+		for (uint32_t k = k0 + lane; k < k1; k += kWave) {
+			int64_t x = (int64_t) start[k] - base;
+			if (x < 0)
+				x = 0; // a row that starts before base 0 is in force from the first base
+			if (x < kPaintTile)
+				atomicMax(&mark[x], (int32_t) k);
 		}
+		__builtin_amdgcn_wave_barrier();
+		// the row in force when the tile begins: the last row that starts before it
+		int carry = (int) k0 - 1;
+		// four passes of 256 bases: lane l owns bases [4 (64 q + l), +4), so every store instruction of the
+		// wave writes 1 KiB contiguously
+#pragma unroll
+		for (int q = 0; q < kPaintTile / 256; q++) {
+			const int seg = q * kWave + lane;
+			const int4 mk = *reinterpret_cast<const int4 *>(&mark[seg * 4]);
+			int lane_max = (mk.x > mk.y) ? mk.x : mk.y;
+			lane_max = (mk.z > lane_max) ? mk.z : lane_max;
+			lane_max = (mk.w > lane_max) ? mk.w : lane_max;
+			int cur = wave_excl_scan_max_i32(lane_max, carry);
+			const int m4[4] = {mk.x, mk.y, mk.z, mk.w};
+			int cached = -2;
+			int64_t c_end = -1;
+			float c_val = 0.0f, out[4];
+			const int64_t x0 = base + seg * 4;
+#pragma unroll
+			for (int e = 0; e < 4; e++) {
+				cur = (m4[e] > cur) ? m4[e] : cur;
+				if (cur != cached) {
+					cached = cur;
+					if (cur >= 0) {
+						c_end = end[cur];
+						c_val = val[cur];
+					}
+				}
+				out[e] = (cur >= 0 && c_end >= x0 + e) ? c_val : 0.0f;
+			}
+			if (x0 + 4 <= L)
+				*reinterpret_cast<float4 *>(map + x0) = make_float4(out[0], out[1], out[2], out[3]);
+			else
+				for (int e = 0; e < 4 && x0 + e < L; e++)
+					map[x0 + e] = out[e];
+			// the row in force after this pass = the running row of the last lane
+			carry = __builtin_amdgcn_readlane(cur, kWave - 1);
+		}
+		__builtin_amdgcn_wave_barrier();
 	}
 }
 
