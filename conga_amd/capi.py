@@ -34,7 +34,8 @@ KERNEL_NAMES = ("ingest", "depth_tile", "expected_table", "paint", "interval_red
 EXPORTS = (
     "conga_create", "conga_destroy", "conga_strerror", "conga_last_error", "conga_abi_version",
     "conga_device_count", "conga_reset", "conga_chrom_count", "conga_chrom_select", "conga_chrom_begin", "conga_reads_staging", "conga_reads_commit",
-    "conga_mappability", "conga_intervals", "conga_split_support", "conga_chrom_compute",
+    "conga_mappability", "conga_intervals", "conga_reference", "conga_satellites", "conga_split_reads_staging",
+    "conga_split_reads_commit", "conga_split_support", "conga_chrom_compute",
     "conga_chrom_fetch", "conga_chrom_finish", "conga_results_device", "conga_results_copy",
     "conga_set_profile", "conga_stream", "conga_sync",
     "conga_copy_read_depth", "conga_copy_mappability", "conga_host_repeat_add_f32",
@@ -43,7 +44,13 @@ EXPORTS = (
 
 class Opts(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("mq_threshold", C.c_int32), ("gc_step", C.c_int32),
-                ("flags", C.c_uint32), ("reserved", C.c_int32 * 4)]
+                ("flags", C.c_uint32), ("min_read_length", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+class SplitStaging(C.Structure):
+    _fields_ = [("pos", C.POINTER(C.c_int32)), ("mapq", C.POINTER(C.c_uint8)), ("flag", C.POINTER(C.c_uint16)),
+                ("l_qseq", C.POINTER(C.c_int32)), ("data_off", C.POINTER(C.c_uint64)), ("data", C.POINTER(C.c_uint8)),
+                ("capacity_reads", C.c_size_t), ("capacity_bytes", C.c_size_t)]
 
 
 class ReadStaging(C.Structure):
@@ -54,7 +61,8 @@ class ChromStats(C.Structure):
     _fields_ = [("reads_committed", C.c_int64), ("reads_counted", C.c_int64),
                 ("reads_out_of_range", C.c_int64), ("rd_sum", C.c_int64), ("mean", C.c_float),
                 ("n_kernels", C.c_int32), ("rd_per_gc", C.c_int64 * 101), ("window_per_gc", C.c_int64 * 101),
-                ("kernel_ms", C.c_double * 8)]
+                ("kernel_ms", C.c_double * 8), ("split_elements", C.c_int64), ("split_mappings", C.c_int64),
+                ("split_del_rows", C.c_int64), ("split_dup_rows", C.c_int64)]
 
 
 RESULT_DTYPE = np.dtype([
@@ -110,6 +118,14 @@ def load():
     L.conga_mappability.argtypes = [vp, vp, vp, vp, sz]
     L.conga_intervals.restype = C.c_int
     L.conga_intervals.argtypes = [vp, C.c_char, vp, vp, sz]
+    L.conga_reference.restype = C.c_int
+    L.conga_reference.argtypes = [vp, C.c_char_p, i64]
+    L.conga_satellites.restype = C.c_int
+    L.conga_satellites.argtypes = [vp, vp, vp, sz]
+    L.conga_split_reads_staging.restype = C.c_int
+    L.conga_split_reads_staging.argtypes = [vp, C.POINTER(SplitStaging)]
+    L.conga_split_reads_commit.restype = C.c_int
+    L.conga_split_reads_commit.argtypes = [vp, sz, sz]
     L.conga_split_support.restype = C.c_int
     L.conga_split_support.argtypes = [vp, C.c_char, vp, sz]
     L.conga_chrom_compute.restype = C.c_int
@@ -145,9 +161,9 @@ def _p(a):
 class Context:
     """One conga_ctx: one GPU, one stream, one chromosome in flight."""
 
-    def __init__(self, device=0, mq_threshold=-1, gc_step=100, flags=0):
+    def __init__(self, device=0, mq_threshold=-1, gc_step=100, flags=0, min_read_length=0):
         self._lib = load()
-        opts = Opts(C.sizeof(Opts), mq_threshold, gc_step, flags)
+        opts = Opts(C.sizeof(Opts), mq_threshold, gc_step, flags, min_read_length)
         st = C.c_int(0)
         self._h = self._lib.conga_create(device, C.byref(opts), C.byref(st))
         if not self._h:
@@ -246,6 +262,45 @@ class Context:
         e = np.ascontiguousarray(end, dtype=np.int32)
         self._check(self._lib.conga_intervals(self._h, sv_type.encode()[:1], _p(s), _p(e), len(s)))
         self._meta[self._cur][1 if sv_type == DELETION else 2] = len(s)
+
+    def reference(self, seq):
+        """Chromosome sequence (bytes) for the split-read path."""
+        self._check(self._lib.conga_reference(self._h, seq, len(seq)))
+
+    def satellites(self, start, end):
+        s = np.ascontiguousarray(start, dtype=np.int32)
+        e = np.ascontiguousarray(end, dtype=np.int32)
+        self._check(self._lib.conga_satellites(self._h, _p(s), _p(e), len(s)))
+
+    def split_reads(self, pos, mapq, flag, l_qseq, seq_codes, qual, code_off):
+        """Every record of the BAM loop: seq_codes holds one 4-bit base code per byte and qual the Phred
+        bytes, both starting at code_off[i]; they are packed here into BAM's nibble layout."""
+        pos = np.ascontiguousarray(pos, dtype=np.int32)
+        mapq = np.ascontiguousarray(mapq, dtype=np.uint8)
+        flag = np.ascontiguousarray(flag, dtype=np.uint16)
+        lq = np.ascontiguousarray(l_qseq, dtype=np.int32)
+        stg = SplitStaging()
+        i, n = 0, len(pos)
+        while i < n:
+            self._check(self._lib.conga_split_reads_staging(self._h, C.byref(stg)))
+            data = np.ctypeslib.as_array(stg.data, shape=(stg.capacity_bytes,))
+            k, nb = 0, 0
+            while i + k < n and k < stg.capacity_reads:
+                l = int(lq[i + k])
+                need = (l + 1) // 2 + l
+                if nb + need > stg.capacity_bytes:
+                    break
+                o = int(code_off[i + k])
+                codes = np.zeros((l + 1) // 2 * 2, np.uint8)
+                codes[:l] = seq_codes[o:o + l]
+                data[nb:nb + (l + 1) // 2] = (codes[0::2] << 4) | codes[1::2]
+                data[nb + (l + 1) // 2:nb + need] = qual[o:o + l]
+                stg.data_off[k] = nb
+                stg.pos[k], stg.mapq[k], stg.flag[k], stg.l_qseq[k] = int(pos[i + k]), int(mapq[i + k]), int(flag[i + k]), l
+                nb += need
+                k += 1
+            self._check(self._lib.conga_split_reads_commit(self._h, k, nb))
+            i += k
 
     def split_support(self, sv_type, support):
         s = np.ascontiguousarray(support, dtype=np.int32)

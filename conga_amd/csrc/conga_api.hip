@@ -51,6 +51,11 @@ struct HostSlot {
 	bool has_map = false, map_sorted = false;
 	std::vector<int32_t> map_start, map_end;
 	std::vector<float> map_val;
+	// split-read inputs
+	std::vector<uint8_t> ref;               // upper-cased chromosome sequence
+	std::vector<int32_t> sat_start, sat_end; // sorted, disjoint
+	int64_t sr_off = 0, n_sr = 0;           // this chromosome's records in the split-read arrays
+	int64_t ref_off = 0, sat_off = 0;
 	// filled by prepare()
 	int64_t rd_off = 0, gc_off = 0, tile0 = 0, tidx_off = 0, iv0 = 0, map_row_off = 0, row_tile_off = 0;
 };
@@ -78,13 +83,17 @@ struct conga_ctx {
 
 	// layout totals (prepare)
 	int64_t total_L = 0, total_tiles = 0, total_gc = 0, n_iv = 0, n_items = 0, n_long = 0;
-	bool gc_like_distinct = false, any_map = false, support_given = false;
+	bool gc_like_distinct = false, any_map = false, support_given = false, any_sr = false;
+	int64_t n_sr_total = 0, sr_bytes_total = 0;
+	conga_split_staging sr_stage{}; // one pinned set (the split-read path is not the bench line)
+	bool sr_staged = false;
 
 	// device buffers
 	DevBuf d_pos, d_mapq, d_tile_start, d_rd, d_gc_hist, d_gc_like, d_slots, d_small, d_map, d_winner,
 			d_map_start, d_map_end, d_map_val, d_iv_start, d_iv_end, d_iv_type, d_iv_slot, d_iv_has_map, d_order,
 			d_observed, d_expected, d_item_off, d_item_len, d_item_iv, d_item_has_map, d_item_first, d_map_part,
-			d_support, d_results, d_bases, d_row_tile;
+			d_support, d_results, d_bases, d_row_tile, d_support_base, d_ref, d_sat_start, d_sat_end, d_sr_pos,
+			d_sr_mapq, d_sr_flag, d_sr_lq, d_sr_off, d_sr_data, d_kmer_count, d_kmer_offset, d_kmer_cursor, d_kmer_pos;
 
 	// pinned read-back
 	Small *h_small = nullptr;
@@ -308,6 +317,45 @@ int prepare(conga_ctx *ctx)
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	}
 
+	// ---- split-read inputs: reference sequences and satellite intervals, concatenated
+	ctx->any_sr = false;
+	{
+		int64_t ref_off = 0, sat_off = 0;
+		for (HostSlot &h : ctx->slots) {
+			h.ref_off = ref_off;
+			h.sat_off = sat_off;
+			if (h.n_sr > 0 && !h.ref.empty()) {
+				ctx->any_sr = true;
+				ref_off += ((int64_t) h.ref.size() + 255) & ~(int64_t) 255;
+				sat_off += (int64_t) h.sat_start.size();
+			}
+		}
+		if (ctx->any_sr) {
+			TRY(ensure(ctx, ctx->d_ref, (size_t) ref_off + 256));
+			TRY(ensure(ctx, ctx->d_sat_start, std::max<size_t>((size_t) sat_off, 1) * 4));
+			TRY(ensure(ctx, ctx->d_sat_end, std::max<size_t>((size_t) sat_off, 1) * 4));
+			int64_t max_L = 0;
+			for (const HostSlot &h : ctx->slots) {
+				if (h.n_sr == 0 || h.ref.empty())
+					continue;
+				max_L = std::max(max_L, h.L);
+				HIP_TRY(ctx, hipMemcpyAsync(ptr<uint8_t>(ctx->d_ref) + h.ref_off, h.ref.data(), h.ref.size(),
+						hipMemcpyHostToDevice, ctx->stream));
+				if (!h.sat_start.empty()) {
+					HIP_TRY(ctx, hipMemcpyAsync(ptr<int32_t>(ctx->d_sat_start) + h.sat_off, h.sat_start.data(),
+							h.sat_start.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+					HIP_TRY(ctx, hipMemcpyAsync(ptr<int32_t>(ctx->d_sat_end) + h.sat_off, h.sat_end.data(),
+							h.sat_end.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+				}
+			}
+			TRY(ensure(ctx, ctx->d_kmer_count, (size_t) kKmerBuckets * 4));
+			TRY(ensure(ctx, ctx->d_kmer_cursor, (size_t) kKmerBuckets * 4));
+			TRY(ensure(ctx, ctx->d_kmer_offset, ((size_t) kKmerBuckets + 1) * 4));
+			TRY(ensure(ctx, ctx->d_kmer_pos, (size_t) max_L * 4));
+			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		}
+	}
+
 	// ---- intervals: slot order, dels then dups inside a slot
 	const size_t n = (size_t) ctx->n_iv;
 	ctx->n_items = 0;
@@ -386,8 +434,10 @@ int prepare(conga_ctx *ctx)
 					base += h.iv_start[t].size();
 				}
 			}
-			TRY(upload(ctx, ctx->d_support, support.data(), n * 4));
+			TRY(upload(ctx, ctx->d_support_base, support.data(), n * 4));
 		}
+		if (ctx->support_given || ctx->any_sr)
+			TRY(ensure(ctx, ctx->d_support, n * 4));
 		if (n > ctx->h_results_cap) {
 			if (ctx->h_results)
 				(void) hipHostFree(ctx->h_results);
@@ -427,6 +477,9 @@ void reset_slots(conga_ctx *ctx)
 	ctx->slots.clear();
 	ctx->cur = -1;
 	ctx->n_reads_total = 0;
+	ctx->n_sr_total = 0;
+	ctx->sr_bytes_total = 0;
+	ctx->sr_staged = false;
 	ctx->staging_cur = -1;
 	ctx->layout_dirty = true;
 	ctx->computed = false;
@@ -510,7 +563,11 @@ conga_ctx *conga_create(int device, const conga_opts *opts, int *status)
 		ctx->opts.mq_threshold = opts->mq_threshold;
 		ctx->opts.gc_step = opts->gc_step > 0 ? opts->gc_step : 100;
 		ctx->opts.flags = opts->flags;
+		if (opts->struct_size >= 20)
+			ctx->opts.min_read_length = opts->min_read_length;
 	}
+	if (ctx->opts.min_read_length <= 0)
+		ctx->opts.min_read_length = 60;
 	if (ctx->opts.gc_step > 1024) {
 		*status = CONGA_ERR_INVALID;
 		delete ctx;
@@ -569,7 +626,9 @@ void conga_destroy(conga_ctx *ctx)
 			&ctx->d_map_val, &ctx->d_iv_start, &ctx->d_iv_end, &ctx->d_iv_type, &ctx->d_iv_slot, &ctx->d_iv_has_map,
 			&ctx->d_order, &ctx->d_observed, &ctx->d_expected, &ctx->d_item_off, &ctx->d_item_len, &ctx->d_item_iv,
 			&ctx->d_item_has_map, &ctx->d_item_first, &ctx->d_map_part, &ctx->d_support, &ctx->d_results,
-			&ctx->d_bases, &ctx->d_row_tile};
+			&ctx->d_bases, &ctx->d_row_tile, &ctx->d_support_base, &ctx->d_ref, &ctx->d_sat_start, &ctx->d_sat_end,
+			&ctx->d_sr_pos, &ctx->d_sr_mapq, &ctx->d_sr_flag, &ctx->d_sr_lq, &ctx->d_sr_off, &ctx->d_sr_data,
+			&ctx->d_kmer_count, &ctx->d_kmer_offset, &ctx->d_kmer_cursor, &ctx->d_kmer_pos};
 	for (DevBuf *b : bufs)
 		free_buf(*b);
 	for (auto &s : ctx->staging) {
@@ -579,6 +638,13 @@ void conga_destroy(conga_ctx *ctx)
 			(void) hipHostFree(s.mapq);
 		if (s.copied)
 			(void) hipEventDestroy(s.copied);
+	}
+	{
+		void *pinned[] = {ctx->sr_stage.pos, ctx->sr_stage.mapq, ctx->sr_stage.flag, ctx->sr_stage.l_qseq,
+				ctx->sr_stage.data_off, ctx->sr_stage.data};
+		for (void *q : pinned)
+			if (q)
+				(void) hipHostFree(q);
 	}
 	if (ctx->h_small)
 		(void) hipHostFree(ctx->h_small);
@@ -765,6 +831,127 @@ int conga_intervals(conga_ctx *ctx, char type, const int32_t *start, const int32
 	return CONGA_OK;
 }
 
+int conga_reference(conga_ctx *ctx, const char *seq, int64_t len)
+{
+	if (!ctx || !seq)
+		return CONGA_ERR_INVALID;
+	if (ctx->slots.empty())
+		return fail(ctx, CONGA_ERR_INVALID, "conga_reference: no chromosome open");
+	HostSlot &h = ctx->slots.back();
+	if (len != h.L)
+		return fail(ctx, CONGA_ERR_INVALID, "conga_reference: length differs from the chromosome length");
+	h.ref.resize((size_t) len);
+	for (int64_t i = 0; i < len; i++) { // readReferenceSeq upper-cases every base (common.c:449)
+		const unsigned char c = (unsigned char) seq[i];
+		h.ref[(size_t) i] = (c >= 'a' && c <= 'z') ? (uint8_t) (c - 32) : c;
+	}
+	ctx->layout_dirty = true;
+	ctx->computed = false;
+	return CONGA_OK;
+}
+
+int conga_satellites(conga_ctx *ctx, const int32_t *start, const int32_t *end, size_t n)
+{
+	if (!ctx || (n && (!start || !end)))
+		return CONGA_ERR_INVALID;
+	if (ctx->slots.empty())
+		return fail(ctx, CONGA_ERR_INVALID, "conga_satellites: no chromosome open");
+	HostSlot &h = ctx->slots.back();
+	// sort and merge, so that "any interval overlaps [a, b)" is one binary search on the device
+	std::vector<std::pair<int32_t, int32_t>> iv;
+	for (size_t i = 0; i < n; i++)
+		if (end[i] > start[i])
+			iv.emplace_back(start[i], end[i]);
+	std::sort(iv.begin(), iv.end());
+	h.sat_start.clear();
+	h.sat_end.clear();
+	for (const auto &x : iv) {
+		if (!h.sat_end.empty() && x.first <= h.sat_end.back())
+			h.sat_end.back() = std::max(h.sat_end.back(), x.second);
+		else {
+			h.sat_start.push_back(x.first);
+			h.sat_end.push_back(x.second);
+		}
+	}
+	ctx->layout_dirty = true;
+	ctx->computed = false;
+	return CONGA_OK;
+}
+
+namespace {
+constexpr size_t kSrStageReads = (size_t) 1 << 20;
+constexpr size_t kSrStageBytes = (size_t) 192 << 20;
+}
+
+int conga_split_reads_staging(conga_ctx *ctx, conga_split_staging *out)
+{
+	if (!ctx || !out)
+		return CONGA_ERR_INVALID;
+	if (ctx->slots.empty())
+		return fail(ctx, CONGA_ERR_INVALID, "conga_split_reads_staging: no chromosome open");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	conga_split_staging &s = ctx->sr_stage;
+	if (!s.pos) {
+		HIP_TRY(ctx, hipHostMalloc((void **) &s.pos, kSrStageReads * 4, hipHostMallocDefault));
+		HIP_TRY(ctx, hipHostMalloc((void **) &s.mapq, kSrStageReads, hipHostMallocDefault));
+		HIP_TRY(ctx, hipHostMalloc((void **) &s.flag, kSrStageReads * 2, hipHostMallocDefault));
+		HIP_TRY(ctx, hipHostMalloc((void **) &s.l_qseq, kSrStageReads * 4, hipHostMallocDefault));
+		HIP_TRY(ctx, hipHostMalloc((void **) &s.data_off, kSrStageReads * 8, hipHostMallocDefault));
+		HIP_TRY(ctx, hipHostMalloc((void **) &s.data, kSrStageBytes, hipHostMallocDefault));
+		s.capacity_reads = kSrStageReads;
+		s.capacity_bytes = kSrStageBytes;
+	}
+	ctx->sr_staged = true;
+	*out = s;
+	return CONGA_OK;
+}
+
+int conga_split_reads_commit(conga_ctx *ctx, size_t n_reads, size_t n_bytes)
+{
+	if (!ctx)
+		return CONGA_ERR_INVALID;
+	if (ctx->slots.empty() || !ctx->sr_staged)
+		return fail(ctx, CONGA_ERR_INVALID, "conga_split_reads_commit: call conga_split_reads_staging first");
+	if (n_reads > kSrStageReads || n_bytes > kSrStageBytes)
+		return fail(ctx, CONGA_ERR_INVALID, "conga_split_reads_commit: exceeds the staging capacity");
+	ctx->sr_staged = false;
+	if (n_reads == 0)
+		return CONGA_OK;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	conga_split_staging &st = ctx->sr_stage;
+	HostSlot &h = ctx->slots.back();
+	for (size_t i = 0; i < n_reads; i++) {
+		const int32_t l = st.l_qseq[i];
+		if (l < 0 || st.data_off[i] + (uint64_t) (l + 1) / 2 + (uint64_t) l > n_bytes)
+			return fail(ctx, CONGA_ERR_RANGE, "conga_split_reads_commit: record block outside the committed bytes");
+		st.data_off[i] += (uint64_t) ctx->sr_bytes_total; // rebase into the device arena
+	}
+	const size_t nr = (size_t) ctx->n_sr_total + n_reads, nb = (size_t) ctx->sr_bytes_total + n_bytes;
+	TRY(ensure(ctx, ctx->d_sr_pos, std::max(nr, (size_t) 1 << 20) * 4, true));
+	TRY(ensure(ctx, ctx->d_sr_mapq, std::max(nr, (size_t) 1 << 20), true));
+	TRY(ensure(ctx, ctx->d_sr_flag, std::max(nr, (size_t) 1 << 20) * 2, true));
+	TRY(ensure(ctx, ctx->d_sr_lq, std::max(nr, (size_t) 1 << 20) * 4, true));
+	TRY(ensure(ctx, ctx->d_sr_off, std::max(nr, (size_t) 1 << 20) * 8, true));
+	TRY(ensure(ctx, ctx->d_sr_data, std::max(nb, (size_t) 64 << 20), true));
+	hipStream_t s = ctx->stream;
+	const int64_t o = ctx->n_sr_total;
+	HIP_TRY(ctx, hipMemcpyAsync(ptr<int32_t>(ctx->d_sr_pos) + o, st.pos, n_reads * 4, hipMemcpyHostToDevice, s));
+	HIP_TRY(ctx, hipMemcpyAsync(ptr<uint8_t>(ctx->d_sr_mapq) + o, st.mapq, n_reads, hipMemcpyHostToDevice, s));
+	HIP_TRY(ctx, hipMemcpyAsync(ptr<uint16_t>(ctx->d_sr_flag) + o, st.flag, n_reads * 2, hipMemcpyHostToDevice, s));
+	HIP_TRY(ctx, hipMemcpyAsync(ptr<int32_t>(ctx->d_sr_lq) + o, st.l_qseq, n_reads * 4, hipMemcpyHostToDevice, s));
+	HIP_TRY(ctx, hipMemcpyAsync(ptr<uint64_t>(ctx->d_sr_off) + o, st.data_off, n_reads * 8, hipMemcpyHostToDevice, s));
+	HIP_TRY(ctx, hipMemcpyAsync(ptr<uint8_t>(ctx->d_sr_data) + ctx->sr_bytes_total, st.data, n_bytes, hipMemcpyHostToDevice, s));
+	HIP_TRY(ctx, hipStreamSynchronize(s)); // single staging set: it is the caller's again on return
+	if (h.n_sr == 0)
+		h.sr_off = ctx->n_sr_total;
+	h.n_sr += (int64_t) n_reads;
+	ctx->n_sr_total += (int64_t) n_reads;
+	ctx->sr_bytes_total += (int64_t) n_bytes;
+	ctx->layout_dirty = true;
+	ctx->computed = false;
+	return CONGA_OK;
+}
+
 int conga_split_support(conga_ctx *ctx, char type, const int32_t *support, size_t n)
 {
 	if (!ctx || (n && !support))
@@ -897,6 +1084,58 @@ int conga_chrom_compute(conga_ctx *ctx)
 		}
 	}
 
+	if (ctx->n_iv > 0 && (ctx->support_given || ctx->any_sr)) {
+		if (ctx->support_given)
+			HIP_TRY(ctx, hipMemcpyAsync(ctx->d_support.p, ctx->d_support_base.p, (size_t) ctx->n_iv * 4, hipMemcpyDeviceToDevice, st));
+		else
+			HIP_TRY(ctx, hipMemsetAsync(ctx->d_support.p, 0, (size_t) ctx->n_iv * 4, st));
+	}
+	// split-read evidence, chromosome by chromosome (k-mer index -> half-read mapping -> pairing -> support)
+	if (ctx->any_sr && ctx->n_iv > 0) {
+		for (int s = 0; s < n_slots; s++) {
+			const HostSlot &h = ctx->slots[s];
+			const size_t nd = h.iv_start[0].size(), nu = h.iv_start[1].size();
+			if (h.n_sr == 0 || h.ref.empty() || nd + nu == 0)
+				continue; // count_ReadPairs runs only for chromosomes with SVs (likelihood.c:332-348)
+			const uint8_t *ref = ptr<uint8_t>(ctx->d_ref) + h.ref_off;
+			uint32_t *cnt = ptr<uint32_t>(ctx->d_kmer_count), *cur = ptr<uint32_t>(ctx->d_kmer_cursor);
+			uint32_t *off = ptr<uint32_t>(ctx->d_kmer_offset);
+			int32_t *kpos = ptr<int32_t>(ctx->d_kmer_pos);
+			HIP_TRY(ctx, hipMemsetAsync(cnt, 0, (size_t) kKmerBuckets * 4, st));
+			HIP_TRY(ctx, hipMemsetAsync(cur, 0, (size_t) kKmerBuckets * 4, st));
+			const int grid = (int) std::min<int64_t>((h.L + 255) / 256, (int64_t) ctx->n_cu * 8);
+			hipLaunchKernelGGL(kmer_index_kernel<false>, dim3(grid), dim3(256), 0, st, ref, h.L, cnt, off, cur, kpos);
+			hipLaunchKernelGGL(kmer_offsets_kernel, dim3(1), dim3(1024), 0, st, cnt, off);
+			hipLaunchKernelGGL(kmer_index_kernel<true>, dim3(grid), dim3(256), 0, st, ref, h.L, cnt, off, cur, kpos);
+			SplitArgs a;
+			a.pos = ptr<int32_t>(ctx->d_sr_pos) + h.sr_off;
+			a.mapq = ptr<uint8_t>(ctx->d_sr_mapq) + h.sr_off;
+			a.flag = ptr<uint16_t>(ctx->d_sr_flag) + h.sr_off;
+			a.l_qseq = ptr<int32_t>(ctx->d_sr_lq) + h.sr_off;
+			a.data_off = ptr<uint64_t>(ctx->d_sr_off) + h.sr_off;
+			a.data = ptr<uint8_t>(ctx->d_sr_data);
+			a.n_reads = h.n_sr;
+			a.ref = ref;
+			a.L = h.L;
+			a.sat_start = ptr<int32_t>(ctx->d_sat_start) + h.sat_off;
+			a.sat_end = ptr<int32_t>(ctx->d_sat_end) + h.sat_off;
+			a.n_sat = (int32_t) h.sat_start.size();
+			a.offset = off;
+			a.positions = kpos;
+			a.iv_start = ptr<int32_t>(ctx->d_iv_start);
+			a.iv_end = ptr<int32_t>(ctx->d_iv_end);
+			a.iv0 = (int32_t) h.iv0;
+			a.n_dels = (int32_t) nd;
+			a.n_dups = (int32_t) nu;
+			a.support = ptr<int32_t>(ctx->d_support);
+			a.mq_threshold = ctx->opts.mq_threshold;
+			a.min_read_length = ctx->opts.min_read_length;
+			a.counters = small[s].counters;
+			const int sgrid = (int) std::min<int64_t>((h.n_sr + 3) / 4, (int64_t) ctx->n_cu * 8);
+			hipLaunchKernelGGL(split_read_kernel, dim3(sgrid), dim3(256), 0, st, a);
+		}
+	}
+
 	if (ctx->n_iv > 0) {
 		HIP_TRY(ctx, hipMemsetAsync(ctx->d_observed.p, 0, (size_t) ctx->n_iv * 4, st));
 		if (ctx->n_items > 0) {
@@ -952,7 +1191,7 @@ int conga_chrom_compute(conga_ctx *ctx)
 			a.map_part = ptr<double>(ctx->d_map_part);
 			a.item_first = ptr<int32_t>(ctx->d_item_first);
 			a.iv_has_map = ptr<uint8_t>(ctx->d_iv_has_map);
-			a.support = ctx->support_given ? ptr<int32_t>(ctx->d_support) : nullptr;
+			a.support = (ctx->support_given || ctx->any_sr) ? ptr<int32_t>(ctx->d_support) : nullptr;
 			a.out = ptr<conga_result>(ctx->d_results);
 			const int grid = (int) ((ctx->n_iv + 63) / 64);
 			hipLaunchKernelGGL(interval_score_kernel, dim3(grid), dim3(64), 0, st, a);
@@ -1006,6 +1245,10 @@ int conga_chrom_fetch(conga_ctx *ctx, conga_result *dels, conga_result *dups, fl
 		stats->rd_sum = total;
 		stats->mean = (float) ((double) total / (double) h->L); // read_distribution.c:39
 		stats->n_kernels = CONGA_K_COUNT;
+		stats->split_elements = (int64_t) sb.counters[CNT_SR_ELEMENTS];
+		stats->split_mappings = (int64_t) sb.counters[CNT_SR_MAPPINGS];
+		stats->split_del_rows = (int64_t) sb.counters[CNT_SR_DEL_ROWS];
+		stats->split_dup_rows = (int64_t) sb.counters[CNT_SR_DUP_ROWS];
 		if (ctx->opts.flags & CONGA_FLAG_PROFILE) {
 			for (int k = 0; k < CONGA_K_COUNT; k++) {
 				float ms = 0.0f;

@@ -24,7 +24,7 @@ constexpr int kWave = 64;
 constexpr int kGcBins = 101; // read_distribution.c:51-52
 
 constexpr uint32_t kStatusUnsorted = 1u; // Small.status bits
-enum { CNT_COUNTED = 0, CNT_OUT_OF_RANGE, CNT_N };
+enum { CNT_COUNTED = 0, CNT_OUT_OF_RANGE, CNT_SR_ELEMENTS, CNT_SR_MAPPINGS, CNT_SR_DEL_ROWS, CNT_SR_DUP_ROWS, CNT_N };
 
 // One chromosome of the batch.  Offsets are in elements of the respective concatenated buffer.
 struct Slot {
@@ -1021,6 +1021,285 @@ __global__ __launch_bounds__(256) void interval_score_kernel(ScoreArgs a)
 			r.rp = a.support[iv];
 	}
 	a.out[iv] = r;
+}
+
+// ===========================================================================================
+// Split-read evidence (--rp with --dups).
+// One launch set per chromosome; this path is a parity case (BASELINE configs[4]), not the bench line.
+// ===========================================================================================
+constexpr int kKmerLen = 10;              // HASHKMERLEN (split_read.h:17)
+constexpr int kKmerBuckets = 1 << 20;     // 4^10
+constexpr int kMaxSrHit = 50000;          // MAX_SR_HIT (split_read.h:12)
+constexpr int kMaxMapping = 100;          // MAX_MAPPING (split_read.h:13)
+constexpr int kSrLookahead = 100000;      // SR_LOOKAHEAD (split_read.c:6)
+constexpr int kSoftclipWindow = 50;       // SOFTCLIP_WRONGMAP_WINDOW (bam_data.h:14)
+constexpr int kWrongmapWindow = 100;      // WRONGMAP_WINDOW (likelihood.h:17)
+constexpr int kWrongmapWindowDel = 5000;  // WRONGMAP_WINDOW_DEL (likelihood.h:18)
+constexpr int kSrMaxHalf = 512;           // char str[512] in find_split_reads (split_read.c:211)
+
+__device__ __forceinline__ bool is_dna_letter(uint8_t c)
+{
+	return c == 'A' || c == 'C' || c == 'G' || c == 'T';
+}
+
+// split_read.c:37-49: two bits per base, (c & 6) >> 1 (A 0, C 1, T 2, G 3); -1 when a base is not ACGT
+template <typename F> __device__ __forceinline__ int kmer_hash(F base_at)
+{
+	uint32_t v = 0;
+#pragma unroll
+	for (int i = 0; i < kKmerLen; i++) {
+		const uint8_t c = base_at(i);
+		if (!is_dna_letter(c))
+			return -1;
+		v = (v << 2) | ((uint32_t) (c & 0x6) >> 1);
+	}
+	return (int) v;
+}
+
+// K6 count / fill passes of build_hash_table (split_read.c:357-442): every position whose 10-mer is ACGT-only
+template <bool FILL> __global__ __launch_bounds__(256) void kmer_index_kernel(const uint8_t *__restrict__ ref, int64_t len,
+		uint32_t *__restrict__ count, const uint32_t *__restrict__ offset, uint32_t *__restrict__ cursor,
+		int32_t *__restrict__ positions)
+{
+	const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+	for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i + kKmerLen <= len; i += stride) {
+		const int h = kmer_hash([&](int k) { return ref[i + k]; });
+		if (h < 0)
+			continue;
+		if (!FILL)
+			atomicAdd(&count[h], 1u);
+		else if (offset[h + 1] > offset[h]) // kept bucket (init_hash_table, split_read.c:444-460)
+			positions[offset[h] + atomicAdd(&cursor[h], 1u)] = (int32_t) i;
+	}
+}
+
+// init_hash_table: buckets with count == 0 or >= MAX_SR_HIT are dropped; exclusive scan of the kept counts.
+// One workgroup of 1024 threads, 1024 buckets each.
+__global__ __launch_bounds__(1024) void kmer_offsets_kernel(const uint32_t *__restrict__ count, uint32_t *__restrict__ offset)
+{
+	__shared__ uint32_t part[1024];
+	constexpr int kPer = kKmerBuckets / 1024;
+	const int t = threadIdx.x;
+	uint32_t sum = 0;
+	for (int k = 0; k < kPer; k++) {
+		const uint32_t c = count[t * kPer + k];
+		sum += (c < (uint32_t) kMaxSrHit) ? c : 0u;
+	}
+	part[t] = sum;
+	__syncthreads();
+	for (int o = 1; o < 1024; o <<= 1) { // Hillis-Steele over the 1024 partial sums
+		const uint32_t v = (t >= o) ? part[t - o] : 0u;
+		__syncthreads();
+		part[t] += v;
+		__syncthreads();
+	}
+	uint32_t run = part[t] - sum;
+	for (int k = 0; k < kPer; k++) {
+		const uint32_t c = count[t * kPer + k];
+		offset[t * kPer + k] = run;
+		run += (c < (uint32_t) kMaxSrHit) ? c : 0u;
+	}
+	if (t == 1023)
+		offset[kKmerBuckets] = run;
+}
+
+struct SplitArgs {
+	// reads of this chromosome: the fields of bam1_t the path touches
+	const int32_t *pos;
+	const uint8_t *mapq;
+	const uint16_t *flag;
+	const int32_t *l_qseq;
+	const uint64_t *data_off; // per read: packed 4-bit sequence ((l + 1) / 2 bytes) followed by l quality bytes
+	const uint8_t *data;
+	int64_t n_reads;
+	// chromosome
+	const uint8_t *ref; // upper-case
+	int64_t L;
+	const int32_t *sat_start; // sorted, disjoint
+	const int32_t *sat_end;
+	int32_t n_sat;
+	// k-mer index
+	const uint32_t *offset;
+	const int32_t *positions;
+	// known SVs of this chromosome
+	const int32_t *iv_start;
+	const int32_t *iv_end;
+	int32_t iv0, n_dels, n_dups;
+	int32_t *support; // [n_iv] rp (dups) / border_rp (dels)
+	int32_t mq_threshold, min_read_length;
+	unsigned long long *counters;
+};
+
+// sonic_is_satellite(chr, a, b): any satellite interval overlapping [a, b)
+__device__ __forceinline__ int is_satellite_dev(const SplitArgs &a, int64_t lo_, int64_t hi_)
+{
+	int lo = 0, hi = a.n_sat;
+	while (lo < hi) { // first interval with end > lo_
+		const int mid = (lo + hi) >> 1;
+		if ((int64_t) a.sat_end[mid] <= lo_)
+			lo = mid + 1;
+		else
+			hi = mid;
+	}
+	return (lo < a.n_sat && (int64_t) a.sat_start[lo] < hi_) ? 1 : 0;
+}
+
+// almostPerfect_match_seq_ref for one orientation (split_read.c:116-129 / 164-180): scan the seed's bucket, keep hits
+// within SR_LOOKAHEAD of the anchor whose Hamming distance to the reference is <= dist_max.
+__device__ __forceinline__ int split_scan_bucket(const SplitArgs &a, const uint8_t *str, int n, int anchor, int dist_max,
+		char orient, int size, int32_t *hit_pos, char *hit_orient, int lane, bool stop_past_max)
+{
+	const int h = kmer_hash([&](int k) { return str[k]; });
+	if (h < 0)
+		return size;
+	const uint32_t b0 = a.offset[h], b1 = a.offset[h + 1];
+	for (uint32_t base = b0; base < b1; base += kWave) {
+		const uint32_t k = base + lane;
+		bool hit = false;
+		int p = 0;
+		if (k < b1) {
+			p = a.positions[k];
+			int d = p - anchor;
+			d = d < 0 ? -d : d;
+			if (d < kSrLookahead) {
+				int dist = 0;
+				for (int j = 0; j < n && dist <= dist_max; j++) {
+					const int64_t at = (int64_t) p + j;
+					if (at >= a.L || a.ref[at] != str[j]) // hammingDistance (common.c:278-287)
+						dist++;
+				}
+				hit = dist <= dist_max;
+			}
+		}
+		const unsigned long long m = __ballot(hit);
+		if (hit) {
+			const int slot = size + __popcll(m & ((1ull << lane) - 1ull));
+			if (slot < kMaxMapping) {
+				hit_pos[slot] = p;
+				hit_orient[slot] = orient;
+			}
+		}
+		size += __popcll(m);
+		if (stop_past_max && size > kMaxMapping)
+			break;
+	}
+	return size;
+}
+
+// find_split_reads + read_SplitReads + determine_SvType + count_ReadPairs, one wave per read.
+__global__ __launch_bounds__(256) void split_read_kernel(SplitArgs a)
+{
+	__shared__ uint8_t s_str[4][kSrMaxHalf], s_rev[4][kSrMaxHalf], s_qual[4][2 * kSrMaxHalf];
+	__shared__ int32_t s_hit_pos[4][kMaxMapping];
+	__shared__ char s_hit_orient[4][kMaxMapping];
+	const int wv = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+	uint8_t *str = s_str[wv], *rev = s_rev[wv], *ql = s_qual[wv];
+	int32_t *hit_pos = s_hit_pos[wv];
+	char *hit_orient = s_hit_orient[wv];
+	const int64_t n_waves = (int64_t) gridDim.x * 4;
+	unsigned long long n_elem = 0, n_map = 0, n_del = 0, n_dup = 0;
+
+	for (int64_t r = (int64_t) blockIdx.x * 4 + wv; r < a.n_reads; r += n_waves) {
+		const int l = a.l_qseq[r], p = a.pos[r], q = a.mapq[r], fl = a.flag[r];
+		// gate of count_reads_bam (bam_data.c:205-207) and find_split_reads' pos == 0 (split_read.c:216)
+		if (!(q > a.mq_threshold) || !(l > a.min_read_length) || (fl & (0x100 | 0x800 | 0x400 | 0x200)) != 0)
+			continue;
+		if (p == 0 || l > 2 * kSrMaxHalf - 2 || is_satellite_dev(a, p, (int64_t) p + 20))
+			continue;
+		const uint8_t *sq = a.data + a.data_off[r];
+		const uint8_t *qq = sq + (l + 1) / 2;
+		const int half = l / 2;
+		__builtin_amdgcn_wave_barrier();
+		for (int i = lane; i < l; i += kWave)
+			ql[i] = qq[i];
+		__builtin_amdgcn_wave_barrier();
+
+		float avg = 0.0f;
+		for (int e = 0; e < 2; e++) {
+			// element 1: anchor pos, maps bases [l/2, l); element 2: anchor pos + l/2, maps [0, l/2)
+			const int from = (e == 0) ? half : 0, n = (e == 0) ? l - half : half;
+			const int anchor = (e == 0) ? p : p + half;
+			// mean base quality of the mapped half; the accumulator is NOT reset between the two
+			// elements (split_read.c:238-243,307-312), sequential float adds as in the reference
+			for (int i = from; i < from + n; i++)
+				avg = avg + (float) ql[i];
+			avg = avg / (float) n;
+			if ((int) floorf(avg) < a.mq_threshold)
+				break; // element 1 dropped -> element 2 never created; element 2 dropped -> done
+			n_elem++;
+			__builtin_amdgcn_wave_barrier();
+			for (int i = lane; i < n; i += kWave) {
+				const int b = from + i;
+				const int code = (b & 1) ? (sq[b >> 1] & 0xF) : (sq[b >> 1] >> 4); // bam_seqi
+				const uint8_t c = code == 1 ? 'A' : code == 2 ? 'C' : code == 4 ? 'G' : code == 8 ? 'T' : 'N';
+				str[i] = c;
+				rev[n - i - 1] = c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'G' ? 'C' : c == 'C' ? 'G' : 'N';
+			}
+			__builtin_amdgcn_wave_barrier();
+			if (n < kKmerLen)
+				continue;
+			const int dist_max = (int) (0.05 * (double) n);
+			int size = split_scan_bucket(a, str, n, anchor, dist_max, 'F', 0, hit_pos, hit_orient, lane, false);
+			if (size < kMaxMapping)
+				size = split_scan_bucket(a, rev, n, anchor, dist_max, 'R', size, hit_pos, hit_orient, lane, true);
+			__builtin_amdgcn_wave_barrier();
+			if (!(size > 0 && size < kMaxMapping))
+				continue;
+			n_map += (unsigned long long) size;
+			const int mapq_sr = 60 / size;
+			// read_SplitReads / determine_SvType (bam_data.c:29-154) for every mapping, then count_ReadPairs
+			// (likelihood.c:41-94) against this chromosome's SVs
+			for (int m = 0; m < size; m++) {
+				const int posMap = hit_pos[m];
+				const char orient = hit_orient[m];
+				if (is_satellite_dev(a, anchor, (int64_t) anchor + 1) + is_satellite_dev(a, posMap, (int64_t) posMap + 1) != 0)
+					continue;
+				if (!(mapq_sr > a.mq_threshold && anchor > 0 && posMap > 0 && anchor < a.L && posMap < a.L))
+					continue;
+				const int lengthSplit = l / 2, lengthRead = l - lengthSplit;
+				int pos1_2, pos2_1;
+				if (anchor < posMap) {
+					pos1_2 = anchor + lengthRead;
+					pos2_1 = posMap;
+				} else if (posMap < anchor) {
+					pos1_2 = posMap + lengthSplit;
+					pos2_1 = anchor;
+				} else
+					continue;
+				if (pos1_2 >= pos2_1 || orient != 'F')
+					continue;
+				const bool is_del = (anchor < posMap && e == 0) || (anchor > posMap && e == 1);
+				const int left_end = pos1_2 - kSoftclipWindow, right_start = pos2_1 + kSoftclipWindow;
+				if (is_del) {
+					n_del++;
+					for (int i = lane; i < a.n_dels; i += kWave) {
+						const int s0 = a.iv_start[a.iv0 + i], e0 = a.iv_end[a.iv0 + i];
+						if (left_end <= s0 + kWrongmapWindow && left_end >= s0 - kWrongmapWindowDel
+								&& right_start >= e0 - kWrongmapWindow && right_start <= e0 + kWrongmapWindowDel)
+							atomicAdd(&a.support[a.iv0 + i], 1);
+					}
+				} else {
+					n_dup++;
+					for (int i = lane; i < a.n_dups; i += kWave) {
+						const int iv = a.iv0 + a.n_dels + i;
+						const int lo = a.iv_start[iv] - kWrongmapWindowDel, hi = a.iv_end[iv] + kWrongmapWindowDel;
+						if (left_end >= lo && left_end <= hi && right_start <= hi && right_start >= lo)
+							atomicAdd(&a.support[iv], 1);
+					}
+				}
+			}
+		}
+	}
+	if (lane == 0) {
+		if (n_elem)
+			atomicAdd(&a.counters[CNT_SR_ELEMENTS], n_elem);
+		if (n_map)
+			atomicAdd(&a.counters[CNT_SR_MAPPINGS], n_map);
+		if (n_del)
+			atomicAdd(&a.counters[CNT_SR_DEL_ROWS], n_del);
+		if (n_dup)
+			atomicAdd(&a.counters[CNT_SR_DUP_ROWS], n_dup);
+	}
 }
 
 } // namespace conga

@@ -70,7 +70,8 @@ typedef struct conga_opts {
 	int32_t mq_threshold;    /* params->mq_threshold (cmdline.c:188-194): a read counts iff mapq > this; -1 = all */
 	int32_t gc_step;         /* WINDOWSLIDE (read_distribution.h:8): bases per GC byte; 0 -> 100 */
 	uint32_t flags;          /* CONGA_FLAG_* */
-	int32_t reserved[4];
+	int32_t min_read_length; /* params->min_read_length (cmdline.c:162-166), split reads only; <= 0 -> 60 */
+	int32_t reserved[3];
 } conga_opts;
 
 /* Pinned host buffers the BAM loop fills (structure of arrays).  Replaces the fields of
@@ -117,6 +118,11 @@ typedef struct conga_chrom_stats {
 	int64_t rd_per_gc[101];     /* rd_per_gc_unfiltered (read_distribution.c:52) */
 	int64_t window_per_gc[101]; /* window_per_gc (read_distribution.c:51) */
 	double kernel_ms[8];        /* per-kernel device time of the last compute (CONGA_FLAG_PROFILE), else 0 */
+	/* split-read evidence (only when split reads and a reference sequence were given) */
+	int64_t split_elements;     /* split_read_count (split_read.c:14): half-read elements created */
+	int64_t split_mappings;     /* mappings emitted by almostPerfect_match_seq_ref (split_read.c:185-201) */
+	int64_t split_del_rows;     /* SplitRow records of type DELETION (bam_data.c:104-146) */
+	int64_t split_dup_rows;     /* ... of type DUPLICATION */
 } conga_chrom_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------- */
@@ -166,6 +172,31 @@ int conga_mappability(conga_ctx *ctx, const int32_t *start, const int32_t *end, 
  * (end - start >= min_sv_size) and sorted by (start, end) (likelihood.c:324-328), type
  * CONGA_DELETION or CONGA_DUPLICATION.  Copies the arrays; once per type per chromosome. */
 int conga_intervals(conga_ctx *ctx, char type, const int32_t *start, const int32_t *end, size_t n);
+
+/* ---- split-read evidence: find_split_reads / read_SplitReads / count_ReadPairs on the device --------------
+ * Used when the reference would run its split-read path (`--rp` given AND `--dups` given: svdepth.c:57,
+ * bam_data.c:207,306,331, likelihood.c:344).  For the chromosome begun last, hand over
+ *   - its reference sequence (readReferenceSeq, common.c:423-463; upper-cased by the callee),
+ *   - its satellite intervals (sonic_is_satellite, bam_data.c:96-97,207; any order, may overlap),
+ *   - every record of the BAM loop with the fields find_split_reads touches (split_read.c:206-354):
+ *     core.pos, core.qual, core.flag, core.l_qseq, the packed 4-bit sequence and the base qualities.
+ * The gate of bam_data.c:205-207 (mapq, length, flags, satellite) is applied by the engine.
+ * conga_chrom_compute() then builds the 10-mer index, maps both halves of every read, pairs them and adds the
+ * support counts into conga_result.rp (dups) / border_rp (dels). */
+typedef struct conga_split_staging {
+	int32_t *pos;       /* bam1_core_t.pos */
+	uint8_t *mapq;      /* bam1_core_t.qual */
+	uint16_t *flag;     /* bam1_core_t.flag */
+	int32_t *l_qseq;    /* bam1_core_t.l_qseq */
+	uint64_t *data_off; /* offset of record i's block inside `data` */
+	uint8_t *data;      /* per record: (l_qseq + 1) / 2 bytes bam_get_seq() then l_qseq bytes bam_get_qual() */
+	size_t capacity_reads;
+	size_t capacity_bytes;
+} conga_split_staging;
+int conga_reference(conga_ctx *ctx, const char *seq, int64_t len);
+int conga_satellites(conga_ctx *ctx, const int32_t *start, const int32_t *end, size_t n);
+int conga_split_reads_staging(conga_ctx *ctx, conga_split_staging *out);
+int conga_split_reads_commit(conga_ctx *ctx, size_t n_reads, size_t n_bytes);
 
 /* count_ReadPairs result for this chromosome (likelihood.c:41-94): per-interval split-read support
  * in the order of conga_intervals(); copied through to conga_result.rp (dups) / border_rp (dels). */

@@ -99,6 +99,13 @@ int64_t oracle_load_known_SVs(const char *bed_path, const char *chr, int min_sv_
 /* svs.c:317-377: parse the whole mappability BED and paint rows of `chr`.  Returns rows painted or -1. */
 int64_t oracle_load_mappability_regions(const char *bed_path, const char *chr, float *mappability, int64_t L);
 
+/* split_read.c:31-466 + bam_data.c:29-154,205-210 for one chromosome (conga_oracle_sr.c).  seq: one 4-bit BAM
+ * base code per byte, qual: Phred bytes, both at data_off[i].  counts: {elements, mappings, DEL rows, DUP rows}. */
+int64_t oracle_split_read_rows(const char *ref, int64_t L, const int32_t *sat_start, const int32_t *sat_end,
+		int64_t n_sat, int64_t n_reads, const int32_t *pos, const uint8_t *mapq, const uint16_t *flag,
+		const int32_t *l_qseq, const uint64_t *data_off, const uint8_t *seq, const uint8_t *qual, int mq_threshold,
+		int min_read_length, oracle_split_row **rows_out, int64_t counts[4]);
+
 /* likelihood.c:41-94 */
 void oracle_count_ReadPairs(const oracle_split_row *rows, int64_t n_rows, oracle_sv *dels, int64_t del_count,
 		oracle_sv *dups, int64_t dup_count);

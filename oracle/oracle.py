@@ -37,10 +37,9 @@ SPLIT_ROW_DTYPE = np.dtype([("left_end", "<i4"), ("right_start", "<i4"), ("sv_ty
 
 def build(force=False):
     """Compile liboracle.so with the committed Makefile (gcc only)."""
-    src = os.path.join(_HERE, "conga_oracle.c")
-    hdr = os.path.join(_HERE, "conga_oracle.h")
+    srcs = [os.path.join(_HERE, f) for f in ("conga_oracle.c", "conga_oracle_sr.c", "conga_oracle.h", "Makefile")]
     if (not force and os.path.exists(_LIB_PATH)
-            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(f) for f in srcs)):
         return _LIB_PATH
     subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
@@ -77,6 +76,9 @@ def lib():
         L.oracle_load_known_SVs.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(p)]
         L.oracle_load_mappability_regions.restype = C.c_int64
         L.oracle_load_mappability_regions.argtypes = [C.c_char_p, C.c_char_p, p, C.c_int64]
+        L.oracle_split_read_rows.restype = C.c_int64
+        L.oracle_split_read_rows.argtypes = [C.c_char_p, C.c_int64, p, p, C.c_int64, C.c_int64, p, p, p, p, p, p, p,
+                                             C.c_int, C.c_int, C.POINTER(p), p]
         L.oracle_count_ReadPairs.restype = None
         L.oracle_count_ReadPairs.argtypes = [p, C.c_int64, p, C.c_int64, p, C.c_int64]
         L.oracle_output_SVs_paths.restype = C.c_int
@@ -178,6 +180,34 @@ def load_mappability_regions(bed_path, chrom, L):
     if n < 0:
         raise FileNotFoundError(bed_path)
     return m, int(n)
+
+
+def split_read_rows(ref, sat_start, sat_end, pos, mapq, flag, l_qseq, data_off, seq, qual, mq_threshold=-1,
+                    min_read_length=60):
+    """One chromosome's split-read rows. ref: bytes (upper-case); seq: uint8 base codes (one per byte);
+    -> (rows SPLIT_ROW_DTYPE[], counts int64[4] = elements, mappings, DEL rows, DUP rows)"""
+    ss = np.ascontiguousarray(sat_start, dtype=np.int32)
+    se = np.ascontiguousarray(sat_end, dtype=np.int32)
+    pos = np.ascontiguousarray(pos, dtype=np.int32)
+    mapq = np.ascontiguousarray(mapq, dtype=np.uint8)
+    flag = np.ascontiguousarray(flag, dtype=np.uint16)
+    lq = np.ascontiguousarray(l_qseq, dtype=np.int32)
+    off = np.ascontiguousarray(data_off, dtype=np.uint64)
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    qual = np.ascontiguousarray(qual, dtype=np.uint8)
+    out = C.c_void_p()
+    counts = np.zeros(4, dtype=np.int64)
+    n = lib().oracle_split_read_rows(ref, len(ref), _ptr(ss), _ptr(se), len(ss), len(pos), _ptr(pos), _ptr(mapq),
+                                     _ptr(flag), _ptr(lq), _ptr(off), _ptr(seq), _ptr(qual), mq_threshold,
+                                     min_read_length, C.byref(out), _ptr(counts))
+    if n > 0:
+        buf = (C.c_char * (n * SPLIT_ROW_DTYPE.itemsize)).from_address(out.value)
+        rows = np.frombuffer(buf, dtype=SPLIT_ROW_DTYPE).copy()
+    else:
+        rows = np.zeros(0, dtype=SPLIT_ROW_DTYPE)
+    if out.value:
+        C.CDLL(None).free(out)
+    return rows, counts
 
 
 def count_read_pairs(rows, dels, dups):

@@ -1,0 +1,112 @@
+"""Split-read evidence (--rp with --dups; SURVEY.md section 8 rows a15-a18, BASELINE configs[4]) through the C-ABI
+against the oracle restatement of split_read.c / bam_data.c:29-154 / likelihood.c:41-94."""
+import numpy as np
+import pytest
+
+from conga_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+CODE = {ord("A"): 1, ord("C"): 2, ord("G"): 4, ord("T"): 8, ord("N"): 15}
+
+
+def make_case(seed=3, L=400_000, n_normal=9000):
+    rng = np.random.default_rng(seed)
+    ref = rng.choice(np.frombuffer(b"ACGT", np.uint8), L)
+    ref[50_000:50_400] = ord("N")                                   # N block: 10-mers across it are not indexed
+    ref[250_000:311_000] = ord("A")                                 # one 10-mer 61,000 times: bucket dropped (>= 50000)
+    ref[120_000:120_300] = ref[20_000:20_300]                       # a repeat within 100 kb: two mappings, mapq 30
+    lower = ref.copy()
+    lower[300:900] |= 0x20                                          # soft-masked bases: upper-cased on load
+    dels = [(30_000, 34_000), (100_000, 103_000), (150_000, 151_500)]
+    dups = [(200_000, 204_000), (330_000, 345_000)]
+    reads = []  # (pos, bases uint8[], mapq, flag, qual)
+
+    def add(pos, bases, mapq=60, flag=0, q=30):
+        reads.append((int(pos), np.asarray(bases, np.uint8), mapq, flag, np.full(len(bases), q, np.uint8)))
+
+    for (s, e) in dels[1:]:                                         # reads across a deletion junction
+        for k in range(25, 80, 3):
+            add(s - k, np.concatenate([ref[s - k:s], ref[e:e + 100 - k]]))
+    for (s, e) in dups:                                             # reads across a tandem-duplication junction
+        for k in range(30, 75, 4):
+            add(e - k, np.concatenate([ref[e - k:e], ref[s:s + 100 - k]]))
+    for _ in range(n_normal):                                       # ordinary reads, some noisy
+        l = int(rng.choice([100, 100, 100, 101, 76, 70, 59, 60, 61, 151]))
+        p = int(rng.integers(0, L - 200))
+        b = ref[p:p + l].copy()
+        if rng.random() < 0.3:
+            idx = rng.integers(0, l, int(rng.integers(1, 5)))
+            b[idx] = rng.choice(np.frombuffer(b"ACGTN", np.uint8), len(idx))
+        mapq = int(rng.choice([60, 60, 60, 0, 17, 40]))
+        flag = int(rng.choice([0, 0, 0, 0, 0x400, 0x100, 0x800, 0x200, 16]))
+        add(p, b, mapq, flag, int(rng.choice([30, 30, 12, 2])))
+    add(0, ref[0:100])                                              # pos == 0 is skipped
+    add(20_000, ref[20_000:20_100])                                 # second half sits in the repeat: 2 mappings
+    add(20_100, ref[20_100:20_200])
+    reads.sort(key=lambda r: r[0])
+    pos = np.array([r[0] for r in reads], np.int32)
+    lq = np.array([len(r[1]) for r in reads], np.int32)
+    off = np.concatenate([[0], np.cumsum(lq)[:-1]]).astype(np.uint64)
+    lut = np.full(256, 15, np.uint8)
+    for k, v in CODE.items():
+        lut[k] = v
+    codes = lut[np.concatenate([r[1] for r in reads])]
+    qual = np.concatenate([r[4] for r in reads])
+    mapq = np.array([r[2] for r in reads], np.uint8)
+    flag = np.array([r[3] for r in reads], np.uint16)
+    sat_s = np.array([60_000, 380_000, 61_000], np.int32)          # unsorted, overlapping on purpose
+    sat_e = np.array([62_000, 381_000, 64_000], np.int32)
+    return dict(L=L, ref=bytes(ref), ref_lower=bytes(lower), dels=dels, dups=dups, pos=pos, mapq=mapq, flag=flag, lq=lq,
+                off=off, codes=codes, qual=qual, sat_s=sat_s, sat_e=sat_e)
+
+
+def run_both(capi, oracle, c, mq=-1, min_read_length=60):
+    ds, de = np.array([d[0] for d in c["dels"]], np.int32), np.array([d[1] for d in c["dels"]], np.int32)
+    us, ue = np.array([d[0] for d in c["dups"]], np.int32), np.array([d[1] for d in c["dups"]], np.int32)
+    rows, counts = oracle.split_read_rows(c["ref"], c["sat_s"], c["sat_e"], c["pos"], c["mapq"], c["flag"], c["lq"], c["off"],
+                                          c["codes"], c["qual"], mq, min_read_length)
+    od, ou = oracle.make_svs(ds, de), oracle.make_svs(us, ue)
+    oracle.count_read_pairs(rows, od, ou)
+    gc = np.full((c["L"] + 99) // 100, 40, np.uint8)
+    with capi.Context(device=0, mq_threshold=mq, min_read_length=min_read_length) as ctx:
+        ctx.chrom_begin(c["L"], gc)
+        ctx.reads(c["pos"], c["mapq"])
+        ctx.reference(c["ref_lower"])
+        ctx.satellites(c["sat_s"], c["sat_e"])
+        ctx.split_reads(c["pos"], c["mapq"], c["flag"], c["lq"], c["codes"], c["qual"], c["off"])
+        ctx.intervals("D", ds, de)
+        ctx.intervals("E", us, ue)
+        dels, dups, _, st = ctx.finish()
+        again = ctx.finish()
+    assert np.array_equal(again[0]["border_rp"], dels["border_rp"]) and np.array_equal(again[1]["rp"], dups["rp"])
+    return (dels, dups, st), (od, ou, rows, counts)
+
+
+@pytest.mark.parametrize("mq,min_len", [(-1, 60), (20, 60), (35, 75), (-1, 10)])
+def test_split_read_support_matches_the_oracle(capi, oracle, mq, min_len):
+    c = make_case()
+    (dels, dups, st), (od, ou, rows, counts) = run_both(capi, oracle, c, mq, min_len)
+    assert (st.split_elements, st.split_mappings, st.split_del_rows, st.split_dup_rows) == tuple(int(x) for x in counts)
+    assert np.array_equal(dels["border_rp"], od["border_rp"]) and np.all(dels["rp"] == 0)
+    assert np.array_equal(dups["rp"], ou["rp"]) and np.all(dups["border_rp"] == 0)
+    if mq == -1 and min_len == 60:
+        # the planted junctions are found: every deletion / duplication with spanning reads gets support
+        assert od["border_rp"][1] > 5 and od["border_rp"][2] > 5 and od["border_rp"][0] == 0
+        assert ou["rp"][0] > 5 and ou["rp"][1] > 5
+        assert counts[0] > 5_000 and counts[1] > 3_000
+
+
+def test_without_reference_or_reads_nothing_is_counted(capi):
+    c = make_case(n_normal=200)
+    ds, de = np.array([100_000], np.int32), np.array([103_000], np.int32)
+    gc = np.full((c["L"] + 99) // 100, 40, np.uint8)
+    with capi.Context(device=0) as ctx:
+        ctx.chrom_begin(c["L"], gc)
+        ctx.reads(c["pos"], c["mapq"])
+        ctx.split_reads(c["pos"], c["mapq"], c["flag"], c["lq"], c["codes"], c["qual"], c["off"])
+        ctx.intervals("D", ds, de)
+        dels, _, _, st = ctx.finish()
+        assert st.split_elements == 0 and np.all(dels["border_rp"] == 0)
+        with pytest.raises(capi.CongaError):
+            ctx.reference(b"ACGT")  # wrong length
