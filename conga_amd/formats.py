@@ -94,10 +94,27 @@ def _reg2bin(beg, end):
     return 0
 
 
-def write_bam(path, sample, chroms, read_len=100, unplaced=0, block_payload=60000):
+def write_fasta(path, chroms, width=60, index=True):
+    """chroms: list of (name, bytes).  Also writes path + '.fai' (name, length, offset, linebases, linewidth)."""
+    fai = []
+    with open(path, "wb") as f:
+        for name, seq in chroms:
+            f.write(b">" + name.encode() + b"\n")
+            fai.append((name, len(seq), f.tell(), width, width + 1))
+            for i in range(0, len(seq), width):
+                f.write(seq[i:i + width] + b"\n")
+    if index:
+        with open(path + ".fai", "w") as f:
+            for r in fai:
+                f.write("\t".join(str(x) for x in r) + "\n")
+
+
+def write_bam(path, sample, chroms, read_len=100, unplaced=0, block_payload=60000, records=None):
     """chroms: list of (name, length, pos int32[n] sorted, mapq uint8[n][, flag uint16[n]]).
     Every record gets a `read_len`M CIGAR, an all-A sequence and quality 30; `unplaced` unmapped records
-    (refID -1) are appended at the end, as in a real coordinate-sorted BAM."""
+    (refID -1) are appended at the end, as in a real coordinate-sorted BAM.
+    records: optional {chrom name: (l_qseq int32[n], codes uint8[], qual uint8[], off uint64[n])} with one 4-bit
+    base code per byte -- then every record carries its own sequence, qualities and an <l>M CIGAR."""
     text = "@HD\tVN:1.6\tSO:coordinate\n"
     for c in chroms:
         text += "@SQ\tSN:%s\tLN:%d\n" % (c[0], c[1])
@@ -122,10 +139,20 @@ def write_bam(path, sample, chroms, read_len=100, unplaced=0, block_payload=6000
         for tid, c in enumerate(chroms):
             pos, mapq = np.asarray(c[2]), np.asarray(c[3])
             flag = np.asarray(c[4]) if len(c) > 4 else np.zeros(len(pos), np.uint16)
-            for p, q, fl in zip(pos.tolist(), mapq.tolist(), flag.tolist()):
+            rec = records.get(c[0]) if records else None
+            for j, (p, q, fl) in enumerate(zip(pos.tolist(), mapq.tolist(), flag.tolist())):
                 name = ("r%d" % k).encode() + b"\x00"
                 k += 1
-                body = struct.pack("<iiBBHHHiiii", tid, p, len(name), q, _reg2bin(p, p + read_len), 1, fl, l_seq,
+                if rec is not None:
+                    l_seq = int(rec[0][j])
+                    o = int(rec[3][j])
+                    codes = np.zeros((l_seq + 1) // 2 * 2, np.uint8)
+                    codes[:l_seq] = rec[1][o:o + l_seq]
+                    seq = ((codes[0::2] << 4) | codes[1::2]).tobytes()
+                    qual = np.asarray(rec[2][o:o + l_seq], np.uint8).tobytes()
+                    cigar = struct.pack("<I", (l_seq << 4) | 0)
+                    read_len = l_seq
+                body = struct.pack("<iiBBHHHiiii", tid, p, len(name), q, _reg2bin(p, p + max(read_len, 1)), 1, fl, l_seq,
                                    -1, -1, 0) + name + cigar + seq + qual
                 out += struct.pack("<i", len(body)) + body
                 if len(out) >= block_payload:

@@ -5,6 +5,7 @@
 // Outputs are byte-identical to doing begin / finish per chromosome; the GPU just gets launches that fill it.
 #include "bam_data.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -48,7 +49,8 @@ void engine_check(conga_ctx *ctx, int rc, const char *what)
 }
 
 // count_reads_bam (bam_data.c:192-221), producer side: records go straight into the pinned staging ring.
-int64_t count_reads_bam(conga_ctx *ctx, read_source *src, int chr_index_bam, int64_t chrom_len)
+// With split reads enabled (--rp and --dups) every record is also handed over whole (split_read.c:206-354).
+int64_t count_reads_bam(conga_ctx *ctx, read_source *src, int chr_index_bam, int64_t chrom_len, bool split_reads)
 {
 	std::string err;
 	if (!src->begin(chr_index_bam, chrom_len, &err)) {
@@ -56,6 +58,34 @@ int64_t count_reads_bam(conga_ctx *ctx, read_source *src, int chr_index_bam, int
 		exit(1);
 	}
 	int64_t cnt = 0;
+	if (split_reads) {
+		for (;;) {
+			conga_split_staging ss;
+			engine_check(ctx, conga_split_reads_staging(ctx, &ss), "conga_split_reads_staging");
+			full_batch fb = {ss.pos, ss.mapq, ss.flag, ss.l_qseq, ss.data_off, ss.data, ss.capacity_reads, ss.capacity_bytes, 0, 0};
+			if (!src->next_full(&fb, &err))
+				print_error("[CONGA INPUT ERROR] " + err);
+			// the depth side gets the same records
+			for (size_t done = 0; done < fb.n_reads || (done == 0 && fb.n_reads == 0);) {
+				conga_read_staging stg;
+				engine_check(ctx, conga_reads_staging(ctx, &stg), "conga_reads_staging");
+				const size_t k = std::min(stg.capacity, fb.n_reads - done);
+				if (k) {
+					memcpy(stg.pos, fb.pos + done, k * sizeof(int32_t));
+					memcpy(stg.mapq, fb.mapq + done, k);
+				}
+				engine_check(ctx, conga_reads_commit(ctx, k), "conga_reads_commit");
+				done += k;
+				if (fb.n_reads == 0)
+					break;
+			}
+			engine_check(ctx, conga_split_reads_commit(ctx, fb.n_reads, fb.n_bytes), "conga_split_reads_commit");
+			cnt += (int64_t) fb.n_reads;
+			if (fb.n_reads == 0)
+				break;
+		}
+		return cnt;
+	}
 	for (;;) {
 		conga_read_staging stg;
 		engine_check(ctx, conga_reads_staging(ctx, &stg), "conga_reads_staging");
@@ -117,6 +147,9 @@ int read_bam(parameters *params, sonic *this_sonic)
 	opts.mq_threshold = params->mq_threshold;
 	opts.gc_step = this_sonic->gc_step;
 	opts.flags = CONGA_FLAG_BATCH;
+	opts.min_read_length = params->min_read_length;
+	// the reference's split-read gate: `!no_sr && dup_file` (svdepth.c:57, bam_data.c:207,306,331, likelihood.c:344)
+	const bool split_reads = !params->no_sr && params->have_dups;
 	int status = 0;
 	conga_ctx *ctx = conga_create(params->device, &opts, &status);
 	if (!ctx) {
@@ -150,8 +183,18 @@ int read_bam(parameters *params, sonic *this_sonic)
 		engine_check(ctx, conga_chrom_begin(ctx, L, gc_hist_w.data(), gc_like_w.data(), (int64_t) gc_hist_w.size()),
 				"conga_chrom_begin");
 
+		if (split_reads) {
+			// readReferenceSeq (common.c:423-463) and the satellite annotation (bam_data.c:96-97,207)
+			fprintf(stderr, "\nReading the Reference Genome");
+			std::string ref_seq;
+			if (!load_fasta_chrom(params->ref_genome, name, L, &ref_seq, &err))
+				print_error(err);
+			engine_check(ctx, conga_reference(ctx, ref_seq.data(), (int64_t) ref_seq.size()), "conga_reference");
+			engine_check(ctx, conga_satellites(ctx, this_sonic->sat_start[chr_index].data(), this_sonic->sat_end[chr_index].data(),
+					this_sonic->sat_start[chr_index].size()), "conga_satellites");
+		}
 		fprintf(stderr, "\n-->counting reads");
-		const int64_t cnt_reads = count_reads_bam(ctx, src.get(), chr_index_bam, L);
+		const int64_t cnt_reads = count_reads_bam(ctx, src.get(), chr_index_bam, L, split_reads);
 		fprintf(stderr, " (%lld reads, %ld split-reads)\n", (long long) cnt_reads, 0L);
 
 		// find_SVs, loading half (likelihood.c:319-336): BED rows are matched against the BAM's target name
@@ -211,6 +254,8 @@ int read_bam(parameters *params, sonic *this_sonic)
 			// calc_mu_per_chr's log line (read_distribution.c:41)
 			fprintf(logFile, "Read Count:%li  Window count:%li mean=%f\n", (long) st.rd_sum,
 					(long) this_sonic->chromosome_lengths[sonic_refind_chromosome_index(this_sonic, cs.chr_name)], st.mean);
+			if (split_reads)
+				fprintf(stderr, "\nCONGA paired %lld single-end reads\n", (long long) (st.split_del_rows + st.split_dup_rows));
 			if (cs.dels.size() + cs.dups.size() == 0)
 				continue; // find_SVs returns before output_SVs when the chromosome has no SV (likelihood.c:332-336)
 			output_SVs(params, cs, fpSVs, fpDel, fpDup);

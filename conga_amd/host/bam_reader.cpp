@@ -248,11 +248,66 @@ public:
 		return true;
 	}
 
+	bool next_full(full_batch *fb, std::string *err) override
+	{
+		fb->n_reads = fb->n_bytes = 0;
+		keep_body_ = true;
+		while (!done_ && fb->n_reads < fb->cap_reads) {
+			core c;
+			if (have_pending_) {
+				c = pending_;
+				body_.swap(pending_body_);
+				have_pending_ = false;
+			} else if (!read_core(&c, err)) {
+				if (!err->empty())
+					return false;
+				done_ = true;
+				break;
+			}
+			last_ref_ = c.ref_id;
+			if (c.ref_id >= 0 && c.ref_id < tid_)
+				continue;
+			if (c.ref_id != tid_ || c.pos >= len_) {
+				pending_ = c;
+				pending_body_ = body_;
+				have_pending_ = true;
+				done_ = true;
+				break;
+			}
+			if (c.pos < 0)
+				continue;
+			const size_t l = (size_t) (c.l_seq > 0 ? c.l_seq : 0);
+			const size_t need = (l + 1) / 2 + l;
+			// body_ = read_name | cigar | seq | qual | aux
+			const size_t seq_at = (size_t) c.l_read_name + (size_t) c.n_cigar * 4;
+			if (seq_at + need > body_.size()) {
+				*err = "corrupt BAM record";
+				return false;
+			}
+			if (fb->n_bytes + need > fb->cap_bytes) { // no room: hand the record over next time
+				pending_ = c;
+				pending_body_ = body_;
+				have_pending_ = true;
+				break;
+			}
+			const size_t k = fb->n_reads++;
+			fb->pos[k] = c.pos;
+			fb->mapq[k] = c.mapq;
+			fb->flag[k] = c.flag;
+			fb->l_qseq[k] = c.l_seq;
+			fb->data_off[k] = fb->n_bytes;
+			memcpy(fb->data + fb->n_bytes, body_.data() + seq_at, need);
+			fb->n_bytes += need;
+		}
+		keep_body_ = false;
+		return true;
+	}
+
 private:
 	struct core {
 		int32_t ref_id, pos;
-		uint8_t mapq;
-		uint16_t flag;
+		uint8_t mapq, l_read_name;
+		uint16_t flag, n_cigar;
 		int32_t l_seq;
 	};
 
@@ -317,10 +372,19 @@ private:
 		}
 		memcpy(&c->ref_id, b, 4);
 		memcpy(&c->pos, b + 4, 4);
+		c->l_read_name = b[8];
 		c->mapq = b[9];
+		memcpy(&c->n_cigar, b + 12, 2);
 		memcpy(&c->flag, b + 14, 2);
 		memcpy(&c->l_seq, b + 16, 4);
-		if (!bgzf_.skip((size_t) block_size - 32)) {
+		const size_t rest = (size_t) block_size - 32;
+		bool ok;
+		if (keep_body_) {
+			body_.resize(rest);
+			ok = bgzf_.read(body_.data(), rest);
+		} else
+			ok = bgzf_.skip(rest);
+		if (!ok) {
 			*err = "truncated BAM record";
 			return false;
 		}
@@ -369,8 +433,9 @@ private:
 	std::vector<uint8_t> mapq_;
 	int tid_ = -1, last_ref_ = -2;
 	int64_t len_ = 0;
-	bool done_ = false, have_pending_ = false;
+	bool done_ = false, have_pending_ = false, keep_body_ = false;
 	core pending_{};
+	std::vector<uint8_t> body_, pending_body_;
 };
 
 } // namespace

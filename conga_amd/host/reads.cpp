@@ -5,6 +5,8 @@
 #include <fcntl.h>
 #include <unistd.h>
 
+#include <algorithm>
+#include <cctype>
 #include <cstdio>
 #include <cstring>
 
@@ -165,6 +167,69 @@ read_source *open_reads(const std::string &path, std::string *err)
 		return open_bam(path, err);
 	*err = path + ": neither a BAM nor a CONGATP1 read-tuple container (CRAM is not supported)";
 	return nullptr;
+}
+
+bool load_fasta_chrom(const std::string &fasta_path, const std::string &name, int64_t chrom_len, std::string *seq,
+		std::string *err)
+{
+	FILE *f = fopen(fasta_path.c_str(), "rb");
+	if (!f) {
+		*err = "[CONGA INPUT ERROR] Unable to open file " + fasta_path + " in read mode.";
+		return false;
+	}
+	seq->clear();
+	seq->reserve((size_t) chrom_len);
+	bool found = false;
+	// .fai: name, length, offset, bases per line, bytes per line
+	FILE *fai = fopen((fasta_path + ".fai").c_str(), "r");
+	if (fai) {
+		char nm[1024];
+		long long len, off, lb, lw;
+		while (fscanf(fai, "%1023s %lld %lld %lld %lld", nm, &len, &off, &lb, &lw) == 5) {
+			if (name == nm && lb > 0 && lw >= lb) {
+				found = true;
+				const long long want = std::min<long long>(len, chrom_len);
+				std::vector<char> line((size_t) lw);
+				fseeko(f, (off_t) off, SEEK_SET);
+				while ((long long) seq->size() < want) {
+					const size_t got = fread(line.data(), 1, (size_t) lw, f);
+					if (got == 0)
+						break;
+					const size_t take = std::min<size_t>(std::min<size_t>(got, (size_t) lb), (size_t) (want - (long long) seq->size()));
+					seq->append(line.data(), take);
+				}
+				break;
+			}
+		}
+		fclose(fai);
+	}
+	if (!found) { // no index: scan for ">name"
+		std::vector<char> buf(1 << 16);
+		bool in_rec = false;
+		while (fgets(buf.data(), (int) buf.size(), f)) {
+			if (buf[0] == '>') {
+				if (in_rec)
+					break;
+				size_t k = 1;
+				while (buf[k] && !isspace((unsigned char) buf[k]))
+					k++;
+				in_rec = found = (std::string(buf.data() + 1, k - 1) == name);
+				continue;
+			}
+			if (!in_rec)
+				continue;
+			for (const char *c = buf.data(); *c && (int64_t) seq->size() < chrom_len; c++)
+				if (!isspace((unsigned char) *c))
+					seq->push_back(*c);
+		}
+	}
+	fclose(f);
+	if (!found) {
+		*err = "chromosome " + name + " is not in " + fasta_path;
+		return false;
+	}
+	seq->resize((size_t) chrom_len, 'N');
+	return true;
 }
 
 int find_chr_index_bam(const std::string &chromosome_name, const read_source &src)

@@ -14,6 +14,18 @@ struct read_batch {
 	size_t n;
 };
 
+// Everything find_split_reads touches of a record (split_read.c:206-354), laid out as conga_split_staging wants it.
+struct full_batch {
+	int32_t *pos;
+	uint8_t *mapq;
+	uint16_t *flag;
+	int32_t *l_qseq;
+	uint64_t *data_off;
+	uint8_t *data; // per record: (l_qseq + 1) / 2 bytes of packed sequence, then l_qseq quality bytes
+	size_t cap_reads, cap_bytes;
+	size_t n_reads, n_bytes; // filled by next_full
+};
+
 class read_source {
 public:
 	virtual ~read_source() {}
@@ -25,7 +37,18 @@ public:
 	// (the analogue of sam_itr_queryi(idx, tid, 0, L) + sam_itr_next: bam_data.c:293,201).
 	virtual bool begin(int tid, int64_t chrom_len, std::string *err) = 0;
 	virtual bool next(size_t max_n, read_batch *out, std::string *err) = 0;
+	// Same iteration, whole records (--rp).  Sources without sequences return false.
+	virtual bool next_full(full_batch *fb, std::string *err)
+	{
+		*err = "this input holds no read sequences: --rp needs a BAM";
+		return false;
+	}
 };
+
+// readReferenceSeq (common.c:423-463): one chromosome of the --ref FASTA (through its .fai when there is one),
+// exactly chrom_len bases; a shorter FASTA record is padded with 'N'.
+bool load_fasta_chrom(const std::string &fasta_path, const std::string &name, int64_t chrom_len, std::string *seq,
+		std::string *err);
 
 read_source *open_reads(const std::string &path, std::string *err);
 int find_chr_index_bam(const std::string &chromosome_name, const read_source &src); // common.c:289-300

@@ -176,3 +176,61 @@ def test_cli_outputs_are_byte_identical_to_the_oracle(tmp_path, oracle, inp, del
             assert open(got_path, "rb").read() == open(w, "rb").read(), k
     log = open(os.path.join(d, "conga.log")).read()
     assert "#CreationDate=" in log and "Read Count:" in log and "mean=" in log
+
+
+@pytest.mark.gpu
+def test_cli_split_reads_rp(tmp_path, oracle):
+    """--rp with --dups: FASTA + BAM sequences -> READ_PAIR columns and the `rp > rp_support` rule of _svs.bed
+    (likelihood.c:243-279), byte-identical to the oracle."""
+    from test_gpu_split_reads import make_case
+    d = str(tmp_path)
+    c = make_case(seed=5, L=300_000, n_normal=4000)
+    # one chromosome with the planted junctions plus a plain one
+    plain = synth.make_chrom("2", 120_000, cov=2.0, n_dels=8, n_dups=3, gaps=False)
+    gc1 = np.full((c["L"] + 99) // 100, 41, np.uint8)
+    formats.write_annotation(os.path.join(d, "a.cga"), [("1", c["L"], gc1, c["sat_s"][:2], c["sat_e"][:2]),
+                                                          ("2", plain.length, plain.gc, [], [])])
+    rng = np.random.default_rng(0)
+    ref2 = rng.choice(np.frombuffer(b"ACGT", np.uint8), plain.length).tobytes()
+    formats.write_fasta(os.path.join(d, "ref.fa"), [("1", c["ref_lower"]), ("2", ref2)])
+    lut = np.full(256, 15, np.uint8)
+    for k, v in {65: 1, 67: 2, 71: 4, 84: 8}.items():
+        lut[k] = v
+    r2 = np.frombuffer(ref2, np.uint8)
+    ok2 = plain.pos + 100 < plain.length
+    pos2, mq2 = plain.pos[ok2], plain.mapq[ok2]
+    lq2 = np.full(len(pos2), 100, np.int32)
+    off2 = (np.arange(len(pos2), dtype=np.uint64) * 100)
+    codes2 = lut[np.concatenate([r2[p:p + 100] for p in pos2])] if len(pos2) else np.zeros(0, np.uint8)
+    qual2 = np.full(len(codes2), 30, np.uint8)
+    formats.write_bam(os.path.join(d, "r.bam"), "S1",
+                      [("1", c["L"], c["pos"], c["mapq"], c["flag"]), ("2", plain.length, pos2, mq2)],
+                      records={"1": (c["lq"], c["codes"], c["qual"], c["off"]), "2": (lq2, codes2, qual2, off2)})
+    synth.write_bed(os.path.join(d, "dels.bed"), [("1", s, e) for s, e in c["dels"]] + [("2", s, e) for s, e in zip(plain.del_start, plain.del_end)])
+    synth.write_bed(os.path.join(d, "dups.bed"), [("1", s, e) for s, e in c["dups"]] + [("2", s, e) for s, e in zip(plain.dup_start, plain.dup_end)])
+    r = run(["-i", "r.bam", "--out", "got", "--ref", "ref.fa", "--sonic", "a.cga", "--dels", "dels.bed", "--dups",
+             "dups.bed", "--rp", "3"], d)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "CONGA paired" in r.stderr
+
+    paths = [os.path.join(d, "want_%s.bed" % k) for k in ("svs", "dels", "dups")]
+    first = True
+    for name, L, gc, pos, mapq, flag, lq, codes, qual, off, ref, ss, se in (
+            ("1", c["L"], gc1, c["pos"], c["mapq"], c["flag"], c["lq"], c["codes"], c["qual"], c["off"], c["ref"], c["sat_s"][:2], c["sat_e"][:2]),
+            ("2", plain.length, plain.gc, pos2, mq2, np.zeros(len(pos2), np.uint16), lq2, codes2, qual2, off2, ref2, [], [])):
+        ds = oracle.sort_svs(oracle.load_known_SVs(os.path.join(d, "dels.bed"), name, 1000))
+        us = oracle.sort_svs(oracle.load_known_SVs(os.path.join(d, "dups.bed"), name, 1000))
+        if len(ds) + len(us) == 0:
+            continue
+        rd, _ = oracle.count_reads(L, pos, mapq, -1)
+        E, _, _ = oracle.calc_mean_per_chr(rd, gc)
+        oracle.find_depths(rd, None, gc, E, "D", ds)
+        oracle.find_depths(rd, None, gc, E, "E", us)
+        rows, _ = oracle.split_read_rows(ref, ss, se, pos, mapq, flag, lq, off, codes, qual, -1, 60)
+        oracle.count_read_pairs(rows, ds, us)
+        oracle.output_svs(name, ds, us, *paths, have_mappability=False, no_sr=0, rp_support=3, write_headers=first)
+        first = False
+    for k, w in zip(("svs", "dels", "dups"), paths):
+        assert open(os.path.join(d, "got_%s.bed" % k), "rb").read() == open(w, "rb").read(), k
+    dup_rows = [l.split("\t") for l in open(os.path.join(d, "got_dups.bed")).read().splitlines()[1:]]
+    assert max(int(x[5]) for x in dup_rows) > 3          # READ_PAIR support was found for a planted duplication
