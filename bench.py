@@ -159,10 +159,19 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # Rehearsal hook for a one-GPU box: CONGA_BENCH_REHEARSAL=1 puts every rank on cuda:0 and gathers over gloo
+    # (host tensors).  Never set by the driver; numbers from it are not benchmark results.
+    rehearsal = os.environ.get("CONGA_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    gather_dev = torch.device("cpu") if rehearsal else dev
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)  # RCCL
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
 
     units = build_units(args, world)
     ctx = capi.Context(device=local_rank, flags=capi.FLAG_BATCH)  # every chromosome of this rank, one launch per kernel
@@ -175,7 +184,7 @@ def main():
     # interval counts after the min-size filter are only known to the owner: exchange them once
     my_bytes = sum(u["n_iv"] for u in mine) * rec
     if world > 1:
-        t = torch.tensor([my_bytes], dtype=torch.int64, device=dev)
+        t = torch.tensor([my_bytes], dtype=torch.int64, device=gather_dev)
         all_b = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(all_b, t)
         bytes_per_rank = [int(x.item()) for x in all_b]
@@ -191,7 +200,8 @@ def main():
         ctx.sync()                                  # N=1: the records are in pinned host memory now
         if world == 1:
             return [packed[:0]]
-        return shard.gather_records(packed[:my_bytes], bytes_per_rank, rank, world, dev)
+        local = packed[:my_bytes].cpu() if rehearsal else packed[:my_bytes]
+        return shard.gather_records(local, bytes_per_rank, rank, world, gather_dev)
 
     def barrier():
         if world > 1:
@@ -207,7 +217,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps

@@ -164,3 +164,76 @@ def write_bam(path, sample, chroms, read_len=100, unplaced=0, block_payload=6000
             out += struct.pack("<i", len(body)) + body
         flush(final=True)
         f.write(_BGZF_EOF)
+
+
+def write_bam_fast(path, sample, chroms, read_len=100, level=1, block_payload=65280, realistic=False, seed=1):
+    """Vectorised writer for large synthetic BAMs: every record has the same layout (fixed-width read name,
+    <read_len>M CIGAR, all-A sequence, quality 30), so a chromosome is one numpy structured array.
+    chroms: list of (name, length, pos int32[n] sorted, mapq uint8[n])."""
+    text = "@HD\tVN:1.6\tSO:coordinate\n"
+    for c in chroms:
+        text += "@SQ\tSN:%s\tLN:%d\n" % (c[0], c[1])
+    text += "@RG\tID:rg1\tSM:%s\tPL:ILLUMINA\n" % sample
+    tb = text.encode()
+    head = bytearray(b"BAM\x01" + struct.pack("<i", len(tb)) + tb + struct.pack("<i", len(chroms)))
+    for c in chroms:
+        nb = c[0].encode() + b"\x00"
+        head += struct.pack("<i", len(nb)) + nb + struct.pack("<i", c[1])
+    n_seq = (read_len + 1) // 2
+    rec = np.dtype([("block_size", "<i4"), ("ref_id", "<i4"), ("pos", "<i4"), ("l_read_name", "u1"), ("mapq", "u1"),
+                    ("bin", "<u2"), ("n_cigar", "<u2"), ("flag", "<u2"), ("l_seq", "<i4"), ("next_ref", "<i4"),
+                    ("next_pos", "<i4"), ("tlen", "<i4"), ("name", "S12"), ("cigar", "<u4"), ("seq", "u1", (n_seq,)),
+                    ("qual", "u1", (read_len,))])
+    with open(path, "wb") as f:
+        pending = bytes(head)
+
+        def emit(buf, final=False):
+            nonlocal pending
+            data = pending + buf
+            n_full = len(data) // block_payload
+            for b in range(n_full):
+                f.write(_bgzf_block_level(data[b * block_payload:(b + 1) * block_payload], level))
+            pending = data[n_full * block_payload:]
+            if final and pending:
+                f.write(_bgzf_block_level(pending, level))
+                pending = b""
+
+        serial = 0
+        for tid, c in enumerate(chroms):
+            pos = np.asarray(c[2], np.int32)
+            for a in range(0, len(pos), 1 << 20):
+                p = pos[a:a + (1 << 20)]
+                r = np.zeros(len(p), dtype=rec)
+                r["block_size"] = rec.itemsize - 4
+                r["ref_id"] = tid
+                r["pos"] = p
+                r["l_read_name"] = 12
+                r["mapq"] = np.asarray(c[3], np.uint8)[a:a + (1 << 20)]
+                r["bin"] = 4681 + (p >> 14)      # reg2bin of a read inside one 16 kb bin (exact bins do not matter here)
+                r["n_cigar"] = 1
+                r["l_seq"] = read_len
+                r["next_ref"] = -1
+                r["next_pos"] = -1
+                ids = np.arange(serial, serial + len(p))
+                serial += len(p)
+                r["name"] = np.char.add("r", np.char.zfill(ids.astype("U10"), 10)).astype("S12")
+                r["cigar"] = (read_len << 4)
+                if realistic:   # random bases and qualities: compresses about as poorly as real data
+                    rr = np.random.default_rng(seed + serial)
+                    nib = np.array([1, 2, 4, 8], np.uint8)
+                    r["seq"] = (nib[rr.integers(0, 4, (len(p), n_seq))] << 4) | nib[rr.integers(0, 4, (len(p), n_seq))]
+                    r["qual"] = rr.integers(2, 41, (len(p), read_len), dtype=np.uint8)
+                else:
+                    r["seq"] = 0x11
+                    r["qual"] = 30
+                emit(r.tobytes())
+        emit(b"", final=True)
+        f.write(_BGZF_EOF)
+
+
+def _bgzf_block_level(data, level):
+    co = zlib.compressobj(level, zlib.DEFLATED, -15)
+    cdata = co.compress(data) + co.flush()
+    bsize = len(cdata) + 25
+    return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize)
+            + cdata + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))

@@ -5,12 +5,20 @@
 // 32-byte record core is decoded (refID, pos, mapq, flag, l_seq) -- the depth path reads nothing else.
 // Record set (parity unpinned): all records with refID == tid and 0 <= pos < L, in
 // file order, which is what sam_itr_queryi(idx, tid, 0, L) + sam_itr_next yield (bam_data.c:293,201).
-// CRAM is not supported.  Inflate is zlib, single-threaded.
+// CRAM is not supported.  Inflate is zlib on a pool of worker threads with a 48-block read-ahead
+// (CONGA_BAM_THREADS overrides the worker count; 0 = inflate inline).
 #include <zlib.h>
 
+#include <algorithm>
+#include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "reads.h"
@@ -19,51 +27,65 @@ namespace conga_host {
 
 namespace {
 
+// BGZF reader with read-ahead: the calling thread reads raw blocks from the file (cheap, page cache) and a small
+// pool of workers inflates them; blocks are consumed strictly in file order.
 class bgzf_reader {
 public:
+	bgzf_reader()
+	{
+		int n = (int) std::thread::hardware_concurrency();
+		if (const char *e = getenv("CONGA_BAM_THREADS"))
+			n = atoi(e) + 1;
+		n_workers_ = std::max(0, std::min(n - 1, 15));
+		for (int i = 0; i < n_workers_; i++)
+			workers_.emplace_back([this] { work(); });
+	}
+	bgzf_reader(const bgzf_reader &) = delete;
+	bgzf_reader &operator=(const bgzf_reader &) = delete;
 	~bgzf_reader()
 	{
+		{
+			std::lock_guard<std::mutex> g(mu_);
+			quit_ = true;
+		}
+		cv_work_.notify_all();
+		for (auto &t : workers_)
+			t.join();
 		if (f_)
 			fclose(f_);
 	}
-	bgzf_reader() {}
-	bgzf_reader(const bgzf_reader &) = delete;
-	bgzf_reader &operator=(const bgzf_reader &) = delete;
 	bool open(const std::string &path)
 	{
+		drain();
 		if (f_)
 			fclose(f_);
 		f_ = fopen(path.c_str(), "rb");
-		block_.clear();
-		at_ = 0;
-		eof_ = false;
-		err_.clear();
+		reset_state();
 		return f_ != nullptr;
 	}
 	// virtual offset = compressed block offset << 16 | offset inside the inflated block
 	bool seek(uint64_t voffset)
 	{
+		drain();
 		if (fseeko(f_, (off_t) (voffset >> 16), SEEK_SET) != 0)
 			return false;
-		block_.clear();
-		at_ = 0;
-		eof_ = false;
+		reset_state();
 		if (!load_block())
 			return false;
 		at_ = (size_t) (voffset & 0xFFFF);
-		return at_ <= block_.size();
+		return at_ <= cur_size();
 	}
 	// read exactly n bytes; false on EOF / error
 	bool read(void *dst, size_t n)
 	{
 		uint8_t *d = (uint8_t *) dst;
 		while (n) {
-			if (at_ == block_.size()) {
-				if (!load_block() || block_.empty())
+			if (at_ == cur_size()) {
+				if (!load_block() || cur_size() == 0)
 					return false;
 			}
-			const size_t k = std::min(n, block_.size() - at_);
-			memcpy(d, block_.data() + at_, k);
+			const size_t k = std::min(n, cur_size() - at_);
+			memcpy(d, cur_->out.data() + at_, k);
 			at_ += k;
 			d += k;
 			n -= k;
@@ -73,11 +95,11 @@ public:
 	bool skip(size_t n)
 	{
 		while (n) {
-			if (at_ == block_.size()) {
-				if (!load_block() || block_.empty())
+			if (at_ == cur_size()) {
+				if (!load_block() || cur_size() == 0)
 					return false;
 			}
-			const size_t k = std::min(n, block_.size() - at_);
+			const size_t k = std::min(n, cur_size() - at_);
 			at_ += k;
 			n -= k;
 		}
@@ -85,10 +107,12 @@ public:
 	}
 	bool at_eof()
 	{
-		while (at_ == block_.size()) {
-			if (eof_)
+		while (at_ == cur_size()) {
+			if (file_eof_ && queue_.empty())
 				return true;
 			if (!load_block())
+				return true;
+			if (cur_size() == 0 && file_eof_ && queue_.empty())
 				return true;
 		}
 		return false;
@@ -96,15 +120,80 @@ public:
 	const std::string &error() const { return err_; }
 
 private:
-	bool load_block()
+	struct task {
+		std::vector<uint8_t> cdata, out;
+		uint32_t isize = 0;
+		bool done = false, failed = false;
+	};
+	static constexpr size_t kAhead = 48;
+
+	size_t cur_size() const { return cur_ ? cur_->out.size() : 0; }
+
+	void reset_state()
 	{
-		block_.clear();
+		cur_.reset();
 		at_ = 0;
+		file_eof_ = false;
+		err_.clear();
+	}
+
+	// wait for every dispatched block and forget them (before seek / reopen)
+	void drain()
+	{
+		std::unique_lock<std::mutex> lk(mu_);
+		for (auto &t : queue_)
+			cv_done_.wait(lk, [&] { return t->done; });
+		queue_.clear();
+		todo_.clear();
+	}
+
+	static bool inflate_block(task &t)
+	{
+		t.out.resize(t.isize);
+		z_stream zs;
+		memset(&zs, 0, sizeof zs);
+		if (inflateInit2(&zs, -15) != Z_OK)
+			return false;
+		zs.next_in = t.cdata.data();
+		zs.avail_in = (uInt) t.cdata.size();
+		zs.next_out = t.out.data();
+		zs.avail_out = t.isize;
+		const int rc = inflate(&zs, Z_FINISH);
+		inflateEnd(&zs);
+		return rc == Z_STREAM_END && zs.avail_out == 0;
+	}
+
+	void work()
+	{
+		for (;;) {
+			std::shared_ptr<task> t;
+			{
+				std::unique_lock<std::mutex> lk(mu_);
+				cv_work_.wait(lk, [&] { return quit_ || !todo_.empty(); });
+				if (quit_)
+					return;
+				t = todo_.front();
+				todo_.pop_front();
+			}
+			const bool ok = inflate_block(*t);
+			{
+				std::lock_guard<std::mutex> g(mu_);
+				t->failed = !ok;
+				t->done = true;
+			}
+			cv_done_.notify_all();
+		}
+	}
+
+	// read one raw block from the file into a task; false on error; sets file_eof_ at the end
+	bool read_raw(std::shared_ptr<task> *out)
+	{
 		for (;;) { // skip empty blocks (the EOF marker is one)
 			uint8_t h[12];
 			const size_t got = fread(h, 1, 12, f_);
 			if (got == 0) {
-				eof_ = true;
+				file_eof_ = true;
+				out->reset();
 				return true;
 			}
 			if (got != 12 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) {
@@ -133,40 +222,75 @@ private:
 				err_ = "bad BGZF block size";
 				return false;
 			}
-			cbuf_.resize((size_t) cdata + 8);
-			if (fread(cbuf_.data(), 1, cbuf_.size(), f_) != cbuf_.size()) {
+			auto t = std::make_shared<task>();
+			t->cdata.resize((size_t) cdata + 8);
+			if (fread(t->cdata.data(), 1, t->cdata.size(), f_) != t->cdata.size()) {
 				err_ = "truncated BGZF block";
 				return false;
 			}
-			uint32_t isize;
-			memcpy(&isize, cbuf_.data() + cdata + 4, 4);
-			if (isize == 0)
+			memcpy(&t->isize, t->cdata.data() + cdata + 4, 4);
+			t->cdata.resize((size_t) cdata);
+			if (t->isize == 0)
 				continue;
-			block_.resize(isize);
-			z_stream zs;
-			memset(&zs, 0, sizeof zs);
-			if (inflateInit2(&zs, -15) != Z_OK) {
-				err_ = "zlib init failed";
-				return false;
-			}
-			zs.next_in = cbuf_.data();
-			zs.avail_in = (uInt) cdata;
-			zs.next_out = block_.data();
-			zs.avail_out = isize;
-			const int rc = inflate(&zs, Z_FINISH);
-			inflateEnd(&zs);
-			if (rc != Z_STREAM_END || zs.avail_out != 0) {
-				err_ = "BGZF inflate failed";
-				return false;
-			}
+			*out = t;
 			return true;
 		}
 	}
+
+	// make the next block current (empty current block at end of file)
+	bool load_block()
+	{
+		at_ = 0;
+		// keep the read-ahead queue full
+		while (!file_eof_ && queue_.size() < kAhead) {
+			std::shared_ptr<task> t;
+			if (!read_raw(&t))
+				return false;
+			if (!t)
+				break;
+			if (n_workers_ == 0) {
+				t->failed = !inflate_block(*t);
+				t->done = true;
+				queue_.push_back(t);
+			} else {
+				{
+					std::lock_guard<std::mutex> g(mu_);
+					queue_.push_back(t);
+					todo_.push_back(t);
+				}
+				cv_work_.notify_one();
+			}
+		}
+		if (queue_.empty()) {
+			cur_.reset();
+			return true;
+		}
+		std::shared_ptr<task> t;
+		{
+			std::unique_lock<std::mutex> lk(mu_);
+			t = queue_.front();
+			cv_done_.wait(lk, [&] { return t->done; });
+			queue_.pop_front();
+		}
+		if (t->failed) {
+			err_ = "BGZF inflate failed";
+			return false;
+		}
+		cur_ = t;
+		return true;
+	}
+
 	FILE *f_ = nullptr;
-	std::vector<uint8_t> block_, cbuf_;
+	std::shared_ptr<task> cur_;
 	size_t at_ = 0;
-	bool eof_ = false;
+	bool file_eof_ = false;
 	std::string err_;
+	int n_workers_ = 0;
+	std::vector<std::thread> workers_;
+	std::mutex mu_;
+	std::condition_variable cv_work_, cv_done_;
+	std::deque<std::shared_ptr<task>> queue_, todo_; // queue_: in file order (consumer); todo_: not yet inflated
+	bool quit_ = false;
 };
 
 class bam_file : public read_source {

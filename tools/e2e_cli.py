@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""End-to-end run of the `conga` executable on a synthetic BAM (BASELINE configs[0] shape by default: chr21 only,
+~2k deletions, 0.5x) and a larger one; prints wall times.  The outputs are compared with the oracle's files.
+Not a benchmark line (bench.py is): host BAM decoding and text parsing dominate here."""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from conga_amd import formats, synth  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--chroms", default="21")
+    ap.add_argument("--cov", type=float, default=0.5)
+    ap.add_argument("--dels", type=int, default=2000)
+    ap.add_argument("--check", type=int, default=1)
+    a = ap.parse_args()
+    d = tempfile.mkdtemp(prefix="conga_e2e_")
+    names = a.chroms.split(",")
+    lens = dict(synth.GRCH37_AUTOSOMES)
+    total = sum(lens[n] for n in names)
+    cs = [synth.make_chrom(n, lens[n], cov=a.cov, n_dels=int(round(a.dels * lens[n] / total))) for n in names]
+    formats.write_annotation(os.path.join(d, "a.cga"), [(c.name, c.length, c.gc, [], []) for c in cs])
+    t0 = time.time()
+    formats.write_bam_fast(os.path.join(d, "r.bam"), "SYNTH", [(c.name, c.length, c.pos, c.mapq) for c in cs], realistic=True)
+    t_bam = time.time() - t0
+    synth.write_bed(os.path.join(d, "dels.bed"), [(c.name, s, e) for c in cs for s, e in zip(c.del_start, c.del_end)])
+    t0 = time.time()
+    r = subprocess.run([os.path.join(ROOT, "conga_amd", "host", "conga"), "-i", "r.bam", "--out", "got", "--ref", "none.fa",
+                        "--sonic", "a.cga", "--dels", "dels.bed"], cwd=d, capture_output=True, text=True)
+    t_cli = time.time() - t0
+    assert r.returncode == 0, r.stderr[-2000:]
+    ok = None
+    if a.check:
+        paths = [os.path.join(d, "want_%s.bed" % k) for k in ("svs", "dels")]
+        first = True
+        for c in cs:
+            ds = O.sort_svs(O.load_known_SVs(os.path.join(d, "dels.bed"), c.name, 1000))
+            if len(ds) == 0:
+                continue
+            rd, _ = O.count_reads(c.length, c.pos, c.mapq, -1)
+            E, _, _ = O.calc_mean_per_chr(rd, c.gc)
+            O.find_depths(rd, None, c.gc, E, "D", ds)
+            O.output_svs(c.name, ds, None, paths[0], paths[1], None, have_mappability=False, write_headers=first)
+            first = False
+        ok = all(open(os.path.join(d, "got_%s.bed" % k), "rb").read() == open(w, "rb").read()
+                 for k, w in zip(("svs", "dels"), paths))
+    n_iv = sum(1 for _ in open(os.path.join(d, "got_dels.bed"))) - 1
+    print(json.dumps(dict(chroms=names, reads=int(sum(len(c.pos) for c in cs)), bam_mb=round(os.path.getsize(os.path.join(d, "r.bam")) / 1e6, 1),
+                          intervals=n_iv, cli_wall_s=round(t_cli, 3), intervals_per_s=round(n_iv / t_cli, 1),
+                          bam_write_s=round(t_bam, 1), outputs_match_oracle=ok, host_cpus=os.cpu_count())))
+
+
+if __name__ == "__main__":
+    main()
