@@ -67,6 +67,8 @@ struct conga_ctx {
 	int n_cu = 256;
 	int depth_blocks_per_cu = 8; // resident depth_tile workgroups per CU (occupancy query)
 	hipStream_t stream = nullptr;
+	hipStream_t stream2 = nullptr; // runs interval_reduce beside the float chain (both are latency-bound)
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	conga_opts opts{};
 	std::string err;
 
@@ -607,6 +609,10 @@ conga_ctx *conga_create(int device, const conga_opts *opts, int *status)
 		return bail(CONGA_ERR_HIP);
 	if (hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming) != hipSuccess)
 		return bail(CONGA_ERR_HIP);
+	if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess
+			|| hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess
+			|| hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess)
+		return bail(CONGA_ERR_HIP);
 	for (int k = 0; k < CONGA_K_COUNT; k++)
 		if (hipEventCreate(&ctx->ev_k0[k]) != hipSuccess || hipEventCreate(&ctx->ev_k1[k]) != hipSuccess)
 			return bail(CONGA_ERR_HIP);
@@ -621,6 +627,14 @@ void conga_destroy(conga_ctx *ctx)
 	(void) hipSetDevice(ctx->device);
 	if (ctx->stream)
 		(void) hipStreamSynchronize(ctx->stream);
+	if (ctx->stream2) {
+		(void) hipStreamSynchronize(ctx->stream2);
+		(void) hipStreamDestroy(ctx->stream2);
+	}
+	if (ctx->ev_fork)
+		(void) hipEventDestroy(ctx->ev_fork);
+	if (ctx->ev_join)
+		(void) hipEventDestroy(ctx->ev_join);
 	DevBuf *bufs[] = {&ctx->d_pos, &ctx->d_mapq, &ctx->d_tile_start, &ctx->d_rd, &ctx->d_gc_hist, &ctx->d_gc_like,
 			&ctx->d_slots, &ctx->d_small, &ctx->d_map, &ctx->d_winner, &ctx->d_map_start, &ctx->d_map_end,
 			&ctx->d_map_val, &ctx->d_iv_start, &ctx->d_iv_end, &ctx->d_iv_type, &ctx->d_iv_slot, &ctx->d_iv_has_map,
@@ -1137,7 +1151,17 @@ int conga_chrom_compute(conga_ctx *ctx)
 	}
 
 	if (ctx->n_iv > 0) {
-		HIP_TRY(ctx, hipMemsetAsync(ctx->d_observed.p, 0, (size_t) ctx->n_iv * 4, st));
+		// interval_reduce needs read_depth (and the painted track); the float chain needs only the depth table:
+		// they run side by side on two streams and meet again in front of interval_score.  With per-kernel
+		// timing on (CONGA_FLAG_PROFILE) everything stays on one stream so the event pairs bracket one kernel each.
+		const bool fork = ctx->n_items > 0 && (ctx->opts.flags & CONGA_FLAG_PROFILE) == 0;
+		hipStream_t st_reduce = st;
+		if (fork) {
+			HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
+			HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+			st_reduce = ctx->stream2;
+		}
+		HIP_TRY(ctx, hipMemsetAsync(ctx->d_observed.p, 0, (size_t) ctx->n_iv * 4, st_reduce));
 		if (ctx->n_items > 0) {
 			KernelTimer t(ctx, CONGA_K_REDUCE);
 			ReduceArgs a;
@@ -1152,8 +1176,10 @@ int conga_chrom_compute(conga_ctx *ctx)
 			a.map_part = ptr<double>(ctx->d_map_part);
 			const int waves_per_block = 256 / kWave;
 			const int grid = (int) ((ctx->n_items + waves_per_block - 1) / waves_per_block);
-			hipLaunchKernelGGL(interval_reduce_kernel, dim3(grid), dim3(256), 0, st, a);
+			hipLaunchKernelGGL(interval_reduce_kernel, dim3(grid), dim3(256), 0, st_reduce, a);
 		}
+		if (fork)
+			HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
 		{
 			KernelTimer t(ctx, CONGA_K_CHAIN);
 			ChainArgs c;
@@ -1179,6 +1205,8 @@ int conga_chrom_compute(conga_ctx *ctx)
 				hipLaunchKernelGGL(interval_chain_kernel<16>, dim3(grid), dim3(256), 0, st, c);
 			}
 		}
+		if (fork)
+			HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
 		{
 			KernelTimer t(ctx, CONGA_K_SCORE);
 			ScoreArgs a;
