@@ -96,7 +96,7 @@ def depth_kernel_bytes(units):
     for u in units:
         L, n = u["length"], u["n_reads"]
         n_win = (L + 99) // 100
-        n_tiles = (L + 7999) // 8000
+        n_tiles = (L + 2047) // 2048
         total += 2 * L + 5 * n + n_win + 4 * (n_tiles + 1)
     return total
 

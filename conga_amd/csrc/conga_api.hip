@@ -72,7 +72,7 @@ struct conga_ctx {
 	conga_opts opts{};
 	std::string err;
 
-	int32_t step = 100, tile_win = 0;
+	int32_t step = 100, tile_len = 0;
 	std::vector<HostSlot> slots;
 	int cur = -1; // selected slot
 	bool layout_dirty = true;
@@ -222,7 +222,7 @@ int prepare(conga_ctx *ctx)
 		d.tile0 = h.tile0;
 		d.n_tiles = h.n_tiles;
 		d.tidx_off = h.tidx_off;
-		rd_off += (h.L + 7) & ~(int64_t) 7;
+		rd_off += (h.L + kDepthMaxTile - 1) & ~(int64_t) (kDepthMaxTile - 1); // whole tiles: 4 KiB-aligned regions
 		gc_off += (h.n_win + 15) & ~(int64_t) 15;
 		tile0 += h.n_tiles;
 		iv0 += (int64_t) (h.iv_start[0].size() + h.iv_start[1].size());
@@ -576,18 +576,19 @@ conga_ctx *conga_create(int device, const conga_opts *opts, int *status)
 		return nullptr;
 	}
 	ctx->step = ctx->opts.gc_step;
-	// tile = tile_win windows; tile_win * step must be a multiple of 8 (16-byte stores) and fit the LDS tile
-	int32_t tw = std::min<int32_t>(kDepthMaxTile / ctx->step, kDepthMaxWin);
-	while (tw > 1 && ((int64_t) tw * ctx->step) % 8 != 0)
-		tw--;
-	if (((int64_t) tw * ctx->step) % 8 != 0 || tw < 1)
-		tw = 8; // step > 256 and odd: 8 windows still fit (8 * 1024 = kDepthMaxTile * 4 is checked below)
-	if ((int64_t) tw * ctx->step > kDepthMaxTile) {
-		*status = CONGA_ERR_INVALID; // gc_step too large for the LDS tile
-		delete ctx;
-		return nullptr;
+	// depth tile: 2048 positions (4 KiB of int16, so every tile is one aligned 4 KiB store run) unless the GC step is
+	// so small that a tile would touch more than kDepthMaxWin windows
+	{
+		int32_t tl = kDepthMaxTile;
+		if ((int64_t) (kDepthMaxWin - 2) * ctx->step < tl)
+			tl = (int32_t) (((int64_t) (kDepthMaxWin - 2) * ctx->step) & ~7);
+		if (tl < 8) {
+			*status = CONGA_ERR_INVALID;
+			delete ctx;
+			return nullptr;
+		}
+		ctx->tile_len = tl;
 	}
-	ctx->tile_win = tw;
 
 	auto bail = [&](int st) -> conga_ctx * {
 		*status = st;
@@ -707,7 +708,7 @@ int conga_chrom_begin(conga_ctx *ctx, int64_t chrom_len, const uint8_t *gc_hist_
 	HostSlot h;
 	h.L = chrom_len;
 	h.n_win = n_win;
-	const int64_t T = (int64_t) ctx->tile_win * step;
+	const int64_t T = ctx->tile_len;
 	h.n_tiles = (chrom_len + T - 1) / T;
 	h.read_off = ctx->n_reads_total;
 	h.gc_hist.assign(gc_hist_w, gc_hist_w + n_win);
@@ -1014,7 +1015,7 @@ int conga_chrom_compute(conga_ctx *ctx)
 			if (ctx->n_reads_total > 0) {
 				const int grid = (int) std::min<int64_t>((ctx->n_reads_total + 255) / 256, (int64_t) ctx->n_cu * 8);
 				hipLaunchKernelGGL(ingest_kernel, dim3(grid), dim3(256), 0, st, ptr<int32_t>(ctx->d_pos),
-						ctx->n_reads_total, dslots, n_slots, ctx->tile_win * ctx->step,
+						ctx->n_reads_total, dslots, n_slots, ctx->tile_len,
 						ptr<uint32_t>(ctx->d_tile_start), small);
 			}
 		}
@@ -1032,7 +1033,7 @@ int conga_chrom_compute(conga_ctx *ctx)
 			a.n_slots = n_slots;
 			a.step = ctx->step;
 			a.step_magic = (uint32_t) (0x100000000ull / (uint64_t) ctx->step) + 1u;
-			a.tile_win = ctx->tile_win;
+			a.tile_len = ctx->tile_len;
 			a.mq_threshold = ctx->opts.mq_threshold;
 			a.total_tiles = ctx->total_tiles;
 			// one resident set of waves, each with a contiguous run of tiles

@@ -208,7 +208,8 @@ __global__ __launch_bounds__(256) void ingest_kernel(const int32_t *__restrict__
 // (read_distribution.c:33-37,63-73).
 //
 // Every WAVE is an independent worker (no workgroup barrier anywhere): it owns a contiguous run of
-// tiles of tile_win * step positions and a private LDS area.  Per tile it zeroes 16-bit counters
+// 2048-position tiles (4 KiB of int16, 4 KiB-aligned in HBM; tiles are NOT aligned to GC windows -- a
+// window that straddles two tiles adds both parts into the same bin) and a private LDS area.  Per tile it zeroes 16-bit counters
 // in LDS (two per dword -- the layout of the int16 output), adds the tile's tuples with LDS
 // atomics, then streams the tile out ONCE with one ds_read_b128 + one 16-byte global store per lane
 // (1 KiB per wave-instruction; read_depth is written exactly once and never read back for the
@@ -222,8 +223,8 @@ __global__ __launch_bounds__(256) void ingest_kernel(const int32_t *__restrict__
 // -------------------------------------------------------------------------------------------
 constexpr int kDepthBlock = 256;
 constexpr int kDepthWaves = kDepthBlock / kWave;
-constexpr int kDepthMaxTile = 2048; // positions per wave tile (4 KiB of packed LDS counters)
-constexpr int kDepthMaxWin = 64;    // GC windows per wave tile
+constexpr int kDepthMaxTile = 2048; // positions per wave tile: 4 KiB of packed LDS counters = 4 KiB-aligned stores
+constexpr int kDepthMaxWin = 64;    // GC windows (or parts of windows) a tile may touch
 
 struct DepthArgs {
 	const int32_t *pos;
@@ -236,7 +237,8 @@ struct DepthArgs {
 	int32_t n_slots;
 	int32_t step;
 	uint32_t step_magic; // floor(2^32 / step) + 1: j / step == umulhi(j, magic) for j * step < 2^32
-	int32_t tile_win;
+	int32_t tile_len;    // positions per tile: a multiple of 8, NOT of step -- a window may straddle two tiles,
+	                     // both parts then add into the same GC bin
 	int32_t mq_threshold;
 	uint32_t n_total;    // tuples in the batch
 	int64_t total_tiles;
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(kDepthBlock) void depth_tile_kernel(DepthArgs a)
 	int32_t *wsum = wsum_all[wv];
 	unsigned long long *h_sum = h_sum_all[wv];
 
-	const int T = a.tile_win * a.step;
+	const int T = a.tile_len;
 	const int64_t wave_id = (int64_t) blockIdx.x * kDepthWaves + wv;
 	const int64_t g_begin = wave_id * a.tiles_per_wave;
 	const int64_t g_end = (g_begin + a.tiles_per_wave < a.total_tiles) ? g_begin + a.tiles_per_wave : a.total_tiles;
@@ -284,8 +286,8 @@ __global__ __launch_bounds__(kDepthBlock) void depth_tile_kernel(DepthArgs a)
 		return (v == 0xFFFFFFFFu) ? a.n_total : v;
 	};
 	auto gc_of = [&](const Slot &sl_, int64_t gt_) -> uint32_t {
-		// GC byte of window `lane` of global tile gt_ (only lanes < tile_win matter)
-		int64_t wg = (gt_ - sl_.tile0) * a.tile_win + lane;
+		// GC byte of the lane-th window touched by global tile gt_ (lanes past the tile's last window are unused)
+		int64_t wg = (uint32_t) ((gt_ - sl_.tile0) * T) / (uint32_t) a.step + lane;
 		if (wg >= sl_.n_win)
 			wg = sl_.n_win - 1;
 		return a.gc_hist[sl_.gc_off + wg];
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(kDepthBlock) void depth_tile_kernel(DepthArgs a)
 		c_pos[k] = (i < c_hi) ? a.pos[i] : INT32_MIN; // INT32_MIN: no tuple (fails the range check below)
 		c_mq[k] = (i < c_hi) ? (int) a.mapq[i] : 0;
 	}
-	uint32_t c_gc = (lane < a.tile_win) ? gc_of(sl, g_begin) : 0;
+	uint32_t c_gc = (lane < kDepthMaxWin) ? gc_of(sl, g_begin) : 0;
 
 	for (int64_t gt = g_begin; gt < g_end; gt++) {
 		if (gt >= sl.tile0 + sl.n_tiles) {
@@ -337,17 +339,18 @@ __global__ __launch_bounds__(kDepthBlock) void depth_tile_kernel(DepthArgs a)
 			n_pos[k] = ok ? a.pos[i] : INT32_MIN;
 			n_mq[k] = ok ? (int) a.mapq[i] : 0;
 		}
-		const uint32_t n_gc = (have_next && lane < a.tile_win) ? gc_of(sl_n, gt + 1) : 0;
+		const uint32_t n_gc = (have_next && lane < kDepthMaxWin) ? gc_of(sl_n, gt + 1) : 0;
 
 		// ---- tile gt
 		const int64_t tile = gt - sl.tile0;
 		const int64_t base = tile * T;
 		const int len = (int) ((sl.L - base < T) ? (sl.L - base) : T);
+		// offset of the tile's first base inside its GC window (one 32-bit division per tile)
+		const int r0 = (int) ((uint32_t) base - ((uint32_t) base / (uint32_t) a.step) * (uint32_t) a.step);
 
 		for (int j = lane * 4; j < T / 2; j += kWave * 4)
 			*reinterpret_cast<uint4 *>(&cnt2[j]) = make_uint4(0, 0, 0, 0);
-		if (lane < a.tile_win)
-			wsum[lane] = 0;
+		wsum[lane] = 0; // kDepthMaxWin == kWave
 		__builtin_amdgcn_wave_barrier();
 
 		auto add_tuple = [&](int32_t pp, int mq) {
@@ -380,8 +383,9 @@ __global__ __launch_bounds__(kDepthBlock) void depth_tile_kernel(DepthArgs a)
 			*reinterpret_cast<uint4 *>(out + j) = q;
 			if ((q.x | q.y | q.z | q.w) != 0u) { // sparse: most 8-base groups hold no read start
 				const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
-				int w = (a.step == 1) ? j : (int) __umulhi((uint32_t) j, a.step_magic);
-				int r = j - w * a.step;
+				const int t0 = j + r0; // position relative to the start of the tile's first window
+				int w = (a.step == 1) ? t0 : (int) __umulhi((uint32_t) t0, a.step_magic);
+				int r = t0 - w * a.step;
 				int acc = 0;
 #pragma unroll
 				for (int e = 0; e < 8; e++) {
@@ -401,8 +405,8 @@ __global__ __launch_bounds__(kDepthBlock) void depth_tile_kernel(DepthArgs a)
 		}
 		__builtin_amdgcn_wave_barrier();
 
-		// per-window depth sums -> GC bins (read_distribution.c:70-71)
-		const int nw = (a.step == 1) ? len : (int) __umulhi((uint32_t) (len + a.step - 1), a.step_magic);
+		// per-window (or window-part) depth sums -> GC bins (read_distribution.c:70-71)
+		const int nw = (a.step == 1) ? len : (int) __umulhi((uint32_t) (len + r0 + a.step - 1), a.step_magic);
 		if (lane < nw) {
 			const int sw = wsum[lane];
 			if (sw && c_gc < (uint32_t) kGcBins)

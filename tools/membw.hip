@@ -85,8 +85,15 @@ int main()
 		snprintf(nm, sizeof nm, "wave runs 4000 B nt, %d blocks/CU", per_cu);
 		time(nm, [&] { hipLaunchKernelGGL(fill_wave_runs<true>, dim3(256 * per_cu), dim3(256), 0, st, (uint4 *) buf, n_tiles, tpw, 250); });
 	}
-	for (int tile_bytes : {4000, 4096, 6400, 8192})
-		for (int run : {1, 4, 16}) {
+	for (int tile_bytes : {4096, 8192}) {
+		const size_t n_tiles = bytes / tile_bytes, waves = (size_t) 256 * 7 * 4;
+		const size_t tpw = (n_tiles + waves - 1) / waves;
+		char nm[64];
+		snprintf(nm, sizeof nm, "wave runs %d B aligned, 7 blk/CU", tile_bytes);
+		time(nm, [&] { hipLaunchKernelGGL(fill_wave_runs<false>, dim3(256 * 7), dim3(256), 0, st, (uint4 *) buf, n_tiles, tpw, tile_bytes / 16); });
+	}
+	for (int tile_bytes : {4000, 4096})
+		for (int run : {1, 16, 64}) {
 			const size_t n_tiles = bytes / tile_bytes;
 			char nm[64];
 			snprintf(nm, sizeof nm, "round-robin %d B x%d, 7 blk/CU", tile_bytes, run);
