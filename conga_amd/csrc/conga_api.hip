@@ -84,7 +84,7 @@ struct conga_ctx {
 	int staging_cur = -1; // buffer handed out and not yet committed
 
 	// layout totals (prepare)
-	int64_t total_L = 0, total_tiles = 0, total_gc = 0, n_iv = 0, n_items = 0, n_long = 0;
+	int64_t total_L = 0, total_tiles = 0, total_gc = 0, n_iv = 0, n_items = 0, n_long = 0, n_depth_blocks = 0;
 	bool gc_like_distinct = false, any_map = false, support_given = false, any_sr = false;
 	int64_t n_sr_total = 0, sr_bytes_total = 0;
 	conga_split_staging sr_stage{}; // one pinned set (the split-read path is not the bench line)
@@ -94,7 +94,7 @@ struct conga_ctx {
 	DevBuf d_pos, d_mapq, d_tile_start, d_rd, d_gc_hist, d_gc_like, d_slots, d_small, d_map, d_winner,
 			d_map_start, d_map_end, d_map_val, d_iv_start, d_iv_end, d_iv_type, d_iv_slot, d_iv_has_map, d_order,
 			d_observed, d_expected, d_item_off, d_item_len, d_item_iv, d_item_has_map, d_item_first, d_map_part,
-			d_support, d_results, d_bases, d_row_tile, d_support_base, d_ref, d_sat_start, d_sat_end, d_sr_pos,
+			d_support, d_results, d_bases, d_row_tile, d_depth_blocks, d_support_base, d_ref, d_sat_start, d_sat_end, d_sr_pos,
 			d_sr_mapq, d_sr_flag, d_sr_lq, d_sr_off, d_sr_data, d_kmer_count, d_kmer_offset, d_kmer_cursor, d_kmer_pos;
 
 	// pinned read-back
@@ -240,6 +240,23 @@ int prepare(conga_ctx *ctx)
 	ctx->n_iv = iv0;
 
 	TRY(upload(ctx, ctx->d_slots, dslots.data(), dslots.size() * sizeof(Slot)));
+	{
+		// depth workgroups: contiguous tile ranges that never cross a chromosome, dispatched in genome order
+		std::vector<DepthBlock> blocks;
+		for (int s = 0; s < n_slots; s++) {
+			const HostSlot &h = ctx->slots[s];
+			for (int64_t t = 0; t < h.n_tiles; t += kDepthTilesPerBlock) {
+				DepthBlock b;
+				b.slot = s;
+				b.n_tiles = (int32_t) std::min<int64_t>(kDepthTilesPerBlock, h.n_tiles - t);
+				b.first_tile = h.tile0 + t;
+				blocks.push_back(b);
+			}
+		}
+		ctx->n_depth_blocks = (int64_t) blocks.size();
+		TRY(upload(ctx, ctx->d_depth_blocks, blocks.data(), blocks.size() * sizeof(DepthBlock)));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	}
 	TRY(ensure(ctx, ctx->d_small, std::max<size_t>(n_slots, 1) * sizeof(Small)));
 	TRY(ensure(ctx, ctx->d_rd, std::max<size_t>((size_t) ctx->total_L, 8) * 2));
 	TRY(ensure(ctx, ctx->d_tile_start, ((size_t) ctx->total_tiles + 2) * 4));
@@ -641,7 +658,7 @@ void conga_destroy(conga_ctx *ctx)
 			&ctx->d_map_val, &ctx->d_iv_start, &ctx->d_iv_end, &ctx->d_iv_type, &ctx->d_iv_slot, &ctx->d_iv_has_map,
 			&ctx->d_order, &ctx->d_observed, &ctx->d_expected, &ctx->d_item_off, &ctx->d_item_len, &ctx->d_item_iv,
 			&ctx->d_item_has_map, &ctx->d_item_first, &ctx->d_map_part, &ctx->d_support, &ctx->d_results,
-			&ctx->d_bases, &ctx->d_row_tile, &ctx->d_support_base, &ctx->d_ref, &ctx->d_sat_start, &ctx->d_sat_end,
+			&ctx->d_bases, &ctx->d_row_tile, &ctx->d_depth_blocks, &ctx->d_support_base, &ctx->d_ref, &ctx->d_sat_start, &ctx->d_sat_end,
 			&ctx->d_sr_pos, &ctx->d_sr_mapq, &ctx->d_sr_flag, &ctx->d_sr_lq, &ctx->d_sr_off, &ctx->d_sr_data,
 			&ctx->d_kmer_count, &ctx->d_kmer_offset, &ctx->d_kmer_cursor, &ctx->d_kmer_pos};
 	for (DevBuf *b : bufs)
@@ -1029,18 +1046,14 @@ int conga_chrom_compute(conga_ctx *ctx)
 			a.rd = ptr<int16_t>(ctx->d_rd);
 			a.gc_hist = ptr<uint8_t>(ctx->d_gc_hist);
 			a.slots = dslots;
+			a.blocks = ptr<DepthBlock>(ctx->d_depth_blocks);
 			a.small = small;
-			a.n_slots = n_slots;
 			a.step = ctx->step;
 			a.step_magic = (uint32_t) (0x100000000ull / (uint64_t) ctx->step) + 1u;
 			a.tile_len = ctx->tile_len;
 			a.mq_threshold = ctx->opts.mq_threshold;
 			a.total_tiles = ctx->total_tiles;
-			// one resident set of waves, each with a contiguous run of tiles
-			const int64_t max_waves = (int64_t) ctx->n_cu * ctx->depth_blocks_per_cu * kDepthWaves;
-			a.tiles_per_wave = std::max<int64_t>(1, (ctx->total_tiles + max_waves - 1) / max_waves);
-			const int64_t n_waves = (ctx->total_tiles + a.tiles_per_wave - 1) / a.tiles_per_wave;
-			const int grid = (int) ((n_waves + kDepthWaves - 1) / kDepthWaves);
+			const int grid = (int) ctx->n_depth_blocks;
 			hipLaunchKernelGGL(depth_tile_kernel, dim3(grid), dim3(kDepthBlock), 0, st, a);
 		}
 	} else {

@@ -225,6 +225,14 @@ constexpr int kDepthBlock = 256;
 constexpr int kDepthWaves = kDepthBlock / kWave;
 constexpr int kDepthMaxTile = 2048; // positions per wave tile: 4 KiB of packed LDS counters = 4 KiB-aligned stores
 constexpr int kDepthMaxWin = 64;    // GC windows (or parts of windows) a tile may touch
+constexpr int kDepthTilesPerBlock = 128; // tiles per workgroup (512 KiB of read_depth): one histogram flush each
+
+// One workgroup = one contiguous range of tiles inside ONE chromosome (table built on the host).
+struct DepthBlock {
+	int32_t slot;
+	int32_t n_tiles;
+	int64_t first_tile; // global tile index
+};
 
 struct DepthArgs {
 	const int32_t *pos;
@@ -233,8 +241,8 @@ struct DepthArgs {
 	int16_t *rd;
 	const uint8_t *gc_hist;
 	const Slot *slots;
+	const DepthBlock *blocks;
 	Small *small;
-	int32_t n_slots;
 	int32_t step;
 	uint32_t step_magic; // floor(2^32 / step) + 1: j / step == umulhi(j, magic) for j * step < 2^32
 	int32_t tile_len;    // positions per tile: a multiple of 8, NOT of step -- a window may straddle two tiles,
@@ -242,190 +250,172 @@ struct DepthArgs {
 	int32_t mq_threshold;
 	uint32_t n_total;    // tuples in the batch
 	int64_t total_tiles;
-	int64_t tiles_per_wave;
 };
 
-__device__ __forceinline__ void depth_flush(Small *sm, unsigned long long *h_sum, unsigned int counted, int lane)
-{
-	for (int g = lane; g < kGcBins; g += kWave) {
-		if (h_sum[g])
-			atomicAdd(&sm->hist_sum[g], h_sum[g]);
-		h_sum[g] = 0;
-	}
-	const int w = wave_sum_i32((int) counted);
-	if (lane == 0 && w)
-		atomicAdd(&sm->counters[CNT_COUNTED], (unsigned long long) w);
-}
-
-constexpr int kDepthPrefetch = 2; // tuples per lane fetched one tile ahead (128 per 2000-base tile = 6x coverage)
+constexpr int kDepthPrefetch = 2; // tuples per lane fetched one tile ahead (128 per 2048-base tile = 6x coverage)
 
 __global__ __launch_bounds__(kDepthBlock) void depth_tile_kernel(DepthArgs a)
 {
 	__shared__ __attribute__((aligned(16))) uint32_t cnt2_all[kDepthWaves][kDepthMaxTile / 2];
 	__shared__ int32_t wsum_all[kDepthWaves][kDepthMaxWin + 8];
-	__shared__ unsigned long long h_sum_all[kDepthWaves][kGcBins];
+	__shared__ unsigned long long h_sum[kGcBins]; // shared by the workgroup's waves (LDS atomics)
+	__shared__ unsigned int h_counted;
 
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
 	const int lane = threadIdx.x & (kWave - 1);
 	uint32_t *cnt2 = cnt2_all[wv];
 	int32_t *wsum = wsum_all[wv];
-	unsigned long long *h_sum = h_sum_all[wv];
 
-	const int T = a.tile_len;
-	const int64_t wave_id = (int64_t) blockIdx.x * kDepthWaves + wv;
-	const int64_t g_begin = wave_id * a.tiles_per_wave;
-	const int64_t g_end = (g_begin + a.tiles_per_wave < a.total_tiles) ? g_begin + a.tiles_per_wave : a.total_tiles;
-	if (g_begin >= g_end)
-		return; // wave-uniform; the kernel has no workgroup barrier
-
-	for (int g = lane; g < kGcBins; g += kWave)
+	for (int g = threadIdx.x; g < kGcBins; g += kDepthBlock)
 		h_sum[g] = 0;
+	if (threadIdx.x == 0)
+		h_counted = 0;
+	__syncthreads();
+
+	const DepthBlock blk = a.blocks[blockIdx.x];
+	const int s = blk.slot;
+	const Slot sl = a.slots[s];
+	const int T = a.tile_len;
+	const bool skip = (a.small[s].status & kStatusUnsorted) != 0; // then this chromosome's tile index is meaningless
+	const int64_t g_end = blk.first_tile + blk.n_tiles;
+	unsigned int counted = 0;
 
 	auto first_of = [&](int64_t t) -> uint32_t {
 		const uint32_t v = a.tile_first[(t < a.total_tiles) ? t : a.total_tiles];
 		return (v == 0xFFFFFFFFu) ? a.n_total : v;
 	};
-	auto gc_of = [&](const Slot &sl_, int64_t gt_) -> uint32_t {
+	auto gc_of = [&](int64_t gt_) -> uint32_t {
 		// GC byte of the lane-th window touched by global tile gt_ (lanes past the tile's last window are unused)
-		int64_t wg = (uint32_t) ((gt_ - sl_.tile0) * T) / (uint32_t) a.step + lane;
-		if (wg >= sl_.n_win)
-			wg = sl_.n_win - 1;
-		return a.gc_hist[sl_.gc_off + wg];
+		int64_t wg = (uint32_t) ((gt_ - sl.tile0) * T) / (uint32_t) a.step + lane;
+		if (wg >= sl.n_win)
+			wg = sl.n_win - 1;
+		return a.gc_hist[sl.gc_off + wg];
+	};
+	auto load_tuples = [&](uint32_t lo, uint32_t hi, int32_t *p_out, int *q_out) {
+#pragma unroll
+		for (int k = 0; k < kDepthPrefetch; k++) {
+			const uint32_t i = lo + k * kWave + lane;
+			p_out[k] = (i < hi) ? a.pos[i] : INT32_MIN; // INT32_MIN: no tuple (fails the range check)
+			q_out[k] = (i < hi) ? (int) a.mapq[i] : 0;
+		}
 	};
 
-	// ---- software pipeline: everything tile gt + 1 needs from HBM is requested while tile gt is
-	// processed (tile index two tiles ahead), so no wave ever waits on a dependent load chain
-	int s = find_slot(a.n_slots, g_begin, [&](int k) { return a.slots[k].tile0; });
-	Slot sl = a.slots[s];
-	int s_n = s;
-	Slot sl_n = sl;
-	bool skip = (a.small[s].status & kStatusUnsorted) != 0; // then this chromosome's tile index is meaningless
-	unsigned int counted = 0;
+	// The waves of the workgroup alternate tiles of its range (tile = first + wave, + 4, + 8, ...), and workgroups
+	// are dispatched in order over the genome: the chip writes one advancing front of read_depth rather than
+	// thousands of separate streams (tools/membw.hip: 5.9 vs 5.6 TB/s with pure stores).
+	// Software pipeline: tile index two of this wave's tiles ahead, tuples and GC bytes one ahead.
+	int64_t gt = blk.first_tile + wv;
+	if (gt < g_end) {
+		uint32_t c_lo = first_of(gt), c_hi = first_of(gt + 1);
+		uint32_t n_lo = first_of(gt + kDepthWaves), n_hi = first_of(gt + kDepthWaves + 1);
+		int32_t c_pos[kDepthPrefetch];
+		int c_mq[kDepthPrefetch];
+		load_tuples(c_lo, c_hi, c_pos, c_mq);
+		uint32_t c_gc = gc_of(gt);
 
-	uint32_t c_lo = first_of(g_begin), c_hi = first_of(g_begin + 1), n_hi = first_of(g_begin + 2);
-	int32_t c_pos[kDepthPrefetch];
-	int c_mq[kDepthPrefetch];
-#pragma unroll
-	for (int k = 0; k < kDepthPrefetch; k++) {
-		const uint32_t i = c_lo + k * kWave + lane;
-		c_pos[k] = (i < c_hi) ? a.pos[i] : INT32_MIN; // INT32_MIN: no tuple (fails the range check below)
-		c_mq[k] = (i < c_hi) ? (int) a.mapq[i] : 0;
-	}
-	uint32_t c_gc = (lane < kDepthMaxWin) ? gc_of(sl, g_begin) : 0;
+		for (; gt < g_end; gt += kDepthWaves) {
+			const bool have_next = gt + kDepthWaves < g_end;
+			const uint32_t nn_lo = first_of(gt + 2 * kDepthWaves), nn_hi = first_of(gt + 2 * kDepthWaves + 1);
+			int32_t n_pos[kDepthPrefetch];
+			int n_mq[kDepthPrefetch];
+			load_tuples(n_lo, have_next ? n_hi : n_lo, n_pos, n_mq);
+			const uint32_t n_gc = have_next ? gc_of(gt + kDepthWaves) : 0;
 
-	for (int64_t gt = g_begin; gt < g_end; gt++) {
-		if (gt >= sl.tile0 + sl.n_tiles) {
-			// next chromosome: hand this one's partial histogram and read count over
-			depth_flush(&a.small[s], h_sum, counted, lane);
-			counted = 0;
-			s = s_n;
-			sl = sl_n;
-			skip = (a.small[s].status & kStatusUnsorted) != 0;
-		}
-		// ---- requests for tile gt + 1 (and the tile index of gt + 2)
-		const bool have_next = gt + 1 < g_end;
-		if (have_next && gt + 1 >= sl_n.tile0 + sl_n.n_tiles) {
-			while (gt + 1 >= a.slots[s_n].tile0 + a.slots[s_n].n_tiles)
-				s_n++;
-			sl_n = a.slots[s_n];
-		}
-		const uint32_t nn_hi = first_of(gt + 3);
-		int32_t n_pos[kDepthPrefetch];
-		int n_mq[kDepthPrefetch];
-#pragma unroll
-		for (int k = 0; k < kDepthPrefetch; k++) {
-			const uint32_t i = c_hi + k * kWave + lane;
-			const bool ok = have_next && i < n_hi;
-			n_pos[k] = ok ? a.pos[i] : INT32_MIN;
-			n_mq[k] = ok ? (int) a.mapq[i] : 0;
-		}
-		const uint32_t n_gc = (have_next && lane < kDepthMaxWin) ? gc_of(sl_n, gt + 1) : 0;
+			// ---- tile gt
+			const int64_t tile = gt - sl.tile0;
+			const int64_t base = tile * T;
+			const int len = (int) ((sl.L - base < T) ? (sl.L - base) : T);
+			// offset of the tile's first base inside its GC window (one 32-bit division per tile)
+			const int r0 = (int) ((uint32_t) base - ((uint32_t) base / (uint32_t) a.step) * (uint32_t) a.step);
 
-		// ---- tile gt
-		const int64_t tile = gt - sl.tile0;
-		const int64_t base = tile * T;
-		const int len = (int) ((sl.L - base < T) ? (sl.L - base) : T);
-		// offset of the tile's first base inside its GC window (one 32-bit division per tile)
-		const int r0 = (int) ((uint32_t) base - ((uint32_t) base / (uint32_t) a.step) * (uint32_t) a.step);
+			for (int j = lane * 4; j < T / 2; j += kWave * 4)
+				*reinterpret_cast<uint4 *>(&cnt2[j]) = make_uint4(0, 0, 0, 0);
+			wsum[lane] = 0; // kDepthMaxWin == kWave
+			__builtin_amdgcn_wave_barrier();
 
-		for (int j = lane * 4; j < T / 2; j += kWave * 4)
-			*reinterpret_cast<uint4 *>(&cnt2[j]) = make_uint4(0, 0, 0, 0);
-		wsum[lane] = 0; // kDepthMaxWin == kWave
-		__builtin_amdgcn_wave_barrier();
-
-		auto add_tuple = [&](int32_t pp, int mq) {
-			const int64_t p = (int64_t) pp - base;
-			if (p >= 0 && p < len && mq > a.mq_threshold) {
-				if (p & 1)
-					atomicAdd(&cnt2[p >> 1], 0x10000u);
-				else {
-					const uint32_t old = atomicAdd(&cnt2[p >> 1], 1u);
-					if ((old & 0xFFFFu) == 0xFFFFu)
-						atomicSub(&cnt2[p >> 1], 0x10000u); // the low short wrapped: undo its carry
-				}
-				counted++;
-			}
-		};
-		if (!skip) {
-#pragma unroll
-			for (int k = 0; k < kDepthPrefetch; k++)
-				add_tuple(c_pos[k], c_mq[k]); // lanes past c_hi carry INT32_MIN and fail the range check
-			for (uint32_t i = c_lo + kDepthPrefetch * kWave + lane; i < c_hi; i += kWave) // deep tiles: direct loads
-				add_tuple(a.pos[i], (int) a.mapq[i]);
-		}
-		__builtin_amdgcn_wave_barrier();
-
-		// stream the tile out: 8 positions (16 bytes) per lane per step; the slot's region is padded to
-		// a multiple of 8 elements and positions >= len hold zeros, so the last store may run over len
-		int16_t *out = a.rd + sl.rd_off + base;
-		for (int j = lane * 8; j < len; j += kWave * 8) {
-			const uint4 q = *reinterpret_cast<const uint4 *>(&cnt2[j >> 1]);
-			*reinterpret_cast<uint4 *>(out + j) = q;
-			if ((q.x | q.y | q.z | q.w) != 0u) { // sparse: most 8-base groups hold no read start
-				const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
-				const int t0 = j + r0; // position relative to the start of the tile's first window
-				int w = (a.step == 1) ? t0 : (int) __umulhi((uint32_t) t0, a.step_magic);
-				int r = t0 - w * a.step;
-				int acc = 0;
-#pragma unroll
-				for (int e = 0; e < 8; e++) {
-					const uint32_t half = (e & 1) ? (wd[e >> 1] >> 16) : (wd[e >> 1] & 0xFFFFu);
-					acc += (int) (int16_t) half;
-					if (++r == a.step) {
-						if (acc)
-							atomicAdd(&wsum[w], acc);
-						acc = 0;
-						r = 0;
-						w++;
+			auto add_tuple = [&](int32_t pp, int mq) {
+				const int64_t p = (int64_t) pp - base;
+				if (p >= 0 && p < len && mq > a.mq_threshold) {
+					if (p & 1)
+						atomicAdd(&cnt2[p >> 1], 0x10000u);
+					else {
+						const uint32_t old = atomicAdd(&cnt2[p >> 1], 1u);
+						if ((old & 0xFFFFu) == 0xFFFFu)
+							atomicSub(&cnt2[p >> 1], 0x10000u); // the low short wrapped: undo its carry
 					}
+					counted++;
 				}
-				if (acc)
-					atomicAdd(&wsum[w], acc);
-			}
-		}
-		__builtin_amdgcn_wave_barrier();
-
-		// per-window (or window-part) depth sums -> GC bins (read_distribution.c:70-71)
-		const int nw = (a.step == 1) ? len : (int) __umulhi((uint32_t) (len + r0 + a.step - 1), a.step_magic);
-		if (lane < nw) {
-			const int sw = wsum[lane];
-			if (sw && c_gc < (uint32_t) kGcBins)
-				atomicAdd(&h_sum[c_gc], (unsigned long long) (long long) sw);
-		}
-		__builtin_amdgcn_wave_barrier();
-
-		// ---- rotate the pipeline
-		c_lo = c_hi;
-		c_hi = n_hi;
-		n_hi = nn_hi;
+			};
+			if (!skip) {
 #pragma unroll
-		for (int k = 0; k < kDepthPrefetch; k++) {
-			c_pos[k] = n_pos[k];
-			c_mq[k] = n_mq[k];
+				for (int k = 0; k < kDepthPrefetch; k++)
+					add_tuple(c_pos[k], c_mq[k]); // lanes past c_hi carry INT32_MIN and fail the range check
+				for (uint32_t i = c_lo + kDepthPrefetch * kWave + lane; i < c_hi; i += kWave) // deep tiles: direct loads
+					add_tuple(a.pos[i], (int) a.mapq[i]);
+			}
+			__builtin_amdgcn_wave_barrier();
+
+			// stream the tile out: 8 positions (16 bytes) per lane per step; the slot's region is padded to whole
+			// tiles and positions >= len hold zeros, so the last store may run over len
+			int16_t *out = a.rd + sl.rd_off + base;
+			for (int j = lane * 8; j < len; j += kWave * 8) {
+				const uint4 q = *reinterpret_cast<const uint4 *>(&cnt2[j >> 1]);
+				*reinterpret_cast<uint4 *>(out + j) = q;
+				if ((q.x | q.y | q.z | q.w) != 0u) { // sparse: most 8-base groups hold no read start
+					const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+					const int t0 = j + r0; // position relative to the start of the tile's first window
+					int w = (a.step == 1) ? t0 : (int) __umulhi((uint32_t) t0, a.step_magic);
+					int r = t0 - w * a.step;
+					int acc = 0;
+#pragma unroll
+					for (int e = 0; e < 8; e++) {
+						const uint32_t half = (e & 1) ? (wd[e >> 1] >> 16) : (wd[e >> 1] & 0xFFFFu);
+						acc += (int) (int16_t) half;
+						if (++r == a.step) {
+							if (acc)
+								atomicAdd(&wsum[w], acc);
+							acc = 0;
+							r = 0;
+							w++;
+						}
+					}
+					if (acc)
+						atomicAdd(&wsum[w], acc);
+				}
+			}
+			__builtin_amdgcn_wave_barrier();
+
+			// per-window (or window-part) depth sums -> GC bins (read_distribution.c:70-71)
+			const int nw = (a.step == 1) ? len : (int) __umulhi((uint32_t) (len + r0 + a.step - 1), a.step_magic);
+			if (lane < nw) {
+				const int sw = wsum[lane];
+				if (sw && c_gc < (uint32_t) kGcBins)
+					atomicAdd(&h_sum[c_gc], (unsigned long long) (long long) sw);
+			}
+			__builtin_amdgcn_wave_barrier();
+
+			// ---- rotate the pipeline
+			c_lo = n_lo;
+			c_hi = n_hi;
+			n_lo = nn_lo;
+			n_hi = nn_hi;
+#pragma unroll
+			for (int k = 0; k < kDepthPrefetch; k++) {
+				c_pos[k] = n_pos[k];
+				c_mq[k] = n_mq[k];
+			}
+			c_gc = n_gc;
 		}
-		c_gc = n_gc;
 	}
-	depth_flush(&a.small[s], h_sum, counted, lane);
+	const int w = wave_sum_i32((int) counted);
+	if (lane == 0 && w)
+		atomicAdd(&h_counted, (unsigned int) w);
+	__syncthreads(); // the only workgroup barrier: every wave's tiles are in the shared histogram
+	for (int g = threadIdx.x; g < kGcBins; g += kDepthBlock)
+		if (h_sum[g])
+			atomicAdd(&a.small[s].hist_sum[g], h_sum[g]);
+	if (threadIdx.x == 0 && h_counted)
+		atomicAdd(&a.small[s].counters[CNT_COUNTED], (unsigned long long) h_counted);
 }
 
 // window_per_gc (read_distribution.c:72) depends on the annotation only: one thread per GC window,

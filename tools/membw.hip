@@ -49,6 +49,22 @@ __global__ __launch_bounds__(256) void fill_round_robin(uint4 *p, size_t n_tiles
 		}
 }
 
+// the waves of a workgroup share one contiguous region and alternate 4 KiB tiles inside it
+template <int BLOCK> __global__ __launch_bounds__(BLOCK) void fill_block_interleaved(uint4 *p, size_t n_tiles, size_t tiles_per_block)
+{
+	constexpr int W = BLOCK / 64;
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const size_t t0 = (size_t) blockIdx.x * tiles_per_block;
+	size_t t1 = t0 + tiles_per_block;
+	if (t1 > n_tiles)
+		t1 = n_tiles;
+	for (size_t t = t0 + wv; t < t1; t += W) {
+		uint4 *q = p + t * 256;
+		for (int j = lane; j < 256; j += 64)
+			q[j] = make_uint4(0, 0, 0, 0);
+	}
+}
+
 int main()
 {
 	const size_t bytes = 5762066572ull / 16 * 16;
@@ -92,8 +108,24 @@ int main()
 		snprintf(nm, sizeof nm, "wave runs %d B aligned, 7 blk/CU", tile_bytes);
 		time(nm, [&] { hipLaunchKernelGGL(fill_wave_runs<false>, dim3(256 * 7), dim3(256), 0, st, (uint4 *) buf, n_tiles, tpw, tile_bytes / 16); });
 	}
-	for (int tile_bytes : {4000, 4096})
-		for (int run : {1, 16, 64}) {
+	{
+		const size_t n_tiles = bytes / 4096;
+		size_t blocks = 256 * 7, tpb = (n_tiles + blocks - 1) / blocks;
+		time("block-interleaved 4 waves, 7 blk/CU", [&] { hipLaunchKernelGGL(fill_block_interleaved<256>, dim3(blocks), dim3(256), 0, st, (uint4 *) buf, n_tiles, tpb); });
+		blocks = 256 * 2; tpb = (n_tiles + blocks - 1) / blocks;
+		time("block-interleaved 16 waves, 2 blk/CU", [&] { hipLaunchKernelGGL(fill_block_interleaved<1024>, dim3(blocks), dim3(1024), 0, st, (uint4 *) buf, n_tiles, tpb); });
+		blocks = 256; tpb = (n_tiles + blocks - 1) / blocks;
+		time("block-interleaved 16 waves, 1 blk/CU", [&] { hipLaunchKernelGGL(fill_block_interleaved<1024>, dim3(blocks), dim3(1024), 0, st, (uint4 *) buf, n_tiles, tpb); });
+		// non-persistent: one 16-wave workgroup per 64 KiB, dispatched in order
+		blocks = (n_tiles + 15) / 16;
+		time("non-persistent 16 waves x 1 tile", [&] { hipLaunchKernelGGL(fill_block_interleaved<1024>, dim3(blocks), dim3(1024), 0, st, (uint4 *) buf, n_tiles, (size_t) 16); });
+		blocks = (n_tiles + 3) / 4;
+		time("non-persistent 4 waves x 1 tile", [&] { hipLaunchKernelGGL(fill_block_interleaved<256>, dim3(blocks), dim3(256), 0, st, (uint4 *) buf, n_tiles, (size_t) 4); });
+		blocks = (n_tiles + 31) / 32;
+		time("non-persistent 4 waves x 8 tiles", [&] { hipLaunchKernelGGL(fill_block_interleaved<256>, dim3(blocks), dim3(256), 0, st, (uint4 *) buf, n_tiles, (size_t) 32); });
+	}
+	for (int tile_bytes : {4096})
+		for (int run : {1, 16}) {
 			const size_t n_tiles = bytes / tile_bytes;
 			char nm[64];
 			snprintf(nm, sizeof nm, "round-robin %d B x%d, 7 blk/CU", tile_bytes, run);
