@@ -243,12 +243,15 @@ int prepare(conga_ctx *ctx)
 	{
 		// depth workgroups: contiguous tile ranges that never cross a chromosome, dispatched in genome order
 		std::vector<DepthBlock> blocks;
+		int64_t tiles_per_block = kDepthTilesPerBlock;
+		if (const char *e = getenv("CONGA_DEPTH_TILES_PER_BLOCK")) // tuning knob
+			tiles_per_block = std::max(1, atoi(e));
 		for (int s = 0; s < n_slots; s++) {
 			const HostSlot &h = ctx->slots[s];
-			for (int64_t t = 0; t < h.n_tiles; t += kDepthTilesPerBlock) {
+			for (int64_t t = 0; t < h.n_tiles; t += tiles_per_block) {
 				DepthBlock b;
 				b.slot = s;
-				b.n_tiles = (int32_t) std::min<int64_t>(kDepthTilesPerBlock, h.n_tiles - t);
+				b.n_tiles = (int32_t) std::min<int64_t>(tiles_per_block, h.n_tiles - t);
 				b.first_tile = h.tile0 + t;
 				blocks.push_back(b);
 			}

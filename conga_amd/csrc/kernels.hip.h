@@ -225,7 +225,7 @@ constexpr int kDepthBlock = 256;
 constexpr int kDepthWaves = kDepthBlock / kWave;
 constexpr int kDepthMaxTile = 2048; // positions per wave tile: 4 KiB of packed LDS counters = 4 KiB-aligned stores
 constexpr int kDepthMaxWin = 64;    // GC windows (or parts of windows) a tile may touch
-constexpr int kDepthTilesPerBlock = 128; // tiles per workgroup (512 KiB of read_depth): one histogram flush each
+constexpr int kDepthTilesPerBlock = 32; // tiles per workgroup (128 KiB of read_depth, one histogram flush); 32-64 measured best
 
 // One workgroup = one contiguous range of tiles inside ONE chromosome (table built on the host).
 struct DepthBlock {
