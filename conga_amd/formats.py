@@ -109,12 +109,13 @@ def write_fasta(path, chroms, width=60, index=True):
                 f.write("\t".join(str(x) for x in r) + "\n")
 
 
-def write_bam(path, sample, chroms, read_len=100, unplaced=0, block_payload=60000, records=None):
+def write_bam(path, sample, chroms, read_len=100, unplaced=0, block_payload=60000, records=None, index=False):
     """chroms: list of (name, length, pos int32[n] sorted, mapq uint8[n][, flag uint16[n]]).
     Every record gets a `read_len`M CIGAR, an all-A sequence and quality 30; `unplaced` unmapped records
     (refID -1) are appended at the end, as in a real coordinate-sorted BAM.
     records: optional {chrom name: (l_qseq int32[n], codes uint8[], qual uint8[], off uint64[n])} with one 4-bit
-    base code per byte -- then every record carries its own sequence, qualities and an <l>M CIGAR."""
+    base code per byte -- then every record carries its own sequence, qualities and an <l>M CIGAR.
+    index=True also writes path + '.bai' (bins with one merged chunk each + the 16 kb linear index)."""
     text = "@HD\tVN:1.6\tSO:coordinate\n"
     for c in chroms:
         text += "@SQ\tSN:%s\tLN:%d\n" % (c[0], c[1])
@@ -130,12 +131,19 @@ def write_bam(path, sample, chroms, read_len=100, unplaced=0, block_payload=6000
     qual = bytes([30]) * l_seq
     cigar = struct.pack("<I", (read_len << 4) | 0)
     k = 0
+    bins = [dict() for _ in chroms]      # per reference: bin -> [voffset begin, voffset end]
+    linear = [dict() for _ in chroms]    # per reference: 16 kb window -> smallest voffset
     with open(path, "wb") as f:
         def flush(final=False):
             nonlocal out
             while len(out) >= block_payload or (final and len(out)):
                 f.write(_bgzf_block(bytes(out[:block_payload])))
                 out = out[block_payload:]
+
+        def voffset():
+            # records are appended to `out`; everything before it is already in closed blocks of block_payload bytes
+            return (f.tell() + 0) << 16 | len(out) if len(out) < block_payload else None
+
         for tid, c in enumerate(chroms):
             pos, mapq = np.asarray(c[2]), np.asarray(c[3])
             flag = np.asarray(c[4]) if len(c) > 4 else np.zeros(len(pos), np.uint16)
@@ -152,11 +160,20 @@ def write_bam(path, sample, chroms, read_len=100, unplaced=0, block_payload=6000
                     qual = np.asarray(rec[2][o:o + l_seq], np.uint8).tobytes()
                     cigar = struct.pack("<I", (l_seq << 4) | 0)
                     read_len = l_seq
-                body = struct.pack("<iiBBHHHiiii", tid, p, len(name), q, _reg2bin(p, p + max(read_len, 1)), 1, fl, l_seq,
+                b = _reg2bin(p, p + max(read_len, 1))
+                body = struct.pack("<iiBBHHHiiii", tid, p, len(name), q, b, 1, fl, l_seq,
                                    -1, -1, 0) + name + cigar + seq + qual
-                out += struct.pack("<i", len(body)) + body
                 if len(out) >= block_payload:
                     flush()
+                v0 = (f.tell() << 16) | len(out)
+                out += struct.pack("<i", len(body)) + body
+                if index and p >= 0:
+                    # the record may run into the next block; its end offset is only used as a chunk end (an upper bound)
+                    v1 = (f.tell() << 16) | min(len(out), 0xFFFF)
+                    e = bins[tid].setdefault(b, [v0, v1])
+                    e[1] = max(e[1], v1)
+                    for w in range(p >> 14, ((p + max(read_len, 1) - 1) >> 14) + 1):
+                        linear[tid].setdefault(w, v0)
         for _ in range(unplaced):
             name = ("u%d" % k).encode() + b"\x00"
             k += 1
@@ -164,6 +181,20 @@ def write_bam(path, sample, chroms, read_len=100, unplaced=0, block_payload=6000
             out += struct.pack("<i", len(body)) + body
         flush(final=True)
         f.write(_BGZF_EOF)
+    if index:
+        with open(path + ".bai", "wb") as f:
+            f.write(b"BAI\x01" + struct.pack("<i", len(chroms)))
+            for tid in range(len(chroms)):
+                f.write(struct.pack("<i", len(bins[tid])))
+                for b, (v0, v1) in sorted(bins[tid].items()):
+                    f.write(struct.pack("<Ii", b, 1) + struct.pack("<QQ", v0, v1))
+                n_intv = (max(linear[tid]) + 1) if linear[tid] else 0
+                f.write(struct.pack("<i", n_intv))
+                last = 0
+                for w in range(n_intv):
+                    last = linear[tid].get(w, last)
+                    f.write(struct.pack("<Q", last))
+            f.write(struct.pack("<Q", 0))
 
 
 def write_bam_fast(path, sample, chroms, read_len=100, level=1, block_payload=65280, realistic=False, seed=1):

@@ -234,3 +234,25 @@ def test_cli_split_reads_rp(tmp_path, oracle):
         assert open(os.path.join(d, "got_%s.bed" % k), "rb").read() == open(w, "rb").read(), k
     dup_rows = [l.split("\t") for l in open(os.path.join(d, "got_dups.bed")).read().splitlines()[1:]]
     assert max(int(x[5]) for x in dup_rows) > 3          # READ_PAIR support was found for a planted duplication
+
+
+def test_bai_seek_gives_the_same_records_in_any_chromosome_order(tmp_path):
+    """With a .bai the reader seeks to a reference's first chunk (sam_index_load + sam_itr_queryi, bam_data.c:259,293);
+    the annotation may list chromosomes in another order than the BAM header."""
+    d = str(tmp_path)
+    cs = [synth.make_chrom(n, L, cov=3.0, gaps=False) for n, L in (("1", 150_000), ("2", 90_000), ("3", 200_000))]
+    formats.write_bam(os.path.join(d, "r.bam"), "S", [(c.name, c.length, c.pos, c.mapq) for c in cs], index=True,
+                      block_payload=20_000, unplaced=3)
+    assert os.path.getsize(os.path.join(d, "r.bam.bai")) > 100
+    order = [cs[2], cs[0], cs[1]]                       # annotation order differs from the BAM's
+    formats.write_annotation(os.path.join(d, "a.cga"), [(c.name, c.length, c.gc, [], []) for c in order])
+    outs = {}
+    for tag in ("with_bai", "no_bai"):
+        if tag == "no_bai":
+            os.remove(os.path.join(d, "r.bam.bai"))
+        r = run(["-i", "r.bam", "--out", "o", "--ref", "r.fa", "--sonic", "a.cga", "--dump-reads"], d)
+        assert r.returncode == 0, r.stderr
+        outs[tag] = [l for l in r.stdout.splitlines() if l[:1].isdigit()]
+    assert outs["with_bai"] == outs["no_bai"]
+    want = ["%s\t%d\t%d\t%d" % (c.name, len(c.pos), c.pos.astype(np.int64).sum(), c.mapq.astype(np.int64).sum()) for c in order]
+    assert outs["with_bai"] == want
