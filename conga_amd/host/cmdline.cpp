@@ -21,7 +21,7 @@
 namespace conga_host {
 
 namespace {
-enum { OPT_FIRST_CHROM = 10001, OPT_LAST_CHROM = 10002, OPT_DEVICE = 10003, OPT_DUMP = 10004, OPT_DUMP_READS = 10005 };
+enum { OPT_FIRST_CHROM = 10001, OPT_LAST_CHROM = 10002, OPT_DEVICE = 10003, OPT_DUMP = 10004, OPT_DUMP_READS = 10005, OPT_DUMP_MAP = 10006 };
 }
 
 void print_help(void)
@@ -91,6 +91,7 @@ int parse_cmd_line(int argc, char **argv, parameters *params)
 		{"device", required_argument, 0, OPT_DEVICE},
 		{"dump-intervals", required_argument, 0, OPT_DUMP},
 		{"dump-reads", no_argument, 0, OPT_DUMP_READS},
+		{"dump-mappability", required_argument, 0, OPT_DUMP_MAP},
 		{0, 0, 0, 0}};
 
 	if (argc == 1) {
@@ -129,6 +130,7 @@ int parse_cmd_line(int argc, char **argv, parameters *params)
 		case OPT_DEVICE: params->device = atoi(optarg); break;
 		case OPT_DUMP: params->dump_intervals_chr = optarg; break;
 		case OPT_DUMP_READS: params->dump_reads = true; break;
+		case OPT_DUMP_MAP: params->dump_mappability_chr = optarg; break;
 		default: break;
 		}
 	}

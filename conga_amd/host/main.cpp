@@ -67,6 +67,20 @@ int main(int argc, char **argv)
 		return EXIT_SUCCESS;
 	}
 
+	if (!params.dump_mappability_chr.empty()) {
+		bed_index bed;
+		if (!params.have_map || !load_bed(params.mappability_file, true, &bed)) {
+			fprintf(stderr, "\n[CONGA INPUT ERROR] Unable to open file %s in read mode.\nInvoke parameter -h for help.\n", params.mappability_file.c_str());
+			return CONGA_EXIT_COMMON;
+		}
+		const auto &rows = bed.rows[params.dump_mappability_chr];
+		const auto &vals = bed.values[params.dump_mappability_chr];
+		for (size_t i = 0; i < rows.size(); i++)
+			printf("MAP\t%d\t%d\t%a\n", rows[i].start, rows[i].end, (double) vals[i]);
+		fclose(logFile);
+		return EXIT_SUCCESS;
+	}
+
 	std::string err;
 	std::unique_ptr<sonic> this_sonic(sonic_load(params.sonic_file, &err));
 	if (!this_sonic) {

@@ -33,6 +33,7 @@ struct parameters {
 	// extensions of this implementation (not in the reference)
 	int device = 0;                  // --device
 	std::string dump_intervals_chr;  // --dump-intervals CHR : print the kept, sorted SV rows and exit (no GPU)
+	std::string dump_mappability_chr; // --dump-mappability CHR : print the parsed mappability rows of CHR and exit (no GPU)
 	bool dump_reads = false;         // --dump-reads : per chromosome, count and checksums of the records the BAM loop would count (no GPU)
 };
 

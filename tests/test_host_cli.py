@@ -256,3 +256,43 @@ def test_bai_seek_gives_the_same_records_in_any_chromosome_order(tmp_path):
     assert outs["with_bai"] == outs["no_bai"]
     want = ["%s\t%d\t%d\t%d" % (c.name, len(c.pos), c.pos.astype(np.int64).sum(), c.mapq.astype(np.int64).sum()) for c in order]
     assert outs["with_bai"] == want
+
+
+def test_fast_bed_parser_equals_the_literal_fgets_strtok_reader(tmp_path, oracle):
+    """svs.cpp parses BEDs from an mmap on several threads; it must yield the rows of the reference's literal
+    fgets(512) / strtok / atoi / atof reader (svs.c:7-240,317-377), which stays in the binary as the fallback."""
+    d = str(tmp_path)
+    rng = np.random.default_rng(4)
+    lines = ["#chr\tstart\tend\tvalue", "", "   ", "1\t100\t2200\t0.5", "1 300   1400\t1", "  1\t+500\t1600\t.25",
+             "1\t-5\t1200\t5.", "1\t1e3\t2500\t1e-1", "1\t2000\t3100\t0.333333abc", "1\t7\t", "1", "2\t10\t5000\t0.75",
+             "1\t4000\t5200\t0.1\textra\tcolumns", "1\t6000\t7300\t0.123456789012345678", "1\t8000\t9100\tnan",
+             "1\t9000\t10100\t-0.5", "X\t1\t2000\t1"]
+    for _ in range(300_000):                                     # > 4 MB so the threaded path is taken
+        s = int(rng.integers(0, 10_000_000))
+        lines.append("%s\t%d\t%d\t%s" % (rng.choice(["1", "2", "21"]), s, s + int(rng.integers(1, 5000)),
+                                         rng.choice(["1", "0.5", "0.333333", "0.25", "0.2", "0.1"])))
+    open(os.path.join(d, "m.bed"), "w").write("\r\n".join(lines[:12]) + "\n" + "\n".join(lines[12:]))
+    long_file = os.path.join(d, "long.bed")                      # one 600-character line: the reference splits it in two chunks
+    open(long_file, "w").write("1\t100\t2200\t0.5\n" + "1\t300\t1400\t" + "0" * 600 + "\n1\t5\t1500\t1\n")
+    outs = {}
+    for literal in ("0", "1"):
+        env = dict(os.environ)
+        if literal == "1":
+            env["CONGA_BED_LITERAL"] = "1"
+        for f in ("m.bed", "long.bed"):
+            for chrom in ("1", "2"):
+                r = subprocess.run([CONGA, "-i", "x", "--out", "o", "--ref", "r.fa", "--mappability", f, "--dels", f,
+                                    "--dump-mappability", chrom], cwd=d, capture_output=True, text=True, env=env)
+                assert r.returncode == 0
+                outs[(literal, f, chrom, "map")] = [l for l in r.stdout.splitlines() if l.startswith("MAP")]
+                r = subprocess.run([CONGA, "-i", "x", "--out", "o", "--ref", "r.fa", "--dels", f, "--dump-intervals", chrom],
+                                   cwd=d, capture_output=True, text=True, env=env)
+                outs[(literal, f, chrom, "iv")] = [l for l in r.stdout.splitlines() if l.startswith("DEL")]
+    for f in ("m.bed", "long.bed"):
+        for chrom in ("1", "2"):
+            for kind in ("map", "iv"):
+                assert outs[("0", f, chrom, kind)] == outs[("1", f, chrom, kind)], (f, chrom, kind)
+    assert len(outs[("0", "m.bed", "1", "map")]) > 90_000
+    # and the interval side agrees with the oracle's reader too
+    svs = oracle.sort_svs(oracle.load_known_SVs(os.path.join(d, "m.bed"), "1", 1000))
+    assert outs[("0", "m.bed", "1", "iv")] == ["DEL\t1\t%d\t%d" % (s, e) for s, e in zip(svs["start"], svs["end"])]
