@@ -134,3 +134,66 @@ def test_output_format(oracle, tmp_path):
     # _svs.bed DEL rows without mappability have seven columns
     assert all(len(l.split("\t")) == 7 for l in svs_txt.splitlines()[1:] if "\tDEL\t" in l)
     assert dup_txt.splitlines()[1].split("\t")[3] in ("1/1", "0/1")
+
+
+def test_oracle_reproduces_the_committed_golden_fixture(oracle, tmp_path):
+    """tests/golden/small_chr.npz + the six .bed files were generated by tests/golden/make_golden.py; the oracle must
+    keep producing them bit for bit / byte for byte (they pin the checker against drift; they are not reference outputs)."""
+    z = np.load(os.path.join(GOLDEN, "small_chr.npz"))
+    L, step = int(z["length"]), int(z["step"])
+    rd, counted = oracle.count_reads(L, z["pos"], z["mapq"], -1)
+    want_rd = np.zeros(L, np.int16)
+    want_rd[z["rd_nonzero_idx"]] = z["rd_nonzero_val"]
+    assert np.array_equal(rd, want_rd) and counted == int(z["counted"])
+    E, S, W = oracle.calc_mean_per_chr(rd, z["gc"], step)
+    assert np.array_equal(E.view(np.uint32), z["E"].view(np.uint32))
+    assert np.array_equal(S, z["S"]) and np.array_equal(W, z["W"])
+    m = oracle.paint_mappability(L, z["map_start"], z["map_end"], z["map_val"])
+    dels = oracle.find_depths(rd, m, z["gc"], E, "D", oracle.make_svs(z["dels"]["start"], z["dels"]["end"]), step)
+    dups = oracle.find_depths(rd, m, z["gc"], E, "E", oracle.make_svs(z["dups"]["start"], z["dups"]["end"]), step)
+    assert dels.tobytes() == z["dels"].tobytes() and dups.tobytes() == z["dups"].tobytes()
+    for tag, have_map in (("map", True), ("nomap", False)):
+        paths = [str(tmp_path / ("%s_%s.bed" % (tag, k))) for k in ("svs", "dels", "dups")]
+        oracle.output_svs("21", dels, dups, *paths, have_mappability=have_map, write_headers=True)
+        for k, p in zip(("svs", "dels", "dups"), paths):
+            assert open(p, "rb").read() == open(os.path.join(GOLDEN, "small_chr_%s_%s.bed" % (tag, k)), "rb").read(), (tag, k)
+
+
+def test_split_read_oracle_on_planted_junctions(oracle):
+    """split_read.c / bam_data.c:29-154 semantics on hand-made reads: a deletion junction, a tandem-duplication
+    junction, an ordinary read, the quality-mean carry-over between the two half reads, and pos == 0."""
+    rng = np.random.default_rng(2)
+    L = 30_000
+    ref = rng.choice(np.frombuffer(b"ACGT", np.uint8), L)
+    code = np.full(256, 15, np.uint8)
+    for k, v in {65: 1, 67: 2, 71: 4, 84: 8}.items():
+        code[k] = v
+    reads = [
+        (9_950, np.concatenate([ref[9_950:10_000], ref[12_000:12_050]]), np.full(100, 30)),   # deletion 10000-12000
+        (17_950, np.concatenate([ref[17_950:18_000], ref[15_000:15_050]]), np.full(100, 30)), # tandem dup 15000-18000
+        (20_000, ref[20_000:20_100], np.full(100, 30)),                                        # ordinary
+        (0, ref[0:100], np.full(100, 30)),                                                     # pos == 0: skipped
+        # first half qualities sum to 499: a fresh mean would be 9 (< threshold 10), the carried-over mean is 10
+        (22_000, ref[22_000:22_100], np.concatenate([np.full(49, 10), [9], np.full(50, 40)])),
+    ]
+    reads.sort(key=lambda r: r[0])
+    pos = np.array([r[0] for r in reads], np.int32)
+    lq = np.full(len(reads), 100, np.int32)
+    off = (np.arange(len(reads)) * 100).astype(np.uint64)
+    seq = code[np.concatenate([r[1] for r in reads])]
+    qual = np.concatenate([r[2] for r in reads]).astype(np.uint8)
+    mapq = np.full(len(reads), 60, np.uint8)
+    flag = np.zeros(len(reads), np.uint16)
+    rows, counts = oracle.split_read_rows(bytes(ref), [], [], pos, mapq, flag, lq, off, seq, qual, mq_threshold=10)
+    # every read but the one at pos 0 yields two elements, including the carry-over read's second element
+    assert counts[0] == 8
+    got = sorted((r["sv_type"].decode(), int(r["left_end"]), int(r["right_start"])) for r in rows)
+    # deletion: anchor 9950 (first half), second half maps at 12000 -> left end 9950+50-50, right start 12000+50
+    # duplication: anchor 17950, second half maps back at 15000 -> left end 15000+50-50, right start 17950+50
+    assert got == [("D", 9_950, 12_050), ("E", 15_000, 18_000)]
+    dels, dups = oracle.make_svs([10_000], [12_000]), oracle.make_svs([15_000], [18_000])
+    oracle.count_read_pairs(rows, dels, dups)
+    assert dels["border_rp"][0] == 1 and dups["rp"][0] == 1
+    # with the threshold at 11 the carry-over read loses its second element only
+    _, counts11 = oracle.split_read_rows(bytes(ref), [], [], pos, mapq, flag, lq, off, seq, qual, mq_threshold=11)
+    assert counts11[0] == 7
