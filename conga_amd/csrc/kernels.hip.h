@@ -829,7 +829,11 @@ template <int G> __global__ __launch_bounds__(256) void interval_chain_kernel(Ch
 {
 	constexpr int kGroups = kWave / G;
 	constexpr int kBlockGroups = 256 / G;
+	// GC bytes are staged through LDS in 16-byte pieces: a whole short interval at once (G = 16: 256 windows), or
+	// double-buffered 1 KiB chunks fetched one chunk (16 steps) ahead (G = 64), so that no step waits on HBM
+	constexpr int kChunk = G * 16; // windows per staged chunk
 	__shared__ float sE[kBlockGroups][kGcBins + 3]; // one expected_read_depth table per lane group
+	__shared__ __attribute__((aligned(16))) uint8_t sGc[kBlockGroups][2][kChunk];
 
 	const int lane = threadIdx.x & (kWave - 1);
 	const int gl = lane & (G - 1);  // lane inside the group
@@ -839,6 +843,7 @@ template <int G> __global__ __launch_bounds__(256) void interval_chain_kernel(Ch
 	const int64_t slot_idx = wave * kGroups + grp;
 	const bool have = slot_idx < a.count;
 	float *E = sE[threadIdx.x / G];
+	uint8_t(*gcbuf)[kChunk] = sGc[threadIdx.x / G];
 
 	int32_t iv = 0;
 	int64_t s0 = 0, e0 = 0, w_first = 0, w_end = 0, n_win = 1;
@@ -858,83 +863,97 @@ template <int G> __global__ __launch_bounds__(256) void interval_chain_kernel(Ch
 			w_end = (uint32_t) (e0 - 1) / (uint32_t) a.step + 1;
 		}
 	}
-	__builtin_amdgcn_wave_barrier(); // the table is written and read by lanes of the same wave: LDS ops stay in order
 	const int64_t step = a.step;
+	const int64_t n_win_pad = (n_win + 15) & ~(int64_t) 15; // the slot's GC region is padded to 16 bytes
+	const uint32_t gc_last = have ? gc[n_win - 1] : 0;      // windows past the chromosome end use the last one
+	// 16 bytes of chunk c for this lane (zero past the padded region)
+	auto fetch = [&](int64_t chunk_base) -> uint4 {
+		const int64_t at = chunk_base + (int64_t) gl * 16;
+		return (have && at < n_win_pad) ? *reinterpret_cast<const uint4 *>(gc + at) : make_uint4(0, 0, 0, 0);
+	};
 
 	float s = 0.0f; // uniform inside a group
-	int64_t wb = w_first;
-	// the GC byte of this lane's window in the NEXT step is requested one step ahead
-	uint32_t g_cur = (wb + gl < w_end) ? gc[(wb + gl < n_win) ? wb + gl : n_win - 1] : 0;
-	while (__any(wb < w_end)) {
-		const int64_t w = wb + gl;
-		const bool active = w < w_end;
-		const int64_t wn = w + G;
-		const uint32_t g_next = (wn < w_end) ? gc[(wn < n_win) ? wn : n_win - 1] : 0;
-		uint32_t k = 0, bc = 0;
-		float c = 0.0f;
-		if (active) {
-			const int64_t lo = (w * step > s0) ? w * step : s0;
-			const int64_t hi = ((w + 1) * step < e0) ? (w + 1) * step : e0;
-			k = (uint32_t) (hi - lo);
-			c = (g_cur < (uint32_t) kGcBins) ? E[g_cur] : 0.0f;
-			bc = conga_f32_bits(c);
-		}
-		unsigned long long todo = __ballot(active) & gmask; // this group's windows still to apply
-		while (__any(todo != 0ull)) {
-			const uint32_t bs = conga_f32_bits(s);
-			const uint32_t es = bs >> 23;
-			const uint32_t ms = (bs & 0x7FFFFFu) | 0x800000u;
-			const bool in = (todo >> lane) & 1ull;
-			const conga_step st = conga_step_for(es & 0xFFu, bc);
-			const bool valid = in && st.delta != 0xFFFFFFFFu && !st.tie && !(bs >> 31) && !(bc >> 31);
-			uint32_t adv = 0;
-			if (valid) {
-				const uint64_t a64 = (uint64_t) k * st.delta;
-				adv = (a64 > (1u << 25)) ? (1u << 25) : (uint32_t) a64;
+	int64_t cb = w_first & ~(int64_t) (G - 1); // chunk base: steps are aligned to it, lanes in front of w_first idle
+	int cur = 0;
+	*reinterpret_cast<uint4 *>(&gcbuf[0][gl * 16]) = fetch(cb);
+	__builtin_amdgcn_wave_barrier(); // table and chunk are written and read by lanes of the same wave: LDS ops stay in order
+	while (__any(cb < w_end)) {
+		const uint4 nxt = fetch(cb + kChunk); // in flight while this chunk's 16 steps run
+		for (int st_i = 0; st_i < 16; st_i++) {
+			const int64_t wb = cb + (int64_t) st_i * G;
+			if (!__any(wb < w_end))
+				break;
+			const int64_t w = wb + gl;
+			const bool active = w >= w_first && w < w_end;
+			uint32_t k = 0, bc = 0;
+			float c = 0.0f;
+			if (active) {
+				const int64_t lo = (w * step > s0) ? w * step : s0;
+				const int64_t hi = ((w + 1) * step < e0) ? (w + 1) * step : e0;
+				k = (uint32_t) (hi - lo);
+				const uint32_t g_cur = (w < n_win) ? gcbuf[cur][st_i * G + gl] : gc_last;
+				c = (g_cur < (uint32_t) kGcBins) ? E[g_cur] : 0.0f;
+				bc = conga_f32_bits(c);
 			}
-			const uint32_t incl = group_incl_scan_u32<G>(adv, gl);
-			const uint32_t pre = incl - adv;
-			const uint32_t m = ms + pre; // mantissa in front of this lane's window (< 2^32)
-			bool ok = true;
-			if (in)
-				ok = valid && (st.delta == 0 || (m <= st.lim && (uint64_t) (k - 1u) * st.delta <= (uint64_t) (st.lim - m)));
-			const unsigned long long bad_all = __ballot(!ok);
-			const unsigned long long bad = bad_all & gmask;
-			uint32_t total, pre_fb = 0, k_fb = 0;
-			float c_fb = 0.0f;
-			const int fb = bad ? (__ffsll((long long) bad) - 1 - grp * G) : 0;
-			if (G == 64) {
-				// one group = the wave: everything is wave-uniform, so scalar lane reads do
-				total = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
-				if (bad_all) {
-					const int fbu = __builtin_amdgcn_readfirstlane(fb);
-					pre_fb = (uint32_t) __builtin_amdgcn_readlane((int) pre, fbu);
-					c_fb = conga_bits_f32((uint32_t) __builtin_amdgcn_readlane((int) bc, fbu));
-					k_fb = (uint32_t) __builtin_amdgcn_readlane((int) k, fbu);
+			unsigned long long todo = __ballot(active) & gmask; // this group's windows still to apply
+			while (__any(todo != 0ull)) {
+				const uint32_t bs = conga_f32_bits(s);
+				const uint32_t es = bs >> 23;
+				const uint32_t ms = (bs & 0x7FFFFFu) | 0x800000u;
+				const bool in = (todo >> lane) & 1ull;
+				const conga_step st = conga_step_for(es & 0xFFu, bc);
+				const bool valid = in && st.delta != 0xFFFFFFFFu && !st.tie && !(bs >> 31) && !(bc >> 31);
+				uint32_t adv = 0;
+				if (valid) {
+					const uint64_t a64 = (uint64_t) k * st.delta;
+					adv = (a64 > (1u << 25)) ? (1u << 25) : (uint32_t) a64;
 				}
-			} else {
-				total = __shfl(incl, G - 1, G);
-				if (bad_all) { // some group of this wave has an irregular window
-					pre_fb = __shfl(pre, fb, G);
-					c_fb = __shfl(c, fb, G);
-					k_fb = __shfl(k, fb, G);
-				}
-			}
-			if (todo != 0ull) {
-				if (bad == 0ull) {
-					if (total)
-						s = compose_f32(es, ms + total);
-					todo = 0ull;
+				const uint32_t incl = group_incl_scan_u32<G>(adv, gl);
+				const uint32_t pre = incl - adv;
+				const uint32_t m = ms + pre; // mantissa in front of this lane's window (< 2^32)
+				bool ok = true;
+				if (in)
+					ok = valid && (st.delta == 0 || (m <= st.lim && (uint64_t) (k - 1u) * st.delta <= (uint64_t) (st.lim - m)));
+				const unsigned long long bad_all = __ballot(!ok);
+				const unsigned long long bad = bad_all & gmask;
+				uint32_t total, pre_fb = 0, k_fb = 0;
+				float c_fb = 0.0f;
+				const int fb = bad ? (__ffsll((long long) bad) - 1 - grp * G) : 0;
+				if (G == 64) {
+					// one group = the wave: everything is wave-uniform, so scalar lane reads do
+					total = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
+					if (bad_all) {
+						const int fbu = __builtin_amdgcn_readfirstlane(fb);
+						pre_fb = (uint32_t) __builtin_amdgcn_readlane((int) pre, fbu);
+						c_fb = conga_bits_f32((uint32_t) __builtin_amdgcn_readlane((int) bc, fbu));
+						k_fb = (uint32_t) __builtin_amdgcn_readlane((int) k, fbu);
+					}
 				} else {
-					if (pre_fb)
-						s = compose_f32(es, ms + pre_fb); // exact state in front of the irregular window
-					s = conga_repeat_add_f32(s, c_fb, k_fb); // real adds where rounding is not a constant step
-					todo &= ~(((2ull << (fb + grp * G)) - 1ull));
+					total = __shfl(incl, G - 1, G);
+					if (bad_all) { // some group of this wave has an irregular window
+						pre_fb = __shfl(pre, fb, G);
+						c_fb = __shfl(c, fb, G);
+						k_fb = __shfl(k, fb, G);
+					}
+				}
+				if (todo != 0ull) {
+					if (bad == 0ull) {
+						if (total)
+							s = compose_f32(es, ms + total);
+						todo = 0ull;
+					} else {
+						if (pre_fb)
+							s = compose_f32(es, ms + pre_fb); // exact state in front of the irregular window
+						s = conga_repeat_add_f32(s, c_fb, k_fb); // real adds where rounding is not a constant step
+						todo &= ~(((2ull << (fb + grp * G)) - 1ull));
+					}
 				}
 			}
 		}
-		wb += G;
-		g_cur = g_next;
+		cb += kChunk;
+		cur ^= 1;
+		*reinterpret_cast<uint4 *>(&gcbuf[cur][gl * 16]) = nxt;
+		__builtin_amdgcn_wave_barrier();
 	}
 	if (have && gl == 0)
 		a.expected[iv] = s;
