@@ -28,7 +28,7 @@ DELETION = "D"
 DUPLICATION = "E"
 
 KERNEL_NAMES = ("ingest", "depth_tile", "expected_table", "paint", "interval_reduce", "interval_score",
-                "chain_long")
+                "interval_chain")
 
 # every symbol include/conga_hip.h declares
 EXPORTS = (
