@@ -1098,7 +1098,7 @@ int conga_chrom_compute(conga_ctx *ctx)
 			const int64_t m = (int64_t) h.map_start.size();
 			if (h.map_sorted) {
 				const int64_t n_pt = (h.L + kPaintTile - 1) / kPaintTile;
-				const int grid = (int) std::min<int64_t>((n_pt + 3) / 4, (int64_t) ctx->n_cu * 8);
+				const int grid = (int) ((n_pt + kPaintTilesPerBlock - 1) / kPaintTilesPerBlock);
 				hipLaunchKernelGGL(paint_sorted_kernel, dim3(grid), dim3(256), 0, st, ms, me, mv, m,
 						ptr<uint32_t>(ctx->d_row_tile) + h.row_tile_off, map, h.L);
 			} else {

@@ -588,35 +588,89 @@ __device__ __forceinline__ int wave_excl_scan_max_i32(int v, int carry)
 	return (up > carry) ? up : carry;
 }
 
+constexpr int kPaintTilesPerBlock = 32; // 128 KiB of floats per workgroup, workgroups dispatched in genome order
+
 __global__ __launch_bounds__(256) void paint_sorted_kernel(const int32_t *__restrict__ start,
 		const int32_t *__restrict__ end, const float *__restrict__ val, int64_t m,
 		const uint32_t *__restrict__ row_tile_first, float *__restrict__ map, int64_t L)
 {
 	__shared__ __attribute__((aligned(16))) int32_t mark_all[4][kPaintTile];
-	const int wv = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+	__shared__ int32_t row_end_all[4][kWave];
+	__shared__ float row_val_all[4][kWave];
+	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = threadIdx.x & (kWave - 1);
 	int32_t *mark = mark_all[wv];
+	int32_t *row_end = row_end_all[wv];
+	float *row_val = row_val_all[wv];
 	const int64_t n_tiles = (L + kPaintTile - 1) / kPaintTile;
-	const int64_t n_waves = (int64_t) gridDim.x * 4;
-	for (int64_t tile = (int64_t) blockIdx.x * 4 + wv; tile < n_tiles; tile += n_waves) {
+	const int64_t t_begin = (int64_t) blockIdx.x * kPaintTilesPerBlock;
+	const int64_t t_end = (t_begin + kPaintTilesPerBlock < n_tiles) ? t_begin + kPaintTilesPerBlock : n_tiles;
+
+	auto first_row = [&](int64_t t) -> uint32_t {
+		const uint32_t v = row_tile_first[(t < n_tiles) ? t : n_tiles];
+		return (v == 0xFFFFFFFFu) ? (uint32_t) m : v;
+	};
+	// the rows a tile can need: the last one that starts before it (k0 - 1) and those that start inside it;
+	// one row per lane is fetched a tile ahead (tiles with more than 63 starting rows fall back to direct loads)
+	struct RowRegs {
+		int32_t s, e;
+		float v;
+	};
+	auto load_row = [&](uint32_t k0, uint32_t k1) -> RowRegs {
+		RowRegs r = {INT32_MIN, -1, 0.0f};
+		const int64_t k = (int64_t) k0 - 1 + lane;
+		if (k >= 0 && k < (int64_t) k1) {
+			r.s = start[k];
+			r.e = end[k];
+			r.v = val[k];
+		}
+		return r;
+	};
+
+	// the four waves of the workgroup alternate tiles; tile index two of this wave's tiles ahead, rows one ahead
+	int64_t tile = t_begin + wv;
+	if (tile >= t_end)
+		return;
+	uint32_t c_k0 = first_row(tile), c_k1 = first_row(tile + 1);
+	uint32_t n_k0 = first_row(tile + 4), n_k1 = first_row(tile + 5);
+	RowRegs c_row = load_row(c_k0, c_k1);
+	for (; tile < t_end; tile += 4) {
+		const bool have_next = tile + 4 < t_end;
+		const uint32_t nn_k0 = first_row(tile + 8), nn_k1 = first_row(tile + 9);
+		RowRegs n_row = {INT32_MIN, -1, 0.0f};
+		if (have_next)
+			n_row = load_row(n_k0, n_k1);
+
 		const int64_t base = tile * kPaintTile;
-		uint32_t k0 = row_tile_first[tile], k1 = row_tile_first[tile + 1];
-		if (k0 == 0xFFFFFFFFu)
-			k0 = (uint32_t) m;
-		if (k1 == 0xFFFFFFFFu)
-			k1 = (uint32_t) m;
+		const uint32_t k0 = c_k0, k1 = c_k1;
+		const bool in_lds = (int64_t) k1 - ((int64_t) k0 - 1) <= kWave; // every needed row sits in a lane
 		for (int j = lane * 4; j < kPaintTile; j += kWave * 4)
 			*reinterpret_cast<int4 *>(&mark[j]) = make_int4(-1, -1, -1, -1);
+		row_end[lane] = c_row.e;
+		row_val[lane] = c_row.v;
 		__builtin_amdgcn_wave_barrier();
-		for (uint32_t k = k0 + lane; k < k1; k += kWave) {
-			int64_t x = (int64_t) start[k] - base;
-			if (x < 0)
-				x = 0; // a row that starts before base 0 is in force from the first base
-			if (x < kPaintTile)
-				atomicMax(&mark[x], (int32_t) k);
+		if (in_lds) {
+			// lane l holds row k0 - 1 + l; lane 0's row starts before the tile and only seeds the carry
+			const int64_t k = (int64_t) k0 - 1 + lane;
+			if (lane > 0 && k < (int64_t) k1) {
+				int64_t x = (int64_t) c_row.s - base;
+				if (x < 0)
+					x = 0; // a row that starts before base 0 is in force from the first base
+				if (x < kPaintTile)
+					atomicMax(&mark[x], (int32_t) k);
+			}
+		} else {
+			for (uint32_t k = k0 + lane; k < k1; k += kWave) {
+				int64_t x = (int64_t) start[k] - base;
+				if (x < 0)
+					x = 0;
+				if (x < kPaintTile)
+					atomicMax(&mark[x], (int32_t) k);
+			}
 		}
 		__builtin_amdgcn_wave_barrier();
 		// the row in force when the tile begins: the last row that starts before it
 		int carry = (int) k0 - 1;
+		const int row0 = (int) k0 - 1; // row held by lane 0
 		// four passes of 256 bases: lane l owns bases [4 (64 q + l), +4), so every store instruction of the
 		// wave writes 1 KiB contiguously
 #pragma unroll
@@ -638,8 +692,13 @@ __global__ __launch_bounds__(256) void paint_sorted_kernel(const int32_t *__rest
 				if (cur != cached) {
 					cached = cur;
 					if (cur >= 0) {
-						c_end = end[cur];
-						c_val = val[cur];
+						if (in_lds) {
+							c_end = row_end[cur - row0];
+							c_val = row_val[cur - row0];
+						} else {
+							c_end = end[cur];
+							c_val = val[cur];
+						}
 					}
 				}
 				out[e] = (cur >= 0 && c_end >= x0 + e) ? c_val : 0.0f;
@@ -653,6 +712,11 @@ __global__ __launch_bounds__(256) void paint_sorted_kernel(const int32_t *__rest
 			carry = __builtin_amdgcn_readlane(cur, kWave - 1);
 		}
 		__builtin_amdgcn_wave_barrier();
+		c_k0 = n_k0;
+		c_k1 = n_k1;
+		n_k0 = nn_k0;
+		n_k1 = nn_k1;
+		c_row = n_row;
 	}
 }
 
