@@ -190,10 +190,15 @@ def main():
         bytes_per_rank = [int(x.item()) for x in all_b]
     else:
         bytes_per_rank = [my_bytes]
-    packed = torch.zeros(max(my_bytes, 1), dtype=torch.uint8, device=dev)
+    # two gather buffers, used alternately: the (asynchronous) RCCL gather of step k may still be reading one
+    # while step k + 1 copies its records into the other
+    packed2 = [torch.zeros(max(my_bytes, 1), dtype=torch.uint8, device=dev) for _ in range(2)]
     total_iv = sum(bytes_per_rank) // rec
+    step_no = [0]
 
     def step():
+        packed = packed2[step_no[0] & 1]
+        step_no[0] += 1
         ctx.compute()                               # whole hot path for this rank's chromosomes, async
         if world > 1:
             ctx.results_copy(packed.data_ptr(), my_bytes)   # records stay on the device for the RCCL gather
