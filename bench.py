@@ -39,6 +39,8 @@ def parse_args():
     ap.add_argument("--config", choices=("dels", "dels+dups+map"), default="dels",
                     help="dels = BASELINE configs[1]; dels+dups+map = configs[2]")
     ap.add_argument("--cov", type=float, default=1.0)
+    ap.add_argument("--formulation", choices=("auto", "dense"), default="auto",
+                    help="auto = tuple space whenever identical (library default); dense = CONGA_FLAG_MATERIALIZE_DEPTH")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="lower bound of CPU-baseline work (oracle, 1 thread); 0 disables the leg")
     ap.add_argument("--chroms", type=str, default="", help="comma list of chromosome names (debug)")
@@ -174,7 +176,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
 
     units = build_units(args, world)
-    ctx = capi.Context(device=local_rank, flags=capi.FLAG_BATCH)  # every chromosome of this rank, one launch per kernel
+    flags = capi.FLAG_BATCH | (capi.FLAG_MATERIALIZE_DEPTH if args.formulation == "dense" else 0)
+    ctx = capi.Context(device=local_rank, flags=flags)  # every chromosome of this rank, one launch per kernel
     mine = [make_unit(u, args) for u in units if u["owner"] == rank]
     for u in mine:
         upload_unit(u, ctx)
@@ -246,7 +249,7 @@ def main():
         ctx.set_profile(False)
         depth_bytes = depth_kernel_bytes(mine) * reps
         depth_ms = kms[1]
-        achieved = depth_bytes / (depth_ms * 1e-3) / 1e9
+        achieved = depth_bytes / (max(depth_ms, 1e-9) * 1e-3) / 1e9
         launches = reps
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "depth_tile_traffic.json")

@@ -23,12 +23,13 @@ CONGA_ERR_RANGE = -6
 FLAG_READS_UNSORTED = 0x1
 FLAG_PROFILE = 0x2
 FLAG_BATCH = 0x4
+FLAG_MATERIALIZE_DEPTH = 0x8
 
 DELETION = "D"
 DUPLICATION = "E"
 
 KERNEL_NAMES = ("ingest", "depth_tile", "expected_table", "paint", "interval_reduce", "interval_score",
-                "interval_chain")
+                "interval_chain", "interval_count")
 
 # every symbol include/conga_hip.h declares
 EXPORTS = (
@@ -62,7 +63,8 @@ class ChromStats(C.Structure):
                 ("reads_out_of_range", C.c_int64), ("rd_sum", C.c_int64), ("mean", C.c_float),
                 ("n_kernels", C.c_int32), ("rd_per_gc", C.c_int64 * 101), ("window_per_gc", C.c_int64 * 101),
                 ("kernel_ms", C.c_double * 8), ("split_elements", C.c_int64), ("split_mappings", C.c_int64),
-                ("split_del_rows", C.c_int64), ("split_dup_rows", C.c_int64)]
+                ("split_del_rows", C.c_int64), ("split_dup_rows", C.c_int64),
+                ("depth_materialized", C.c_int32), ("reserved", C.c_int32)]
 
 
 RESULT_DTYPE = np.dtype([
@@ -80,6 +82,8 @@ class CongaError(RuntimeError):
 
 
 _lib = None
+# OR-ed into the flags of every Context (tests run each parity case under both formulations with it)
+EXTRA_FLAGS = 0
 
 
 def load():
@@ -163,6 +167,7 @@ class Context:
 
     def __init__(self, device=0, mq_threshold=-1, gc_step=100, flags=0, min_read_length=0):
         self._lib = load()
+        flags |= EXTRA_FLAGS
         opts = Opts(C.sizeof(Opts), mq_threshold, gc_step, flags, min_read_length)
         st = C.c_int(0)
         self._h = self._lib.conga_create(device, C.byref(opts), C.byref(st))

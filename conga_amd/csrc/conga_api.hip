@@ -17,6 +17,7 @@
 #include <cstring>
 #include <new>
 #include <numeric>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -46,6 +47,8 @@ struct Staging {
 struct HostSlot {
 	int64_t L = 0, n_win = 0, n_tiles = 0;
 	int64_t read_off = 0, n_reads = 0;
+	int32_t tail_val = 0;  // position of the last committed tuple and the length of the run of equal
+	int64_t tail_len = 0;  // positions that ends there (capped): see wrap_risk
 	std::vector<uint8_t> gc_hist, gc_like; // gc_like empty = same as gc_hist
 	std::vector<int32_t> iv_start[2], iv_end[2], iv_support[2]; // [0] = dels, [1] = dups
 	bool has_map = false, map_sorted = false;
@@ -58,6 +61,7 @@ struct HostSlot {
 	int64_t ref_off = 0, sat_off = 0;
 	// filled by prepare()
 	int64_t rd_off = 0, gc_off = 0, tile0 = 0, tidx_off = 0, iv0 = 0, map_row_off = 0, row_tile_off = 0;
+	int64_t ctile0 = 0, n_ctiles = 0;
 };
 
 } // namespace
@@ -79,19 +83,22 @@ struct conga_ctx {
 
 	// reads
 	int64_t n_reads_total = 0;
+	bool wrap_risk = false;      // some position may hold more than 32767 reads: only the dense kernels reproduce the `short` wrap
+	bool depth_resident = false; // read_depth[] of the last compute is in d_rd
+	int32_t ctile_shift = 14;    // coarse tuple-index tiles of the tuple-space formulation: 2^shift positions
 	Staging staging[kStagingRing];
 	int staging_next = 0; // buffer the next conga_reads_staging() hands out
 	int staging_cur = -1; // buffer handed out and not yet committed
 
 	// layout totals (prepare)
-	int64_t total_L = 0, total_tiles = 0, total_gc = 0, n_iv = 0, n_items = 0, n_long = 0, n_depth_blocks = 0;
+	int64_t total_L = 0, total_tiles = 0, total_ctiles = 0, total_gc = 0, n_iv = 0, n_items = 0, n_long = 0, n_depth_blocks = 0;
 	bool gc_like_distinct = false, any_map = false, support_given = false, any_sr = false;
 	int64_t n_sr_total = 0, sr_bytes_total = 0;
 	conga_split_staging sr_stage{}; // one pinned set (the split-read path is not the bench line)
 	bool sr_staged = false;
 
 	// device buffers
-	DevBuf d_pos, d_mapq, d_tile_start, d_rd, d_gc_hist, d_gc_like, d_slots, d_small, d_map, d_winner,
+	DevBuf d_pos, d_mapq, d_tile_start, d_ctile, d_small_scratch, d_item_ct0, d_item_ct1, d_item_lo, d_rd, d_gc_hist, d_gc_like, d_slots, d_small, d_map, d_winner,
 			d_map_start, d_map_end, d_map_val, d_iv_start, d_iv_end, d_iv_type, d_iv_slot, d_iv_has_map, d_order,
 			d_observed, d_expected, d_item_off, d_item_len, d_item_iv, d_item_has_map, d_item_first, d_map_part,
 			d_support, d_results, d_bases, d_row_tile, d_depth_blocks, d_support_base, d_ref, d_sat_start, d_sat_end, d_sr_pos,
@@ -199,7 +206,8 @@ int prepare(conga_ctx *ctx)
 	const int n_slots = (int) ctx->slots.size();
 
 	// ---- geometry
-	int64_t rd_off = 0, gc_off = 0, tile0 = 0, iv0 = 0, map_rows = 0;
+	int64_t rd_off = 0, gc_off = 0, tile0 = 0, ctile0 = 0, iv0 = 0, map_rows = 0;
+	const int64_t ctile_len = (int64_t) 1 << ctx->ctile_shift;
 	ctx->gc_like_distinct = false;
 	ctx->any_map = false;
 	ctx->support_given = false;
@@ -210,6 +218,8 @@ int prepare(conga_ctx *ctx)
 		h.gc_off = gc_off;
 		h.tile0 = tile0;
 		h.tidx_off = tile0 + s;
+		h.ctile0 = ctile0;
+		h.n_ctiles = (h.L + ctile_len - 1) / ctile_len;
 		h.iv0 = iv0;
 		h.map_row_off = map_rows;
 		Slot &d = dslots[s];
@@ -222,6 +232,9 @@ int prepare(conga_ctx *ctx)
 		d.tile0 = h.tile0;
 		d.n_tiles = h.n_tiles;
 		d.tidx_off = h.tidx_off;
+		d.ctile0 = h.ctile0;
+		d.n_ctiles = h.n_ctiles;
+		ctile0 += h.n_ctiles;
 		rd_off += (h.L + kDepthMaxTile - 1) & ~(int64_t) (kDepthMaxTile - 1); // whole tiles: 4 KiB-aligned regions
 		gc_off += (h.n_win + 15) & ~(int64_t) 15;
 		tile0 += h.n_tiles;
@@ -237,6 +250,7 @@ int prepare(conga_ctx *ctx)
 	ctx->total_L = rd_off;
 	ctx->total_gc = gc_off;
 	ctx->total_tiles = tile0;
+	ctx->total_ctiles = ctile0;
 	ctx->n_iv = iv0;
 
 	TRY(upload(ctx, ctx->d_slots, dslots.data(), dslots.size() * sizeof(Slot)));
@@ -261,8 +275,8 @@ int prepare(conga_ctx *ctx)
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	}
 	TRY(ensure(ctx, ctx->d_small, std::max<size_t>(n_slots, 1) * sizeof(Small)));
-	TRY(ensure(ctx, ctx->d_rd, std::max<size_t>((size_t) ctx->total_L, 8) * 2));
-	TRY(ensure(ctx, ctx->d_tile_start, ((size_t) ctx->total_tiles + 2) * 4));
+	TRY(ensure(ctx, ctx->d_ctile, ((size_t) ctx->total_ctiles + 2) * 4));
+	// d_rd / d_tile_start (6 GB for a human genome) are allocated by the first compute that materialises read_depth
 	if ((size_t) n_slots > ctx->h_small_cap) {
 		if (ctx->h_small)
 			(void) hipHostFree(ctx->h_small);
@@ -410,7 +424,8 @@ int prepare(conga_ctx *ctx)
 
 		// reduce work items: [start, min(end, L)) cut into kItemLen pieces
 		std::vector<int64_t> item_off;
-		std::vector<int32_t> item_len, item_iv;
+		std::vector<int32_t> item_len, item_iv, item_lo;
+		std::vector<uint32_t> item_ct0, item_ct1;
 		std::vector<uint8_t> item_has_map;
 		item_off.reserve(n + n / 2);
 		item_len.reserve(n + n / 2);
@@ -425,6 +440,10 @@ int prepare(conga_ctx *ctx)
 				item_len.push_back((int32_t) std::min<int64_t>(kItemLen, e - a));
 				item_iv.push_back((int32_t) i);
 				item_has_map.push_back(iv_has_map[i]);
+				const int64_t b = std::min<int64_t>(a + kItemLen, e); // a < b <= L
+				item_lo.push_back((int32_t) a);
+				item_ct0.push_back((uint32_t) (h.ctile0 + (a >> ctx->ctile_shift)));
+				item_ct1.push_back((uint32_t) (h.ctile0 + ((b - 1) >> ctx->ctile_shift) + 1));
 			}
 		}
 		item_first[n] = (int32_t) item_off.size();
@@ -441,6 +460,9 @@ int prepare(conga_ctx *ctx)
 		TRY(upload(ctx, ctx->d_item_len, item_len.data(), item_len.size() * 4));
 		TRY(upload(ctx, ctx->d_item_iv, item_iv.data(), item_iv.size() * 4));
 		TRY(upload(ctx, ctx->d_item_has_map, item_has_map.data(), item_has_map.size()));
+		TRY(upload(ctx, ctx->d_item_lo, item_lo.data(), item_lo.size() * 4));
+		TRY(upload(ctx, ctx->d_item_ct0, item_ct0.data(), item_ct0.size() * 4));
+		TRY(upload(ctx, ctx->d_item_ct1, item_ct1.data(), item_ct1.size() * 4));
 		TRY(ensure(ctx, ctx->d_observed, n * 4));
 		TRY(ensure(ctx, ctx->d_expected, n * 4));
 		TRY(ensure(ctx, ctx->d_map_part, std::max<size_t>(item_off.size(), 1) * 8));
@@ -499,6 +521,8 @@ void reset_slots(conga_ctx *ctx)
 	ctx->slots.clear();
 	ctx->cur = -1;
 	ctx->n_reads_total = 0;
+	ctx->wrap_risk = false;
+	ctx->depth_resident = false;
 	ctx->n_sr_total = 0;
 	ctx->sr_bytes_total = 0;
 	ctx->sr_staged = false;
@@ -512,6 +536,82 @@ HostSlot *current(conga_ctx *ctx)
 	if (ctx->cur < 0 || ctx->cur >= (int) ctx->slots.size())
 		return nullptr;
 	return &ctx->slots[ctx->cur];
+}
+
+// read_depth[] is a `short` (common.h:91): the 32768th read starting at one base wraps it.  The tuple-space
+// formulation counts reads and cannot reproduce that, so the commit path looks for runs of equal positions
+// (reads are position-sorted, so the reads of one base are consecutive) and flags the batch for the dense kernels
+// when one may reach kWrapRun.  Conservative and cheap: inside a batch it probes every 1024th tuple against the
+// one kWrapRun - 1 behind it -- any run of 32768 contains such a pair -- and it carries the run that ends a batch
+// into the next one.  All tuples count here, whatever their MAPQ.
+constexpr int64_t kWrapProbeStride = 1024;
+constexpr int64_t kWrapRun = 32768 - kWrapProbeStride + 1; // 31745
+
+void note_equal_runs(conga_ctx *ctx, HostSlot &h, const int32_t *pos, size_t n)
+{
+	if (ctx->wrap_risk || n == 0)
+		return;
+	const int64_t N = (int64_t) n;
+	int64_t lead = 0;
+	if (h.n_reads > 0) {
+		while (lead < N && pos[lead] == h.tail_val)
+			lead++;
+		if (h.tail_len + lead >= kWrapRun)
+			ctx->wrap_risk = true;
+	}
+	for (int64_t i = 0; i + (kWrapRun - 1) < N; i += kWrapProbeStride)
+		if (pos[i] == pos[i + (kWrapRun - 1)])
+			ctx->wrap_risk = true;
+	if (lead == N)
+		h.tail_len = std::min<int64_t>(h.tail_len + N, kWrapRun);
+	else {
+		int64_t len = 1;
+		while (len < N && len < kWrapRun && pos[N - 1 - len] == pos[N - 1])
+			len++;
+		h.tail_val = pos[N - 1];
+		h.tail_len = len;
+	}
+}
+
+// The dense formulation's front end on the sorted tuples: K0 tile index, then K1 + K2 (read_depth[] in d_rd, the
+// GC sums and the read counters into `small`).  Also used to materialise read_depth after a tuple-space compute.
+int launch_dense_depth(conga_ctx *ctx, Small *small, bool timed)
+{
+	hipStream_t st = ctx->stream;
+	const int n_slots = (int) ctx->slots.size();
+	const Slot *dslots = ptr<Slot>(ctx->d_slots);
+	TRY(ensure(ctx, ctx->d_rd, std::max<size_t>((size_t) ctx->total_L, 8) * 2));
+	TRY(ensure(ctx, ctx->d_tile_start, ((size_t) ctx->total_tiles + 2) * 4));
+	HIP_TRY(ctx, hipMemsetAsync(ctx->d_tile_start.p, 0xFF, ((size_t) ctx->total_tiles + 2) * 4, st));
+	{
+		std::unique_ptr<KernelTimer> t(timed ? new KernelTimer(ctx, CONGA_K_INGEST) : nullptr);
+		if (ctx->n_reads_total > 0) {
+			const int grid = (int) std::min<int64_t>((ctx->n_reads_total + 255) / 256, (int64_t) ctx->n_cu * 8);
+			hipLaunchKernelGGL(ingest_kernel, dim3(grid), dim3(256), 0, st, ptr<int32_t>(ctx->d_pos),
+					ctx->n_reads_total, dslots, n_slots, ctx->tile_len, ptr<uint32_t>(ctx->d_tile_start), small);
+		}
+	}
+	{
+		std::unique_ptr<KernelTimer> t(timed ? new KernelTimer(ctx, CONGA_K_DEPTH) : nullptr);
+		DepthArgs a;
+		a.pos = ptr<int32_t>(ctx->d_pos);
+		a.mapq = ptr<uint8_t>(ctx->d_mapq);
+		a.tile_first = ptr<uint32_t>(ctx->d_tile_start);
+		a.n_total = (uint32_t) ctx->n_reads_total;
+		a.rd = ptr<int16_t>(ctx->d_rd);
+		a.gc_hist = ptr<uint8_t>(ctx->d_gc_hist);
+		a.slots = dslots;
+		a.blocks = ptr<DepthBlock>(ctx->d_depth_blocks);
+		a.small = small;
+		a.step = ctx->step;
+		a.step_magic = (uint32_t) (0x100000000ull / (uint64_t) ctx->step) + 1u;
+		a.tile_len = ctx->tile_len;
+		a.mq_threshold = ctx->opts.mq_threshold;
+		a.total_tiles = ctx->total_tiles;
+		const int grid = (int) ctx->n_depth_blocks;
+		hipLaunchKernelGGL(depth_tile_kernel, dim3(grid), dim3(kDepthBlock), 0, st, a);
+	}
+	return CONGA_OK;
 }
 
 } // namespace
@@ -656,7 +756,8 @@ void conga_destroy(conga_ctx *ctx)
 		(void) hipEventDestroy(ctx->ev_fork);
 	if (ctx->ev_join)
 		(void) hipEventDestroy(ctx->ev_join);
-	DevBuf *bufs[] = {&ctx->d_pos, &ctx->d_mapq, &ctx->d_tile_start, &ctx->d_rd, &ctx->d_gc_hist, &ctx->d_gc_like,
+	DevBuf *bufs[] = {&ctx->d_pos, &ctx->d_mapq, &ctx->d_tile_start, &ctx->d_ctile, &ctx->d_small_scratch, &ctx->d_item_ct0,
+			&ctx->d_item_ct1, &ctx->d_item_lo, &ctx->d_rd, &ctx->d_gc_hist, &ctx->d_gc_like,
 			&ctx->d_slots, &ctx->d_small, &ctx->d_map, &ctx->d_winner, &ctx->d_map_start, &ctx->d_map_end,
 			&ctx->d_map_val, &ctx->d_iv_start, &ctx->d_iv_end, &ctx->d_iv_type, &ctx->d_iv_slot, &ctx->d_iv_has_map,
 			&ctx->d_order, &ctx->d_observed, &ctx->d_expected, &ctx->d_item_off, &ctx->d_item_len, &ctx->d_item_iv,
@@ -802,6 +903,7 @@ int conga_reads_commit(conga_ctx *ctx, size_t n)
 		TRY(ensure(ctx, ctx->d_pos, want * 4, true));
 		TRY(ensure(ctx, ctx->d_mapq, want, true));
 	}
+	note_equal_runs(ctx, h, s.pos, n);
 	HIP_TRY(ctx, hipMemcpyAsync(ptr<int32_t>(ctx->d_pos) + ctx->n_reads_total, s.pos, n * 4, hipMemcpyHostToDevice, ctx->stream));
 	HIP_TRY(ctx, hipMemcpyAsync(ptr<uint8_t>(ctx->d_mapq) + ctx->n_reads_total, s.mapq, n, hipMemcpyHostToDevice, ctx->stream));
 	HIP_TRY(ctx, hipEventRecord(s.copied, ctx->stream));
@@ -1028,38 +1130,39 @@ int conga_chrom_compute(conga_ctx *ctx)
 
 	HIP_TRY(ctx, hipMemsetAsync(small, 0, (size_t) n_slots * sizeof(Small), st));
 
-	if (!unsorted_mode) {
-		HIP_TRY(ctx, hipMemsetAsync(ctx->d_tile_start.p, 0xFF, ((size_t) ctx->total_tiles + 2) * 4, st));
-		{
-			KernelTimer t(ctx, CONGA_K_INGEST);
-			if (ctx->n_reads_total > 0) {
-				const int grid = (int) std::min<int64_t>((ctx->n_reads_total + 255) / 256, (int64_t) ctx->n_cu * 8);
-				hipLaunchKernelGGL(ingest_kernel, dim3(grid), dim3(256), 0, st, ptr<int32_t>(ctx->d_pos),
-						ctx->n_reads_total, dslots, n_slots, ctx->tile_len,
-						ptr<uint32_t>(ctx->d_tile_start), small);
-			}
-		}
-		{
-			KernelTimer t(ctx, CONGA_K_DEPTH);
-			DepthArgs a;
+	// Formulation: tuple-space unless read_depth[] was asked for, the reads may be unsorted, or a `short` may wrap.
+	const bool dense = unsorted_mode || (ctx->opts.flags & CONGA_FLAG_MATERIALIZE_DEPTH) != 0 || ctx->wrap_risk;
+	ctx->depth_resident = false;
+	if (!dense) {
+		HIP_TRY(ctx, hipMemsetAsync(ctx->d_ctile.p, 0xFF, ((size_t) ctx->total_ctiles + 2) * 4, st));
+		KernelTimer t(ctx, CONGA_K_INGEST);
+		if (ctx->n_reads_total > 0) {
+			TupleArgs a;
 			a.pos = ptr<int32_t>(ctx->d_pos);
 			a.mapq = ptr<uint8_t>(ctx->d_mapq);
-			a.tile_first = ptr<uint32_t>(ctx->d_tile_start);
 			a.n_total = (uint32_t) ctx->n_reads_total;
-			a.rd = ptr<int16_t>(ctx->d_rd);
-			a.gc_hist = ptr<uint8_t>(ctx->d_gc_hist);
 			a.slots = dslots;
-			a.blocks = ptr<DepthBlock>(ctx->d_depth_blocks);
-			a.small = small;
+			a.n_slots = n_slots;
+			a.gc_hist = ptr<uint8_t>(ctx->d_gc_hist);
 			a.step = ctx->step;
-			a.step_magic = (uint32_t) (0x100000000ull / (uint64_t) ctx->step) + 1u;
-			a.tile_len = ctx->tile_len;
+			a.tile_shift = ctx->ctile_shift;
+			a.ctile_first = ptr<uint32_t>(ctx->d_ctile);
 			a.mq_threshold = ctx->opts.mq_threshold;
-			a.total_tiles = ctx->total_tiles;
-			const int grid = (int) ctx->n_depth_blocks;
-			hipLaunchKernelGGL(depth_tile_kernel, dim3(grid), dim3(kDepthBlock), 0, st, a);
+			a.small = small;
+			a.n_chunks = (uint32_t) ((ctx->n_reads_total + kTupleChunk - 1) / kTupleChunk);
+			int blocks = ctx->n_cu * 8;
+			if (const char *e = getenv("CONGA_TUPLE_BLOCKS_PER_CU")) // tuning knob
+				blocks = ctx->n_cu * std::max(1, atoi(e));
+			a.chunks_per_block = (a.n_chunks + (uint32_t) blocks - 1) / (uint32_t) blocks;
+			const int grid = (int) ((a.n_chunks + a.chunks_per_block - 1) / a.chunks_per_block);
+			hipLaunchKernelGGL(ingest_tuples_kernel, dim3(grid), dim3(kTupleBlock), 0, st, a);
 		}
+	} else if (!unsorted_mode) {
+		TRY(launch_dense_depth(ctx, small, true));
+		ctx->depth_resident = true;
 	} else {
+		TRY(ensure(ctx, ctx->d_rd, std::max<size_t>((size_t) ctx->total_L, 8) * 2));
+		ctx->depth_resident = true;
 		KernelTimer t(ctx, CONGA_K_DEPTH);
 		HIP_TRY(ctx, hipMemsetAsync(ctx->d_rd.p, 0, (size_t) ctx->total_L * 2, st));
 		for (int s = 0; s < n_slots; s++) {
@@ -1179,10 +1282,30 @@ int conga_chrom_compute(conga_ctx *ctx)
 			st_reduce = ctx->stream2;
 		}
 		HIP_TRY(ctx, hipMemsetAsync(ctx->d_observed.p, 0, (size_t) ctx->n_iv * 4, st_reduce));
-		if (ctx->n_items > 0) {
+		if (ctx->n_items > 0 && !dense) {
+			KernelTimer t(ctx, CONGA_K_COUNT_READS);
+			CountArgs a;
+			a.pos = ptr<int32_t>(ctx->d_pos);
+			a.mapq = ptr<uint8_t>(ctx->d_mapq);
+			a.n_total = (uint32_t) ctx->n_reads_total;
+			a.ctile_first = ptr<uint32_t>(ctx->d_ctile);
+			a.item_ct0 = ptr<uint32_t>(ctx->d_item_ct0);
+			a.item_ct1 = ptr<uint32_t>(ctx->d_item_ct1);
+			a.item_lo = ptr<int32_t>(ctx->d_item_lo);
+			a.item_len = ptr<int32_t>(ctx->d_item_len);
+			a.item_iv = ptr<int32_t>(ctx->d_item_iv);
+			a.n_items = ctx->n_items;
+			a.mq_threshold = ctx->opts.mq_threshold;
+			a.observed = ptr<int32_t>(ctx->d_observed);
+			const int waves_per_block = 256 / kWave;
+			const int grid = (int) ((ctx->n_items + waves_per_block - 1) / waves_per_block);
+			if (ctx->n_reads_total > 0)
+				hipLaunchKernelGGL(interval_count_kernel, dim3(grid), dim3(256), 0, st_reduce, a);
+		}
+		if (ctx->n_items > 0 && (dense || ctx->any_map)) {
 			KernelTimer t(ctx, CONGA_K_REDUCE);
 			ReduceArgs a;
-			a.rd = ptr<int16_t>(ctx->d_rd);
+			a.rd = dense ? ptr<int16_t>(ctx->d_rd) : nullptr;
 			a.map = ptr<float>(ctx->d_map);
 			a.item_off = ptr<int64_t>(ctx->d_item_off);
 			a.item_len = ptr<int32_t>(ctx->d_item_len);
@@ -1294,6 +1417,7 @@ int conga_chrom_fetch(conga_ctx *ctx, conga_result *dels, conga_result *dups, fl
 		stats->split_mappings = (int64_t) sb.counters[CNT_SR_MAPPINGS];
 		stats->split_del_rows = (int64_t) sb.counters[CNT_SR_DEL_ROWS];
 		stats->split_dup_rows = (int64_t) sb.counters[CNT_SR_DUP_ROWS];
+		stats->depth_materialized = ctx->depth_resident ? 1 : 0;
 		if (ctx->opts.flags & CONGA_FLAG_PROFILE) {
 			for (int k = 0; k < CONGA_K_COUNT; k++) {
 				float ms = 0.0f;
@@ -1372,6 +1496,15 @@ int conga_copy_read_depth(conga_ctx *ctx, int16_t *out, int64_t n)
 	if (!ctx || !out || !ctx->computed || !h || n > h->L || n < 0)
 		return CONGA_ERR_INVALID;
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	if (!ctx->depth_resident) {
+		// tuple-space compute: build read_depth[] now; its by-products go to a scratch block, not into the results
+		const size_t bytes = ctx->slots.size() * sizeof(Small);
+		TRY(ensure(ctx, ctx->d_small_scratch, bytes));
+		HIP_TRY(ctx, hipMemsetAsync(ctx->d_small_scratch.p, 0, bytes, ctx->stream));
+		TRY(launch_dense_depth(ctx, ptr<Small>(ctx->d_small_scratch), false));
+		HIP_TRY(ctx, hipGetLastError());
+		ctx->depth_resident = true;
+	}
 	HIP_TRY(ctx, hipMemcpyAsync(out, ptr<int16_t>(ctx->d_rd) + h->rd_off, (size_t) n * 2, hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	return CONGA_OK;

@@ -37,6 +37,8 @@ struct Slot {
 	int64_t tile0;    // first global depth tile
 	int64_t n_tiles;
 	int64_t tidx_off; // first entry in tile_start (n_tiles + 1 entries per slot)
+	int64_t ctile0;   // first global COARSE tile (tuple index of the tuple-space formulation, 2^shift positions each)
+	int64_t n_ctiles;
 };
 
 // Small per-chromosome block, read back after every compute.
@@ -198,6 +200,319 @@ __global__ __launch_bounds__(256) void ingest_kernel(const int32_t *__restrict__
 			t_prev_known = true;
 		}
 	}
+}
+
+// -------------------------------------------------------------------------------------------
+// Tuple-space formulation (default whenever it is provably identical to the dense one).
+//
+// read_depth[i] is "how many kept reads start at i", so as long as no position collects more than 32767 reads
+// (no `short` wrap -- conga_reads_commit checks that on the host and falls back to the dense kernels otherwise)
+//   rd_per_gc[g]            = number of kept reads whose start lies in a window of GC bin g
+//   sum(read_depth[a .. b)) = number of kept reads with a <= pos < b
+// and neither needs read_depth[L] in HBM: the sample is 5 bytes per READ of traffic instead of 4+ bytes per BASE.
+//
+// K0' ingest_tuples: one pass over the tuples.  Each workgroup owns a contiguous run of 1024-tuple chunks and
+// keeps the next chunk's loads in flight while it works on the current one.
+//   * the checks of K0 (order inside a chromosome, range);
+//   * kept = in range and mapq > threshold (bam_data.c:205): counted, and added to the GC bin of its window in a
+//     workgroup-private LDS histogram (32 copies, copy c at odd stride 101 words, so one wave's atomics on one
+//     bin land in 32 different banks); one global atomic per non-empty bin when the workgroup ends or moves on
+//     to another chromosome;
+//   * ctile_first[t] = first tuple of COARSE tile t (2^shift positions) or later -- same construction as K0's
+//     index, 8x fewer entries; interval_count only needs it to bound its scan.
+// A chunk that is not strictly inside one chromosome (its first chunk, a straddling one, the ragged end: ~45 of
+// 28,000) goes tuple by tuple into the global counters.
+// -------------------------------------------------------------------------------------------
+constexpr int kTupleBlock = 256;
+constexpr int kTupleChunk = kTupleBlock * 4; // tuples per workgroup step: one 16-byte position load per lane
+constexpr int kHistCopies = 32;
+
+struct TupleArgs {
+	const int32_t *pos;
+	const uint8_t *mapq;
+	uint32_t n_total;
+	const Slot *slots;
+	int n_slots;
+	const uint8_t *gc_hist;
+	int32_t step;
+	int32_t tile_shift;
+	uint32_t *ctile_first;
+	int32_t mq_threshold;
+	Small *small;
+	uint32_t n_chunks;          // ceil(n_total / kTupleChunk)
+	uint32_t chunks_per_block;  // consecutive chunks per workgroup
+};
+
+struct TupleSlot {
+	uint32_t r0, r1; // tuple index range
+	int32_t L;
+	uint32_t tile0, last_tile; // coarse
+	uint32_t gc_off;
+};
+
+__device__ __forceinline__ TupleSlot tuple_slot(const Slot &sl)
+{
+	TupleSlot o;
+	o.r0 = (uint32_t) sl.read_off;
+	o.r1 = (uint32_t) (sl.read_off + sl.n_reads);
+	o.L = (int32_t) sl.L;
+	o.tile0 = (uint32_t) sl.ctile0;
+	o.last_tile = (uint32_t) (sl.ctile0 + sl.n_ctiles - 1);
+	o.gc_off = (uint32_t) sl.gc_off;
+	return o;
+}
+
+__device__ __forceinline__ uint32_t coarse_tile_of(const TupleSlot &sl, int32_t p, int shift)
+{
+	if (p < 0)
+		return sl.tile0;
+	if (p >= sl.L)
+		return sl.last_tile;
+	return sl.tile0 + ((uint32_t) p >> shift);
+}
+
+struct TupleRegs { // one chunk's share of a lane: four tuples and, for lane 0 of a wave, the tuple in front of them
+	int4 q;
+	uint32_t mq;
+	int32_t pv;
+};
+
+__device__ __forceinline__ TupleRegs load_tuples(const TupleArgs &a, uint32_t chunk, uint32_t n_chunks)
+{
+	TupleRegs r;
+	r.q = make_int4(0, 0, 0, 0);
+	r.mq = 0;
+	r.pv = 0;
+	const uint32_t i0 = chunk * (uint32_t) kTupleChunk + threadIdx.x * 4;
+	if (chunk < n_chunks && i0 + 4 <= a.n_total) { // a ragged last chunk is re-read by the general path
+		r.q = *reinterpret_cast<const int4 *>(a.pos + i0);
+		r.mq = *reinterpret_cast<const uint32_t *>(a.mapq + i0);
+		if ((threadIdx.x & (kWave - 1)) == 0 && i0 > 0)
+			r.pv = a.pos[i0 - 1];
+	}
+	return r;
+}
+
+// A chunk that lies inside one chromosome (all but ~21 of 28,000): no per-tuple chromosome lookup, four tuples
+// per lane handled without a branch except for the rare tile boundary / out-of-range tuple.
+__device__ __forceinline__ int ingest_chunk_inside(const TupleArgs &a, const TupleSlot &sl, int home, uint32_t base,
+		const TupleRegs &r, uint32_t *my_hist, float inv_step)
+{
+	const int lane = threadIdx.x & (kWave - 1);
+	const uint32_t step = (uint32_t) a.step;
+	const uint32_t i0 = base + threadIdx.x * 4;
+	const int32_t p[4] = {r.q.x, r.q.y, r.q.z, r.q.w};
+	int32_t prev = __shfl_up(p[3], 1, kWave); // the neighbour lane holds the tuple in front of this lane's four
+	if (lane == 0)
+		prev = r.pv;
+	if ((p[0] < prev) | (p[1] < p[0]) | (p[2] < p[1]) | (p[3] < p[2]))
+		atomicOr(&a.small[home].status, kStatusUnsorted);
+	bool in[4];
+	int n_in = 0;
+#pragma unroll
+	for (int e = 0; e < 4; e++) {
+		in[e] = (uint32_t) p[e] < (uint32_t) sl.L;
+		n_in += in[e] ? 1 : 0;
+	}
+	if (n_in != 4)
+		atomicAdd(&a.small[home].counters[CNT_OUT_OF_RANGE], (unsigned long long) (4 - n_in));
+	const uint32_t t_prev = coarse_tile_of(sl, prev, a.tile_shift);
+	const uint32_t t_last = coarse_tile_of(sl, p[3], a.tile_shift);
+	if (t_last != t_prev) { // some tile starts inside this lane's four tuples
+		uint32_t t_done = t_prev;
+		for (int e = 0; e < 4; e++) {
+			const uint32_t t_cur = coarse_tile_of(sl, p[e], a.tile_shift);
+			for (int64_t t = (int64_t) t_done + 1; t <= (int64_t) t_cur; t++)
+				a.ctile_first[t] = i0 + e;
+			if (t_cur > t_done)
+				t_done = t_cur;
+		}
+	}
+	uint32_t w[4];
+	bool k[4];
+	int kept = 0;
+#pragma unroll
+	for (int e = 0; e < 4; e++) {
+		k[e] = in[e] && (int) ((r.mq >> (8 * e)) & 0xFFu) > a.mq_threshold;
+		w[e] = !k[e] ? 0u : (step == 1) ? (uint32_t) p[e] : div_tile((uint32_t) p[e], step, inv_step);
+		kept += k[e] ? 1 : 0;
+	}
+	int g[4];
+#pragma unroll
+	for (int e = 0; e < 4; e++)
+		g[e] = a.gc_hist[(uint64_t) sl.gc_off + w[e]];
+#pragma unroll
+	for (int e = 0; e < 4; e++)
+		if (k[e])
+			atomicAdd(&my_hist[g[e]], 1u);
+	return kept;
+}
+
+// Any other chunk (two chromosomes, a ragged end, the very first tuple): tuple by tuple, straight into the
+// global counters.
+__device__ __forceinline__ void ingest_chunk_general(const TupleArgs &a, uint32_t base, float inv_step)
+{
+	const uint32_t n_total = a.n_total;
+	const uint32_t step = (uint32_t) a.step;
+	const uint32_t i0 = base + threadIdx.x * 4;
+	if (i0 >= n_total)
+		return;
+	int s = -1;
+	TupleSlot sl = {1, 0, 0, 0, 0, 0}; // empty range: the first tuple refreshes it
+	int32_t prev = (i0 > 0) ? a.pos[i0 - 1] : 0;
+	uint32_t t_prev = 0;
+	bool t_prev_known = false;
+	for (int e = 0; e < 4; e++) {
+		const uint32_t i = i0 + e;
+		if (i >= n_total)
+			break;
+		if (i < sl.r0 || i >= sl.r1) {
+			s = find_slot(a.n_slots, (int64_t) i, [&](int k) { return a.slots[k].read_off; });
+			sl = tuple_slot(a.slots[s]);
+			t_prev_known = false;
+		}
+		const int32_t p = a.pos[i];
+		const bool in_range = p >= 0 && p < sl.L;
+		if (!in_range)
+			atomicAdd(&a.small[s].counters[CNT_OUT_OF_RANGE], 1ull);
+		const uint32_t t_cur = coarse_tile_of(sl, p, a.tile_shift);
+		int64_t first_fill;
+		if (i == 0)
+			first_fill = 0;
+		else {
+			if (i > sl.r0) { // `prev` is in the same chromosome
+				if (p < prev)
+					atomicOr(&a.small[s].status, kStatusUnsorted);
+				if (!t_prev_known)
+					t_prev = coarse_tile_of(sl, prev, a.tile_shift);
+			} else {
+				const int sp = find_slot(a.n_slots, (int64_t) i - 1, [&](int k) { return a.slots[k].read_off; });
+				t_prev = coarse_tile_of(tuple_slot(a.slots[sp]), prev, a.tile_shift);
+			}
+			first_fill = (int64_t) t_prev + 1;
+		}
+		for (int64_t t = first_fill; t <= (int64_t) t_cur; t++)
+			a.ctile_first[t] = i;
+		prev = p;
+		t_prev = t_cur;
+		t_prev_known = true;
+		if (in_range && (int) a.mapq[i] > a.mq_threshold) {
+			const uint32_t w = (step == 1) ? (uint32_t) p : div_tile((uint32_t) p, step, inv_step);
+			const int g = a.gc_hist[(uint64_t) sl.gc_off + w];
+			atomicAdd(&a.small[s].hist_sum[g], 1ull);
+			atomicAdd(&a.small[s].counters[CNT_COUNTED], 1ull);
+		}
+	}
+}
+
+__global__ __launch_bounds__(kTupleBlock) void ingest_tuples_kernel(TupleArgs a)
+{
+	__shared__ uint32_t hist[kHistCopies * kGcBins];
+	__shared__ uint32_t kept_block;
+	const uint32_t c0 = blockIdx.x * a.chunks_per_block;
+	const uint32_t c1 = min(c0 + a.chunks_per_block, a.n_chunks);
+	TupleRegs next = load_tuples(a, c0, c1); // in flight while the histogram is cleared
+	for (int k = threadIdx.x; k < kHistCopies * kGcBins; k += kTupleBlock)
+		hist[k] = 0;
+	if (threadIdx.x == 0)
+		kept_block = 0;
+	__syncthreads();
+
+	const int lane = threadIdx.x & (kWave - 1);
+	const float inv_step = 1.0f / (float) a.step;
+	uint32_t *const my_hist = hist + (threadIdx.x & (kHistCopies - 1)) * kGcBins;
+	int home = -1; // chromosome the LDS histogram belongs to
+	TupleSlot hs = {1, 0, 0, 0, 0, 0};
+	int kept = 0;
+
+	auto flush = [&]() { // workgroup-uniform
+		kept = wave_sum_i32(kept);
+		if (lane == 0 && kept)
+			atomicAdd(&kept_block, (uint32_t) kept);
+		kept = 0;
+		__syncthreads();
+		if (threadIdx.x < kGcBins) {
+			uint32_t sum = 0;
+#pragma unroll 8
+			for (int c = 0; c < kHistCopies; c++) {
+				sum += hist[c * kGcBins + threadIdx.x];
+				hist[c * kGcBins + threadIdx.x] = 0;
+			}
+			if (sum)
+				atomicAdd(&a.small[home].hist_sum[threadIdx.x], (unsigned long long) sum);
+		}
+		if (threadIdx.x == 128 && kept_block) {
+			atomicAdd(&a.small[home].counters[CNT_COUNTED], (unsigned long long) kept_block);
+			kept_block = 0;
+		}
+		__syncthreads();
+	};
+
+	for (uint32_t c = c0; c < c1; c++) {
+		const TupleRegs cur = next;
+		next = load_tuples(a, c + 1, c1);
+		const uint32_t base = c * (uint32_t) kTupleChunk;
+		if (!(base > hs.r0 && (uint64_t) base + kTupleChunk <= (uint64_t) hs.r1)) { // chunk not inside `home`
+			if (home >= 0)
+				flush();
+			home = -1;
+			const int s = find_slot(a.n_slots, (int64_t) base, [&](int k) { return a.slots[k].read_off; });
+			const TupleSlot cand = tuple_slot(a.slots[s]);
+			if (base > cand.r0 && (uint64_t) base + kTupleChunk <= (uint64_t) cand.r1) {
+				home = s;
+				hs = cand;
+			} else {
+				hs.r0 = 1;
+				hs.r1 = 0;
+				ingest_chunk_general(a, base, inv_step);
+				continue;
+			}
+		}
+		kept += ingest_chunk_inside(a, hs, home, base, cur, my_hist, inv_step);
+	}
+	if (home >= 0)
+		flush();
+}
+
+// -------------------------------------------------------------------------------------------
+// K4' interval_count: observed_rd_sv of the tuple-space formulation (likelihood.c:111-114 without read_depth):
+// one wave per reduce item [lo, lo + len) (<= 16384 bases of one interval), which counts the kept tuples with
+// lo <= pos < lo + len among the tuples of the coarse tiles the item touches.  Integer, order-free.
+// -------------------------------------------------------------------------------------------
+struct CountArgs {
+	const int32_t *pos;
+	const uint8_t *mapq;
+	uint32_t n_total;
+	const uint32_t *ctile_first;
+	const uint32_t *item_ct0; // global coarse tile of the item's first base
+	const uint32_t *item_ct1; // one past the global coarse tile of its last base
+	const int32_t *item_lo;   // first base, chromosome coordinates
+	const int32_t *item_len;
+	const int32_t *item_iv;
+	int64_t n_items;
+	int32_t mq_threshold;
+	int32_t *observed; // [n_iv], zeroed before launch
+};
+
+__global__ __launch_bounds__(256) void interval_count_kernel(CountArgs a)
+{
+	const int lane = threadIdx.x & (kWave - 1);
+	const int64_t item = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+	if (item >= a.n_items)
+		return; // wave-uniform
+	const int32_t lo = a.item_lo[item], hi = lo + a.item_len[item];
+	uint32_t u = a.ctile_first[a.item_ct0[item]], v = a.ctile_first[a.item_ct1[item]];
+	u = min(u, a.n_total); // entries behind the last tuple's tile keep 0xFFFFFFFF
+	v = min(v, a.n_total);
+	int acc = 0;
+	for (uint32_t j = u + lane; j < v; j += kWave) {
+		const int32_t p = a.pos[j];
+		const int m = a.mapq[j];
+		acc += (p >= lo && p < hi && m > a.mq_threshold) ? 1 : 0;
+	}
+	acc = wave_sum_i32(acc);
+	if (lane == 0 && acc)
+		atomicAdd(&a.observed[a.item_iv[item]], acc);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -782,9 +1097,9 @@ __global__ __launch_bounds__(256) void interval_reduce_kernel(ReduceArgs a)
 		return; // wave-uniform
 	const int64_t s = a.item_off[item], e = s + a.item_len[item];
 
-	// ---- depth: int16, 8 per lane
+	// ---- depth: int16, 8 per lane (skipped when the tuple-space formulation counts reads instead)
 	int acc = 0;
-	{
+	if (a.rd) {
 		int64_t head = (s + 7) & ~(int64_t) 7; // first 16-byte aligned index
 		if (head > e)
 			head = e;

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define CONGA_ABI_VERSION 1
+#define CONGA_ABI_VERSION 2
 
 typedef struct conga_ctx conga_ctx;
 
@@ -60,6 +60,15 @@ typedef enum conga_status {
 #define CONGA_FLAG_PROFILE 0x2u        /* bracket every kernel with HIP events; conga_chrom_stats.kernel_ms is filled */
 #define CONGA_FLAG_BATCH 0x4u          /* conga_chrom_begin() ADDS a chromosome instead of replacing the previous one;
                                           conga_chrom_compute() then covers all of them in one launch per kernel */
+#define CONGA_FLAG_MATERIALIZE_DEPTH 0x8u /* always build bam_info.read_depth[] in HBM, the way the reference does
+                                          (the "dense" formulation: 4+ bytes of traffic per BASE).  Without this flag
+                                          the engine works in tuple space whenever that is provably identical --
+                                          read_depth[i] is a count of read starts, so the GC sums are a histogram over
+                                          the kept READS and an interval's observed depth is the number of kept reads
+                                          that start inside it (5 bytes of traffic per READ) -- and builds read_depth[]
+                                          only when conga_copy_read_depth() asks for it.  It switches to the dense
+                                          kernels by itself when the reads may be unsorted or when one base may hold
+                                          more than 32767 read starts (the `short` of common.h:91 would wrap). */
 
 /* SV types, as the reference's DELETION / DUPLICATION (common.h:12-13) */
 #define CONGA_DELETION 'D'
@@ -98,13 +107,15 @@ typedef struct conga_result {
 } conga_result;
 
 enum {
-	CONGA_K_INGEST = 0,   /* sortedness / range check + tile index over the read tuples */
-	CONGA_K_DEPTH,        /* LDS-tiled depth build + GC histogram (K1 + K2) */
+	CONGA_K_INGEST = 0,   /* sortedness / range check + tile index over the read tuples; tuple-space formulation: also
+	                         the read filter and the GC histogram over reads (K1 + K2 without read_depth[]) */
+	CONGA_K_DEPTH,        /* dense formulation: LDS-tiled depth build + GC histogram (K1 + K2) */
 	CONGA_K_EXPECTED,     /* expected_read_depth[101] */
 	CONGA_K_PAINT,        /* mappability paint (K3) */
 	CONGA_K_REDUCE,       /* per-interval integer depth sum + mappability sum (K4, memory side) */
 	CONGA_K_SCORE,        /* serial-float expected chain (short intervals) + likelihoods + CN (K4 chain + K5) */
 	CONGA_K_CHAIN,        /* serial-float expected chain of long intervals, one wave per interval */
+	CONGA_K_COUNT_READS,  /* tuple-space formulation: per-interval count of kept reads (replaces the depth side of K_REDUCE) */
 	CONGA_K_COUNT
 };
 
@@ -123,6 +134,8 @@ typedef struct conga_chrom_stats {
 	int64_t split_mappings;     /* mappings emitted by almostPerfect_match_seq_ref (split_read.c:185-201) */
 	int64_t split_del_rows;     /* SplitRow records of type DELETION (bam_data.c:104-146) */
 	int64_t split_dup_rows;     /* ... of type DUPLICATION */
+	int32_t depth_materialized; /* 1: the last compute built read_depth[] (dense formulation), 0: tuple space */
+	int32_t reserved;
 } conga_chrom_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------- */
@@ -233,7 +246,8 @@ void *conga_stream(conga_ctx *ctx);
 /* Blocks until the context's stream is idle. */
 int conga_sync(conga_ctx *ctx);
 /* Test hooks: copy bam_info.read_depth (int16[chrom_len]) / bam_info.mappability (float[chrom_len])
- * of the last compute back to the host. */
+ * of the last compute back to the host.  After a tuple-space compute conga_copy_read_depth() first builds
+ * read_depth[] from the resident tuples (K0 + K1). */
 int conga_copy_read_depth(conga_ctx *ctx, int16_t *out, int64_t n);
 int conga_copy_mappability(conga_ctx *ctx, float *out, int64_t n);
 

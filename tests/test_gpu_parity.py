@@ -12,6 +12,15 @@ from conga_amd import synth
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["tuple_space", "dense"])
+def formulation(request, capi):
+    """Every case runs twice: in tuple space (the default: no read_depth[] in HBM) and with
+    CONGA_FLAG_MATERIALIZE_DEPTH (the reference's dense formulation).  Results must not differ."""
+    capi.EXTRA_FLAGS = capi.FLAG_MATERIALIZE_DEPTH if request.param == "dense" else 0
+    yield request.param
+    capi.EXTRA_FLAGS = 0
+
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 ATOL = 1e-6  # north_star: "log-likelihoods agree within 1e-6"
 RTOL_SCORE = 1e-6
@@ -73,7 +82,8 @@ def run_gpu(capi, length, gc, pos, mapq, ds, de, us, ue, mq=-1, step=100, rows=N
         ctx.intervals("E", us, ue)
         dels, dups, E, st = ctx.finish()
         out = dict(dels=dels, dups=dups, E=E, counted=st.reads_counted, oor=st.reads_out_of_range,
-                   S=np.array(st.rd_per_gc[:]), W=np.array(st.window_per_gc[:]), mean=st.mean, rd_sum=st.rd_sum)
+                   S=np.array(st.rd_per_gc[:]), W=np.array(st.window_per_gc[:]), mean=st.mean, rd_sum=st.rd_sum,
+                   dense=bool(st.depth_materialized))
         if want_tracks:
             out["rd"] = ctx.read_depth()
             if rows is not None and (len(ds) + len(us)) > 0:
@@ -124,12 +134,13 @@ def test_golden_fixture(capi):
     ("6", 3_000_017, dict(cov=30.0, n_dels=50, n_dups=12, gaps=True), 0, False),
     ("8", 99_999, dict(cov=0.5, n_dels=10, n_dups=3), 59, False),
 ])
-def test_random_chromosomes(capi, oracle, name, length, kw, mq, with_map):
+def test_random_chromosomes(capi, oracle, formulation, name, length, kw, mq, with_map):
     c, ds, de, us, ue = chrom_case(name, length, **kw)
     rows = (c.map_start, c.map_end, c.map_val) if with_map else None
     want = run_oracle(oracle, c.length, c.gc, c.pos, c.mapq, ds, de, us, ue, mq=mq, rows=rows)
     got = run_gpu(capi, c.length, c.gc, c.pos, c.mapq, ds, de, us, ue, mq=mq, rows=rows)
     compare(got, want, with_map)
+    assert got["dense"] == (formulation == "dense")
 
 
 @pytest.mark.parametrize("step", [1, 7, 64, 100, 128, 1000])
@@ -197,6 +208,43 @@ def test_pileup_wraps_like_a_short(capi, oracle):
     got = run_gpu(capi, c.length, c.gc, pos, mapq, ds, de, us, ue)
     assert want["rd"][60_001] == np.int16(70_000 + int((c.pos == 60_001).sum()) - 65536)
     compare(got, want, False)
+    assert got["dense"], "a possible `short` wrap must send the batch to the dense kernels"
+
+
+def test_pileup_straddling_two_commits_is_still_detected(capi, oracle):
+    """33000 reads on one base, 14304 of them at the end of the first 4M-tuple commit and the rest in the next:
+    neither part alone looks like a wrap, the run carried across the commit does."""
+    L = 6_000_000
+    rng = np.random.default_rng(77)
+    n_before = (1 << 22) - 14_304
+    before = np.sort(rng.integers(0, 3_000_000, n_before)).astype(np.int32)
+    after = np.sort(rng.integers(3_000_001, L, 500_000)).astype(np.int32)
+    pos = np.concatenate([before, np.full(33_000, 3_000_000, np.int32), after])
+    mapq = np.full(len(pos), 60, np.uint8)
+    gc = synth.make_gc_track(L, rng, gaps=False)
+    ds = np.array([2_990_000, 10_000, 2_999_999], np.int32)
+    de = np.array([3_010_000, 2_000_000, 3_000_002], np.int32)
+    ds, de = synth.kept_sorted(ds, de, min_sv_size=0)
+    us, ue = np.zeros(0, np.int32), np.zeros(0, np.int32)
+    want = run_oracle(oracle, L, gc, pos, mapq, ds, de, us, ue)
+    got = run_gpu(capi, L, gc, pos, mapq, ds, de, us, ue)
+    assert want["rd"][3_000_000] == np.int16(33_000 - 65536)
+    compare(got, want, False)
+    assert got["dense"]
+
+
+def test_deep_pileup_below_the_wrap_stays_exact(capi, oracle, formulation):
+    """30000 reads on one base (no wrap, below the detector's threshold): both formulations agree with the oracle."""
+    c, ds, de, us, ue = chrom_case("14", 120_000, cov=2.0, n_dels=10, n_dups=2, gaps=False)
+    pos = np.sort(np.concatenate([c.pos, np.full(30_000, 70_001, np.int32)]), kind="stable")
+    mapq = np.full(len(pos), 60, np.uint8)
+    ds = np.concatenate([ds, [69_000, 70_001, 70_002]]).astype(np.int32)
+    de = np.concatenate([de, [71_500, 70_002, 70_500]]).astype(np.int32)
+    ds, de = synth.kept_sorted(ds, de, min_sv_size=0)
+    want = run_oracle(oracle, c.length, c.gc, pos, mapq, ds, de, us, ue)
+    got = run_gpu(capi, c.length, c.gc, pos, mapq, ds, de, us, ue)
+    compare(got, want, False)
+    assert got["dense"] == (formulation == "dense")
 
 
 def test_out_of_range_reads_are_skipped_and_counted(capi, oracle):
@@ -219,6 +267,7 @@ def test_unsorted_reads_fail_loudly_or_take_the_atomic_path(capi, oracle):
     want = run_oracle(oracle, c.length, c.gc, pos, mapq, ds, de, us, ue, mq=10)
     got = run_gpu(capi, c.length, c.gc, pos, mapq, ds, de, us, ue, mq=10, flags=capi.FLAG_READS_UNSORTED)
     compare(got, want, False)
+    assert got["dense"]
 
 
 def test_streaming_commits_larger_than_the_staging_ring(capi, oracle):
@@ -274,7 +323,11 @@ def test_replay_is_idempotent_and_split_support_is_copied_through(capi, oracle):
         assert first[0].tobytes() == second[0].tobytes() and first[1].tobytes() == second[1].tobytes()
         assert np.array_equal(first[0]["border_rp"], np.arange(len(ds))) and np.all(first[0]["rp"] == 0)
         assert np.array_equal(first[1]["rp"], np.arange(len(us)) * 3) and np.all(first[1]["border_rp"] == 0)
-        assert second[3].kernel_ms[1] > 0  # depth_tile was timed
+        k = second[3].kernel_ms
+        if capi.EXTRA_FLAGS & capi.FLAG_MATERIALIZE_DEPTH:
+            assert k[1] > 0 and k[4] > 0 and k[7] == 0  # depth_tile and interval_reduce were timed
+        else:
+            assert k[0] > 0 and k[7] > 0 and k[1] == 0  # ingest (tuples) and interval_count were timed
         # a second chromosome on the same context starts from clean state
         ctx.chrom_begin(c.length, c.gc)
         ctx.reads(c.pos[:1000], c.mapq[:1000])
