@@ -1332,18 +1332,11 @@ int conga_chrom_compute(conga_ctx *ctx)
 			c.small = small;
 			c.step = ctx->step;
 			c.expected = ptr<float>(ctx->d_expected);
-			if (ctx->n_long > 0) {
-				c.first = 0;
-				c.count = ctx->n_long;
-				const int grid = (int) ((ctx->n_long + 3) / 4); // one wave per interval, 4 waves per block
-				hipLaunchKernelGGL(interval_chain_kernel<64>, dim3(grid), dim3(256), 0, st, c);
-			}
-			if (ctx->n_iv > ctx->n_long) {
-				c.first = ctx->n_long;
-				c.count = ctx->n_iv - ctx->n_long;
-				const int grid = (int) ((c.count + 15) / 16); // four 16-lane groups per wave
-				hipLaunchKernelGGL(interval_chain_kernel<16>, dim3(grid), dim3(256), 0, st, c);
-			}
+			c.n_long = ctx->n_long;
+			c.n_iv = ctx->n_iv;
+			c.long_blocks = (int32_t) ((ctx->n_long + 3) / 4); // one wave per long interval, 4 waves per block
+			const int short_blocks = (int) ((ctx->n_iv - ctx->n_long + 15) / 16); // four 16-lane groups per wave
+			hipLaunchKernelGGL(interval_chain_kernel, dim3(c.long_blocks + short_blocks), dim3(256), 0, st, c);
 		}
 		if (fork)
 			HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));

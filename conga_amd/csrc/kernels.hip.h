@@ -1167,8 +1167,9 @@ struct ChainArgs {
 	const int32_t *end;
 	const int32_t *iv_slot;
 	const int32_t *order; // interval ids, longest first
-	int64_t first;        // slots [first, first + count) of order[] belong to this launch
-	int64_t count;
+	int64_t n_long;       // order[0 .. n_long): one wave each (workgroups [0, long_blocks))
+	int64_t n_iv;         // order[n_long .. n_iv): one 16-lane group each (the remaining workgroups)
+	int32_t long_blocks;
 	const uint8_t *gc_like;
 	const Slot *slots;
 	const Small *small;
@@ -1204,31 +1205,32 @@ __device__ __forceinline__ float compose_f32(uint32_t es, uint32_t ms)
 	return (ms == 0x1000000u) ? conga_bits_f32((es + 1u) << 23) : conga_bits_f32((es << 23) | (ms & 0x7FFFFFu));
 }
 
-template <int G> __global__ __launch_bounds__(256) void interval_chain_kernel(ChainArgs a)
+constexpr int kChainTableWords = (256 / 16) * (kGcBins + 3); // one expected_read_depth table per lane group
+constexpr int kChainGcBytes = 256 * 2 * 16;                  // per lane group: two chunks of G * 16 windows
+
+template <int G> __device__ __forceinline__ void interval_chain_body(const ChainArgs &a, int64_t block, int64_t first,
+		int64_t count, float *sE_raw, uint8_t *sGc_raw)
 {
 	constexpr int kGroups = kWave / G;
-	constexpr int kBlockGroups = 256 / G;
 	// GC bytes are staged through LDS in 16-byte pieces: a whole short interval at once (G = 16: 256 windows), or
 	// double-buffered 1 KiB chunks fetched one chunk (16 steps) ahead (G = 64), so that no step waits on HBM
 	constexpr int kChunk = G * 16; // windows per staged chunk
-	__shared__ float sE[kBlockGroups][kGcBins + 3]; // one expected_read_depth table per lane group
-	__shared__ __attribute__((aligned(16))) uint8_t sGc[kBlockGroups][2][kChunk];
 
 	const int lane = threadIdx.x & (kWave - 1);
 	const int gl = lane & (G - 1);  // lane inside the group
 	const int grp = lane / G;       // group inside the wave
 	const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << (grp * G));
-	const int64_t wave = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+	const int64_t wave = (block * blockDim.x + threadIdx.x) / kWave;
 	const int64_t slot_idx = wave * kGroups + grp;
-	const bool have = slot_idx < a.count;
-	float *E = sE[threadIdx.x / G];
-	uint8_t(*gcbuf)[kChunk] = sGc[threadIdx.x / G];
+	const bool have = slot_idx < count;
+	float *E = sE_raw + (threadIdx.x / G) * (kGcBins + 3);
+	uint8_t(*gcbuf)[kChunk] = reinterpret_cast<uint8_t(*)[kChunk]>(sGc_raw + (size_t) (threadIdx.x / G) * 2 * kChunk);
 
 	int32_t iv = 0;
 	int64_t s0 = 0, e0 = 0, w_first = 0, w_end = 0, n_win = 1;
 	const uint8_t *gc = a.gc_like;
 	if (have) {
-		iv = a.order[a.first + slot_idx];
+		iv = a.order[first + slot_idx];
 		s0 = a.start[iv];
 		e0 = a.end[iv];
 		const int sl = a.iv_slot[iv];
@@ -1336,6 +1338,17 @@ template <int G> __global__ __launch_bounds__(256) void interval_chain_kernel(Ch
 	}
 	if (have && gl == 0)
 		a.expected[iv] = s;
+}
+
+// One launch for both classes, so the few long chains (one wave each, latency-bound) run beside the many short ones.
+__global__ __launch_bounds__(256) void interval_chain_kernel(ChainArgs a)
+{
+	__shared__ float sE[kChainTableWords];
+	__shared__ __attribute__((aligned(16))) uint8_t sGc[kChainGcBytes];
+	if ((int) blockIdx.x < a.long_blocks)
+		interval_chain_body<64>(a, (int64_t) blockIdx.x, 0, a.n_long, sE, sGc);
+	else
+		interval_chain_body<16>(a, (int64_t) blockIdx.x - a.long_blocks, a.n_long, a.n_iv - a.n_long, sE, sGc);
 }
 
 // -------------------------------------------------------------------------------------------
