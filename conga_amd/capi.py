@@ -39,7 +39,7 @@ EXPORTS = (
     "conga_split_reads_commit", "conga_split_support", "conga_chrom_compute",
     "conga_chrom_fetch", "conga_chrom_finish", "conga_results_device", "conga_results_copy",
     "conga_set_profile", "conga_stream", "conga_sync",
-    "conga_copy_read_depth", "conga_copy_mappability", "conga_host_repeat_add_f32",
+    "conga_copy_read_depth", "conga_copy_mappability", "conga_host_repeat_add_f32", "conga_host_window_add_f32",
 )
 
 
@@ -154,6 +154,8 @@ def load():
     L.conga_copy_mappability.argtypes = [vp, vp, i64]
     L.conga_host_repeat_add_f32.restype = C.c_float
     L.conga_host_repeat_add_f32.argtypes = [C.c_float, C.c_float, C.c_uint32]
+    L.conga_host_window_add_f32.restype = C.c_float
+    L.conga_host_window_add_f32.argtypes = [C.c_float, C.c_float, C.c_uint32]
     _lib = L
     return L
 
@@ -367,4 +369,10 @@ class Context:
 
 
 def host_repeat_add_f32(s, c, k):
-    return np.float32(load().conga_host_repeat_add_f32(C.c_float(float(s)), C.c_float(float(c)), int(k)))
+    """Both host builds of the fast-forward (the general routine and the per-window one the chain kernels call)
+    must agree; returns their common value."""
+    a = np.float32(load().conga_host_repeat_add_f32(C.c_float(float(s)), C.c_float(float(c)), int(k)))
+    b = np.float32(load().conga_host_window_add_f32(C.c_float(float(s)), C.c_float(float(c)), int(k)))
+    if a.view(np.uint32) != b.view(np.uint32) and not (np.isnan(a) and np.isnan(b)):
+        raise AssertionError("conga_window_add_f32 %r != conga_repeat_add_f32 %r for s=%r c=%r k=%d" % (b, a, s, c, k))
+    return a

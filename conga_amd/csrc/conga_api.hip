@@ -61,7 +61,6 @@ struct HostSlot {
 	int64_t ref_off = 0, sat_off = 0;
 	// filled by prepare()
 	int64_t rd_off = 0, gc_off = 0, tile0 = 0, tidx_off = 0, iv0 = 0, map_row_off = 0, row_tile_off = 0;
-	int64_t ctile0 = 0, n_ctiles = 0;
 };
 
 } // namespace
@@ -72,7 +71,7 @@ struct conga_ctx {
 	int depth_blocks_per_cu = 8; // resident depth_tile workgroups per CU (occupancy query)
 	hipStream_t stream = nullptr;
 	hipStream_t stream2 = nullptr; // runs interval_reduce beside the float chain (both are latency-bound)
-	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join = nullptr;
 	conga_opts opts{};
 	std::string err;
 
@@ -85,20 +84,19 @@ struct conga_ctx {
 	int64_t n_reads_total = 0;
 	bool wrap_risk = false;      // some position may hold more than 32767 reads: only the dense kernels reproduce the `short` wrap
 	bool depth_resident = false; // read_depth[] of the last compute is in d_rd
-	int32_t ctile_shift = 14;    // coarse tuple-index tiles of the tuple-space formulation: 2^shift positions
 	Staging staging[kStagingRing];
 	int staging_next = 0; // buffer the next conga_reads_staging() hands out
 	int staging_cur = -1; // buffer handed out and not yet committed
 
 	// layout totals (prepare)
-	int64_t total_L = 0, total_tiles = 0, total_ctiles = 0, total_gc = 0, n_iv = 0, n_items = 0, n_long = 0, n_depth_blocks = 0;
+	int64_t total_L = 0, total_tiles = 0, total_gc = 0, n_iv = 0, n_items = 0, n_chain_a = 0, n_chain_b = 0, n_depth_blocks = 0;
 	bool gc_like_distinct = false, any_map = false, support_given = false, any_sr = false;
 	int64_t n_sr_total = 0, sr_bytes_total = 0;
 	conga_split_staging sr_stage{}; // one pinned set (the split-read path is not the bench line)
 	bool sr_staged = false;
 
 	// device buffers
-	DevBuf d_pos, d_mapq, d_tile_start, d_ctile, d_small_scratch, d_item_ct0, d_item_ct1, d_item_lo, d_rd, d_gc_hist, d_gc_like, d_slots, d_small, d_map, d_winner,
+	DevBuf d_pos, d_mapq, d_tile_start, d_small_scratch, d_item_r0, d_item_r1, d_item_lo, d_rd, d_gc_hist, d_gc_like, d_slots, d_small, d_map, d_winner,
 			d_map_start, d_map_end, d_map_val, d_iv_start, d_iv_end, d_iv_type, d_iv_slot, d_iv_has_map, d_order,
 			d_observed, d_expected, d_item_off, d_item_len, d_item_iv, d_item_has_map, d_item_first, d_map_part,
 			d_support, d_results, d_bases, d_row_tile, d_depth_blocks, d_support_base, d_ref, d_sat_start, d_sat_end, d_sr_pos,
@@ -111,6 +109,9 @@ struct conga_ctx {
 	size_t h_results_cap = 0;
 
 	bool computed = false;
+	hipGraphExec_t graph_exec = nullptr; // the captured step; dropped whenever the layout changes
+	bool graph_dense = false;
+	int computes_on_layout = 0;          // computes since the layout last changed
 	hipEvent_t ev_done = nullptr;
 	hipEvent_t ev_k0[CONGA_K_COUNT] = {}, ev_k1[CONGA_K_COUNT] = {};
 	bool ev_used[CONGA_K_COUNT] = {};
@@ -123,6 +124,16 @@ int fail(conga_ctx *ctx, int status, const std::string &msg)
 	if (ctx)
 		ctx->err = msg;
 	return status;
+}
+
+int enqueue_compute(conga_ctx *ctx, bool dense);
+
+void drop_graph(conga_ctx *ctx)
+{
+	if (ctx->graph_exec)
+		(void) hipGraphExecDestroy(ctx->graph_exec);
+	ctx->graph_exec = nullptr;
+	ctx->computes_on_layout = 0;
 }
 
 #define HIP_TRY(ctx, call)                                                                              \
@@ -204,10 +215,10 @@ bool batch_mode(const conga_ctx *ctx)
 int prepare(conga_ctx *ctx)
 {
 	const int n_slots = (int) ctx->slots.size();
+	drop_graph(ctx); // buffers, sizes and grids below are baked into the captured step
 
 	// ---- geometry
-	int64_t rd_off = 0, gc_off = 0, tile0 = 0, ctile0 = 0, iv0 = 0, map_rows = 0;
-	const int64_t ctile_len = (int64_t) 1 << ctx->ctile_shift;
+	int64_t rd_off = 0, gc_off = 0, tile0 = 0, iv0 = 0, map_rows = 0;
 	ctx->gc_like_distinct = false;
 	ctx->any_map = false;
 	ctx->support_given = false;
@@ -218,8 +229,6 @@ int prepare(conga_ctx *ctx)
 		h.gc_off = gc_off;
 		h.tile0 = tile0;
 		h.tidx_off = tile0 + s;
-		h.ctile0 = ctile0;
-		h.n_ctiles = (h.L + ctile_len - 1) / ctile_len;
 		h.iv0 = iv0;
 		h.map_row_off = map_rows;
 		Slot &d = dslots[s];
@@ -232,9 +241,6 @@ int prepare(conga_ctx *ctx)
 		d.tile0 = h.tile0;
 		d.n_tiles = h.n_tiles;
 		d.tidx_off = h.tidx_off;
-		d.ctile0 = h.ctile0;
-		d.n_ctiles = h.n_ctiles;
-		ctile0 += h.n_ctiles;
 		rd_off += (h.L + kDepthMaxTile - 1) & ~(int64_t) (kDepthMaxTile - 1); // whole tiles: 4 KiB-aligned regions
 		gc_off += (h.n_win + 15) & ~(int64_t) 15;
 		tile0 += h.n_tiles;
@@ -250,7 +256,6 @@ int prepare(conga_ctx *ctx)
 	ctx->total_L = rd_off;
 	ctx->total_gc = gc_off;
 	ctx->total_tiles = tile0;
-	ctx->total_ctiles = ctile0;
 	ctx->n_iv = iv0;
 
 	TRY(upload(ctx, ctx->d_slots, dslots.data(), dslots.size() * sizeof(Slot)));
@@ -275,7 +280,6 @@ int prepare(conga_ctx *ctx)
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	}
 	TRY(ensure(ctx, ctx->d_small, std::max<size_t>(n_slots, 1) * sizeof(Small)));
-	TRY(ensure(ctx, ctx->d_ctile, ((size_t) ctx->total_ctiles + 2) * 4));
 	// d_rd / d_tile_start (6 GB for a human genome) are allocated by the first compute that materialises read_depth
 	if ((size_t) n_slots > ctx->h_small_cap) {
 		if (ctx->h_small)
@@ -395,7 +399,8 @@ int prepare(conga_ctx *ctx)
 	// ---- intervals: slot order, dels then dups inside a slot
 	const size_t n = (size_t) ctx->n_iv;
 	ctx->n_items = 0;
-	ctx->n_long = 0;
+	ctx->n_chain_a = 0;
+	ctx->n_chain_b = 0;
 	if (n > 0) {
 		std::vector<int32_t> start(n), end(n), iv_slot(n), order(n), item_first(n + 1), support;
 		std::vector<uint8_t> type(n), iv_has_map(n);
@@ -415,17 +420,28 @@ int prepare(conga_ctx *ctx)
 		for (size_t i = 0; i < n; i++)
 			n_windows[i] = (end[i] <= start[i]) ? 0
 					: (int32_t) (((int64_t) end[i] - 1) / ctx->step - (int64_t) start[i] / ctx->step + 1);
-		// longest chains first: the groups of a wave in interval_chain_kernel then retire together, and
-		// the first n_long entries are the intervals that get a whole wave
+		// longest chains first: the lanes / groups of a wave in interval_chain_kernel then retire together, and the
+		// three classes of that kernel are contiguous ranges of order[]
 		std::iota(order.begin(), order.end(), 0);
 		std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return n_windows[x] > n_windows[y]; });
-		while ((size_t) ctx->n_long < n && n_windows[order[ctx->n_long]] > kLongWindows)
-			ctx->n_long++;
+		int32_t long_min = kChainLongWindows, serial_max = kChainSerialWindows;
+		if (const char *e = getenv("CONGA_CHAIN_LONG_WINDOWS")) // tuning knobs
+			long_min = std::max(1, atoi(e));
+		if (const char *e = getenv("CONGA_CHAIN_SERIAL_WINDOWS"))
+			serial_max = std::max(0, atoi(e));
+		size_t na = 0;
+		while (na < n && n_windows[order[na]] > long_min)
+			na++;
+		size_t nb = na;
+		while (nb < n && n_windows[order[nb]] > serial_max)
+			nb++;
+		ctx->n_chain_a = (int64_t) na;
+		ctx->n_chain_b = (int64_t) (nb - na);
 
 		// reduce work items: [start, min(end, L)) cut into kItemLen pieces
 		std::vector<int64_t> item_off;
 		std::vector<int32_t> item_len, item_iv, item_lo;
-		std::vector<uint32_t> item_ct0, item_ct1;
+		std::vector<uint32_t> item_r0, item_r1;
 		std::vector<uint8_t> item_has_map;
 		item_off.reserve(n + n / 2);
 		item_len.reserve(n + n / 2);
@@ -440,10 +456,9 @@ int prepare(conga_ctx *ctx)
 				item_len.push_back((int32_t) std::min<int64_t>(kItemLen, e - a));
 				item_iv.push_back((int32_t) i);
 				item_has_map.push_back(iv_has_map[i]);
-				const int64_t b = std::min<int64_t>(a + kItemLen, e); // a < b <= L
 				item_lo.push_back((int32_t) a);
-				item_ct0.push_back((uint32_t) (h.ctile0 + (a >> ctx->ctile_shift)));
-				item_ct1.push_back((uint32_t) (h.ctile0 + ((b - 1) >> ctx->ctile_shift) + 1));
+				item_r0.push_back((uint32_t) h.read_off);
+				item_r1.push_back((uint32_t) (h.read_off + h.n_reads));
 			}
 		}
 		item_first[n] = (int32_t) item_off.size();
@@ -461,8 +476,8 @@ int prepare(conga_ctx *ctx)
 		TRY(upload(ctx, ctx->d_item_iv, item_iv.data(), item_iv.size() * 4));
 		TRY(upload(ctx, ctx->d_item_has_map, item_has_map.data(), item_has_map.size()));
 		TRY(upload(ctx, ctx->d_item_lo, item_lo.data(), item_lo.size() * 4));
-		TRY(upload(ctx, ctx->d_item_ct0, item_ct0.data(), item_ct0.size() * 4));
-		TRY(upload(ctx, ctx->d_item_ct1, item_ct1.data(), item_ct1.size() * 4));
+		TRY(upload(ctx, ctx->d_item_r0, item_r0.data(), item_r0.size() * 4));
+		TRY(upload(ctx, ctx->d_item_r1, item_r1.data(), item_r1.size() * 4));
 		TRY(ensure(ctx, ctx->d_observed, n * 4));
 		TRY(ensure(ctx, ctx->d_expected, n * 4));
 		TRY(ensure(ctx, ctx->d_map_part, std::max<size_t>(item_off.size(), 1) * 8));
@@ -656,6 +671,11 @@ float conga_host_repeat_add_f32(float s, float c, uint32_t k)
 	return conga_repeat_add_f32(s, c, k);
 }
 
+float conga_host_window_add_f32(float s, float c, uint32_t k)
+{
+	return conga_window_add_f32(s, c, k);
+}
+
 conga_ctx *conga_create(int device, const conga_opts *opts, int *status)
 {
 	int st_dummy;
@@ -732,6 +752,7 @@ conga_ctx *conga_create(int device, const conga_opts *opts, int *status)
 		return bail(CONGA_ERR_HIP);
 	if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess
 			|| hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess
+			|| hipEventCreateWithFlags(&ctx->ev_fork2, hipEventDisableTiming) != hipSuccess
 			|| hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess)
 		return bail(CONGA_ERR_HIP);
 	for (int k = 0; k < CONGA_K_COUNT; k++)
@@ -748,16 +769,19 @@ void conga_destroy(conga_ctx *ctx)
 	(void) hipSetDevice(ctx->device);
 	if (ctx->stream)
 		(void) hipStreamSynchronize(ctx->stream);
+	drop_graph(ctx);
 	if (ctx->stream2) {
 		(void) hipStreamSynchronize(ctx->stream2);
 		(void) hipStreamDestroy(ctx->stream2);
 	}
 	if (ctx->ev_fork)
 		(void) hipEventDestroy(ctx->ev_fork);
+	if (ctx->ev_fork2)
+		(void) hipEventDestroy(ctx->ev_fork2);
 	if (ctx->ev_join)
 		(void) hipEventDestroy(ctx->ev_join);
-	DevBuf *bufs[] = {&ctx->d_pos, &ctx->d_mapq, &ctx->d_tile_start, &ctx->d_ctile, &ctx->d_small_scratch, &ctx->d_item_ct0,
-			&ctx->d_item_ct1, &ctx->d_item_lo, &ctx->d_rd, &ctx->d_gc_hist, &ctx->d_gc_like,
+	DevBuf *bufs[] = {&ctx->d_pos, &ctx->d_mapq, &ctx->d_tile_start, &ctx->d_small_scratch, &ctx->d_item_r0,
+			&ctx->d_item_r1, &ctx->d_item_lo, &ctx->d_rd, &ctx->d_gc_hist, &ctx->d_gc_like,
 			&ctx->d_slots, &ctx->d_small, &ctx->d_map, &ctx->d_winner, &ctx->d_map_start, &ctx->d_map_end,
 			&ctx->d_map_val, &ctx->d_iv_start, &ctx->d_iv_end, &ctx->d_iv_type, &ctx->d_iv_slot, &ctx->d_iv_has_map,
 			&ctx->d_order, &ctx->d_observed, &ctx->d_expected, &ctx->d_item_off, &ctx->d_item_len, &ctx->d_item_iv,
@@ -1118,23 +1142,112 @@ int conga_chrom_compute(conga_ctx *ctx)
 		TRY(ensure(ctx, ctx->d_pos, 256));
 		TRY(ensure(ctx, ctx->d_mapq, 256));
 	}
+	// Formulation: tuple-space unless read_depth[] was asked for, the reads may be unsorted, or a `short` may wrap.
+	const bool unsorted_mode = (ctx->opts.flags & CONGA_FLAG_READS_UNSORTED) != 0;
+	const bool dense = unsorted_mode || (ctx->opts.flags & CONGA_FLAG_MATERIALIZE_DEPTH) != 0 || ctx->wrap_risk;
+	if (dense) { // nothing may be allocated while the launches are being captured
+		TRY(ensure(ctx, ctx->d_rd, std::max<size_t>((size_t) ctx->total_L, 8) * 2));
+		if (!unsorted_mode)
+			TRY(ensure(ctx, ctx->d_tile_start, ((size_t) ctx->total_tiles + 2) * 4));
+	}
+	for (int k = 0; k < CONGA_K_COUNT; k++)
+		ctx->ev_used[k] = false;
 
+	// The step is a fixed sequence of small launches on the same resident buffers.  With CONGA_GRAPH=1 in the
+	// environment it is captured into a hipGraph on the third compute of an unchanged layout and replayed from then
+	// on.  Off by default: on ROCm 7.2 / MI355X the replay was measured no faster than the two-stream launch sequence
+	// (0.275 vs 0.268 ms per genome), and instantiation costs tens of milliseconds.
+	hipStream_t st = ctx->stream;
+	ctx->computes_on_layout++;
+	const bool use_graph = (ctx->opts.flags & CONGA_FLAG_PROFILE) == 0 && getenv("CONGA_GRAPH")
+			&& (ctx->graph_exec || ctx->computes_on_layout >= 3);
+	if (!use_graph)
+		TRY(enqueue_compute(ctx, dense));
+	else {
+		if (!ctx->graph_exec || ctx->graph_dense != dense) {
+			drop_graph(ctx);
+			hipGraph_t graph = nullptr;
+			HIP_TRY(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+			const int rc = enqueue_compute(ctx, dense);
+			const hipError_t e = hipStreamEndCapture(st, &graph);
+			if (rc != CONGA_OK || e != hipSuccess || !graph) {
+				if (graph)
+					(void) hipGraphDestroy(graph);
+				(void) hipGetLastError();
+				return rc != CONGA_OK ? rc : fail(ctx, CONGA_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+			}
+			const hipError_t ei = hipGraphInstantiate(&ctx->graph_exec, graph, nullptr, nullptr, 0);
+			(void) hipGraphDestroy(graph);
+			if (ei != hipSuccess) {
+				ctx->graph_exec = nullptr;
+				return fail(ctx, CONGA_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei));
+			}
+			ctx->graph_dense = dense;
+		}
+		HIP_TRY(ctx, hipGraphLaunch(ctx->graph_exec, st));
+	}
+	ctx->depth_resident = dense;
+	HIP_TRY(ctx, hipEventRecord(ctx->ev_done, st));
+	HIP_TRY(ctx, hipGetLastError());
+	ctx->computed = true;
+	return CONGA_OK;
+}
+
+} // extern "C"
+
+namespace {
+
+// Every launch of one compute, in order, on ctx->stream (and ctx->stream2 for the forked interval count / reduce).
+// Allocates nothing, waits for nothing: it can run under stream capture.
+int enqueue_compute(conga_ctx *ctx, bool dense)
+{
 	hipStream_t st = ctx->stream;
 	const int n_slots = (int) ctx->slots.size();
 	Small *small = ptr<Small>(ctx->d_small);
 	const Slot *dslots = ptr<Slot>(ctx->d_slots);
 	const uint8_t *gc_like = ctx->gc_like_distinct ? ptr<uint8_t>(ctx->d_gc_like) : ptr<uint8_t>(ctx->d_gc_hist);
 	const bool unsorted_mode = (ctx->opts.flags & CONGA_FLAG_READS_UNSORTED) != 0;
-	for (int k = 0; k < CONGA_K_COUNT; k++)
-		ctx->ev_used[k] = false;
 
 	HIP_TRY(ctx, hipMemsetAsync(small, 0, (size_t) n_slots * sizeof(Small), st));
+	// The Small blocks are final after expected_table unless split-read kernels add their counters later: that
+	// kernel then writes the pinned host copy itself (pinned host memory is device-visible) and the copy at the end goes away.
+	const bool small_by_kernel = !(ctx->any_sr && ctx->n_iv > 0);
+	// Scoring inside the chain kernel: possible when nothing the score needs is produced beside the chain.
+	const bool fused_score = !dense && !ctx->any_map && ctx->n_iv > 0;
 
-	// Formulation: tuple-space unless read_depth[] was asked for, the reads may be unsorted, or a `short` may wrap.
-	const bool dense = unsorted_mode || (ctx->opts.flags & CONGA_FLAG_MATERIALIZE_DEPTH) != 0 || ctx->wrap_risk;
-	ctx->depth_resident = false;
+	// Second stream: work that does not depend on the main chain of kernels.  With per-kernel timing on
+	// (CONGA_FLAG_PROFILE) everything stays on one stream so the event pairs bracket one kernel each.
+	const bool two_streams = (ctx->opts.flags & CONGA_FLAG_PROFILE) == 0;
+	bool forked = false, observed_zeroed = false;
+	if (!dense && ctx->n_iv > 0 && ctx->n_items > 0) {
+		// tuple space: the per-interval read counts need nothing but the tuples, so they run beside ingest_tuples
+		hipStream_t sc = st;
+		if (two_streams) {
+			HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
+			HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+			sc = ctx->stream2;
+			forked = true;
+		}
+		HIP_TRY(ctx, hipMemsetAsync(ctx->d_observed.p, 0, (size_t) ctx->n_iv * 4, sc));
+		observed_zeroed = true;
+		KernelTimer t(ctx, CONGA_K_COUNT_READS);
+		CountArgs a;
+		a.pos = ptr<int32_t>(ctx->d_pos);
+		a.mapq = ptr<uint8_t>(ctx->d_mapq);
+		a.item_r0 = ptr<uint32_t>(ctx->d_item_r0);
+		a.item_r1 = ptr<uint32_t>(ctx->d_item_r1);
+		a.item_lo = ptr<int32_t>(ctx->d_item_lo);
+		a.item_len = ptr<int32_t>(ctx->d_item_len);
+		a.item_iv = ptr<int32_t>(ctx->d_item_iv);
+		a.n_items = ctx->n_items;
+		a.mq_threshold = ctx->opts.mq_threshold;
+		a.observed = ptr<int32_t>(ctx->d_observed);
+		const int grid = (int) ((ctx->n_items + 255) / 256);
+		if (ctx->n_reads_total > 0)
+			hipLaunchKernelGGL(interval_count_kernel, dim3(grid), dim3(256), 0, sc, a);
+	}
+
 	if (!dense) {
-		HIP_TRY(ctx, hipMemsetAsync(ctx->d_ctile.p, 0xFF, ((size_t) ctx->total_ctiles + 2) * 4, st));
 		KernelTimer t(ctx, CONGA_K_INGEST);
 		if (ctx->n_reads_total > 0) {
 			TupleArgs a;
@@ -1145,8 +1258,6 @@ int conga_chrom_compute(conga_ctx *ctx)
 			a.n_slots = n_slots;
 			a.gc_hist = ptr<uint8_t>(ctx->d_gc_hist);
 			a.step = ctx->step;
-			a.tile_shift = ctx->ctile_shift;
-			a.ctile_first = ptr<uint32_t>(ctx->d_ctile);
 			a.mq_threshold = ctx->opts.mq_threshold;
 			a.small = small;
 			a.n_chunks = (uint32_t) ((ctx->n_reads_total + kTupleChunk - 1) / kTupleChunk);
@@ -1159,10 +1270,7 @@ int conga_chrom_compute(conga_ctx *ctx)
 		}
 	} else if (!unsorted_mode) {
 		TRY(launch_dense_depth(ctx, small, true));
-		ctx->depth_resident = true;
 	} else {
-		TRY(ensure(ctx, ctx->d_rd, std::max<size_t>((size_t) ctx->total_L, 8) * 2));
-		ctx->depth_resident = true;
 		KernelTimer t(ctx, CONGA_K_DEPTH);
 		HIP_TRY(ctx, hipMemsetAsync(ctx->d_rd.p, 0, (size_t) ctx->total_L * 2, st));
 		for (int s = 0; s < n_slots; s++) {
@@ -1183,7 +1291,7 @@ int conga_chrom_compute(conga_ctx *ctx)
 	{
 		KernelTimer t(ctx, CONGA_K_EXPECTED);
 		hipLaunchKernelGGL(expected_table_kernel, dim3(n_slots), dim3(128), 0, st, small,
-				ptr<unsigned long long>(ctx->d_bases));
+				ptr<unsigned long long>(ctx->d_bases), small_by_kernel ? ctx->h_small : (Small *) nullptr);
 	}
 
 	// the reference paints the track only when the chromosome has at least one kept SV
@@ -1271,38 +1379,19 @@ int conga_chrom_compute(conga_ctx *ctx)
 	}
 
 	if (ctx->n_iv > 0) {
-		// interval_reduce needs read_depth (and the painted track); the float chain needs only the depth table:
-		// they run side by side on two streams and meet again in front of interval_score.  With per-kernel
-		// timing on (CONGA_FLAG_PROFILE) everything stays on one stream so the event pairs bracket one kernel each.
-		const bool fork = ctx->n_items > 0 && (ctx->opts.flags & CONGA_FLAG_PROFILE) == 0;
+		// interval_reduce needs read_depth and / or the painted track; the float chain needs only the depth table:
+		// they run side by side on two streams and meet again in front of interval_score.
 		hipStream_t st_reduce = st;
-		if (fork) {
-			HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
-			HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+		const bool reduce = ctx->n_items > 0 && (dense || ctx->any_map);
+		if (reduce && two_streams) {
+			HIP_TRY(ctx, hipEventRecord(ctx->ev_fork2, st));
+			HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork2, 0));
 			st_reduce = ctx->stream2;
+			forked = true;
 		}
-		HIP_TRY(ctx, hipMemsetAsync(ctx->d_observed.p, 0, (size_t) ctx->n_iv * 4, st_reduce));
-		if (ctx->n_items > 0 && !dense) {
-			KernelTimer t(ctx, CONGA_K_COUNT_READS);
-			CountArgs a;
-			a.pos = ptr<int32_t>(ctx->d_pos);
-			a.mapq = ptr<uint8_t>(ctx->d_mapq);
-			a.n_total = (uint32_t) ctx->n_reads_total;
-			a.ctile_first = ptr<uint32_t>(ctx->d_ctile);
-			a.item_ct0 = ptr<uint32_t>(ctx->d_item_ct0);
-			a.item_ct1 = ptr<uint32_t>(ctx->d_item_ct1);
-			a.item_lo = ptr<int32_t>(ctx->d_item_lo);
-			a.item_len = ptr<int32_t>(ctx->d_item_len);
-			a.item_iv = ptr<int32_t>(ctx->d_item_iv);
-			a.n_items = ctx->n_items;
-			a.mq_threshold = ctx->opts.mq_threshold;
-			a.observed = ptr<int32_t>(ctx->d_observed);
-			const int waves_per_block = 256 / kWave;
-			const int grid = (int) ((ctx->n_items + waves_per_block - 1) / waves_per_block);
-			if (ctx->n_reads_total > 0)
-				hipLaunchKernelGGL(interval_count_kernel, dim3(grid), dim3(256), 0, st_reduce, a);
-		}
-		if (ctx->n_items > 0 && (dense || ctx->any_map)) {
+		if (!observed_zeroed)
+			HIP_TRY(ctx, hipMemsetAsync(ctx->d_observed.p, 0, (size_t) ctx->n_iv * 4, st_reduce));
+		if (reduce) {
 			KernelTimer t(ctx, CONGA_K_REDUCE);
 			ReduceArgs a;
 			a.rd = dense ? ptr<int16_t>(ctx->d_rd) : nullptr;
@@ -1318,11 +1407,28 @@ int conga_chrom_compute(conga_ctx *ctx)
 			const int grid = (int) ((ctx->n_items + waves_per_block - 1) / waves_per_block);
 			hipLaunchKernelGGL(interval_reduce_kernel, dim3(grid), dim3(256), 0, st_reduce, a);
 		}
-		if (fork)
+		if (forked)
 			HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+		if (forked && fused_score)
+			HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0)); // observed[] must be final before the first chain ends
+		ScoreArgs sa;
+		sa.start = ptr<int32_t>(ctx->d_iv_start);
+		sa.end = ptr<int32_t>(ctx->d_iv_end);
+		sa.type = ptr<uint8_t>(ctx->d_iv_type);
+		sa.n_iv = ctx->n_iv;
+		sa.observed = ptr<int32_t>(ctx->d_observed);
+		sa.expected = ptr<float>(ctx->d_expected);
+		sa.map_part = ptr<double>(ctx->d_map_part);
+		sa.item_first = ptr<int32_t>(ctx->d_item_first);
+		sa.iv_has_map = ptr<uint8_t>(ctx->d_iv_has_map);
+		sa.support = (ctx->support_given || ctx->any_sr) ? ptr<int32_t>(ctx->d_support) : nullptr;
+		sa.out = ptr<conga_result>(ctx->d_results);
 		{
 			KernelTimer t(ctx, CONGA_K_CHAIN);
 			ChainArgs c;
+			c.fused_score = fused_score ? 1 : 0;
+			c.score = sa;
+			c.out_host = ctx->h_results;
 			c.start = ptr<int32_t>(ctx->d_iv_start);
 			c.end = ptr<int32_t>(ctx->d_iv_end);
 			c.iv_slot = ptr<int32_t>(ctx->d_iv_slot);
@@ -1332,40 +1438,35 @@ int conga_chrom_compute(conga_ctx *ctx)
 			c.small = small;
 			c.step = ctx->step;
 			c.expected = ptr<float>(ctx->d_expected);
-			c.n_long = ctx->n_long;
+			c.n_a = ctx->n_chain_a;
+			c.n_b = ctx->n_chain_b;
 			c.n_iv = ctx->n_iv;
-			c.long_blocks = (int32_t) ((ctx->n_long + 3) / 4); // one wave per long interval, 4 waves per block
-			const int short_blocks = (int) ((ctx->n_iv - ctx->n_long + 15) / 16); // four 16-lane groups per wave
-			hipLaunchKernelGGL(interval_chain_kernel, dim3(c.long_blocks + short_blocks), dim3(256), 0, st, c);
+			c.n_slots = n_slots;
+			c.blocks_a = (int32_t) ((c.n_a + 3) / 4);   // one wave per interval, 4 waves per block
+			c.blocks_b = (int32_t) ((c.n_b + 15) / 16); // four 16-lane groups per wave
+			const int blocks_c = (int) ((c.n_iv - c.n_a - c.n_b + 255) / 256); // one lane per interval
+			hipLaunchKernelGGL(interval_chain_kernel, dim3(c.blocks_a + c.blocks_b + blocks_c), dim3(256), 0, st, c);
 		}
-		if (fork)
-			HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
-		{
-			KernelTimer t(ctx, CONGA_K_SCORE);
-			ScoreArgs a;
-			a.start = ptr<int32_t>(ctx->d_iv_start);
-			a.end = ptr<int32_t>(ctx->d_iv_end);
-			a.type = ptr<uint8_t>(ctx->d_iv_type);
-			a.n_iv = ctx->n_iv;
-			a.observed = ptr<int32_t>(ctx->d_observed);
-			a.expected = ptr<float>(ctx->d_expected);
-			a.map_part = ptr<double>(ctx->d_map_part);
-			a.item_first = ptr<int32_t>(ctx->d_item_first);
-			a.iv_has_map = ptr<uint8_t>(ctx->d_iv_has_map);
-			a.support = (ctx->support_given || ctx->any_sr) ? ptr<int32_t>(ctx->d_support) : nullptr;
-			a.out = ptr<conga_result>(ctx->d_results);
-			const int grid = (int) ((ctx->n_iv + 63) / 64);
-			hipLaunchKernelGGL(interval_score_kernel, dim3(grid), dim3(64), 0, st, a);
+		if (!fused_score) {
+			if (forked)
+				HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
+			{
+				KernelTimer t(ctx, CONGA_K_SCORE);
+				const int grid = (int) ((ctx->n_iv + 63) / 64);
+				hipLaunchKernelGGL(interval_score_kernel, dim3(grid), dim3(64), 0, st, sa);
+			}
+			HIP_TRY(ctx, hipMemcpyAsync(ctx->h_results, ctx->d_results.p, (size_t) ctx->n_iv * sizeof(conga_result),
+					hipMemcpyDeviceToHost, st));
 		}
-		HIP_TRY(ctx, hipMemcpyAsync(ctx->h_results, ctx->d_results.p, (size_t) ctx->n_iv * sizeof(conga_result),
-				hipMemcpyDeviceToHost, st));
 	}
+	if (!small_by_kernel)
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small, small, (size_t) n_slots * sizeof(Small), hipMemcpyDeviceToHost, st));
-	HIP_TRY(ctx, hipEventRecord(ctx->ev_done, st));
-	HIP_TRY(ctx, hipGetLastError());
-	ctx->computed = true;
 	return CONGA_OK;
 }
+
+} // namespace
+
+extern "C" {
 
 int conga_chrom_fetch(conga_ctx *ctx, conga_result *dels, conga_result *dups, float expected_rd[101],
 		conga_chrom_stats *stats)

@@ -37,8 +37,6 @@ struct Slot {
 	int64_t tile0;    // first global depth tile
 	int64_t n_tiles;
 	int64_t tidx_off; // first entry in tile_start (n_tiles + 1 entries per slot)
-	int64_t ctile0;   // first global COARSE tile (tuple index of the tuple-space formulation, 2^shift positions each)
-	int64_t n_ctiles;
 };
 
 // Small per-chromosome block, read back after every compute.
@@ -218,8 +216,6 @@ __global__ __launch_bounds__(256) void ingest_kernel(const int32_t *__restrict__
 //     workgroup-private LDS histogram (32 copies, copy c at odd stride 101 words, so one wave's atomics on one
 //     bin land in 32 different banks); one global atomic per non-empty bin when the workgroup ends or moves on
 //     to another chromosome;
-//   * ctile_first[t] = first tuple of COARSE tile t (2^shift positions) or later -- same construction as K0's
-//     index, 8x fewer entries; interval_count only needs it to bound its scan.
 // A chunk that is not strictly inside one chromosome (its first chunk, a straddling one, the ragged end: ~45 of
 // 28,000) goes tuple by tuple into the global counters.
 // -------------------------------------------------------------------------------------------
@@ -235,8 +231,6 @@ struct TupleArgs {
 	int n_slots;
 	const uint8_t *gc_hist;
 	int32_t step;
-	int32_t tile_shift;
-	uint32_t *ctile_first;
 	int32_t mq_threshold;
 	Small *small;
 	uint32_t n_chunks;          // ceil(n_total / kTupleChunk)
@@ -246,7 +240,6 @@ struct TupleArgs {
 struct TupleSlot {
 	uint32_t r0, r1; // tuple index range
 	int32_t L;
-	uint32_t tile0, last_tile; // coarse
 	uint32_t gc_off;
 };
 
@@ -256,19 +249,8 @@ __device__ __forceinline__ TupleSlot tuple_slot(const Slot &sl)
 	o.r0 = (uint32_t) sl.read_off;
 	o.r1 = (uint32_t) (sl.read_off + sl.n_reads);
 	o.L = (int32_t) sl.L;
-	o.tile0 = (uint32_t) sl.ctile0;
-	o.last_tile = (uint32_t) (sl.ctile0 + sl.n_ctiles - 1);
 	o.gc_off = (uint32_t) sl.gc_off;
 	return o;
-}
-
-__device__ __forceinline__ uint32_t coarse_tile_of(const TupleSlot &sl, int32_t p, int shift)
-{
-	if (p < 0)
-		return sl.tile0;
-	if (p >= sl.L)
-		return sl.last_tile;
-	return sl.tile0 + ((uint32_t) p >> shift);
 }
 
 struct TupleRegs { // one chunk's share of a lane: four tuples and, for lane 0 of a wave, the tuple in front of them
@@ -300,7 +282,6 @@ __device__ __forceinline__ int ingest_chunk_inside(const TupleArgs &a, const Tup
 {
 	const int lane = threadIdx.x & (kWave - 1);
 	const uint32_t step = (uint32_t) a.step;
-	const uint32_t i0 = base + threadIdx.x * 4;
 	const int32_t p[4] = {r.q.x, r.q.y, r.q.z, r.q.w};
 	int32_t prev = __shfl_up(p[3], 1, kWave); // the neighbour lane holds the tuple in front of this lane's four
 	if (lane == 0)
@@ -316,18 +297,6 @@ __device__ __forceinline__ int ingest_chunk_inside(const TupleArgs &a, const Tup
 	}
 	if (n_in != 4)
 		atomicAdd(&a.small[home].counters[CNT_OUT_OF_RANGE], (unsigned long long) (4 - n_in));
-	const uint32_t t_prev = coarse_tile_of(sl, prev, a.tile_shift);
-	const uint32_t t_last = coarse_tile_of(sl, p[3], a.tile_shift);
-	if (t_last != t_prev) { // some tile starts inside this lane's four tuples
-		uint32_t t_done = t_prev;
-		for (int e = 0; e < 4; e++) {
-			const uint32_t t_cur = coarse_tile_of(sl, p[e], a.tile_shift);
-			for (int64_t t = (int64_t) t_done + 1; t <= (int64_t) t_cur; t++)
-				a.ctile_first[t] = i0 + e;
-			if (t_cur > t_done)
-				t_done = t_cur;
-		}
-	}
 	uint32_t w[4];
 	bool k[4];
 	int kept = 0;
@@ -358,10 +327,8 @@ __device__ __forceinline__ void ingest_chunk_general(const TupleArgs &a, uint32_
 	if (i0 >= n_total)
 		return;
 	int s = -1;
-	TupleSlot sl = {1, 0, 0, 0, 0, 0}; // empty range: the first tuple refreshes it
+	TupleSlot sl = {1, 0, 0, 0}; // empty range: the first tuple refreshes it
 	int32_t prev = (i0 > 0) ? a.pos[i0 - 1] : 0;
-	uint32_t t_prev = 0;
-	bool t_prev_known = false;
 	for (int e = 0; e < 4; e++) {
 		const uint32_t i = i0 + e;
 		if (i >= n_total)
@@ -369,33 +336,14 @@ __device__ __forceinline__ void ingest_chunk_general(const TupleArgs &a, uint32_
 		if (i < sl.r0 || i >= sl.r1) {
 			s = find_slot(a.n_slots, (int64_t) i, [&](int k) { return a.slots[k].read_off; });
 			sl = tuple_slot(a.slots[s]);
-			t_prev_known = false;
 		}
 		const int32_t p = a.pos[i];
 		const bool in_range = p >= 0 && p < sl.L;
 		if (!in_range)
 			atomicAdd(&a.small[s].counters[CNT_OUT_OF_RANGE], 1ull);
-		const uint32_t t_cur = coarse_tile_of(sl, p, a.tile_shift);
-		int64_t first_fill;
-		if (i == 0)
-			first_fill = 0;
-		else {
-			if (i > sl.r0) { // `prev` is in the same chromosome
-				if (p < prev)
-					atomicOr(&a.small[s].status, kStatusUnsorted);
-				if (!t_prev_known)
-					t_prev = coarse_tile_of(sl, prev, a.tile_shift);
-			} else {
-				const int sp = find_slot(a.n_slots, (int64_t) i - 1, [&](int k) { return a.slots[k].read_off; });
-				t_prev = coarse_tile_of(tuple_slot(a.slots[sp]), prev, a.tile_shift);
-			}
-			first_fill = (int64_t) t_prev + 1;
-		}
-		for (int64_t t = first_fill; t <= (int64_t) t_cur; t++)
-			a.ctile_first[t] = i;
+		if (i > sl.r0 && p < prev) // `prev` is in the same chromosome
+			atomicOr(&a.small[s].status, kStatusUnsorted);
 		prev = p;
-		t_prev = t_cur;
-		t_prev_known = true;
 		if (in_range && (int) a.mapq[i] > a.mq_threshold) {
 			const uint32_t w = (step == 1) ? (uint32_t) p : div_tile((uint32_t) p, step, inv_step);
 			const int g = a.gc_hist[(uint64_t) sl.gc_off + w];
@@ -422,7 +370,7 @@ __global__ __launch_bounds__(kTupleBlock) void ingest_tuples_kernel(TupleArgs a)
 	const float inv_step = 1.0f / (float) a.step;
 	uint32_t *const my_hist = hist + (threadIdx.x & (kHistCopies - 1)) * kGcBins;
 	int home = -1; // chromosome the LDS histogram belongs to
-	TupleSlot hs = {1, 0, 0, 0, 0, 0};
+	TupleSlot hs = {1, 0, 0, 0};
 	int kept = 0;
 
 	auto flush = [&]() { // workgroup-uniform
@@ -475,18 +423,19 @@ __global__ __launch_bounds__(kTupleBlock) void ingest_tuples_kernel(TupleArgs a)
 }
 
 // -------------------------------------------------------------------------------------------
-// K4' interval_count: observed_rd_sv of the tuple-space formulation (likelihood.c:111-114 without read_depth):
-// one wave per reduce item [lo, lo + len) (<= 16384 bases of one interval), which counts the kept tuples with
-// lo <= pos < lo + len among the tuples of the coarse tiles the item touches.  Integer, order-free.
+// K4' interval_count: observed_rd_sv of the tuple-space formulation (likelihood.c:111-114 without read_depth).
+// One lane per reduce item [lo, lo + len) (<= 16384 bases of one interval): two interleaved binary searches over
+// the chromosome's sorted positions give the index range of the tuples that start inside it -- with the default
+// threshold (-1: every read counts, cmdline.c:188-194) the difference IS the sum -- otherwise the wave walks the
+// 64 ranges of its lanes one after the other and counts the MAPQ bytes above the threshold.  Reads only the
+// tuples, so it runs beside ingest_tuples on the second stream.  Integer, order-free.
 // -------------------------------------------------------------------------------------------
 struct CountArgs {
 	const int32_t *pos;
 	const uint8_t *mapq;
-	uint32_t n_total;
-	const uint32_t *ctile_first;
-	const uint32_t *item_ct0; // global coarse tile of the item's first base
-	const uint32_t *item_ct1; // one past the global coarse tile of its last base
-	const int32_t *item_lo;   // first base, chromosome coordinates
+	const uint32_t *item_r0; // tuple index range of the item's chromosome
+	const uint32_t *item_r1;
+	const int32_t *item_lo;  // first base, chromosome coordinates
 	const int32_t *item_len;
 	const int32_t *item_iv;
 	int64_t n_items;
@@ -497,22 +446,51 @@ struct CountArgs {
 __global__ __launch_bounds__(256) void interval_count_kernel(CountArgs a)
 {
 	const int lane = threadIdx.x & (kWave - 1);
-	const int64_t item = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) / kWave;
-	if (item >= a.n_items)
-		return; // wave-uniform
-	const int32_t lo = a.item_lo[item], hi = lo + a.item_len[item];
-	uint32_t u = a.ctile_first[a.item_ct0[item]], v = a.ctile_first[a.item_ct1[item]];
-	u = min(u, a.n_total); // entries behind the last tuple's tile keep 0xFFFFFFFF
-	v = min(v, a.n_total);
-	int acc = 0;
-	for (uint32_t j = u + lane; j < v; j += kWave) {
-		const int32_t p = a.pos[j];
-		const int m = a.mapq[j];
-		acc += (p >= lo && p < hi && m > a.mq_threshold) ? 1 : 0;
+	const int64_t item = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	const bool have = item < a.n_items;
+	int32_t lo = 0, hi = 0;
+	uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0; // first tuple with pos >= lo lies in [a0, a1], with pos >= hi in [b0, b1]
+	if (have) {
+		lo = a.item_lo[item];
+		hi = lo + a.item_len[item];
+		a0 = b0 = a.item_r0[item];
+		a1 = b1 = a.item_r1[item];
 	}
-	acc = wave_sum_i32(acc);
-	if (lane == 0 && acc)
-		atomicAdd(&a.observed[a.item_iv[item]], acc);
+	while (__any(a0 < a1 || b0 < b1)) {
+		const uint32_t ma = a0 + ((a1 - a0) >> 1), mb = b0 + ((b1 - b0) >> 1);
+		const int32_t pa = (a0 < a1) ? a.pos[ma] : 0;
+		const int32_t pb = (b0 < b1) ? a.pos[mb] : 0;
+		if (a0 < a1) {
+			if (pa < lo)
+				a0 = ma + 1;
+			else
+				a1 = ma;
+		}
+		if (b0 < b1) {
+			if (pb < hi)
+				b0 = mb + 1;
+			else
+				b1 = mb;
+		}
+	}
+	int cnt = (int) (b0 - a0); // tuples with lo <= pos < hi
+	if (a.mq_threshold >= 0) { // some reads may be filtered out: look at the MAPQ bytes
+		cnt = 0;
+		for (int i = 0; i < kWave; i++) {
+			const uint32_t u = (uint32_t) __builtin_amdgcn_readlane((int) a0, i);
+			const uint32_t v = (uint32_t) __builtin_amdgcn_readlane((int) b0, i);
+			int total = 0; // wave-uniform
+			for (uint32_t j0 = u; j0 < v; j0 += kWave) {
+				const uint32_t j = j0 + lane;
+				const bool kept = j < v && (int) a.mapq[j] > a.mq_threshold;
+				total += (int) __popcll(__ballot(kept));
+			}
+			if (lane == i)
+				cnt = total;
+		}
+	}
+	if (have && cnt)
+		atomicAdd(&a.observed[a.item_iv[item]], cnt);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -832,10 +810,21 @@ __global__ __launch_bounds__(256) void gc_hist_kernel(const int16_t *__restrict_
 // float goes through double (exact below 2^53, then one rounding), which equals the correctly
 // rounded direct conversion.
 // -------------------------------------------------------------------------------------------
-__global__ void expected_table_kernel(Small *__restrict__ small, const unsigned long long *__restrict__ bases)
+__global__ void expected_table_kernel(Small *__restrict__ small, const unsigned long long *__restrict__ bases,
+		Small *__restrict__ host_small)
 {
 	Small &sm = small[blockIdx.x];
 	const int g = threadIdx.x;
+	if (host_small) { // pinned host copy of the block, written by the kernel instead of a separate copy
+		Small &hs = host_small[blockIdx.x];
+		if (g == 0) {
+			hs.status = sm.status;
+			hs.pad = 0;
+			hs.pad2 = 0.0f;
+		}
+		if (g < CNT_N)
+			hs.counters[g] = sm.counters[g];
+	}
 	if (g >= kGcBins)
 		return;
 	if (bases)
@@ -849,6 +838,12 @@ __global__ void expected_table_kernel(Small *__restrict__ small, const unsigned 
 			e = 0.0f;
 	}
 	sm.E[g] = e;
+	if (host_small) {
+		Small &hs = host_small[blockIdx.x];
+		hs.hist_sum[g] = sm.hist_sum[g];
+		hs.hist_bases[g] = sm.hist_bases[g];
+		hs.E[g] = e;
+	}
 }
 
 // -------------------------------------------------------------------------------------------
@@ -1147,213 +1142,11 @@ __global__ __launch_bounds__(256) void interval_reduce_kernel(ReduceArgs a)
 }
 
 // -------------------------------------------------------------------------------------------
-// K4 (chain) interval_chain<G>: the serial float32 accumulation `expected_rd += E[gc]`
-// (likelihood.c:111,115-119), bit-exact, G lanes per interval (G = 64: one wave per long interval;
-// G = 16: four short intervals per wave).
-//
-// Inside one binade of the accumulator every GC window advances the mantissa by k * delta ulps
-// (conga_step_for, serial_f32.h), an INTEGER, so the G per-window advances are combined with a
-// prefix sum over the lane group.  A window is "regular" when its whole run of k adds stays below
-// the binade top and is not an exact tie; the first irregular window of the group (ballot + ffs)
-// is applied with the scalar routine conga_repeat_add_f32 -- which performs the real rounding --
-// and the scan restarts behind it.  Irregular windows are rare (one per binade crossing, i.e.
-// O(log) per interval), so a 5 Mb interval costs ~800 group steps instead of 50,000 dependent
-// window updates.  Windows are consumed left to right, so the rounding sequence is the reference's.
-// -------------------------------------------------------------------------------------------
-constexpr int kLongWindows = 192; // intervals with more GC windows than this get a whole wave
-
-struct ChainArgs {
-	const int32_t *start;
-	const int32_t *end;
-	const int32_t *iv_slot;
-	const int32_t *order; // interval ids, longest first
-	int64_t n_long;       // order[0 .. n_long): one wave each (workgroups [0, long_blocks))
-	int64_t n_iv;         // order[n_long .. n_iv): one 16-lane group each (the remaining workgroups)
-	int32_t long_blocks;
-	const uint8_t *gc_like;
-	const Slot *slots;
-	const Small *small;
-	int32_t step;
-	float *expected; // [n_iv]
-};
-
-// Inclusive prefix sum over a lane group through DPP (no LDS crossbar): row_shr 1/2/4/8 inside each
-// 16-lane row, then row_bcast:15 / row_bcast:31 to carry row totals across the wave (gfx9 wave64).
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_add(uint32_t v)
-{
-	// lanes without a source (shifted in from outside the row / masked rows) add 0
-	return v + (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, CTRL, ROW_MASK, 0xF, false);
-}
-
-template <int G> __device__ __forceinline__ uint32_t group_incl_scan_u32(uint32_t v, int gl)
-{
-	static_assert(G == 16 || G == 64, "lane groups are one DPP row or the whole wave");
-	v = dpp_add<0x111, 0xF>(v); // row_shr:1
-	v = dpp_add<0x112, 0xF>(v); // row_shr:2
-	v = dpp_add<0x114, 0xF>(v); // row_shr:4
-	v = dpp_add<0x118, 0xF>(v); // row_shr:8
-	if (G == 64) {
-		v = dpp_add<0x142, 0xA>(v); // row_bcast:15 -> rows 1 and 3
-		v = dpp_add<0x143, 0xC>(v); // row_bcast:31 -> rows 2 and 3
-	}
-	(void) gl;
-	return v;
-}
-
-__device__ __forceinline__ float compose_f32(uint32_t es, uint32_t ms)
-{
-	return (ms == 0x1000000u) ? conga_bits_f32((es + 1u) << 23) : conga_bits_f32((es << 23) | (ms & 0x7FFFFFu));
-}
-
-constexpr int kChainTableWords = (256 / 16) * (kGcBins + 3); // one expected_read_depth table per lane group
-constexpr int kChainGcBytes = 256 * 2 * 16;                  // per lane group: two chunks of G * 16 windows
-
-template <int G> __device__ __forceinline__ void interval_chain_body(const ChainArgs &a, int64_t block, int64_t first,
-		int64_t count, float *sE_raw, uint8_t *sGc_raw)
-{
-	constexpr int kGroups = kWave / G;
-	// GC bytes are staged through LDS in 16-byte pieces: a whole short interval at once (G = 16: 256 windows), or
-	// double-buffered 1 KiB chunks fetched one chunk (16 steps) ahead (G = 64), so that no step waits on HBM
-	constexpr int kChunk = G * 16; // windows per staged chunk
-
-	const int lane = threadIdx.x & (kWave - 1);
-	const int gl = lane & (G - 1);  // lane inside the group
-	const int grp = lane / G;       // group inside the wave
-	const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << (grp * G));
-	const int64_t wave = (block * blockDim.x + threadIdx.x) / kWave;
-	const int64_t slot_idx = wave * kGroups + grp;
-	const bool have = slot_idx < count;
-	float *E = sE_raw + (threadIdx.x / G) * (kGcBins + 3);
-	uint8_t(*gcbuf)[kChunk] = reinterpret_cast<uint8_t(*)[kChunk]>(sGc_raw + (size_t) (threadIdx.x / G) * 2 * kChunk);
-
-	int32_t iv = 0;
-	int64_t s0 = 0, e0 = 0, w_first = 0, w_end = 0, n_win = 1;
-	const uint8_t *gc = a.gc_like;
-	if (have) {
-		iv = a.order[first + slot_idx];
-		s0 = a.start[iv];
-		e0 = a.end[iv];
-		const int sl = a.iv_slot[iv];
-		gc = a.gc_like + a.slots[sl].gc_off;
-		n_win = a.slots[sl].n_win;
-		const float *Eg = a.small[sl].E;
-		for (int g = gl; g < kGcBins; g += G)
-			E[g] = Eg[g];
-		if (e0 > s0) {
-			w_first = (uint32_t) s0 / (uint32_t) a.step;
-			w_end = (uint32_t) (e0 - 1) / (uint32_t) a.step + 1;
-		}
-	}
-	const int64_t step = a.step;
-	const int64_t n_win_pad = (n_win + 15) & ~(int64_t) 15; // the slot's GC region is padded to 16 bytes
-	const uint32_t gc_last = have ? gc[n_win - 1] : 0;      // windows past the chromosome end use the last one
-	// 16 bytes of chunk c for this lane (zero past the padded region)
-	auto fetch = [&](int64_t chunk_base) -> uint4 {
-		const int64_t at = chunk_base + (int64_t) gl * 16;
-		return (have && at < n_win_pad) ? *reinterpret_cast<const uint4 *>(gc + at) : make_uint4(0, 0, 0, 0);
-	};
-
-	float s = 0.0f; // uniform inside a group
-	int64_t cb = w_first & ~(int64_t) (G - 1); // chunk base: steps are aligned to it, lanes in front of w_first idle
-	int cur = 0;
-	*reinterpret_cast<uint4 *>(&gcbuf[0][gl * 16]) = fetch(cb);
-	__builtin_amdgcn_wave_barrier(); // table and chunk are written and read by lanes of the same wave: LDS ops stay in order
-	while (__any(cb < w_end)) {
-		const uint4 nxt = fetch(cb + kChunk); // in flight while this chunk's 16 steps run
-		for (int st_i = 0; st_i < 16; st_i++) {
-			const int64_t wb = cb + (int64_t) st_i * G;
-			if (!__any(wb < w_end))
-				break;
-			const int64_t w = wb + gl;
-			const bool active = w >= w_first && w < w_end;
-			uint32_t k = 0, bc = 0;
-			float c = 0.0f;
-			if (active) {
-				const int64_t lo = (w * step > s0) ? w * step : s0;
-				const int64_t hi = ((w + 1) * step < e0) ? (w + 1) * step : e0;
-				k = (uint32_t) (hi - lo);
-				const uint32_t g_cur = (w < n_win) ? gcbuf[cur][st_i * G + gl] : gc_last;
-				c = (g_cur < (uint32_t) kGcBins) ? E[g_cur] : 0.0f;
-				bc = conga_f32_bits(c);
-			}
-			unsigned long long todo = __ballot(active) & gmask; // this group's windows still to apply
-			while (__any(todo != 0ull)) {
-				const uint32_t bs = conga_f32_bits(s);
-				const uint32_t es = bs >> 23;
-				const uint32_t ms = (bs & 0x7FFFFFu) | 0x800000u;
-				const bool in = (todo >> lane) & 1ull;
-				const conga_step st = conga_step_for(es & 0xFFu, bc);
-				const bool valid = in && st.delta != 0xFFFFFFFFu && !st.tie && !(bs >> 31) && !(bc >> 31);
-				uint32_t adv = 0;
-				if (valid) {
-					const uint64_t a64 = (uint64_t) k * st.delta;
-					adv = (a64 > (1u << 25)) ? (1u << 25) : (uint32_t) a64;
-				}
-				const uint32_t incl = group_incl_scan_u32<G>(adv, gl);
-				const uint32_t pre = incl - adv;
-				const uint32_t m = ms + pre; // mantissa in front of this lane's window (< 2^32)
-				bool ok = true;
-				if (in)
-					ok = valid && (st.delta == 0 || (m <= st.lim && (uint64_t) (k - 1u) * st.delta <= (uint64_t) (st.lim - m)));
-				const unsigned long long bad_all = __ballot(!ok);
-				const unsigned long long bad = bad_all & gmask;
-				uint32_t total, pre_fb = 0, k_fb = 0;
-				float c_fb = 0.0f;
-				const int fb = bad ? (__ffsll((long long) bad) - 1 - grp * G) : 0;
-				if (G == 64) {
-					// one group = the wave: everything is wave-uniform, so scalar lane reads do
-					total = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
-					if (bad_all) {
-						const int fbu = __builtin_amdgcn_readfirstlane(fb);
-						pre_fb = (uint32_t) __builtin_amdgcn_readlane((int) pre, fbu);
-						c_fb = conga_bits_f32((uint32_t) __builtin_amdgcn_readlane((int) bc, fbu));
-						k_fb = (uint32_t) __builtin_amdgcn_readlane((int) k, fbu);
-					}
-				} else {
-					total = __shfl(incl, G - 1, G);
-					if (bad_all) { // some group of this wave has an irregular window
-						pre_fb = __shfl(pre, fb, G);
-						c_fb = __shfl(c, fb, G);
-						k_fb = __shfl(k, fb, G);
-					}
-				}
-				if (todo != 0ull) {
-					if (bad == 0ull) {
-						if (total)
-							s = compose_f32(es, ms + total);
-						todo = 0ull;
-					} else {
-						if (pre_fb)
-							s = compose_f32(es, ms + pre_fb); // exact state in front of the irregular window
-						s = conga_repeat_add_f32(s, c_fb, k_fb); // real adds where rounding is not a constant step
-						todo &= ~(((2ull << (fb + grp * G)) - 1ull));
-					}
-				}
-			}
-		}
-		cb += kChunk;
-		cur ^= 1;
-		*reinterpret_cast<uint4 *>(&gcbuf[cur][gl * 16]) = nxt;
-		__builtin_amdgcn_wave_barrier();
-	}
-	if (have && gl == 0)
-		a.expected[iv] = s;
-}
-
-// One launch for both classes, so the few long chains (one wave each, latency-bound) run beside the many short ones.
-__global__ __launch_bounds__(256) void interval_chain_kernel(ChainArgs a)
-{
-	__shared__ float sE[kChainTableWords];
-	__shared__ __attribute__((aligned(16))) uint8_t sGc[kChainGcBytes];
-	if ((int) blockIdx.x < a.long_blocks)
-		interval_chain_body<64>(a, (int64_t) blockIdx.x, 0, a.n_long, sE, sGc);
-	else
-		interval_chain_body<16>(a, (int64_t) blockIdx.x - a.long_blocks, a.n_long, a.n_iv - a.n_long, sE, sGc);
-}
-
-// -------------------------------------------------------------------------------------------
-// K5 interval_score: lpoisson x3, the int-truncated max, the c-score and the CN call
-// (likelihood.c:96-105,131-168).  One lane per interval.
+// K5 scoring: lpoisson x3, the int-truncated max, the c-score and the CN call (likelihood.c:96-105,131-168).
+// Used by interval_score_kernel (one lane per interval) and, when every input of an interval is final before its
+// chain starts (tuple space, no mappability track), by the chain kernel itself: the lane that finishes an
+// interval's chain scores it and writes the record to HBM and straight into the caller's pinned host buffer, so
+// the records of the short chains cross PCIe while the long chains are still running.
 // -------------------------------------------------------------------------------------------
 struct ScoreArgs {
 	const int32_t *start;
@@ -1384,13 +1177,10 @@ __device__ __forceinline__ int trunc_max(double x, double y)
 	return (xi < yi) ? yi : xi;
 }
 
-__global__ __launch_bounds__(256) void interval_score_kernel(ScoreArgs a)
+// One interval's record from its two reduced depths (likelihood.c:131-168).
+__device__ __forceinline__ conga_result score_interval(const ScoreArgs &a, int64_t iv, float expected)
 {
-	const int64_t iv = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-	if (iv >= a.n_iv)
-		return;
 	const int observed = a.observed[iv];
-	const float expected = a.expected[iv];
 	const uint8_t type = a.type[iv];
 	const double ex = (double) expected;
 
@@ -1425,7 +1215,387 @@ __global__ __launch_bounds__(256) void interval_score_kernel(ScoreArgs a)
 		else
 			r.rp = a.support[iv];
 	}
-	a.out[iv] = r;
+	return r;
+}
+
+// -------------------------------------------------------------------------------------------
+// K4 (chain) interval_chain: the serial float32 accumulation `expected_rd += E[gc]`
+// (likelihood.c:111,115-119), bit-exact.  One launch, three classes of intervals (order[] is sorted by the
+// number of GC windows, longest first), so the few long chains run beside the many short ones:
+//   A  more than kChainLongWindows windows   one WAVE per interval, 8 windows per lane and step
+//   B  kChainSerialWindows + 1 .. kChainLongWindows    one 16-lane group per interval, 4 windows per lane and step
+//   C  at most kChainSerialWindows windows   one LANE per interval
+//
+// Inside one binade of the accumulator every GC window advances the mantissa by k * delta ulps
+// (conga_step_for, serial_f32.h), an INTEGER.  A and B: each lane sums the advances of its W consecutive windows,
+// a DPP prefix sum over the lane group places them, and a window is "regular" when its whole run of k adds stays
+// below the binade top and is not an exact tie.  The first irregular window of the group (ballot + ffs, then the
+// lane's first irregular sub-window) is applied with the scalar routine conga_repeat_add_f32 -- which performs
+// the real rounding -- and the step resumes behind it in the new binade.  Irregular windows are rare (one per
+// binade crossing, i.e. O(log) per interval), so a 2 Mb interval costs ~40 + 16 passes instead of 20,000
+// dependent window updates.  C: the lane applies its windows one after the other (the same O(1) fast-forward per
+// window); 64 intervals of similar length share a wave.  Windows are always consumed left to right, so the
+// rounding sequence is the reference's.
+// -------------------------------------------------------------------------------------------
+constexpr int kChainLongWindows = 512;
+constexpr int kChainSerialWindows = 64;
+constexpr int kChainSerialMaxSlots = 32; // class C keeps every chromosome's table in LDS up to this many
+
+struct ChainArgs {
+	const int32_t *start;
+	const int32_t *end;
+	const int32_t *iv_slot;
+	const int32_t *order; // interval ids, longest first
+	int64_t n_a, n_b, n_iv; // order[0, n_a): class A, [n_a, n_a + n_b): class B, the rest: class C
+	int32_t blocks_a, blocks_b;
+	int32_t n_slots;
+	const uint8_t *gc_like;
+	const Slot *slots;
+	const Small *small;
+	int32_t step;
+	float *expected; // [n_iv]
+	int32_t fused_score;   // 1: score each interval as its chain ends (score.observed etc. are final already)
+	ScoreArgs score;
+	conga_result *out_host; // pinned host copy of score.out (may be null)
+};
+
+__device__ __forceinline__ void chain_emit(const ChainArgs &a, int32_t iv, float expected)
+{
+	a.expected[iv] = expected;
+	if (a.fused_score) {
+		const conga_result r = score_interval(a.score, iv, expected);
+		a.score.out[iv] = r;
+		if (a.out_host)
+			a.out_host[iv] = r;
+	}
+}
+
+// Inclusive prefix sum over a lane group through DPP (no LDS crossbar): row_shr 1/2/4/8 inside each
+// 16-lane row, then row_bcast:15 / row_bcast:31 to carry row totals across the wave (gfx9 wave64).
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_add(uint32_t v)
+{
+	// lanes without a source (shifted in from outside the row / masked rows) add 0
+	return v + (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, CTRL, ROW_MASK, 0xF, false);
+}
+
+template <int G> __device__ __forceinline__ uint32_t group_incl_scan_u32(uint32_t v)
+{
+	static_assert(G == 16 || G == 64, "lane groups are one DPP row or the whole wave");
+	v = dpp_add<0x111, 0xF>(v); // row_shr:1
+	v = dpp_add<0x112, 0xF>(v); // row_shr:2
+	v = dpp_add<0x114, 0xF>(v); // row_shr:4
+	v = dpp_add<0x118, 0xF>(v); // row_shr:8
+	if (G == 64) {
+		v = dpp_add<0x142, 0xA>(v); // row_bcast:15 -> rows 1 and 3
+		v = dpp_add<0x143, 0xC>(v); // row_bcast:31 -> rows 2 and 3
+	}
+	return v;
+}
+
+// value of lane `src` (group-relative) for every lane of the group
+template <int G> __device__ __forceinline__ uint32_t group_bcast_u32(uint32_t v, int src)
+{
+	if (G == 64)
+		return (uint32_t) __builtin_amdgcn_readlane((int) v, __builtin_amdgcn_readfirstlane(src));
+	return (uint32_t) __shfl((int) v, src, G);
+}
+
+struct ChainInterval {
+	int32_t iv;
+	int64_t s0, e0, w_first, w_end, n_win;
+	const uint8_t *gc;
+	int sl;
+};
+
+__device__ __forceinline__ ChainInterval chain_interval(const ChainArgs &a, int64_t at)
+{
+	ChainInterval c;
+	c.iv = a.order[at];
+	c.s0 = a.start[c.iv];
+	c.e0 = a.end[c.iv];
+	c.sl = a.iv_slot[c.iv];
+	c.gc = a.gc_like + a.slots[c.sl].gc_off;
+	c.n_win = a.slots[c.sl].n_win;
+	c.w_first = 0;
+	c.w_end = 0;
+	if (c.e0 > c.s0) {
+		c.w_first = (uint32_t) c.s0 / (uint32_t) a.step;
+		c.w_end = (uint32_t) (c.e0 - 1) / (uint32_t) a.step + 1;
+	}
+	return c;
+}
+
+// Classes A (G = 64, W = 8) and B (G = 16, W = 4).
+template <int G, int W> __device__ __forceinline__ void chain_group_body(const ChainArgs &a, int64_t block, int64_t first,
+		int64_t count, float *sE_raw)
+{
+	constexpr int kGroups = kWave / G;
+	constexpr int SW = G * W; // windows per step
+	static_assert(W == 4 || W == 8, "a lane's windows are one aligned 4- or 8-byte word of GC bytes");
+
+	const int lane = threadIdx.x & (kWave - 1);
+	const int gl = lane & (G - 1);  // lane inside the group
+	const int grp = lane / G;       // group inside the wave
+	const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << (grp * G));
+	const int64_t wave = (block * blockDim.x + threadIdx.x) / kWave;
+	const int64_t slot_idx = wave * kGroups + grp;
+	const bool have = slot_idx < count;
+	float *E = sE_raw + (threadIdx.x / G) * (kGcBins + 3);
+
+	ChainInterval ci = {0, 0, 0, 0, 0, 1, a.gc_like, 0};
+	if (have) {
+		ci = chain_interval(a, first + slot_idx);
+		const float *Eg = a.small[ci.sl].E;
+		for (int g = gl; g < kGcBins; g += G)
+			E[g] = Eg[g];
+	}
+	const int64_t s0 = ci.s0, e0 = ci.e0, w_first = ci.w_first, w_end = ci.w_end, n_win = ci.n_win;
+	const uint8_t *gc = ci.gc;
+	const int64_t step = a.step;
+	const int64_t n_win_pad = (n_win + 15) & ~(int64_t) 15; // the slot's GC region is padded to 16 bytes
+	const uint32_t gc_last = have ? gc[n_win - 1] : 0;      // windows past the chromosome end use the last one
+	// this lane's W GC bytes of the step that starts at window `step_base` (zero past the padded region)
+	auto fetch = [&](int64_t step_base) -> uint64_t {
+		const int64_t at = step_base + (int64_t) gl * W;
+		if (!have || at >= n_win_pad)
+			return 0;
+		if (W == 8)
+			return *reinterpret_cast<const uint64_t *>(gc + at);
+		return *reinterpret_cast<const uint32_t *>(gc + at);
+	};
+
+	float s = 0.0f; // uniform inside a group
+	int64_t wb = w_first & ~(int64_t) (SW - 1); // steps are aligned, lanes in front of w_first idle
+	uint64_t cur = fetch(wb), nxt1 = fetch(wb + SW);
+	__builtin_amdgcn_wave_barrier(); // the table is written and read by lanes of the same wave: LDS ops stay in order
+	while (__any(wb < w_end)) {
+		const uint64_t nxt2 = fetch(wb + 2 * SW); // two steps ahead, so that no step waits on HBM
+		uint32_t k[W], bc[W];
+		conga_addend ca[W];
+		bool any_act = false;
+		{
+			const uint32_t w0 = (uint32_t) wb + (uint32_t) gl * W; // positions stay below 2^31 + step
+			uint32_t edge = w0 * (uint32_t) step;                  // first base of window w0 + j
+#pragma unroll
+			for (int j = 0; j < W; j++) {
+				const uint32_t w = w0 + j;
+				k[j] = 0;
+				bc[j] = 0;
+				if (w >= (uint32_t) w_first && w < (uint32_t) w_end) {
+					const uint32_t lo = (edge > (uint32_t) s0) ? edge : (uint32_t) s0;
+					const uint32_t hi = (edge + (uint32_t) step < (uint32_t) e0) ? edge + (uint32_t) step : (uint32_t) e0;
+					k[j] = hi - lo; // >= 1
+					const uint32_t g_cur = (w < (uint32_t) n_win) ? (uint32_t) ((cur >> (8 * j)) & 0xFFu) : gc_last;
+					bc[j] = conga_f32_bits((g_cur < (uint32_t) kGcBins) ? E[g_cur] : 0.0f);
+					any_act = true;
+				}
+				ca[j] = conga_addend_of(bc[j]);
+				edge += (uint32_t) step;
+			}
+		}
+		int next = 0; // first position of this step (gl * W + j) that is not applied yet; uniform inside a group
+		bool pending = (__ballot(any_act) & gmask) != 0ull;
+		while (__any(pending)) {
+			const uint32_t bs = conga_f32_bits(s);
+			const uint32_t es = bs >> 23;
+			const uint32_t ms = (bs & 0x7FFFFFu) | 0x800000u;
+			uint32_t adv[W], lim[W], dl[W];
+			bool in[W], valid[W];
+			uint32_t lane_total = 0;
+#pragma unroll
+			for (int j = 0; j < W; j++) {
+				in[j] = pending && k[j] != 0 && (gl * W + j) >= next;
+				// ok implies delta <= 2^21, which keeps k * delta (k <= gc_step <= 1024) inside 32 bits and lets the
+				// 24-bit multiplier do it at full rate; larger steps (accumulator within 8x of the addend: the first
+				// window or two of an interval) go the irregular way, as do ties and a negative accumulator (es >= 256)
+				const conga_lean_step st = conga_step_lean(es, ca[j]);
+				valid[j] = in[j] && st.ok != 0u && st.tie == 0u;
+				dl[j] = st.delta;
+				lim[j] = st.lim;
+				adv[j] = 0;
+				if (valid[j]) {
+					const uint32_t a32 = __umul24(k[j], st.delta);
+					adv[j] = (a32 > (1u << 24)) ? (1u << 24) : a32; // beyond the binade top anyway
+				}
+				lane_total += adv[j];
+			}
+			if (lane_total > (1u << 25))
+				lane_total = 1u << 25; // keeps the group sum below 2^32; only ever hit behind an irregular window
+			const uint32_t incl = group_incl_scan_u32<G>(lane_total);
+			uint32_t m = ms + (incl - lane_total); // mantissa in front of this lane's first window
+			int jb = W;         // first irregular window of this lane
+			uint32_t m_bad = 0; // mantissa in front of it
+#pragma unroll
+			for (int j = 0; j < W; j++) {
+				if (jb == W && in[j]) {
+					const bool ok = valid[j] && (dl[j] == 0 || (m <= lim[j] && __umul24(k[j] - 1u, dl[j]) <= lim[j] - m));
+					if (!ok) {
+						jb = j;
+						m_bad = m;
+					}
+				}
+				m += adv[j];
+			}
+			const unsigned long long bad_all = __ballot(jb < W);
+			const unsigned long long bad = bad_all & gmask;
+			const int fb = bad ? (__ffsll((long long) bad) - 1 - grp * G) : 0;
+			const uint32_t total = group_bcast_u32<G>(incl, G - 1);
+			uint32_t m_fb = 0, k_fb = 0, bc_fb = 0;
+			int j_fb = 0;
+			if (bad_all) { // some group of this wave has an irregular window
+				uint32_t k_sel = 0, bc_sel = 0;
+#pragma unroll
+				for (int j = 0; j < W; j++)
+					if (j == jb) {
+						k_sel = k[j];
+						bc_sel = bc[j];
+					}
+				m_fb = group_bcast_u32<G>(m_bad, fb);
+				j_fb = (int) group_bcast_u32<G>((uint32_t) jb, fb);
+				k_fb = group_bcast_u32<G>(k_sel, fb);
+				bc_fb = group_bcast_u32<G>(bc_sel, fb);
+			}
+			if (pending) {
+				if (bad == 0ull) {
+					if (total)
+						s = conga_compose_f32(es, ms + total);
+					pending = false;
+				} else {
+					if (m_fb != ms)
+						s = conga_compose_f32(es, m_fb); // exact state in front of the irregular window
+					s = conga_window_add_f32(s, conga_bits_f32(bc_fb), k_fb); // real adds where rounding is not a constant step
+					next = fb * W + j_fb + 1;
+					if (next >= SW)
+						pending = false;
+				}
+			}
+		}
+		wb += SW;
+		cur = nxt1;
+		nxt1 = nxt2;
+	}
+	if (have && gl == 0)
+		chain_emit(a, ci.iv, s);
+}
+
+// Class C: one lane per interval.  The addend of window w + 1 (GC byte -> table lookup) is fetched while window w
+// is applied, so the only latency a trip waits for is its own dozen dependent ALU operations.
+template <bool LDS_TABLES> __device__ __forceinline__ void chain_serial_lanes(const ChainArgs &a, int64_t idx, int64_t first,
+		int64_t count, const float *sE_all, uint4 *stage)
+{
+	const bool have = idx < count;
+	ChainInterval ci = {0, 0, 0, 0, 0, 1, a.gc_like, 0};
+	if (have)
+		ci = chain_interval(a, first + idx);
+	const float *E = LDS_TABLES ? sE_all + ci.sl * (kGcBins + 3) : a.small[ci.sl].E;
+	const int64_t s0 = ci.s0, e0 = ci.e0, n_win = ci.n_win, w_end = ci.w_end;
+	const uint8_t *gc = ci.gc;
+	const int64_t step = a.step;
+	const int64_t n_win_pad = (n_win + 15) & ~(int64_t) 15;
+	const uint32_t gc_last = have ? gc[n_win - 1] : 0;
+	auto fetch = [&](int64_t word) -> uint32_t { // GC bytes of windows [4 * word, 4 * word + 4)
+		return (have && word * 4 < n_win_pad) ? *reinterpret_cast<const uint32_t *>(gc + word * 4) : 0u;
+	};
+	int64_t word = ci.w_first >> 2; // word that `cur` holds
+	uint32_t cur = fetch(word), nxt = fetch(word + 1);
+	// k and the addend's bits for the next window; positions stay below 2^31 + step, so 32-bit arithmetic does
+	uint32_t at = (uint32_t) s0;                                       // first base not yet accounted for
+	uint32_t edge = ((uint32_t) ci.w_first + 1u) * (uint32_t) step;    // first base of the window after `w`
+	int64_t w = ci.w_first;
+	auto window = [&](uint32_t &k, uint32_t &bc) {
+		if ((w >> 2) != word) {
+			word = w >> 2;
+			cur = nxt;
+			nxt = fetch(word + 1);
+		}
+		k = 0;
+		bc = 0;
+		if (w < w_end) {
+			const uint32_t hi = (edge < (uint32_t) e0) ? edge : (uint32_t) e0;
+			k = hi - at;
+			at = hi;
+			const uint32_t g_cur = (w < n_win) ? ((cur >> (8 * (int) (w & 3))) & 0xFFu) : gc_last;
+			bc = conga_f32_bits((g_cur < (uint32_t) kGcBins) ? E[g_cur] : 0.0f);
+		}
+		edge += (uint32_t) step;
+		w++;
+	};
+	float s = 0.0f;
+	uint32_t k, bc;
+	window(k, bc);
+	while (__any(k != 0)) {
+		uint32_t k_next, bc_next;
+		window(k_next, bc_next); // the next addend is on its way while this window is applied
+		if (k)
+			s = conga_window_add_f32(s, conga_bits_f32(bc), k); // inside one binade: k adds = one integer step
+		k = k_next;
+		bc = bc_next;
+	}
+	if (!a.fused_score || !a.out_host) {
+		if (have)
+			chain_emit(a, ci.iv, s);
+		return;
+	}
+	// Scored here, and the pinned host copy written in whole 64-byte records: every lane parks its record in LDS,
+	// then four neighbouring lanes write one record's four 16-byte quarters in one instruction -- a full line per
+	// record on the way to PCIe instead of sixteen-byte crumbs.
+	const int lane = threadIdx.x & (kWave - 1);
+	uint4 *my_stage = stage + (size_t) (threadIdx.x / kWave) * kWave * 4; // this wave's 64 records
+	if (have) {
+		a.expected[ci.iv] = s;
+		const conga_result r = score_interval(a.score, ci.iv, s);
+		a.score.out[ci.iv] = r;
+		*reinterpret_cast<conga_result *>(my_stage + lane * 4) = r;
+	}
+	__builtin_amdgcn_wave_barrier(); // written and read by lanes of the same wave: LDS ops stay in order
+#pragma unroll
+	for (int t = 0; t < 4; t++) {
+		const int src = t * 16 + (lane >> 2);
+		const int iv_src = __shfl(ci.iv, src, kWave);
+		const int have_src = __shfl(have ? 1 : 0, src, kWave);
+		const uint4 v = my_stage[src * 4 + (lane & 3)];
+		if (have_src)
+			reinterpret_cast<uint4 *>(a.out_host + iv_src)[lane & 3] = v;
+	}
+}
+
+__device__ __forceinline__ void chain_serial_body(const ChainArgs &a, int64_t block, int64_t first, int64_t count,
+		float *sE_all, uint4 *stage)
+{
+	const int64_t idx = block * blockDim.x + threadIdx.x;
+	if (a.n_slots <= kChainSerialMaxSlots) { // workgroup-uniform: every chromosome's table fits in LDS
+		for (int i = threadIdx.x; i < a.n_slots * kGcBins; i += blockDim.x)
+			sE_all[(i / kGcBins) * (kGcBins + 3) + i % kGcBins] = a.small[i / kGcBins].E[i % kGcBins];
+		__syncthreads();
+		chain_serial_lanes<true>(a, idx, first, count, sE_all, stage);
+	} else
+		chain_serial_lanes<false>(a, idx, first, count, sE_all, stage);
+}
+
+constexpr int kChainLdsWords = kChainSerialMaxSlots * (kGcBins + 3); // >= 16 group tables of class B
+
+__global__ __launch_bounds__(256) void interval_chain_kernel(ChainArgs a)
+{
+	__shared__ float sE[kChainLdsWords];
+	__shared__ uint4 stage[256 * 4]; // class C: one 64-byte record per lane on its way to the host
+	const int b = (int) blockIdx.x;
+	if (b < a.blocks_a)
+		chain_group_body<64, 8>(a, (int64_t) b, 0, a.n_a, sE);
+	else if (b < a.blocks_a + a.blocks_b)
+		chain_group_body<16, 4>(a, (int64_t) (b - a.blocks_a), a.n_a, a.n_b, sE);
+	else
+		chain_serial_body(a, (int64_t) (b - a.blocks_a - a.blocks_b), a.n_a + a.n_b, a.n_iv - a.n_a - a.n_b, sE, stage);
+}
+
+// -------------------------------------------------------------------------------------------
+// K5 interval_score: score_interval for every interval, one lane each (the path that waits for interval_reduce).
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void interval_score_kernel(ScoreArgs a)
+{
+	const int64_t iv = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (iv >= a.n_iv)
+		return;
+	a.out[iv] = score_interval(a, iv, a.expected[iv]);
 }
 
 // ===========================================================================================

@@ -21,6 +21,21 @@
 #define CONGA_HD static inline
 #endif
 
+// The general routine is the rare path of every kernel that uses it: keeping it out of line keeps the chain
+// kernel's loops small enough for the instruction cache.
+#if defined(__HIPCC__)
+#define CONGA_HD_RARE __host__ __device__ inline __attribute__((noinline))
+#else
+#define CONGA_HD_RARE static inline
+#endif
+
+// product of two operands below 2^24 whose result fits 32 bits: the full-rate 24-bit multiplier on the device
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CONGA_MUL24(a, b) __umul24((a), (b))
+#else
+#define CONGA_MUL24(a, b) ((uint32_t) (a) * (uint32_t) (b))
+#endif
+
 CONGA_HD uint32_t conga_f32_bits(float x)
 {
 	uint32_t u;
@@ -112,7 +127,7 @@ CONGA_HD float conga_repeat_add_nonneg_f32(float s, float c, uint32_t k)
 // Any finite operands.  expected_read_depth can only go negative when a `short` depth counter has
 // wrapped (more than 32767 read starts on one base); round-to-nearest-even is symmetric, so equal
 // signs reuse the non-negative routine and mixed signs fall back to literal adds.
-CONGA_HD float conga_repeat_add_f32(float s, float c, uint32_t k)
+CONGA_HD_RARE float conga_repeat_add_f32(float s, float c, uint32_t k)
 {
 	while (k) {
 		const uint32_t bs = conga_f32_bits(s), bc = conga_f32_bits(c);
@@ -127,4 +142,101 @@ CONGA_HD float conga_repeat_add_f32(float s, float c, uint32_t k)
 		--k;
 	}
 	return s;
+}
+
+// ---- the lean forms the chain kernels use ---------------------------------------------------------------------
+// Same arithmetic as conga_step_for, split so that the part that depends only on the addend is done once per GC
+// window and the part that depends on the accumulator's binade is a dozen select-style operations without a
+// branch (the chain kernels evaluate it for every window of every pass).
+struct conga_addend {
+	uint32_t ec;   // biased exponent
+	uint32_t mc;   // 24-bit significand
+	uint32_t zero; // addend is +0
+	uint32_t bad;  // negative, sub-normal, inf / nan: only the general routine handles it
+};
+
+CONGA_HD conga_addend conga_addend_of(uint32_t bits_c)
+{
+	conga_addend c;
+	c.ec = (bits_c >> 23) & 0xFFu;
+	c.mc = (bits_c & 0x7FFFFFu) | 0x800000u;
+	c.zero = (bits_c == 0u) ? 1u : 0u;
+	c.bad = ((bits_c >> 31) != 0u || (c.ec == 0u && bits_c != 0u) || c.ec == 255u) ? 1u : 0u;
+	return c;
+}
+
+struct conga_lean_step {
+	uint32_t delta;
+	uint32_t lim;
+	uint32_t tie; // exact tie: delta holds only from an even mantissa
+	uint32_t ok;  // 0: outside the regular regime (or a step above 2^21 ulps, which would not fit the 24-bit multiplies)
+};
+
+CONGA_HD conga_lean_step conga_step_lean(uint32_t es, const conga_addend &c)
+{
+	conga_lean_step st;
+	const int d = (int) es - (int) c.ec;
+	const bool stuck = c.zero != 0u || d >= 25; // adding +0, or an addend below half an ulp
+	const bool reg = d >= 1 && d <= 24;
+	const uint32_t dd = (uint32_t) ((d < 1) ? 1 : (d > 24 ? 24 : d));
+	const uint32_t q = c.mc >> dd;
+	const uint32_t r = c.mc & ((1u << dd) - 1u);
+	const uint32_t half = 1u << (dd - 1u);
+	const uint32_t tie = (r == half) ? 1u : 0u;
+	st.delta = stuck ? 0u : q + ((r > half) ? 1u : 0u) + (tie & q);
+	st.lim = stuck ? 0xFFFFFFu : 0xFFFFFFu - q;
+	st.tie = stuck ? 0u : tie;
+	st.ok = (c.bad == 0u && es >= 1u && es <= 254u && (stuck || reg) && st.delta <= (1u << 21)) ? 1u : 0u;
+	return st;
+}
+
+// bits of the float with biased exponent es and 24-bit significand ms in [2^23, 2^24] (2^24 = the next binade's 1.0)
+CONGA_HD float conga_compose_f32(uint32_t es, uint32_t ms)
+{
+	return conga_bits_f32((es << 23) + (ms - 0x800000u));
+}
+
+// The same result as conga_repeat_add_f32 for the case the chain kernels meet all the time: k <= 1024 adds
+// (one GC window) that either stay inside the accumulator's binade or cross its top ONCE.  No loop and no integer
+// divide: the number of regular adds in front of the crossing is a quotient below 1024, so a float estimate is at
+// most one off and two 24-bit multiplies settle it; then one real add (the crossing) and one more integer step in
+// the next binade.  Anything else (mixed signs, sub-normals, a tie from an odd mantissa, a second crossing, steps
+// above 2^21 ulps) is handed to the general routine.
+CONGA_HD float conga_window_add_f32(float s, float c, uint32_t k)
+{
+	if (k == 0)
+		return s;
+	const uint32_t bs = conga_f32_bits(s);
+	const conga_addend ca = conga_addend_of(conga_f32_bits(c));
+	const uint32_t es = bs >> 23; // a negative accumulator shows up as es >= 256: not ok
+	const conga_lean_step st = conga_step_lean(es, ca);
+	uint32_t ms = (bs & 0x7FFFFFu) | 0x800000u;
+	const bool fast = st.ok != 0u && k <= 1024u && !(st.tie != 0u && (ms & 1u) != 0u);
+	const bool room_ok = ms <= st.lim;
+	const uint32_t room = room_ok ? st.lim - ms : 0u; // < 2^24
+	if (fast && room_ok && CONGA_MUL24(k - 1u, st.delta) <= room)
+		return conga_compose_f32(es, ms + CONGA_MUL24(k, st.delta)); // the whole window inside one binade
+	if (!fast || st.delta == 0u)
+		return conga_repeat_add_f32(s, c, k);
+	uint32_t n1 = 0; // regular adds in front of the crossing: the last one starts at or below lim
+	if (room_ok) {
+		uint32_t q = (uint32_t) ((float) room / (float) st.delta); // true quotient < k - 1 <= 1023
+		if (CONGA_MUL24(q, st.delta) > room)
+			q--;
+		else if (CONGA_MUL24(q + 1u, st.delta) <= room)
+			q++;
+		n1 = q + 1u;
+		ms += CONGA_MUL24(n1, st.delta); // lim < ms <= 2^24
+	}
+	const float s2 = conga_compose_f32(es, ms) + c; // the add that reaches or crosses the binade top: real rounding
+	const uint32_t r = k - n1 - 1u;
+	if (r == 0)
+		return s2;
+	const uint32_t bs2 = conga_f32_bits(s2);
+	const uint32_t es2 = bs2 >> 23;
+	const conga_lean_step st2 = conga_step_lean(es2, ca);
+	const uint32_t ms2 = (bs2 & 0x7FFFFFu) | 0x800000u;
+	if (st2.ok != 0u && !(st2.tie != 0u && (ms2 & 1u) != 0u) && ms2 <= st2.lim && CONGA_MUL24(r - 1u, st2.delta) <= st2.lim - ms2)
+		return conga_compose_f32(es2, ms2 + CONGA_MUL24(r, st2.delta));
+	return conga_repeat_add_f32(s2, c, r);
 }

@@ -254,6 +254,9 @@ int conga_copy_mappability(conga_ctx *ctx, float *out, int64_t n);
 /* Host-callable build of the device routine that advances the serial float32 accumulator of
  * likelihood.c:119 by k equal addends in O(1) (used by CPU tests to check it against k real adds). */
 float conga_host_repeat_add_f32(float s, float c, uint32_t k);
+/* Host build of the per-window variant the chain kernels call (at most one binade crossing handled without a
+ * loop or an integer divide, everything else passed on to the routine above); same contract. */
+float conga_host_window_add_f32(float s, float c, uint32_t k);
 
 #ifdef __cplusplus
 }

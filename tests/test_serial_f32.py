@@ -62,6 +62,23 @@ def test_signed_operands_of_similar_magnitude(capi, e, ms, mc, de, k, sn, cn):
     assert bits(capi.host_repeat_add_f32(s, c, k)) == bits(naive(s, c, k))
 
 
+@settings(max_examples=600, deadline=None)
+@given(ec=st.integers(110, 125), mc=st.integers(0, 0x7FFFFF), de=st.integers(2, 24), back=st.integers(0, 1100),
+       k=st.integers(1, 1024))
+def test_one_crossing_inside_a_window(capi, ec, mc, de, back, k):
+    """The chain kernels' common irregular case: the accumulator sits `back` steps below a binade top and one GC
+    window (k <= 1024 adds) carries it across -- conga_window_add_f32 resolves that without its general loop."""
+    c = f32((ec << 23) | mc)
+    top = f32((ec + de + 1) << 23)
+    s = np.float32(top)
+    for _ in range(3):
+        s = np.nextafter(s, np.float32(0), dtype=np.float32)
+    s = np.float32(s - np.float32(back) * c)
+    if not np.isfinite(s) or s <= 0:
+        s = np.float32(top / 2)
+    assert bits(capi.host_repeat_add_f32(s, c, k)) == bits(naive(s, c, k))
+
+
 def test_subnormals_and_zero(capi):
     rng = np.random.default_rng(5)
     for _ in range(300):
