@@ -4,9 +4,19 @@
 Workload at N=1 (BASELINE.json configs[1]): the full 1000G-Phase-3-sized deletion set (~42k rows
 before the min-size filter) over the 22 GRCh37 autosomes against a 1x synthetic sample.  A "step"
 is one pass of the whole hot path over that sample: for every chromosome, read tuples (already
-resident in HBM) -> read_depth + GC histogram -> expected_read_depth[101] -> per-interval depth
-sums, serial-float expected chain, 3-state log-likelihoods, c-score and CN -> result records
+resident in HBM) -> GC-stratified depth sums -> expected_read_depth[101] -> per-interval observed
+depth, serial-float expected chain, 3-state log-likelihoods, c-score and CN -> result records
 gathered on rank 0.  Host-side BAM decoding and BED parsing are outside the timed region.
+
+Formulation: the library default (`--formulation auto`) works in tuple space (SURVEY.md section 8d,
+"sparse reformulation"): read_depth[i] is a count of read starts, so the GC sums are a histogram over
+the kept reads and an interval's observed depth is the number of kept reads that start inside it --
+identical results (asserted against the oracle on the whole genome below), 5 bytes per read of HBM
+traffic instead of 4+ bytes per base.  `--formulation dense` forces the reference's formulation
+(read_depth[] materialised in HBM); at N=1 a short dense leg runs after the timed region so that the
+line carries both: `roofline` (dominant HBM-bound kernel of the timed path), `roofline_dense`
+(depth_tile_kernel, the most HBM-intensive kernel of the library) and `dense_equivalent` (the dense
+formulation's algorithmic bytes divided by the measured step time, as SURVEY.md 8d asks).
 
 Multi-GPU: one process per GPU (torchrun), chromosomes sharded LPT across ranks, no data-path
 collective, one RCCL gather of the fixed-size result records per step.  Default scaling is weak:
@@ -44,6 +54,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="lower bound of CPU-baseline work (oracle, 1 thread); 0 disables the leg")
     ap.add_argument("--chroms", type=str, default="", help="comma list of chromosome names (debug)")
+    ap.add_argument("--no-dense-leg", dest="dense_leg", action="store_false",
+                    help="skip the dense-formulation leg that follows the timed region at N=1")
     return ap.parse_args()
 
 
@@ -101,6 +113,12 @@ def depth_kernel_bytes(units):
         n_tiles = (L + 2047) // 2048
         total += 2 * L + 5 * n + n_win + 4 * (n_tiles + 1)
     return total
+
+
+def tuple_kernel_bytes(units):
+    """Algorithmic bytes of one ingest_tuples launch over these chromosomes: every tuple read
+    once (int32 pos + uint8 mapq) and each GC byte at most once."""
+    return sum(5 * u["n_reads"] + (u["length"] + 99) // 100 for u in units)
 
 
 def dense_reference_bytes(u, with_map):
@@ -236,30 +254,42 @@ def main():
             got = sum(g.numel() for g in gathered) // rec
             assert got == total_iv, (got, total_iv)
 
-        # ---- roofline of the dominant kernel: HIP events recorded on the context's own stream around
+        # ---- roofline of the dominant HBM-bound kernel: HIP events recorded on the context's own stream around
         # every kernel (CONGA_FLAG_PROFILE), same resident inputs, one launch per kernel per compute
-        ctx.set_profile(True)
-        kms = np.zeros(len(capi.KERNEL_NAMES))
-        reps = 10
-        for _ in range(reps):
-            ctx.compute()
-            ctx.select(0)
-            st = ctx.fetch()[3]
-            kms += np.array(st.kernel_ms[:len(capi.KERNEL_NAMES)])
-        ctx.set_profile(False)
-        depth_bytes = depth_kernel_bytes(mine) * reps
-        depth_ms = kms[1]
-        achieved = depth_bytes / (max(depth_ms, 1e-9) * 1e-3) / 1e9
-        launches = reps
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "depth_tile_traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        roofline = dict(bound="hbm", kernel="depth_tile_kernel", achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
-                        unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                        algorithmic_bytes_per_launch=depth_bytes // launches,
-                        avg_launch_ms=round(depth_ms / launches, 5), traffic=traffic,
-                        kernel_ms_per_step={k: round(v / reps, 4) for k, v in zip(capi.KERNEL_NAMES, kms)})
+        def profile_kernels(c, reps=10):
+            c.set_profile(True)
+            kms = np.zeros(len(capi.KERNEL_NAMES))
+            dense_ran = False
+            for _ in range(reps):
+                c.compute()
+                c.select(0)
+                st = c.fetch()[3]
+                kms += np.array(st.kernel_ms[:len(capi.KERNEL_NAMES)])
+                dense_ran = bool(st.depth_materialized)
+            c.set_profile(False)
+            return kms / reps, dense_ran
+
+        def traffic_of(name):
+            tpath = os.path.join(ROOT, "profiles", name)
+            return json.load(open(tpath)).get("hbm_bytes_per_launch") if os.path.exists(tpath) else None
+
+        def roofline_of(kernel, ms, nbytes, kms, traffic):
+            achieved = nbytes / (max(ms, 1e-9) * 1e-3) / 1e9
+            return dict(bound="hbm", kernel=kernel, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(achieved / HBM_PEAK_GBS, 4), algorithmic_bytes_per_launch=int(nbytes),
+                        avg_launch_ms=round(float(ms), 5), traffic=traffic,
+                        kernel_ms_per_step={k: round(float(v), 4) for k, v in zip(capi.KERNEL_NAMES, kms)})
+
+        kms, dense_ran = profile_kernels(ctx)
+        if dense_ran:
+            roofline = roofline_of("depth_tile_kernel", kms[1], depth_kernel_bytes(mine), kms,
+                                   traffic_of("depth_tile_traffic.json"))
+        else:
+            # the serial-float chain is latency-bound ("report its time separately"); the HBM-bound
+            # kernel of the tuple-space path is the one pass over the tuples
+            roofline = roofline_of("ingest_tuples_kernel", kms[0], tuple_kernel_bytes(mine), kms,
+                                   traffic_of("ingest_tuples_traffic.json"))
+            roofline["chain_ms"] = round(float(kms[6]), 4)
 
         dense = sum(dense_reference_bytes(u, args.config != "dels") for u in mine)
         cfg = dict(workload=("BASELINE configs[1]: GRCh37 autosomes 1-22, %d deletion rows (%d kept >= 1000 bp)%s, "
@@ -276,7 +306,12 @@ def main():
                    value=round(total_iv * args.steps / elapsed, 1), unit="intervals/s", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
                    higher_is_better=True, scaling=args.scaling, vs_baseline=None, dtype="i16/i32+f32/f64",
-                   data="synthetic", config=cfg, roofline=roofline)
+                   data="synthetic", config=cfg, roofline=roofline,
+                   formulation="dense" if dense_ran else "tuple-space",
+                   dense_equivalent=dict(bytes=int(dense), achieved=round(dense / (ms_per_step * 1e-3) / 1e9, 1),
+                                         unit="GB/s", x_hbm_peak=round(dense / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
+                                         note="SURVEY.md 8d dense-formulation bytes / measured step time; above 1.0 "
+                                              "only because the tuple-space formulation never moves them"))
         if world == 1:
             # never `value`: the same pass fed from host buffers (pageable numpy -> pinned ring -> H2D over PCIe,
             # layout upload, compute), i.e. what a caller holding decoded tuples in host memory sees
@@ -288,6 +323,42 @@ def main():
             ctx.sync()
             out["host_buffers_inclusive"] = dict(value=round(total_iv / (time.perf_counter() - t1), 1),
                                                  unit="intervals/s", note="one pass incl. PCIe staging; not the metric")
+        if world == 1 and not dense_ran and args.dense_leg:
+            # the reference's dense formulation on the same resident inputs: a second context with
+            # CONGA_FLAG_MATERIALIZE_DEPTH, a few steps, and the roofline of its depth_tile kernel
+            dctx = capi.Context(device=local_rank, flags=capi.FLAG_BATCH | capi.FLAG_MATERIALIZE_DEPTH)
+            for u in mine:
+                c = u["chrom"]
+                dctx.chrom_begin(c.length, c.gc)
+                dctx.reads(c.pos, c.mapq)
+                if c.map_start is not None:
+                    dctx.mappability(c.map_start, c.map_end, c.map_val)
+                dctx.intervals("D", u["ds"], u["de"])
+                if u["n_dups"]:
+                    dctx.intervals("E", u["us"], u["ue"])
+            for _ in range(3):
+                dctx.compute()
+            dctx.sync()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                dctx.compute()
+                dctx.sync()
+            d_ms = (time.perf_counter() - t1) / 5 * 1e3
+            dk, _ = profile_kernels(dctx, reps=5)
+            out["roofline_dense"] = roofline_of("depth_tile_kernel", dk[1], depth_kernel_bytes(mine), dk,
+                                                traffic_of("depth_tile_traffic.json"))
+            out["roofline_dense"]["ms_per_step"] = round(d_ms, 4)
+            out["roofline_dense"]["value"] = round(total_iv / (d_ms * 1e-3), 1)
+            # both formulations must give the same records
+            ctx.compute()
+            ctx.sync()
+            for u in mine:
+                ctx.select(u["index"])
+                dctx.select(u["index"])
+                g1, g2 = ctx.fetch(), dctx.fetch()
+                assert g1[0].tobytes() == g2[0].tobytes() and g1[1].tobytes() == g2[1].tobytes(), \
+                    "tuple-space and dense records differ on chr" + u["name"]
+            dctx.close()
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(mine, ctx, args)
             out["cn_concordance"] = 1.0  # asserted bit-exact against the oracle on the cpu_baseline sample
