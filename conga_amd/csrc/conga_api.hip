@@ -71,7 +71,7 @@ struct conga_ctx {
 	int depth_blocks_per_cu = 8; // resident depth_tile workgroups per CU (occupancy query)
 	hipStream_t stream = nullptr;
 	hipStream_t stream2 = nullptr; // runs interval_reduce beside the float chain (both are latency-bound)
-	hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join = nullptr;
+	hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_depth = nullptr, ev_counted = nullptr, ev_join = nullptr;
 	conga_opts opts{};
 	std::string err;
 
@@ -82,6 +82,7 @@ struct conga_ctx {
 
 	// reads
 	int64_t n_reads_total = 0;
+	size_t small_bytes = 0;      // d_small holds Small[n_slots] (padded to this many bytes), then int32 observed[n_iv]
 	bool wrap_risk = false;      // some position may hold more than 32767 reads: only the dense kernels reproduce the `short` wrap
 	bool depth_resident = false; // read_depth[] of the last compute is in d_rd
 	Staging staging[kStagingRing];
@@ -98,7 +99,7 @@ struct conga_ctx {
 	// device buffers
 	DevBuf d_pos, d_mapq, d_tile_start, d_small_scratch, d_item_r0, d_item_r1, d_item_lo, d_rd, d_gc_hist, d_gc_like, d_slots, d_small, d_map, d_winner,
 			d_map_start, d_map_end, d_map_val, d_iv_start, d_iv_end, d_iv_type, d_iv_slot, d_iv_has_map, d_order,
-			d_observed, d_expected, d_item_off, d_item_len, d_item_iv, d_item_has_map, d_item_first, d_map_part,
+			d_expected, d_item_off, d_item_len, d_item_iv, d_item_has_map, d_item_first, d_map_part,
 			d_support, d_results, d_bases, d_row_tile, d_depth_blocks, d_support_base, d_ref, d_sat_start, d_sat_end, d_sr_pos,
 			d_sr_mapq, d_sr_flag, d_sr_lq, d_sr_off, d_sr_data, d_kmer_count, d_kmer_offset, d_kmer_cursor, d_kmer_pos;
 
@@ -127,6 +128,11 @@ int fail(conga_ctx *ctx, int status, const std::string &msg)
 }
 
 int enqueue_compute(conga_ctx *ctx, bool dense);
+
+int32_t *observed_of(conga_ctx *ctx)
+{
+	return reinterpret_cast<int32_t *>(static_cast<char *>(ctx->d_small.p) + ctx->small_bytes);
+}
 
 void drop_graph(conga_ctx *ctx)
 {
@@ -279,7 +285,9 @@ int prepare(conga_ctx *ctx)
 		TRY(upload(ctx, ctx->d_depth_blocks, blocks.data(), blocks.size() * sizeof(DepthBlock)));
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	}
-	TRY(ensure(ctx, ctx->d_small, std::max<size_t>(n_slots, 1) * sizeof(Small)));
+	// one arena, one memset per compute: the per-chromosome blocks, then observed[n_iv]
+	ctx->small_bytes = (std::max<size_t>(n_slots, 1) * sizeof(Small) + 255) & ~(size_t) 255;
+	TRY(ensure(ctx, ctx->d_small, ctx->small_bytes + std::max<size_t>((size_t) ctx->n_iv, 1) * 4));
 	// d_rd / d_tile_start (6 GB for a human genome) are allocated by the first compute that materialises read_depth
 	if ((size_t) n_slots > ctx->h_small_cap) {
 		if (ctx->h_small)
@@ -478,7 +486,6 @@ int prepare(conga_ctx *ctx)
 		TRY(upload(ctx, ctx->d_item_lo, item_lo.data(), item_lo.size() * 4));
 		TRY(upload(ctx, ctx->d_item_r0, item_r0.data(), item_r0.size() * 4));
 		TRY(upload(ctx, ctx->d_item_r1, item_r1.data(), item_r1.size() * 4));
-		TRY(ensure(ctx, ctx->d_observed, n * 4));
 		TRY(ensure(ctx, ctx->d_expected, n * 4));
 		TRY(ensure(ctx, ctx->d_map_part, std::max<size_t>(item_off.size(), 1) * 8));
 		TRY(ensure(ctx, ctx->d_results, n * sizeof(conga_result)));
@@ -753,6 +760,8 @@ conga_ctx *conga_create(int device, const conga_opts *opts, int *status)
 	if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess
 			|| hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess
 			|| hipEventCreateWithFlags(&ctx->ev_fork2, hipEventDisableTiming) != hipSuccess
+			|| hipEventCreateWithFlags(&ctx->ev_depth, hipEventDisableTiming) != hipSuccess
+			|| hipEventCreateWithFlags(&ctx->ev_counted, hipEventDisableTiming) != hipSuccess
 			|| hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess)
 		return bail(CONGA_ERR_HIP);
 	for (int k = 0; k < CONGA_K_COUNT; k++)
@@ -778,13 +787,17 @@ void conga_destroy(conga_ctx *ctx)
 		(void) hipEventDestroy(ctx->ev_fork);
 	if (ctx->ev_fork2)
 		(void) hipEventDestroy(ctx->ev_fork2);
+	if (ctx->ev_depth)
+		(void) hipEventDestroy(ctx->ev_depth);
+	if (ctx->ev_counted)
+		(void) hipEventDestroy(ctx->ev_counted);
 	if (ctx->ev_join)
 		(void) hipEventDestroy(ctx->ev_join);
 	DevBuf *bufs[] = {&ctx->d_pos, &ctx->d_mapq, &ctx->d_tile_start, &ctx->d_small_scratch, &ctx->d_item_r0,
 			&ctx->d_item_r1, &ctx->d_item_lo, &ctx->d_rd, &ctx->d_gc_hist, &ctx->d_gc_like,
 			&ctx->d_slots, &ctx->d_small, &ctx->d_map, &ctx->d_winner, &ctx->d_map_start, &ctx->d_map_end,
 			&ctx->d_map_val, &ctx->d_iv_start, &ctx->d_iv_end, &ctx->d_iv_type, &ctx->d_iv_slot, &ctx->d_iv_has_map,
-			&ctx->d_order, &ctx->d_observed, &ctx->d_expected, &ctx->d_item_off, &ctx->d_item_len, &ctx->d_item_iv,
+			&ctx->d_order, &ctx->d_expected, &ctx->d_item_off, &ctx->d_item_len, &ctx->d_item_iv,
 			&ctx->d_item_has_map, &ctx->d_item_first, &ctx->d_map_part, &ctx->d_support, &ctx->d_results,
 			&ctx->d_bases, &ctx->d_row_tile, &ctx->d_depth_blocks, &ctx->d_support_base, &ctx->d_ref, &ctx->d_sat_start, &ctx->d_sat_end,
 			&ctx->d_sr_pos, &ctx->d_sr_mapq, &ctx->d_sr_flag, &ctx->d_sr_lq, &ctx->d_sr_off, &ctx->d_sr_data,
@@ -1208,7 +1221,7 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 	const uint8_t *gc_like = ctx->gc_like_distinct ? ptr<uint8_t>(ctx->d_gc_like) : ptr<uint8_t>(ctx->d_gc_hist);
 	const bool unsorted_mode = (ctx->opts.flags & CONGA_FLAG_READS_UNSORTED) != 0;
 
-	HIP_TRY(ctx, hipMemsetAsync(small, 0, (size_t) n_slots * sizeof(Small), st));
+	HIP_TRY(ctx, hipMemsetAsync(small, 0, ctx->small_bytes + (size_t) ctx->n_iv * 4, st)); // Small blocks + observed[]
 	// The Small blocks are final after expected_table unless split-read kernels add their counters later: that
 	// kernel then writes the pinned host copy itself (pinned host memory is device-visible) and the copy at the end goes away.
 	const bool small_by_kernel = !(ctx->any_sr && ctx->n_iv > 0);
@@ -1217,37 +1230,58 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 
 	// Second stream: work that does not depend on the main chain of kernels.  With per-kernel timing on
 	// (CONGA_FLAG_PROFILE) everything stays on one stream so the event pairs bracket one kernel each.
-	const bool two_streams = (ctx->opts.flags & CONGA_FLAG_PROFILE) == 0;
-	bool forked = false, observed_zeroed = false;
-	if (!dense && ctx->n_iv > 0 && ctx->n_items > 0) {
-		// tuple space: the per-interval read counts need nothing but the tuples, so they run beside ingest_tuples
-		hipStream_t sc = st;
+	// (measured: a cross-stream event dependency costs more than a 15 us kernel, so stream2 is only used where it
+	// hides a long one: interval_reduce beside the chain)
+	const bool two_streams = (ctx->opts.flags & CONGA_FLAG_PROFILE) == 0 && ctx->n_items > 0 && (dense || ctx->any_map);
+	hipStream_t s2 = two_streams ? ctx->stream2 : st;
+	bool s2_busy = false;      // something was put on stream2 that the main stream has not waited for yet
+	bool count_pending = false; // ev_counted marks the end of interval_count on stream2
+	// stream2 continues from this point of the main stream
+	auto fork_to_s2 = [&](hipEvent_t ev) -> int {
 		if (two_streams) {
-			HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
-			HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-			sc = ctx->stream2;
-			forked = true;
+			HIP_TRY(ctx, hipEventRecord(ev, st));
+			HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ev, 0));
+			s2_busy = true;
 		}
-		HIP_TRY(ctx, hipMemsetAsync(ctx->d_observed.p, 0, (size_t) ctx->n_iv * 4, sc));
-		observed_zeroed = true;
-		KernelTimer t(ctx, CONGA_K_COUNT_READS);
-		CountArgs a;
-		a.pos = ptr<int32_t>(ctx->d_pos);
-		a.mapq = ptr<uint8_t>(ctx->d_mapq);
-		a.item_r0 = ptr<uint32_t>(ctx->d_item_r0);
-		a.item_r1 = ptr<uint32_t>(ctx->d_item_r1);
-		a.item_lo = ptr<int32_t>(ctx->d_item_lo);
-		a.item_len = ptr<int32_t>(ctx->d_item_len);
-		a.item_iv = ptr<int32_t>(ctx->d_item_iv);
-		a.n_items = ctx->n_items;
-		a.mq_threshold = ctx->opts.mq_threshold;
-		a.observed = ptr<int32_t>(ctx->d_observed);
-		const int grid = (int) ((ctx->n_items + 255) / 256);
-		if (ctx->n_reads_total > 0)
-			hipLaunchKernelGGL(interval_count_kernel, dim3(grid), dim3(256), 0, sc, a);
-	}
-
+		return CONGA_OK;
+	};
+	// the main stream waits for everything stream2 holds
+	auto join_s2 = [&]() -> int {
+		if (s2_busy) {
+			HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+			HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
+			s2_busy = false;
+			count_pending = false;
+		}
+		return CONGA_OK;
+	};
+	const bool profile = (ctx->opts.flags & CONGA_FLAG_PROFILE) != 0;
 	if (!dense) {
+		// tuple space: the per-interval read counts need nothing but the tuples.  Outside profiling they share ONE launch
+		// with the pass over the tuples (tuple_pass_kernel); with a second stream in use they go there.
+		const bool want_count = ctx->n_iv > 0 && ctx->n_items > 0 && ctx->n_reads_total > 0;
+		CountArgs c;
+		c.pos = ptr<int32_t>(ctx->d_pos);
+		c.mapq = ptr<uint8_t>(ctx->d_mapq);
+		c.item_r0 = ptr<uint32_t>(ctx->d_item_r0);
+		c.item_r1 = ptr<uint32_t>(ctx->d_item_r1);
+		c.item_lo = ptr<int32_t>(ctx->d_item_lo);
+		c.item_len = ptr<int32_t>(ctx->d_item_len);
+		c.item_iv = ptr<int32_t>(ctx->d_item_iv);
+		c.n_items = ctx->n_items;
+		c.mq_threshold = ctx->opts.mq_threshold;
+		c.observed = observed_of(ctx);
+		const int count_grid = (int) ((ctx->n_items + 255) / 256);
+		const bool fuse_count = want_count && !profile && !two_streams;
+		if (want_count && !fuse_count) {
+			TRY(fork_to_s2(ctx->ev_fork));
+			KernelTimer t(ctx, CONGA_K_COUNT_READS);
+			hipLaunchKernelGGL(interval_count_kernel, dim3(count_grid), dim3(256), 0, s2, c);
+			if (two_streams) {
+				HIP_TRY(ctx, hipEventRecord(ctx->ev_counted, ctx->stream2));
+				count_pending = true;
+			}
+		}
 		KernelTimer t(ctx, CONGA_K_INGEST);
 		if (ctx->n_reads_total > 0) {
 			TupleArgs a;
@@ -1266,7 +1300,10 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 				blocks = ctx->n_cu * std::max(1, atoi(e));
 			a.chunks_per_block = (a.n_chunks + (uint32_t) blocks - 1) / (uint32_t) blocks;
 			const int grid = (int) ((a.n_chunks + a.chunks_per_block - 1) / a.chunks_per_block);
-			hipLaunchKernelGGL(ingest_tuples_kernel, dim3(grid), dim3(kTupleBlock), 0, st, a);
+			if (fuse_count)
+				hipLaunchKernelGGL(tuple_pass_kernel, dim3(count_grid + grid), dim3(kTupleBlock), 0, st, a, c, count_grid);
+			else
+				hipLaunchKernelGGL(ingest_tuples_kernel, dim3(grid), dim3(kTupleBlock), 0, st, a);
 		}
 	} else if (!unsorted_mode) {
 		TRY(launch_dense_depth(ctx, small, true));
@@ -1288,7 +1325,10 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 		}
 	}
 
-	{
+	// expected_read_depth[101] per chromosome.  The chain kernel derives its tables from the two histograms itself,
+	// so outside profiling this job rides along as a few extra workgroups of the chain launch.
+	const bool fuse_tables = !profile && ctx->n_iv > 0;
+	if (!fuse_tables) {
 		KernelTimer t(ctx, CONGA_K_EXPECTED);
 		hipLaunchKernelGGL(expected_table_kernel, dim3(n_slots), dim3(128), 0, st, small,
 				ptr<unsigned long long>(ctx->d_bases), small_by_kernel ? ctx->h_small : (Small *) nullptr);
@@ -1383,14 +1423,10 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 		// they run side by side on two streams and meet again in front of interval_score.
 		hipStream_t st_reduce = st;
 		const bool reduce = ctx->n_items > 0 && (dense || ctx->any_map);
-		if (reduce && two_streams) {
-			HIP_TRY(ctx, hipEventRecord(ctx->ev_fork2, st));
-			HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork2, 0));
-			st_reduce = ctx->stream2;
-			forked = true;
+		if (reduce) {
+			TRY(fork_to_s2(ctx->ev_fork2));
+			st_reduce = s2;
 		}
-		if (!observed_zeroed)
-			HIP_TRY(ctx, hipMemsetAsync(ctx->d_observed.p, 0, (size_t) ctx->n_iv * 4, st_reduce));
 		if (reduce) {
 			KernelTimer t(ctx, CONGA_K_REDUCE);
 			ReduceArgs a;
@@ -1401,22 +1437,20 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 			a.item_iv = ptr<int32_t>(ctx->d_item_iv);
 			a.item_has_map = ptr<uint8_t>(ctx->d_item_has_map);
 			a.n_items = ctx->n_items;
-			a.observed = ptr<int32_t>(ctx->d_observed);
+			a.observed = observed_of(ctx);
 			a.map_part = ptr<double>(ctx->d_map_part);
 			const int waves_per_block = 256 / kWave;
 			const int grid = (int) ((ctx->n_items + waves_per_block - 1) / waves_per_block);
 			hipLaunchKernelGGL(interval_reduce_kernel, dim3(grid), dim3(256), 0, st_reduce, a);
 		}
-		if (forked)
-			HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
-		if (forked && fused_score)
-			HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0)); // observed[] must be final before the first chain ends
+		if (fused_score && count_pending)
+			HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_counted, 0)); // observed[] must be final before the first chain ends
 		ScoreArgs sa;
 		sa.start = ptr<int32_t>(ctx->d_iv_start);
 		sa.end = ptr<int32_t>(ctx->d_iv_end);
 		sa.type = ptr<uint8_t>(ctx->d_iv_type);
 		sa.n_iv = ctx->n_iv;
-		sa.observed = ptr<int32_t>(ctx->d_observed);
+		sa.observed = observed_of(ctx);
 		sa.expected = ptr<float>(ctx->d_expected);
 		sa.map_part = ptr<double>(ctx->d_map_part);
 		sa.item_first = ptr<int32_t>(ctx->d_item_first);
@@ -1436,6 +1470,7 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 			c.gc_like = gc_like;
 			c.slots = dslots;
 			c.small = small;
+			c.bases = ptr<unsigned long long>(ctx->d_bases);
 			c.step = ctx->step;
 			c.expected = ptr<float>(ctx->d_expected);
 			c.n_a = ctx->n_chain_a;
@@ -1445,11 +1480,13 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 			c.blocks_a = (int32_t) ((c.n_a + 3) / 4);   // one wave per interval, 4 waves per block
 			c.blocks_b = (int32_t) ((c.n_b + 15) / 16); // four 16-lane groups per wave
 			const int blocks_c = (int) ((c.n_iv - c.n_a - c.n_b + 255) / 256); // one lane per interval
-			hipLaunchKernelGGL(interval_chain_kernel, dim3(c.blocks_a + c.blocks_b + blocks_c), dim3(256), 0, st, c);
+			c.table_blocks = fuse_tables ? n_slots : 0;
+			c.host_small = small_by_kernel ? ctx->h_small : nullptr;
+			hipLaunchKernelGGL(interval_chain_kernel, dim3(c.blocks_a + c.blocks_b + blocks_c + c.table_blocks), dim3(256), 0,
+					st, c);
 		}
 		if (!fused_score) {
-			if (forked)
-				HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
+			TRY(join_s2());
 			{
 				KernelTimer t(ctx, CONGA_K_SCORE);
 				const int grid = (int) ((ctx->n_iv + 63) / 64);
@@ -1459,6 +1496,7 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 					hipMemcpyDeviceToHost, st));
 		}
 	}
+	TRY(join_s2());
 	if (!small_by_kernel)
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small, small, (size_t) n_slots * sizeof(Small), hipMemcpyDeviceToHost, st));
 	return CONGA_OK;

@@ -353,11 +353,9 @@ __device__ __forceinline__ void ingest_chunk_general(const TupleArgs &a, uint32_
 	}
 }
 
-__global__ __launch_bounds__(kTupleBlock) void ingest_tuples_kernel(TupleArgs a)
+__device__ __forceinline__ void ingest_tuples_body(const TupleArgs &a, uint32_t block, uint32_t *hist, uint32_t &kept_block)
 {
-	__shared__ uint32_t hist[kHistCopies * kGcBins];
-	__shared__ uint32_t kept_block;
-	const uint32_t c0 = blockIdx.x * a.chunks_per_block;
+	const uint32_t c0 = block * a.chunks_per_block;
 	const uint32_t c1 = min(c0 + a.chunks_per_block, a.n_chunks);
 	TupleRegs next = load_tuples(a, c0, c1); // in flight while the histogram is cleared
 	for (int k = threadIdx.x; k < kHistCopies * kGcBins; k += kTupleBlock)
@@ -422,6 +420,13 @@ __global__ __launch_bounds__(kTupleBlock) void ingest_tuples_kernel(TupleArgs a)
 		flush();
 }
 
+__global__ __launch_bounds__(kTupleBlock) void ingest_tuples_kernel(TupleArgs a)
+{
+	__shared__ uint32_t hist[kHistCopies * kGcBins];
+	__shared__ uint32_t kept_block;
+	ingest_tuples_body(a, blockIdx.x, hist, kept_block);
+}
+
 // -------------------------------------------------------------------------------------------
 // K4' interval_count: observed_rd_sv of the tuple-space formulation (likelihood.c:111-114 without read_depth).
 // One lane per reduce item [lo, lo + len) (<= 16384 bases of one interval): two interleaved binary searches over
@@ -443,10 +448,10 @@ struct CountArgs {
 	int32_t *observed; // [n_iv], zeroed before launch
 };
 
-__global__ __launch_bounds__(256) void interval_count_kernel(CountArgs a)
+__device__ __forceinline__ void interval_count_body(const CountArgs &a, int64_t block)
 {
 	const int lane = threadIdx.x & (kWave - 1);
-	const int64_t item = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	const int64_t item = block * blockDim.x + threadIdx.x;
 	const bool have = item < a.n_items;
 	int32_t lo = 0, hi = 0;
 	uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0; // first tuple with pos >= lo lies in [a0, a1], with pos >= hi in [b0, b1]
@@ -491,6 +496,24 @@ __global__ __launch_bounds__(256) void interval_count_kernel(CountArgs a)
 	}
 	if (have && cnt)
 		atomicAdd(&a.observed[a.item_iv[item]], cnt);
+}
+
+__global__ __launch_bounds__(256) void interval_count_kernel(CountArgs a)
+{
+	interval_count_body(a, (int64_t) blockIdx.x);
+}
+
+// K0' and K4' in one launch (the step is launch-gap-bound: every dependent launch costs ~10 us on this stack, and a
+// second stream's event dependency costs more than it hides): the first count_blocks workgroups search and count,
+// the rest stream the tuples.  The two halves touch disjoint outputs and only read the tuples.
+__global__ __launch_bounds__(kTupleBlock) void tuple_pass_kernel(TupleArgs a, CountArgs c, int count_blocks)
+{
+	__shared__ uint32_t hist[kHistCopies * kGcBins];
+	__shared__ uint32_t kept_block;
+	if ((int) blockIdx.x < count_blocks)
+		interval_count_body(c, (int64_t) blockIdx.x);
+	else
+		ingest_tuples_body(a, blockIdx.x - (uint32_t) count_blocks, hist, kept_block);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -810,13 +833,23 @@ __global__ __launch_bounds__(256) void gc_hist_kernel(const int16_t *__restrict_
 // float goes through double (exact below 2^53, then one rounding), which equals the correctly
 // rounded direct conversion.
 // -------------------------------------------------------------------------------------------
-__global__ void expected_table_kernel(Small *__restrict__ small, const unsigned long long *__restrict__ bases,
-		Small *__restrict__ host_small)
+__device__ __forceinline__ float expected_value(unsigned long long sum, unsigned long long bases, int g)
 {
-	Small &sm = small[blockIdx.x];
+	if (g == 0)
+		return 0.0f;
+	const float num = (float) (double) (long long) sum;
+	const float den = (float) (double) (int) bases;
+	const float e = num / den;
+	return (isnan(e) || isinf(e)) ? 0.0f : e;
+}
+
+__device__ __forceinline__ void expected_table_body(Small *__restrict__ small, const unsigned long long *__restrict__ bases,
+		Small *__restrict__ host_small, int slot)
+{
+	Small &sm = small[slot];
 	const int g = threadIdx.x;
 	if (host_small) { // pinned host copy of the block, written by the kernel instead of a separate copy
-		Small &hs = host_small[blockIdx.x];
+		Small &hs = host_small[slot];
 		if (g == 0) {
 			hs.status = sm.status;
 			hs.pad = 0;
@@ -828,22 +861,21 @@ __global__ void expected_table_kernel(Small *__restrict__ small, const unsigned 
 	if (g >= kGcBins)
 		return;
 	if (bases)
-		sm.hist_bases[g] = bases[(int64_t) blockIdx.x * kGcBins + g];
-	float e = 0.0f;
-	if (g > 0) {
-		const float num = (float) (double) (long long) sm.hist_sum[g];
-		const float den = (float) (double) (int) sm.hist_bases[g];
-		e = num / den;
-		if (isnan(e) || isinf(e))
-			e = 0.0f;
-	}
+		sm.hist_bases[g] = bases[(int64_t) slot * kGcBins + g];
+	const float e = expected_value(sm.hist_sum[g], bases ? bases[(int64_t) slot * kGcBins + g] : sm.hist_bases[g], g);
 	sm.E[g] = e;
 	if (host_small) {
-		Small &hs = host_small[blockIdx.x];
+		Small &hs = host_small[slot];
 		hs.hist_sum[g] = sm.hist_sum[g];
 		hs.hist_bases[g] = sm.hist_bases[g];
 		hs.E[g] = e;
 	}
+}
+
+__global__ void expected_table_kernel(Small *__restrict__ small, const unsigned long long *__restrict__ bases,
+		Small *__restrict__ host_small)
+{
+	expected_table_body(small, bases, host_small, (int) blockIdx.x);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -1251,13 +1283,23 @@ struct ChainArgs {
 	int32_t n_slots;
 	const uint8_t *gc_like;
 	const Slot *slots;
-	const Small *small;
+	Small *small;                      // hist_sum is final (the depth pass is done); E may not be written yet
+	const unsigned long long *bases;   // window_per_gc, [n_slots][101]
 	int32_t step;
 	float *expected; // [n_iv]
 	int32_t fused_score;   // 1: score each interval as its chain ends (score.observed etc. are final already)
 	ScoreArgs score;
 	conga_result *out_host; // pinned host copy of score.out (may be null)
+	int32_t table_blocks;   // > 0: that many trailing workgroups do expected_table_kernel's job (one chromosome each)
+	Small *host_small;      // its pinned host copy (may be null)
 };
+
+// expected_read_depth[g] of chromosome sl, computed from the two histograms so that the chain does not have to wait
+// for expected_table_kernel (which then only serves the host copy and runs beside the chain)
+__device__ __forceinline__ float chain_table_entry(const ChainArgs &a, int sl, int g)
+{
+	return expected_value(a.small[sl].hist_sum[g], a.bases[(int64_t) sl * kGcBins + g], g);
+}
 
 __device__ __forceinline__ void chain_emit(const ChainArgs &a, int32_t iv, float expected)
 {
@@ -1345,9 +1387,8 @@ template <int G, int W> __device__ __forceinline__ void chain_group_body(const C
 	ChainInterval ci = {0, 0, 0, 0, 0, 1, a.gc_like, 0};
 	if (have) {
 		ci = chain_interval(a, first + slot_idx);
-		const float *Eg = a.small[ci.sl].E;
 		for (int g = gl; g < kGcBins; g += G)
-			E[g] = Eg[g];
+			E[g] = chain_table_entry(a, ci.sl, g);
 	}
 	const int64_t s0 = ci.s0, e0 = ci.e0, w_first = ci.w_first, w_end = ci.w_end, n_win = ci.n_win;
 	const uint8_t *gc = ci.gc;
@@ -1487,7 +1528,7 @@ template <bool LDS_TABLES> __device__ __forceinline__ void chain_serial_lanes(co
 	ChainInterval ci = {0, 0, 0, 0, 0, 1, a.gc_like, 0};
 	if (have)
 		ci = chain_interval(a, first + idx);
-	const float *E = LDS_TABLES ? sE_all + ci.sl * (kGcBins + 3) : a.small[ci.sl].E;
+	const float *E = sE_all + ci.sl * (kGcBins + 3); // LDS_TABLES only
 	const int64_t s0 = ci.s0, e0 = ci.e0, n_win = ci.n_win, w_end = ci.w_end;
 	const uint8_t *gc = ci.gc;
 	const int64_t step = a.step;
@@ -1515,7 +1556,10 @@ template <bool LDS_TABLES> __device__ __forceinline__ void chain_serial_lanes(co
 			k = hi - at;
 			at = hi;
 			const uint32_t g_cur = (w < n_win) ? ((cur >> (8 * (int) (w & 3))) & 0xFFu) : gc_last;
-			bc = conga_f32_bits((g_cur < (uint32_t) kGcBins) ? E[g_cur] : 0.0f);
+			float c = 0.0f;
+			if (g_cur < (uint32_t) kGcBins)
+				c = LDS_TABLES ? E[g_cur] : chain_table_entry(a, ci.sl, (int) g_cur);
+			bc = conga_f32_bits(c);
 		}
 		edge += (uint32_t) step;
 		w++;
@@ -1565,7 +1609,7 @@ __device__ __forceinline__ void chain_serial_body(const ChainArgs &a, int64_t bl
 	const int64_t idx = block * blockDim.x + threadIdx.x;
 	if (a.n_slots <= kChainSerialMaxSlots) { // workgroup-uniform: every chromosome's table fits in LDS
 		for (int i = threadIdx.x; i < a.n_slots * kGcBins; i += blockDim.x)
-			sE_all[(i / kGcBins) * (kGcBins + 3) + i % kGcBins] = a.small[i / kGcBins].E[i % kGcBins];
+			sE_all[(i / kGcBins) * (kGcBins + 3) + i % kGcBins] = chain_table_entry(a, i / kGcBins, i % kGcBins);
 		__syncthreads();
 		chain_serial_lanes<true>(a, idx, first, count, sE_all, stage);
 	} else
@@ -1583,6 +1627,8 @@ __global__ __launch_bounds__(256) void interval_chain_kernel(ChainArgs a)
 		chain_group_body<64, 8>(a, (int64_t) b, 0, a.n_a, sE);
 	else if (b < a.blocks_a + a.blocks_b)
 		chain_group_body<16, 4>(a, (int64_t) (b - a.blocks_a), a.n_a, a.n_b, sE);
+	else if (b >= (int) gridDim.x - a.table_blocks)
+		expected_table_body(a.small, a.bases, a.host_small, b - ((int) gridDim.x - a.table_blocks));
 	else
 		chain_serial_body(a, (int64_t) (b - a.blocks_a - a.blocks_b), a.n_a + a.n_b, a.n_iv - a.n_a - a.n_b, sE, stage);
 }
