@@ -90,7 +90,7 @@ struct conga_ctx {
 	int staging_cur = -1; // buffer handed out and not yet committed
 
 	// layout totals (prepare)
-	int64_t total_L = 0, total_tiles = 0, total_gc = 0, n_iv = 0, n_items = 0, n_chain_a = 0, n_chain_b = 0, n_depth_blocks = 0;
+	int64_t total_L = 0, total_tiles = 0, total_gc = 0, n_iv = 0, n_items = 0, n_chain_x = 0, n_chain_a = 0, n_chain_b = 0, n_depth_blocks = 0;
 	bool gc_like_distinct = false, any_map = false, support_given = false, any_sr = false;
 	int64_t n_sr_total = 0, sr_bytes_total = 0;
 	conga_split_staging sr_stage{}; // one pinned set (the split-read path is not the bench line)
@@ -108,6 +108,8 @@ struct conga_ctx {
 	size_t h_small_cap = 0;
 	conga_result *h_results = nullptr;
 	size_t h_results_cap = 0;
+	std::vector<int32_t> order_pos;    // position of interval iv in the chain kernel's processing order
+	bool host_results_by_order = false; // h_results of the last compute is laid out in that order (fused scoring)
 
 	bool computed = false;
 	hipGraphExec_t graph_exec = nullptr; // the captured step; dropped whenever the layout changes
@@ -407,6 +409,7 @@ int prepare(conga_ctx *ctx)
 	// ---- intervals: slot order, dels then dups inside a slot
 	const size_t n = (size_t) ctx->n_iv;
 	ctx->n_items = 0;
+	ctx->n_chain_x = 0;
 	ctx->n_chain_a = 0;
 	ctx->n_chain_b = 0;
 	if (n > 0) {
@@ -437,14 +440,24 @@ int prepare(conga_ctx *ctx)
 			long_min = std::max(1, atoi(e));
 		if (const char *e = getenv("CONGA_CHAIN_SERIAL_WINDOWS"))
 			serial_max = std::max(0, atoi(e));
-		size_t na = 0;
+		int32_t block_min = kChainBlockWindows;
+		if (const char *e = getenv("CONGA_CHAIN_BLOCK_WINDOWS"))
+			block_min = std::max(1, atoi(e));
+		size_t nx = 0;
+		while (nx < n && n_windows[order[nx]] > std::max(block_min, long_min))
+			nx++;
+		size_t na = nx;
 		while (na < n && n_windows[order[na]] > long_min)
 			na++;
 		size_t nb = na;
 		while (nb < n && n_windows[order[nb]] > serial_max)
 			nb++;
-		ctx->n_chain_a = (int64_t) na;
+		ctx->n_chain_x = (int64_t) nx;
+		ctx->n_chain_a = (int64_t) (na - nx);
 		ctx->n_chain_b = (int64_t) (nb - na);
+		ctx->order_pos.assign(n, 0);
+		for (size_t k2 = 0; k2 < n; k2++)
+			ctx->order_pos[(size_t) order[k2]] = (int32_t) k2;
 
 		// reduce work items: [start, min(end, L)) cut into kItemLen pieces
 		std::vector<int64_t> item_off;
@@ -1463,6 +1476,7 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 			c.fused_score = fused_score ? 1 : 0;
 			c.score = sa;
 			c.out_host = ctx->h_results;
+			ctx->host_results_by_order = fused_score;
 			c.start = ptr<int32_t>(ctx->d_iv_start);
 			c.end = ptr<int32_t>(ctx->d_iv_end);
 			c.iv_slot = ptr<int32_t>(ctx->d_iv_slot);
@@ -1473,16 +1487,17 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 			c.bases = ptr<unsigned long long>(ctx->d_bases);
 			c.step = ctx->step;
 			c.expected = ptr<float>(ctx->d_expected);
+			c.n_x = ctx->n_chain_x;
 			c.n_a = ctx->n_chain_a;
 			c.n_b = ctx->n_chain_b;
 			c.n_iv = ctx->n_iv;
 			c.n_slots = n_slots;
 			c.blocks_a = (int32_t) ((c.n_a + 3) / 4);   // one wave per interval, 4 waves per block
 			c.blocks_b = (int32_t) ((c.n_b + 15) / 16); // four 16-lane groups per wave
-			const int blocks_c = (int) ((c.n_iv - c.n_a - c.n_b + 255) / 256); // one lane per interval
+			const int blocks_c = (int) ((c.n_iv - c.n_x - c.n_a - c.n_b + 255) / 256); // one lane per interval
 			c.table_blocks = fuse_tables ? n_slots : 0;
 			c.host_small = small_by_kernel ? ctx->h_small : nullptr;
-			hipLaunchKernelGGL(interval_chain_kernel, dim3(c.blocks_a + c.blocks_b + blocks_c + c.table_blocks), dim3(256), 0,
+			hipLaunchKernelGGL(interval_chain_kernel, dim3((int) c.n_x + c.blocks_a + c.blocks_b + blocks_c + c.table_blocks), dim3(256), 0,
 					st, c);
 		}
 		if (!fused_score) {
@@ -1525,10 +1540,17 @@ int conga_chrom_fetch(conga_ctx *ctx, conga_result *dels, conga_result *dups, fl
 	const size_t nd = h->iv_start[0].size(), nu = h->iv_start[1].size();
 	if ((nd && !dels) || (nu && !dups))
 		return fail(ctx, CONGA_ERR_INVALID, "conga_chrom_fetch: result array missing");
-	if (nd)
-		memcpy(dels, ctx->h_results + h->iv0, nd * sizeof(conga_result));
-	if (nu)
-		memcpy(dups, ctx->h_results + h->iv0 + nd, nu * sizeof(conga_result));
+	if (!ctx->host_results_by_order) {
+		if (nd)
+			memcpy(dels, ctx->h_results + h->iv0, nd * sizeof(conga_result));
+		if (nu)
+			memcpy(dups, ctx->h_results + h->iv0 + nd, nu * sizeof(conga_result));
+	} else { // the chain kernel wrote the host copy in its own processing order
+		for (size_t i = 0; i < nd; i++)
+			dels[i] = ctx->h_results[ctx->order_pos[(size_t) h->iv0 + i]];
+		for (size_t i = 0; i < nu; i++)
+			dups[i] = ctx->h_results[ctx->order_pos[(size_t) h->iv0 + nd + i]];
+	}
 	if (expected_rd)
 		memcpy(expected_rd, sb.E, kGcBins * sizeof(float));
 	if (stats) {

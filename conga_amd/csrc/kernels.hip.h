@@ -277,8 +277,14 @@ __device__ __forceinline__ TupleRegs load_tuples(const TupleArgs &a, uint32_t ch
 
 // A chunk that lies inside one chromosome (all but ~21 of 28,000): no per-tuple chromosome lookup, four tuples
 // per lane handled without a branch except for the rare tile boundary / out-of-range tuple.
-__device__ __forceinline__ int ingest_chunk_inside(const TupleArgs &a, const TupleSlot &sl, int home, uint32_t base,
-		const TupleRegs &r, uint32_t *my_hist, float inv_step)
+struct GcRegs { // stage 1 -> stage 2 of a chunk: the GC bins of a lane's four tuples (loads in flight) and which of them count
+	int g[4];
+	uint32_t kmask;
+};
+
+// Stage 1: checks, read filter, window index, and the four GC-byte loads -- issued, not waited for.
+__device__ __forceinline__ GcRegs ingest_chunk_inside(const TupleArgs &a, const TupleSlot &sl, int home,
+		const TupleRegs &r, float inv_step, int &kept)
 {
 	const int lane = threadIdx.x & (kWave - 1);
 	const uint32_t step = (uint32_t) a.step;
@@ -298,23 +304,32 @@ __device__ __forceinline__ int ingest_chunk_inside(const TupleArgs &a, const Tup
 	if (n_in != 4)
 		atomicAdd(&a.small[home].counters[CNT_OUT_OF_RANGE], (unsigned long long) (4 - n_in));
 	uint32_t w[4];
-	bool k[4];
-	int kept = 0;
+	GcRegs out;
+	out.kmask = 0;
 #pragma unroll
 	for (int e = 0; e < 4; e++) {
-		k[e] = in[e] && (int) ((r.mq >> (8 * e)) & 0xFFu) > a.mq_threshold;
-		w[e] = !k[e] ? 0u : (step == 1) ? (uint32_t) p[e] : div_tile((uint32_t) p[e], step, inv_step);
-		kept += k[e] ? 1 : 0;
+		const bool k = in[e] && (int) ((r.mq >> (8 * e)) & 0xFFu) > a.mq_threshold;
+		// the usual 100-base window: one multiply-high (p < 2^31: floor(p / 100) = (p * 0x51EB851F) >> 37)
+		const uint32_t q = (step == 100u) ? (__umulhi((uint32_t) p[e], 0x51EB851Fu) >> 5)
+				: (step == 1u) ? (uint32_t) p[e] : div_tile((uint32_t) p[e], step, inv_step);
+		w[e] = k ? q : 0u;
+		out.kmask |= (k ? 1u : 0u) << e;
 	}
-	int g[4];
+	kept += __popc(out.kmask);
+	const uint8_t *gc = a.gc_hist + sl.gc_off; // uniform base, 32-bit lane offsets
 #pragma unroll
 	for (int e = 0; e < 4; e++)
-		g[e] = a.gc_hist[(uint64_t) sl.gc_off + w[e]];
+		out.g[e] = gc[w[e]];
+	return out;
+}
+
+// Stage 2, one workgroup step later: the histogram adds.
+__device__ __forceinline__ void ingest_chunk_count(const GcRegs &r, uint32_t *my_hist)
+{
 #pragma unroll
 	for (int e = 0; e < 4; e++)
-		if (k[e])
-			atomicAdd(&my_hist[g[e]], 1u);
-	return kept;
+		if ((r.kmask >> e) & 1u)
+			atomicAdd(&my_hist[r.g[e]], 1u);
 }
 
 // Any other chunk (two chromosomes, a ragged end, the very first tuple): tuple by tuple, straight into the
@@ -357,7 +372,8 @@ __device__ __forceinline__ void ingest_tuples_body(const TupleArgs &a, uint32_t 
 {
 	const uint32_t c0 = block * a.chunks_per_block;
 	const uint32_t c1 = min(c0 + a.chunks_per_block, a.n_chunks);
-	TupleRegs next = load_tuples(a, c0, c1); // in flight while the histogram is cleared
+	// software pipeline over the workgroup's chunks: tuples two chunks ahead, GC bytes one chunk ahead
+	TupleRegs t1 = load_tuples(a, c0, c1), t2 = load_tuples(a, c0 + 1, c1); // in flight while the histogram is cleared
 	for (int k = threadIdx.x; k < kHistCopies * kGcBins; k += kTupleBlock)
 		hist[k] = 0;
 	if (threadIdx.x == 0)
@@ -370,6 +386,7 @@ __device__ __forceinline__ void ingest_tuples_body(const TupleArgs &a, uint32_t 
 	int home = -1; // chromosome the LDS histogram belongs to
 	TupleSlot hs = {1, 0, 0, 0};
 	int kept = 0;
+	GcRegs pend = {{0, 0, 0, 0}, 0u}; // stage-1 result of the previous chunk (kmask 0: nothing pending)
 
 	auto flush = [&]() { // workgroup-uniform
 		kept = wave_sum_i32(kept);
@@ -395,10 +412,13 @@ __device__ __forceinline__ void ingest_tuples_body(const TupleArgs &a, uint32_t 
 	};
 
 	for (uint32_t c = c0; c < c1; c++) {
-		const TupleRegs cur = next;
-		next = load_tuples(a, c + 1, c1);
+		const TupleRegs cur = t1;
+		t1 = t2;
+		t2 = load_tuples(a, c + 2, c1);
 		const uint32_t base = c * (uint32_t) kTupleChunk;
 		if (!(base > hs.r0 && (uint64_t) base + kTupleChunk <= (uint64_t) hs.r1)) { // chunk not inside `home`
+			ingest_chunk_count(pend, my_hist); // the previous chunk still belongs to the old chromosome
+			pend.kmask = 0;
 			if (home >= 0)
 				flush();
 			home = -1;
@@ -414,8 +434,11 @@ __device__ __forceinline__ void ingest_tuples_body(const TupleArgs &a, uint32_t 
 				continue;
 			}
 		}
-		kept += ingest_chunk_inside(a, hs, home, base, cur, my_hist, inv_step);
+		const GcRegs g = ingest_chunk_inside(a, hs, home, cur, inv_step, kept); // GC loads of this chunk go out ...
+		ingest_chunk_count(pend, my_hist);                                        // ... before the previous chunk's are used
+		pend = g;
 	}
+	ingest_chunk_count(pend, my_hist);
 	if (home >= 0)
 		flush();
 }
@@ -1269,6 +1292,7 @@ __device__ __forceinline__ conga_result score_interval(const ScoreArgs &a, int64
 // window); 64 intervals of similar length share a wave.  Windows are always consumed left to right, so the
 // rounding sequence is the reference's.
 // -------------------------------------------------------------------------------------------
+constexpr int kChainBlockWindows = 4096; // class A+ above this
 constexpr int kChainLongWindows = 512;
 constexpr int kChainSerialWindows = 64;
 constexpr int kChainSerialMaxSlots = 32; // class C keeps every chromosome's table in LDS up to this many
@@ -1278,8 +1302,8 @@ struct ChainArgs {
 	const int32_t *end;
 	const int32_t *iv_slot;
 	const int32_t *order; // interval ids, longest first
-	int64_t n_a, n_b, n_iv; // order[0, n_a): class A, [n_a, n_a + n_b): class B, the rest: class C
-	int32_t blocks_a, blocks_b;
+	int64_t n_x, n_a, n_b, n_iv; // order[0, n_x): class A+, [n_x, n_x + n_a): class A, then n_b of class B, the rest: class C
+	int32_t blocks_a, blocks_b;   // class A+ takes n_x workgroups in front of these
 	int32_t n_slots;
 	const uint8_t *gc_like;
 	const Slot *slots;
@@ -1289,7 +1313,8 @@ struct ChainArgs {
 	float *expected; // [n_iv]
 	int32_t fused_score;   // 1: score each interval as its chain ends (score.observed etc. are final already)
 	ScoreArgs score;
-	conga_result *out_host; // pinned host copy of score.out (may be null)
+	conga_result *out_host; // pinned host copy of the records (may be null), in the order of order[]: what one wave
+	                        // writes is contiguous, so it crosses PCIe in large writes; the host un-permutes at fetch
 	int32_t table_blocks;   // > 0: that many trailing workgroups do expected_table_kernel's job (one chromosome each)
 	Small *host_small;      // its pinned host copy (may be null)
 };
@@ -1301,14 +1326,14 @@ __device__ __forceinline__ float chain_table_entry(const ChainArgs &a, int sl, i
 	return expected_value(a.small[sl].hist_sum[g], a.bases[(int64_t) sl * kGcBins + g], g);
 }
 
-__device__ __forceinline__ void chain_emit(const ChainArgs &a, int32_t iv, float expected)
+__device__ __forceinline__ void chain_emit(const ChainArgs &a, int32_t iv, int64_t order_pos, float expected)
 {
 	a.expected[iv] = expected;
 	if (a.fused_score) {
 		const conga_result r = score_interval(a.score, iv, expected);
 		a.score.out[iv] = r;
 		if (a.out_host)
-			a.out_host[iv] = r;
+			a.out_host[order_pos] = r;
 	}
 }
 
@@ -1516,7 +1541,171 @@ template <int G, int W> __device__ __forceinline__ void chain_group_body(const C
 		nxt1 = nxt2;
 	}
 	if (have && gl == 0)
-		chain_emit(a, ci.iv, s);
+		chain_emit(a, ci.iv, first + slot_idx, s);
+}
+
+// Class A+: one WORKGROUP per interval (the handful of chains with thousands of windows that would otherwise be the
+// tail of the launch): the same pass as chain_group_body<64, 8>, 2048 windows wide.  The four waves exchange their
+// totals and their first irregular window through LDS (two barriers per pass, slots alternate between passes).
+__device__ __forceinline__ void chain_block_body(const ChainArgs &a, int64_t block, int64_t first, int64_t count,
+		float *E, uint32_t *xw)
+{
+	constexpr int W = 8;
+	constexpr int SW = 256 * W; // windows per step
+	const int lane = threadIdx.x & (kWave - 1);
+	const int wid = threadIdx.x / kWave;
+	const int gl = threadIdx.x; // lane inside the group = the workgroup
+	const bool have = block < count;
+	ChainInterval ci = {0, 0, 0, 0, 0, 1, a.gc_like, 0};
+	if (have) {
+		ci = chain_interval(a, first + block);
+		if (gl < kGcBins)
+			E[gl] = chain_table_entry(a, ci.sl, gl);
+	}
+	__syncthreads();
+	const int64_t s0 = ci.s0, e0 = ci.e0, w_first = ci.w_first, w_end = ci.w_end, n_win = ci.n_win;
+	const uint8_t *gc = ci.gc;
+	const int64_t step = a.step;
+	const int64_t n_win_pad = (n_win + 15) & ~(int64_t) 15;
+	const uint32_t gc_last = have ? gc[n_win - 1] : 0;
+	auto fetch = [&](int64_t step_base) -> uint64_t {
+		const int64_t at = step_base + (int64_t) gl * W;
+		return (have && at < n_win_pad) ? *reinterpret_cast<const uint64_t *>(gc + at) : 0ull;
+	};
+
+	float s = 0.0f; // uniform in the workgroup
+	int64_t wb = w_first & ~(int64_t) (SW - 1);
+	uint64_t cur = fetch(wb), nxt1 = fetch(wb + SW);
+	uint32_t pass = 0;
+	while (wb < w_end) { // workgroup-uniform
+		const uint64_t nxt2 = fetch(wb + 2 * SW);
+		uint32_t k[W], bc[W];
+		conga_addend ca[W];
+		bool any_act = false;
+		{
+			const uint32_t w0 = (uint32_t) wb + (uint32_t) gl * W;
+			uint32_t edge = w0 * (uint32_t) step;
+#pragma unroll
+			for (int j = 0; j < W; j++) {
+				const uint32_t w = w0 + j;
+				k[j] = 0;
+				bc[j] = 0;
+				if (w >= (uint32_t) w_first && w < (uint32_t) w_end) {
+					const uint32_t lo = (edge > (uint32_t) s0) ? edge : (uint32_t) s0;
+					const uint32_t hi = (edge + (uint32_t) step < (uint32_t) e0) ? edge + (uint32_t) step : (uint32_t) e0;
+					k[j] = hi - lo;
+					const uint32_t g_cur = (w < (uint32_t) n_win) ? (uint32_t) ((cur >> (8 * j)) & 0xFFu) : gc_last;
+					bc[j] = conga_f32_bits((g_cur < (uint32_t) kGcBins) ? E[g_cur] : 0.0f);
+					any_act = true;
+				}
+				ca[j] = conga_addend_of(bc[j]);
+				edge += (uint32_t) step;
+			}
+		}
+		(void) any_act;
+		int next = 0;        // first position of this step (gl * W + j) that is not applied yet
+		bool pending = true; // the step holds at least one window of the interval (wb < w_end, steps are aligned)
+		while (pending) {    // workgroup-uniform
+			uint32_t *slot = xw + (pass & 1u) * 32; // [0..3] wave totals, [4..7] first irregular position, [8..19] its m / k / bc
+			pass++;
+			const uint32_t bs = conga_f32_bits(s);
+			const uint32_t es = bs >> 23;
+			const uint32_t ms = (bs & 0x7FFFFFu) | 0x800000u;
+			uint32_t adv[W], lim[W], dl[W];
+			bool in[W], valid[W];
+			uint32_t lane_total = 0;
+#pragma unroll
+			for (int j = 0; j < W; j++) {
+				in[j] = k[j] != 0 && (gl * W + j) >= next;
+				const conga_lean_step st = conga_step_lean(es, ca[j]);
+				valid[j] = in[j] && st.ok != 0u && st.tie == 0u;
+				dl[j] = st.delta;
+				lim[j] = st.lim;
+				adv[j] = 0;
+				if (valid[j]) {
+					const uint32_t a32 = __umul24(k[j], st.delta);
+					adv[j] = (a32 > (1u << 24)) ? (1u << 24) : a32;
+				}
+				lane_total += adv[j];
+			}
+			// A regular prefix never exceeds 2^24, so every clamp below (lane 2^25, wave 2^31, workgroup 2^30) is only
+			// ever hit behind an irregular window, where the value is not used.
+			if (lane_total > (1u << 25))
+				lane_total = 1u << 25;
+			const uint32_t incl_w = group_incl_scan_u32<64>(lane_total);
+			if (lane == kWave - 1)
+				slot[wid] = incl_w;
+			__syncthreads();
+			uint32_t before = 0, total = 0;
+#pragma unroll
+			for (int v = 0; v < 4; v++) {
+				const uint32_t t = min(slot[v], 1u << 28);
+				before += (v < wid) ? t : 0u;
+				total += t;
+			}
+			uint32_t m = ms + before + (incl_w - lane_total); // mantissa in front of this lane's first window
+			int jb = W;
+			uint32_t m_bad = 0;
+#pragma unroll
+			for (int j = 0; j < W; j++) {
+				if (jb == W && in[j]) {
+					const bool ok = valid[j] && (dl[j] == 0 || (m <= lim[j] && __umul24(k[j] - 1u, dl[j]) <= lim[j] - m));
+					if (!ok) {
+						jb = j;
+						m_bad = m;
+					}
+				}
+				m += adv[j];
+			}
+			const unsigned long long bad = __ballot(jb < W);
+			if (bad) { // wave-uniform: this wave's first irregular window goes to LDS
+				const int fb = __ffsll((long long) bad) - 1;
+				uint32_t k_sel = 0, bc_sel = 0;
+#pragma unroll
+				for (int j = 0; j < W; j++)
+					if (j == jb) {
+						k_sel = k[j];
+						bc_sel = bc[j];
+					}
+				if (lane == fb) {
+					slot[4 + wid] = (uint32_t) (gl * W + jb);
+					slot[8 + wid] = m_bad;
+					slot[12 + wid] = k_sel;
+					slot[16 + wid] = bc_sel;
+				}
+			} else if (lane == 0)
+				slot[4 + wid] = 0xFFFFFFFFu;
+			__syncthreads();
+			uint32_t first_pos = 0xFFFFFFFFu, m_fb = 0, k_fb = 0, bc_fb = 0;
+#pragma unroll
+			for (int v = 0; v < 4; v++) { // waves hold ascending positions: the first wave with an entry wins
+				const uint32_t p = slot[4 + v];
+				if (first_pos == 0xFFFFFFFFu && p != 0xFFFFFFFFu) {
+					first_pos = p;
+					m_fb = slot[8 + v];
+					k_fb = slot[12 + v];
+					bc_fb = slot[16 + v];
+				}
+			}
+			if (first_pos == 0xFFFFFFFFu) {
+				if (total)
+					s = conga_compose_f32(es, ms + total);
+				pending = false;
+			} else {
+				if (m_fb != ms)
+					s = conga_compose_f32(es, m_fb); // exact state in front of the irregular window
+				s = conga_window_add_f32(s, conga_bits_f32(bc_fb), k_fb);
+				next = (int) first_pos + 1;
+				if (next >= SW)
+					pending = false;
+			}
+		}
+		wb += SW;
+		cur = nxt1;
+		nxt1 = nxt2;
+	}
+	if (have && gl == 0)
+		chain_emit(a, ci.iv, first + block, s);
 }
 
 // Class C: one lane per interval.  The addend of window w + 1 (GC byte -> table lookup) is fetched while window w
@@ -1577,12 +1766,12 @@ template <bool LDS_TABLES> __device__ __forceinline__ void chain_serial_lanes(co
 	}
 	if (!a.fused_score || !a.out_host) {
 		if (have)
-			chain_emit(a, ci.iv, s);
+			chain_emit(a, ci.iv, first + idx, s);
 		return;
 	}
-	// Scored here, and the pinned host copy written in whole 64-byte records: every lane parks its record in LDS,
-	// then four neighbouring lanes write one record's four 16-byte quarters in one instruction -- a full line per
-	// record on the way to PCIe instead of sixteen-byte crumbs.
+	// Scored here, and the pinned host copy written as one contiguous 4 KiB run per wave: every lane parks its record
+	// in LDS, then four neighbouring lanes write one record's four 16-byte quarters, sixteen records (1 KiB) per
+	// instruction -- large PCIe writes instead of sixteen-byte crumbs.
 	const int lane = threadIdx.x & (kWave - 1);
 	uint4 *my_stage = stage + (size_t) (threadIdx.x / kWave) * kWave * 4; // this wave's 64 records
 	if (have) {
@@ -1595,11 +1784,10 @@ template <bool LDS_TABLES> __device__ __forceinline__ void chain_serial_lanes(co
 #pragma unroll
 	for (int t = 0; t < 4; t++) {
 		const int src = t * 16 + (lane >> 2);
-		const int iv_src = __shfl(ci.iv, src, kWave);
-		const int have_src = __shfl(have ? 1 : 0, src, kWave);
+		const int64_t pos_src = first + idx - lane + src; // lanes of a wave hold consecutive entries of order[]
 		const uint4 v = my_stage[src * 4 + (lane & 3)];
-		if (have_src)
-			reinterpret_cast<uint4 *>(a.out_host + iv_src)[lane & 3] = v;
+		if (pos_src < first + count)
+			reinterpret_cast<uint4 *>(a.out_host + pos_src)[lane & 3] = v;
 	}
 }
 
@@ -1622,15 +1810,30 @@ __global__ __launch_bounds__(256) void interval_chain_kernel(ChainArgs a)
 {
 	__shared__ float sE[kChainLdsWords];
 	__shared__ uint4 stage[256 * 4]; // class C: one 64-byte record per lane on its way to the host
-	const int b = (int) blockIdx.x;
-	if (b < a.blocks_a)
-		chain_group_body<64, 8>(a, (int64_t) b, 0, a.n_a, sE);
-	else if (b < a.blocks_a + a.blocks_b)
-		chain_group_body<16, 4>(a, (int64_t) (b - a.blocks_a), a.n_a, a.n_b, sE);
-	else if (b >= (int) gridDim.x - a.table_blocks)
-		expected_table_body(a.small, a.bases, a.host_small, b - ((int) gridDim.x - a.table_blocks));
-	else
-		chain_serial_body(a, (int64_t) (b - a.blocks_a - a.blocks_b), a.n_a + a.n_b, a.n_iv - a.n_a - a.n_b, sE, stage);
+	__shared__ uint32_t xw[64];      // class A+: what the four waves of a pass tell each other
+	int b = (int) blockIdx.x;
+	if (b < (int) a.n_x) {
+		chain_block_body(a, (int64_t) b, 0, a.n_x, sE, xw);
+		return;
+	}
+	b -= (int) a.n_x;
+	// The launch is instruction-issue-bound and the classes share SIMDs.  The many short chains are given issue
+	// priority over the few long ones: they end early, and their records cross PCIe (40 us for a 1000G-sized set)
+	// while the long chains are still computing instead of after them.
+	const int grid = (int) gridDim.x - (int) a.n_x;
+	if (b < a.blocks_a) {
+		chain_group_body<64, 8>(a, (int64_t) b, a.n_x, a.n_a, sE);
+	} else if (b < a.blocks_a + a.blocks_b) {
+		__builtin_amdgcn_s_setprio(2);
+		chain_group_body<16, 4>(a, (int64_t) (b - a.blocks_a), a.n_x + a.n_a, a.n_b, sE);
+	} else if (b >= grid - a.table_blocks) {
+		__builtin_amdgcn_s_setprio(3);
+		expected_table_body(a.small, a.bases, a.host_small, b - (grid - a.table_blocks));
+	} else {
+		__builtin_amdgcn_s_setprio(3);
+		chain_serial_body(a, (int64_t) (b - a.blocks_a - a.blocks_b), a.n_x + a.n_a + a.n_b,
+				a.n_iv - a.n_x - a.n_a - a.n_b, sE, stage);
+	}
 }
 
 // -------------------------------------------------------------------------------------------

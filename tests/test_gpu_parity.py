@@ -417,6 +417,28 @@ def test_long_chains_random_tables(capi, oracle):
         compare(got, want, False)
 
 
+@pytest.mark.parametrize("knobs", [
+    dict(CONGA_CHAIN_BLOCK_WINDOWS="40", CONGA_CHAIN_LONG_WINDOWS="30", CONGA_CHAIN_SERIAL_WINDOWS="8"),
+    dict(CONGA_CHAIN_BLOCK_WINDOWS="1000000", CONGA_CHAIN_LONG_WINDOWS="100", CONGA_CHAIN_SERIAL_WINDOWS="0"),
+    dict(CONGA_CHAIN_BLOCK_WINDOWS="1000000", CONGA_CHAIN_LONG_WINDOWS="1000000", CONGA_CHAIN_SERIAL_WINDOWS="1000000"),
+    dict(CONGA_CHAIN_BLOCK_WINDOWS="1", CONGA_CHAIN_LONG_WINDOWS="1", CONGA_CHAIN_SERIAL_WINDOWS="0"),
+])
+def test_every_chain_class_gives_the_same_sums(capi, oracle, monkeypatch, knobs):
+    """The chain kernel sorts intervals into four classes by length (workgroup / wave / 16-lane group / lane per
+    interval).  The thresholds are tuning knobs: whichever class an interval lands in, its float32 sum is the oracle's."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    c = synth.make_chrom("9", 4_000_000, cov=3.0, seed=11, gaps=True, n_dels=150, n_dups=30)
+    rng = np.random.default_rng(12)
+    s = rng.integers(0, 3_000_000, 60).astype(np.int32)
+    e = (s + rng.integers(1_000, 900_000, 60)).astype(np.int32)
+    ds, de = synth.kept_sorted(np.concatenate([c.del_start, s]), np.concatenate([c.del_end, e]))
+    us, ue = synth.kept_sorted(c.dup_start, c.dup_end)
+    want = run_oracle(oracle, c.length, c.gc, c.pos, c.mapq, ds, de, us, ue)
+    got = run_gpu(capi, c.length, c.gc, c.pos, c.mapq, ds, de, us, ue, want_tracks=False)
+    compare(got, want, False)
+
+
 def test_batch_mode_matches_per_chromosome_results(capi, oracle):
     """CONGA_FLAG_BATCH: several chromosomes resident at once, every kernel launched once over the batch.
     Mixed bag on purpose: with/without mappability, no intervals, no reads, a distinct likelihood GC array."""
