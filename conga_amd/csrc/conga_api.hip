@@ -92,12 +92,14 @@ struct conga_ctx {
 	// layout totals (prepare)
 	int64_t total_L = 0, total_tiles = 0, total_gc = 0, n_iv = 0, n_items = 0, n_chain_x = 0, n_chain_a = 0, n_chain_b = 0, n_depth_blocks = 0;
 	bool gc_like_distinct = false, any_map = false, support_given = false, any_sr = false;
+	bool any_map_painted = false; // some chromosome's track is painted into d_map by compute (dense formulation / unsorted rows)
+	bool any_map_rows = false;    // some chromosome's track is summed in row space (sorted rows, tuple-space formulation)
 	int64_t n_sr_total = 0, sr_bytes_total = 0;
 	conga_split_staging sr_stage{}; // one pinned set (the split-read path is not the bench line)
 	bool sr_staged = false;
 
 	// device buffers
-	DevBuf d_pos, d_mapq, d_tile_start, d_small_scratch, d_item_r0, d_item_r1, d_item_lo, d_rd, d_gc_hist, d_gc_like, d_slots, d_small, d_map, d_winner,
+	DevBuf d_pos, d_mapq, d_tile_start, d_small_scratch, d_item_r0, d_item_r1, d_item_row0, d_item_row1, d_item_lo, d_rd, d_gc_hist, d_gc_like, d_slots, d_small, d_map, d_winner,
 			d_map_start, d_map_end, d_map_val, d_iv_start, d_iv_end, d_iv_type, d_iv_slot, d_iv_has_map, d_order,
 			d_expected, d_item_off, d_item_len, d_item_iv, d_item_has_map, d_item_first, d_map_part,
 			d_support, d_results, d_bases, d_row_tile, d_depth_blocks, d_support_base, d_ref, d_sat_start, d_sat_end, d_sr_pos,
@@ -130,6 +132,19 @@ int fail(conga_ctx *ctx, int status, const std::string &msg)
 }
 
 int enqueue_compute(conga_ctx *ctx, bool dense);
+
+// Formulation: tuple / row space unless the arrays were asked for, the reads may be unsorted, or a `short` may wrap.
+bool dense_formulation(const conga_ctx *ctx)
+{
+	return (ctx->opts.flags & (CONGA_FLAG_READS_UNSORTED | CONGA_FLAG_MATERIALIZE_DEPTH)) != 0 || ctx->wrap_risk;
+}
+
+// A chromosome's track is painted into mappability[L] (and summed from there) in the dense formulation and whenever
+// its rows are not sorted-and-at-most-abutting; otherwise interval_map_rows sums straight from the rows.
+bool track_painted(const conga_ctx *ctx, const HostSlot &h)
+{
+	return h.has_map && (dense_formulation(ctx) || !h.map_sorted);
+}
 
 int32_t *observed_of(conga_ctx *ctx)
 {
@@ -229,6 +244,8 @@ int prepare(conga_ctx *ctx)
 	int64_t rd_off = 0, gc_off = 0, tile0 = 0, iv0 = 0, map_rows = 0;
 	ctx->gc_like_distinct = false;
 	ctx->any_map = false;
+	ctx->any_map_painted = false;
+	ctx->any_map_rows = false;
 	ctx->support_given = false;
 	std::vector<Slot> dslots(n_slots);
 	for (int s = 0; s < n_slots; s++) {
@@ -258,6 +275,12 @@ int prepare(conga_ctx *ctx)
 			ctx->gc_like_distinct = true;
 		if (h.has_map)
 			ctx->any_map = true;
+		if (h.has_map && h.iv_start[0].size() + h.iv_start[1].size() > 0) {
+			if (track_painted(ctx, h))
+				ctx->any_map_painted = true;
+			else
+				ctx->any_map_rows = true;
+		}
 		if (!h.iv_support[0].empty() || !h.iv_support[1].empty())
 			ctx->support_given = true;
 	}
@@ -343,7 +366,8 @@ int prepare(conga_ctx *ctx)
 		TRY(upload(ctx, ctx->d_map_start, ms.data(), ms.size() * 4));
 		TRY(upload(ctx, ctx->d_map_end, me.data(), me.size() * 4));
 		TRY(upload(ctx, ctx->d_map_val, mv.data(), mv.size() * 4));
-		TRY(ensure(ctx, ctx->d_map, std::max<size_t>((size_t) ctx->total_L, 8) * 4));
+		if (ctx->any_map_painted) // 11.5 GB for a human genome: only when some track really is painted
+			TRY(ensure(ctx, ctx->d_map, std::max<size_t>((size_t) ctx->total_L, 8) * 4));
 		if (any_unsorted)
 			TRY(ensure(ctx, ctx->d_winner, (size_t) max_L * 4));
 		// per-tile first-row index of every sorted track (rows do not change between computes)
@@ -424,7 +448,7 @@ int prepare(conga_ctx *ctx)
 					end[k] = h.iv_end[t][i];
 					type[k] = t == 0 ? CONGA_DELETION : CONGA_DUPLICATION;
 					iv_slot[k] = s;
-					iv_has_map[k] = h.has_map ? 1 : 0;
+					iv_has_map[k] = !h.has_map ? 0 : track_painted(ctx, h) ? 2 : 1;
 				}
 		}
 		std::vector<int32_t> n_windows(n);
@@ -462,7 +486,7 @@ int prepare(conga_ctx *ctx)
 		// reduce work items: [start, min(end, L)) cut into kItemLen pieces
 		std::vector<int64_t> item_off;
 		std::vector<int32_t> item_len, item_iv, item_lo;
-		std::vector<uint32_t> item_r0, item_r1;
+		std::vector<uint32_t> item_r0, item_r1, item_row0, item_row1;
 		std::vector<uint8_t> item_has_map;
 		item_off.reserve(n + n / 2);
 		item_len.reserve(n + n / 2);
@@ -480,6 +504,8 @@ int prepare(conga_ctx *ctx)
 				item_lo.push_back((int32_t) a);
 				item_r0.push_back((uint32_t) h.read_off);
 				item_r1.push_back((uint32_t) (h.read_off + h.n_reads));
+				item_row0.push_back((uint32_t) h.map_row_off);
+				item_row1.push_back((uint32_t) (h.map_row_off + (int64_t) h.map_start.size()));
 			}
 		}
 		item_first[n] = (int32_t) item_off.size();
@@ -499,6 +525,8 @@ int prepare(conga_ctx *ctx)
 		TRY(upload(ctx, ctx->d_item_lo, item_lo.data(), item_lo.size() * 4));
 		TRY(upload(ctx, ctx->d_item_r0, item_r0.data(), item_r0.size() * 4));
 		TRY(upload(ctx, ctx->d_item_r1, item_r1.data(), item_r1.size() * 4));
+		TRY(upload(ctx, ctx->d_item_row0, item_row0.data(), item_row0.size() * 4));
+		TRY(upload(ctx, ctx->d_item_row1, item_row1.data(), item_row1.size() * 4));
 		TRY(ensure(ctx, ctx->d_expected, n * 4));
 		TRY(ensure(ctx, ctx->d_map_part, std::max<size_t>(item_off.size(), 1) * 8));
 		TRY(ensure(ctx, ctx->d_results, n * sizeof(conga_result)));
@@ -807,7 +835,7 @@ void conga_destroy(conga_ctx *ctx)
 	if (ctx->ev_join)
 		(void) hipEventDestroy(ctx->ev_join);
 	DevBuf *bufs[] = {&ctx->d_pos, &ctx->d_mapq, &ctx->d_tile_start, &ctx->d_small_scratch, &ctx->d_item_r0,
-			&ctx->d_item_r1, &ctx->d_item_lo, &ctx->d_rd, &ctx->d_gc_hist, &ctx->d_gc_like,
+			&ctx->d_item_r1, &ctx->d_item_row0, &ctx->d_item_row1, &ctx->d_item_lo, &ctx->d_rd, &ctx->d_gc_hist, &ctx->d_gc_like,
 			&ctx->d_slots, &ctx->d_small, &ctx->d_map, &ctx->d_winner, &ctx->d_map_start, &ctx->d_map_end,
 			&ctx->d_map_val, &ctx->d_iv_start, &ctx->d_iv_end, &ctx->d_iv_type, &ctx->d_iv_slot, &ctx->d_iv_has_map,
 			&ctx->d_order, &ctx->d_expected, &ctx->d_item_off, &ctx->d_item_len, &ctx->d_item_iv,
@@ -1239,13 +1267,13 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 	// kernel then writes the pinned host copy itself (pinned host memory is device-visible) and the copy at the end goes away.
 	const bool small_by_kernel = !(ctx->any_sr && ctx->n_iv > 0);
 	// Scoring inside the chain kernel: possible when nothing the score needs is produced beside the chain.
-	const bool fused_score = !dense && !ctx->any_map && ctx->n_iv > 0;
+	const bool fused_score = !dense && !ctx->any_map_painted && ctx->n_iv > 0;
 
 	// Second stream: work that does not depend on the main chain of kernels.  With per-kernel timing on
 	// (CONGA_FLAG_PROFILE) everything stays on one stream so the event pairs bracket one kernel each.
 	// (measured: a cross-stream event dependency costs more than a 15 us kernel, so stream2 is only used where it
 	// hides a long one: interval_reduce beside the chain)
-	const bool two_streams = (ctx->opts.flags & CONGA_FLAG_PROFILE) == 0 && ctx->n_items > 0 && (dense || ctx->any_map);
+	const bool two_streams = (ctx->opts.flags & CONGA_FLAG_PROFILE) == 0 && ctx->n_items > 0 && (dense || ctx->any_map_painted);
 	hipStream_t s2 = two_streams ? ctx->stream2 : st;
 	bool s2_busy = false;      // something was put on stream2 that the main stream has not waited for yet
 	bool count_pending = false; // ev_counted marks the end of interval_count on stream2
@@ -1285,8 +1313,21 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 		c.mq_threshold = ctx->opts.mq_threshold;
 		c.observed = observed_of(ctx);
 		const int count_grid = (int) ((ctx->n_items + 255) / 256);
-		const bool fuse_count = want_count && !profile && !two_streams;
-		if (want_count && !fuse_count) {
+		// ... and so do the mappability sums of the chromosomes whose track is summed in row space
+		const bool want_rows = ctx->any_map_rows && ctx->n_iv > 0 && ctx->n_items > 0;
+		MapRowsArgs mr;
+		mr.row_start = ptr<int32_t>(ctx->d_map_start);
+		mr.row_end = ptr<int32_t>(ctx->d_map_end);
+		mr.row_val = ptr<float>(ctx->d_map_val);
+		mr.item_row0 = ptr<uint32_t>(ctx->d_item_row0);
+		mr.item_row1 = ptr<uint32_t>(ctx->d_item_row1);
+		mr.item_lo = ptr<int32_t>(ctx->d_item_lo);
+		mr.item_len = ptr<int32_t>(ctx->d_item_len);
+		mr.item_has_map = ptr<uint8_t>(ctx->d_item_has_map);
+		mr.n_items = ctx->n_items;
+		mr.map_part = ptr<double>(ctx->d_map_part);
+		const bool fuse = !profile && !two_streams && ctx->n_reads_total > 0;
+		if (want_count && !fuse) {
 			TRY(fork_to_s2(ctx->ev_fork));
 			KernelTimer t(ctx, CONGA_K_COUNT_READS);
 			hipLaunchKernelGGL(interval_count_kernel, dim3(count_grid), dim3(256), 0, s2, c);
@@ -1294,6 +1335,10 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 				HIP_TRY(ctx, hipEventRecord(ctx->ev_counted, ctx->stream2));
 				count_pending = true;
 			}
+		}
+		if (want_rows && !fuse) {
+			KernelTimer t(ctx, CONGA_K_REDUCE);
+			hipLaunchKernelGGL(interval_map_rows_kernel, dim3(count_grid), dim3(256), 0, st, mr);
 		}
 		KernelTimer t(ctx, CONGA_K_INGEST);
 		if (ctx->n_reads_total > 0) {
@@ -1313,9 +1358,10 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 				blocks = ctx->n_cu * std::max(1, atoi(e));
 			a.chunks_per_block = (a.n_chunks + (uint32_t) blocks - 1) / (uint32_t) blocks;
 			const int grid = (int) ((a.n_chunks + a.chunks_per_block - 1) / a.chunks_per_block);
-			if (fuse_count)
-				hipLaunchKernelGGL(tuple_pass_kernel, dim3(count_grid + grid), dim3(kTupleBlock), 0, st, a, c, count_grid);
-			else
+			if (fuse && (want_count || want_rows)) {
+				const int cb = want_count ? count_grid : 0, mb = want_rows ? count_grid : 0;
+				hipLaunchKernelGGL(tuple_pass_kernel, dim3(cb + mb + grid), dim3(kTupleBlock), 0, st, a, c, cb, mr, mb);
+			} else
 				hipLaunchKernelGGL(ingest_tuples_kernel, dim3(grid), dim3(kTupleBlock), 0, st, a);
 		}
 	} else if (!unsorted_mode) {
@@ -1349,11 +1395,11 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 
 	// the reference paints the track only when the chromosome has at least one kept SV
 	// (likelihood.c:332-336 returns before :352-356)
-	if (ctx->any_map && ctx->n_iv > 0) {
+	if (ctx->any_map_painted && ctx->n_iv > 0) {
 		KernelTimer t(ctx, CONGA_K_PAINT);
 		for (int s = 0; s < n_slots; s++) {
 			const HostSlot &h = ctx->slots[s];
-			if (!h.has_map || h.iv_start[0].size() + h.iv_start[1].size() == 0)
+			if (!track_painted(ctx, h) || h.iv_start[0].size() + h.iv_start[1].size() == 0)
 				continue;
 			const int32_t *ms = ptr<int32_t>(ctx->d_map_start) + h.map_row_off;
 			const int32_t *me = ptr<int32_t>(ctx->d_map_end) + h.map_row_off;
@@ -1435,7 +1481,7 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 		// interval_reduce needs read_depth and / or the painted track; the float chain needs only the depth table:
 		// they run side by side on two streams and meet again in front of interval_score.
 		hipStream_t st_reduce = st;
-		const bool reduce = ctx->n_items > 0 && (dense || ctx->any_map);
+		const bool reduce = ctx->n_items > 0 && (dense || ctx->any_map_painted);
 		if (reduce) {
 			TRY(fork_to_s2(ctx->ev_fork2));
 			st_reduce = s2;
@@ -1671,6 +1717,17 @@ int conga_copy_mappability(conga_ctx *ctx, float *out, int64_t n)
 			|| n > h->L || n < 0)
 		return CONGA_ERR_INVALID;
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	if (!track_painted(ctx, *h)) {
+		// row-space compute: paint this chromosome's (sorted) track now
+		TRY(ensure(ctx, ctx->d_map, std::max<size_t>((size_t) ctx->total_L, 8) * 4));
+		const int64_t n_pt = (h->L + kPaintTile - 1) / kPaintTile;
+		const int grid = (int) ((n_pt + kPaintTilesPerBlock - 1) / kPaintTilesPerBlock);
+		hipLaunchKernelGGL(paint_sorted_kernel, dim3(grid), dim3(256), 0, ctx->stream,
+				ptr<int32_t>(ctx->d_map_start) + h->map_row_off, ptr<int32_t>(ctx->d_map_end) + h->map_row_off,
+				ptr<float>(ctx->d_map_val) + h->map_row_off, (int64_t) h->map_start.size(),
+				ptr<uint32_t>(ctx->d_row_tile) + h->row_tile_off, ptr<float>(ctx->d_map) + h->rd_off, h->L);
+		HIP_TRY(ctx, hipGetLastError());
+	}
 	HIP_TRY(ctx, hipMemcpyAsync(out, ptr<float>(ctx->d_map) + h->rd_off, (size_t) n * 4, hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	return CONGA_OK;

@@ -526,17 +526,113 @@ __global__ __launch_bounds__(256) void interval_count_kernel(CountArgs a)
 	interval_count_body(a, (int64_t) blockIdx.x);
 }
 
+// -------------------------------------------------------------------------------------------
+// K3' interval_map_rows: the mappability sum of loop C (likelihood.c:113,121) without painting mappability[L].
+// For a track whose rows are sorted and at most abutting (what conga_mappability() detects: the bedGraph layout of
+// README.md:77-88) the painted value of base x is that of the LAST row with start <= x, if its end >= x
+// (svs.c:363-371: end inclusive, later rows overwrite), i.e. row k covers [start_k, min(end_k, start_{k+1} - 1)].
+// An item's sum is therefore sum_k val_k * |cover_k  intersected with  [lo, hi)|: float x integer products are exact in
+// double, and whenever the per-base partial sums of the reference are exact (k-mer-track values) so is this.
+// One lane per item finds its row range with two interleaved binary searches; the wave then walks the 64 ranges
+// of its lanes (coalesced row loads, fixed-shape double reduction).  ~3 M rows touched for a 1000G-sized call set
+// instead of 11.5 GB painted and 2 GB read back.
+// -------------------------------------------------------------------------------------------
+struct MapRowsArgs {
+	const int32_t *row_start; // concatenated per-chromosome row arrays
+	const int32_t *row_end;
+	const float *row_val;
+	const uint32_t *item_row0; // row range of the item's chromosome (indices into the arrays above)
+	const uint32_t *item_row1;
+	const int32_t *item_lo;
+	const int32_t *item_len;
+	const uint8_t *item_has_map; // 1: summed here, 2: summed from the painted track by interval_reduce, 0: no track
+	int64_t n_items;
+	double *map_part; // [n_items]
+};
+
+__device__ __forceinline__ void interval_map_rows_body(const MapRowsArgs &a, int64_t block)
+{
+	const int lane = threadIdx.x & (kWave - 1);
+	const int64_t item = block * blockDim.x + threadIdx.x;
+	const bool have = item < a.n_items && a.item_has_map[item] == 1;
+	int32_t lo = 0, hi = 0;
+	uint32_t r1 = 0, a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+	if (have) {
+		lo = a.item_lo[item];
+		hi = lo + a.item_len[item];
+		a0 = b0 = a.item_row0[item];
+		a1 = b1 = r1 = a.item_row1[item];
+	}
+	const uint32_t r0 = a0;
+	while (__any(a0 < a1 || b0 < b1)) { // a: first row with start > lo; b: first row with start >= hi
+		const uint32_t ma = a0 + ((a1 - a0) >> 1), mb = b0 + ((b1 - b0) >> 1);
+		const int32_t sa = (a0 < a1) ? a.row_start[ma] : 0;
+		const int32_t sb = (b0 < b1) ? a.row_start[mb] : 0;
+		if (a0 < a1) {
+			if (sa <= lo)
+				a0 = ma + 1;
+			else
+				a1 = ma;
+		}
+		if (b0 < b1) {
+			if (sb < hi)
+				b0 = mb + 1;
+			else
+				b1 = mb;
+		}
+	}
+	const uint32_t k_lo = (a0 > r0) ? a0 - 1 : r0; // the last row that starts at or before lo may still cover it
+	const uint32_t k_hi = b0;
+	double mine = 0.0;
+	for (int i = 0; i < kWave; i++) {
+		if (!__builtin_amdgcn_readlane(have ? 1 : 0, i))
+			continue; // wave-uniform
+		const uint32_t u = (uint32_t) __builtin_amdgcn_readlane((int) k_lo, i);
+		const uint32_t v = (uint32_t) __builtin_amdgcn_readlane((int) k_hi, i);
+		const uint32_t end_rows = (uint32_t) __builtin_amdgcn_readlane((int) r1, i);
+		const int32_t lo_i = __builtin_amdgcn_readlane(lo, i), hi_i = __builtin_amdgcn_readlane(hi, i);
+		double acc = 0.0;
+		for (uint32_t j0 = u; j0 < v; j0 += kWave) {
+			const uint32_t j = j0 + lane;
+			if (j < v) {
+				const int32_t s = a.row_start[j], e = a.row_end[j];
+				const int32_t nxt = (j + 1 < end_rows) ? a.row_start[j + 1] : INT32_MAX;
+				const int32_t eff = (e < nxt - 1) ? e : nxt - 1;
+				const int32_t from = (s > lo_i) ? s : lo_i;
+				const int32_t to = (eff < hi_i - 1) ? eff : hi_i - 1;
+				if (to >= from)
+					acc += (double) a.row_val[j] * (double) (to - from + 1);
+			}
+		}
+		acc = wave_sum_f64(acc); // total in lane 0
+		const double total = __shfl(acc, 0, kWave);
+		if (lane == i)
+			mine = total;
+	}
+	if (have)
+		a.map_part[item] = mine;
+}
+
+__global__ __launch_bounds__(256) void interval_map_rows_kernel(MapRowsArgs a)
+{
+	interval_map_rows_body(a, (int64_t) blockIdx.x);
+}
+
 // K0' and K4' in one launch (the step is launch-gap-bound: every dependent launch costs ~10 us on this stack, and a
 // second stream's event dependency costs more than it hides): the first count_blocks workgroups search and count,
 // the rest stream the tuples.  The two halves touch disjoint outputs and only read the tuples.
-__global__ __launch_bounds__(kTupleBlock) void tuple_pass_kernel(TupleArgs a, CountArgs c, int count_blocks)
+__global__ __launch_bounds__(kTupleBlock) void tuple_pass_kernel(TupleArgs a, CountArgs c, int count_blocks, MapRowsArgs m,
+		int map_blocks)
 {
 	__shared__ uint32_t hist[kHistCopies * kGcBins];
 	__shared__ uint32_t kept_block;
-	if ((int) blockIdx.x < count_blocks)
-		interval_count_body(c, (int64_t) blockIdx.x);
+	const int b = (int) blockIdx.x;
+	if (b < count_blocks)
+		interval_count_body(c, (int64_t) b);
+	else if (b < count_blocks + map_blocks)
+		interval_map_rows_body(m, (int64_t) (b - count_blocks));
 	else
-		ingest_tuples_body(a, blockIdx.x - (uint32_t) count_blocks, hist, kept_block);
+		ingest_tuples_body(a, (uint32_t) (b - count_blocks - map_blocks), hist, kept_block);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -1173,7 +1269,7 @@ __global__ __launch_bounds__(256) void interval_reduce_kernel(ReduceArgs a)
 		atomicAdd(&a.observed[a.item_iv[item]], acc);
 
 	// ---- mappability: float, 4 per lane, summed in double
-	if (a.item_has_map[item]) {
+	if (a.item_has_map[item] == 2) { // 1 = summed in row space by interval_map_rows
 		double m = 0.0;
 		int64_t head = (s + 3) & ~(int64_t) 3;
 		if (head > e)

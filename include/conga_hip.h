@@ -68,7 +68,10 @@ typedef enum conga_status {
                                           that start inside it (5 bytes of traffic per READ) -- and builds read_depth[]
                                           only when conga_copy_read_depth() asks for it.  It switches to the dense
                                           kernels by itself when the reads may be unsorted or when one base may hold
-                                          more than 32767 read starts (the `short` of common.h:91 would wrap). */
+                                          more than 32767 read starts (the `short` of common.h:91 would wrap).
+                                          The same holds for bam_info.mappability[]: a track whose rows are sorted
+                                          and at most abutting is summed per interval straight from its rows; with
+                                          this flag (or rows in any other order) it is painted base by base. */
 
 /* SV types, as the reference's DELETION / DUPLICATION (common.h:12-13) */
 #define CONGA_DELETION 'D'
@@ -178,7 +181,8 @@ int conga_reads_commit(conga_ctx *ctx, size_t n);
 
 /* load_mappability_regions: rows of this chromosome in FILE ORDER (later rows overwrite earlier
  * ones, end inclusive: svs.c:368).  Copies the arrays; call at most once per chromosome.
- * Not calling it means "no --mappability" (conga_result.mappability = 0). */
+ * Not calling it means "no --mappability" (conga_result.mappability = 0).  Rows that are sorted by start with
+ * start[k + 1] >= end[k] (the bedGraph layout of the reference's README) take the fast paths. */
 int conga_mappability(conga_ctx *ctx, const int32_t *start, const int32_t *end, const float *val, size_t m);
 
 /* load_known_SVs + qsort output for this chromosome: rows already filtered
