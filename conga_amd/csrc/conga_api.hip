@@ -82,7 +82,12 @@ struct conga_ctx {
 
 	// reads
 	int64_t n_reads_total = 0;
-	size_t small_bytes = 0;      // d_small holds Small[n_slots] (padded to this many bytes), then int32 observed[n_iv]
+	// d_small holds TWO accumulator arenas, each Small[n_slots] (padded to small_bytes) followed by int32 observed[n_iv]
+	// (arena_bytes in all).  A compute adds into arena `small_cur`; the chain launch clears the other one on the
+	// side, so the next compute starts on a zeroed arena without a memset launch of its own.
+	size_t small_bytes = 0, arena_bytes = 0;
+	int small_cur = 0, small_cur_next = 0;
+	bool arena_zeroed[2] = {false, false};
 	bool wrap_risk = false;      // some position may hold more than 32767 reads: only the dense kernels reproduce the `short` wrap
 	bool depth_resident = false; // read_depth[] of the last compute is in d_rd
 	Staging staging[kStagingRing];
@@ -146,9 +151,14 @@ bool track_painted(const conga_ctx *ctx, const HostSlot &h)
 	return h.has_map && (dense_formulation(ctx) || !h.map_sorted);
 }
 
+char *arena_of(conga_ctx *ctx, int which)
+{
+	return static_cast<char *>(ctx->d_small.p) + (size_t) which * ctx->arena_bytes;
+}
+
 int32_t *observed_of(conga_ctx *ctx)
 {
-	return reinterpret_cast<int32_t *>(static_cast<char *>(ctx->d_small.p) + ctx->small_bytes);
+	return reinterpret_cast<int32_t *>(arena_of(ctx, ctx->small_cur) + ctx->small_bytes);
 }
 
 void drop_graph(conga_ctx *ctx)
@@ -312,7 +322,10 @@ int prepare(conga_ctx *ctx)
 	}
 	// one arena, one memset per compute: the per-chromosome blocks, then observed[n_iv]
 	ctx->small_bytes = (std::max<size_t>(n_slots, 1) * sizeof(Small) + 255) & ~(size_t) 255;
-	TRY(ensure(ctx, ctx->d_small, ctx->small_bytes + std::max<size_t>((size_t) ctx->n_iv, 1) * 4));
+	ctx->arena_bytes = (ctx->small_bytes + std::max<size_t>((size_t) ctx->n_iv, 1) * 4 + 255) & ~(size_t) 255;
+	TRY(ensure(ctx, ctx->d_small, 2 * ctx->arena_bytes));
+	ctx->small_cur = 0;
+	ctx->arena_zeroed[0] = ctx->arena_zeroed[1] = false;
 	// d_rd / d_tile_start (6 GB for a human genome) are allocated by the first compute that materialises read_depth
 	if ((size_t) n_slots > ctx->h_small_cap) {
 		if (ctx->h_small)
@@ -1241,6 +1254,7 @@ int conga_chrom_compute(conga_ctx *ctx)
 		HIP_TRY(ctx, hipGraphLaunch(ctx->graph_exec, st));
 	}
 	ctx->depth_resident = dense;
+	ctx->small_cur = ctx->small_cur_next; // the arena the chain launch has just cleared, if it did
 	HIP_TRY(ctx, hipEventRecord(ctx->ev_done, st));
 	HIP_TRY(ctx, hipGetLastError());
 	ctx->computed = true;
@@ -1257,12 +1271,14 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 {
 	hipStream_t st = ctx->stream;
 	const int n_slots = (int) ctx->slots.size();
-	Small *small = ptr<Small>(ctx->d_small);
+	Small *small = reinterpret_cast<Small *>(arena_of(ctx, ctx->small_cur));
 	const Slot *dslots = ptr<Slot>(ctx->d_slots);
 	const uint8_t *gc_like = ctx->gc_like_distinct ? ptr<uint8_t>(ctx->d_gc_like) : ptr<uint8_t>(ctx->d_gc_hist);
 	const bool unsorted_mode = (ctx->opts.flags & CONGA_FLAG_READS_UNSORTED) != 0;
 
-	HIP_TRY(ctx, hipMemsetAsync(small, 0, ctx->small_bytes + (size_t) ctx->n_iv * 4, st)); // Small blocks + observed[]
+	if (!ctx->arena_zeroed[ctx->small_cur])
+		HIP_TRY(ctx, hipMemsetAsync(small, 0, ctx->arena_bytes, st)); // Small blocks + observed[]
+	ctx->arena_zeroed[ctx->small_cur] = false; // dirty from here on
 	// The Small blocks are final after expected_table unless split-read kernels add their counters later: that
 	// kernel then writes the pinned host copy itself (pinned host memory is device-visible) and the copy at the end goes away.
 	const bool small_by_kernel = !(ctx->any_sr && ctx->n_iv > 0);
@@ -1297,6 +1313,7 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 		return CONGA_OK;
 	};
 	const bool profile = (ctx->opts.flags & CONGA_FLAG_PROFILE) != 0;
+	int next_arena = ctx->small_cur;
 	if (!dense) {
 		// tuple space: the per-interval read counts need nothing but the tuples.  Outside profiling they share ONE launch
 		// with the pass over the tuples (tuple_pass_kernel); with a second stream in use they go there.
@@ -1543,7 +1560,16 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 			const int blocks_c = (int) ((c.n_iv - c.n_x - c.n_a - c.n_b + 255) / 256); // one lane per interval
 			c.table_blocks = fuse_tables ? n_slots : 0;
 			c.host_small = small_by_kernel ? ctx->h_small : nullptr;
-			hipLaunchKernelGGL(interval_chain_kernel, dim3((int) c.n_x + c.blocks_a + c.blocks_b + blocks_c + c.table_blocks), dim3(256), 0,
+			// clear the other arena on the side (not when the step is being captured into a graph: pointers are baked in)
+			const int other = ctx->small_cur ^ 1;
+			const bool zero_other = fuse_tables && !getenv("CONGA_GRAPH");
+			c.zero_blocks = zero_other ? 8 : 0;
+			c.zero_ptr = reinterpret_cast<uint4 *>(arena_of(ctx, other));
+			c.zero_n16 = (int64_t) (ctx->arena_bytes / 16);
+			next_arena = zero_other ? other : ctx->small_cur;
+			if (zero_other)
+				ctx->arena_zeroed[other] = true;
+			hipLaunchKernelGGL(interval_chain_kernel, dim3((int) c.n_x + c.blocks_a + c.blocks_b + blocks_c + c.zero_blocks + c.table_blocks), dim3(256), 0,
 					st, c);
 		}
 		if (!fused_score) {
@@ -1558,6 +1584,7 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 		}
 	}
 	TRY(join_s2());
+	ctx->small_cur_next = next_arena;
 	if (!small_by_kernel)
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->h_small, small, (size_t) n_slots * sizeof(Small), hipMemcpyDeviceToHost, st));
 	return CONGA_OK;

@@ -1413,6 +1413,9 @@ struct ChainArgs {
 	                        // writes is contiguous, so it crosses PCIe in large writes; the host un-permutes at fetch
 	int32_t table_blocks;   // > 0: that many trailing workgroups do expected_table_kernel's job (one chromosome each)
 	Small *host_small;      // its pinned host copy (may be null)
+	int32_t zero_blocks;    // > 0: that many workgroups in front of those clear the OTHER accumulator arena (the
+	uint4 *zero_ptr;        // per-chromosome blocks and observed[] the next compute will add into), so the next
+	int64_t zero_n16;       // step needs no memset launch of its own
 };
 
 // expected_read_depth[g] of chromosome sl, computed from the two histograms so that the chain does not have to wait
@@ -1917,6 +1920,12 @@ __global__ __launch_bounds__(256) void interval_chain_kernel(ChainArgs a)
 	// priority over the few long ones: they end early, and their records cross PCIe (40 us for a 1000G-sized set)
 	// while the long chains are still computing instead of after them.
 	const int grid = (int) gridDim.x - (int) a.n_x;
+	if (b >= grid - a.table_blocks - a.zero_blocks && b < grid - a.table_blocks) {
+		const int zb = b - (grid - a.table_blocks - a.zero_blocks);
+		for (int64_t i = (int64_t) zb * blockDim.x + threadIdx.x; i < a.zero_n16; i += (int64_t) a.zero_blocks * blockDim.x)
+			a.zero_ptr[i] = make_uint4(0, 0, 0, 0);
+		return;
+	}
 	if (b < a.blocks_a) {
 		chain_group_body<64, 8>(a, (int64_t) b, a.n_x, a.n_a, sE);
 	} else if (b < a.blocks_a + a.blocks_b) {
