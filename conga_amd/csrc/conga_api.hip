@@ -86,6 +86,7 @@ struct conga_ctx {
 	// (arena_bytes in all).  A compute adds into arena `small_cur`; the chain launch clears the other one on the
 	// side, so the next compute starts on a zeroed arena without a memset launch of its own.
 	size_t small_bytes = 0, arena_bytes = 0;
+	uint32_t tuple_chunks = 0, tuple_chunks_per_block = 1; // geometry of the tuple pass (prepare)
 	int small_cur = 0, small_cur_next = 0;
 	bool arena_zeroed[2] = {false, false};
 	bool wrap_risk = false;      // some position may hold more than 32767 reads: only the dense kernels reproduce the `short` wrap
@@ -104,7 +105,7 @@ struct conga_ctx {
 	bool sr_staged = false;
 
 	// device buffers
-	DevBuf d_pos, d_mapq, d_tile_start, d_small_scratch, d_item_r0, d_item_r1, d_item_row0, d_item_row1, d_item_lo, d_rd, d_gc_hist, d_gc_like, d_slots, d_small, d_map, d_winner,
+	DevBuf d_pos, d_mapq, d_tile_start, d_small_scratch, d_item_r0, d_item_r1, d_item_row0, d_item_row1, d_block_home, d_item_lo, d_rd, d_gc_hist, d_gc_like, d_slots, d_small, d_map, d_winner,
 			d_map_start, d_map_end, d_map_val, d_iv_start, d_iv_end, d_iv_type, d_iv_slot, d_iv_has_map, d_order,
 			d_expected, d_item_off, d_item_len, d_item_iv, d_item_has_map, d_item_first, d_map_part,
 			d_support, d_results, d_bases, d_row_tile, d_depth_blocks, d_support_base, d_ref, d_sat_start, d_sat_end, d_sr_pos,
@@ -300,6 +301,36 @@ int prepare(conga_ctx *ctx)
 	ctx->n_iv = iv0;
 
 	TRY(upload(ctx, ctx->d_slots, dslots.data(), dslots.size() * sizeof(Slot)));
+	{
+		// tuple pass geometry: contiguous runs of 1024-tuple chunks per workgroup, and the chromosome each run starts in
+		ctx->tuple_chunks = (uint32_t) ((ctx->n_reads_total + kTupleChunk - 1) / kTupleChunk);
+		int blocks = ctx->n_cu * 8;
+		if (const char *e = getenv("CONGA_TUPLE_BLOCKS_PER_CU")) // tuning knob
+			blocks = ctx->n_cu * std::max(1, atoi(e));
+		ctx->tuple_chunks_per_block = std::max<uint32_t>(1, (ctx->tuple_chunks + (uint32_t) blocks - 1) / (uint32_t) blocks);
+		const uint32_t grid = (ctx->tuple_chunks + ctx->tuple_chunks_per_block - 1) / ctx->tuple_chunks_per_block;
+		std::vector<TupleBlockHome> homes(std::max<uint32_t>(grid, 1));
+		int s = 0;
+		for (uint32_t b = 0; b < grid; b++) {
+			TupleBlockHome &bh = homes[b];
+			memset(&bh, 0, sizeof bh);
+			bh.sl.r0 = 1; // empty range
+			bh.slot = -1;
+			const int64_t base = (int64_t) b * ctx->tuple_chunks_per_block * kTupleChunk;
+			while (s + 1 < n_slots && ctx->slots[s + 1].read_off <= base)
+				s++;
+			const HostSlot &h = ctx->slots[s];
+			if (base >= h.read_off && base + kTupleChunk <= h.read_off + h.n_reads) { // first chunk inside one chromosome
+				bh.sl.r0 = (uint32_t) h.read_off;
+				bh.sl.r1 = (uint32_t) (h.read_off + h.n_reads);
+				bh.sl.L = (int32_t) h.L;
+				bh.sl.gc_off = (uint32_t) h.gc_off;
+				bh.slot = s;
+			}
+		}
+		TRY(upload(ctx, ctx->d_block_home, homes.data(), homes.size() * sizeof(TupleBlockHome)));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // `homes` dies here
+	}
 	{
 		// depth workgroups: contiguous tile ranges that never cross a chromosome, dispatched in genome order
 		std::vector<DepthBlock> blocks;
@@ -848,7 +879,7 @@ void conga_destroy(conga_ctx *ctx)
 	if (ctx->ev_join)
 		(void) hipEventDestroy(ctx->ev_join);
 	DevBuf *bufs[] = {&ctx->d_pos, &ctx->d_mapq, &ctx->d_tile_start, &ctx->d_small_scratch, &ctx->d_item_r0,
-			&ctx->d_item_r1, &ctx->d_item_row0, &ctx->d_item_row1, &ctx->d_item_lo, &ctx->d_rd, &ctx->d_gc_hist, &ctx->d_gc_like,
+			&ctx->d_item_r1, &ctx->d_item_row0, &ctx->d_item_row1, &ctx->d_block_home, &ctx->d_item_lo, &ctx->d_rd, &ctx->d_gc_hist, &ctx->d_gc_like,
 			&ctx->d_slots, &ctx->d_small, &ctx->d_map, &ctx->d_winner, &ctx->d_map_start, &ctx->d_map_end,
 			&ctx->d_map_val, &ctx->d_iv_start, &ctx->d_iv_end, &ctx->d_iv_type, &ctx->d_iv_slot, &ctx->d_iv_has_map,
 			&ctx->d_order, &ctx->d_expected, &ctx->d_item_off, &ctx->d_item_len, &ctx->d_item_iv,
@@ -1369,11 +1400,9 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 			a.step = ctx->step;
 			a.mq_threshold = ctx->opts.mq_threshold;
 			a.small = small;
-			a.n_chunks = (uint32_t) ((ctx->n_reads_total + kTupleChunk - 1) / kTupleChunk);
-			int blocks = ctx->n_cu * 8;
-			if (const char *e = getenv("CONGA_TUPLE_BLOCKS_PER_CU")) // tuning knob
-				blocks = ctx->n_cu * std::max(1, atoi(e));
-			a.chunks_per_block = (a.n_chunks + (uint32_t) blocks - 1) / (uint32_t) blocks;
+			a.n_chunks = ctx->tuple_chunks;
+			a.chunks_per_block = ctx->tuple_chunks_per_block;
+			a.block_home = ptr<TupleBlockHome>(ctx->d_block_home);
 			const int grid = (int) ((a.n_chunks + a.chunks_per_block - 1) / a.chunks_per_block);
 			if (fuse && (want_count || want_rows)) {
 				const int cb = want_count ? count_grid : 0, mb = want_rows ? count_grid : 0;

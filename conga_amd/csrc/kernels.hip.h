@@ -216,8 +216,8 @@ __global__ __launch_bounds__(256) void ingest_kernel(const int32_t *__restrict__
 //     workgroup-private LDS histogram (32 copies, copy c at odd stride 101 words, so one wave's atomics on one
 //     bin land in 32 different banks); one global atomic per non-empty bin when the workgroup ends or moves on
 //     to another chromosome;
-// A chunk that is not strictly inside one chromosome (its first chunk, a straddling one, the ragged end: ~45 of
-// 28,000) goes tuple by tuple into the global counters.
+// A chunk that is not inside one chromosome (a straddling one, the ragged end: ~23 of 28,000) goes tuple by tuple
+// into the global counters.
 // -------------------------------------------------------------------------------------------
 constexpr int kTupleBlock = 256;
 constexpr int kTupleChunk = kTupleBlock * 4; // tuples per workgroup step: one 16-byte position load per lane
@@ -235,12 +235,19 @@ struct TupleArgs {
 	Small *small;
 	uint32_t n_chunks;          // ceil(n_total / kTupleChunk)
 	uint32_t chunks_per_block;  // consecutive chunks per workgroup
+	const struct TupleBlockHome *block_home; // per workgroup: the chromosome of its first chunk, looked up by the host
 };
 
 struct TupleSlot {
 	uint32_t r0, r1; // tuple index range
 	int32_t L;
 	uint32_t gc_off;
+};
+
+struct TupleBlockHome { // 32 bytes: one load at workgroup start instead of a binary search over the Slot table
+	TupleSlot sl;
+	int32_t slot; // -1: the first chunk is not inside one chromosome
+	int32_t pad[3];
 };
 
 __device__ __forceinline__ TupleSlot tuple_slot(const Slot &sl)
@@ -283,7 +290,7 @@ struct GcRegs { // stage 1 -> stage 2 of a chunk: the GC bins of a lane's four t
 };
 
 // Stage 1: checks, read filter, window index, and the four GC-byte loads -- issued, not waited for.
-__device__ __forceinline__ GcRegs ingest_chunk_inside(const TupleArgs &a, const TupleSlot &sl, int home,
+__device__ __forceinline__ GcRegs ingest_chunk_inside(const TupleArgs &a, const TupleSlot &sl, int home, uint32_t base,
 		const TupleRegs &r, float inv_step, int &kept)
 {
 	const int lane = threadIdx.x & (kWave - 1);
@@ -292,7 +299,8 @@ __device__ __forceinline__ GcRegs ingest_chunk_inside(const TupleArgs &a, const 
 	int32_t prev = __shfl_up(p[3], 1, kWave); // the neighbour lane holds the tuple in front of this lane's four
 	if (lane == 0)
 		prev = r.pv;
-	if ((p[0] < prev) | (p[1] < p[0]) | (p[2] < p[1]) | (p[3] < p[2]))
+	const bool first_of_chrom = base + threadIdx.x * 4 == sl.r0; // its predecessor belongs to another chromosome
+	if (((p[0] < prev) & !first_of_chrom) | (p[1] < p[0]) | (p[2] < p[1]) | (p[3] < p[2]))
 		atomicOr(&a.small[home].status, kStatusUnsorted);
 	bool in[4];
 	int n_in = 0;
@@ -344,11 +352,15 @@ __device__ __forceinline__ void ingest_chunk_general(const TupleArgs &a, uint32_
 	int s = -1;
 	TupleSlot sl = {1, 0, 0, 0}; // empty range: the first tuple refreshes it
 	int32_t prev = (i0 > 0) ? a.pos[i0 - 1] : 0;
+	unsigned long long kept = 0; // kept tuples of chromosome s seen by this lane
 	for (int e = 0; e < 4; e++) {
 		const uint32_t i = i0 + e;
 		if (i >= n_total)
 			break;
 		if (i < sl.r0 || i >= sl.r1) {
+			if (kept)
+				atomicAdd(&a.small[s].counters[CNT_COUNTED], kept);
+			kept = 0;
 			s = find_slot(a.n_slots, (int64_t) i, [&](int k) { return a.slots[k].read_off; });
 			sl = tuple_slot(a.slots[s]);
 		}
@@ -363,15 +375,18 @@ __device__ __forceinline__ void ingest_chunk_general(const TupleArgs &a, uint32_
 			const uint32_t w = (step == 1) ? (uint32_t) p : div_tile((uint32_t) p, step, inv_step);
 			const int g = a.gc_hist[(uint64_t) sl.gc_off + w];
 			atomicAdd(&a.small[s].hist_sum[g], 1ull);
-			atomicAdd(&a.small[s].counters[CNT_COUNTED], 1ull);
+			kept++;
 		}
 	}
+	if (kept)
+		atomicAdd(&a.small[s].counters[CNT_COUNTED], kept);
 }
 
 __device__ __forceinline__ void ingest_tuples_body(const TupleArgs &a, uint32_t block, uint32_t *hist, uint32_t &kept_block)
 {
 	const uint32_t c0 = block * a.chunks_per_block;
 	const uint32_t c1 = min(c0 + a.chunks_per_block, a.n_chunks);
+	const TupleBlockHome bh = a.block_home[block]; // in flight with the tuple loads below
 	// software pipeline over the workgroup's chunks: tuples two chunks ahead, GC bytes one chunk ahead
 	TupleRegs t1 = load_tuples(a, c0, c1), t2 = load_tuples(a, c0 + 1, c1); // in flight while the histogram is cleared
 	for (int k = threadIdx.x; k < kHistCopies * kGcBins; k += kTupleBlock)
@@ -383,8 +398,8 @@ __device__ __forceinline__ void ingest_tuples_body(const TupleArgs &a, uint32_t 
 	const int lane = threadIdx.x & (kWave - 1);
 	const float inv_step = 1.0f / (float) a.step;
 	uint32_t *const my_hist = hist + (threadIdx.x & (kHistCopies - 1)) * kGcBins;
-	int home = -1; // chromosome the LDS histogram belongs to
-	TupleSlot hs = {1, 0, 0, 0};
+	int home = bh.slot; // chromosome the LDS histogram belongs to
+	TupleSlot hs = bh.sl; // (an empty range when slot is -1)
 	int kept = 0;
 	GcRegs pend = {{0, 0, 0, 0}, 0u}; // stage-1 result of the previous chunk (kmask 0: nothing pending)
 
@@ -416,7 +431,7 @@ __device__ __forceinline__ void ingest_tuples_body(const TupleArgs &a, uint32_t 
 		t1 = t2;
 		t2 = load_tuples(a, c + 2, c1);
 		const uint32_t base = c * (uint32_t) kTupleChunk;
-		if (!(base > hs.r0 && (uint64_t) base + kTupleChunk <= (uint64_t) hs.r1)) { // chunk not inside `home`
+		if (!(base >= hs.r0 && (uint64_t) base + kTupleChunk <= (uint64_t) hs.r1)) { // chunk not inside `home`
 			ingest_chunk_count(pend, my_hist); // the previous chunk still belongs to the old chromosome
 			pend.kmask = 0;
 			if (home >= 0)
@@ -424,7 +439,7 @@ __device__ __forceinline__ void ingest_tuples_body(const TupleArgs &a, uint32_t 
 			home = -1;
 			const int s = find_slot(a.n_slots, (int64_t) base, [&](int k) { return a.slots[k].read_off; });
 			const TupleSlot cand = tuple_slot(a.slots[s]);
-			if (base > cand.r0 && (uint64_t) base + kTupleChunk <= (uint64_t) cand.r1) {
+			if (base >= cand.r0 && (uint64_t) base + kTupleChunk <= (uint64_t) cand.r1) {
 				home = s;
 				hs = cand;
 			} else {
@@ -434,7 +449,7 @@ __device__ __forceinline__ void ingest_tuples_body(const TupleArgs &a, uint32_t 
 				continue;
 			}
 		}
-		const GcRegs g = ingest_chunk_inside(a, hs, home, cur, inv_step, kept); // GC loads of this chunk go out ...
+		const GcRegs g = ingest_chunk_inside(a, hs, home, base, cur, inv_step, kept); // GC loads of this chunk go out ...
 		ingest_chunk_count(pend, my_hist);                                        // ... before the previous chunk's are used
 		pend = g;
 	}
