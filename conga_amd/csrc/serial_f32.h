@@ -196,47 +196,49 @@ CONGA_HD float conga_compose_f32(uint32_t es, uint32_t ms)
 	return conga_bits_f32((es << 23) + (ms - 0x800000u));
 }
 
-// The same result as conga_repeat_add_f32 for the case the chain kernels meet all the time: k <= 1024 adds
-// (one GC window) that either stay inside the accumulator's binade or cross its top ONCE.  No loop and no integer
-// divide: the number of regular adds in front of the crossing is a quotient below 1024, so a float estimate is at
-// most one off and two 24-bit multiplies settle it; then one real add (the crossing) and one more integer step in
-// the next binade.  Anything else (mixed signs, sub-normals, a tie from an odd mantissa, a second crossing, steps
-// above 2^21 ulps) is handed to the general routine.
+// The same result as conga_repeat_add_f32, shaped for the chain kernels: k <= 1024 adds (one GC window) of a
+// non-negative normal addend.  One loop iteration per binade the accumulator passes through: the regular adds in
+// front of the binade top are one integer step -- their number is a quotient below 1024, so a float estimate is at
+// most one off and two 24-bit multiplies settle it, no integer divide -- then one real add carries the accumulator
+// across.  Wherever the integer step does not apply (accumulator still within 8x of the addend, which includes the
+// start from zero; a tie from an odd mantissa) the iteration is one literal add, which is always right.  Only
+// negative, sub-normal, infinite operands or k > 1024 go to the general routine.
 CONGA_HD float conga_window_add_f32(float s, float c, uint32_t k)
 {
-	if (k == 0)
-		return s;
-	const uint32_t bs = conga_f32_bits(s);
-	const conga_addend ca = conga_addend_of(conga_f32_bits(c));
-	const uint32_t es = bs >> 23; // a negative accumulator shows up as es >= 256: not ok
-	const conga_lean_step st = conga_step_lean(es, ca);
-	uint32_t ms = (bs & 0x7FFFFFu) | 0x800000u;
-	const bool fast = st.ok != 0u && k <= 1024u && !(st.tie != 0u && (ms & 1u) != 0u);
-	const bool room_ok = ms <= st.lim;
-	const uint32_t room = room_ok ? st.lim - ms : 0u; // < 2^24
-	if (fast && room_ok && CONGA_MUL24(k - 1u, st.delta) <= room)
-		return conga_compose_f32(es, ms + CONGA_MUL24(k, st.delta)); // the whole window inside one binade
-	if (!fast || st.delta == 0u)
+	const uint32_t bc = conga_f32_bits(c);
+	const conga_addend ca = conga_addend_of(bc);
+	if (ca.bad != 0u || k > 1024u || (conga_f32_bits(s) >> 31) != 0u)
 		return conga_repeat_add_f32(s, c, k);
-	uint32_t n1 = 0; // regular adds in front of the crossing: the last one starts at or below lim
-	if (room_ok) {
-		uint32_t q = (uint32_t) ((float) room / (float) st.delta); // true quotient < k - 1 <= 1023
-		if (CONGA_MUL24(q, st.delta) > room)
-			q--;
-		else if (CONGA_MUL24(q + 1u, st.delta) <= room)
-			q++;
-		n1 = q + 1u;
-		ms += CONGA_MUL24(n1, st.delta); // lim < ms <= 2^24
+	while (k != 0u) {
+		const uint32_t bs = conga_f32_bits(s);
+		const uint32_t es = bs >> 23;
+		if (es >= 255u)
+			return conga_repeat_add_f32(s, c, k); // inf / nan
+		const conga_lean_step st = conga_step_lean(es, ca);
+		uint32_t ms = (bs & 0x7FFFFFu) | 0x800000u;
+		if (st.ok == 0u || (st.tie != 0u && (ms & 1u) != 0u)) {
+			s = s + c; // outside the regular regime: the literal operation
+			--k;
+			continue;
+		}
+		if (st.delta == 0u)
+			return s; // +0, or an addend below half an ulp: stuck
+		const bool room_ok = ms <= st.lim;
+		const uint32_t room = room_ok ? st.lim - ms : 0u; // < 2^24
+		if (room_ok && CONGA_MUL24(k - 1u, st.delta) <= room)
+			return conga_compose_f32(es, ms + CONGA_MUL24(k, st.delta)); // the rest of the window inside this binade
+		uint32_t n1 = 0; // regular adds in front of the crossing: the last one starts at or below lim
+		if (room_ok) {
+			uint32_t q = (uint32_t) ((float) room / (float) st.delta); // true quotient < k - 1 <= 1023
+			if (CONGA_MUL24(q, st.delta) > room)
+				q--;
+			else if (CONGA_MUL24(q + 1u, st.delta) <= room)
+				q++;
+			n1 = q + 1u;
+			ms += CONGA_MUL24(n1, st.delta); // lim < ms <= 2^24
+		}
+		s = conga_compose_f32(es, ms) + c; // the add that reaches or crosses the binade top: real rounding
+		k -= n1 + 1u;
 	}
-	const float s2 = conga_compose_f32(es, ms) + c; // the add that reaches or crosses the binade top: real rounding
-	const uint32_t r = k - n1 - 1u;
-	if (r == 0)
-		return s2;
-	const uint32_t bs2 = conga_f32_bits(s2);
-	const uint32_t es2 = bs2 >> 23;
-	const conga_lean_step st2 = conga_step_lean(es2, ca);
-	const uint32_t ms2 = (bs2 & 0x7FFFFFu) | 0x800000u;
-	if (st2.ok != 0u && !(st2.tie != 0u && (ms2 & 1u) != 0u) && ms2 <= st2.lim && CONGA_MUL24(r - 1u, st2.delta) <= st2.lim - ms2)
-		return conga_compose_f32(es2, ms2 + CONGA_MUL24(r, st2.delta));
-	return conga_repeat_add_f32(s2, c, r);
+	return s;
 }

@@ -79,6 +79,25 @@ def test_one_crossing_inside_a_window(capi, ec, mc, de, back, k):
     assert bits(capi.host_repeat_add_f32(s, c, k)) == bits(naive(s, c, k))
 
 
+def test_chains_from_zero_like_the_kernels_walk_them(capi):
+    """What interval_chain does: start at 0, one call per GC window (k <= step bases of one table value), left to
+    right.  The early windows cross several binades inside one call; compare with the literal per-base loop."""
+    rng = np.random.default_rng(20221124)
+    for case in range(40):
+        table = (rng.random(12).astype(np.float32) * np.float32(10.0 ** rng.integers(-4, 2))).astype(np.float32)
+        table[rng.integers(0, 12)] = np.float32(0)
+        s_fast = np.float32(0)
+        s_ref = np.float32(0)
+        for w in range(int(rng.integers(5, 160))):
+            c = table[rng.integers(0, 12)]
+            k = int(rng.choice([1, 7, 37, 100, 100, 100, 1000, 1024]))
+            s_fast = capi.host_repeat_add_f32(s_fast, c, k)
+            with np.errstate(over="ignore"):
+                acc = np.full(k, c, np.float32)
+                s_ref = np.add.accumulate(np.concatenate([[s_ref], acc]).astype(np.float32), dtype=np.float32)[-1]
+            assert bits(s_fast) == bits(s_ref), (case, w, float(c), k)
+
+
 def test_subnormals_and_zero(capi):
     rng = np.random.default_rng(5)
     for _ in range(300):
