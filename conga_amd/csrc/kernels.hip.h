@@ -1578,16 +1578,16 @@ template <int G, int W> __device__ __forceinline__ void chain_group_body(const C
 #pragma unroll
 			for (int j = 0; j < W; j++) {
 				const uint32_t w = w0 + j;
-				k[j] = 0;
-				bc[j] = 0;
-				if (w >= (uint32_t) w_first && w < (uint32_t) w_end) {
-					const uint32_t lo = (edge > (uint32_t) s0) ? edge : (uint32_t) s0;
-					const uint32_t hi = (edge + (uint32_t) step < (uint32_t) e0) ? edge + (uint32_t) step : (uint32_t) e0;
-					k[j] = hi - lo; // >= 1
-					const uint32_t g_cur = (w < (uint32_t) n_win) ? (uint32_t) ((cur >> (8 * j)) & 0xFFu) : gc_last;
-					bc[j] = conga_f32_bits((g_cur < (uint32_t) kGcBins) ? E[g_cur] : 0.0f);
-					any_act = true;
-				}
+				// select-style on purpose: this loop and the passes below are executed by every lane, and a branch around a
+				// few instructions costs more (mask bookkeeping on the scalar unit, a refilled instruction buffer) than they do
+				const bool act = w >= (uint32_t) w_first && w < (uint32_t) w_end;
+				const uint32_t lo = (edge > (uint32_t) s0) ? edge : (uint32_t) s0;
+				const uint32_t hi = (edge + (uint32_t) step < (uint32_t) e0) ? edge + (uint32_t) step : (uint32_t) e0;
+				k[j] = act ? hi - lo : 0u; // >= 1 when active
+				const uint32_t g_cur = (w < (uint32_t) n_win) ? (uint32_t) ((cur >> (8 * j)) & 0xFFu) : gc_last;
+				const float e_cur = E[(g_cur < (uint32_t) kGcBins) ? g_cur : 0u];
+				bc[j] = (act && g_cur < (uint32_t) kGcBins) ? conga_f32_bits(e_cur) : 0u;
+				any_act |= act;
 				ca[j] = conga_addend_of(bc[j]);
 				edge += (uint32_t) step;
 			}
@@ -1611,11 +1611,8 @@ template <int G, int W> __device__ __forceinline__ void chain_group_body(const C
 				valid[j] = in[j] && st.ok != 0u && st.tie == 0u;
 				dl[j] = st.delta;
 				lim[j] = st.lim;
-				adv[j] = 0;
-				if (valid[j]) {
-					const uint32_t a32 = __umul24(k[j], st.delta);
-					adv[j] = (a32 > (1u << 24)) ? (1u << 24) : a32; // beyond the binade top anyway
-				}
+				const uint32_t a32 = __umul24(k[j], st.delta & 0x3FFFFFu); // (delta <= 2^21 whenever it is used)
+				adv[j] = !valid[j] ? 0u : (a32 > (1u << 24)) ? (1u << 24) : a32; // beyond the binade top anyway
 				lane_total += adv[j];
 			}
 			if (lane_total > (1u << 25))
@@ -1626,13 +1623,12 @@ template <int G, int W> __device__ __forceinline__ void chain_group_body(const C
 			uint32_t m_bad = 0; // mantissa in front of it
 #pragma unroll
 			for (int j = 0; j < W; j++) {
-				if (jb == W && in[j]) {
-					const bool ok = valid[j] && (dl[j] == 0 || (m <= lim[j] && __umul24(k[j] - 1u, dl[j]) <= lim[j] - m));
-					if (!ok) {
-						jb = j;
-						m_bad = m;
-					}
-				}
+				// regular: the whole run of k adds starts at or below lim.  (A stuck window, delta 0 / lim 2^24 - 1, behind
+				// a prefix that landed exactly on the binade top is sent the irregular way too: the top is the next binade.)
+				const bool ok = valid[j] & (m <= lim[j]) & (__umul24((k[j] - 1u) & 0x7FFu, dl[j] & 0x3FFFFFu) <= lim[j] - m);
+				const bool first_bad = in[j] & !ok & (jb == W);
+				jb = first_bad ? j : jb;
+				m_bad = first_bad ? m : m_bad;
 				m += adv[j];
 			}
 			const unsigned long long bad_all = __ballot(jb < W);
@@ -1721,16 +1717,14 @@ __device__ __forceinline__ void chain_block_body(const ChainArgs &a, int64_t blo
 #pragma unroll
 			for (int j = 0; j < W; j++) {
 				const uint32_t w = w0 + j;
-				k[j] = 0;
-				bc[j] = 0;
-				if (w >= (uint32_t) w_first && w < (uint32_t) w_end) {
-					const uint32_t lo = (edge > (uint32_t) s0) ? edge : (uint32_t) s0;
-					const uint32_t hi = (edge + (uint32_t) step < (uint32_t) e0) ? edge + (uint32_t) step : (uint32_t) e0;
-					k[j] = hi - lo;
-					const uint32_t g_cur = (w < (uint32_t) n_win) ? (uint32_t) ((cur >> (8 * j)) & 0xFFu) : gc_last;
-					bc[j] = conga_f32_bits((g_cur < (uint32_t) kGcBins) ? E[g_cur] : 0.0f);
-					any_act = true;
-				}
+				const bool act = w >= (uint32_t) w_first && w < (uint32_t) w_end;
+				const uint32_t lo = (edge > (uint32_t) s0) ? edge : (uint32_t) s0;
+				const uint32_t hi = (edge + (uint32_t) step < (uint32_t) e0) ? edge + (uint32_t) step : (uint32_t) e0;
+				k[j] = act ? hi - lo : 0u;
+				const uint32_t g_cur = (w < (uint32_t) n_win) ? (uint32_t) ((cur >> (8 * j)) & 0xFFu) : gc_last;
+				const float e_cur = E[(g_cur < (uint32_t) kGcBins) ? g_cur : 0u];
+				bc[j] = (act && g_cur < (uint32_t) kGcBins) ? conga_f32_bits(e_cur) : 0u;
+				any_act |= act;
 				ca[j] = conga_addend_of(bc[j]);
 				edge += (uint32_t) step;
 			}
@@ -1754,11 +1748,8 @@ __device__ __forceinline__ void chain_block_body(const ChainArgs &a, int64_t blo
 				valid[j] = in[j] && st.ok != 0u && st.tie == 0u;
 				dl[j] = st.delta;
 				lim[j] = st.lim;
-				adv[j] = 0;
-				if (valid[j]) {
-					const uint32_t a32 = __umul24(k[j], st.delta);
-					adv[j] = (a32 > (1u << 24)) ? (1u << 24) : a32;
-				}
+				const uint32_t a32 = __umul24(k[j], st.delta & 0x3FFFFFu);
+				adv[j] = !valid[j] ? 0u : (a32 > (1u << 24)) ? (1u << 24) : a32;
 				lane_total += adv[j];
 			}
 			// A regular prefix never exceeds 2^24, so every clamp below (lane 2^25, wave 2^31, workgroup 2^30) is only
@@ -1781,13 +1772,12 @@ __device__ __forceinline__ void chain_block_body(const ChainArgs &a, int64_t blo
 			uint32_t m_bad = 0;
 #pragma unroll
 			for (int j = 0; j < W; j++) {
-				if (jb == W && in[j]) {
-					const bool ok = valid[j] && (dl[j] == 0 || (m <= lim[j] && __umul24(k[j] - 1u, dl[j]) <= lim[j] - m));
-					if (!ok) {
-						jb = j;
-						m_bad = m;
-					}
-				}
+				// regular: the whole run of k adds starts at or below lim.  (A stuck window, delta 0 / lim 2^24 - 1, behind
+				// a prefix that landed exactly on the binade top is sent the irregular way too: the top is the next binade.)
+				const bool ok = valid[j] & (m <= lim[j]) & (__umul24((k[j] - 1u) & 0x7FFu, dl[j] & 0x3FFFFFu) <= lim[j] - m);
+				const bool first_bad = in[j] & !ok & (jb == W);
+				jb = first_bad ? j : jb;
+				m_bad = first_bad ? m : m_bad;
 				m += adv[j];
 			}
 			const unsigned long long bad = __ballot(jb < W);
