@@ -216,8 +216,8 @@ __global__ __launch_bounds__(256) void ingest_kernel(const int32_t *__restrict__
 //     workgroup-private LDS histogram (32 copies, copy c at odd stride 101 words, so one wave's atomics on one
 //     bin land in 32 different banks); one global atomic per non-empty bin when the workgroup ends or moves on
 //     to another chromosome;
-// A chunk that is not inside one chromosome (a straddling one, the ragged end: ~23 of 28,000) goes tuple by tuple
-// into the global counters.
+// A chunk that straddles chromosomes is taken once per chromosome with the other tuples masked out; only the
+// ragged last chunk of the batch goes tuple by tuple into the global counters.
 // -------------------------------------------------------------------------------------------
 constexpr int kTupleBlock = 256;
 constexpr int kTupleChunk = kTupleBlock * 4; // tuples per workgroup step: one 16-byte position load per lane
@@ -290,27 +290,39 @@ struct GcRegs { // stage 1 -> stage 2 of a chunk: the GC bins of a lane's four t
 };
 
 // Stage 1: checks, read filter, window index, and the four GC-byte loads -- issued, not waited for.
-__device__ __forceinline__ GcRegs ingest_chunk_inside(const TupleArgs &a, const TupleSlot &sl, int home, uint32_t base,
-		const TupleRegs &r, float inv_step, int &kept)
+// MASKED: only the tuples with index in [lo, hi) belong to chromosome `home` (a chunk that straddles two).
+template <bool MASKED> __device__ __forceinline__ GcRegs ingest_chunk_inside(const TupleArgs &a, const TupleSlot &sl, int home,
+		uint32_t base, const TupleRegs &r, float inv_step, int &kept, uint32_t lo = 0, uint32_t hi = 0)
 {
 	const int lane = threadIdx.x & (kWave - 1);
 	const uint32_t step = (uint32_t) a.step;
+	const uint32_t i0 = base + threadIdx.x * 4;
 	const int32_t p[4] = {r.q.x, r.q.y, r.q.z, r.q.w};
 	int32_t prev = __shfl_up(p[3], 1, kWave); // the neighbour lane holds the tuple in front of this lane's four
 	if (lane == 0)
 		prev = r.pv;
-	const bool first_of_chrom = base + threadIdx.x * 4 == sl.r0; // its predecessor belongs to another chromosome
-	if (((p[0] < prev) & !first_of_chrom) | (p[1] < p[0]) | (p[2] < p[1]) | (p[3] < p[2]))
+	bool mine[4] = {true, true, true, true};
+	if (MASKED) {
+#pragma unroll
+		for (int e = 0; e < 4; e++)
+			mine[e] = i0 + e >= lo && i0 + e < hi;
+	}
+	// a tuple is compared with its predecessor only when that one belongs to the same chromosome
+	bool unsorted = mine[0] & (i0 != sl.r0) & (p[0] < prev);
+#pragma unroll
+	for (int e = 1; e < 4; e++)
+		unsorted |= mine[e] & (!MASKED | (i0 + e != sl.r0)) & (p[e] < p[e - 1]);
+	if (unsorted)
 		atomicOr(&a.small[home].status, kStatusUnsorted);
 	bool in[4];
-	int n_in = 0;
+	int n_out = 0;
 #pragma unroll
 	for (int e = 0; e < 4; e++) {
-		in[e] = (uint32_t) p[e] < (uint32_t) sl.L;
-		n_in += in[e] ? 1 : 0;
+		in[e] = mine[e] & ((uint32_t) p[e] < (uint32_t) sl.L);
+		n_out += (mine[e] & !in[e]) ? 1 : 0;
 	}
-	if (n_in != 4)
-		atomicAdd(&a.small[home].counters[CNT_OUT_OF_RANGE], (unsigned long long) (4 - n_in));
+	if (n_out)
+		atomicAdd(&a.small[home].counters[CNT_OUT_OF_RANGE], (unsigned long long) n_out);
 	uint32_t w[4];
 	GcRegs out;
 	out.kmask = 0;
@@ -437,20 +449,32 @@ __device__ __forceinline__ void ingest_tuples_body(const TupleArgs &a, uint32_t 
 			if (home >= 0)
 				flush();
 			home = -1;
-			const int s = find_slot(a.n_slots, (int64_t) base, [&](int k) { return a.slots[k].read_off; });
-			const TupleSlot cand = tuple_slot(a.slots[s]);
-			if (base >= cand.r0 && (uint64_t) base + kTupleChunk <= (uint64_t) cand.r1) {
-				home = s;
-				hs = cand;
-			} else {
-				hs.r0 = 1;
-				hs.r1 = 0;
+			hs.r0 = 1;
+			hs.r1 = 0;
+			if ((uint64_t) base + kTupleChunk > (uint64_t) a.n_total) { // the ragged last chunk of the batch
 				ingest_chunk_general(a, base, inv_step);
 				continue;
 			}
+			// one masked pass per chromosome the chunk touches (usually one or two); the last one stays `home`
+			uint32_t from = base;
+			for (;;) {
+				home = find_slot(a.n_slots, (int64_t) from, [&](int k) { return a.slots[k].read_off; });
+				hs = tuple_slot(a.slots[home]);
+				const uint32_t to = min(base + (uint32_t) kTupleChunk, hs.r1);
+				if (from == base && to == base + (uint32_t) kTupleChunk)
+					break; // the whole chunk lies in this chromosome after all: the plain path below
+				const GcRegs g = ingest_chunk_inside<true>(a, hs, home, base, cur, inv_step, kept, from, to);
+				ingest_chunk_count(g, my_hist);
+				from = to;
+				if (from >= base + (uint32_t) kTupleChunk)
+					break;
+				flush();
+			}
+			if (from != base)
+				continue; // handled chromosome by chromosome
 		}
-		const GcRegs g = ingest_chunk_inside(a, hs, home, base, cur, inv_step, kept); // GC loads of this chunk go out ...
-		ingest_chunk_count(pend, my_hist);                                        // ... before the previous chunk's are used
+		const GcRegs g = ingest_chunk_inside<false>(a, hs, home, base, cur, inv_step, kept); // GC loads of this chunk go out ...
+		ingest_chunk_count(pend, my_hist);                                                  // ... before the previous chunk's are used
 		pend = g;
 	}
 	ingest_chunk_count(pend, my_hist);
