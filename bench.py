@@ -195,6 +195,8 @@ def main():
 
     units = build_units(args, world)
     flags = capi.FLAG_BATCH | (capi.FLAG_MATERIALIZE_DEPTH if args.formulation == "dense" else 0)
+    if world > 1:
+        flags |= capi.FLAG_RESULTS_ON_DEVICE  # the records travel device-to-device into the RCCL gather, not over PCIe
     ctx = capi.Context(device=local_rank, flags=flags)  # every chromosome of this rank, one launch per kernel
     mine = [make_unit(u, args) for u in units if u["owner"] == rank]
     for u in mine:

@@ -24,6 +24,7 @@ FLAG_READS_UNSORTED = 0x1
 FLAG_PROFILE = 0x2
 FLAG_BATCH = 0x4
 FLAG_MATERIALIZE_DEPTH = 0x8
+FLAG_RESULTS_ON_DEVICE = 0x10
 
 DELETION = "D"
 DUPLICATION = "E"

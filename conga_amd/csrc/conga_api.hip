@@ -118,6 +118,7 @@ struct conga_ctx {
 	size_t h_results_cap = 0;
 	std::vector<int32_t> order_pos;    // position of interval iv in the chain kernel's processing order
 	bool host_results_by_order = false; // h_results of the last compute is laid out in that order (fused scoring)
+	bool host_results_valid = false;    // h_results holds the records of the last compute (CONGA_FLAG_RESULTS_ON_DEVICE: not until fetched)
 
 	bool computed = false;
 	hipGraphExec_t graph_exec = nullptr; // the captured step; dropped whenever the layout changes
@@ -1567,8 +1568,10 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 			ChainArgs c;
 			c.fused_score = fused_score ? 1 : 0;
 			c.score = sa;
-			c.out_host = ctx->h_results;
-			ctx->host_results_by_order = fused_score;
+			const bool to_host = (ctx->opts.flags & CONGA_FLAG_RESULTS_ON_DEVICE) == 0;
+			c.out_host = to_host ? ctx->h_results : nullptr;
+			ctx->host_results_by_order = fused_score && to_host;
+			ctx->host_results_valid = to_host;
 			c.start = ptr<int32_t>(ctx->d_iv_start);
 			c.end = ptr<int32_t>(ctx->d_iv_end);
 			c.iv_slot = ptr<int32_t>(ctx->d_iv_slot);
@@ -1608,8 +1611,9 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 				const int grid = (int) ((ctx->n_iv + 63) / 64);
 				hipLaunchKernelGGL(interval_score_kernel, dim3(grid), dim3(64), 0, st, sa);
 			}
-			HIP_TRY(ctx, hipMemcpyAsync(ctx->h_results, ctx->d_results.p, (size_t) ctx->n_iv * sizeof(conga_result),
-					hipMemcpyDeviceToHost, st));
+			if ((ctx->opts.flags & CONGA_FLAG_RESULTS_ON_DEVICE) == 0)
+				HIP_TRY(ctx, hipMemcpyAsync(ctx->h_results, ctx->d_results.p, (size_t) ctx->n_iv * sizeof(conga_result),
+						hipMemcpyDeviceToHost, st));
 		}
 	}
 	TRY(join_s2());
@@ -1642,6 +1646,13 @@ int conga_chrom_fetch(conga_ctx *ctx, conga_result *dels, conga_result *dups, fl
 	const size_t nd = h->iv_start[0].size(), nu = h->iv_start[1].size();
 	if ((nd && !dels) || (nu && !dups))
 		return fail(ctx, CONGA_ERR_INVALID, "conga_chrom_fetch: result array missing");
+	if (!ctx->host_results_valid && ctx->n_iv > 0) { // CONGA_FLAG_RESULTS_ON_DEVICE: bring the records over now
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->h_results, ctx->d_results.p, (size_t) ctx->n_iv * sizeof(conga_result),
+				hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		ctx->host_results_by_order = false;
+		ctx->host_results_valid = true;
+	}
 	if (!ctx->host_results_by_order) {
 		if (nd)
 			memcpy(dels, ctx->h_results + h->iv0, nd * sizeof(conga_result));

@@ -73,6 +73,11 @@ typedef enum conga_status {
                                           and at most abutting is summed per interval straight from its rows; with
                                           this flag (or rows in any other order) it is painted base by base. */
 
+#define CONGA_FLAG_RESULTS_ON_DEVICE 0x10u /* leave the result records in HBM: a compute does not send them over PCIe, and
+                                          conga_chrom_fetch() copies them on demand.  For callers that consume the
+                                          records on the device (conga_results_device / conga_results_copy: the
+                                          multi-GPU gather over xGMI). */
+
 /* SV types, as the reference's DELETION / DUPLICATION (common.h:12-13) */
 #define CONGA_DELETION 'D'
 #define CONGA_DUPLICATION 'E'

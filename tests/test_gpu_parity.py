@@ -439,6 +439,17 @@ def test_every_chain_class_gives_the_same_sums(capi, oracle, monkeypatch, knobs)
     compare(got, want, False)
 
 
+def test_results_on_device_are_fetched_on_demand(capi, oracle):
+    """CONGA_FLAG_RESULTS_ON_DEVICE: the compute sends no records over PCIe; fetch copies them when asked, and the
+    device copy is what conga_results_copy hands to a gather."""
+    c, ds, de, us, ue = chrom_case("11", 900_000, cov=2.0, n_dels=50, n_dups=12)
+    want = run_oracle(oracle, c.length, c.gc, c.pos, c.mapq, ds, de, us, ue)
+    got = run_gpu(capi, c.length, c.gc, c.pos, c.mapq, ds, de, us, ue, flags=capi.FLAG_RESULTS_ON_DEVICE, want_tracks=False)
+    compare(got, want, False)
+    plain = run_gpu(capi, c.length, c.gc, c.pos, c.mapq, ds, de, us, ue, want_tracks=False)
+    assert got["dels"].tobytes() == plain["dels"].tobytes() and got["dups"].tobytes() == plain["dups"].tobytes()
+
+
 def test_batch_mode_matches_per_chromosome_results(capi, oracle):
     """CONGA_FLAG_BATCH: several chromosomes resident at once, every kernel launched once over the batch.
     Mixed bag on purpose: with/without mappability, no intervals, no reads, a distinct likelihood GC array."""
