@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libconga_hip.so")
+LIB_PATH = os.environ.get("CONGA_LIB_PATH") or os.path.join(_HERE, "libconga_hip.so")  # override: A/B runs of two builds
 
 CONGA_OK = 0
 CONGA_ERR_INVALID = -1

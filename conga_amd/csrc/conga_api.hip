@@ -1407,7 +1407,10 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 			const int grid = (int) ((a.n_chunks + a.chunks_per_block - 1) / a.chunks_per_block);
 			if (fuse && (want_count || want_rows)) {
 				const int cb = want_count ? count_grid : 0, mb = want_rows ? count_grid : 0;
-				hipLaunchKernelGGL(tuple_pass_kernel, dim3(cb + mb + grid), dim3(kTupleBlock), 0, st, a, c, cb, mr, mb);
+				if (mb)
+					hipLaunchKernelGGL(tuple_pass_kernel<true>, dim3(cb + mb + grid), dim3(kTupleBlock), 0, st, a, c, cb, mr, mb);
+				else
+					hipLaunchKernelGGL(tuple_pass_kernel<false>, dim3(cb + grid), dim3(kTupleBlock), 0, st, a, c, cb, mr, 0);
 			} else
 				hipLaunchKernelGGL(ingest_tuples_kernel, dim3(grid), dim3(kTupleBlock), 0, st, a);
 		}

@@ -482,7 +482,7 @@ __device__ __forceinline__ void ingest_tuples_body(const TupleArgs &a, uint32_t 
 		flush();
 }
 
-__global__ __launch_bounds__(kTupleBlock) void ingest_tuples_kernel(TupleArgs a)
+__global__ __launch_bounds__(kTupleBlock, 8) void ingest_tuples_kernel(TupleArgs a)
 {
 	__shared__ uint32_t hist[kHistCopies * kGcBins];
 	__shared__ uint32_t kept_block;
@@ -660,15 +660,15 @@ __global__ __launch_bounds__(256) void interval_map_rows_kernel(MapRowsArgs a)
 // K0' and K4' in one launch (the step is launch-gap-bound: every dependent launch costs ~10 us on this stack, and a
 // second stream's event dependency costs more than it hides): the first count_blocks workgroups search and count,
 // the rest stream the tuples.  The two halves touch disjoint outputs and only read the tuples.
-__global__ __launch_bounds__(kTupleBlock) void tuple_pass_kernel(TupleArgs a, CountArgs c, int count_blocks, MapRowsArgs m,
-		int map_blocks)
+template <bool MAP_ROWS> __global__ __launch_bounds__(kTupleBlock, 8) void tuple_pass_kernel(TupleArgs a, CountArgs c,
+		int count_blocks, MapRowsArgs m, int map_blocks)
 {
 	__shared__ uint32_t hist[kHistCopies * kGcBins];
 	__shared__ uint32_t kept_block;
 	const int b = (int) blockIdx.x;
 	if (b < count_blocks)
 		interval_count_body(c, (int64_t) b);
-	else if (b < count_blocks + map_blocks)
+	else if (MAP_ROWS && b < count_blocks + map_blocks)
 		interval_map_rows_body(m, (int64_t) (b - count_blocks));
 	else
 		ingest_tuples_body(a, (uint32_t) (b - count_blocks - map_blocks), hist, kept_block);
