@@ -69,6 +69,7 @@ struct conga_ctx {
 	int device = 0;
 	int n_cu = 256;
 	int depth_blocks_per_cu = 8; // resident depth_tile workgroups per CU (occupancy query)
+	int tuple_blocks_per_cu = 8; // resident workgroups per CU of the tuple pass: its grid is exactly one resident wave of them
 	hipStream_t stream = nullptr;
 	hipStream_t stream2 = nullptr; // runs interval_reduce beside the float chain (both are latency-bound)
 	hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_depth = nullptr, ev_counted = nullptr, ev_join = nullptr;
@@ -305,7 +306,7 @@ int prepare(conga_ctx *ctx)
 	{
 		// tuple pass geometry: contiguous runs of 1024-tuple chunks per workgroup, and the chromosome each run starts in
 		ctx->tuple_chunks = (uint32_t) ((ctx->n_reads_total + kTupleChunk - 1) / kTupleChunk);
-		int blocks = ctx->n_cu * 8;
+		int blocks = ctx->n_cu * ctx->tuple_blocks_per_cu;
 		if (const char *e = getenv("CONGA_TUPLE_BLOCKS_PER_CU")) // tuning knob
 			blocks = ctx->n_cu * std::max(1, atoi(e));
 		ctx->tuple_chunks_per_block = std::max<uint32_t>(1, (ctx->tuple_chunks + (uint32_t) blocks - 1) / (uint32_t) blocks);
@@ -838,6 +839,16 @@ conga_ctx *conga_create(int device, const conga_opts *opts, int *status)
 		int nb = 0;
 		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, depth_tile_kernel, kDepthBlock, 0) == hipSuccess && nb > 0)
 			ctx->depth_blocks_per_cu = std::min(nb, 8);
+		// the tuple pass hands each workgroup a contiguous run of chunks and sizes the grid to one resident wave of
+		// workgroups: a workgroup that had to wait for a free slot would double the launch time
+		int occ = 8;
+		for (const void *k : {(const void *) ingest_tuples_kernel, (const void *) tuple_pass_kernel<false>,
+				(const void *) tuple_pass_kernel<true>}) {
+			int n = 0;
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, kTupleBlock, 0) == hipSuccess && n > 0)
+				occ = std::min(occ, n);
+		}
+		ctx->tuple_blocks_per_cu = occ;
 	}
 	if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess)
 		return bail(CONGA_ERR_HIP);
