@@ -72,7 +72,7 @@ struct conga_ctx {
 	int tuple_blocks_per_cu = 8; // resident workgroups per CU of the tuple pass: its grid is exactly one resident wave of them
 	hipStream_t stream = nullptr;
 	hipStream_t stream2 = nullptr; // runs interval_reduce beside the float chain (both are latency-bound)
-	hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_depth = nullptr, ev_counted = nullptr, ev_join = nullptr;
+	hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_counted = nullptr, ev_join = nullptr;
 	conga_opts opts{};
 	std::string err;
 
@@ -502,7 +502,7 @@ int prepare(conga_ctx *ctx)
 			n_windows[i] = (end[i] <= start[i]) ? 0
 					: (int32_t) (((int64_t) end[i] - 1) / ctx->step - (int64_t) start[i] / ctx->step + 1);
 		// longest chains first: the lanes / groups of a wave in interval_chain_kernel then retire together, and the
-		// three classes of that kernel are contiguous ranges of order[]
+		// four classes of that kernel are contiguous ranges of order[]
 		std::iota(order.begin(), order.end(), 0);
 		std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return n_windows[x] > n_windows[y]; });
 		int32_t long_min = kChainLongWindows, serial_max = kChainSerialWindows;
@@ -857,7 +857,6 @@ conga_ctx *conga_create(int device, const conga_opts *opts, int *status)
 	if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess
 			|| hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess
 			|| hipEventCreateWithFlags(&ctx->ev_fork2, hipEventDisableTiming) != hipSuccess
-			|| hipEventCreateWithFlags(&ctx->ev_depth, hipEventDisableTiming) != hipSuccess
 			|| hipEventCreateWithFlags(&ctx->ev_counted, hipEventDisableTiming) != hipSuccess
 			|| hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess)
 		return bail(CONGA_ERR_HIP);
@@ -884,8 +883,6 @@ void conga_destroy(conga_ctx *ctx)
 		(void) hipEventDestroy(ctx->ev_fork);
 	if (ctx->ev_fork2)
 		(void) hipEventDestroy(ctx->ev_fork2);
-	if (ctx->ev_depth)
-		(void) hipEventDestroy(ctx->ev_depth);
 	if (ctx->ev_counted)
 		(void) hipEventDestroy(ctx->ev_counted);
 	if (ctx->ev_join)

@@ -1,14 +1,20 @@
 // kernels.hip.h -- gfx950 (CDNA4, wave64) kernels of the read-depth / likelihood path.
 //
-// All kernels are HBM-bound integer/byte work or short scalar chains; none is a contraction, so no
+// All kernels are HBM-bound integer/byte work, searches or short scalar chains; none is a contraction, so no
 // MFMA is used.  Every kernel works on a BATCH of chromosomes ("slots") in one launch: a whole
 // sample is a handful of launches, not a handful per chromosome.
+//
+// Two formulations of the same arithmetic:
+//   tuple / row space (default)  tuple_pass_kernel (ingest_tuples + interval_count + interval_map_rows) and
+//                                interval_chain_kernel (+ scoring): read_depth[] and mappability[] are never built
+//   dense (the reference's)      ingest_kernel, depth_tile_kernel, paint_*, interval_reduce_kernel, interval_chain_kernel,
+//                                interval_score_kernel: CONGA_FLAG_MATERIALIZE_DEPTH, unsorted reads / rows, possible wraps
 //
 // Layout in HBM; every per-chromosome array is a region of one concatenated buffer,
 // located through the Slot table:
 //   pos   int32[N], mapq uint8[N]   read tuples in BAM order (sorted by pos inside a slot)
-//   rd    int16[sum L]              bam_info.read_depth          (common.h:91)
-//   map   float[sum L]              bam_info.mappability         (common.h:92)
+//   rd    int16[sum L]              bam_info.read_depth          (common.h:91)   dense formulation only
+//   map   float[sum L]              bam_info.mappability         (common.h:92)   painted tracks only
 //   gc_*  uint8[sum n_win]          rounded GC% per `step`-base window
 //   small Small[n_slots]            status, counters, GC histogram, expected_read_depth[101]
 #pragma once
@@ -1429,21 +1435,23 @@ __device__ __forceinline__ conga_result score_interval(const ScoreArgs &a, int64
 
 // -------------------------------------------------------------------------------------------
 // K4 (chain) interval_chain: the serial float32 accumulation `expected_rd += E[gc]`
-// (likelihood.c:111,115-119), bit-exact.  One launch, three classes of intervals (order[] is sorted by the
+// (likelihood.c:111,115-119), bit-exact.  One launch, four classes of intervals (order[] is sorted by the
 // number of GC windows, longest first), so the few long chains run beside the many short ones:
-//   A  more than kChainLongWindows windows   one WAVE per interval, 8 windows per lane and step
-//   B  kChainSerialWindows + 1 .. kChainLongWindows    one 16-lane group per interval, 4 windows per lane and step
-//   C  at most kChainSerialWindows windows   one LANE per interval
+//   A+ more than kChainBlockWindows windows  one WORKGROUP per interval, 8 windows per lane and pass (2048 per pass)
+//   A  kChainLongWindows + 1 .. kChainBlockWindows      one WAVE per interval, 8 windows per lane and pass
+//   B  kChainSerialWindows + 1 .. kChainLongWindows     one 16-lane group per interval, 4 windows per lane and pass
+//   C  at most kChainSerialWindows windows    one LANE per interval
 //
 // Inside one binade of the accumulator every GC window advances the mantissa by k * delta ulps
-// (conga_step_for, serial_f32.h), an INTEGER.  A and B: each lane sums the advances of its W consecutive windows,
-// a DPP prefix sum over the lane group places them, and a window is "regular" when its whole run of k adds stays
-// below the binade top and is not an exact tie.  The first irregular window of the group (ballot + ffs, then the
-// lane's first irregular sub-window) is applied with the scalar routine conga_repeat_add_f32 -- which performs
-// the real rounding -- and the step resumes behind it in the new binade.  Irregular windows are rare (one per
-// binade crossing, i.e. O(log) per interval), so a 2 Mb interval costs ~40 + 16 passes instead of 20,000
-// dependent window updates.  C: the lane applies its windows one after the other (the same O(1) fast-forward per
-// window); 64 intervals of similar length share a wave.  Windows are always consumed left to right, so the
+// (conga_step_lean, serial_f32.h), an INTEGER.  A+, A and B: each lane sums the advances of its W consecutive
+// windows, a DPP prefix sum over the lane group (and LDS across the waves of A+) places them, and a window is
+// "regular" when its whole run of k adds stays below the binade top and is not an exact tie.  The first irregular
+// window of the group (ballot + ffs, then the lane's first irregular sub-window) is applied with
+// conga_window_add_f32 -- which performs the real rounding -- and the pass resumes behind it in the new binade.
+// Irregular windows are rare (one per binade crossing, i.e. O(log) per interval), so a 2 Mb interval costs ~10 + 16
+// passes instead of 20,000 dependent window updates.  C: the lane applies its windows one after the other (the same
+// O(1) fast-forward per window); 64 intervals of similar length share a wave.  Windows are always consumed left to
+// right, so the
 // rounding sequence is the reference's.
 // -------------------------------------------------------------------------------------------
 constexpr int kChainBlockWindows = 4096; // class A+ above this
