@@ -307,6 +307,32 @@ def test_mappability_is_exact_for_kmer_track_values(capi, oracle):
     assert np.array_equal(got["dups"]["mappability"], want["dups"]["mappability"])
 
 
+def test_mappability_sorted_rows_edge_cases(capi, oracle):
+    """Rows that qualify for the row-space sum (sorted, next start >= previous end) in their awkward forms: abutting
+    rows that share their endpoint (the later row owns the shared base: svs.c:368 paints end inclusive, in file
+    order), single-base rows, repeated starts, gaps, a row that begins before base 0 and one that ends past the
+    chromosome.  Intervals start / end on those very bases.  Exact values, so the sums must be bit-identical."""
+    c, _, _, _, _ = chrom_case("19", 300_000, cov=1.0, n_dels=5, n_dups=2, gaps=False)
+    L = c.length
+    rows = [(-50, 10, 0.5), (10, 10, 0.25), (10, 10, 0.75), (10, 500, 1.0), (500, 900, 0.5), (900, 900, 0.125),
+            (1_200, 1_200, 0.25), (1_200, 40_000, 1.0), (40_000, 40_001, 0.5), (40_001, 150_000, 0.75),
+            (150_000, 150_000, 0.125), (200_000, 250_000, 0.5), (250_000, L + 400, 0.25)]
+    ms = np.array([r[0] for r in rows], np.int32)
+    me = np.array([r[1] for r in rows], np.int32)
+    mv = np.array([r[2] for r in rows], np.float32)
+    s = np.array([0, 9, 10, 11, 400, 899, 900, 1_000, 1_199, 39_000, 40_000, 40_001, 149_000, 150_000, 199_000,
+                  249_000, L - 1_500, 5], np.int32)
+    e = np.array([1_500, 1_010, 1_011, 2_000, 1_400, 1_900, 1_901, 2_500, 41_000, 41_000, 41_001, 42_000, 151_000,
+                  151_001, 251_000, L, L, L], np.int32)
+    ds, de = synth.kept_sorted(s, e)
+    us, ue = ds[::3], de[::3]
+    want = run_oracle(oracle, L, c.gc, c.pos, c.mapq, ds, de, us, ue, rows=(ms, me, mv))
+    got = run_gpu(capi, L, c.gc, c.pos, c.mapq, ds, de, us, ue, rows=(ms, me, mv))
+    compare(got, want, True)
+    assert np.array_equal(got["dels"]["mappability"], want["dels"]["mappability"])
+    assert np.array_equal(got["dups"]["mappability"], want["dups"]["mappability"])
+
+
 def test_replay_is_idempotent_and_split_support_is_copied_through(capi, oracle):
     c, ds, de, us, ue = chrom_case("20", 600_000, cov=1.0, n_dels=30, n_dups=8, gaps=False)
     with capi.Context(device=0, flags=capi.FLAG_PROFILE) as ctx:
