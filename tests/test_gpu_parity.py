@@ -465,6 +465,26 @@ def test_every_chain_class_gives_the_same_sums(capi, oracle, monkeypatch, knobs)
     compare(got, want, False)
 
 
+def test_graph_replay_gives_the_same_records(capi, oracle, monkeypatch):
+    """CONGA_GRAPH=1: from the third compute of an unchanged layout the step is replayed from a captured hipGraph."""
+    c, ds, de, us, ue = chrom_case("12", 700_000, cov=2.0, n_dels=40, n_dups=10)
+    want = run_oracle(oracle, c.length, c.gc, c.pos, c.mapq, ds, de, us, ue)
+    monkeypatch.setenv("CONGA_GRAPH", "1")
+    with capi.Context(device=0) as ctx:
+        ctx.chrom_begin(c.length, c.gc)
+        ctx.reads(c.pos, c.mapq)
+        ctx.intervals("D", ds, de)
+        ctx.intervals("E", us, ue)
+        runs = []
+        for _ in range(5):
+            ctx.compute()
+            dels, dups, E, st = ctx.fetch()
+            runs.append((dels.tobytes(), dups.tobytes(), E.tobytes(), st.reads_counted))
+        assert all(r == runs[0] for r in runs)
+        assert_records(dels, want["dels"], False)
+        assert_records(dups, want["dups"], False)
+
+
 def test_results_on_device_are_fetched_on_demand(capi, oracle):
     """CONGA_FLAG_RESULTS_ON_DEVICE: the compute sends no records over PCIe; fetch copies them when asked, and the
     device copy is what conga_results_copy hands to a gather."""
