@@ -54,6 +54,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="lower bound of CPU-baseline work (oracle, 1 thread); 0 disables the leg")
     ap.add_argument("--chroms", type=str, default="", help="comma list of chromosome names (debug)")
+    ap.add_argument("--results-on-device", action="store_true",
+                    help="CONGA_FLAG_RESULTS_ON_DEVICE at N=1 too (what every rank of a multi-GPU run does)")
     ap.add_argument("--no-dense-leg", dest="dense_leg", action="store_false",
                     help="skip the dense-formulation leg that follows the timed region at N=1")
     return ap.parse_args()
@@ -195,7 +197,7 @@ def main():
 
     units = build_units(args, world)
     flags = capi.FLAG_BATCH | (capi.FLAG_MATERIALIZE_DEPTH if args.formulation == "dense" else 0)
-    if world > 1:
+    if world > 1 or args.results_on_device:
         flags |= capi.FLAG_RESULTS_ON_DEVICE  # the records travel device-to-device into the RCCL gather, not over PCIe
     ctx = capi.Context(device=local_rank, flags=flags)  # every chromosome of this rank, one launch per kernel
     mine = [make_unit(u, args) for u in units if u["owner"] == rank]

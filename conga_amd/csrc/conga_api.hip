@@ -1598,8 +1598,10 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 			c.n_b = ctx->n_chain_b;
 			c.n_iv = ctx->n_iv;
 			c.n_slots = n_slots;
-			c.blocks_a = (int32_t) ((c.n_a + 3) / 4);   // one wave per interval, 4 waves per block
-			c.blocks_b = (int32_t) ((c.n_b + 15) / 16); // four 16-lane groups per wave
+			// classes A and B share workgroups: one class-A wave in each of the first n_a, class-B waves (four 16-lane
+			// groups each) in every other slot
+			const int64_t waves_b = (c.n_b + 3) / 4;
+			c.blocks_ab = (int32_t) (waves_b <= 3 * c.n_a ? c.n_a : c.n_a + (waves_b - 3 * c.n_a + 3) / 4);
 			const int blocks_c = (int) ((c.n_iv - c.n_x - c.n_a - c.n_b + 255) / 256); // one lane per interval
 			c.table_blocks = fuse_tables ? n_slots : 0;
 			c.host_small = small_by_kernel ? ctx->h_small : nullptr;
@@ -1612,7 +1614,7 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 			next_arena = zero_other ? other : ctx->small_cur;
 			if (zero_other)
 				ctx->arena_zeroed[other] = true;
-			hipLaunchKernelGGL(interval_chain_kernel, dim3((int) c.n_x + c.blocks_a + c.blocks_b + blocks_c + c.zero_blocks + c.table_blocks), dim3(256), 0,
+			hipLaunchKernelGGL(interval_chain_kernel, dim3((int) c.n_x + c.blocks_ab + blocks_c + c.zero_blocks + c.table_blocks), dim3(256), 0,
 					st, c);
 		}
 		if (!fused_score) {

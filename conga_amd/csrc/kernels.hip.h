@@ -1341,8 +1341,9 @@ __global__ __launch_bounds__(256) void interval_reduce_kernel(ReduceArgs a)
 // K5 scoring: lpoisson x3, the int-truncated max, the c-score and the CN call (likelihood.c:96-105,131-168).
 // Used by interval_score_kernel (one lane per interval) and, when every input of an interval is final before its
 // chain starts (tuple space, no mappability track), by the chain kernel itself: the lane that finishes an
-// interval's chain scores it and writes the record to HBM and straight into the caller's pinned host buffer, so
-// the records of the short chains cross PCIe while the long chains are still running.
+// interval's chain scores it and writes the record to HBM and straight into the caller's pinned host buffer: no
+// score launch, no copy launch, no gaps between them.  (The stores reach the host when the kernel ends -- measured,
+// tools/hostwrite.hip -- so the PCIe time itself is not hidden.)
 // -------------------------------------------------------------------------------------------
 struct ScoreArgs {
 	const int32_t *start;
@@ -1465,7 +1466,7 @@ struct ChainArgs {
 	const int32_t *iv_slot;
 	const int32_t *order; // interval ids, longest first
 	int64_t n_x, n_a, n_b, n_iv; // order[0, n_x): class A+, [n_x, n_x + n_a): class A, then n_b of class B, the rest: class C
-	int32_t blocks_a, blocks_b;   // class A+ takes n_x workgroups in front of these
+	int32_t blocks_ab;            // workgroups shared by classes A and B (behind the n_x of class A+)
 	int32_t n_slots;
 	const uint8_t *gc_like;
 	const Slot *slots;
@@ -1476,7 +1477,7 @@ struct ChainArgs {
 	int32_t fused_score;   // 1: score each interval as its chain ends (score.observed etc. are final already)
 	ScoreArgs score;
 	conga_result *out_host; // pinned host copy of the records (may be null), in the order of order[]: what one wave
-	                        // writes is contiguous, so it crosses PCIe in large writes; the host un-permutes at fetch
+	                        // writes is contiguous; the host un-permutes at fetch
 	int32_t table_blocks;   // > 0: that many trailing workgroups do expected_table_kernel's job (one chromosome each)
 	Small *host_small;      // its pinned host copy (may be null)
 	int32_t zero_blocks;    // > 0: that many workgroups in front of those clear the OTHER accumulator arena (the
@@ -1558,8 +1559,9 @@ __device__ __forceinline__ ChainInterval chain_interval(const ChainArgs &a, int6
 }
 
 // Classes A (G = 64, W = 8) and B (G = 16, W = 4).
-template <int G, int W> __device__ __forceinline__ void chain_group_body(const ChainArgs &a, int64_t block, int64_t first,
-		int64_t count, float *sE_raw)
+// `wave`: index of this wave inside its class; `sE_wave`: this wave's LDS (one depth table per lane group).
+template <int G, int W> __device__ __forceinline__ void chain_group_body(const ChainArgs &a, int64_t wave, int64_t first,
+		int64_t count, float *sE_wave)
 {
 	constexpr int kGroups = kWave / G;
 	constexpr int SW = G * W; // windows per step
@@ -1569,10 +1571,9 @@ template <int G, int W> __device__ __forceinline__ void chain_group_body(const C
 	const int gl = lane & (G - 1);  // lane inside the group
 	const int grp = lane / G;       // group inside the wave
 	const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << (grp * G));
-	const int64_t wave = (block * blockDim.x + threadIdx.x) / kWave;
 	const int64_t slot_idx = wave * kGroups + grp;
 	const bool have = slot_idx < count;
-	float *E = sE_raw + (threadIdx.x / G) * (kGcBins + 3);
+	float *E = sE_wave + grp * (kGcBins + 3);
 
 	ChainInterval ci = {0, 0, 0, 0, 0, 1, a.gc_like, 0};
 	if (have) {
@@ -1926,7 +1927,7 @@ template <bool LDS_TABLES> __device__ __forceinline__ void chain_serial_lanes(co
 	}
 	// Scored here, and the pinned host copy written as one contiguous 4 KiB run per wave: every lane parks its record
 	// in LDS, then four neighbouring lanes write one record's four 16-byte quarters, sixteen records (1 KiB) per
-	// instruction -- large PCIe writes instead of sixteen-byte crumbs.
+	// instruction.
 	const int lane = threadIdx.x & (kWave - 1);
 	uint4 *my_stage = stage + (size_t) (threadIdx.x / kWave) * kWave * 4; // this wave's 64 records
 	if (have) {
@@ -1973,9 +1974,9 @@ __global__ __launch_bounds__(256) void interval_chain_kernel(ChainArgs a)
 		return;
 	}
 	b -= (int) a.n_x;
-	// The launch is instruction-issue-bound and the classes share SIMDs.  The many short chains are given issue
-	// priority over the few long ones: they end early, and their records cross PCIe (40 us for a 1000G-sized set)
-	// while the long chains are still computing instead of after them.
+	// The classes share SIMDs.  Giving the many short chains issue priority over the few long ones was measured
+	// 13 us faster than equal priorities (and than favouring the long ones): their waves retire early and leave the
+	// SIMDs to the long chains.
 	const int grid = (int) gridDim.x - (int) a.n_x;
 	if (b >= grid - a.table_blocks - a.zero_blocks && b < grid - a.table_blocks) {
 		const int zb = b - (grid - a.table_blocks - a.zero_blocks);
@@ -1983,18 +1984,27 @@ __global__ __launch_bounds__(256) void interval_chain_kernel(ChainArgs a)
 			a.zero_ptr[i] = make_uint4(0, 0, 0, 0);
 		return;
 	}
-	if (b < a.blocks_a) {
-		chain_group_body<64, 8>(a, (int64_t) b, a.n_x, a.n_a, sE);
-	} else if (b < a.blocks_a + a.blocks_b) {
-		__builtin_amdgcn_s_setprio(2);
-		chain_group_body<16, 4>(a, (int64_t) (b - a.blocks_a), a.n_x + a.n_a, a.n_b, sE);
+	if (b < a.blocks_ab) {
+		// Classes A and B share workgroups: one wave of each of the first n_a workgroups takes a long chain (class A,
+		// the slot rotates so that they land on different SIMDs), every other wave takes four class-B chains.  Packing
+		// four long chains into one workgroup put them on one CU, whose SIMDs then ran 1.5x the work of the others.
+		const int wid = threadIdx.x / kWave;
+		float *sE_wave = sE + wid * 4 * (kGcBins + 3);
+		const int a_slot = b & 3;
+		if (b < (int) a.n_a && wid == a_slot)
+			chain_group_body<64, 8>(a, (int64_t) b, a.n_x, a.n_a, sE_wave);
+		else {
+			const int64_t bw = (b < (int) a.n_a) ? (int64_t) b * 3 + (wid - (wid > a_slot ? 1 : 0))
+					: a.n_a * 3 + ((int64_t) b - a.n_a) * 4 + wid;
+			__builtin_amdgcn_s_setprio(2);
+			chain_group_body<16, 4>(a, bw, a.n_x + a.n_a, a.n_b, sE_wave);
+		}
 	} else if (b >= grid - a.table_blocks) {
 		__builtin_amdgcn_s_setprio(3);
 		expected_table_body(a.small, a.bases, a.host_small, b - (grid - a.table_blocks));
 	} else {
 		__builtin_amdgcn_s_setprio(3);
-		chain_serial_body(a, (int64_t) (b - a.blocks_a - a.blocks_b), a.n_x + a.n_a + a.n_b,
-				a.n_iv - a.n_x - a.n_a - a.n_b, sE, stage);
+		chain_serial_body(a, (int64_t) (b - a.blocks_ab), a.n_x + a.n_a + a.n_b, a.n_iv - a.n_x - a.n_a - a.n_b, sE, stage);
 	}
 
 }
