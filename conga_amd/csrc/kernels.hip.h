@@ -1970,6 +1970,7 @@ __global__ __launch_bounds__(256) void interval_chain_kernel(ChainArgs a)
 	__shared__ uint32_t xw[64];      // class A+: what the four waves of a pass tell each other
 	int b = (int) blockIdx.x;
 	if (b < (int) a.n_x) {
+		__builtin_amdgcn_s_setprio(3); // a handful of workgroups, and the longest critical path of the launch
 		chain_block_body(a, (int64_t) b, 0, a.n_x, sE, xw);
 		return;
 	}
@@ -1992,7 +1993,7 @@ __global__ __launch_bounds__(256) void interval_chain_kernel(ChainArgs a)
 		float *sE_wave = sE + wid * 4 * (kGcBins + 3);
 		const int a_slot = b & 3;
 		if (b < (int) a.n_a && wid == a_slot)
-			chain_group_body<64, 8>(a, (int64_t) b, a.n_x, a.n_a, sE_wave);
+			chain_group_body<64, 4>(a, (int64_t) b, a.n_x, a.n_a, sE_wave);
 		else {
 			const int64_t bw = (b < (int) a.n_a) ? (int64_t) b * 3 + (wid - (wid > a_slot ? 1 : 0))
 					: a.n_a * 3 + ((int64_t) b - a.n_a) * 4 + wid;
