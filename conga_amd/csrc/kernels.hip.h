@@ -1455,7 +1455,7 @@ __device__ __forceinline__ conga_result score_interval(const ScoreArgs &a, int64
 // right, so the
 // rounding sequence is the reference's.
 // -------------------------------------------------------------------------------------------
-constexpr int kChainBlockWindows = 4096; // class A+ above this
+constexpr int kChainBlockWindows = 2048; // class A+ above this
 constexpr int kChainLongWindows = 512;
 constexpr int kChainSerialWindows = 64;
 constexpr int kChainSerialMaxSlots = 32; // class C keeps every chromosome's table in LDS up to this many
