@@ -106,7 +106,7 @@ struct conga_ctx {
 	bool sr_staged = false;
 
 	// device buffers
-	DevBuf d_pos, d_mapq, d_tile_start, d_small_scratch, d_item_r0, d_item_r1, d_item_row0, d_item_row1, d_block_home, d_item_lo, d_rd, d_gc_hist, d_gc_like, d_slots, d_small, d_map, d_winner,
+	DevBuf d_pos, d_mapq, d_tile_start, d_small_scratch, d_item_r0, d_item_r1, d_item_row0, d_item_row1, d_item_rt_off, d_block_home, d_item_lo, d_rd, d_gc_hist, d_gc_like, d_slots, d_small, d_map, d_winner,
 			d_map_start, d_map_end, d_map_val, d_iv_start, d_iv_end, d_iv_type, d_iv_slot, d_iv_has_map, d_order,
 			d_expected, d_item_off, d_item_len, d_item_iv, d_item_has_map, d_item_first, d_map_part,
 			d_support, d_results, d_bases, d_row_tile, d_depth_blocks, d_support_base, d_ref, d_sat_start, d_sat_end, d_sr_pos,
@@ -532,7 +532,7 @@ int prepare(conga_ctx *ctx)
 		// reduce work items: [start, min(end, L)) cut into kItemLen pieces
 		std::vector<int64_t> item_off;
 		std::vector<int32_t> item_len, item_iv, item_lo;
-		std::vector<uint32_t> item_r0, item_r1, item_row0, item_row1;
+		std::vector<uint32_t> item_r0, item_r1, item_row0, item_row1, item_rt_off;
 		std::vector<uint8_t> item_has_map;
 		item_off.reserve(n + n / 2);
 		item_len.reserve(n + n / 2);
@@ -552,6 +552,7 @@ int prepare(conga_ctx *ctx)
 				item_r1.push_back((uint32_t) (h.read_off + h.n_reads));
 				item_row0.push_back((uint32_t) h.map_row_off);
 				item_row1.push_back((uint32_t) (h.map_row_off + (int64_t) h.map_start.size()));
+				item_rt_off.push_back((uint32_t) h.row_tile_off);
 			}
 		}
 		item_first[n] = (int32_t) item_off.size();
@@ -573,6 +574,7 @@ int prepare(conga_ctx *ctx)
 		TRY(upload(ctx, ctx->d_item_r1, item_r1.data(), item_r1.size() * 4));
 		TRY(upload(ctx, ctx->d_item_row0, item_row0.data(), item_row0.size() * 4));
 		TRY(upload(ctx, ctx->d_item_row1, item_row1.data(), item_row1.size() * 4));
+		TRY(upload(ctx, ctx->d_item_rt_off, item_rt_off.data(), item_rt_off.size() * 4));
 		TRY(ensure(ctx, ctx->d_expected, n * 4));
 		TRY(ensure(ctx, ctx->d_map_part, std::max<size_t>(item_off.size(), 1) * 8));
 		TRY(ensure(ctx, ctx->d_results, n * sizeof(conga_result)));
@@ -888,7 +890,7 @@ void conga_destroy(conga_ctx *ctx)
 	if (ctx->ev_join)
 		(void) hipEventDestroy(ctx->ev_join);
 	DevBuf *bufs[] = {&ctx->d_pos, &ctx->d_mapq, &ctx->d_tile_start, &ctx->d_small_scratch, &ctx->d_item_r0,
-			&ctx->d_item_r1, &ctx->d_item_row0, &ctx->d_item_row1, &ctx->d_block_home, &ctx->d_item_lo, &ctx->d_rd, &ctx->d_gc_hist, &ctx->d_gc_like,
+			&ctx->d_item_r1, &ctx->d_item_row0, &ctx->d_item_row1, &ctx->d_item_rt_off, &ctx->d_block_home, &ctx->d_item_lo, &ctx->d_rd, &ctx->d_gc_hist, &ctx->d_gc_like,
 			&ctx->d_slots, &ctx->d_small, &ctx->d_map, &ctx->d_winner, &ctx->d_map_start, &ctx->d_map_end,
 			&ctx->d_map_val, &ctx->d_iv_start, &ctx->d_iv_end, &ctx->d_iv_type, &ctx->d_iv_slot, &ctx->d_iv_has_map,
 			&ctx->d_order, &ctx->d_expected, &ctx->d_item_off, &ctx->d_item_len, &ctx->d_item_iv,
@@ -1378,11 +1380,14 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 		mr.row_val = ptr<float>(ctx->d_map_val);
 		mr.item_row0 = ptr<uint32_t>(ctx->d_item_row0);
 		mr.item_row1 = ptr<uint32_t>(ctx->d_item_row1);
+		mr.row_tile = ptr<uint32_t>(ctx->d_row_tile);
+		mr.item_rt_off = ptr<uint32_t>(ctx->d_item_rt_off);
 		mr.item_lo = ptr<int32_t>(ctx->d_item_lo);
 		mr.item_len = ptr<int32_t>(ctx->d_item_len);
 		mr.item_has_map = ptr<uint8_t>(ctx->d_item_has_map);
 		mr.n_items = ctx->n_items;
 		mr.map_part = ptr<double>(ctx->d_map_part);
+		const int map_grid = (int) ((ctx->n_items + kMapRowsItemsPerBlock - 1) / kMapRowsItemsPerBlock);
 		const bool fuse = !profile && !two_streams && ctx->n_reads_total > 0;
 		if (want_count && !fuse) {
 			TRY(fork_to_s2(ctx->ev_fork));
@@ -1395,7 +1400,7 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 		}
 		if (want_rows && !fuse) {
 			KernelTimer t(ctx, CONGA_K_REDUCE);
-			hipLaunchKernelGGL(interval_map_rows_kernel, dim3(count_grid), dim3(256), 0, st, mr);
+			hipLaunchKernelGGL(interval_map_rows_kernel, dim3(map_grid), dim3(256), 0, st, mr);
 		}
 		KernelTimer t(ctx, CONGA_K_INGEST);
 		if (ctx->n_reads_total > 0) {
@@ -1414,7 +1419,7 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 			a.block_home = ptr<TupleBlockHome>(ctx->d_block_home);
 			const int grid = (int) ((a.n_chunks + a.chunks_per_block - 1) / a.chunks_per_block);
 			if (fuse && (want_count || want_rows)) {
-				const int cb = want_count ? count_grid : 0, mb = want_rows ? count_grid : 0;
+				const int cb = want_count ? count_grid : 0, mb = want_rows ? map_grid : 0;
 				if (mb)
 					hipLaunchKernelGGL(tuple_pass_kernel<true>, dim3(cb + mb + grid), dim3(kTupleBlock), 0, st, a, c, cb, mr, mb);
 				else

@@ -588,6 +588,8 @@ struct MapRowsArgs {
 	const float *row_val;
 	const uint32_t *item_row0; // row range of the item's chromosome (indices into the arrays above)
 	const uint32_t *item_row1;
+	const uint32_t *row_tile;    // per chromosome: first row (chromosome-local) that starts in 1024-base tile t or later
+	const uint32_t *item_rt_off; // where the item's chromosome begins in row_tile
 	const int32_t *item_lo;
 	const int32_t *item_len;
 	const uint8_t *item_has_map; // 1: summed here, 2: summed from the painted track by interval_reduce, 0: no track
@@ -595,21 +597,28 @@ struct MapRowsArgs {
 	double *map_part; // [n_items]
 };
 
+// items a workgroup of 256 lanes takes: one per 16-lane row
+constexpr int kMapRowsItemsPerBlock = 16;
+
 __device__ __forceinline__ void interval_map_rows_body(const MapRowsArgs &a, int64_t block)
 {
-	const int lane = threadIdx.x & (kWave - 1);
-	const int64_t item = block * blockDim.x + threadIdx.x;
-	const bool have = item < a.n_items && a.item_has_map[item] == 1;
-	int32_t lo = 0, hi = 0;
-	uint32_t r1 = 0, a0 = 0, a1 = 0, b0 = 0, b1 = 0;
-	if (have) {
-		lo = a.item_lo[item];
-		hi = lo + a.item_len[item];
-		a0 = b0 = a.item_row0[item];
-		a1 = b1 = r1 = a.item_row1[item];
-	}
-	const uint32_t r0 = a0;
-	while (__any(a0 < a1 || b0 < b1)) { // a: first row with start > lo; b: first row with start >= hi
+	// One 16-lane DPP row per item, no traffic between rows: every lane of the row runs the (short) searches, then
+	// the row walks the item's rows with stride 16 and sums inside the row.  Many short independent waves hide the
+	// memory latency that a wave walking 64 items one after the other could not.
+	const int gl = threadIdx.x & 15;
+	const int64_t item = block * kMapRowsItemsPerBlock + (threadIdx.x >> 4);
+	if (item >= a.n_items || a.item_has_map[item] != 1)
+		return; // uniform inside the row (a row never waits for another one below)
+	const int32_t lo = a.item_lo[item], hi = lo + a.item_len[item];
+	const uint32_t r0 = a.item_row0[item], r1 = a.item_row1[item];
+	// the per-tile row index of the track (built once per layout for the painter) narrows both searches to the rows
+	// of one 1024-base tile: ~3 probes instead of ~20 over a million rows
+	const uint32_t *rt = a.row_tile + a.item_rt_off[item];
+	const uint32_t m = r1 - r0;
+	const uint32_t ta = (uint32_t) lo >> 10, tb = (uint32_t) hi >> 10;
+	uint32_t a0 = r0 + min(rt[ta], m), a1 = r0 + min(rt[ta + 1], m); // first row with start > lo
+	uint32_t b0 = r0 + min(rt[tb], m), b1 = r0 + min(rt[tb + 1], m); // first row with start >= hi
+	while (a0 < a1 || b0 < b1) {
 		const uint32_t ma = a0 + ((a1 - a0) >> 1), mb = b0 + ((b1 - b0) >> 1);
 		const int32_t sa = (a0 < a1) ? a.row_start[ma] : 0;
 		const int32_t sb = (b0 < b1) ? a.row_start[mb] : 0;
@@ -626,36 +635,49 @@ __device__ __forceinline__ void interval_map_rows_body(const MapRowsArgs &a, int
 				b1 = mb;
 		}
 	}
-	const uint32_t k_lo = (a0 > r0) ? a0 - 1 : r0; // the last row that starts at or before lo may still cover it
-	const uint32_t k_hi = b0;
-	double mine = 0.0;
-	for (int i = 0; i < kWave; i++) {
-		if (!__builtin_amdgcn_readlane(have ? 1 : 0, i))
-			continue; // wave-uniform
-		const uint32_t u = (uint32_t) __builtin_amdgcn_readlane((int) k_lo, i);
-		const uint32_t v = (uint32_t) __builtin_amdgcn_readlane((int) k_hi, i);
-		const uint32_t end_rows = (uint32_t) __builtin_amdgcn_readlane((int) r1, i);
-		const int32_t lo_i = __builtin_amdgcn_readlane(lo, i), hi_i = __builtin_amdgcn_readlane(hi, i);
-		double acc = 0.0;
-		for (uint32_t j0 = u; j0 < v; j0 += kWave) {
-			const uint32_t j = j0 + lane;
-			if (j < v) {
-				const int32_t s = a.row_start[j], e = a.row_end[j];
-				const int32_t nxt = (j + 1 < end_rows) ? a.row_start[j + 1] : INT32_MAX;
-				const int32_t eff = (e < nxt - 1) ? e : nxt - 1;
-				const int32_t from = (s > lo_i) ? s : lo_i;
-				const int32_t to = (eff < hi_i - 1) ? eff : hi_i - 1;
-				if (to >= from)
-					acc += (double) a.row_val[j] * (double) (to - from + 1);
-			}
+	const uint32_t u = (a0 > r0) ? a0 - 1 : r0; // the last row that starts at or before lo may still cover it
+	const uint32_t v = b0;
+	double acc = 0.0;
+	// eight strided rows per lane are requested before the first is used (128 rows per pass: the whole item in one
+	// memory round trip for a 100-mer track); longer row ranges take more passes
+	for (uint32_t j0 = u + gl; j0 < v; j0 += 128) {
+		int32_t rs[8], re[8], rn[8];
+		float rv[8];
+#pragma unroll
+		for (int q = 0; q < 8; q++) {
+			const uint32_t j = j0 + 16 * q;
+			const bool in = j < v;
+			rs[q] = in ? a.row_start[j] : 0;
+			re[q] = in ? a.row_end[j] : -1;
+			rn[q] = (in && j + 1 < r1) ? a.row_start[j + 1] : INT32_MAX;
+			rv[q] = in ? a.row_val[j] : 0.0f;
 		}
-		acc = wave_sum_f64(acc); // total in lane 0
-		const double total = __shfl(acc, 0, kWave);
-		if (lane == i)
-			mine = total;
+#pragma unroll
+		for (int q = 0; q < 8; q++) {
+			const int32_t eff = (re[q] < rn[q] - 1) ? re[q] : rn[q] - 1;
+			const int32_t from = (rs[q] > lo) ? rs[q] : lo;
+			const int32_t to = (eff < hi - 1) ? eff : hi - 1;
+			if (j0 + 16 * q < v && to >= from)
+				acc += (double) rv[q] * (double) (to - from + 1);
+		}
 	}
-	if (have)
-		a.map_part[item] = mine;
+	// sum over the 16 lanes of the row: row_shr 1, 2, 4, 8 leave the total in the row's last lane (lanes shifted in
+	// from outside the row add +0.0)
+#pragma unroll
+	for (int sh = 0; sh < 4; sh++) {
+		const uint64_t bits = __double_as_longlong(acc);
+		const uint32_t lo32 = (uint32_t) (sh == 0 ? __builtin_amdgcn_update_dpp(0, (int) (uint32_t) bits, 0x111, 0xF, 0xF, true)
+				: sh == 1 ? __builtin_amdgcn_update_dpp(0, (int) (uint32_t) bits, 0x112, 0xF, 0xF, true)
+				: sh == 2 ? __builtin_amdgcn_update_dpp(0, (int) (uint32_t) bits, 0x114, 0xF, 0xF, true)
+				          : __builtin_amdgcn_update_dpp(0, (int) (uint32_t) bits, 0x118, 0xF, 0xF, true));
+		const uint32_t hi32 = (uint32_t) (sh == 0 ? __builtin_amdgcn_update_dpp(0, (int) (uint32_t) (bits >> 32), 0x111, 0xF, 0xF, true)
+				: sh == 1 ? __builtin_amdgcn_update_dpp(0, (int) (uint32_t) (bits >> 32), 0x112, 0xF, 0xF, true)
+				: sh == 2 ? __builtin_amdgcn_update_dpp(0, (int) (uint32_t) (bits >> 32), 0x114, 0xF, 0xF, true)
+				          : __builtin_amdgcn_update_dpp(0, (int) (uint32_t) (bits >> 32), 0x118, 0xF, 0xF, true));
+		acc += __longlong_as_double((long long) (((uint64_t) hi32 << 32) | lo32));
+	}
+	if (gl == 15)
+		a.map_part[item] = acc;
 }
 
 __global__ __launch_bounds__(256) void interval_map_rows_kernel(MapRowsArgs a)
