@@ -309,7 +309,8 @@ def main():
         out = dict(metric="CNV intervals genotyped/sec (1000G Phase-3 set); CN-call concordance vs ref",
                    value=round(total_iv * args.steps / elapsed, 1), unit="intervals/s", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
-                   higher_is_better=True, scaling=args.scaling, vs_baseline=None, dtype="i16/i32+f32/f64",
+                   higher_is_better=True, scaling=args.scaling, vs_baseline=None,
+                   dtype="i16/i32+f32/f64" if dense_ran else "i32+f32/f64",  # counts, serial float32 chain, double scores
                    data="synthetic", config=cfg, roofline=roofline,
                    formulation="dense" if dense_ran else "tuple-space",
                    dense_equivalent=dict(bytes=int(dense), achieved=round(dense / (ms_per_step * 1e-3) / 1e9, 1),
