@@ -222,8 +222,8 @@ __global__ __launch_bounds__(256) void ingest_kernel(const int32_t *__restrict__
 //     workgroup-private LDS histogram (32 copies, copy c at odd stride 101 words, so one wave's atomics on one
 //     bin land in 32 different banks); one global atomic per non-empty bin when the workgroup ends or moves on
 //     to another chromosome;
-// A chunk that straddles chromosomes is taken once per chromosome with the other tuples masked out; only the
-// ragged last chunk of the batch goes tuple by tuple into the global counters.
+// A chunk that straddles chromosomes (or is cut short by the end of the batch) is taken once per chromosome with
+// the other tuples masked out.
 // -------------------------------------------------------------------------------------------
 constexpr int kTupleBlock = 256;
 constexpr int kTupleChunk = kTupleBlock * 4; // tuples per workgroup step: one 16-byte position load per lane
@@ -279,12 +279,21 @@ __device__ __forceinline__ TupleRegs load_tuples(const TupleArgs &a, uint32_t ch
 	r.mq = 0;
 	r.pv = 0;
 	const uint32_t i0 = chunk * (uint32_t) kTupleChunk + threadIdx.x * 4;
-	if (chunk < n_chunks && i0 + 4 <= a.n_total) { // a ragged last chunk is re-read by the general path
+	if (chunk >= n_chunks || i0 >= a.n_total)
+		return r;
+	if (i0 + 4 <= a.n_total) {
 		r.q = *reinterpret_cast<const int4 *>(a.pos + i0);
 		r.mq = *reinterpret_cast<const uint32_t *>(a.mapq + i0);
-		if ((threadIdx.x & (kWave - 1)) == 0 && i0 > 0)
-			r.pv = a.pos[i0 - 1];
+	} else { // the lane that holds the ragged end of the batch: element by element, zeros behind the last tuple
+		int32_t t[4] = {0, 0, 0, 0};
+		for (uint32_t e = 0; i0 + e < a.n_total; e++) {
+			t[e] = a.pos[i0 + e];
+			r.mq |= (uint32_t) a.mapq[i0 + e] << (8 * e);
+		}
+		r.q = make_int4(t[0], t[1], t[2], t[3]);
 	}
+	if ((threadIdx.x & (kWave - 1)) == 0 && i0 > 0)
+		r.pv = a.pos[i0 - 1];
 	return r;
 }
 
@@ -358,48 +367,6 @@ __device__ __forceinline__ void ingest_chunk_count(const GcRegs &r, uint32_t *my
 			atomicAdd(&my_hist[r.g[e]], 1u);
 }
 
-// Any other chunk (two chromosomes, a ragged end, the very first tuple): tuple by tuple, straight into the
-// global counters.
-__device__ __forceinline__ void ingest_chunk_general(const TupleArgs &a, uint32_t base, float inv_step)
-{
-	const uint32_t n_total = a.n_total;
-	const uint32_t step = (uint32_t) a.step;
-	const uint32_t i0 = base + threadIdx.x * 4;
-	if (i0 >= n_total)
-		return;
-	int s = -1;
-	TupleSlot sl = {1, 0, 0, 0}; // empty range: the first tuple refreshes it
-	int32_t prev = (i0 > 0) ? a.pos[i0 - 1] : 0;
-	unsigned long long kept = 0; // kept tuples of chromosome s seen by this lane
-	for (int e = 0; e < 4; e++) {
-		const uint32_t i = i0 + e;
-		if (i >= n_total)
-			break;
-		if (i < sl.r0 || i >= sl.r1) {
-			if (kept)
-				atomicAdd(&a.small[s].counters[CNT_COUNTED], kept);
-			kept = 0;
-			s = find_slot(a.n_slots, (int64_t) i, [&](int k) { return a.slots[k].read_off; });
-			sl = tuple_slot(a.slots[s]);
-		}
-		const int32_t p = a.pos[i];
-		const bool in_range = p >= 0 && p < sl.L;
-		if (!in_range)
-			atomicAdd(&a.small[s].counters[CNT_OUT_OF_RANGE], 1ull);
-		if (i > sl.r0 && p < prev) // `prev` is in the same chromosome
-			atomicOr(&a.small[s].status, kStatusUnsorted);
-		prev = p;
-		if (in_range && (int) a.mapq[i] > a.mq_threshold) {
-			const uint32_t w = (step == 1) ? (uint32_t) p : div_tile((uint32_t) p, step, inv_step);
-			const int g = a.gc_hist[(uint64_t) sl.gc_off + w];
-			atomicAdd(&a.small[s].hist_sum[g], 1ull);
-			kept++;
-		}
-	}
-	if (kept)
-		atomicAdd(&a.small[s].counters[CNT_COUNTED], kept);
-}
-
 __device__ __forceinline__ void ingest_tuples_body(const TupleArgs &a, uint32_t block, uint32_t *hist, uint32_t &kept_block)
 {
 	const uint32_t c0 = block * a.chunks_per_block;
@@ -453,26 +420,25 @@ __device__ __forceinline__ void ingest_tuples_body(const TupleArgs &a, uint32_t 
 			ingest_chunk_count(pend, my_hist); // the previous chunk still belongs to the old chromosome
 			pend.kmask = 0;
 			if (home >= 0)
-				flush();
-			home = -1;
-			hs.r0 = 1;
-			hs.r1 = 0;
-			if ((uint64_t) base + kTupleChunk > (uint64_t) a.n_total) { // the ragged last chunk of the batch
-				ingest_chunk_general(a, base, inv_step);
-				continue;
-			}
-			// one masked pass per chromosome the chunk touches (usually one or two); the last one stays `home`
+				flush(); // (keeps `home`: the walk below starts from it)
+			// One masked pass per chromosome the chunk touches (usually one or two; the ragged last chunk of the batch is
+			// simply cut at n_total); the last one stays `home`.  Chromosomes follow each other in the tuple array, so
+			// the walk continues from the previous home instead of searching.
+			const uint32_t chunk_end = min(base + (uint32_t) kTupleChunk, a.n_total);
 			uint32_t from = base;
-			for (;;) {
+			if (home < 0)
 				home = find_slot(a.n_slots, (int64_t) from, [&](int k) { return a.slots[k].read_off; });
+			for (;;) {
 				hs = tuple_slot(a.slots[home]);
-				const uint32_t to = min(base + (uint32_t) kTupleChunk, hs.r1);
+				while (from >= hs.r1) // next chromosome that holds tuples (never runs off the table: from < n_total)
+					hs = tuple_slot(a.slots[++home]);
+				const uint32_t to = min(chunk_end, hs.r1);
 				if (from == base && to == base + (uint32_t) kTupleChunk)
 					break; // the whole chunk lies in this chromosome after all: the plain path below
 				const GcRegs g = ingest_chunk_inside<true>(a, hs, home, base, cur, inv_step, kept, from, to);
 				ingest_chunk_count(g, my_hist);
 				from = to;
-				if (from >= base + (uint32_t) kTupleChunk)
+				if (from >= chunk_end)
 					break;
 				flush();
 			}
