@@ -549,6 +549,52 @@ def test_batch_mode_matches_per_chromosome_results(capi, oracle):
         assert_records(dels, want["dels"], False)
 
 
+@pytest.mark.parametrize("total_reads", [None, 4096, 5 * 1024 + 1, 1023])
+def test_batch_of_many_tiny_chromosomes(capi, oracle, total_reads):
+    """Sixty contigs of a few kb with 0 .. 900 reads each in one batch: one 1024-tuple chunk of the tuple pass spans
+    several chromosomes (and empty ones), the batch ends exactly on / just past / before a chunk boundary, intervals
+    of one base, intervals that reach the contig end."""
+    rng = np.random.default_rng(31337)
+    contigs = []
+    for i in range(60):
+        L = int(rng.integers(1_500, 60_000))
+        n = int(rng.integers(0, 900)) if i % 7 else 0
+        contigs.append([L, n])
+    if total_reads is not None:  # trim / pad the last non-empty contigs so that the batch has exactly this many tuples
+        have = sum(n for _, n in contigs)
+        i = len(contigs) - 1
+        while have != total_reads:
+            d = total_reads - have
+            n_new = max(0, min(5000, contigs[i][1] + d))
+            have += n_new - contigs[i][1]
+            contigs[i][1] = n_new
+            i = (i - 1) % len(contigs)
+    cases = []
+    with capi.Context(device=0, mq_threshold=9, flags=capi.FLAG_BATCH) as ctx:
+        for L, n in contigs:
+            gc = synth.make_gc_track(L, rng, gaps=False)
+            pos = np.sort(rng.integers(0, L, n)).astype(np.int32)
+            mapq = rng.choice(np.array([0, 5, 9, 10, 30, 60], np.uint8), n)
+            k = int(rng.integers(0, 6))
+            s = rng.integers(0, max(L - 1, 1), k).astype(np.int32)
+            e = np.minimum(s + rng.integers(1, L, k), L).astype(np.int32)
+            ds, de = synth.kept_sorted(s, e, min_sv_size=1)
+            us, ue = ds[::2], de[::2]
+            ctx.chrom_begin(L, gc)
+            ctx.reads(pos, mapq)
+            ctx.intervals("D", ds, de)
+            ctx.intervals("E", us, ue)
+            cases.append((L, gc, pos, mapq, ds, de, us, ue))
+        ctx.compute()
+        for i, (L, gc, pos, mapq, ds, de, us, ue) in enumerate(cases):
+            ctx.select(i)
+            dels, dups, E, st = ctx.fetch()
+            got = dict(dels=dels, dups=dups, E=E, counted=st.reads_counted, S=np.array(st.rd_per_gc[:]),
+                       W=np.array(st.window_per_gc[:]))
+            want = run_oracle(oracle, L, gc, pos, mapq, ds, de, us, ue, mq=9)
+            compare(got, want, False)
+
+
 def test_batch_unsorted_chromosome_is_reported_per_chromosome(capi):
     c1, ds, de, us, ue = chrom_case("7", 200_000, cov=1.0, n_dels=10, gaps=False)
     with capi.Context(device=0, flags=capi.FLAG_BATCH) as ctx:
