@@ -1421,9 +1421,9 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 			if (fuse && (want_count || want_rows)) {
 				const int cb = want_count ? count_grid : 0, mb = want_rows ? map_grid : 0;
 				if (mb)
-					hipLaunchKernelGGL(tuple_pass_kernel<true>, dim3(cb + mb + grid), dim3(kTupleBlock), 0, st, a, c, cb, mr, mb);
+					hipLaunchKernelGGL(tuple_pass_kernel<true>, dim3(grid + cb + mb), dim3(kTupleBlock), 0, st, a, c, cb, mr, mb, grid);
 				else
-					hipLaunchKernelGGL(tuple_pass_kernel<false>, dim3(cb + grid), dim3(kTupleBlock), 0, st, a, c, cb, mr, 0);
+					hipLaunchKernelGGL(tuple_pass_kernel<false>, dim3(grid + cb), dim3(kTupleBlock), 0, st, a, c, cb, mr, 0, grid);
 			} else
 				hipLaunchKernelGGL(ingest_tuples_kernel, dim3(grid), dim3(kTupleBlock), 0, st, a);
 		}

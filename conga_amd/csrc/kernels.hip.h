@@ -655,17 +655,19 @@ __global__ __launch_bounds__(256) void interval_map_rows_kernel(MapRowsArgs a)
 // second stream's event dependency costs more than it hides): the first count_blocks workgroups search and count,
 // the rest stream the tuples.  The two halves touch disjoint outputs and only read the tuples.
 template <bool MAP_ROWS> __global__ __launch_bounds__(kTupleBlock, 8) void tuple_pass_kernel(TupleArgs a, CountArgs c,
-		int count_blocks, MapRowsArgs m, int map_blocks)
+		int count_blocks, MapRowsArgs m, int map_blocks, int ingest_blocks)
 {
 	__shared__ uint32_t hist[kHistCopies * kGcBins];
 	__shared__ uint32_t kept_block;
+	// The ingest workgroups come first: their grid is one resident wave of workgroups, and a single one left waiting
+	// for a slot behind the (short) search workgroups would stretch the launch by a whole workgroup lifetime.
 	const int b = (int) blockIdx.x;
-	if (b < count_blocks)
-		interval_count_body(c, (int64_t) b);
-	else if (MAP_ROWS && b < count_blocks + map_blocks)
-		interval_map_rows_body(m, (int64_t) (b - count_blocks));
-	else
-		ingest_tuples_body(a, (uint32_t) (b - count_blocks - map_blocks), hist, kept_block);
+	if (b < ingest_blocks)
+		ingest_tuples_body(a, (uint32_t) b, hist, kept_block);
+	else if (b < ingest_blocks + count_blocks)
+		interval_count_body(c, (int64_t) (b - ingest_blocks));
+	else if (MAP_ROWS)
+		interval_map_rows_body(m, (int64_t) (b - ingest_blocks - count_blocks));
 }
 
 // -------------------------------------------------------------------------------------------
