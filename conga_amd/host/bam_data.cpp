@@ -6,6 +6,7 @@
 #include "bam_data.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -128,6 +129,15 @@ int read_bam(parameters *params, sonic *this_sonic)
 		fprintf(fpDup, "#CHR\tSTART_SV\tEND_SV\tCOPY_NUMBER\tLIKELIHOOD\tREAD_PAIR\tMAPPABILITY\tOBSERVED_READS\tEXPECTED_READS\n");
 	}
 
+	// CONGA_TIMING=1: wall time of the host phases on stderr (where an end-to-end run spends its time)
+	const bool timing = getenv("CONGA_TIMING") != nullptr;
+	auto now = [] { return std::chrono::steady_clock::now(); };
+	auto ms_since = [&](std::chrono::steady_clock::time_point t) {
+		return std::chrono::duration<double, std::milli>(now() - t).count();
+	};
+	const auto t_start = now();
+	double ms_inputs = 0, ms_create = 0, ms_reads = 0, ms_compute = 0, ms_output = 0;
+
 	// ---- inputs (bam_data.c:253-267); the BED files are parsed once instead of once per chromosome
 	std::string err;
 	std::unique_ptr<read_source> src(open_reads(params->bam_file, &err));
@@ -141,6 +151,8 @@ int read_bam(parameters *params, sonic *this_sonic)
 	if (params->have_map && !load_bed(params->mappability_file, true, &map_bed))
 		print_error("[CONGA INPUT ERROR] Unable to open file " + params->mappability_file + " in read mode.");
 
+	ms_inputs = ms_since(t_start);
+	const auto t_create = now();
 	conga_opts opts;
 	memset(&opts, 0, sizeof opts);
 	opts.struct_size = sizeof opts;
@@ -157,6 +169,9 @@ int read_bam(parameters *params, sonic *this_sonic)
 				conga_strerror(status));
 		return CONGA_EXIT_COMMON;
 	}
+
+	ms_create = ms_since(t_create);
+	const auto t_loop = now();
 
 	// ---- chromosome loop (bam_data.c:269-339)
 	std::vector<chrom_svs> work;
@@ -239,10 +254,17 @@ int read_bam(parameters *params, sonic *this_sonic)
 		work.push_back(std::move(cs));
 	}
 
+	ms_reads = ms_since(t_loop);
+
 	// ---- calc_mean_per_chr + find_depths for every chromosome at once, then output in loop order
 	if (!work.empty()) {
 		fprintf(stderr, "\nCalculating Likelihoods\n");
+		const auto t_compute = now();
 		engine_check(ctx, conga_chrom_compute(ctx), "conga_chrom_compute");
+		if (timing)
+			engine_check(ctx, conga_sync(ctx), "conga_sync");
+		ms_compute = ms_since(t_compute);
+		const auto t_out = now();
 		for (size_t i = 0; i < work.size(); i++) {
 			chrom_svs &cs = work[i];
 			cs.del_res.resize(cs.dels.size());
@@ -260,8 +282,13 @@ int read_bam(parameters *params, sonic *this_sonic)
 				continue; // find_SVs returns before output_SVs when the chromosome has no SV (likelihood.c:332-336)
 			output_SVs(params, cs, fpSVs, fpDel, fpDup);
 		}
+		ms_output = ms_since(t_out);
 	}
 	conga_destroy(ctx);
+	if (timing)
+		fprintf(stderr, "\n[timing] open + BED parsing %.1f ms, engine create %.1f ms, chromosome loop (annotation, read decode + staging, "
+				"intervals) %.1f ms, layout + compute %.1f ms, fetch + output %.1f ms, total %.1f ms\n", ms_inputs, ms_create, ms_reads,
+				ms_compute, ms_output, ms_since(t_start));
 
 	fprintf(stderr, "\n");
 	if (fpDel)

@@ -44,7 +44,8 @@ def main():
     synth.write_bed(os.path.join(d, "dels.bed"), [(c.name, s, e) for c in cs for s, e in zip(c.del_start, c.del_end)])
     t0 = time.time()
     r = subprocess.run([os.path.join(ROOT, "conga_amd", "host", "conga"), "-i", reads_file, "--out", "got", "--ref", "none.fa",
-                        "--sonic", "a.cga", "--dels", "dels.bed"], cwd=d, capture_output=True, text=True)
+                        "--sonic", "a.cga", "--dels", "dels.bed"], cwd=d, capture_output=True, text=True,
+                       env=dict(os.environ, CONGA_TIMING="1"))
     t_cli = time.time() - t0
     assert r.returncode == 0, r.stderr[-2000:]
     ok = None
@@ -62,6 +63,9 @@ def main():
             first = False
         ok = all(open(os.path.join(d, "got_%s.bed" % k), "rb").read() == open(w, "rb").read()
                  for k, w in zip(("svs", "dels"), paths))
+    for line in r.stderr.splitlines():
+        if "[timing" in line:
+            print(line, file=sys.stderr)
     n_iv = sum(1 for _ in open(os.path.join(d, "got_dels.bed"))) - 1
     print(json.dumps(dict(chroms=names, reads=int(sum(len(c.pos) for c in cs)), input=a.input, input_mb=round(os.path.getsize(os.path.join(d, reads_file)) / 1e6, 1),
                           intervals=n_iv, cli_wall_s=round(t_cli, 3), intervals_per_s=round(n_iv / t_cli, 1),
