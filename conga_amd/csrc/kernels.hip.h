@@ -1447,7 +1447,7 @@ __device__ __forceinline__ conga_result score_interval(const ScoreArgs &a, int64
 // -------------------------------------------------------------------------------------------
 constexpr int kChainBlockWindows = 2048; // class A+ above this
 constexpr int kChainLongWindows = 512;
-constexpr int kChainSerialWindows = 64;
+constexpr int kChainSerialWindows = 56;
 constexpr int kChainSerialMaxSlots = 32; // class C keeps every chromosome's table in LDS up to this many
 
 struct ChainArgs {
@@ -1953,7 +1953,10 @@ __device__ __forceinline__ void chain_serial_body(const ChainArgs &a, int64_t bl
 
 constexpr int kChainLdsWords = kChainSerialMaxSlots * (kGcBins + 3); // >= 16 group tables of class B
 
-__global__ __launch_bounds__(256) void interval_chain_kernel(ChainArgs a)
+// Register budget for 5 waves per SIMD: the launch (~1000 workgroups for a 1000G-sized call set) must stay inside one
+// resident wave of workgroups.  At 4 per SIMD the limit is 1024 workgroups, and a call set that needs 1040 runs 25 us
+// longer (measured by moving the class-C threshold from 56 to 52 windows).
+__global__ __launch_bounds__(256, 5) void interval_chain_kernel(ChainArgs a)
 {
 	__shared__ float sE[kChainLdsWords];
 	__shared__ uint4 stage[256 * 4]; // class C: one 64-byte record per lane on its way to the host
