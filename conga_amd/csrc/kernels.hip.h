@@ -1869,20 +1869,39 @@ template <bool LDS_TABLES> __device__ __forceinline__ void chain_serial_lanes(co
 	const int64_t step = a.step;
 	const int64_t n_win_pad = (n_win + 15) & ~(int64_t) 15;
 	const uint32_t gc_last = have ? gc[n_win - 1] : 0;
-	auto fetch = [&](int64_t word) -> uint32_t { // GC bytes of windows [4 * word, 4 * word + 4)
-		return (have && word * 4 < n_win_pad) ? *reinterpret_cast<const uint32_t *>(gc + word * 4) : 0u;
+	// GC bytes: 64 windows at a time (16 aligned dwords per lane) sit in the wave's slice of `stage`, one LDS column per
+	// lane (dword k of lane l at [k * 64 + l]: conflict-free), and the next 64 are already in registers.  No global
+	// load inside the trip loop: one that the loop top has to wait for (every fourth trip, with the words fetched one
+	// at a time) cost more than the arithmetic of the trip.
+	uint32_t *col = reinterpret_cast<uint32_t *>(stage) + (threadIdx.x / kWave) * (kWave * 16) + (threadIdx.x & (kWave - 1));
+	int64_t chunk_w = ci.w_first & ~(int64_t) 3; // first window of the chunk in the column
+	uint32_t ahead[16];
+	auto load16 = [&](int64_t from) {
+#pragma unroll
+		for (int q = 0; q < 16; q++) {
+			const int64_t at = from + 4 * q;
+			ahead[q] = (have && at < n_win_pad) ? *reinterpret_cast<const uint32_t *>(gc + at) : 0u;
+		}
 	};
-	int64_t word = ci.w_first >> 2; // word that `cur` holds
-	uint32_t cur = fetch(word), nxt = fetch(word + 1);
+	auto to_column = [&]() {
+#pragma unroll
+		for (int q = 0; q < 16; q++)
+			col[q * kWave] = ahead[q];
+	};
+	load16(chunk_w);
+	to_column();
+	if (w_end > chunk_w + 64)
+		load16(chunk_w + 64);
 	// k and the addend's bits for the next window; positions stay below 2^31 + step, so 32-bit arithmetic does
 	uint32_t at = (uint32_t) s0;                                       // first base not yet accounted for
 	uint32_t edge = ((uint32_t) ci.w_first + 1u) * (uint32_t) step;    // first base of the window after `w`
 	int64_t w = ci.w_first;
 	auto window = [&](uint32_t &k, uint32_t &bc) {
-		if ((w >> 2) != word) {
-			word = w >> 2;
-			cur = nxt;
-			nxt = fetch(word + 1);
+		if (w - chunk_w >= 64 && w < w_end) { // this lane moves on to its next 64 windows
+			to_column();
+			chunk_w += 64;
+			if (w_end > chunk_w + 64)
+				load16(chunk_w + 64);
 		}
 		k = 0;
 		bc = 0;
@@ -1890,7 +1909,9 @@ template <bool LDS_TABLES> __device__ __forceinline__ void chain_serial_lanes(co
 			const uint32_t hi = (edge < (uint32_t) e0) ? edge : (uint32_t) e0;
 			k = hi - at;
 			at = hi;
-			const uint32_t g_cur = (w < n_win) ? ((cur >> (8 * (int) (w & 3))) & 0xFFu) : gc_last;
+			const uint32_t rel = (uint32_t) (w - chunk_w);
+			const uint32_t word = col[(rel >> 2) * kWave];
+			const uint32_t g_cur = (w < n_win) ? ((word >> (8 * (rel & 3u))) & 0xFFu) : gc_last;
 			float c = 0.0f;
 			if (g_cur < (uint32_t) kGcBins)
 				c = LDS_TABLES ? E[g_cur] : chain_table_entry(a, ci.sl, (int) g_cur);

@@ -196,14 +196,14 @@ CONGA_HD float conga_compose_f32(uint32_t es, uint32_t ms)
 	return conga_bits_f32((es << 23) + (ms - 0x800000u));
 }
 
-// The same result as conga_repeat_add_f32, shaped for the chain kernels: k <= 1024 adds (one GC window) of a
+// The same result as conga_repeat_add_f32 for k <= 1024 adds (one GC window) of a
 // non-negative normal addend.  One loop iteration per binade the accumulator passes through: the regular adds in
 // front of the binade top are one integer step -- their number is a quotient below 1024, so a float estimate is at
 // most one off and two 24-bit multiplies settle it, no integer divide -- then one real add carries the accumulator
 // across.  Wherever the integer step does not apply (accumulator still within 8x of the addend, which includes the
 // start from zero; a tie from an odd mantissa) the iteration is one literal add, which is always right.  Only
 // negative, sub-normal, infinite operands or k > 1024 go to the general routine.
-CONGA_HD float conga_window_add_f32(float s, float c, uint32_t k)
+CONGA_HD_RARE float conga_window_add_loop_f32(float s, float c, uint32_t k)
 {
 	const uint32_t bc = conga_f32_bits(c);
 	const conga_addend ca = conga_addend_of(bc);
@@ -241,4 +241,52 @@ CONGA_HD float conga_window_add_f32(float s, float c, uint32_t k)
 		k -= n1 + 1u;
 	}
 	return s;
+}
+
+// What the chain kernels call for every window.  Straight-line, select-style code for the two cases that make up
+// all but the first windows of a chain -- the whole window inside the accumulator's binade, or exactly one crossing of
+// its top -- because in the lane-per-interval class every lane of the wave sits in this routine once per trip and a
+// branch taken by one lane is paid by all 64 (branches and their mask bookkeeping, not arithmetic, were most of a
+// trip).  Both candidates are always computed; everything else (start from zero, ties from odd mantissas, two
+// crossings in one window, odd operands) goes to the loop above through one rarely taken branch.
+CONGA_HD float conga_window_add_f32(float s, float c, uint32_t k)
+{
+	if (k == 0u)
+		return s;
+	const uint32_t bs = conga_f32_bits(s);
+	const conga_addend ca = conga_addend_of(conga_f32_bits(c));
+	// ---- stage 1: the accumulator's binade
+	const uint32_t es = bs >> 23; // a negative accumulator shows up as es >= 256: not ok
+	const conga_lean_step st = conga_step_lean(es, ca);
+	const uint32_t ms = (bs & 0x7FFFFFu) | 0x800000u;
+	const bool ok1 = st.ok != 0u && k <= 1024u && !(st.tie != 0u && (ms & 1u) != 0u);
+	const bool room_ok = ms <= st.lim;
+	const uint32_t room = room_ok ? st.lim - ms : 0u; // < 2^24
+	const uint32_t dl = st.delta & 0x3FFFFFu;          // (<= 2^21 whenever ok)
+	const uint32_t kk = k & 0x7FFu;                    // (<= 1024 whenever ok)
+	const bool fit = room_ok && CONGA_MUL24((kk - 1u) & 0x7FFu, dl) <= room;
+	const float res_fit = conga_compose_f32(es & 0xFFu, ms + CONGA_MUL24(kk, dl));
+	// ---- one crossing: n1 regular adds (the last one starts at or below lim), one real add, the rest in the next binade
+	uint32_t q = (uint32_t) ((float) room / (float) (dl | (dl == 0u ? 1u : 0u))); // true quotient < k - 1 <= 1023 when it matters
+	q = (q > 2047u) ? 2047u : q;
+	const bool q_high = CONGA_MUL24(q, dl) > room;
+	const bool q_low = !q_high && CONGA_MUL24(q + 1u, dl) <= room;
+	q = q_high ? q - 1u : (q_low ? q + 1u : q);
+	const uint32_t n1 = room_ok ? q + 1u : 0u;
+	const uint32_t ms1 = ms + CONGA_MUL24(n1 & 0x7FFu, dl); // lim < ms1 <= 2^24 in the case that is used
+	const float s2 = conga_compose_f32(es & 0xFFu, ms1) + c; // the add that reaches or crosses the binade top: real rounding
+	const uint32_t r = kk - n1 - 1u;                          // adds left (wraps when the window fits: unused then)
+	// ---- stage 2: the next binade
+	const uint32_t bs2 = conga_f32_bits(s2);
+	const uint32_t es2 = bs2 >> 23;
+	const conga_lean_step st2 = conga_step_lean(es2, ca);
+	const uint32_t ms2 = (bs2 & 0x7FFFFFu) | 0x800000u;
+	const uint32_t dl2 = st2.delta & 0x3FFFFFu;
+	const bool ok2 = st2.ok != 0u && !(st2.tie != 0u && (ms2 & 1u) != 0u) && ms2 <= st2.lim
+			&& CONGA_MUL24((r - 1u) & 0x7FFu, dl2) <= st2.lim - ms2;
+	const float res_cross = (r == 0u) ? s2 : conga_compose_f32(es2 & 0xFFu, ms2 + CONGA_MUL24(r & 0x7FFu, dl2));
+	const bool cross_ok = st.delta != 0u && n1 < kk && (r == 0u || ok2);
+	if (ok1 && (fit || cross_ok))
+		return fit ? res_fit : res_cross;
+	return conga_window_add_loop_f32(s, c, k);
 }
