@@ -215,23 +215,42 @@ def main():
         bytes_per_rank = [int(x.item()) for x in all_b]
     else:
         bytes_per_rank = [my_bytes]
-    # two gather buffers, used alternately: the (asynchronous) RCCL gather of step k may still be reading one
-    # while step k + 1 copies its records into the other
-    packed2 = [torch.zeros(max(my_bytes, 1), dtype=torch.uint8, device=dev) for _ in range(2)]
+    # Two sets of gather buffers, used alternately, padded to the largest contribution so that they go into the RCCL
+    # gather as they are (no per-step allocation, no extra copy).  The gather of step k is asynchronous and overlaps the
+    # compute of step k + 1; before step k + 2 copies its records into the same buffer, the context's stream is made to
+    # wait for the event recorded behind gather k.
+    pad = max(max(bytes_per_rank), 1)
+    packed2 = [torch.zeros(pad, dtype=torch.uint8, device=dev) for _ in range(2)]
+    recv2 = [[torch.empty(pad, dtype=torch.uint8, device=gather_dev) for _ in range(world)] if (rank == 0 and world > 1) else None
+             for _ in range(2)]
+    gathered_ev = [None, None]
+    ext_stream = torch.cuda.ExternalStream(ctx.stream(), device=dev) if (world > 1 and not rehearsal) else None
     total_iv = sum(bytes_per_rank) // rec
     step_no = [0]
 
     def step():
-        packed = packed2[step_no[0] & 1]
+        slot = step_no[0] & 1
+        packed = packed2[slot]
         step_no[0] += 1
+        if ext_stream is not None and gathered_ev[slot] is not None:
+            ext_stream.wait_event(gathered_ev[slot])      # the gather that read this buffer two steps ago is done
         ctx.compute()                               # whole hot path for this rank's chromosomes, async
         if world > 1:
             ctx.results_copy(packed.data_ptr(), my_bytes)   # records stay on the device for the RCCL gather
         ctx.sync()                                  # N=1: the records are in pinned host memory now
         if world == 1:
             return [packed[:0]]
-        local = packed[:my_bytes].cpu() if rehearsal else packed[:my_bytes]
-        return shard.gather_records(local, bytes_per_rank, rank, world, gather_dev)
+        if rehearsal:                               # one GPU, gloo: host tensors
+            send = packed.cpu()
+            dist.gather(send, recv2[slot], dst=0)
+        else:
+            dist.gather(packed, recv2[slot], dst=0)  # RCCL over xGMI; ordered behind the host-side sync above
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            gathered_ev[slot] = ev
+        if rank != 0:
+            return None
+        return [recv2[slot][r][:bytes_per_rank[r]] for r in range(world)]
 
     def barrier():
         if world > 1:

@@ -485,6 +485,19 @@ def test_graph_replay_gives_the_same_records(capi, oracle, monkeypatch):
         assert_records(dups, want["dups"], False)
 
 
+def test_results_copy_into_a_torch_tensor_with_stream_events():
+    """What every rank of the multi-GPU bench does per step, without the collective (tools/check_torch_interop.py).
+    In a process of its own: torch brings its own HIP runtime along and has to be imported before libconga_hip.so is
+    loaded, as bench.py does."""
+    import subprocess
+    import sys
+    pytest.importorskip("torch")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_torch_interop.py")], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_results_on_device_are_fetched_on_demand(capi, oracle):
     """CONGA_FLAG_RESULTS_ON_DEVICE: the compute sends no records over PCIe; fetch copies them when asked, and the
     device copy is what conga_results_copy hands to a gather."""
