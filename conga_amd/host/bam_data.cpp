@@ -1,16 +1,20 @@
 // bam_data.cpp -- read_bam / count_reads_bam / find_SVs re-hosted on the C-ABI of include/conga_hip.h.
 //
-// Order of work differs from the reference on purpose: all chromosomes are handed to ONE batch context
+// Order of work differs from the reference on purpose: all chromosomes of a context are handed to it as ONE batch
 // (CONGA_FLAG_BATCH) and computed by a single conga_chrom_compute(), then written out in annotation order.
 // Outputs are byte-identical to doing begin / finish per chromosome; the GPU just gets launches that fill it.
+// `--gpus N` runs N such contexts, one host thread and one HIP device each, over a longest-first partition of the
+// chromosomes; the files are still written by the calling thread in annotation order.
 #include "bam_data.h"
 
 #include <algorithm>
 #include <chrono>
+#include <cstdarg>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/conga_hip.h"
@@ -105,6 +109,162 @@ int64_t count_reads_bam(conga_ctx *ctx, read_source *src, int chr_index_bam, int
 	return cnt;
 }
 
+// One chromosome of the loop of read_bam (bam_data.c:269-339), from selection to output.
+struct chrom_job {
+	int chr_index = 0;     // in the annotation
+	int chr_index_bam = 0; // in the BAM header
+	int64_t L = 0;
+	int worker = 0;
+	std::string messages;  // progress lines of the reference, in its order (held back when several workers run)
+	chrom_svs cs;
+	conga_chrom_stats st;
+	bool staged = false;
+};
+
+// Where the reference's stderr progress lines go: straight out with one worker, into the job's buffer with several
+// (they are then printed in annotation order once every worker is done).
+struct progress {
+	std::string *buf; // nullptr: stderr
+	void say(const char *fmt, ...) __attribute__((format(printf, 2, 3)))
+	{
+		va_list ap;
+		va_start(ap, fmt);
+		if (!buf) {
+			vfprintf(stderr, fmt, ap);
+		} else {
+			char tmp[1024];
+			vsnprintf(tmp, sizeof tmp, fmt, ap);
+			*buf += tmp;
+		}
+		va_end(ap);
+	}
+};
+
+struct worker_timing {
+	double ms_create = 0, ms_reads = 0, ms_compute = 0, ms_fetch = 0;
+};
+
+// The work of one context: stage every chromosome of `mine` (annotation order), one batch compute, fetch.
+// One host thread per context, one context per GPU; chromosomes are independent in the
+// reference (bam_data.c:269-339), so no worker ever needs another's data.
+void run_worker(const parameters *params, const sonic *this_sonic, read_source *src, int device, bool buffered,
+		const bed_index &map_bed, std::vector<chrom_job *> &mine, bool announce_compute, worker_timing *wt)
+{
+	auto now = [] { return std::chrono::steady_clock::now(); };
+	auto ms_since = [&](std::chrono::steady_clock::time_point t) {
+		return std::chrono::duration<double, std::milli>(now() - t).count();
+	};
+	const auto t_create = now();
+	conga_opts opts;
+	memset(&opts, 0, sizeof opts);
+	opts.struct_size = sizeof opts;
+	opts.mq_threshold = params->mq_threshold;
+	opts.gc_step = this_sonic->gc_step;
+	opts.flags = CONGA_FLAG_BATCH;
+	opts.min_read_length = params->min_read_length;
+	// the reference's split-read gate: `!no_sr && dup_file` (svdepth.c:57, bam_data.c:207,306,331, likelihood.c:344)
+	const bool split_reads = !params->no_sr && params->have_dups;
+	int status = 0;
+	conga_ctx *ctx = conga_create(device, &opts, &status);
+	if (!ctx) {
+		fprintf(stderr, "\n[CONGA ENGINE ERROR] cannot create a context on HIP device %d: %s\n", device, conga_strerror(status));
+		exit(CONGA_EXIT_COMMON);
+	}
+	wt->ms_create = ms_since(t_create);
+	const auto t_loop = now();
+
+	std::string err;
+	for (chrom_job *job : mine) {
+		progress out = {buffered ? &job->messages : nullptr};
+		if (!buffered && !job->messages.empty()) {
+			fputs(job->messages.c_str(), stderr); // what the selection pass had to say before this chromosome
+			job->messages.clear();
+		}
+		const std::string &name = this_sonic->chromosome_names[job->chr_index];
+		const int64_t L = job->L;
+		out.say("\n");
+		out.say("Reading BAM [%s] - Chromosome: %s", src->sample_name().c_str(), src->target_name(job->chr_index_bam).c_str());
+
+		// init_rd_per_chr + the GC side of calc_mean_per_chr (read_distribution.c:12-18,63-73)
+		std::vector<uint8_t> gc_hist_w, gc_like_w;
+		gc_window_arrays(this_sonic, job->chr_index, &gc_hist_w, &gc_like_w);
+		engine_check(ctx, conga_chrom_begin(ctx, L, gc_hist_w.data(), gc_like_w.data(), (int64_t) gc_hist_w.size()),
+				"conga_chrom_begin");
+
+		if (split_reads) {
+			// readReferenceSeq (common.c:423-463) and the satellite annotation (bam_data.c:96-97,207)
+			out.say("\nReading the Reference Genome");
+			std::string ref_seq;
+			if (!load_fasta_chrom(params->ref_genome, name, L, &ref_seq, &err))
+				print_error(err);
+			engine_check(ctx, conga_reference(ctx, ref_seq.data(), (int64_t) ref_seq.size()), "conga_reference");
+			engine_check(ctx, conga_satellites(ctx, this_sonic->sat_start[job->chr_index].data(),
+					this_sonic->sat_end[job->chr_index].data(), this_sonic->sat_start[job->chr_index].size()), "conga_satellites");
+		}
+		out.say("\n-->counting reads");
+		const int64_t cnt_reads = count_reads_bam(ctx, src, job->chr_index_bam, L, split_reads);
+		out.say(" (%lld reads, %ld split-reads)\n", (long long) cnt_reads, 0L);
+
+		// find_SVs, loading half (likelihood.c:319-336); the rows were picked by the selection pass
+		chrom_svs &cs = job->cs;
+		out.say("\nLoading known SVs");
+		out.say("(%d DELS, %d DUPS in chromosome %s - larger than the threshold %d)\n", (int) cs.dels.size(), (int) cs.dups.size(),
+				cs.chr_name.c_str(), params->min_sv_size);
+		std::vector<int32_t> s, e;
+		auto hand_over = [&](char type, const std::vector<sv_row> &rows) {
+			s.resize(rows.size());
+			e.resize(rows.size());
+			for (size_t i = 0; i < rows.size(); i++) {
+				s[i] = rows[i].start;
+				e[i] = rows[i].end;
+			}
+			engine_check(ctx, conga_intervals(ctx, type, s.data(), e.data(), rows.size()), "conga_intervals");
+		};
+		hand_over(CONGA_DELETION, cs.dels);
+		hand_over(CONGA_DUPLICATION, cs.dups);
+		if (params->have_map && cs.dels.size() + cs.dups.size() > 0) {
+			// load_mappability_regions (svs.c:317-377) runs only for chromosomes that have SVs (likelihood.c:332-356)
+			out.say("Finding mappability for each region\n");
+			auto it = map_bed.rows.find(cs.chr_name);
+			std::vector<int32_t> ms, me;
+			const float *mv = nullptr;
+			if (it != map_bed.rows.end()) {
+				ms.resize(it->second.size());
+				me.resize(it->second.size());
+				for (size_t i = 0; i < it->second.size(); i++) {
+					ms[i] = it->second[i].start;
+					me[i] = it->second[i].end;
+				}
+				mv = map_bed.values.at(cs.chr_name).data();
+			}
+			engine_check(ctx, conga_mappability(ctx, ms.data(), me.data(), mv, ms.size()), "conga_mappability");
+		}
+		job->staged = true;
+	}
+	wt->ms_reads = ms_since(t_loop);
+
+	// ---- calc_mean_per_chr + find_depths for every chromosome of this context at once
+	if (!mine.empty()) {
+		if (announce_compute)
+			fprintf(stderr, "\nCalculating Likelihoods\n");
+		const auto t_compute = now();
+		engine_check(ctx, conga_chrom_compute(ctx), "conga_chrom_compute");
+		engine_check(ctx, conga_sync(ctx), "conga_sync");
+		wt->ms_compute = ms_since(t_compute);
+		const auto t_fetch = now();
+		for (size_t i = 0; i < mine.size(); i++) {
+			chrom_svs &cs = mine[i]->cs;
+			cs.del_res.resize(cs.dels.size());
+			cs.dup_res.resize(cs.dups.size());
+			float expected_rd[101];
+			engine_check(ctx, conga_chrom_select(ctx, (int) i), "conga_chrom_select");
+			engine_check(ctx, conga_chrom_fetch(ctx, cs.del_res.data(), cs.dup_res.data(), expected_rd, &mine[i]->st), "conga_chrom_fetch");
+		}
+		wt->ms_fetch = ms_since(t_fetch);
+	}
+	conga_destroy(ctx);
+}
+
 } // namespace
 
 int read_bam(parameters *params, sonic *this_sonic)
@@ -136,7 +296,6 @@ int read_bam(parameters *params, sonic *this_sonic)
 		return std::chrono::duration<double, std::milli>(now() - t).count();
 	};
 	const auto t_start = now();
-	double ms_inputs = 0, ms_create = 0, ms_reads = 0, ms_compute = 0, ms_output = 0;
 
 	// ---- inputs (bam_data.c:253-267); the BED files are parsed once instead of once per chromosome
 	std::string err;
@@ -150,31 +309,11 @@ int read_bam(parameters *params, sonic *this_sonic)
 		print_error("[CONGA INPUT ERROR] Unable to open file " + params->dup_file + " in read mode.");
 	if (params->have_map && !load_bed(params->mappability_file, true, &map_bed))
 		print_error("[CONGA INPUT ERROR] Unable to open file " + params->mappability_file + " in read mode.");
+	const double ms_inputs = ms_since(t_start);
 
-	ms_inputs = ms_since(t_start);
-	const auto t_create = now();
-	conga_opts opts;
-	memset(&opts, 0, sizeof opts);
-	opts.struct_size = sizeof opts;
-	opts.mq_threshold = params->mq_threshold;
-	opts.gc_step = this_sonic->gc_step;
-	opts.flags = CONGA_FLAG_BATCH;
-	opts.min_read_length = params->min_read_length;
-	// the reference's split-read gate: `!no_sr && dup_file` (svdepth.c:57, bam_data.c:207,306,331, likelihood.c:344)
-	const bool split_reads = !params->no_sr && params->have_dups;
-	int status = 0;
-	conga_ctx *ctx = conga_create(params->device, &opts, &status);
-	if (!ctx) {
-		fprintf(stderr, "\n[CONGA ENGINE ERROR] cannot create a context on HIP device %d: %s\n", params->device,
-				conga_strerror(status));
-		return CONGA_EXIT_COMMON;
-	}
-
-	ms_create = ms_since(t_create);
-	const auto t_loop = now();
-
-	// ---- chromosome loop (bam_data.c:269-339)
-	std::vector<chrom_svs> work;
+	// ---- chromosome selection (bam_data.c:269-291) and the known SVs of each (likelihood.c:319-331)
+	std::vector<chrom_job> jobs;
+	std::string pending; // messages of skipped chromosomes: they belong in front of the next one that runs
 	for (int chr_index = 0; chr_index < this_sonic->number_of_chromosomes; chr_index++) {
 		if (chr_index < params->first_chrom)
 			chr_index = params->first_chrom;
@@ -185,110 +324,109 @@ int read_bam(parameters *params, sonic *this_sonic)
 			continue; // strstr(name, "X") / "Y" (bam_data.c:280)
 		const int chr_index_bam = find_chr_index_bam(name, *src);
 		if (chr_index_bam == -1) {
-			fprintf(stderr, "\nCannot find chromosome name %s in BAM/CRAM %s", name.c_str(), src->sample_name().c_str());
+			pending += "\nCannot find chromosome name " + name + " in BAM/CRAM " + src->sample_name();
 			continue;
 		}
-		const int64_t L = this_sonic->chromosome_lengths[chr_index];
-		fprintf(stderr, "\n");
-		fprintf(stderr, "Reading BAM [%s] - Chromosome: %s", src->sample_name().c_str(), src->target_name(chr_index_bam).c_str());
-
-		// init_rd_per_chr + the GC side of calc_mean_per_chr (read_distribution.c:12-18,63-73)
-		std::vector<uint8_t> gc_hist_w, gc_like_w;
-		gc_window_arrays(this_sonic, chr_index, &gc_hist_w, &gc_like_w);
-		engine_check(ctx, conga_chrom_begin(ctx, L, gc_hist_w.data(), gc_like_w.data(), (int64_t) gc_hist_w.size()),
-				"conga_chrom_begin");
-
-		if (split_reads) {
-			// readReferenceSeq (common.c:423-463) and the satellite annotation (bam_data.c:96-97,207)
-			fprintf(stderr, "\nReading the Reference Genome");
-			std::string ref_seq;
-			if (!load_fasta_chrom(params->ref_genome, name, L, &ref_seq, &err))
-				print_error(err);
-			engine_check(ctx, conga_reference(ctx, ref_seq.data(), (int64_t) ref_seq.size()), "conga_reference");
-			engine_check(ctx, conga_satellites(ctx, this_sonic->sat_start[chr_index].data(), this_sonic->sat_end[chr_index].data(),
-					this_sonic->sat_start[chr_index].size()), "conga_satellites");
-		}
-		fprintf(stderr, "\n-->counting reads");
-		const int64_t cnt_reads = count_reads_bam(ctx, src.get(), chr_index_bam, L, split_reads);
-		fprintf(stderr, " (%lld reads, %ld split-reads)\n", (long long) cnt_reads, 0L);
-
-		// find_SVs, loading half (likelihood.c:319-336): BED rows are matched against the BAM's target name
-		chrom_svs cs;
-		cs.chr_name = src->target_name(chr_index_bam);
-		fprintf(stderr, "\nLoading known SVs");
+		chrom_job job;
+		job.chr_index = chr_index;
+		job.chr_index_bam = chr_index_bam;
+		job.L = this_sonic->chromosome_lengths[chr_index];
+		job.messages.swap(pending);
+		// BED rows are matched against the BAM's target name
+		job.cs.chr_name = src->target_name(chr_index_bam);
 		if (params->have_dels)
-			cs.dels = known_SVs_for(dels_bed, cs.chr_name, params->min_sv_size);
+			job.cs.dels = known_SVs_for(dels_bed, job.cs.chr_name, params->min_sv_size);
 		if (params->have_dups)
-			cs.dups = known_SVs_for(dups_bed, cs.chr_name, params->min_sv_size);
-		fprintf(stderr, "(%d DELS, %d DUPS in chromosome %s - larger than the threshold %d)\n", (int) cs.dels.size(),
-				(int) cs.dups.size(), cs.chr_name.c_str(), params->min_sv_size);
-		std::vector<int32_t> s, e;
-		auto hand_over = [&](char type, const std::vector<sv_row> &rows) {
-			s.resize(rows.size());
-			e.resize(rows.size());
-			for (size_t i = 0; i < rows.size(); i++) {
-				s[i] = rows[i].start;
-				e[i] = rows[i].end;
-			}
-			engine_check(ctx, conga_intervals(ctx, type, s.data(), e.data(), rows.size()), "conga_intervals");
-		};
-		hand_over(CONGA_DELETION, cs.dels);
-		hand_over(CONGA_DUPLICATION, cs.dups);
-		if (params->have_map && cs.dels.size() + cs.dups.size() > 0) {
-			// load_mappability_regions (svs.c:317-377) runs only for chromosomes that have SVs (likelihood.c:332-356)
-			fprintf(stderr, "Finding mappability for each region\n");
-			auto it = map_bed.rows.find(cs.chr_name);
-			std::vector<int32_t> ms, me;
-			std::vector<float> mv;
-			if (it != map_bed.rows.end()) {
-				ms.resize(it->second.size());
-				me.resize(it->second.size());
-				for (size_t i = 0; i < it->second.size(); i++) {
-					ms[i] = it->second[i].start;
-					me[i] = it->second[i].end;
-				}
-				mv = map_bed.values[cs.chr_name];
-			}
-			engine_check(ctx, conga_mappability(ctx, ms.data(), me.data(), mv.data(), ms.size()), "conga_mappability");
-		}
-		work.push_back(std::move(cs));
+			job.cs.dups = known_SVs_for(dups_bed, job.cs.chr_name, params->min_sv_size);
+		jobs.push_back(std::move(job));
 	}
 
-	ms_reads = ms_since(t_loop);
-
-	// ---- calc_mean_per_chr + find_depths for every chromosome at once, then output in loop order
-	if (!work.empty()) {
-		fprintf(stderr, "\nCalculating Likelihoods\n");
-		const auto t_compute = now();
-		engine_check(ctx, conga_chrom_compute(ctx), "conga_chrom_compute");
-		if (timing)
-			engine_check(ctx, conga_sync(ctx), "conga_sync");
-		ms_compute = ms_since(t_compute);
-		const auto t_out = now();
-		for (size_t i = 0; i < work.size(); i++) {
-			chrom_svs &cs = work[i];
-			cs.del_res.resize(cs.dels.size());
-			cs.dup_res.resize(cs.dups.size());
-			float expected_rd[101];
-			conga_chrom_stats st;
-			engine_check(ctx, conga_chrom_select(ctx, (int) i), "conga_chrom_select");
-			engine_check(ctx, conga_chrom_fetch(ctx, cs.del_res.data(), cs.dup_res.data(), expected_rd, &st), "conga_chrom_fetch");
-			// calc_mu_per_chr's log line (read_distribution.c:41)
-			fprintf(logFile, "Read Count:%li  Window count:%li mean=%f\n", (long) st.rd_sum,
-					(long) this_sonic->chromosome_lengths[sonic_refind_chromosome_index(this_sonic, cs.chr_name)], st.mean);
-			if (split_reads)
-				fprintf(stderr, "\nCONGA paired %lld single-end reads\n", (long long) (st.split_del_rows + st.split_dup_rows));
-			if (cs.dels.size() + cs.dups.size() == 0)
-				continue; // find_SVs returns before output_SVs when the chromosome has no SV (likelihood.c:332-336)
-			output_SVs(params, cs, fpSVs, fpDel, fpDup);
+	// ---- chromosomes -> contexts: longest-processing-time-first on L + 2 * sum(interval length), the cost model of
+	// conga_amd/shard.py.  Worker k drives HIP device (--device + k) modulo the visible devices.
+	int n_workers = std::max(1, std::min(params->n_gpus, (int) std::max<size_t>(jobs.size(), 1)));
+	const int n_dev = conga_device_count();
+	if (n_workers > 1 && n_dev > 0 && n_dev < n_workers)
+		fprintf(stderr, "\n[CONGA] --gpus %d with %d visible HIP device(s): contexts share devices\n", n_workers, n_dev);
+	std::vector<std::vector<chrom_job *>> mine((size_t) n_workers);
+	{
+		std::vector<size_t> order(jobs.size());
+		std::vector<double> cost(jobs.size());
+		for (size_t i = 0; i < jobs.size(); i++) {
+			order[i] = i;
+			double sum_len = 0;
+			for (const sv_row &r : jobs[i].cs.dels)
+				sum_len += (double) r.end - (double) r.start;
+			for (const sv_row &r : jobs[i].cs.dups)
+				sum_len += (double) r.end - (double) r.start;
+			cost[i] = (double) jobs[i].L + 2.0 * sum_len;
 		}
-		ms_output = ms_since(t_out);
+		std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return cost[a] > cost[b]; });
+		std::vector<double> load((size_t) n_workers, 0.0);
+		for (size_t i : order) {
+			const size_t w = (size_t) (std::min_element(load.begin(), load.end()) - load.begin());
+			jobs[i].worker = (int) w;
+			load[w] += cost[i];
+		}
+		for (chrom_job &j : jobs)
+			mine[(size_t) j.worker].push_back(&j); // annotation order within a worker
 	}
-	conga_destroy(ctx);
-	if (timing)
-		fprintf(stderr, "\n[timing] open + BED parsing %.1f ms, engine create %.1f ms, chromosome loop (annotation, read decode + staging, "
-				"intervals) %.1f ms, layout + compute %.1f ms, fetch + output %.1f ms, total %.1f ms\n", ms_inputs, ms_create, ms_reads,
-				ms_compute, ms_output, ms_since(t_start));
+
+	const auto t_work = now();
+	std::vector<worker_timing> wt((size_t) n_workers);
+	if (n_workers == 1) {
+		run_worker(params, this_sonic, src.get(), params->device, false, map_bed, mine[0], true, &wt[0]);
+	} else {
+		set_reader_share(n_workers); // each worker's BAM reader gets its share of the inflate threads
+		std::vector<std::thread> threads;
+		for (int w = 0; w < n_workers; w++) {
+			threads.emplace_back([&, w] {
+				std::string werr;
+				std::unique_ptr<read_source> wsrc(open_reads(params->bam_file, &werr));
+				if (!wsrc)
+					print_error(werr);
+				const int device = n_dev > 0 ? (params->device + w) % n_dev : params->device + w;
+				run_worker(params, this_sonic, wsrc.get(), device, true, map_bed, mine[(size_t) w], false, &wt[(size_t) w]);
+			});
+		}
+		for (std::thread &t : threads)
+			t.join();
+		for (const chrom_job &j : jobs)
+			fputs(j.messages.c_str(), stderr);
+		if (!jobs.empty())
+			fprintf(stderr, "\nCalculating Likelihoods\n");
+	}
+	if (!pending.empty())
+		fputs(pending.c_str(), stderr);
+	const double ms_work = ms_since(t_work);
+
+	// ---- output in annotation order (rank 0's job in SURVEY.md section 8e)
+	const auto t_out = now();
+	const bool split_reads = !params->no_sr && params->have_dups;
+	for (const chrom_job &job : jobs) {
+		const chrom_svs &cs = job.cs;
+		// calc_mu_per_chr's log line (read_distribution.c:41)
+		fprintf(logFile, "Read Count:%li  Window count:%li mean=%f\n", (long) job.st.rd_sum, (long) job.L, job.st.mean);
+		if (split_reads)
+			fprintf(stderr, "\nCONGA paired %lld single-end reads\n", (long long) (job.st.split_del_rows + job.st.split_dup_rows));
+		if (cs.dels.size() + cs.dups.size() == 0)
+			continue; // find_SVs returns before output_SVs when the chromosome has no SV (likelihood.c:332-336)
+		output_SVs(params, cs, fpSVs, fpDel, fpDup);
+	}
+	const double ms_output = ms_since(t_out);
+	if (timing) {
+		if (n_workers == 1)
+			fprintf(stderr, "\n[timing] open + BED parsing %.1f ms, engine create %.1f ms, chromosome loop (annotation, read decode + "
+					"staging, intervals) %.1f ms, layout + compute %.1f ms, fetch + output %.1f ms, total %.1f ms\n", ms_inputs,
+					wt[0].ms_create, wt[0].ms_reads, wt[0].ms_compute, wt[0].ms_fetch + ms_output, ms_since(t_start));
+		else {
+			fprintf(stderr, "\n[timing] open + BED parsing %.1f ms, %d workers %.1f ms, output %.1f ms, total %.1f ms\n", ms_inputs,
+					n_workers, ms_work, ms_output, ms_since(t_start));
+			for (int w = 0; w < n_workers; w++)
+				fprintf(stderr, "[timing] worker %d: %zu chromosomes, engine create %.1f ms, chromosome loop %.1f ms, layout + compute "
+						"%.1f ms, fetch %.1f ms\n", w, mine[(size_t) w].size(), wt[(size_t) w].ms_create, wt[(size_t) w].ms_reads,
+						wt[(size_t) w].ms_compute, wt[(size_t) w].ms_fetch);
+		}
+	}
 
 	fprintf(stderr, "\n");
 	if (fpDel)

@@ -33,7 +33,7 @@ class bgzf_reader {
 public:
 	bgzf_reader()
 	{
-		int n = (int) std::thread::hardware_concurrency();
+		int n = std::max(2, usable_cpus() / reader_share());
 		if (const char *e = getenv("CONGA_BAM_THREADS"))
 			n = atoi(e) + 1;
 		n_workers_ = std::max(0, std::min(n - 1, 15));

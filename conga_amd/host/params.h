@@ -32,6 +32,7 @@ struct parameters {
 	int no_sr = 1;           // 0 when --rp was given
 	// extensions of this implementation (not in the reference)
 	int device = 0;                  // --device
+	int n_gpus = 1;                  // --gpus N : N contexts (one host thread + one HIP device each), chromosomes sharded longest-first
 	std::string dump_intervals_chr;  // --dump-intervals CHR : print the kept, sorted SV rows and exit (no GPU)
 	std::string dump_mappability_chr; // --dump-mappability CHR : print the parsed mappability rows of CHR and exit (no GPU)
 	bool dump_reads = false;         // --dump-reads : per chromosome, count and checksums of the records the BAM loop would count (no GPU)

@@ -5,6 +5,10 @@
 #include <fcntl.h>
 #include <unistd.h>
 
+#include <sched.h>
+
+#include <atomic>
+#include <thread>
 #include <algorithm>
 #include <cctype>
 #include <cstdio>
@@ -144,6 +148,42 @@ private:
 };
 
 } // namespace
+
+namespace {
+std::atomic<int> g_reader_share{1};
+}
+void set_reader_share(int n) { g_reader_share = n < 1 ? 1 : n; }
+int reader_share() { return g_reader_share; }
+
+// CPUs this process may actually use: the affinity mask, cut down to a cgroup v2 / v1 CPU quota when one is set
+// (a container on a 256-thread host is often allowed 16).
+int usable_cpus()
+{
+	int n = (int) std::thread::hardware_concurrency();
+	cpu_set_t set;
+	if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0)
+		n = std::min(n, (int) CPU_COUNT(&set));
+	long long quota = -1, period = -1;
+	if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+		char q[32] = "";
+		if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0)
+			quota = atoll(q);
+		fclose(f);
+	} else {
+		FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"), *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+		if (fq && fp && fscanf(fq, "%lld", &quota) == 1 && fscanf(fp, "%lld", &period) == 1) {
+		} else {
+			quota = -1;
+		}
+		if (fq)
+			fclose(fq);
+		if (fp)
+			fclose(fp);
+	}
+	if (quota > 0 && period > 0)
+		n = std::min(n, (int) std::max(1LL, (quota + period - 1) / period));
+	return std::max(n, 1);
+}
 
 read_source *open_reads(const std::string &path, std::string *err)
 {

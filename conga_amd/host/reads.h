@@ -51,6 +51,10 @@ bool load_fasta_chrom(const std::string &fasta_path, const std::string &name, in
 		std::string *err);
 
 read_source *open_reads(const std::string &path, std::string *err);
+// Readers opened from now on size their inflate pool for 1/n of the host's threads (n readers run side by side).
+void set_reader_share(int n);
+int reader_share();
+int usable_cpus(); // affinity mask and cgroup CPU quota taken into account
 int find_chr_index_bam(const std::string &chromosome_name, const read_source &src); // common.c:289-300
 
 } // namespace conga_host

@@ -179,6 +179,32 @@ def test_cli_outputs_are_byte_identical_to_the_oracle(tmp_path, oracle, inp, del
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("inp,n", [("r.bam", 2), ("r.ctp", 3), ("r.bam", 7)])
+def test_cli_gpus_shards_chromosomes_and_keeps_every_byte(tmp_path, inp, n):
+    """`--gpus N` (chromosomes -> contexts, output by the calling thread in annotation order): the three
+    files, conga.log and the progress text are those of the one-context run.  On a one-GPU box the contexts share it."""
+    d = str(tmp_path)
+    make_inputs(d)
+    base = ["-i", inp, "--ref", "r.fa", "--sonic", "a.cga", "--dels", "dels.bed", "--dups", "dups.bed",
+            "--mappability", "map.bed"]
+    one = run(base + ["--out", "one"], d)
+    assert one.returncode == 0, one.stderr[-2000:]
+    log_one = open(os.path.join(d, "conga.log")).read()
+    many = run(base + ["--out", "many", "--gpus", str(n)], d)
+    assert many.returncode == 0, many.stderr[-2000:]
+    log_many = open(os.path.join(d, "conga.log")).read()
+    for k in ("svs", "dels", "dups"):
+        a = open(os.path.join(d, "one_%s.bed" % k), "rb").read()
+        assert a.count(b"\n") > 1
+        assert a == open(os.path.join(d, "many_%s.bed" % k), "rb").read(), k
+    assert log_one == log_many
+
+    def progress(text, prefix):
+        return [ln.replace(prefix, "OUT") for ln in text.splitlines() if ln and not ln.startswith("[CONGA] --gpus")]
+    assert progress(one.stderr, "one") == progress(many.stderr, "many")
+
+
+@pytest.mark.gpu
 def test_cli_split_reads_rp(tmp_path, oracle):
     """--rp with --dups: FASTA + BAM sequences -> READ_PAIR columns and the `rp > rp_support` rule of _svs.bed
     (likelihood.c:243-279), byte-identical to the oracle."""

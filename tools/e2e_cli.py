@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--input", choices=("bam", "tuples"), default="bam",
                     help="tuples: the read-tuple container (decoded pos / mapq per chromosome) instead of a BAM -- what "
                          "is left of the wall time is file read, PCIe staging, compute and the output writer")
+    ap.add_argument("--gpus", default="1", help="comma list of `conga --gpus` values to run on the same input (contexts "
+                    "share the device when there are fewer devices)")
     a = ap.parse_args()
     d = tempfile.mkdtemp(prefix="conga_e2e_")
     lens = dict(synth.GRCH37_AUTOSOMES)
@@ -42,12 +44,24 @@ def main():
         formats.write_tuples(os.path.join(d, reads_file), "SYNTH", [(c.name, c.length, c.pos, c.mapq) for c in cs])
     t_bam = time.time() - t0
     synth.write_bed(os.path.join(d, "dels.bed"), [(c.name, s, e) for c in cs for s, e in zip(c.del_start, c.del_end)])
-    t0 = time.time()
-    r = subprocess.run([os.path.join(ROOT, "conga_amd", "host", "conga"), "-i", reads_file, "--out", "got", "--ref", "none.fa",
-                        "--sonic", "a.cga", "--dels", "dels.bed"], cwd=d, capture_output=True, text=True,
-                       env=dict(os.environ, CONGA_TIMING="1"))
-    t_cli = time.time() - t0
-    assert r.returncode == 0, r.stderr[-2000:]
+    runs = {}
+    first_bytes = None
+    for g in [int(x) for x in a.gpus.split(",")]:
+        t0 = time.time()
+        r = subprocess.run([os.path.join(ROOT, "conga_amd", "host", "conga"), "-i", reads_file, "--out", "got", "--ref", "none.fa",
+                            "--sonic", "a.cga", "--dels", "dels.bed", "--gpus", str(g)], cwd=d, capture_output=True, text=True,
+                           env=dict(os.environ, CONGA_TIMING="1"))
+        t_cli = time.time() - t0
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs[g] = round(t_cli, 3)
+        got = [open(os.path.join(d, "got_%s.bed" % k), "rb").read() for k in ("svs", "dels")]
+        if first_bytes is None:
+            first_bytes = got
+        assert got == first_bytes, "--gpus %d changed the output files" % g
+        for line in r.stderr.splitlines():
+            if "[timing" in line:
+                print("--gpus %d %s" % (g, line), file=sys.stderr)
+    t_cli = runs[int(a.gpus.split(",")[0])]
     ok = None
     if a.check:
         paths = [os.path.join(d, "want_%s.bed" % k) for k in ("svs", "dels")]
@@ -63,12 +77,9 @@ def main():
             first = False
         ok = all(open(os.path.join(d, "got_%s.bed" % k), "rb").read() == open(w, "rb").read()
                  for k, w in zip(("svs", "dels"), paths))
-    for line in r.stderr.splitlines():
-        if "[timing" in line:
-            print(line, file=sys.stderr)
     n_iv = sum(1 for _ in open(os.path.join(d, "got_dels.bed"))) - 1
     print(json.dumps(dict(chroms=names, reads=int(sum(len(c.pos) for c in cs)), input=a.input, input_mb=round(os.path.getsize(os.path.join(d, reads_file)) / 1e6, 1),
-                          intervals=n_iv, cli_wall_s=round(t_cli, 3), intervals_per_s=round(n_iv / t_cli, 1),
+                          intervals=n_iv, cli_wall_s=round(t_cli, 3), cli_wall_s_by_gpus=runs, intervals_per_s=round(n_iv / t_cli, 1),
                           input_write_s=round(t_bam, 1), outputs_match_oracle=ok, host_cpus=os.cpu_count())))
 
 
