@@ -58,6 +58,9 @@ def parse_args():
                     help="CONGA_FLAG_RESULTS_ON_DEVICE at N=1 too (what every rank of a multi-GPU run does)")
     ap.add_argument("--no-dense-leg", dest="dense_leg", action="store_false",
                     help="skip the dense-formulation leg that follows the timed region at N=1")
+    ap.add_argument("--dist-selftest", action="store_true",
+                    help="run the multi-rank code path (RCCL process group, device-resident records, gather) with the "
+                         "ranks there are, even one -- a one-GPU check of the path the driver runs at N > 1")
     return ap.parse_args()
 
 
@@ -169,6 +172,11 @@ def cpu_baseline(mine, ctx, args):
 
 def main():
     args = parse_args()
+    # stdout carries exactly one JSON line: anything a library prints there while the job runs (RCCL prints a version
+    # banner on stdout when it creates a communicator) goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -189,7 +197,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     gather_dev = torch.device("cpu") if rehearsal else dev
-    if world > 1:
+    dist_on = world > 1 or args.dist_selftest
+    if dist_on:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if rehearsal:
             dist.init_process_group("gloo")
         else:
@@ -197,7 +210,7 @@ def main():
 
     units = build_units(args, world)
     flags = capi.FLAG_BATCH | (capi.FLAG_MATERIALIZE_DEPTH if args.formulation == "dense" else 0)
-    if world > 1 or args.results_on_device:
+    if dist_on or args.results_on_device:
         flags |= capi.FLAG_RESULTS_ON_DEVICE  # the records travel device-to-device into the RCCL gather, not over PCIe
     ctx = capi.Context(device=local_rank, flags=flags)  # every chromosome of this rank, one launch per kernel
     mine = [make_unit(u, args) for u in units if u["owner"] == rank]
@@ -208,7 +221,7 @@ def main():
     bytes_per_rank = [sum((u["n_dels"] + u["n_dups"]) * rec for u in units if u["owner"] == r) for r in range(world)]
     # interval counts after the min-size filter are only known to the owner: exchange them once
     my_bytes = sum(u["n_iv"] for u in mine) * rec
-    if world > 1:
+    if dist_on:
         t = torch.tensor([my_bytes], dtype=torch.int64, device=gather_dev)
         all_b = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(all_b, t)
@@ -221,10 +234,10 @@ def main():
     # wait for the event recorded behind gather k.
     pad = max(max(bytes_per_rank), 1)
     packed2 = [torch.zeros(pad, dtype=torch.uint8, device=dev) for _ in range(2)]
-    recv2 = [[torch.empty(pad, dtype=torch.uint8, device=gather_dev) for _ in range(world)] if (rank == 0 and world > 1) else None
+    recv2 = [[torch.empty(pad, dtype=torch.uint8, device=gather_dev) for _ in range(world)] if (rank == 0 and dist_on) else None
              for _ in range(2)]
     gathered_ev = [None, None]
-    ext_stream = torch.cuda.ExternalStream(ctx.stream(), device=dev) if (world > 1 and not rehearsal) else None
+    ext_stream = torch.cuda.ExternalStream(ctx.stream(), device=dev) if (dist_on and not rehearsal) else None
     total_iv = sum(bytes_per_rank) // rec
     step_no = [0]
 
@@ -235,10 +248,10 @@ def main():
         if ext_stream is not None and gathered_ev[slot] is not None:
             ext_stream.wait_event(gathered_ev[slot])      # the gather that read this buffer two steps ago is done
         ctx.compute()                               # whole hot path for this rank's chromosomes, async
-        if world > 1:
+        if dist_on:
             ctx.results_copy(packed.data_ptr(), my_bytes)   # records stay on the device for the RCCL gather
         ctx.sync()                                  # N=1: the records are in pinned host memory now
-        if world == 1:
+        if not dist_on:
             return [packed[:0]]
         if rehearsal:                               # one GPU, gloo: host tensors
             send = packed.cpu()
@@ -253,7 +266,7 @@ def main():
         return [recv2[slot][r][:bytes_per_rank[r]] for r in range(world)]
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -265,7 +278,7 @@ def main():
         gathered = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -273,9 +286,20 @@ def main():
 
     out = None
     if rank == 0:
-        if world > 1:
+        if dist_on:
             got = sum(g.numel() for g in gathered) // rec
             assert got == total_iv, (got, total_iv)
+            if args.dist_selftest:
+                # the gathered bytes are the records the context holds (un-permuted fetch order = results_copy order)
+                ctx.compute()
+                ctx.sync()
+                want = b""
+                for u in sorted(mine, key=lambda x: x["index"]):
+                    ctx.select(u["index"])
+                    dels, dups = ctx.fetch()[:2]
+                    want += dels.tobytes() + dups.tobytes()
+                have = gathered[0].cpu().numpy().tobytes()
+                assert have == want, "gathered records differ from the fetched ones"
 
         # ---- roofline of the dominant HBM-bound kernel: HIP events recorded on the context's own stream around
         # every kernel (CONGA_FLAG_PROFILE), same resident inputs, one launch per kernel per compute
@@ -388,11 +412,13 @@ def main():
             out["cn_concordance"] = 1.0  # asserted bit-exact against the oracle on the cpu_baseline sample
 
     ctx.close()
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
     if rank == 0:
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,48 @@
+"""bench.py's output contract on a small slice of the workload: stdout is exactly ONE JSON line with the fields the
+driver reads, at N=1 and through the multi-rank code path (RCCL process group, device-resident records, gather) --
+run here with the one rank a one-GPU box has (`--dist-selftest`)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline")
+
+
+def run_bench(extra):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--chroms", "20,21,22", "--steps", "3", "--warmup", "1",
+                        "--no-dense-leg"] + extra, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, "stdout must be one JSON line, got %d lines: %r" % (len(lines), r.stdout[:500])
+    out = json.loads(lines[0])
+    for k in REQUIRED:
+        assert k in out, k
+    assert out["steps"] == 3 and out["warmup"] == 1 and out["n_gpus"] == 1 and out["vs_baseline"] is None
+    assert out["unit"] == "intervals/s" and out["higher_is_better"] is True and out["data"] == "synthetic"
+    rf = out["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert "workload" in out["config"] and "model" not in out["config"]
+    return out
+
+
+@pytest.mark.gpu
+def test_one_json_line_with_cpu_baseline():
+    out = run_bench(["--cpu-seconds", "1"])
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "intervals/s" and cb["value"] > 0 and cb["sample"]
+    assert out["cn_concordance"] == 1.0
+
+
+@pytest.mark.gpu
+def test_multi_rank_code_path_under_rccl_with_one_rank():
+    out = run_bench(["--dist-selftest", "--cpu-seconds", "0"])
+    assert "RCCL gather" in out["config"]["parallelism"]
