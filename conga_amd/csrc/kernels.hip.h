@@ -1429,8 +1429,9 @@ __device__ __forceinline__ conga_result score_interval(const ScoreArgs &a, int64
 // (likelihood.c:111,115-119), bit-exact.  One launch, four classes of intervals (order[] is sorted by the
 // number of GC windows, longest first), so the few long chains run beside the many short ones:
 //   A+ more than kChainBlockWindows windows  one WORKGROUP per interval, 8 windows per lane and pass (2048 per pass)
-//   A  kChainLongWindows + 1 .. kChainBlockWindows      one WAVE per interval, 8 windows per lane and pass
+//   A  kChainLongWindows + 1 .. kChainBlockWindows      one WAVE per interval, 4 windows per lane and pass
 //   B  kChainSerialWindows + 1 .. kChainLongWindows     one 16-lane group per interval, 4 windows per lane and pass
+//      (A and B: the first 64 / 16 windows go one per lane -- most binade crossings of a chain fall there)
 //   C  at most kChainSerialWindows windows    one LANE per interval
 //
 // Inside one binade of the accumulator every GC window advances the mantissa by k * delta ulps
@@ -1548,7 +1549,90 @@ __device__ __forceinline__ ChainInterval chain_interval(const ChainArgs &a, int6
 	return c;
 }
 
-// Classes A (G = 64, W = 8) and B (G = 16, W = 4).
+// The passes of one step of classes A and B: lane gl of a group holds W consecutive windows (k adds of the float whose
+// bits are bc, ca = conga_addend_of(bc); k = 0: no window) and every lane holds the group's accumulator `s`.  Returns
+// the accumulator behind the step's last window.
+template <int G, int W> __device__ __forceinline__ float chain_step_passes(float s, const uint32_t (&k)[W], const uint32_t (&bc)[W],
+		const conga_addend (&ca)[W], bool any_act, int gl, int grp, unsigned long long gmask)
+{
+	constexpr int SW = G * W;
+	int next = 0; // first position of this step (gl * W + j) that is not applied yet; uniform inside a group
+	bool pending = (__ballot(any_act) & gmask) != 0ull;
+	while (__any(pending)) {
+		const uint32_t bs = conga_f32_bits(s);
+		const uint32_t es = bs >> 23;
+		const uint32_t ms = (bs & 0x7FFFFFu) | 0x800000u;
+		uint32_t adv[W], lim[W], dl[W];
+		bool in[W], valid[W];
+		uint32_t lane_total = 0;
+#pragma unroll
+		for (int j = 0; j < W; j++) {
+			in[j] = pending && k[j] != 0 && (gl * W + j) >= next;
+			// ok implies delta <= 2^21, which keeps k * delta (k <= gc_step <= 1024) inside 32 bits and lets the
+			// 24-bit multiplier do it at full rate; larger steps (accumulator within 8x of the addend: the first
+			// window or two of an interval) go the irregular way, as do ties and a negative accumulator (es >= 256)
+			const conga_lean_step st = conga_step_lean(es, ca[j]);
+			valid[j] = in[j] && st.ok != 0u && st.tie == 0u;
+			dl[j] = st.delta;
+			lim[j] = st.lim;
+			const uint32_t a32 = __umul24(k[j], st.delta & 0x3FFFFFu); // (delta <= 2^21 whenever it is used)
+			adv[j] = !valid[j] ? 0u : (a32 > (1u << 24)) ? (1u << 24) : a32; // beyond the binade top anyway
+			lane_total += adv[j];
+		}
+		if (lane_total > (1u << 25))
+			lane_total = 1u << 25; // keeps the group sum below 2^32; only ever hit behind an irregular window
+		const uint32_t incl = group_incl_scan_u32<G>(lane_total);
+		uint32_t m = ms + (incl - lane_total); // mantissa in front of this lane's first window
+		int jb = W;         // first irregular window of this lane
+		uint32_t m_bad = 0; // mantissa in front of it
+#pragma unroll
+		for (int j = 0; j < W; j++) {
+			// regular: the whole run of k adds starts at or below lim.  (A stuck window, delta 0 / lim 2^24 - 1, behind
+			// a prefix that landed exactly on the binade top is sent the irregular way too: the top is the next binade.)
+			const bool ok = valid[j] & (m <= lim[j]) & (__umul24((k[j] - 1u) & 0x7FFu, dl[j] & 0x3FFFFFu) <= lim[j] - m);
+			const bool first_bad = in[j] & !ok & (jb == W);
+			jb = first_bad ? j : jb;
+			m_bad = first_bad ? m : m_bad;
+			m += adv[j];
+		}
+		const unsigned long long bad_all = __ballot(jb < W);
+		const unsigned long long bad = bad_all & gmask;
+		const int fb = bad ? (__ffsll((long long) bad) - 1 - grp * G) : 0;
+		const uint32_t total = group_bcast_u32<G>(incl, G - 1);
+		uint32_t m_fb = 0, k_fb = 0, bc_fb = 0;
+		int j_fb = 0;
+		if (bad_all) { // some group of this wave has an irregular window
+			uint32_t k_sel = 0, bc_sel = 0;
+#pragma unroll
+			for (int j = 0; j < W; j++)
+				if (j == jb) {
+					k_sel = k[j];
+					bc_sel = bc[j];
+				}
+			m_fb = group_bcast_u32<G>(m_bad, fb);
+			j_fb = (int) group_bcast_u32<G>((uint32_t) jb, fb);
+			k_fb = group_bcast_u32<G>(k_sel, fb);
+			bc_fb = group_bcast_u32<G>(bc_sel, fb);
+		}
+		if (pending) {
+			if (bad == 0ull) {
+				if (total)
+					s = conga_compose_f32(es, ms + total);
+				pending = false;
+			} else {
+				if (m_fb != ms)
+					s = conga_compose_f32(es, m_fb); // exact state in front of the irregular window
+				s = conga_window_add_f32(s, conga_bits_f32(bc_fb), k_fb); // real adds where rounding is not a constant step
+				next = fb * W + j_fb + 1;
+				if (next >= SW)
+					pending = false;
+			}
+		}
+	}
+	return s;
+}
+
+// Classes A (G = 64) and B (G = 16), W = 4 windows per lane and pass.
 // `wave`: index of this wave inside its class; `sE_wave`: this wave's LDS (one depth table per lane group).
 template <int G, int W> __device__ __forceinline__ void chain_group_body(const ChainArgs &a, int64_t wave, int64_t first,
 		int64_t count, float *sE_wave)
@@ -1585,109 +1669,52 @@ template <int G, int W> __device__ __forceinline__ void chain_group_body(const C
 			return *reinterpret_cast<const uint64_t *>(gc + at);
 		return *reinterpret_cast<const uint32_t *>(gc + at);
 	};
+	// k and the addend of window w (k = 0: not one of this interval's windows at or behind w_from)
+	auto window = [&](uint32_t w, uint32_t g_raw, uint32_t w_from, uint32_t &k_out, uint32_t &bc_out) -> bool {
+		// select-style on purpose: executed by every lane, and a branch around a few instructions costs more (mask
+		// bookkeeping on the scalar unit, a refilled instruction buffer) than they do
+		const uint32_t edge = w * (uint32_t) step; // first base of window w; positions stay below 2^31 + step
+		const bool act = have && w >= w_from && w < (uint32_t) w_end;
+		const uint32_t lo = (edge > (uint32_t) s0) ? edge : (uint32_t) s0;
+		const uint32_t hi = (edge + (uint32_t) step < (uint32_t) e0) ? edge + (uint32_t) step : (uint32_t) e0;
+		k_out = act ? hi - lo : 0u; // >= 1 when active
+		const uint32_t g_cur = (w < (uint32_t) n_win) ? g_raw : gc_last;
+		const float e_cur = E[(g_cur < (uint32_t) kGcBins) ? g_cur : 0u];
+		bc_out = (act && g_cur < (uint32_t) kGcBins) ? conga_f32_bits(e_cur) : 0u;
+		return act;
+	};
 
 	float s = 0.0f; // uniform inside a group
-	int64_t wb = w_first & ~(int64_t) (SW - 1); // steps are aligned, lanes in front of w_first idle
+	// Head: the first G windows, one per lane.  The accumulator doubles within the first window, again by the
+	// second, the fourth, the eighth ...: most binade crossings of a chain -- each costs a pass -- fall into its first
+	// dozen windows, and a pass over one window per lane is a third of the instructions of a pass over four.
+	const uint32_t head_w = (uint32_t) w_first + (uint32_t) gl;
+	const uint32_t head_g = (have && head_w < (uint32_t) n_win) ? gc[head_w] : 0u;
+	int64_t wb = (w_first + G) & ~(int64_t) (SW - 1); // steps are aligned, lanes in front of w_first + G idle
+	if (w_first + G >= w_end)
+		wb = (w_end + SW - 1) & ~(int64_t) (SW - 1); // (nothing behind the head)
 	uint64_t cur = fetch(wb), nxt1 = fetch(wb + SW);
 	__builtin_amdgcn_wave_barrier(); // the table is written and read by lanes of the same wave: LDS ops stay in order
+	{
+		uint32_t k1[1], bc1[1];
+		conga_addend ca1[1];
+		const bool act = window(head_w, head_g, (uint32_t) w_first, k1[0], bc1[0]);
+		ca1[0] = conga_addend_of(bc1[0]);
+		s = chain_step_passes<G, 1>(s, k1, bc1, ca1, act, gl, grp, gmask);
+	}
+	const uint32_t w_from = (uint32_t) w_first + (uint32_t) G;
 	while (__any(wb < w_end)) {
 		const uint64_t nxt2 = fetch(wb + 2 * SW); // two steps ahead, so that no step waits on HBM
 		uint32_t k[W], bc[W];
 		conga_addend ca[W];
 		bool any_act = false;
-		{
-			const uint32_t w0 = (uint32_t) wb + (uint32_t) gl * W; // positions stay below 2^31 + step
-			uint32_t edge = w0 * (uint32_t) step;                  // first base of window w0 + j
+		const uint32_t w0 = (uint32_t) wb + (uint32_t) gl * W;
 #pragma unroll
-			for (int j = 0; j < W; j++) {
-				const uint32_t w = w0 + j;
-				// select-style on purpose: this loop and the passes below are executed by every lane, and a branch around a
-				// few instructions costs more (mask bookkeeping on the scalar unit, a refilled instruction buffer) than they do
-				const bool act = w >= (uint32_t) w_first && w < (uint32_t) w_end;
-				const uint32_t lo = (edge > (uint32_t) s0) ? edge : (uint32_t) s0;
-				const uint32_t hi = (edge + (uint32_t) step < (uint32_t) e0) ? edge + (uint32_t) step : (uint32_t) e0;
-				k[j] = act ? hi - lo : 0u; // >= 1 when active
-				const uint32_t g_cur = (w < (uint32_t) n_win) ? (uint32_t) ((cur >> (8 * j)) & 0xFFu) : gc_last;
-				const float e_cur = E[(g_cur < (uint32_t) kGcBins) ? g_cur : 0u];
-				bc[j] = (act && g_cur < (uint32_t) kGcBins) ? conga_f32_bits(e_cur) : 0u;
-				any_act |= act;
-				ca[j] = conga_addend_of(bc[j]);
-				edge += (uint32_t) step;
-			}
+		for (int j = 0; j < W; j++) {
+			any_act |= window(w0 + j, (uint32_t) ((cur >> (8 * j)) & 0xFFu), w_from, k[j], bc[j]);
+			ca[j] = conga_addend_of(bc[j]);
 		}
-		int next = 0; // first position of this step (gl * W + j) that is not applied yet; uniform inside a group
-		bool pending = (__ballot(any_act) & gmask) != 0ull;
-		while (__any(pending)) {
-			const uint32_t bs = conga_f32_bits(s);
-			const uint32_t es = bs >> 23;
-			const uint32_t ms = (bs & 0x7FFFFFu) | 0x800000u;
-			uint32_t adv[W], lim[W], dl[W];
-			bool in[W], valid[W];
-			uint32_t lane_total = 0;
-#pragma unroll
-			for (int j = 0; j < W; j++) {
-				in[j] = pending && k[j] != 0 && (gl * W + j) >= next;
-				// ok implies delta <= 2^21, which keeps k * delta (k <= gc_step <= 1024) inside 32 bits and lets the
-				// 24-bit multiplier do it at full rate; larger steps (accumulator within 8x of the addend: the first
-				// window or two of an interval) go the irregular way, as do ties and a negative accumulator (es >= 256)
-				const conga_lean_step st = conga_step_lean(es, ca[j]);
-				valid[j] = in[j] && st.ok != 0u && st.tie == 0u;
-				dl[j] = st.delta;
-				lim[j] = st.lim;
-				const uint32_t a32 = __umul24(k[j], st.delta & 0x3FFFFFu); // (delta <= 2^21 whenever it is used)
-				adv[j] = !valid[j] ? 0u : (a32 > (1u << 24)) ? (1u << 24) : a32; // beyond the binade top anyway
-				lane_total += adv[j];
-			}
-			if (lane_total > (1u << 25))
-				lane_total = 1u << 25; // keeps the group sum below 2^32; only ever hit behind an irregular window
-			const uint32_t incl = group_incl_scan_u32<G>(lane_total);
-			uint32_t m = ms + (incl - lane_total); // mantissa in front of this lane's first window
-			int jb = W;         // first irregular window of this lane
-			uint32_t m_bad = 0; // mantissa in front of it
-#pragma unroll
-			for (int j = 0; j < W; j++) {
-				// regular: the whole run of k adds starts at or below lim.  (A stuck window, delta 0 / lim 2^24 - 1, behind
-				// a prefix that landed exactly on the binade top is sent the irregular way too: the top is the next binade.)
-				const bool ok = valid[j] & (m <= lim[j]) & (__umul24((k[j] - 1u) & 0x7FFu, dl[j] & 0x3FFFFFu) <= lim[j] - m);
-				const bool first_bad = in[j] & !ok & (jb == W);
-				jb = first_bad ? j : jb;
-				m_bad = first_bad ? m : m_bad;
-				m += adv[j];
-			}
-			const unsigned long long bad_all = __ballot(jb < W);
-			const unsigned long long bad = bad_all & gmask;
-			const int fb = bad ? (__ffsll((long long) bad) - 1 - grp * G) : 0;
-			const uint32_t total = group_bcast_u32<G>(incl, G - 1);
-			uint32_t m_fb = 0, k_fb = 0, bc_fb = 0;
-			int j_fb = 0;
-			if (bad_all) { // some group of this wave has an irregular window
-				uint32_t k_sel = 0, bc_sel = 0;
-#pragma unroll
-				for (int j = 0; j < W; j++)
-					if (j == jb) {
-						k_sel = k[j];
-						bc_sel = bc[j];
-					}
-				m_fb = group_bcast_u32<G>(m_bad, fb);
-				j_fb = (int) group_bcast_u32<G>((uint32_t) jb, fb);
-				k_fb = group_bcast_u32<G>(k_sel, fb);
-				bc_fb = group_bcast_u32<G>(bc_sel, fb);
-			}
-			if (pending) {
-				if (bad == 0ull) {
-					if (total)
-						s = conga_compose_f32(es, ms + total);
-					pending = false;
-				} else {
-					if (m_fb != ms)
-						s = conga_compose_f32(es, m_fb); // exact state in front of the irregular window
-					s = conga_window_add_f32(s, conga_bits_f32(bc_fb), k_fb); // real adds where rounding is not a constant step
-					next = fb * W + j_fb + 1;
-					if (next >= SW)
-						pending = false;
-				}
-			}
-		}
+		s = chain_step_passes<G, W>(s, k, bc, ca, any_act, gl, grp, gmask);
 		wb += SW;
 		cur = nxt1;
 		nxt1 = nxt2;
