@@ -954,6 +954,15 @@ int conga_chrom_begin(conga_ctx *ctx, int64_t chrom_len, const uint8_t *gc_hist_
 		return fail(ctx, CONGA_ERR_INVALID, "conga_chrom_begin: n_win must be ceil(chrom_len / gc_step)");
 	if (ctx->staging_cur >= 0)
 		return fail(ctx, CONGA_ERR_INVALID, "conga_chrom_begin: a staging buffer is handed out and not committed");
+	{
+		// the reference indexes its 101-entry tables with these (read_distribution.c:71-72, likelihood.c:118): a value
+		// above 100 would read and write past them there
+		uint8_t top = 0;
+		for (int64_t w = 0; w < n_win; w++)
+			top = std::max(top, std::max(gc_hist_w[w], gc_like_w[w]));
+		if (top >= kGcBins)
+			return fail(ctx, CONGA_ERR_RANGE, "conga_chrom_begin: GC value above 100");
+	}
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	if (!batch_mode(ctx)) {
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -172,7 +172,8 @@ int conga_chrom_select(conga_ctx *ctx, int index);
  * chrom_len = sonic->chromosome_lengths[chr_index].  gc_hist_w[w] is the rounded GC% (0..100) that
  * `sonic_get_gc_content(chr, i, min(i + step, L))` yields for bases i in window w (loop of
  * read_distribution.c:63-73); gc_like_w[w] the one `sonic_get_gc_content(chr, i, i + step)` yields
- * (likelihood.c:117).  They may be the same pointer.  n_win must be ceil(chrom_len / gc_step).
+ * (likelihood.c:117).  They may be the same pointer.  n_win must be ceil(chrom_len / gc_step); a value above
+ * 100 is refused with CONGA_ERR_RANGE (the reference would index past its 101-entry tables).
  * The arrays are copied.  Sequential mode: resets all per-chromosome state (reads, intervals,
  * mappability, split support).  Batch mode: opens one more chromosome and selects it. */
 int conga_chrom_begin(conga_ctx *ctx, int64_t chrom_len, const uint8_t *gc_hist_w, const uint8_t *gc_like_w,

@@ -1,0 +1,190 @@
+"""Randomised differential soak: HIP path (through the C-ABI) against the CPU oracle on adversarial small cases.
+
+Not collected by pytest (run it by hand on a GPU box: `python tests/soak.py --cases 300 --seed 1`).  The cases are
+not the bench generator's: chromosome lengths that are not multiples of the window, GC bytes over the whole 0..100
+range, reads piled up on single bases / on the first and last base / out of range, any mapq threshold, intervals of
+any length (zero, one base, nested, identical, whole chromosome, past the end), mappability rows sorted, abutting,
+overlapping or shuffled, several chromosomes per batch, both formulations.  Checks are the parity tests' own
+(`tests/test_gpu_parity.py: compare`): integers and expected_rd bit-exact, log-likelihoods within 1e-6.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def random_case(rng, step=None, mq=None):
+    if step is None:
+        step = int(rng.choice([100, 100, 100, 100, 64, 7, 1000]))
+    L = int(rng.choice([rng.integers(1, 300), rng.integers(300, 20_000), rng.integers(20_000, 400_000),
+                        rng.integers(400_000, 3_000_000)], p=[0.1, 0.3, 0.4, 0.2]))
+    n_win = (L + step - 1) // step
+    kind = rng.integers(0, 5)
+    if kind <= 1:
+        gc = rng.integers(0, 101, n_win).astype(np.uint8)
+    elif kind == 2:
+        gc = np.full(n_win, int(rng.integers(0, 101)), np.uint8)       # one bin only
+    else:
+        walk = np.cumsum(rng.normal(0, 1.5, n_win)) + rng.integers(25, 60)
+        gc = np.clip(np.round(walk), 0, 100).astype(np.uint8)
+        if n_win > 20 and rng.random() < 0.5:                          # a gap
+            a = int(rng.integers(0, n_win - 10))
+            gc[a:a + int(rng.integers(1, n_win - a))] = 0
+    gc_like = None
+    if rng.random() < 0.15:
+        gc_like = gc.copy()
+        gc_like[-1] = rng.integers(0, 101)
+
+    # reads
+    n = int(rng.choice([0, rng.integers(1, 50), rng.integers(50, 5000), rng.integers(5000, 400_000)], p=[0.05, 0.15, 0.4, 0.4]))
+    mode = rng.integers(0, 4)
+    if mode == 0:
+        pos = rng.integers(0, L, n)
+    elif mode == 1:                                                    # clustered: heavy pile-ups
+        centers = rng.integers(0, L, max(1, n // 500 + 1))
+        pos = np.clip(rng.choice(centers, n) + rng.integers(-3, 4, n), 0, L - 1)
+    elif mode == 2:                                                    # everything on a few bases, ends included
+        pos = rng.choice(np.array([0, L - 1, L // 2, min(L - 1, step), max(0, L - step)]), n)
+    else:
+        pos = (rng.random(n) ** 2 * L).astype(np.int64)
+    pos = np.sort(pos).astype(np.int32)
+    mapq = rng.choice([rng.integers(0, 256, n), np.full(n, 60), rng.choice([0, 60], n)]).astype(np.uint8) if n else np.zeros(0, np.uint8)
+    if mq is None:
+        mq = int(rng.choice([-1, -1, 0, 1, 20, 59, 60, 254, 255]))
+
+    def intervals(k):
+        s = rng.integers(0, max(L, 1), k)
+        ln = rng.choice([rng.integers(0, 3, k), rng.integers(1, 2 * step + 2, k), rng.integers(1000, 20_000, k),
+                         rng.integers(1, max(2, L), k), np.full(k, L)])
+        if ln.sum() > 3e7:                                             # the oracle walks every base
+            ln = ln % 20_000
+        e = s + ln
+        if rng.random() < 0.5:
+            e = np.minimum(e, L + int(rng.integers(0, 3 * step)))
+        e = np.minimum(e, 2**31 - 2 - 2 * step)
+        if k > 3 and rng.random() < 0.5:                               # identical and nested rows
+            s[1], e[1] = s[0], e[0]
+            s[2], e[2] = s[0], max(s[0], e[0] - 1)
+        s[rng.random(k) < 0.1] = 0
+        order = np.lexsort((e, s))
+        return s[order].astype(np.int32), e[order].astype(np.int32)
+
+    ds, de = intervals(int(rng.choice([0, 1, 5, 40, 300])))
+    us, ue = intervals(int(rng.choice([0, 0, 1, 8, 60])))
+
+    rows = None
+    if rng.random() < 0.5:
+        m = int(rng.choice([0, 1, 10, 500, 5000]))
+        vals = rng.choice(np.array([1, 0.5, 0.333333, 0.25, 0.2, 0.1, 0.0, 0.7731], np.float32), m)
+        layout = rng.integers(0, 4)
+        if layout == 0 and m:                                          # bedGraph: sorted, abutting (shared end points)
+            cuts = np.sort(rng.integers(0, L, m + 1))
+            ms, me = cuts[:-1], cuts[1:]
+        elif layout == 1 and m:                                        # sorted, disjoint with holes
+            cuts = np.sort(rng.integers(0, L, 2 * m))
+            ms, me = cuts[0::2], np.maximum(cuts[0::2], cuts[1::2] - 1)
+        else:                                                          # any order, overlapping
+            ms = rng.integers(0, L, m)
+            me = np.minimum(ms + rng.integers(0, max(2, L // 4), m), L - 1)
+        rows = (ms.astype(np.int32), me.astype(np.int32), vals.astype(np.float32))
+    return dict(L=L, step=step, gc=gc, gc_like=gc_like, pos=pos, mapq=mapq, mq=mq, ds=ds, de=de, us=us, ue=ue, rows=rows)
+
+
+def describe(c):
+    return ("L=%d step=%d reads=%d mq=%d dels=%d dups=%d rows=%s gc_like=%s" % (
+        c["L"], c["step"], len(c["pos"]), c["mq"], len(c["ds"]), len(c["us"]),
+        None if c["rows"] is None else len(c["rows"][0]), c["gc_like"] is not None))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=200)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--seconds", type=float, default=0, help="stop after this long (0: run all cases)")
+    ap.add_argument("--batch", action="store_true",
+                    help="CONGA_FLAG_BATCH: 1..12 random chromosomes per context (one launch per kernel over all of them), "
+                         "computed twice, with random chain-class thresholds")
+    a = ap.parse_args()
+    import torch  # noqa: F401  (before the library: it ships its own HIP runtime)
+    from conga_amd import capi
+    from oracle import oracle as O
+    import test_gpu_parity as T
+
+    t0 = time.time()
+    done = 0
+    for i in range(a.cases if a.batch else 0):
+        rng = np.random.default_rng([a.seed, 7_000_000 + i])
+        step = int(rng.choice([100, 100, 100, 64, 1000]))
+        mq = int(rng.choice([-1, -1, 0, 20, 60]))
+        cases = [random_case(rng, step, mq) for _ in range(int(rng.integers(1, 13)))]
+        knobs = {}
+        if rng.random() < 0.7:  # class boundaries of the chain kernel (conga_api.hip: prepare)
+            knobs = dict(CONGA_CHAIN_SERIAL_WINDOWS=str(int(rng.choice([0, 3, 20, 56, 200]))),
+                         CONGA_CHAIN_LONG_WINDOWS=str(int(rng.choice([4, 64, 512, 4000]))),
+                         CONGA_CHAIN_BLOCK_WINDOWS=str(int(rng.choice([64, 700, 2048, 100000]))))
+        os.environ.update(knobs)
+        try:
+            for dense in (0, 1):
+                capi.EXTRA_FLAGS = capi.FLAG_MATERIALIZE_DEPTH if dense else 0
+                with capi.Context(device=0, mq_threshold=mq, gc_step=step, flags=capi.FLAG_BATCH) as ctx:
+                    for c in cases:
+                        ctx.chrom_begin(c["L"], c["gc"], c["gc_like"])
+                        ctx.reads(c["pos"], c["mapq"])
+                        if c["rows"] is not None:
+                            ctx.mappability(*c["rows"])
+                        ctx.intervals("D", c["ds"], c["de"])
+                        ctx.intervals("E", c["us"], c["ue"])
+                    ctx.compute()
+                    ctx.compute()
+                    for j, c in enumerate(cases):
+                        ctx.select(j)
+                        dels, dups, E, st = ctx.fetch()
+                        got = dict(dels=dels, dups=dups, E=E, counted=st.reads_counted, S=np.array(st.rd_per_gc[:]),
+                                   W=np.array(st.window_per_gc[:]))
+                        want = T.run_oracle(O, c["L"], c["gc"], c["pos"], c["mapq"], c["ds"], c["de"], c["us"], c["ue"], mq=mq,
+                                            step=step, rows=c["rows"], gc_like=c["gc_like"])
+                        try:
+                            T.compare(got, want, c["rows"] is not None)
+                        except Exception:
+                            print("FAILED batch %d chromosome %d (seed %d, %s, knobs %s): %s" % (
+                                i, j, a.seed, "dense" if dense else "tuple space", knobs, describe(c)), flush=True)
+                            raise
+        finally:
+            for k in knobs:
+                os.environ.pop(k, None)
+        done += 1
+        if i % 10 == 9:
+            print("%d batches ok, %.0f s" % (done, time.time() - t0), flush=True)
+        if a.seconds and time.time() - t0 > a.seconds:
+            break
+    for i in range(0 if a.batch else a.cases):
+        rng = np.random.default_rng([a.seed, i])
+        c = random_case(rng)
+        want = T.run_oracle(O, c["L"], c["gc"], c["pos"], c["mapq"], c["ds"], c["de"], c["us"], c["ue"], mq=c["mq"],
+                            step=c["step"], rows=c["rows"], gc_like=c["gc_like"])
+        for dense in (0, 1):
+            capi.EXTRA_FLAGS = capi.FLAG_MATERIALIZE_DEPTH if dense else 0
+            try:
+                got = T.run_gpu(capi, c["L"], c["gc"], c["pos"], c["mapq"], c["ds"], c["de"], c["us"], c["ue"], mq=c["mq"],
+                                step=c["step"], rows=c["rows"], gc_like=c["gc_like"])
+                T.compare(got, want, c["rows"] is not None)
+            except Exception:
+                print("FAILED case %d (seed %d, %s): %s" % (i, a.seed, "dense" if dense else "tuple space", describe(c)), flush=True)
+                raise
+        done += 1
+        if i % 20 == 19:
+            print("%d cases ok, %.0f s" % (done, time.time() - t0), flush=True)
+        if a.seconds and time.time() - t0 > a.seconds:
+            break
+    capi.EXTRA_FLAGS = 0
+    print("soak: %d %s x 2 formulations agree with the oracle (seed %d, %.0f s)" % (done, "batches" if a.batch else "cases", a.seed, time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()

@@ -49,7 +49,8 @@ def test_no_device_means_no_context(capi):
 
 def test_product_never_touches_the_oracle():
     """Only tests/, __graft_entry__.smoke() and bench.py may use oracle/."""
-    for base, _, files in os.walk(os.path.join(ROOT, "conga_amd")):
+    dirs = [os.path.join(ROOT, "conga_amd"), os.path.join(ROOT, "tools"), os.path.join(ROOT, "include")]
+    for base, _, files in (x for d in dirs for x in os.walk(d)):
         for f in files:
             if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp", ".c")) or f == "Makefile":
                 text = open(os.path.join(base, f), errors="ignore").read()
