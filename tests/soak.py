@@ -96,6 +96,72 @@ def random_case(rng, step=None, mq=None):
     return dict(L=L, step=step, gc=gc, gc_like=gc_like, pos=pos, mapq=mapq, mq=mq, ds=ds, de=de, us=us, ue=ue, rows=rows)
 
 
+CODE = {65: 1, 67: 2, 71: 4, 84: 8}  # BAM 4-bit codes of A C G T; everything else 15 (N)
+
+
+def random_split_case(rng):
+    """Reference + whole BAM records for the --rp path (split_read.c:31-466, bam_data.c:29-154, likelihood.c:41-94)."""
+    L = int(rng.integers(30_000, 500_000))
+    ref = rng.choice(np.frombuffer(b"ACGT", np.uint8), L)
+    for _ in range(int(rng.integers(0, 4))):                        # low-complexity stretches: crowded 10-mer buckets
+        a = int(rng.integers(0, L - 2000))
+        n = int(rng.integers(200, 20_000))
+        ref[a:a + n] = rng.choice(np.frombuffer(rng.choice([b"AC", b"AT", b"A", b"ACG"]), np.uint8), len(ref[a:a + n]))
+    for _ in range(int(rng.integers(0, 6))):                        # repeats (within and beyond the 100 kb look-ahead)
+        n = int(rng.integers(50, 3000))
+        a, b = int(rng.integers(0, L - n)), int(rng.integers(0, L - n))
+        ref[b:b + n] = ref[a:a + n]
+    for _ in range(int(rng.integers(0, 3))):
+        a = int(rng.integers(0, L - 500))
+        ref[a:a + int(rng.integers(1, 400))] = ord("N")
+    lower = ref.copy()
+    a = int(rng.integers(0, L - 100))
+    lower[a:a + int(rng.integers(1, 5000))] |= 0x20
+
+    def ivs(k, lo, hi):
+        s = np.sort(rng.integers(100, max(101, L - hi - 200), k))
+        return [(int(x), int(x + rng.integers(lo, hi))) for x in s]
+    dels = ivs(int(rng.integers(0, 6)), 1000, 8000)
+    dups = ivs(int(rng.integers(1, 6)), 1000, 20_000)
+    reads = []
+
+    def add(pos, bases, mapq=60, flag=0, q=30):
+        if 0 <= pos and len(bases) > 0:
+            reads.append((int(pos), np.asarray(bases, np.uint8), mapq, flag, np.full(len(bases), q, np.uint8)))
+    for (s0, e0) in dels:
+        for k in range(int(rng.integers(20, 40)), 80, int(rng.integers(2, 9))):
+            add(s0 - k, np.concatenate([ref[s0 - k:s0], ref[e0:e0 + 100 - k]]))
+    for (s0, e0) in dups:
+        for k in range(int(rng.integers(25, 45)), 75, int(rng.integers(2, 9))):
+            add(e0 - k, np.concatenate([ref[e0 - k:e0], ref[s0:s0 + 100 - k]]))
+    for _ in range(int(rng.integers(0, 6000))):
+        l = int(rng.choice([100, 100, 101, 76, 70, 59, 60, 61, 151, 36, 250]))
+        p = int(rng.integers(0, max(1, L - l - 1)))
+        b = ref[p:p + l].copy()
+        if rng.random() < 0.3:
+            idx = rng.integers(0, l, int(rng.integers(1, 6)))
+            b[idx] = rng.choice(np.frombuffer(b"ACGTN", np.uint8), len(idx))
+        add(p, b, int(rng.choice([60, 60, 60, 0, 17, 40, 255])), int(rng.choice([0, 0, 0, 0, 0x400, 0x100, 0x800, 0x200, 16, 4])),
+            int(rng.choice([30, 30, 12, 2, 40])))
+    add(0, ref[0:100])
+    reads.sort(key=lambda r: r[0])
+    pos = np.array([r[0] for r in reads], np.int32)
+    lq = np.array([len(r[1]) for r in reads], np.int32)
+    off = np.concatenate([[0], np.cumsum(lq)[:-1]]).astype(np.uint64)
+    lut = np.full(256, 15, np.uint8)
+    for k, v in CODE.items():
+        lut[k] = v
+    codes = lut[np.concatenate([r[1] for r in reads])]
+    qual = np.concatenate([r[4] for r in reads])
+    mapq = np.array([r[2] for r in reads], np.uint8)
+    flag = np.array([r[3] for r in reads], np.uint16)
+    ns = int(rng.integers(0, 5))
+    sat_s = rng.integers(0, L - 10, ns).astype(np.int32)
+    sat_e = (sat_s + rng.integers(1, 5000, ns)).astype(np.int32)
+    return dict(L=L, ref=bytes(ref), ref_lower=bytes(lower), dels=dels, dups=dups, pos=pos, mapq=mapq, flag=flag, lq=lq,
+                off=off, codes=codes, qual=qual, sat_s=sat_s, sat_e=sat_e)
+
+
 def describe(c):
     return ("L=%d step=%d reads=%d mq=%d dels=%d dups=%d rows=%s gc_like=%s" % (
         c["L"], c["step"], len(c["pos"]), c["mq"], len(c["ds"]), len(c["us"]),
@@ -107,6 +173,7 @@ def main():
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--seconds", type=float, default=0, help="stop after this long (0: run all cases)")
+    ap.add_argument("--split-reads", action="store_true", help="the --rp path: random references and whole BAM records")
     ap.add_argument("--batch", action="store_true",
                     help="CONGA_FLAG_BATCH: 1..12 random chromosomes per context (one launch per kernel over all of them), "
                          "computed twice, with random chain-class thresholds")
@@ -118,6 +185,28 @@ def main():
 
     t0 = time.time()
     done = 0
+    if a.split_reads:
+        import test_gpu_split_reads as S
+        for i in range(a.cases):
+            rng = np.random.default_rng([a.seed, 9_000_000 + i])
+            c = random_split_case(rng)
+            mq, min_len = int(rng.choice([-1, -1, 0, 20, 35])), int(rng.choice([60, 60, 10, 75, 100]))
+            try:
+                (dels, dups, st), (od, ou, rows, counts) = S.run_both(capi, O, c, mq, min_len)
+                assert (st.split_elements, st.split_mappings, st.split_del_rows, st.split_dup_rows) == tuple(int(x) for x in counts)
+                assert np.array_equal(dels["border_rp"], od["border_rp"]) and np.all(dels["rp"] == 0)
+                assert np.array_equal(dups["rp"], ou["rp"]) and np.all(dups["border_rp"] == 0)
+            except Exception:
+                print("FAILED split-read case %d (seed %d): L=%d reads=%d dels=%d dups=%d mq=%d min_len=%d" % (
+                    i, a.seed, c["L"], len(c["pos"]), len(c["dels"]), len(c["dups"]), mq, min_len), flush=True)
+                raise
+            done += 1
+            if i % 10 == 9:
+                print("%d split-read cases ok, %.0f s" % (done, time.time() - t0), flush=True)
+            if a.seconds and time.time() - t0 > a.seconds:
+                break
+        print("soak: %d split-read cases agree with the oracle (seed %d, %.0f s)" % (done, a.seed, time.time() - t0))
+        return
     for i in range(a.cases if a.batch else 0):
         rng = np.random.default_rng([a.seed, 7_000_000 + i])
         step = int(rng.choice([100, 100, 100, 64, 1000]))
