@@ -122,7 +122,7 @@ public:
 private:
 	struct task {
 		std::vector<uint8_t> cdata, out;
-		uint32_t isize = 0;
+		uint32_t isize = 0, crc = 0;
 		bool done = false, failed = false;
 	};
 	static constexpr size_t kAhead = 48;
@@ -160,7 +160,10 @@ private:
 		zs.avail_out = t.isize;
 		const int rc = inflate(&zs, Z_FINISH);
 		inflateEnd(&zs);
-		return rc == Z_STREAM_END && zs.avail_out == 0;
+		if (rc != Z_STREAM_END || zs.avail_out != 0)
+			return false;
+		// the gzip trailer's CRC32 of the inflated bytes (htslib's bgzf layer refuses a block that fails it too)
+		return (uint32_t) crc32(crc32(0L, Z_NULL, 0), t.out.data(), (uInt) t.out.size()) == t.crc;
 	}
 
 	void work()
@@ -228,6 +231,7 @@ private:
 				err_ = "truncated BGZF block";
 				return false;
 			}
+			memcpy(&t->crc, t->cdata.data() + cdata, 4);
 			memcpy(&t->isize, t->cdata.data() + cdata + 4, 4);
 			t->cdata.resize((size_t) cdata);
 			if (t->isize == 0)
@@ -273,7 +277,7 @@ private:
 			queue_.pop_front();
 		}
 		if (t->failed) {
-			err_ = "BGZF inflate failed";
+			err_ = "BGZF block does not inflate to its recorded size and CRC32";
 			return false;
 		}
 		cur_ = t;
@@ -491,7 +495,7 @@ private:
 		int32_t block_size;
 		uint8_t b[32];
 		if (!bgzf_.read(&block_size, 4) || block_size < 32 || !bgzf_.read(b, 32)) {
-			*err = "truncated BAM record";
+			*err = bgzf_.error().empty() ? "truncated BAM record" : bgzf_.error();
 			return false;
 		}
 		memcpy(&c->ref_id, b, 4);
@@ -509,7 +513,7 @@ private:
 		} else
 			ok = bgzf_.skip(rest);
 		if (!ok) {
-			*err = "truncated BAM record";
+			*err = bgzf_.error().empty() ? "truncated BAM record" : bgzf_.error();
 			return false;
 		}
 		return true;

@@ -104,6 +104,65 @@ def test_bam_and_tuple_readers_yield_the_same_records(tmp_path):
             assert lines[c.name] == "%d\t%d\t%d" % (len(c.pos), c.pos.astype(np.int64).sum(), c.mapq.astype(np.int64).sum())
 
 
+def _reframe_bgzf(src, dst, payloads, extra_subfield=False, empty_every=0):
+    """Inflate a BAM with Python's gzip (multi-member gzip is what BGZF is) and write the same bytes back in blocks
+    of the given payload sizes (cycled), optionally with a second gzip extra subfield and empty blocks in between."""
+    import gzip
+    import struct
+    import zlib
+    raw = gzip.decompress(open(src, "rb").read())
+
+    def block(data):
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        cdata = co.compress(data) + co.flush()
+        extra = b"BC\x02\x00" + b"\x00\x00"
+        if extra_subfield:
+            extra = b"XY\x03\x00abc" + extra  # another subfield in front of BC (RFC 1952 allows any number)
+        bsize = 12 + len(extra) + len(cdata) + 8 - 1
+        extra = extra[:-2] + struct.pack("<H", bsize)
+        return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", len(extra)) + extra + cdata
+                + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+    out, at, k = [], 0, 0
+    while at < len(raw):
+        n = payloads[k % len(payloads)]
+        out.append(block(raw[at:at + n]))
+        at += n
+        k += 1
+        if empty_every and k % empty_every == 0:
+            out.append(block(b""))
+    out.append(formats._BGZF_EOF)
+    open(dst, "wb").write(b"".join(out))
+    return raw
+
+
+def test_bam_reader_takes_any_valid_bgzf_framing_and_checks_the_crc(tmp_path):
+    """The writer's files are valid multi-member gzip (checked with Python's gzip, which shares no code with the C++
+    reader); the reader gives the same records for blocks of 1 byte .. 64 KiB - 1, records and header fields split
+    across blocks, empty blocks inside the file, extra gzip subfields; a block whose CRC32 is wrong is an error."""
+    d = str(tmp_path)
+    make_inputs(d)
+    args = ["--out", "o", "--ref", "r.fa", "--sonic", "a.cga", "--dump-reads"]
+    want = run(["-i", "r.bam"] + args, d)
+    assert want.returncode == 0, want.stderr
+    raw = None
+    for name, kw in (("tiny.bam", dict(payloads=[1, 2, 3, 5, 7, 64, 4096])),
+                     ("big.bam", dict(payloads=[65535])),  # 0xFFFF: BGZF's limit (incompressible data would not fit; this one does)
+                     ("odd.bam", dict(payloads=[33, 65000, 1], extra_subfield=True, empty_every=3))):
+        raw = _reframe_bgzf(os.path.join(d, "r.bam"), os.path.join(d, name), **kw)
+        got = run(["-i", name] + args, d)
+        assert got.returncode == 0, (name, got.stderr)
+        assert got.stdout.replace(name, "r.bam") == want.stdout, name
+    assert raw[:4] == b"BAM\x01"
+    data = bytearray(open(os.path.join(d, "odd.bam"), "rb").read())
+    first_len = 1 + (data[12 + 7 + 4] | (data[12 + 7 + 5] << 8))  # BSIZE + 1 of the first block (extra: XY(7) then BC)
+    for name, at in (("bad_first.bam", first_len - 8), ("bad_later.bam", len(data) - 28 - 8)):  # a block's CRC32 field
+        bad_bytes = bytearray(data)
+        bad_bytes[at] ^= 0x40
+        open(os.path.join(d, name), "wb").write(bytes(bad_bytes))
+        bad = run(["-i", name] + args, d)
+        assert bad.returncode != 0 and "CRC32" in bad.stderr, (name, bad.stderr)
+
+
 def test_reads_past_the_annotated_length_are_not_returned(tmp_path):
     """sam_itr_queryi(idx, tid, 0, L) yields only pos < L (L from the annotation, not the BAM header)."""
     d = str(tmp_path)
