@@ -1901,12 +1901,17 @@ template <bool LDS_TABLES> __device__ __forceinline__ void chain_serial_lanes(co
 	// load inside the trip loop: one that the loop top has to wait for (every fourth trip, with the words fetched one
 	// at a time) cost more than the arithmetic of the trip.
 	uint32_t *col = reinterpret_cast<uint32_t *>(stage) + (threadIdx.x / kWave) * (kWave * 16) + (threadIdx.x & (kWave - 1));
-	int64_t chunk_w = ci.w_first & ~(int64_t) 3; // first window of the chunk in the column
+	// window indices and positions stay below 2^31 + step: 32-bit arithmetic throughout the trip loop
+	const uint32_t w_end32 = (uint32_t) w_end, n_win32 = (uint32_t) n_win;
+	uint32_t w = (uint32_t) ci.w_first;
+	uint32_t chunk_w = w & ~3u; // first window of the chunk in the column
+	// wave-uniform: no lane of this wave ever moves on to a second column (always so at the default class boundary)
+	const bool one_chunk = __all(!have || w_end32 - chunk_w <= 64u) != 0;
 	uint32_t ahead[16];
-	auto load16 = [&](int64_t from) {
+	auto load16 = [&](uint32_t from) {
 #pragma unroll
 		for (int q = 0; q < 16; q++) {
-			const int64_t at = from + 4 * q;
+			const int64_t at = (int64_t) from + 4 * q;
 			ahead[q] = (have && at < n_win_pad) ? *reinterpret_cast<const uint32_t *>(gc + at) : 0u;
 		}
 	};
@@ -1917,33 +1922,33 @@ template <bool LDS_TABLES> __device__ __forceinline__ void chain_serial_lanes(co
 	};
 	load16(chunk_w);
 	to_column();
-	if (w_end > chunk_w + 64)
-		load16(chunk_w + 64);
-	// k and the addend's bits for the next window; positions stay below 2^31 + step, so 32-bit arithmetic does
-	uint32_t at = (uint32_t) s0;                                       // first base not yet accounted for
-	uint32_t edge = ((uint32_t) ci.w_first + 1u) * (uint32_t) step;    // first base of the window after `w`
-	int64_t w = ci.w_first;
+	if (!one_chunk && w_end32 > chunk_w + 64u)
+		load16(chunk_w + 64u);
+	// k and the addend's bits for the next window
+	uint32_t at = (uint32_t) s0;                           // first base not yet accounted for
+	uint32_t edge = (w + 1u) * (uint32_t) step;            // first base of the window after `w`
 	auto window = [&](uint32_t &k, uint32_t &bc) {
-		if (w - chunk_w >= 64 && w < w_end) { // this lane moves on to its next 64 windows
+		if (!one_chunk && w - chunk_w >= 64u && w < w_end32) { // this lane moves on to its next 64 windows
 			to_column();
-			chunk_w += 64;
-			if (w_end > chunk_w + 64)
-				load16(chunk_w + 64);
+			chunk_w += 64u;
+			if (w_end32 > chunk_w + 64u)
+				load16(chunk_w + 64u);
 		}
-		k = 0;
-		bc = 0;
-		if (w < w_end) {
-			const uint32_t hi = (edge < (uint32_t) e0) ? edge : (uint32_t) e0;
-			k = hi - at;
-			at = hi;
-			const uint32_t rel = (uint32_t) (w - chunk_w);
-			const uint32_t word = col[(rel >> 2) * kWave];
-			const uint32_t g_cur = (w < n_win) ? ((word >> (8 * (rel & 3u))) & 0xFFu) : gc_last;
-			float c = 0.0f;
-			if (g_cur < (uint32_t) kGcBins)
-				c = LDS_TABLES ? E[g_cur] : chain_table_entry(a, ci.sl, (int) g_cur);
-			bc = conga_f32_bits(c);
-		}
+		// select-style: every lane runs this once per trip, and a branch around a few instructions costs more than they do
+		const bool act = w < w_end32;
+		const uint32_t hi = (edge < (uint32_t) e0) ? edge : (uint32_t) e0;
+		k = act ? hi - at : 0u;
+		at = act ? hi : at;
+		const uint32_t rel = act ? w - chunk_w : 0u; // (below 64 when act)
+		const uint32_t word = col[(rel >> 2) * kWave];
+		const uint32_t g_cur = (w < n_win32) ? ((word >> (8 * (rel & 3u))) & 0xFFu) : gc_last;
+		const bool g_ok = g_cur < (uint32_t) kGcBins;
+		float c = 0.0f;
+		if (LDS_TABLES)
+			c = E[g_ok ? g_cur : 0u];
+		else if (act && g_ok)
+			c = chain_table_entry(a, ci.sl, (int) g_cur);
+		bc = (act && g_ok) ? conga_f32_bits(c) : 0u;
 		edge += (uint32_t) step;
 		w++;
 	};
@@ -1953,8 +1958,14 @@ template <bool LDS_TABLES> __device__ __forceinline__ void chain_serial_lanes(co
 	while (__any(k != 0)) {
 		uint32_t k_next, bc_next;
 		window(k_next, bc_next); // the next addend is on its way while this window is applied
-		if (k)
-			s = conga_window_add_f32(s, conga_bits_f32(bc), k); // inside one binade: k adds = one integer step
+		// Inside one binade k adds are one integer step, and that is what most trips are for every lane of the wave: the
+		// one-crossing candidate (a division, a second binade) is only worked out in the trips where some lane needs it.
+		const conga_window_head h = conga_window_stage1(s, conga_bits_f32(bc), k);
+		if (__all(k == 0u || h.fit)) {
+			s = k ? h.res_fit : s;
+		} else if (k) {
+			s = conga_window_finish(h, s, conga_bits_f32(bc), k);
+		}
 		k = k_next;
 		bc = bc_next;
 	}

@@ -249,44 +249,65 @@ CONGA_HD_RARE float conga_window_add_loop_f32(float s, float c, uint32_t k)
 // branch taken by one lane is paid by all 64 (branches and their mask bookkeeping, not arithmetic, were most of a
 // trip).  Both candidates are always computed; everything else (start from zero, ties from odd mantissas, two
 // crossings in one window, odd operands) goes to the loop above through one rarely taken branch.
-CONGA_HD float conga_window_add_f32(float s, float c, uint32_t k)
+struct conga_window_head { // stage 1 of conga_window_add_f32: the accumulator's own binade
+	conga_addend ca;
+	conga_lean_step st;
+	uint32_t es, ms, room, dl, kk;
+	bool ok1, room_ok;
+	bool fit;      // ok1 and the whole window stays inside the binade: res_fit is the answer
+	float res_fit;
+};
+
+CONGA_HD conga_window_head conga_window_stage1(float s, float c, uint32_t k)
 {
-	if (k == 0u)
-		return s;
+	conga_window_head h;
 	const uint32_t bs = conga_f32_bits(s);
-	const conga_addend ca = conga_addend_of(conga_f32_bits(c));
-	// ---- stage 1: the accumulator's binade
-	const uint32_t es = bs >> 23; // a negative accumulator shows up as es >= 256: not ok
-	const conga_lean_step st = conga_step_lean(es, ca);
-	const uint32_t ms = (bs & 0x7FFFFFu) | 0x800000u;
-	const bool ok1 = st.ok != 0u && k <= 1024u && !(st.tie != 0u && (ms & 1u) != 0u);
-	const bool room_ok = ms <= st.lim;
-	const uint32_t room = room_ok ? st.lim - ms : 0u; // < 2^24
-	const uint32_t dl = st.delta & 0x3FFFFFu;          // (<= 2^21 whenever ok)
-	const uint32_t kk = k & 0x7FFu;                    // (<= 1024 whenever ok)
-	const bool fit = room_ok && CONGA_MUL24((kk - 1u) & 0x7FFu, dl) <= room;
-	const float res_fit = conga_compose_f32(es & 0xFFu, ms + CONGA_MUL24(kk, dl));
+	h.ca = conga_addend_of(conga_f32_bits(c));
+	h.es = bs >> 23; // a negative accumulator shows up as es >= 256: not ok
+	h.st = conga_step_lean(h.es, h.ca);
+	h.ms = (bs & 0x7FFFFFu) | 0x800000u;
+	h.ok1 = h.st.ok != 0u && k <= 1024u && !(h.st.tie != 0u && (h.ms & 1u) != 0u);
+	h.room_ok = h.ms <= h.st.lim;
+	h.room = h.room_ok ? h.st.lim - h.ms : 0u; // < 2^24
+	h.dl = h.st.delta & 0x3FFFFFu;              // (<= 2^21 whenever ok)
+	h.kk = k & 0x7FFu;                          // (<= 1024 whenever ok)
+	h.fit = h.ok1 && h.room_ok && CONGA_MUL24((h.kk - 1u) & 0x7FFu, h.dl) <= h.room;
+	h.res_fit = conga_compose_f32(h.es & 0xFFu, h.ms + CONGA_MUL24(h.kk, h.dl));
+	return h;
+}
+
+// Everything behind stage 1 (k != 0): the one-crossing candidate, then the loop.
+CONGA_HD float conga_window_finish(const conga_window_head &h, float s, float c, uint32_t k)
+{
+	const uint32_t es = h.es, ms = h.ms, room = h.room, dl = h.dl, kk = h.kk;
 	// ---- one crossing: n1 regular adds (the last one starts at or below lim), one real add, the rest in the next binade
 	uint32_t q = (uint32_t) ((float) room / (float) (dl | (dl == 0u ? 1u : 0u))); // true quotient < k - 1 <= 1023 when it matters
 	q = (q > 2047u) ? 2047u : q;
 	const bool q_high = CONGA_MUL24(q, dl) > room;
 	const bool q_low = !q_high && CONGA_MUL24(q + 1u, dl) <= room;
 	q = q_high ? q - 1u : (q_low ? q + 1u : q);
-	const uint32_t n1 = room_ok ? q + 1u : 0u;
+	const uint32_t n1 = h.room_ok ? q + 1u : 0u;
 	const uint32_t ms1 = ms + CONGA_MUL24(n1 & 0x7FFu, dl); // lim < ms1 <= 2^24 in the case that is used
 	const float s2 = conga_compose_f32(es & 0xFFu, ms1) + c; // the add that reaches or crosses the binade top: real rounding
 	const uint32_t r = kk - n1 - 1u;                          // adds left (wraps when the window fits: unused then)
 	// ---- stage 2: the next binade
 	const uint32_t bs2 = conga_f32_bits(s2);
 	const uint32_t es2 = bs2 >> 23;
-	const conga_lean_step st2 = conga_step_lean(es2, ca);
+	const conga_lean_step st2 = conga_step_lean(es2, h.ca);
 	const uint32_t ms2 = (bs2 & 0x7FFFFFu) | 0x800000u;
 	const uint32_t dl2 = st2.delta & 0x3FFFFFu;
 	const bool ok2 = st2.ok != 0u && !(st2.tie != 0u && (ms2 & 1u) != 0u) && ms2 <= st2.lim
 			&& CONGA_MUL24((r - 1u) & 0x7FFu, dl2) <= st2.lim - ms2;
 	const float res_cross = (r == 0u) ? s2 : conga_compose_f32(es2 & 0xFFu, ms2 + CONGA_MUL24(r & 0x7FFu, dl2));
-	const bool cross_ok = st.delta != 0u && n1 < kk && (r == 0u || ok2);
-	if (ok1 && (fit || cross_ok))
-		return fit ? res_fit : res_cross;
+	const bool cross_ok = h.st.delta != 0u && n1 < kk && (r == 0u || ok2);
+	if (h.fit || (h.ok1 && cross_ok))
+		return h.fit ? h.res_fit : res_cross;
 	return conga_window_add_loop_f32(s, c, k);
+}
+
+CONGA_HD float conga_window_add_f32(float s, float c, uint32_t k)
+{
+	if (k == 0u)
+		return s;
+	return conga_window_finish(conga_window_stage1(s, c, k), s, c, k);
 }

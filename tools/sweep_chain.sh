@@ -5,7 +5,7 @@ run() {
   echo "$* $(echo "$out" | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["ms_per_step"], d["roofline"]["chain_ms"])')"
 }
 run A=0
-for s in 40 48 52 60 64; do run CONGA_CHAIN_SERIAL_WINDOWS=$s; done
-for l in 256 384 768 1024; do run CONGA_CHAIN_LONG_WINDOWS=$l; done
-for b in 1024 1536 3072 4096; do run CONGA_CHAIN_BLOCK_WINDOWS=$b; done
+for s in ${SERIALS:-40 48 52 60 64 72}; do run CONGA_CHAIN_SERIAL_WINDOWS=$s; done
+for l in ${LONGS:-256 384 768 1024}; do run CONGA_CHAIN_LONG_WINDOWS=$l; done
+for b in ${BLOCKS:-1024 1536 3072 4096}; do run CONGA_CHAIN_BLOCK_WINDOWS=$b; done
 run A=0
