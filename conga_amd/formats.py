@@ -12,7 +12,7 @@ import struct
 import numpy as np
 
 ANNOT_MAGIC = b"CONGAAN1"
-TUPLE_MAGIC = b"CONGATP1"
+TUPLE_MAGIC = b"CONGATP2"  # every array starts on a 16-byte boundary (CONGATP1: no padding; still read)
 
 
 def write_annotation(path, chroms, gc_step=100):
@@ -51,10 +51,10 @@ def read_annotation(path):
     return gc_step, out
 
 
-def write_tuples(path, sample, chroms):
+def write_tuples(path, sample, chroms, aligned=True):
     """chroms: list of (name, length, pos int32[n] sorted, mapq uint8[n][, flag uint16[n], l_qseq int32[n]])."""
     with open(path, "wb") as f:
-        f.write(TUPLE_MAGIC)
+        f.write(TUPLE_MAGIC if aligned else b"CONGATP1")
         sb = sample.encode()
         f.write(struct.pack("<H", len(sb)) + sb)
         f.write(struct.pack("<i", len(chroms)))
@@ -62,12 +62,16 @@ def write_tuples(path, sample, chroms):
             nb = c[0].encode()
             f.write(struct.pack("<H", len(nb)) + nb)
             f.write(struct.pack("<qqB", c[1], len(c[2]), 1 if len(c) > 4 else 0))
+        def put(a, dtype):
+            if aligned:
+                f.write(b"\0" * (-f.tell() % 16))
+            f.write(np.ascontiguousarray(a, dtype=dtype).tobytes())
         for c in chroms:
-            f.write(np.ascontiguousarray(c[2], dtype="<i4").tobytes())
-            f.write(np.ascontiguousarray(c[3], dtype=np.uint8).tobytes())
+            put(c[2], "<i4")
+            put(c[3], np.uint8)
             if len(c) > 4:
-                f.write(np.ascontiguousarray(c[4], dtype="<u2").tobytes())
-                f.write(np.ascontiguousarray(c[5], dtype="<i4").tobytes())
+                put(c[4], "<u2")
+                put(c[5], "<i4")
 
 
 # ------------------------------------------------------------------------------------------------

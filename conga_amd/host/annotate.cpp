@@ -187,7 +187,8 @@ bool write_container(const std::string &path, int gc_window, const std::vector<c
 			e[i] = c.sat[i].second;
 		}
 		ok = ok && fwrite(c.gc.data(), 1, c.gc.size(), f) == c.gc.size();
-		ok = ok && fwrite(s.data(), 4, s.size(), f) == s.size() && fwrite(e.data(), 4, e.size(), f) == e.size();
+		if (!s.empty()) // (fwrite's pointer argument must not be null, even for zero elements)
+			ok = ok && fwrite(s.data(), 4, s.size(), f) == s.size() && fwrite(e.data(), 4, e.size(), f) == e.size();
 	}
 	return fclose(f) == 0 && ok;
 }

@@ -20,7 +20,9 @@ read_source *open_bam(const std::string &path, std::string *err); // bam_reader.
 
 namespace {
 
-// Memory-mapped CONGATP1 container (layout: conga_amd/formats.py write_tuples).
+// Memory-mapped read-tuple container (layout: conga_amd/formats.py write_tuples).  CONGATP2 pads every array to a
+// 16-byte boundary; in a CONGATP1 file the arrays sit wherever the header ends, so positions that are not 4-byte
+// aligned are copied once at open.
 class tuple_file : public read_source {
 public:
 	~tuple_file() override
@@ -46,10 +48,17 @@ public:
 		}
 		const uint8_t *p = (const uint8_t *) map_, *end = p + size_;
 		auto need = [&](size_t n) { return (size_t) (end - p) >= n; };
-		if (!need(8) || memcmp(p, "CONGATP1", 8) != 0) {
-			*err = path + ": not a CONGATP1 read-tuple container";
+		if (!need(8) || (memcmp(p, "CONGATP1", 8) != 0 && memcmp(p, "CONGATP2", 8) != 0)) {
+			*err = path + ": not a CONGATP1 / CONGATP2 read-tuple container";
 			return false;
 		}
+		const bool aligned = p[7] == '2';
+		const uint8_t *const base = p;
+		auto align16 = [&]() {
+			if (aligned)
+				p = base + (((size_t) (p - base) + 15) & ~(size_t) 15);
+			return p <= end;
+		};
 		p += 8;
 		uint16_t ln;
 		if (!need(2))
@@ -86,12 +95,23 @@ public:
 			chroms_.push_back(e);
 		}
 		for (entry &e : chroms_) {
-			const size_t bytes = (size_t) e.n * (5 + (e.ext ? 6 : 0));
-			if (!need(bytes))
-				return trunc(err);
-			e.pos = (const int32_t *) p;
-			e.mapq = p + (size_t) e.n * 4;
-			p += bytes;
+			// pos int32[n], mapq uint8[n] and, with ext, flag uint16[n], l_qseq int32[n] (not used by this reader)
+			const size_t widths[4] = {4, 1, 2, 4};
+			for (int k = 0; k < (e.ext ? 4 : 2); k++) {
+				if (!align16() || !need((size_t) e.n * widths[k]))
+					return trunc(err);
+				if (k == 0) {
+					if (((uintptr_t) p & 3u) == 0)
+						e.pos = (const int32_t *) p;
+					else {
+						e.pos_copy.resize((size_t) e.n);
+						memcpy(e.pos_copy.data(), p, (size_t) e.n * 4);
+						e.pos = e.pos_copy.data();
+					}
+				} else if (k == 1)
+					e.mapq = p;
+				p += (size_t) e.n * widths[k];
+			}
 		}
 		return true;
 	}
@@ -132,6 +152,7 @@ private:
 		int ext = 0;
 		const int32_t *pos = nullptr;
 		const uint8_t *mapq = nullptr;
+		std::vector<int32_t> pos_copy; // CONGATP1 with unaligned positions
 	};
 	bool trunc(std::string *err)
 	{
@@ -195,7 +216,7 @@ read_source *open_reads(const std::string &path, std::string *err)
 	unsigned char magic[8] = {0};
 	const size_t got = fread(magic, 1, 8, f);
 	fclose(f);
-	if (got == 8 && memcmp(magic, "CONGATP1", 8) == 0) {
+	if (got == 8 && (memcmp(magic, "CONGATP1", 8) == 0 || memcmp(magic, "CONGATP2", 8) == 0)) {
 		tuple_file *t = new tuple_file();
 		if (!t->open(path, err)) {
 			delete t;
@@ -205,7 +226,7 @@ read_source *open_reads(const std::string &path, std::string *err)
 	}
 	if (got >= 2 && magic[0] == 0x1f && magic[1] == 0x8b) // gzip member: BGZF-compressed BAM
 		return open_bam(path, err);
-	*err = path + ": neither a BAM nor a CONGATP1 read-tuple container (CRAM is not supported)";
+	*err = path + ": neither a BAM nor a CONGATP1 / CONGATP2 read-tuple container (CRAM is not supported)";
 	return nullptr;
 }
 

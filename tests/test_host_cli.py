@@ -163,6 +163,18 @@ def test_bam_reader_takes_any_valid_bgzf_framing_and_checks_the_crc(tmp_path):
         assert bad.returncode != 0 and "CRC32" in bad.stderr, (name, bad.stderr)
 
 
+def test_both_versions_of_the_tuple_container_read_the_same(tmp_path):
+    """CONGATP2 pads every array to 16 bytes; CONGATP1 files (arrays wherever the header ends, usually unaligned) still load."""
+    d = str(tmp_path)
+    cs, in_bam = make_inputs(d, with_bam=False)
+    formats.write_tuples(os.path.join(d, "old.ctp"), "NA00001", [(c.name, c.length, c.pos, c.mapq) for c in in_bam], aligned=False)
+    assert open(os.path.join(d, "old.ctp"), "rb").read(8) == b"CONGATP1" and open(os.path.join(d, "r.ctp"), "rb").read(8) == b"CONGATP2"
+    outs = [run(["-i", f, "--out", "o", "--ref", "r.fa", "--sonic", "a.cga", "--dump-reads"], d) for f in ("r.ctp", "old.ctp")]
+    assert outs[0].returncode == 0 and outs[1].returncode == 0, outs[1].stderr
+    assert outs[0].stdout.replace("r.ctp", "X") == outs[1].stdout.replace("old.ctp", "X")
+    assert "1\t%d\t" % len(in_bam[0].pos) in outs[0].stdout
+
+
 def test_reads_past_the_annotated_length_are_not_returned(tmp_path):
     """sam_itr_queryi(idx, tid, 0, L) yields only pos < L (L from the annotation, not the BAM header)."""
     d = str(tmp_path)
