@@ -307,12 +307,15 @@ public:
 				*err = "[CONGA INPUT ERROR] Unable to open file " + path + " in read mode.";
 			return false;
 		}
-		load_bai(path + ".bai");
+		// sample.bam.bai (samtools) or sample.bai (Picard); without either the file is read front to back
+		if (!load_bai(path + ".bai") && path.size() > 4 && path.compare(path.size() - 4, 4, ".bam") == 0)
+			load_bai(path.substr(0, path.size() - 4) + ".bai");
 		return true;
 	}
 	int n_targets() const override { return (int) names_.size(); }
 	const std::string &target_name(int tid) const override { return names_[tid]; }
 	const std::string &sample_name() const override { return sample_; }
+	std::string index_path() const override { return ref_beg_.empty() ? "" : bai_path_; }
 
 	bool begin(int tid, int64_t chrom_len, std::string *err) override
 	{
@@ -520,11 +523,11 @@ private:
 	}
 
 	// .bai: only the smallest chunk start per reference is kept (whole-chromosome queries)
-	void load_bai(const std::string &path)
+	bool load_bai(const std::string &path)
 	{
 		FILE *f = fopen(path.c_str(), "rb");
 		if (!f)
-			return;
+			return false;
 		char magic[4];
 		int32_t n_ref;
 		std::vector<uint64_t> beg;
@@ -549,11 +552,14 @@ private:
 			beg.push_back(first);
 		}
 		fclose(f);
-		if (ok && (int) beg.size() == n_targets())
+		if (ok && (int) beg.size() == n_targets()) {
 			ref_beg_ = beg;
+			bai_path_ = path;
+		}
+		return true;
 	}
 
-	std::string path_, sample_;
+	std::string path_, sample_, bai_path_;
 	bgzf_reader bgzf_;
 	std::vector<std::string> names_;
 	std::vector<uint64_t> ref_beg_;

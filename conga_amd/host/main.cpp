@@ -98,6 +98,7 @@ int main(int argc, char **argv)
 			return CONGA_EXIT_COMMON;
 		}
 		printf("sample\t%s\n", src->sample_name().c_str());
+		printf("index\t%s\n", src->index_path().empty() ? "none" : src->index_path().c_str());
 		for (int c = params.first_chrom; c <= params.last_chrom && c < this_sonic->number_of_chromosomes; c++) {
 			const std::string &name = this_sonic->chromosome_names[c];
 			if (name.find('X') != std::string::npos || name.find('Y') != std::string::npos)

@@ -33,6 +33,7 @@ public:
 	virtual int n_targets() const = 0;
 	virtual const std::string &target_name(int tid) const = 0;
 	virtual const std::string &sample_name() const = 0; // @RG SM (get_sample_name, common.c:325-352)
+	virtual std::string index_path() const { return ""; } // the index in use for seeking ("" = none: read front to back)
 	// Iterate the records of target `tid` with 0 <= pos < chrom_len, in file order, at most max_n at a time
 	// (the analogue of sam_itr_queryi(idx, tid, 0, L) + sam_itr_next: bam_data.c:293,201).
 	virtual bool begin(int tid, int64_t chrom_len, std::string *err) = 0;

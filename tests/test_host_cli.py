@@ -344,13 +344,16 @@ def test_bai_seek_gives_the_same_records_in_any_chromosome_order(tmp_path):
     order = [cs[2], cs[0], cs[1]]                       # annotation order differs from the BAM's
     formats.write_annotation(os.path.join(d, "a.cga"), [(c.name, c.length, c.gc, [], []) for c in order])
     outs = {}
-    for tag in ("with_bai", "no_bai"):
+    for tag in ("with_bai", "picard_name", "no_bai"):
+        if tag == "picard_name":                        # sample.bai instead of sample.bam.bai
+            os.rename(os.path.join(d, "r.bam.bai"), os.path.join(d, "r.bai"))
         if tag == "no_bai":
-            os.remove(os.path.join(d, "r.bam.bai"))
+            os.remove(os.path.join(d, "r.bai"))
         r = run(["-i", "r.bam", "--out", "o", "--ref", "r.fa", "--sonic", "a.cga", "--dump-reads"], d)
         assert r.returncode == 0, r.stderr
+        assert "index\t" + {"with_bai": "r.bam.bai", "picard_name": "r.bai", "no_bai": "none"}[tag] in r.stdout
         outs[tag] = [l for l in r.stdout.splitlines() if l[:1].isdigit()]
-    assert outs["with_bai"] == outs["no_bai"]
+    assert outs["with_bai"] == outs["no_bai"] == outs["picard_name"]
     want = ["%s\t%d\t%d\t%d" % (c.name, len(c.pos), c.pos.astype(np.int64).sum(), c.mapq.astype(np.int64).sum()) for c in order]
     assert outs["with_bai"] == want
 
