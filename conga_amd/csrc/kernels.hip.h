@@ -2195,7 +2195,11 @@ __device__ __forceinline__ int is_satellite_dev(const SplitArgs &a, int64_t lo_,
 }
 
 // almostPerfect_match_seq_ref for one orientation (split_read.c:116-129 / 164-180): scan the seed's bucket, keep hits
-// within SR_LOOKAHEAD of the anchor whose Hamming distance to the reference is <= dist_max.
+// within SR_LOOKAHEAD of the anchor whose Hamming distance to the reference is <= dist_max.  The bucket is read 64
+// positions at a time (one per lane); the few of them that lie inside the look-ahead window (about one per scan: the
+// read's own locus) are then compared by the whole wave, lane j on base j -- one coalesced load of the reference per 64
+// bases instead of one lane walking the bases with a dependent load each (which was 85 % of this path's time).
+// Hits are recorded in bucket order, as the reference's scan finds them.
 __device__ __forceinline__ int split_scan_bucket(const SplitArgs &a, const uint8_t *str, int n, int anchor, int dist_max,
 		char orient, int size, int32_t *hit_pos, char *hit_orient, int lane, bool stop_past_max)
 {
@@ -2205,31 +2209,34 @@ __device__ __forceinline__ int split_scan_bucket(const SplitArgs &a, const uint8
 	const uint32_t b0 = a.offset[h], b1 = a.offset[h + 1];
 	for (uint32_t base = b0; base < b1; base += kWave) {
 		const uint32_t k = base + lane;
-		bool hit = false;
 		int p = 0;
+		bool near = false;
 		if (k < b1) {
 			p = a.positions[k];
 			int d = p - anchor;
 			d = d < 0 ? -d : d;
-			if (d < kSrLookahead) {
-				int dist = 0;
-				for (int j = 0; j < n && dist <= dist_max; j++) {
-					const int64_t at = (int64_t) p + j;
-					if (at >= a.L || a.ref[at] != str[j]) // hammingDistance (common.c:278-287)
-						dist++;
+			near = d < kSrLookahead;
+		}
+		unsigned long long cand = __ballot(near);
+		while (cand) { // wave-uniform
+			const int src = __ffsll((long long) cand) - 1;
+			cand &= cand - 1ull;
+			const int pc = __builtin_amdgcn_readlane(p, src);
+			int dist = 0;
+			for (int j0 = 0; j0 < n; j0 += kWave) {
+				const int j = j0 + lane;
+				const int64_t at = (int64_t) pc + j;
+				const bool mism = j < n && (at >= a.L || a.ref[at] != str[j]); // hammingDistance (common.c:278-287)
+				dist += __popcll(__ballot(mism));
+			}
+			if (dist <= dist_max) {
+				if (size < kMaxMapping && lane == 0) {
+					hit_pos[size] = pc;
+					hit_orient[size] = orient;
 				}
-				hit = dist <= dist_max;
+				size++;
 			}
 		}
-		const unsigned long long m = __ballot(hit);
-		if (hit) {
-			const int slot = size + __popcll(m & ((1ull << lane) - 1ull));
-			if (slot < kMaxMapping) {
-				hit_pos[slot] = p;
-				hit_orient[slot] = orient;
-			}
-		}
-		size += __popcll(m);
 		if (stop_past_max && size > kMaxMapping)
 			break;
 	}
