@@ -2200,19 +2200,19 @@ __device__ __forceinline__ int is_satellite_dev(const SplitArgs &a, int64_t lo_,
 // read's own locus) are then compared by the whole wave, lane j on base j -- one coalesced load of the reference per 64
 // bases instead of one lane walking the bases with a dependent load each (which was 85 % of this path's time).
 // Hits are recorded in bucket order, as the reference's scan finds them.
+// [b0, b1): the seed's bucket; p_first: this lane's entry of its first 64 positions, fetched by the caller (the forward
+// and the reverse-complement scan of a half ask for their bucket bounds, and then for their first positions, together:
+// two trips to HBM instead of four).
 __device__ __forceinline__ int split_scan_bucket(const SplitArgs &a, const uint8_t *str, int n, int anchor, int dist_max,
-		char orient, int size, int32_t *hit_pos, char *hit_orient, int lane, bool stop_past_max)
+		char orient, int size, int32_t *hit_pos, char *hit_orient, int lane, bool stop_past_max, uint32_t b0, uint32_t b1,
+		int p_first)
 {
-	const int h = kmer_hash([&](int k) { return str[k]; });
-	if (h < 0)
-		return size;
-	const uint32_t b0 = a.offset[h], b1 = a.offset[h + 1];
 	for (uint32_t base = b0; base < b1; base += kWave) {
 		const uint32_t k = base + lane;
 		int p = 0;
 		bool near = false;
 		if (k < b1) {
-			p = a.positions[k];
+			p = (base == b0) ? p_first : a.positions[k];
 			int d = p - anchor;
 			d = d < 0 ? -d : d;
 			near = d < kSrLookahead;
@@ -2278,8 +2278,23 @@ __global__ __launch_bounds__(256) void split_read_kernel(SplitArgs a)
 			const int anchor = (e == 0) ? p : p + half;
 			// mean base quality of the mapped half; the accumulator is NOT reset between the two
 			// elements (split_read.c:238-243,307-312), sequential float adds as in the reference
-			for (int i = from; i < from + n; i++)
-				avg = avg + (float) ql[i];
+			// The adds are sequential in the reference.  Element 1 starts from 0: every partial sum is an integer below 2^24,
+			// so the float sum is exact in any order and a wave reduction gives it.  Element 2 starts from element 1's mean (a
+			// fraction): its adds stay in order, 64 qualities per LDS read (one per lane, converted there) handed to every
+			// lane in turn by v_readlane -- two instructions per add instead of a byte read from LDS in front of each.
+			if (e == 0) {
+				int isum = 0;
+				for (int i = from + lane; i < from + n; i += kWave)
+					isum += (int) ql[i];
+				avg = (float) __builtin_amdgcn_readfirstlane(wave_sum_i32(isum)); // (the total is in lane 0)
+			} else {
+				for (int c0 = from; c0 < from + n; c0 += kWave) {
+					const float mine = (c0 + lane < from + n) ? (float) ql[c0 + lane] : 0.0f;
+					const int cnt = min(kWave, from + n - c0);
+					for (int j = 0; j < cnt; j++)
+						avg = avg + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), j));
+				}
+			}
 			avg = avg / (float) n;
 			if ((int) floorf(avg) < a.mq_threshold)
 				break; // element 1 dropped -> element 2 never created; element 2 dropped -> done
@@ -2296,9 +2311,21 @@ __global__ __launch_bounds__(256) void split_read_kernel(SplitArgs a)
 			if (n < kKmerLen)
 				continue;
 			const int dist_max = (int) (0.05 * (double) n);
-			int size = split_scan_bucket(a, str, n, anchor, dist_max, 'F', 0, hit_pos, hit_orient, lane, false);
+			const int h_fwd = kmer_hash([&](int k) { return str[k]; }), h_rev = kmer_hash([&](int k) { return rev[k]; });
+			uint32_t f0 = 0, f1 = 0, r0 = 0, r1 = 0; // (a seed with a letter outside ACGT has no bucket)
+			if (h_fwd >= 0) {
+				f0 = a.offset[h_fwd];
+				f1 = a.offset[h_fwd + 1];
+			}
+			if (h_rev >= 0) {
+				r0 = a.offset[h_rev];
+				r1 = a.offset[h_rev + 1];
+			}
+			const int p_fwd = (f0 + (uint32_t) lane < f1) ? a.positions[f0 + lane] : 0;
+			const int p_rev = (r0 + (uint32_t) lane < r1) ? a.positions[r0 + lane] : 0;
+			int size = split_scan_bucket(a, str, n, anchor, dist_max, 'F', 0, hit_pos, hit_orient, lane, false, f0, f1, p_fwd);
 			if (size < kMaxMapping)
-				size = split_scan_bucket(a, rev, n, anchor, dist_max, 'R', size, hit_pos, hit_orient, lane, true);
+				size = split_scan_bucket(a, rev, n, anchor, dist_max, 'R', size, hit_pos, hit_orient, lane, true, r0, r1, p_rev);
 			__builtin_amdgcn_wave_barrier();
 			if (!(size > 0 && size < kMaxMapping))
 				continue;

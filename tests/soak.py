@@ -127,7 +127,10 @@ def random_split_case(rng):
 
     def add(pos, bases, mapq=60, flag=0, q=30):
         if 0 <= pos and len(bases) > 0:
-            reads.append((int(pos), np.asarray(bases, np.uint8), mapq, flag, np.full(len(bases), q, np.uint8)))
+            # base qualities: one value, or anything per base (the half-read means are sequential float sums whose
+            # accumulator is not reset between the halves, and they are compared with the mapq threshold)
+            quals = np.full(len(bases), q, np.uint8) if rng.random() < 0.4 else rng.integers(0, int(rng.choice([42, 61, 94])), len(bases)).astype(np.uint8)
+            reads.append((int(pos), np.asarray(bases, np.uint8), mapq, flag, quals))
     for (s0, e0) in dels:
         for k in range(int(rng.integers(20, 40)), 80, int(rng.integers(2, 9))):
             add(s0 - k, np.concatenate([ref[s0 - k:s0], ref[e0:e0 + 100 - k]]))
@@ -190,7 +193,7 @@ def main():
         for i in range(a.cases):
             rng = np.random.default_rng([a.seed, 9_000_000 + i])
             c = random_split_case(rng)
-            mq, min_len = int(rng.choice([-1, -1, 0, 20, 35])), int(rng.choice([60, 60, 10, 75, 100]))
+            mq, min_len = int(rng.choice([-1, 0, 15, 20, 25, 30, 35, 45])), int(rng.choice([60, 60, 10, 75, 100]))
             try:
                 (dels, dups, st), (od, ou, rows, counts) = S.run_both(capi, O, c, mq, min_len)
                 assert (st.split_elements, st.split_mappings, st.split_del_rows, st.split_dup_rows) == tuple(int(x) for x in counts)

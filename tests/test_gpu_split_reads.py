@@ -23,7 +23,8 @@ def make_case(seed=3, L=400_000, n_normal=9000):
     reads = []  # (pos, bases uint8[], mapq, flag, qual)
 
     def add(pos, bases, mapq=60, flag=0, q=30):
-        reads.append((int(pos), np.asarray(bases, np.uint8), mapq, flag, np.full(len(bases), q, np.uint8)))
+        quals = np.full(len(bases), q, np.uint8) if np.isscalar(q) else np.asarray(q, np.uint8)
+        reads.append((int(pos), np.asarray(bases, np.uint8), mapq, flag, quals))
 
     for (s, e) in dels[1:]:                                         # reads across a deletion junction
         for k in range(25, 80, 3):
@@ -40,7 +41,9 @@ def make_case(seed=3, L=400_000, n_normal=9000):
             b[idx] = rng.choice(np.frombuffer(b"ACGTN", np.uint8), len(idx))
         mapq = int(rng.choice([60, 60, 60, 0, 17, 40]))
         flag = int(rng.choice([0, 0, 0, 0, 0x400, 0x100, 0x800, 0x200, 16]))
-        add(p, b, mapq, flag, int(rng.choice([30, 30, 12, 2])))
+        # base qualities: one value per read, or anything per base (the half-read means are sequential float sums, the
+        # second half starting from the first half's mean, and they gate the element against the mapq threshold)
+        add(p, b, mapq, flag, int(rng.choice([30, 30, 12, 2])) if rng.random() < 0.5 else rng.integers(0, 61, l))
     add(0, ref[0:100])                                              # pos == 0 is skipped
     add(20_000, ref[20_000:20_100])                                 # second half sits in the repeat: 2 mappings
     add(20_100, ref[20_100:20_200])
