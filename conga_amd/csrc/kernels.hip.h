@@ -2243,8 +2243,11 @@ __device__ __forceinline__ int split_scan_bucket(const SplitArgs &a, const uint8
 	return size;
 }
 
-// find_split_reads + read_SplitReads + determine_SvType + count_ReadPairs, one wave per read.
-__global__ __launch_bounds__(256) void split_read_kernel(SplitArgs a)
+// find_split_reads + read_SplitReads + determine_SvType + count_ReadPairs, one wave per read.  A read is a dozen
+// dependent trips to HBM (record -> sequence -> bucket bounds -> bucket -> reference, per half), so the register budget
+// is set for 8 waves per SIMD: at the 98 registers the compiler would otherwise take, 4 waves fit and the launch is 10 %
+// slower (the few spilled values are off the inner loops).
+__global__ __launch_bounds__(256, 8) void split_read_kernel(SplitArgs a)
 {
 	__shared__ uint8_t s_str[4][kSrMaxHalf], s_rev[4][kSrMaxHalf], s_qual[4][2 * kSrMaxHalf];
 	__shared__ int32_t s_hit_pos[4][kMaxMapping];
