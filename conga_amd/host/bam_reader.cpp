@@ -5,7 +5,7 @@
 // 32-byte record core is decoded (refID, pos, mapq, flag, l_seq) -- the depth path reads nothing else.
 // Record set (parity unpinned): all records with refID == tid and 0 <= pos < L, in
 // file order, which is what sam_itr_queryi(idx, tid, 0, L) + sam_itr_next yield (bam_data.c:293,201).
-// CRAM is not supported.  Inflate is zlib on a pool of worker threads with a 48-block read-ahead
+// CRAM is not supported.  Inflate is zlib on a pool of worker threads with a 96-block read-ahead
 // (CONGA_BAM_THREADS overrides the worker count; 0 = inflate inline).
 #include <zlib.h>
 
@@ -36,7 +36,7 @@ public:
 		int n = std::max(2, usable_cpus() / reader_share());
 		if (const char *e = getenv("CONGA_BAM_THREADS"))
 			n = atoi(e) + 1;
-		n_workers_ = std::max(0, std::min(n - 1, 15));
+		n_workers_ = std::max(0, std::min(n - 1, 24)); // one record-walking thread keeps up with ~24 inflating ones
 		for (int i = 0; i < n_workers_; i++)
 			workers_.emplace_back([this] { work(); });
 	}
@@ -125,7 +125,7 @@ private:
 		uint32_t isize = 0, crc = 0;
 		bool done = false, failed = false;
 	};
-	static constexpr size_t kAhead = 48;
+	static constexpr size_t kAhead = 96;
 
 	size_t cur_size() const { return cur_ ? cur_->out.size() : 0; }
 
