@@ -201,10 +201,11 @@ def write_bam(path, sample, chroms, read_len=100, unplaced=0, block_payload=6000
             f.write(struct.pack("<Q", 0))
 
 
-def write_bam_fast(path, sample, chroms, read_len=100, level=1, block_payload=65280, realistic=False, seed=1):
+def write_bam_fast(path, sample, chroms, read_len=100, level=1, block_payload=65280, realistic=False, seed=1, index=False):
     """Vectorised writer for large synthetic BAMs: every record has the same layout (fixed-width read name,
     <read_len>M CIGAR, all-A sequence, quality 30), so a chromosome is one numpy structured array.
-    chroms: list of (name, length, pos int32[n] sorted, mapq uint8[n])."""
+    chroms: list of (name, length, pos int32[n] sorted, mapq uint8[n]).
+    index=True also writes path + '.bai': per reference one chunk in bin 0 and the 16 kb linear index."""
     text = "@HD\tVN:1.6\tSO:coordinate\n"
     for c in chroms:
         text += "@SQ\tSN:%s\tLN:%d\n" % (c[0], c[1])
@@ -227,15 +228,20 @@ def write_bam_fast(path, sample, chroms, read_len=100, level=1, block_payload=65
             data = pending + buf
             n_full = len(data) // block_payload
             for b in range(n_full):
+                block_off.append(f.tell())
                 f.write(_bgzf_block_level(data[b * block_payload:(b + 1) * block_payload], level))
             pending = data[n_full * block_payload:]
             if final and pending:
+                block_off.append(f.tell())
                 f.write(_bgzf_block_level(pending, level))
                 pending = b""
 
         serial = 0
+        block_off = []                 # file offset of every BGZF block, in stream order
+        first_rec = []                 # per reference: index of its first record in the stream
         for tid, c in enumerate(chroms):
             pos = np.asarray(c[2], np.int32)
+            first_rec.append(serial)
             for a in range(0, len(pos), 1 << 20):
                 p = pos[a:a + (1 << 20)]
                 r = np.zeros(len(p), dtype=rec)
@@ -263,7 +269,31 @@ def write_bam_fast(path, sample, chroms, read_len=100, level=1, block_payload=65
                     r["qual"] = 30
                 emit(r.tobytes())
         emit(b"", final=True)
+        block_off.append(f.tell())     # (the EOF block: where a virtual offset behind the last record points)
         f.write(_BGZF_EOF)
+    if index:
+        boff = np.asarray(block_off, np.uint64)
+
+        def voffset(rec_index):
+            at = np.asarray(rec_index, np.uint64) * np.uint64(rec.itemsize) + np.uint64(len(head))
+            return (boff[(at // np.uint64(block_payload)).astype(np.int64)] << np.uint64(16)) | (at % np.uint64(block_payload))
+        with open(path + ".bai", "wb") as f:
+            f.write(b"BAI\x01" + struct.pack("<i", len(chroms)))
+            for tid, c in enumerate(chroms):
+                pos = np.asarray(c[2], np.int64)
+                if len(pos) == 0:
+                    f.write(struct.pack("<ii", 0, 0))
+                    continue
+                v0, v1 = int(voffset(first_rec[tid])), int(voffset(first_rec[tid] + len(pos)))
+                f.write(struct.pack("<i", 1) + struct.pack("<Ii", 0, 1) + struct.pack("<QQ", v0, v1))
+                n_intv = int((pos[-1] + read_len - 1) >> 14) + 1
+                # first record overlapping each window: the first one that ends behind the window's start
+                first = np.searchsorted(pos, np.arange(n_intv, dtype=np.int64) * 16384 - read_len + 1, side="left")
+                lin = voffset(first_rec[tid] + np.minimum(first, len(pos) - 1))
+                lin[first >= len(pos)] = 0
+                lin[np.arange(n_intv) < (pos[0] >> 14)] = 0                # nothing overlaps the windows in front of the first read
+                f.write(struct.pack("<i", n_intv) + lin.astype("<u8").tobytes())
+            f.write(struct.pack("<Q", 0))
 
 
 def _bgzf_block_level(data, level):

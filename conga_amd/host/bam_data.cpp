@@ -91,6 +91,29 @@ int64_t count_reads_bam(conga_ctx *ctx, read_source *src, int chr_index_bam, int
 		}
 		return cnt;
 	}
+	{
+		// a BAM with an index: the whole chromosome decoded by several readers at once (reads.h: read_all)
+		std::vector<int32_t> all_pos;
+		std::vector<uint8_t> all_mapq;
+		if (src->read_all(chr_index_bam, chrom_len, std::max(1, usable_cpus() / reader_share()), &all_pos, &all_mapq, &err)) {
+			for (size_t done = 0;;) {
+				conga_read_staging stg;
+				engine_check(ctx, conga_reads_staging(ctx, &stg), "conga_reads_staging");
+				const size_t k = std::min(stg.capacity, all_pos.size() - done);
+				if (k) {
+					memcpy(stg.pos, all_pos.data() + done, k * sizeof(int32_t));
+					memcpy(stg.mapq, all_mapq.data() + done, k);
+				}
+				engine_check(ctx, conga_reads_commit(ctx, k), "conga_reads_commit");
+				done += k;
+				if (done >= all_pos.size())
+					break;
+			}
+			return (int64_t) all_pos.size();
+		}
+		if (!err.empty())
+			print_error("[CONGA INPUT ERROR] " + err);
+	}
 	for (;;) {
 		conga_read_staging stg;
 		engine_check(ctx, conga_reads_staging(ctx, &stg), "conga_reads_staging");

@@ -31,12 +31,16 @@ namespace {
 // pool of workers inflates them; blocks are consumed strictly in file order.
 class bgzf_reader {
 public:
-	bgzf_reader()
+	// workers < 0: a pool sized for the host (the sequential reader); 0: inflate on the calling thread (what each of the
+	// parallel segment readers of bam_file::read_all does)
+	explicit bgzf_reader(int workers = -1)
 	{
 		int n = std::max(2, usable_cpus() / reader_share());
 		if (const char *e = getenv("CONGA_BAM_THREADS"))
 			n = atoi(e) + 1;
 		n_workers_ = std::max(0, std::min(n - 1, 24)); // one record-walking thread keeps up with ~24 inflating ones
+		if (workers >= 0)
+			n_workers_ = workers;
 		for (int i = 0; i < n_workers_; i++)
 			workers_.emplace_back([this] { work(); });
 	}
@@ -117,11 +121,20 @@ public:
 		}
 		return false;
 	}
+	// virtual offset of the next byte (start of the next block when the current one is used up); kNoOffset at the end
+	static constexpr uint64_t kNoOffset = ~0ull;
+	uint64_t tell()
+	{
+		if (at_eof())
+			return kNoOffset;
+		return ((uint64_t) cur_->coff << 16) | (uint64_t) at_;
+	}
 	const std::string &error() const { return err_; }
 
 private:
 	struct task {
 		std::vector<uint8_t> cdata, out;
+		uint64_t coff = 0; // file offset of the block
 		uint32_t isize = 0, crc = 0;
 		bool done = false, failed = false;
 	};
@@ -193,6 +206,7 @@ private:
 	{
 		for (;;) { // skip empty blocks (the EOF marker is one)
 			uint8_t h[12];
+			const off_t block_at = ftello(f_);
 			const size_t got = fread(h, 1, 12, f_);
 			if (got == 0) {
 				file_eof_ = true;
@@ -226,6 +240,7 @@ private:
 				return false;
 			}
 			auto t = std::make_shared<task>();
+			t->coff = (uint64_t) block_at;
 			t->cdata.resize((size_t) cdata + 8);
 			if (fread(t->cdata.data(), 1, t->cdata.size(), f_) != t->cdata.size()) {
 				err_ = "truncated BGZF block";
@@ -246,7 +261,8 @@ private:
 	{
 		at_ = 0;
 		// keep the read-ahead queue full
-		while (!file_eof_ && queue_.size() < kAhead) {
+		const size_t ahead = n_workers_ ? kAhead : 1; // (inflating on the calling thread: nothing to run ahead with)
+		while (!file_eof_ && queue_.size() < ahead) {
 			std::shared_ptr<task> t;
 			if (!read_raw(&t))
 				return false;
@@ -376,6 +392,148 @@ public:
 		out->pos = pos_.data();
 		out->mapq = mapq_.data();
 		out->n = pos_.size();
+		return true;
+	}
+
+	// Parallel decode of one target.  The linear index gives, for every 16 kb window, the virtual offset of the first
+	// record that overlaps it; records are sorted by position, so the records that START in [w_a, w_b) * 16 kb are a
+	// contiguous run somewhere behind offset[w_a].  The target's stretch of the file is cut into segments of about equal
+	// compressed size at window boundaries; each segment gets its own reader (own file handle, inflating on its own
+	// thread), skips the records in front of its first window and stops at the first record of the next segment.  The
+	// offsets of an index are not trusted blindly: segment k must stop exactly where segment k + 1 found its first
+	// record (virtual offsets compared), otherwise the target is read sequentially.
+	bool read_all(int tid, int64_t chrom_len, int threads, std::vector<int32_t> *pos, std::vector<uint8_t> *mapq,
+			std::string *err) override
+	{
+		if (tid < 0 || tid >= (int) linear_.size() || threads < 2 || ref_beg_[(size_t) tid] == 0)
+			return false;
+		std::vector<uint64_t> lin = linear_[(size_t) tid];
+		const size_t n_win = std::min(lin.size(), (size_t) ((chrom_len + 16383) >> 14));
+		lin.resize(n_win);
+		for (size_t w = 1; w < n_win; w++) // windows nothing overlaps carry 0 (or, from htslib, the previous value)
+			if (lin[w] == 0 || lin[w] < lin[w - 1])
+				lin[w] = lin[w - 1];
+		size_t w_first = 0;
+		while (w_first < n_win && lin[w_first] == 0)
+			w_first++;
+		if (w_first >= n_win)
+			return false;
+		const uint64_t c_lo = lin[w_first] >> 16, c_hi = lin[n_win - 1] >> 16;
+		int want = threads;
+		if (const char *e = getenv("CONGA_BAM_SEGMENTS"))
+			want = atoi(e); // (tests: any number of segments on a small file; 0 / 1: off)
+		else
+			want = (int) std::min<uint64_t>((uint64_t) std::min(threads, 128), (c_hi - c_lo) / (4u << 20)); // >= 4 MiB of file per segment
+		if (want < 2)
+			return false;
+		struct segment {
+			int64_t lo, hi;   // positions [lo, hi)
+			uint64_t at;      // where to start reading
+			uint64_t v_first = bgzf_reader::kNoOffset, v_stop = bgzf_reader::kNoOffset;
+			std::vector<int32_t> pos;
+			std::vector<uint8_t> mapq;
+			std::string err;
+		};
+		std::vector<segment> segs;
+		{
+			std::vector<size_t> cuts = {0}; // windows at which a segment starts (the first one covers everything in front too)
+			for (int k = 1; k < want; k++) {
+				const uint64_t target = c_lo + (c_hi - c_lo) * (uint64_t) k / (uint64_t) want;
+				size_t lo = w_first, hi = n_win; // first window whose offset lies at or behind `target`
+				while (lo < hi) {
+					const size_t mid = (lo + hi) / 2;
+					if ((lin[mid] >> 16) < target)
+						lo = mid + 1;
+					else
+						hi = mid;
+				}
+				if (lo < n_win && lo > cuts.back())
+					cuts.push_back(lo);
+			}
+			for (size_t k = 0; k < cuts.size(); k++) {
+				segment sg;
+				sg.lo = k == 0 ? 0 : (int64_t) cuts[k] << 14;
+				sg.hi = k + 1 < cuts.size() ? (int64_t) cuts[k + 1] << 14 : chrom_len;
+				sg.at = k == 0 ? ref_beg_[(size_t) tid] : lin[cuts[k]];
+				segs.push_back(std::move(sg));
+			}
+		}
+		if (segs.size() < 2)
+			return false;
+		auto run = [&](segment &sg) {
+			bgzf_reader bz(0);
+			if (!bz.open(path_) || !bz.seek(sg.at)) {
+				sg.err = "BAM seek failed";
+				return;
+			}
+			for (;;) {
+				const uint64_t v = bz.tell();
+				if (v == bgzf_reader::kNoOffset) {
+					if (!bz.error().empty())
+						sg.err = bz.error();
+					break; // end of file
+				}
+				int32_t block_size;
+				uint8_t b[32];
+				if (!bz.read(&block_size, 4) || block_size < 32 || !bz.read(b, 32) || !bz.skip((size_t) block_size - 32)) {
+					sg.err = bz.error().empty() ? "truncated BAM record" : bz.error();
+					break;
+				}
+				int32_t ref_id, p;
+				memcpy(&ref_id, b, 4);
+				memcpy(&p, b + 4, 4);
+				if (ref_id >= 0 && ref_id < tid)
+					continue; // (a chunk may begin with the tail of the previous target)
+				if (ref_id != tid || p >= sg.hi) {
+					sg.v_stop = v;
+					if (sg.v_first == bgzf_reader::kNoOffset)
+						sg.v_first = v;
+					break;
+				}
+				if (p < sg.lo)
+					continue; // starts in front of this segment: the previous one's
+				if (sg.v_first == bgzf_reader::kNoOffset)
+					sg.v_first = v;
+				if (p < 0)
+					continue;
+				sg.pos.push_back(p);
+				sg.mapq.push_back(b[9]);
+			}
+		};
+		{
+			std::vector<std::thread> pool;
+			for (size_t k = 1; k < segs.size(); k++)
+				pool.emplace_back([&, k] { run(segs[k]); });
+			run(segs[0]);
+			for (std::thread &t : pool)
+				t.join();
+		}
+		for (const segment &sg : segs)
+			if (!sg.err.empty()) {
+				*err = sg.err;
+				return false;
+			}
+		for (size_t k = 0; k + 1 < segs.size(); k++)
+			if (segs[k].v_stop != segs[k + 1].v_first) {
+				fprintf(stderr, "\n[CONGA] %s: the linear index of target %d does not line up with the records "
+						"(segment %zu); reading it sequentially\n", bai_path_.c_str(), tid, k);
+				return false;
+			}
+		size_t total = 0;
+		for (const segment &sg : segs)
+			total += sg.pos.size();
+		pos->clear();
+		mapq->clear();
+		pos->reserve(total);
+		mapq->reserve(total);
+		for (const segment &sg : segs) {
+			pos->insert(pos->end(), sg.pos.begin(), sg.pos.end());
+			mapq->insert(mapq->end(), sg.mapq.begin(), sg.mapq.end());
+		}
+		// the sequential iterator would now stand behind this target
+		have_pending_ = false;
+		last_ref_ = -2;
+		done_ = true;
 		return true;
 	}
 
@@ -531,6 +689,7 @@ private:
 		char magic[4];
 		int32_t n_ref;
 		std::vector<uint64_t> beg;
+		std::vector<std::vector<uint64_t>> lin; // per reference: smallest virtual offset of a record overlapping each 16 kb window
 		bool ok = fread(magic, 1, 4, f) == 4 && memcmp(magic, "BAI\1", 4) == 0 && fread(&n_ref, 4, 1, f) == 1 && n_ref >= 0;
 		for (int r = 0; ok && r < n_ref; r++) {
 			int32_t n_bin;
@@ -548,12 +707,16 @@ private:
 				}
 			}
 			int32_t n_intv;
-			ok = ok && fread(&n_intv, 4, 1, f) == 1 && n_intv >= 0 && fseeko(f, (off_t) n_intv * 8, SEEK_CUR) == 0;
+			ok = ok && fread(&n_intv, 4, 1, f) == 1 && n_intv >= 0 && n_intv <= (1 << 17);
+			std::vector<uint64_t> iv((size_t) (ok ? n_intv : 0));
+			ok = ok && (iv.empty() || fread(iv.data(), 8, iv.size(), f) == iv.size());
 			beg.push_back(first);
+			lin.push_back(std::move(iv));
 		}
 		fclose(f);
 		if (ok && (int) beg.size() == n_targets()) {
 			ref_beg_ = beg;
+			linear_ = lin;
 			bai_path_ = path;
 		}
 		return true;
@@ -563,6 +726,7 @@ private:
 	bgzf_reader bgzf_;
 	std::vector<std::string> names_;
 	std::vector<uint64_t> ref_beg_;
+	std::vector<std::vector<uint64_t>> linear_;
 	std::vector<int32_t> pos_;
 	std::vector<uint8_t> mapq_;
 	int tid_ = -1, last_ref_ = -2;

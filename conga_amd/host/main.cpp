@@ -6,6 +6,7 @@
 #include <ctime>
 #include <memory>
 #include <string>
+#include <vector>
 
 #include "annotation.h"
 #include "bam_data.h"
@@ -109,6 +110,23 @@ int main(int argc, char **argv)
 				continue;
 			}
 			long long n = 0, sum_pos = 0, sum_mapq = 0;
+			{
+				std::vector<int32_t> all_pos;
+				std::vector<uint8_t> all_mapq;
+				std::string perr;
+				if (src->read_all(tid, this_sonic->chromosome_lengths[c], usable_cpus(), &all_pos, &all_mapq, &perr)) {
+					for (size_t i = 0; i < all_pos.size(); i++) {
+						sum_pos += all_pos[i];
+						sum_mapq += all_mapq[i];
+					}
+					printf("%s\t%lld\t%lld\t%lld\n", name.c_str(), (long long) all_pos.size(), sum_pos, sum_mapq);
+					continue;
+				}
+				if (!perr.empty()) {
+					fprintf(stderr, "%s\n", perr.c_str());
+					return CONGA_EXIT_COMMON;
+				}
+			}
 			if (!src->begin(tid, this_sonic->chromosome_lengths[c], &err)) {
 				fprintf(stderr, "%s\n", err.c_str());
 				return CONGA_EXIT_COMMON;

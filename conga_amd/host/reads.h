@@ -38,6 +38,14 @@ public:
 	// (the analogue of sam_itr_queryi(idx, tid, 0, L) + sam_itr_next: bam_data.c:293,201).
 	virtual bool begin(int tid, int64_t chrom_len, std::string *err) = 0;
 	virtual bool next(size_t max_n, read_batch *out, std::string *err) = 0;
+	// The same records as begin() + next() until exhaustion, all at once, decoded by up to `threads` readers working on
+	// disjoint position ranges of the target (a BAM with the linear offsets of its .bai).  false with an empty *err: not
+	// available for this source / target -- iterate instead; false with a message: the file or its index is broken.
+	virtual bool read_all(int tid, int64_t chrom_len, int threads, std::vector<int32_t> *pos, std::vector<uint8_t> *mapq,
+			std::string *err)
+	{
+		return false;
+	}
 	// Same iteration, whole records (--rp).  Sources without sequences return false.
 	virtual bool next_full(full_batch *fb, std::string *err)
 	{

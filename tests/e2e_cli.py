@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--input", choices=("bam", "tuples"), default="bam",
                     help="tuples: the read-tuple container (decoded pos / mapq per chromosome) instead of a BAM -- what "
                          "is left of the wall time is file read, PCIe staging, compute and the output writer")
+    ap.add_argument("--bai", type=int, default=1, help="write the .bai too (0: the reader then goes through the file front to back)")
     ap.add_argument("--gpus", default="1", help="comma list of `conga --gpus` values to run on the same input (contexts "
                     "share the device when there are fewer devices)")
     a = ap.parse_args()
@@ -39,7 +40,8 @@ def main():
     t0 = time.time()
     reads_file = "r.bam" if a.input == "bam" else "r.ctp"
     if a.input == "bam":
-        formats.write_bam_fast(os.path.join(d, reads_file), "SYNTH", [(c.name, c.length, c.pos, c.mapq) for c in cs], realistic=True)
+        formats.write_bam_fast(os.path.join(d, reads_file), "SYNTH", [(c.name, c.length, c.pos, c.mapq) for c in cs], realistic=True,
+                               index=bool(a.bai))
     else:
         formats.write_tuples(os.path.join(d, reads_file), "SYNTH", [(c.name, c.length, c.pos, c.mapq) for c in cs])
     t_bam = time.time() - t0

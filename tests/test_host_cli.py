@@ -358,6 +358,49 @@ def test_bai_seek_gives_the_same_records_in_any_chromosome_order(tmp_path):
     assert outs["with_bai"] == want
 
 
+def test_parallel_segment_decode_gives_the_same_records(tmp_path):
+    """read_all: a chromosome's stretch of the BAM cut at windows of the .bai's linear index and decoded by several
+    readers at once; any number of segments gives the records of the sequential reader, pile-ups that straddle a
+    window boundary and empty stretches included, and a linear index that does not line up is noticed."""
+    d = str(tmp_path)
+    rng = np.random.default_rng(5)
+    cs = []
+    for n, L in (("1", 900_000), ("2", 300_000), ("3", 1_200_000)):
+        pos = np.sort(np.concatenate([rng.integers(0, L, 20_000), np.full(300, 16384 * 7), np.full(200, 16384 * 7 - 1),
+                                      rng.integers(500_000, 500_100, 500) if L > 600_000 else np.zeros(0, np.int64)])).astype(np.int32)
+        pos = pos[(pos < 200_000) | (pos > 330_000)]                      # a stretch no read starts in
+        cs.append((n, L, pos, rng.integers(0, 61, len(pos)).astype(np.uint8)))
+    formats.write_bam(os.path.join(d, "r.bam"), "S", cs, index=True, block_payload=3000, unplaced=4)
+    formats.write_annotation(os.path.join(d, "a.cga"), [(n, L, np.full((L + 99) // 100, 40, np.uint8), [], []) for n, L, _, _ in cs])
+    args = ["-i", "r.bam", "--out", "o", "--ref", "r.fa", "--sonic", "a.cga", "--dump-reads"]
+    want = ["%s\t%d\t%d\t%d" % (n, len(p), p.astype(np.int64).sum(), q.astype(np.int64).sum()) for n, L, p, q in cs]
+    for k in ("1", "2", "3", "7", "16", "61"):
+        r = subprocess.run([CONGA] + args, cwd=d, capture_output=True, text=True, timeout=600, env=dict(os.environ, CONGA_BAM_SEGMENTS=k))
+        assert r.returncode == 0, r.stderr
+        assert [l for l in r.stdout.splitlines() if l[:1].isdigit()] == want, k
+        assert "does not line up" not in r.stderr
+    # an index whose linear offsets point somewhere else: noticed, and the sequential reader takes over
+    bai = bytearray(open(os.path.join(d, "r.bam.bai"), "rb").read())
+    import struct
+    at = 8
+    (n_bin,) = struct.unpack_from("<i", bai, at)
+    at += 4
+    for _ in range(n_bin):
+        (_, n_chunk) = struct.unpack_from("<Ii", bai, at)
+        at += 8 + 16 * n_chunk
+    (n_intv,) = struct.unpack_from("<i", bai, at)
+    at += 4
+    lin = list(struct.unpack_from("<%dQ" % n_intv, bai, at))
+    for w in range(n_intv // 2, n_intv):                                   # second half: every window claims a LATER offset
+        lin[w] = lin[min(n_intv - 1, w + 9)]                               # (records in between would be lost; an earlier one only costs time)
+    struct.pack_into("<%dQ" % n_intv, bai, at, *lin)
+    open(os.path.join(d, "r.bam.bai"), "wb").write(bytes(bai))
+    r = subprocess.run([CONGA] + args, cwd=d, capture_output=True, text=True, timeout=600, env=dict(os.environ, CONGA_BAM_SEGMENTS="8"))
+    assert r.returncode == 0, r.stderr
+    assert [l for l in r.stdout.splitlines() if l[:1].isdigit()] == want
+    assert "does not line up" in r.stderr
+
+
 def test_fast_bed_parser_equals_the_literal_fgets_strtok_reader(tmp_path, oracle):
     """svs.cpp parses BEDs from an mmap on several threads; it must yield the rows of the reference's literal
     fgets(512) / strtok / atoi / atof reader (svs.c:7-240,317-377), which stays in the binary as the fallback."""
