@@ -160,6 +160,13 @@ struct Bits {
 			}
 		}
 	}
+	// the same with at least eight bytes of input left (the caller knows)
+	inline void refill_fast()
+	{
+		buf |= load64(ip) << cnt;
+		ip += (63 - cnt) >> 3;
+		cnt |= 56;
+	}
 	inline uint32_t peek(int n) const { return (uint32_t) (buf & ((1ull << n) - 1ull)); }
 	inline void drop(int n)
 	{
@@ -290,7 +297,60 @@ bool inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len)
 		}
 
 		// ---- the block's symbols.  One refill covers a whole length / distance pair: 15 + 5 + 15 + 13 = 48 bits.
-		for (;;) {
+		for (bool end_of_block = false; !end_of_block;) {
+			// Fast trips: with 16 bytes of input ahead neither refill of a trip can run dry (each takes 7 bytes at most), and
+			// with 274 bytes of room neither three literals nor a 258-byte match copied in eight-byte steps can run over:
+			// no bounds checks inside.
+			while ((b.iend - b.ip) >= 16 && (oend - op) >= 274) {
+				b.refill_fast();
+				uint32_t e = decode(b, lit, kLitBits);
+				if (e & kLiteral) {
+					*op++ = (uint8_t) (e >> 13);
+					e = decode(b, lit, kLitBits);
+					if (e & kLiteral) {
+						*op++ = (uint8_t) (e >> 13);
+						e = decode(b, lit, kLitBits);
+						if (e & kLiteral) {
+							*op++ = (uint8_t) (e >> 13);
+							continue;
+						}
+					}
+					b.refill_fast();
+				}
+				if (!(e & kValid))
+					return false;
+				if (e & kEnd) {
+					end_of_block = true;
+					break;
+				}
+				const size_t length = ((e >> 13) & 0x7FFFu) + b.take((int) ((e >> 8) & 31u));
+				e = decode(b, dist, kDistBits);
+				if (!(e & kValid))
+					return false;
+				const size_t offset = ((e >> 13) & 0x7FFFu) + b.take((int) ((e >> 8) & 31u));
+				if (offset > (size_t) (op - out))
+					return false;
+				const uint8_t *src = op - offset;
+				if (offset >= 8) {
+					uint8_t *d = op;
+					ptrdiff_t left = (ptrdiff_t) length;
+					do {
+						memcpy(d, src, 8);
+						d += 8;
+						src += 8;
+						left -= 8;
+					} while (left > 0);
+				} else if (offset == 1) {
+					memset(op, *src, length);
+				} else {
+					for (size_t i = 0; i < length; i++)
+						op[i] = src[i];
+				}
+				op += length;
+			}
+			if (end_of_block)
+				break;
+			// One careful trip (the ends of the input and of the output)
 			if (b.cnt < 0)
 				return false;
 			b.refill();
@@ -299,24 +359,7 @@ bool inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len)
 				if (op == oend)
 					return false;
 				*op++ = (uint8_t) (e >> 13);
-				// a second and a third literal from the same refill (15 bits each at most, 56 were there)
-				e = decode(b, lit, kLitBits);
-				if (e & kLiteral) {
-					if (op == oend)
-						return false;
-					*op++ = (uint8_t) (e >> 13);
-					e = decode(b, lit, kLitBits);
-					if (e & kLiteral) {
-						if (op == oend)
-							return false;
-						*op++ = (uint8_t) (e >> 13);
-						continue;
-					}
-				}
-				// not a literal: 45 bits are gone at most and a pair may need 48 -> top up before going on with it
-				if (b.cnt < 0)
-					return false;
-				b.refill();
+				continue;
 			}
 			if (!(e & kValid))
 				return false;
@@ -330,22 +373,8 @@ bool inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len)
 			if (b.cnt < 0 || offset > (size_t) (op - out) || length > (size_t) (oend - op))
 				return false;
 			const uint8_t *src = op - offset;
-			if (offset >= 8 && (size_t) (oend - op) >= length + 8) {
-				// eight bytes at a time; a chunk's source lies entirely in front of its destination
-				uint8_t *d = op;
-				ptrdiff_t left = (ptrdiff_t) length;
-				do {
-					memcpy(d, src, 8);
-					d += 8;
-					src += 8;
-					left -= 8;
-				} while (left > 0);
-			} else if (offset == 1) {
-				memset(op, *src, length);
-			} else {
-				for (size_t i = 0; i < length; i++)
-					op[i] = src[i];
-			}
+			for (size_t i = 0; i < length; i++)
+				op[i] = src[i];
 			op += length;
 		}
 		if (final_block)
