@@ -19,6 +19,7 @@ CONGA_ERR_HIP = -3
 CONGA_ERR_NOMEM = -4
 CONGA_ERR_UNSORTED = -5
 CONGA_ERR_RANGE = -6
+CONGA_ERR_DATA = -7
 
 FLAG_READS_UNSORTED = 0x1
 FLAG_PROFILE = 0x2
@@ -36,6 +37,7 @@ KERNEL_NAMES = ("ingest", "depth_tile", "expected_table", "paint", "interval_red
 EXPORTS = (
     "conga_create", "conga_destroy", "conga_strerror", "conga_last_error", "conga_abi_version",
     "conga_device_count", "conga_reset", "conga_chrom_count", "conga_chrom_select", "conga_chrom_begin", "conga_reads_staging", "conga_reads_commit",
+    "conga_reads_bgzf",
     "conga_mappability", "conga_intervals", "conga_reference", "conga_satellites", "conga_split_reads_staging",
     "conga_split_reads_commit", "conga_split_support", "conga_chrom_compute",
     "conga_chrom_fetch", "conga_chrom_finish", "conga_results_device", "conga_results_copy",

@@ -23,6 +23,7 @@
 
 #include "../../include/conga_hip.h"
 #include "kernels.hip.h"
+#include "kernels_bam.hip.h"
 
 using namespace conga;
 
@@ -47,6 +48,7 @@ struct Staging {
 struct HostSlot {
 	int64_t L = 0, n_win = 0, n_tiles = 0;
 	int64_t read_off = 0, n_reads = 0;
+	bool device_fed = false; // its tuples came from conga_reads_bgzf (not to be mixed with conga_reads_commit)
 	int32_t tail_val = 0;  // position of the last committed tuple and the length of the run of equal
 	int64_t tail_len = 0;  // positions that ends there (capped): see wrap_risk
 	std::vector<uint8_t> gc_hist, gc_like; // gc_like empty = same as gc_hist
@@ -110,7 +112,10 @@ struct conga_ctx {
 			d_map_start, d_map_end, d_map_val, d_iv_start, d_iv_end, d_iv_type, d_iv_slot, d_iv_has_map, d_order,
 			d_expected, d_item_off, d_item_len, d_item_iv, d_item_has_map, d_item_first, d_map_part,
 			d_support, d_results, d_bases, d_row_tile, d_depth_blocks, d_support_base, d_ref, d_sat_start, d_sat_end, d_sr_pos,
-			d_sr_mapq, d_sr_flag, d_sr_lq, d_sr_off, d_sr_data, d_kmer_count, d_kmer_offset, d_kmer_cursor, d_kmer_pos;
+			d_sr_mapq, d_sr_flag, d_sr_lq, d_sr_off, d_sr_data, d_kmer_count, d_kmer_offset, d_kmer_cursor, d_kmer_pos,
+			// conga_reads_bgzf: compressed blocks, their table, the inflated stream, the decoders' scratch, the walk's per-segment results
+			d_bz_in, d_bz_blocks, d_bz_off, d_bz_out, d_bz_status, d_bz_scratch, d_bz_crc, d_bz_seg, d_bz_cnt, d_bz_first, d_bz_stop,
+			d_bz_bad, d_bz_at, d_bz_flag;
 
 	// pinned read-back
 	Small *h_small = nullptr;
@@ -753,6 +758,7 @@ const char *conga_strerror(int status)
 	case CONGA_ERR_NOMEM: return "out of memory";
 	case CONGA_ERR_UNSORTED: return "reads are not sorted by position";
 	case CONGA_ERR_RANGE: return "coordinate out of range";
+	case CONGA_ERR_DATA: return "BGZF / BAM data does not check out (decode on the host)";
 	default: return "unknown status";
 	}
 }
@@ -893,7 +899,8 @@ void conga_destroy(conga_ctx *ctx)
 			&ctx->d_item_r1, &ctx->d_item_row0, &ctx->d_item_row1, &ctx->d_item_rt_off, &ctx->d_block_home, &ctx->d_item_lo, &ctx->d_rd, &ctx->d_gc_hist, &ctx->d_gc_like,
 			&ctx->d_slots, &ctx->d_small, &ctx->d_map, &ctx->d_winner, &ctx->d_map_start, &ctx->d_map_end,
 			&ctx->d_map_val, &ctx->d_iv_start, &ctx->d_iv_end, &ctx->d_iv_type, &ctx->d_iv_slot, &ctx->d_iv_has_map,
-			&ctx->d_order, &ctx->d_expected, &ctx->d_item_off, &ctx->d_item_len, &ctx->d_item_iv,
+			&ctx->d_order, &ctx->d_bz_in, &ctx->d_bz_blocks, &ctx->d_bz_off, &ctx->d_bz_out, &ctx->d_bz_status, &ctx->d_bz_scratch,
+			&ctx->d_bz_crc, &ctx->d_bz_seg, &ctx->d_bz_cnt, &ctx->d_bz_first, &ctx->d_bz_stop, &ctx->d_bz_bad, &ctx->d_bz_at, &ctx->d_bz_flag, &ctx->d_expected, &ctx->d_item_off, &ctx->d_item_len, &ctx->d_item_iv,
 			&ctx->d_item_has_map, &ctx->d_item_first, &ctx->d_map_part, &ctx->d_support, &ctx->d_results,
 			&ctx->d_bases, &ctx->d_row_tile, &ctx->d_depth_blocks, &ctx->d_support_base, &ctx->d_ref, &ctx->d_sat_start, &ctx->d_sat_end,
 			&ctx->d_sr_pos, &ctx->d_sr_mapq, &ctx->d_sr_flag, &ctx->d_sr_lq, &ctx->d_sr_off, &ctx->d_sr_data,
@@ -1032,6 +1039,8 @@ int conga_reads_commit(conga_ctx *ctx, size_t n)
 	if (n > kStagingTuples)
 		return fail(ctx, CONGA_ERR_INVALID, "conga_reads_commit: n exceeds the staging capacity");
 	HostSlot &h = ctx->slots.back(); // reads stream into the chromosome begun last (BAM order)
+	if (n && h.device_fed)
+		return fail(ctx, CONGA_ERR_INVALID, "conga_reads_commit: this chromosome's reads came from conga_reads_bgzf");
 	if ((uint64_t) ctx->n_reads_total + n >= 0xFFFFFFF0ull)
 		return fail(ctx, CONGA_ERR_RANGE, "conga_reads_commit: more than 2^32 reads in one context");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1055,6 +1064,142 @@ int conga_reads_commit(conga_ctx *ctx, size_t n)
 	ctx->staging_next = (ctx->staging_next + 1) % kStagingRing;
 	ctx->layout_dirty = true;
 	ctx->computed = false;
+	return CONGA_OK;
+}
+
+int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const conga_bgzf_block *blocks, size_t n_blocks,
+		const conga_bam_segment *segments, size_t n_segments, int32_t ref_id, uint64_t *n_appended)
+{
+	if (!ctx || !bytes || !blocks || !segments || n_blocks == 0 || n_segments == 0 || n_blocks > (size_t) 1 << 28
+			|| n_segments > (size_t) 1 << 28)
+		return CONGA_ERR_INVALID;
+	if (ctx->slots.empty())
+		return fail(ctx, CONGA_ERR_INVALID, "conga_reads_bgzf: no chromosome open");
+	if (ctx->staging_cur >= 0)
+		return fail(ctx, CONGA_ERR_INVALID, "conga_reads_bgzf: a staging buffer is handed out and not committed");
+	HostSlot &h = ctx->slots.back();
+	if (h.n_reads != 0)
+		return fail(ctx, CONGA_ERR_INVALID, "conga_reads_bgzf: the chromosome already has reads (one call per chromosome)");
+	// the inflated stream: the blocks' payloads one behind the other
+	std::vector<uint64_t> out_off(n_blocks);
+	uint64_t total = 0;
+	for (size_t b = 0; b < n_blocks; b++) {
+		const conga_bgzf_block &bl = blocks[b];
+		if (bl.data_off > n_bytes || (uint64_t) bl.data_len > n_bytes - bl.data_off || bl.inflated_len == 0 || bl.inflated_len > 65536u)
+			return fail(ctx, CONGA_ERR_INVALID, "conga_reads_bgzf: block outside the byte range, empty or larger than 64 KiB");
+		out_off[b] = total;
+		total += bl.inflated_len;
+	}
+	for (size_t k = 0; k < n_segments; k++) {
+		const conga_bam_segment &sg = segments[k];
+		if (sg.start > total || sg.pos_lo > sg.pos_hi || (k && (sg.pos_lo != segments[k - 1].pos_hi || sg.start < segments[k - 1].start)))
+			return fail(ctx, CONGA_ERR_INVALID, "conga_reads_bgzf: segments must be ordered and tile the chromosome");
+	}
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	hipStream_t st = ctx->stream;
+	const uint32_t lanes = (uint32_t) std::min<size_t>((n_blocks + 63) & ~(size_t) 63, 32768);
+	TRY(ensure(ctx, ctx->d_bz_in, n_bytes));
+	TRY(ensure(ctx, ctx->d_bz_blocks, n_blocks * sizeof(conga_bgzf_block)));
+	TRY(ensure(ctx, ctx->d_bz_off, n_blocks * 8));
+	TRY(ensure(ctx, ctx->d_bz_out, (size_t) total + 16));
+	TRY(ensure(ctx, ctx->d_bz_status, n_blocks));
+	TRY(ensure(ctx, ctx->d_bz_scratch, (size_t) lanes * sizeof(InflateScratch)));
+	TRY(ensure(ctx, ctx->d_bz_seg, n_segments * sizeof(conga_bam_segment)));
+	TRY(ensure(ctx, ctx->d_bz_cnt, n_segments * 4));
+	TRY(ensure(ctx, ctx->d_bz_first, n_segments * 8));
+	TRY(ensure(ctx, ctx->d_bz_stop, n_segments * 8));
+	TRY(ensure(ctx, ctx->d_bz_bad, n_segments));
+	TRY(ensure(ctx, ctx->d_bz_at, n_segments * 8));
+	TRY(ensure(ctx, ctx->d_bz_flag, 4));
+	if (!ctx->d_bz_crc.p) {
+		uint32_t table[256];
+		for (uint32_t i = 0; i < 256; i++) {
+			uint32_t c = i;
+			for (int k = 0; k < 8; k++)
+				c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+			table[i] = c;
+		}
+		TRY(upload(ctx, ctx->d_bz_crc, table, sizeof table));
+	}
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bz_in.p, bytes, n_bytes, hipMemcpyHostToDevice, st));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bz_blocks.p, blocks, n_blocks * sizeof(conga_bgzf_block), hipMemcpyHostToDevice, st));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bz_off.p, out_off.data(), n_blocks * 8, hipMemcpyHostToDevice, st));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bz_seg.p, segments, n_segments * sizeof(conga_bam_segment), hipMemcpyHostToDevice, st));
+	hipLaunchKernelGGL(bgzf_inflate_kernel, dim3(lanes / 64), dim3(64), 0, st, (uint32_t) n_blocks, ptr<uint8_t>(ctx->d_bz_in),
+			ptr<conga_bgzf_block>(ctx->d_bz_blocks), ptr<uint64_t>(ctx->d_bz_off), ptr<uint8_t>(ctx->d_bz_out),
+			ptr<InflateScratch>(ctx->d_bz_scratch), ptr<uint32_t>(ctx->d_bz_crc), ptr<uint8_t>(ctx->d_bz_status));
+	BamWalkArgs w;
+	w.stream = ptr<uint8_t>(ctx->d_bz_out);
+	w.stream_len = total;
+	w.segments = ptr<conga_bam_segment>(ctx->d_bz_seg);
+	w.n_segments = (uint32_t) n_segments;
+	w.ref_id = ref_id;
+	w.count = ptr<uint32_t>(ctx->d_bz_cnt);
+	w.v_first = ptr<uint64_t>(ctx->d_bz_first);
+	w.v_stop = ptr<uint64_t>(ctx->d_bz_stop);
+	w.bad = ptr<uint8_t>(ctx->d_bz_bad);
+	w.write_at = ptr<uint64_t>(ctx->d_bz_at);
+	w.pos = nullptr;
+	w.mapq = nullptr;
+	const int wgrid = (int) ((n_segments + 63) / 64);
+	hipLaunchKernelGGL(bam_walk_kernel<false>, dim3(wgrid), dim3(64), 0, st, w);
+	std::vector<uint8_t> status(n_blocks), bad(n_segments);
+	std::vector<uint32_t> count(n_segments);
+	std::vector<uint64_t> v_first(n_segments), v_stop(n_segments);
+	HIP_TRY(ctx, hipMemcpyAsync(status.data(), ctx->d_bz_status.p, n_blocks, hipMemcpyDeviceToHost, st));
+	HIP_TRY(ctx, hipMemcpyAsync(bad.data(), ctx->d_bz_bad.p, n_segments, hipMemcpyDeviceToHost, st));
+	HIP_TRY(ctx, hipMemcpyAsync(count.data(), ctx->d_bz_cnt.p, n_segments * 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(ctx, hipMemcpyAsync(v_first.data(), ctx->d_bz_first.p, n_segments * 8, hipMemcpyDeviceToHost, st));
+	HIP_TRY(ctx, hipMemcpyAsync(v_stop.data(), ctx->d_bz_stop.p, n_segments * 8, hipMemcpyDeviceToHost, st));
+	HIP_TRY(ctx, hipStreamSynchronize(st));
+	for (size_t b = 0; b < n_blocks; b++)
+		if (status[b] != kBgzfOk)
+			return fail(ctx, CONGA_ERR_DATA, status[b] == kBgzfCrc ? "conga_reads_bgzf: a block fails its CRC32"
+					: "conga_reads_bgzf: a block does not inflate to its recorded size");
+	std::vector<uint64_t> write_at(n_segments);
+	uint64_t n_new = 0;
+	for (size_t k = 0; k < n_segments; k++) {
+		if (bad[k])
+			return fail(ctx, CONGA_ERR_DATA, "conga_reads_bgzf: a start point does not lead along whole BAM records");
+		if (k + 1 < n_segments && v_stop[k] != v_first[k + 1])
+			return fail(ctx, CONGA_ERR_DATA, "conga_reads_bgzf: the start points do not line up with the records");
+		write_at[k] = (uint64_t) ctx->n_reads_total + n_new;
+		n_new += count[k];
+	}
+	if ((uint64_t) ctx->n_reads_total + n_new >= 0xFFFFFFF0ull)
+		return fail(ctx, CONGA_ERR_RANGE, "conga_reads_bgzf: more than 2^32 reads in one context");
+	if (n_new) {
+		const size_t total_reads = (size_t) ctx->n_reads_total + (size_t) n_new;
+		if (total_reads * 4 > ctx->d_pos.cap || total_reads > ctx->d_mapq.cap) {
+			const size_t want = std::max(total_reads, (size_t) 1 << 22);
+			TRY(ensure(ctx, ctx->d_pos, want * 4, true));
+			TRY(ensure(ctx, ctx->d_mapq, want, true));
+		}
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bz_at.p, write_at.data(), n_segments * 8, hipMemcpyHostToDevice, st));
+		w.pos = ptr<int32_t>(ctx->d_pos);
+		w.mapq = ptr<uint8_t>(ctx->d_mapq);
+		hipLaunchKernelGGL(bam_walk_kernel<true>, dim3(wgrid), dim3(64), 0, st, w);
+		// more than 32767 read starts on one base would wrap the reference's `short`: only the dense formulation
+		// reproduces that (same guard as note_equal_runs, exact here)
+		HIP_TRY(ctx, hipMemsetAsync(ctx->d_bz_flag.p, 0, 4, st));
+		if (n_new >= 32768) {
+			const int egrid = (int) ((n_new + 255) / 256);
+			hipLaunchKernelGGL(equal_run_kernel, dim3(egrid), dim3(256), 0, st, ptr<int32_t>(ctx->d_pos) + ctx->n_reads_total, n_new, 32768u,
+					ptr<uint32_t>(ctx->d_bz_flag));
+		}
+		uint32_t flag = 0;
+		HIP_TRY(ctx, hipMemcpyAsync(&flag, ctx->d_bz_flag.p, 4, hipMemcpyDeviceToHost, st));
+		HIP_TRY(ctx, hipStreamSynchronize(st));
+		if (flag)
+			ctx->wrap_risk = true;
+	}
+	h.device_fed = true;
+	h.n_reads += (int64_t) n_new;
+	ctx->n_reads_total += (int64_t) n_new;
+	ctx->layout_dirty = true;
+	ctx->computed = false;
+	if (n_appended)
+		*n_appended = n_new;
 	return CONGA_OK;
 }
 

@@ -1,0 +1,137 @@
+// kernels_bam.hip.h -- BAM decode on the device (conga_reads_bgzf): BGZF inflate and the record walk.
+//
+// The producer side of count_reads_bam (bam_data.c:192-221) is htslib's BGZF + BAM iterator in the reference.  Here the
+// compressed blocks go to HBM as they are and
+//   bgzf_inflate_kernel  one LANE per BGZF block runs the host reader's block decoder (conga_amd/host/inflate_core.h,
+//                        the same source, tables in a per-lane scratch in HBM) and checks the block's CRC32.  No wave
+//                        cooperation: a genome's worth of independent blocks keeps every lane of the chip busy, and the
+//                        measured rate (17 GB/s inflated with 45 000 blocks in flight, tools/gpu_inflate.hip) is already
+//                        several times a 16-core host's.
+//   bam_walk_kernel      one lane per start point of the .bai's linear index follows the block_size chain of the
+//                        records, skips what lies in front of its window, stops at the first record of the next
+//                        segment; a counting pass, an exclusive scan on the host, then the same walk writes (pos, mapq)
+//                        into the context's tuple arrays.
+//   equal_run_kernel     the tuple-space formulation's guard (a `short` depth counter wraps after 32767 read starts on
+//                        one base): looks for a run of kWrapRun equal positions in what was appended.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/conga_hip.h"
+#include "../host/inflate_core.h"
+
+namespace conga {
+
+using InflateScratch = conga_host::inflate_core::Decoder;
+
+enum { kBgzfOk = 0, kBgzfRefused = 1, kBgzfCrc = 2 };
+
+__device__ __forceinline__ uint32_t crc32_bytes(const uint32_t *table, const uint8_t *p, uint32_t n)
+{
+	uint32_t c = 0xFFFFFFFFu;
+	for (uint32_t i = 0; i < n; i++)
+		c = table[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
+	return c ^ 0xFFFFFFFFu;
+}
+
+// status[b]: kBgzfOk / kBgzfRefused / kBgzfCrc.  Lanes loop over blocks with the launch's lane count as stride, so the
+// scratch is one decoder per launched lane.
+__global__ __launch_bounds__(64) void bgzf_inflate_kernel(uint32_t n_blocks, const uint8_t *__restrict__ bytes,
+		const conga_bgzf_block *__restrict__ blocks, const uint64_t *__restrict__ out_off, uint8_t *__restrict__ out,
+		InflateScratch *scratch, const uint32_t *__restrict__ crc_table, uint8_t *__restrict__ status)
+{
+	const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x, lanes = gridDim.x * blockDim.x;
+	for (uint32_t b = lane; b < n_blocks; b += lanes) {
+		const conga_bgzf_block bl = blocks[b];
+		uint8_t *dst = out + out_off[b];
+		uint8_t st = kBgzfOk;
+		if (!conga_host::inflate_core::inflate_block_stream(scratch[lane], bytes + bl.data_off, bl.data_len, dst, bl.inflated_len))
+			st = kBgzfRefused;
+		else if (crc32_bytes(crc_table, dst, bl.inflated_len) != bl.crc32)
+			st = kBgzfCrc;
+		status[b] = st;
+	}
+}
+
+struct BamWalkArgs {
+	const uint8_t *stream;  // the inflated blocks, concatenated
+	uint64_t stream_len;
+	const conga_bam_segment *segments;
+	uint32_t n_segments;
+	int32_t ref_id;
+	// per segment
+	uint32_t *count;        // records it owns (pass 1)
+	uint64_t *v_first;      // where it found its first own record (or where it stopped, if it owns none)
+	uint64_t *v_stop;       // the record that ended it (first record of the next segment / of another target); ~0: end of stream
+	uint8_t *bad;           // a record that cannot be one (block_size < 32 or running past the stream)
+	const uint64_t *write_at; // pass 2: first tuple of each segment
+	int32_t *pos;
+	uint8_t *mapq;
+};
+
+__device__ __forceinline__ int32_t load_i32(const uint8_t *p)
+{
+	return (int32_t) ((uint32_t) p[0] | ((uint32_t) p[1] << 8) | ((uint32_t) p[2] << 16) | ((uint32_t) p[3] << 24));
+}
+
+template <bool WRITE> __global__ __launch_bounds__(64) void bam_walk_kernel(BamWalkArgs a)
+{
+	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= a.n_segments)
+		return;
+	const conga_bam_segment sg = a.segments[k];
+	constexpr uint64_t kNone = ~0ull;
+	uint64_t at = sg.start, first = kNone, stop = kNone;
+	uint32_t n = 0;
+	uint64_t w = WRITE ? a.write_at[k] : 0;
+	bool bad = false;
+	for (;;) {
+		if (at + 4 > a.stream_len)
+			break; // end of the stream (stop stays kNone)
+		const uint8_t *r = a.stream + at;
+		const int32_t block_size = load_i32(r);
+		if (block_size < 32 || at + 4 + (uint64_t) block_size > a.stream_len) {
+			bad = true;
+			break;
+		}
+		const int32_t ref = load_i32(r + 4), p = load_i32(r + 8);
+		const uint64_t here = at;
+		at += 4 + (uint64_t) block_size;
+		if (ref >= 0 && ref < a.ref_id)
+			continue; // (the tail of the previous target in front of this one's first record)
+		if (ref != a.ref_id || p >= sg.pos_hi) {
+			stop = here;
+			if (first == kNone)
+				first = here;
+			break;
+		}
+		if (p < sg.pos_lo)
+			continue; // starts in front of this segment: the previous one's
+		if (first == kNone)
+			first = here;
+		if (p < 0)
+			continue;
+		if (WRITE) {
+			a.pos[w] = p;
+			a.mapq[w] = r[13];
+			w++;
+		}
+		n++;
+	}
+	if (!WRITE) {
+		a.count[k] = n;
+		a.v_first[k] = first;
+		a.v_stop[k] = stop;
+		a.bad[k] = bad ? 1 : 0;
+	}
+}
+
+// flag |= 1 when pos[i] == pos[i + run - 1] for some i (positions are sorted: a run of `run` equal values)
+__global__ __launch_bounds__(256) void equal_run_kernel(const int32_t *__restrict__ pos, uint64_t n, uint32_t run, uint32_t *flag)
+{
+	const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (i + run - 1 < n && pos[i] == pos[i + run - 1])
+		atomicOr(flag, 1u);
+}
+
+} // namespace conga

@@ -91,6 +91,24 @@ int64_t count_reads_bam(conga_ctx *ctx, read_source *src, int chr_index_bam, int
 		}
 		return cnt;
 	}
+	if (getenv("CONGA_GPU_BAM") == nullptr || atoi(getenv("CONGA_GPU_BAM")) != 0) {
+		// a BAM with an index: its compressed blocks go to the GPU as they are and are inflated and walked there
+		// (conga_reads_bgzf); anything that does not check out falls through to the host decoders below
+		std::vector<uint8_t> bytes;
+		std::vector<conga_bgzf_block> blocks;
+		std::vector<conga_bam_segment> segments;
+		if (src->device_plan(chr_index_bam, chrom_len, &bytes, &blocks, &segments, &err)) {
+			uint64_t n_new = 0;
+			const int rc = conga_reads_bgzf(ctx, bytes.data(), bytes.size(), blocks.data(), blocks.size(), segments.data(), segments.size(),
+					chr_index_bam, &n_new);
+			if (rc == CONGA_OK)
+				return (int64_t) n_new;
+			if (rc != CONGA_ERR_DATA)
+				engine_check(ctx, rc, "conga_reads_bgzf");
+			fprintf(stderr, "\n[CONGA] decoding on the host: %s\n", conga_last_error(ctx));
+		}
+		err.clear();
+	}
 	{
 		// a BAM with an index: the whole chromosome decoded by several readers at once (reads.h: read_all)
 		std::vector<int32_t> all_pos;

@@ -7,6 +7,7 @@
 // file order, which is what sam_itr_queryi(idx, tid, 0, L) + sam_itr_next yield (bam_data.c:293,201).
 // CRAM is not supported.  Inflate is zlib on a pool of worker threads with a 96-block read-ahead
 // (CONGA_BAM_THREADS overrides the worker count; 0 = inflate inline).
+#include <sys/stat.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -544,6 +545,140 @@ public:
 		return true;
 	}
 
+	// The target's stretch of the file for conga_reads_bgzf: from the block of its first record through the block in
+	// which the next target with records begins (so that the walk sees a record that ends this target; to the end of the
+	// file for the last one), the table of those blocks, and one start point per distinct linear-index offset.
+	bool device_plan(int tid, int64_t chrom_len, std::vector<uint8_t> *bytes, std::vector<conga_bgzf_block> *blocks,
+			std::vector<conga_bam_segment> *segments, std::string *err) override
+	{
+		if (tid < 0 || tid >= (int) linear_.size() || ref_beg_[(size_t) tid] == 0)
+			return false;
+		const uint64_t c_lo = ref_beg_[(size_t) tid] >> 16;
+		uint64_t c_end = 0; // file offset behind the last block to take; 0: the end of the file
+		for (size_t t = (size_t) tid + 1; t < ref_beg_.size(); t++)
+			if (ref_beg_[t] != 0) {
+				c_end = ref_beg_[t] >> 16; // (the block at c_end itself is added below)
+				break;
+			}
+		FILE *f = fopen(path_.c_str(), "rb");
+		if (!f)
+			return false;
+		struct stat st;
+		if (fstat(fileno(f), &st) != 0 || (uint64_t) st.st_size <= c_lo) {
+			fclose(f);
+			return false;
+		}
+		uint64_t stop = (uint64_t) st.st_size;
+		if (c_end && c_end + 65536 + 18 < stop)
+			stop = c_end + 65536 + 18; // enough for the whole block that starts at c_end
+		const uint64_t kMaxPiece = 6ull << 30;
+		if (const char *e = getenv("CONGA_GPU_BAM_MAX_MB")) {
+			if (stop - c_lo > (uint64_t) atoll(e) << 20) {
+				fclose(f);
+				return false;
+			}
+		} else if (stop - c_lo > kMaxPiece) {
+			fclose(f);
+			return false;
+		}
+		bytes->resize((size_t) (stop - c_lo));
+		const bool read_ok = fseeko(f, (off_t) c_lo, SEEK_SET) == 0 && fread(bytes->data(), 1, bytes->size(), f) == bytes->size();
+		fclose(f);
+		if (!read_ok)
+			return false;
+		// block table
+		blocks->clear();
+		std::vector<uint64_t> file_off, inflated_off; // per kept block
+		uint64_t total = 0;
+		size_t at = 0;
+		while (at + 18 <= bytes->size()) {
+			const uint8_t *h = bytes->data() + at;
+			if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) {
+				*err = "not a BGZF block";
+				return false;
+			}
+			const unsigned xlen = h[10] | (h[11] << 8);
+			if (at + 12 + xlen > bytes->size())
+				break;
+			int bsize = -1;
+			for (unsigned i = 0; i + 4 <= xlen;) {
+				const uint8_t *x = h + 12 + i;
+				const unsigned slen = x[2] | (x[3] << 8);
+				if (x[0] == 'B' && x[1] == 'C' && slen == 2 && i + 6 <= xlen)
+					bsize = x[4] | (x[5] << 8);
+				i += 4 + slen;
+			}
+			if (bsize < 0 || bsize + 1 < (int) (12 + xlen + 8)) {
+				*err = "BGZF block without BC field";
+				return false;
+			}
+			if (at + (size_t) bsize + 1 > bytes->size())
+				break; // the piece ends inside this block (only behind c_end)
+			const size_t cdata = (size_t) bsize + 1 - 12 - xlen - 8;
+			conga_bgzf_block b;
+			memset(&b, 0, sizeof b);
+			b.data_off = at + 12 + xlen;
+			b.data_len = (uint32_t) cdata;
+			memcpy(&b.crc32, h + 12 + xlen + cdata, 4);
+			memcpy(&b.inflated_len, h + 12 + xlen + cdata + 4, 4);
+			if (b.inflated_len) {
+				blocks->push_back(b);
+				file_off.push_back(c_lo + at);
+				inflated_off.push_back(total);
+				total += b.inflated_len;
+			}
+			const uint64_t this_off = c_lo + at;
+			at += (size_t) bsize + 1;
+			if (c_end && this_off >= c_end)
+				break; // the block in which the next target begins is in: enough
+		}
+		if (blocks->empty())
+			return false;
+		auto absolute = [&](uint64_t v, uint64_t *out) {
+			const uint64_t c = v >> 16, u = v & 0xFFFF;
+			const size_t k = (size_t) (std::lower_bound(file_off.begin(), file_off.end(), c) - file_off.begin());
+			if (k < file_off.size() && file_off[k] == c && u <= (*blocks)[k].inflated_len) {
+				*out = inflated_off[k] + u;
+				return true;
+			}
+			if (u == 0 && k <= file_off.size()) { // an empty block (not kept): the next one's start
+				*out = k < file_off.size() ? inflated_off[k] : total;
+				return true;
+			}
+			return false;
+		};
+		// start points
+		std::vector<uint64_t> lin = linear_[(size_t) tid];
+		const size_t n_win = std::min(lin.size(), (size_t) ((chrom_len + 16383) >> 14));
+		lin.resize(n_win);
+		for (size_t w = 1; w < n_win; w++)
+			if (lin[w] == 0 || lin[w] < lin[w - 1])
+				lin[w] = lin[w - 1];
+		segments->clear();
+		conga_bam_segment first;
+		first.pos_lo = 0;
+		first.pos_hi = (int32_t) chrom_len;
+		if (!absolute(ref_beg_[(size_t) tid], &first.start))
+			return false;
+		segments->push_back(first);
+		uint64_t prev_v = ref_beg_[(size_t) tid];
+		for (size_t w = 1; w < n_win; w++) {
+			if (lin[w] == 0 || lin[w] == prev_v || lin[w] < prev_v)
+				continue;
+			conga_bam_segment sg;
+			if (!absolute(lin[w], &sg.start))
+				return false;
+			sg.pos_lo = (int32_t) (w << 14);
+			sg.pos_hi = (int32_t) chrom_len;
+			if ((int64_t) sg.pos_lo >= chrom_len)
+				break;
+			segments->back().pos_hi = sg.pos_lo;
+			segments->push_back(sg);
+			prev_v = lin[w];
+		}
+		return true;
+	}
+
 	bool next_full(full_batch *fb, std::string *err) override
 	{
 		fb->n_reads = fb->n_bytes = 0;
@@ -695,12 +830,12 @@ private:
 			return false;
 		char magic[4];
 		int32_t n_ref;
-		std::vector<uint64_t> beg;
+		std::vector<uint64_t> beg, fin; // per reference: smallest chunk begin, largest chunk end
 		std::vector<std::vector<uint64_t>> lin; // per reference: smallest virtual offset of a record overlapping each 16 kb window
 		bool ok = fread(magic, 1, 4, f) == 4 && memcmp(magic, "BAI\1", 4) == 0 && fread(&n_ref, 4, 1, f) == 1 && n_ref >= 0;
 		for (int r = 0; ok && r < n_ref; r++) {
 			int32_t n_bin;
-			uint64_t first = 0;
+			uint64_t first = 0, last = 0;
 			ok = fread(&n_bin, 4, 1, f) == 1 && n_bin >= 0;
 			for (int b = 0; ok && b < n_bin; b++) {
 				uint32_t bin;
@@ -711,6 +846,8 @@ private:
 					ok = fread(ce, 8, 2, f) == 2;
 					if (ok && bin != 37450 && (first == 0 || ce[0] < first))
 						first = ce[0];
+					if (ok && bin != 37450 && ce[1] > last)
+						last = ce[1];
 				}
 			}
 			int32_t n_intv;
@@ -718,11 +855,13 @@ private:
 			std::vector<uint64_t> iv((size_t) (ok ? n_intv : 0));
 			ok = ok && (iv.empty() || fread(iv.data(), 8, iv.size(), f) == iv.size());
 			beg.push_back(first);
+			fin.push_back(last);
 			lin.push_back(std::move(iv));
 		}
 		fclose(f);
 		if (ok && (int) beg.size() == n_targets()) {
 			ref_beg_ = beg;
+			ref_end_ = fin;
 			linear_ = lin;
 			bai_path_ = path;
 		}
@@ -732,7 +871,7 @@ private:
 	std::string path_, sample_, bai_path_;
 	bgzf_reader bgzf_;
 	std::vector<std::string> names_;
-	std::vector<uint64_t> ref_beg_;
+	std::vector<uint64_t> ref_beg_, ref_end_;
 	std::vector<std::vector<uint64_t>> linear_;
 	std::vector<int32_t> pos_;
 	std::vector<uint8_t> mapq_;

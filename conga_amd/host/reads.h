@@ -6,6 +6,8 @@
 #include <string>
 #include <vector>
 
+#include "../../include/conga_hip.h"
+
 namespace conga_host {
 
 struct read_batch {
@@ -43,6 +45,14 @@ public:
 	// available for this source / target -- iterate instead; false with a message: the file or its index is broken.
 	virtual bool read_all(int tid, int64_t chrom_len, int threads, std::vector<int32_t> *pos, std::vector<uint8_t> *mapq,
 			std::string *err)
+	{
+		return false;
+	}
+	// What conga_reads_bgzf (include/conga_hip.h) needs to decode the same records on the GPU: the BGZF blocks that hold
+	// target tid, as they are in the file, and start points from the index's linear offsets.  false with an empty *err: not
+	// available (no index, not a BAM, too large for one piece) -- decode on the host.
+	virtual bool device_plan(int tid, int64_t chrom_len, std::vector<uint8_t> *bytes, std::vector<conga_bgzf_block> *blocks,
+			std::vector<conga_bam_segment> *segments, std::string *err)
 	{
 		return false;
 	}

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define CONGA_ABI_VERSION 2
+#define CONGA_ABI_VERSION 3
 
 typedef struct conga_ctx conga_ctx;
 
@@ -52,7 +52,9 @@ typedef enum conga_status {
 	CONGA_ERR_HIP = -3,         /* a HIP runtime call failed; see conga_last_error() */
 	CONGA_ERR_NOMEM = -4,       /* host or device allocation failed */
 	CONGA_ERR_UNSORTED = -5,    /* committed reads are not sorted by position (and CONGA_FLAG_READS_UNSORTED not set) */
-	CONGA_ERR_RANGE = -6        /* an interval or mappability row lies outside what the engine can address */
+	CONGA_ERR_RANGE = -6,       /* an interval or mappability row lies outside what the engine can address */
+	CONGA_ERR_DATA = -7         /* conga_reads_bgzf: a block does not inflate to its size / CRC32, or the start points do not
+	                               line up with the records; nothing was appended -- decode on the host instead */
 } conga_status;
 
 /* conga_opts.flags */
@@ -195,6 +197,33 @@ int conga_mappability(conga_ctx *ctx, const int32_t *start, const int32_t *end, 
  * (end - start >= min_sv_size) and sorted by (start, end) (likelihood.c:324-328), type
  * CONGA_DELETION or CONGA_DUPLICATION.  Copies the arrays; once per type per chromosome. */
 int conga_intervals(conga_ctx *ctx, char type, const int32_t *start, const int32_t *end, size_t n);
+
+/* ---- count_reads_bam with the BAM decode on the device -------------------------------------------------------
+ * Instead of decoded tuples the caller hands over the BGZF blocks that hold one target's records exactly as they are
+ * in the file, the table of those blocks, and start points taken from the .bai's linear index (16 kb windows).  The
+ * engine inflates the blocks (one GPU lane per block, the decoder of conga_amd/host/inflate_core.h, CRC32 checked) and
+ * walks the records (one lane per start point), and appends (pos, mapq) of the records with refID == ref_id and
+ * 0 <= pos < chrom_len to the chromosome begun last -- the records `sam_itr_queryi(idx, tid, 0, L)` + `sam_itr_next`
+ * hand to count_reads_bam (bam_data.c:192-221, 293) -- in file order, without the tuples ever being on the host.
+ *   blocks[i]   : one BGZF block with a non-empty payload, in file order
+ *   segments[k] : `start` = offset, in the concatenation of the inflated blocks, of a record boundary at or in front
+ *                 of the first record whose position is >= pos_lo; the segment owns the records with
+ *                 pos_lo <= pos < pos_hi.  Segments are in order and tile [0, chrom_len).
+ * The engine verifies that every segment stops exactly where the next one found its first record; if not, or if a
+ * block fails its checks, it returns CONGA_ERR_DATA and has appended nothing.  Not for --rp (no sequences kept). */
+typedef struct conga_bgzf_block {
+	uint64_t data_off;     /* of the raw deflate data inside `bytes` */
+	uint32_t data_len;
+	uint32_t inflated_len; /* ISIZE */
+	uint32_t crc32;        /* of the inflated bytes */
+	uint32_t reserved;
+} conga_bgzf_block;
+typedef struct conga_bam_segment {
+	uint64_t start;
+	int32_t pos_lo, pos_hi;
+} conga_bam_segment;
+int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const conga_bgzf_block *blocks, size_t n_blocks,
+		const conga_bam_segment *segments, size_t n_segments, int32_t ref_id, uint64_t *n_appended);
 
 /* ---- split-read evidence: find_split_reads / read_SplitReads / count_ReadPairs on the device --------------
  * Used when the reference would run its split-read path (`--rp` given AND `--dups` given: svdepth.c:57,

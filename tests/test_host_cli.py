@@ -276,6 +276,71 @@ def test_cli_gpus_shards_chromosomes_and_keeps_every_byte(tmp_path, inp, n):
 
 
 @pytest.mark.gpu
+def test_cli_bam_decoded_on_the_gpu_matches_the_host_decoders(tmp_path, oracle):
+    """A BAM with its .bai: the compressed blocks are inflated and the records walked on the GPU (conga_reads_bgzf).  Same
+    files as with the host decoders, byte for byte, and as the oracle's; an index whose linear offsets skip records is
+    noticed and the host takes over."""
+    d = str(tmp_path)
+    rng = np.random.default_rng(9)
+    cs = [synth.make_chrom(n, L, cov=3.0, n_dels=nd, n_dups=nu, gaps=True) for n, L, nd, nu in
+          (("1", 900_000, 40, 8), ("2", 300_000, 15, 3), ("3", 1_300_000, 50, 10))]
+    # pile-ups on a window boundary of the index and a stretch without reads
+    extra = np.sort(np.concatenate([np.full(400, 16384 * 9), np.full(300, 16384 * 9 - 1)])).astype(np.int32)
+    reads = []
+    for c in cs:
+        pos = np.sort(np.concatenate([c.pos, extra])).astype(np.int32)
+        pos = pos[(pos < 200_000) | (pos > 262_144 + 5)]
+        reads.append((c.name, c.length, pos, rng.integers(0, 61, len(pos)).astype(np.uint8)))
+    formats.write_bam(os.path.join(d, "r.bam"), "S", reads, index=True, block_payload=9000, unplaced=6)
+    formats.write_annotation(os.path.join(d, "a.cga"), [(c.name, c.length, c.gc, [], []) for c in cs])
+    synth.write_bed(os.path.join(d, "dels.bed"), [(c.name, s, e) for c in cs for s, e in zip(c.del_start, c.del_end)])
+    synth.write_bed(os.path.join(d, "dups.bed"), [(c.name, s, e) for c in cs for s, e in zip(c.dup_start, c.dup_end)])
+    base = ["-i", "r.bam", "--ref", "r.fa", "--sonic", "a.cga", "--dels", "dels.bed", "--dups", "dups.bed", "--min-mapq", "10"]
+
+    def cli(out, **env):
+        r = subprocess.run([CONGA] + base + ["--out", out], cwd=d, capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-2000:]
+        return r, [open(os.path.join(d, "%s_%s.bed" % (out, k)), "rb").read() for k in ("svs", "dels", "dups")]
+    r_gpu, gpu = cli("gpu")
+    assert "decoding on the host" not in r_gpu.stderr
+    r_host, host = cli("host", CONGA_GPU_BAM="0")
+    assert gpu == host and gpu[1].count(b"\n") > 50
+    for rr in (r_gpu, r_host):
+        assert [ln for ln in rr.stderr.splitlines() if "reads," in ln] == ["-->counting reads (%d reads, 0 split-reads)" % len(x[2]) for x in reads]
+    # the oracle on the same records
+    want = [os.path.join(d, "want_%s.bed" % k) for k in ("svs", "dels", "dups")]
+    first = True
+    for c, (_, _, pos, mapq) in zip(cs, reads):
+        ds = oracle.sort_svs(oracle.load_known_SVs(os.path.join(d, "dels.bed"), c.name, 1000))
+        us = oracle.sort_svs(oracle.load_known_SVs(os.path.join(d, "dups.bed"), c.name, 1000))
+        rd, _ = oracle.count_reads(c.length, pos, mapq, 10)
+        E, _, _ = oracle.calc_mean_per_chr(rd, c.gc)
+        oracle.find_depths(rd, None, c.gc, E, "D", ds)
+        oracle.find_depths(rd, None, c.gc, E, "E", us)
+        oracle.output_svs(c.name, ds, us, want[0], want[1], want[2], have_mappability=False, c_score=0.5, write_headers=first)
+        first = False
+    assert gpu == [open(w, "rb").read() for w in want]
+    # linear offsets that point behind records: refused by the GPU stage and by the parallel host reader, still right
+    import struct
+    bai = bytearray(open(os.path.join(d, "r.bam.bai"), "rb").read())
+    at = 8
+    (n_bin,) = struct.unpack_from("<i", bai, at)
+    at += 4
+    for _ in range(n_bin):
+        (_, n_chunk) = struct.unpack_from("<Ii", bai, at)
+        at += 8 + 16 * n_chunk
+    (n_intv,) = struct.unpack_from("<i", bai, at)
+    at += 4
+    lin = list(struct.unpack_from("<%dQ" % n_intv, bai, at))
+    for w in range(n_intv // 2, n_intv):
+        lin[w] = lin[min(n_intv - 1, w + 7)]
+    struct.pack_into("<%dQ" % n_intv, bai, at, *lin)
+    open(os.path.join(d, "r.bam.bai"), "wb").write(bytes(bai))
+    r_bad, bad = cli("bad", CONGA_BAM_SEGMENTS="6")
+    assert "decoding on the host" in r_bad.stderr and bad == gpu
+
+
+@pytest.mark.gpu
 def test_cli_split_reads_rp(tmp_path, oracle):
     """--rp with --dups: FASTA + BAM sequences -> READ_PAIR columns and the `rp > rp_support` rule of _svs.bed
     (likelihood.c:243-279), byte-identical to the oracle."""

@@ -1,0 +1,134 @@
+// gpu_inflate.hip -- PROTOTYPE, not part of the product: how fast does an MI355X inflate a BAM if every lane simply
+// runs the host's block decoder (conga_amd/host/inflate_core.h, the same source) on its own BGZF block?
+// No wave cooperation, tables in global scratch, byte stores: the floor of what a GPU-side BGZF stage would do
+// (DESIGN.md section 10).  Every inflated block is checked against its CRC32 on the host.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o gpu_inflate tools/gpu_inflate.hip -lz && ./gpu_inflate file.bam
+#include <hip/hip_runtime.h>
+#include <zlib.h>
+
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../conga_amd/host/inflate_core.h"
+
+using conga_host::inflate_core::Decoder;
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+__global__ __launch_bounds__(64) void inflate_kernel(int n_blocks, const uint8_t *in, const uint64_t *c_off, const uint32_t *c_len,
+		uint8_t *out, const uint64_t *o_off, const uint32_t *o_len, Decoder *scratch, uint8_t *ok)
+{
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= n_blocks)
+		return;
+	ok[t] = conga_host::inflate_core::inflate_block_stream(scratch[t], in + c_off[t], c_len[t], out + o_off[t], o_len[t]) ? 1 : 0;
+}
+
+int main(int argc, char **argv)
+{
+	if (argc < 2) {
+		fprintf(stderr, "usage: gpu_inflate file.bam [max_blocks]\n");
+		return 2;
+	}
+	FILE *f = fopen(argv[1], "rb");
+	if (!f) {
+		perror(argv[1]);
+		return 1;
+	}
+	fseek(f, 0, SEEK_END);
+	const size_t size = (size_t) ftell(f);
+	fseek(f, 0, SEEK_SET);
+	std::vector<uint8_t> file(size);
+	if (fread(file.data(), 1, size, f) != size)
+		return 1;
+	fclose(f);
+	const size_t max_blocks = argc > 2 ? (size_t) atol(argv[2]) : (size_t) 1 << 30;
+	std::vector<uint64_t> c_off, o_off;
+	std::vector<uint32_t> c_len, o_len, crc;
+	uint64_t out_total = 0;
+	for (size_t at = 0; at + 18 <= size && c_off.size() < max_blocks;) { // gzip member: 10 + XLEN(2) + extra + cdata + CRC32 + ISIZE
+		const unsigned xlen = file[at + 10] | (file[at + 11] << 8);
+		int bsize = -1;
+		for (unsigned i = 0; i + 4 <= xlen;) {
+			const uint8_t *x = &file[at + 12 + i];
+			const unsigned slen = x[2] | (x[3] << 8);
+			if (x[0] == 'B' && x[1] == 'C' && slen == 2)
+				bsize = x[4] | (x[5] << 8);
+			i += 4 + slen;
+		}
+		if (bsize < 0)
+			break;
+		const size_t cdata = (size_t) bsize + 1 - 12 - xlen - 8;
+		uint32_t isize, c;
+		memcpy(&c, &file[at + 12 + xlen + cdata], 4);
+		memcpy(&isize, &file[at + 12 + xlen + cdata + 4], 4);
+		if (isize) {
+			c_off.push_back(at + 12 + xlen);
+			c_len.push_back((uint32_t) cdata);
+			o_off.push_back(out_total);
+			o_len.push_back(isize);
+			crc.push_back(c);
+			out_total += isize;
+		}
+		at += (size_t) bsize + 1;
+	}
+	const int n = (int) c_off.size();
+	printf("%s: %d blocks, %.1f MB compressed, %.1f MB inflated\n", argv[1], n, size / 1e6, out_total / 1e6);
+
+	uint8_t *d_in, *d_out, *d_ok;
+	uint64_t *d_c_off, *d_o_off;
+	uint32_t *d_c_len, *d_o_len;
+	Decoder *d_scratch;
+	CHECK(hipMalloc(&d_in, size));
+	CHECK(hipMalloc(&d_out, out_total + 16));
+	CHECK(hipMalloc(&d_ok, (size_t) n));
+	CHECK(hipMalloc(&d_c_off, (size_t) n * 8));
+	CHECK(hipMalloc(&d_o_off, (size_t) n * 8));
+	CHECK(hipMalloc(&d_c_len, (size_t) n * 4));
+	CHECK(hipMalloc(&d_o_len, (size_t) n * 4));
+	CHECK(hipMalloc(&d_scratch, (size_t) n * sizeof(Decoder)));
+	CHECK(hipMemset(d_scratch, 0, (size_t) n * sizeof(Decoder)));
+	printf("decoder scratch: %.1f KB per lane, %.2f GB\n", sizeof(Decoder) / 1e3, (double) n * sizeof(Decoder) / 1e9);
+	auto t0 = std::chrono::steady_clock::now();
+	CHECK(hipMemcpy(d_in, file.data(), size, hipMemcpyHostToDevice));
+	auto t1 = std::chrono::steady_clock::now();
+	CHECK(hipMemcpy(d_c_off, c_off.data(), (size_t) n * 8, hipMemcpyHostToDevice));
+	CHECK(hipMemcpy(d_o_off, o_off.data(), (size_t) n * 8, hipMemcpyHostToDevice));
+	CHECK(hipMemcpy(d_c_len, c_len.data(), (size_t) n * 4, hipMemcpyHostToDevice));
+	CHECK(hipMemcpy(d_o_len, o_len.data(), (size_t) n * 4, hipMemcpyHostToDevice));
+	hipEvent_t e0, e1;
+	CHECK(hipEventCreate(&e0));
+	CHECK(hipEventCreate(&e1));
+	float best = 1e30f;
+	for (int rep = 0; rep < 3; rep++) {
+		CHECK(hipEventRecord(e0));
+		hipLaunchKernelGGL(inflate_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, n, d_in, d_c_off, d_c_len, d_out, d_o_off, d_o_len, d_scratch, d_ok);
+		CHECK(hipEventRecord(e1));
+		CHECK(hipEventSynchronize(e1));
+		float ms;
+		CHECK(hipEventElapsedTime(&ms, e0, e1));
+		printf("  inflate kernel: %.2f ms = %.1f GB/s compressed in, %.1f GB/s inflated out\n", ms, size / ms / 1e6, out_total / ms / 1e6);
+		best = ms < best ? ms : best;
+	}
+	std::vector<uint8_t> out(out_total), ok((size_t) n);
+	CHECK(hipMemcpy(out.data(), d_out, out_total, hipMemcpyDeviceToHost));
+	CHECK(hipMemcpy(ok.data(), d_ok, (size_t) n, hipMemcpyDeviceToHost));
+	long refused = 0, wrong = 0;
+	auto t2 = std::chrono::steady_clock::now();
+	for (int b = 0; b < n; b++) {
+		if (!ok[(size_t) b])
+			refused++;
+		else if ((uint32_t) crc32(crc32(0L, Z_NULL, 0), out.data() + o_off[(size_t) b], o_len[(size_t) b]) != crc[(size_t) b])
+			wrong++;
+	}
+	auto t3 = std::chrono::steady_clock::now();
+	printf("checked against the blocks' CRC32: %ld refused, %ld wrong of %d\n", refused, wrong, n);
+	printf("H2D of the compressed file: %.1f ms (pageable); CRC32 of %.1f MB on one host thread: %.0f ms\n",
+			std::chrono::duration<double, std::milli>(t1 - t0).count(), out_total / 1e6, std::chrono::duration<double, std::milli>(t3 - t2).count());
+	printf("RESULT best %.2f ms, %.1f GB/s inflated\n", best, out_total / best / 1e6);
+	return (refused || wrong) ? 1 : 0;
+}
