@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1097,6 +1098,11 @@ int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const
 	}
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	hipStream_t st = ctx->stream;
+	const bool timing = getenv("CONGA_TIMING") != nullptr;
+	const auto t_begin = std::chrono::steady_clock::now();
+	auto ms_since = [](std::chrono::steady_clock::time_point t) {
+		return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+	};
 	const uint32_t lanes = (uint32_t) std::min<size_t>((n_blocks + 63) & ~(size_t) 63, 32768);
 	TRY(ensure(ctx, ctx->d_bz_in, n_bytes));
 	TRY(ensure(ctx, ctx->d_bz_blocks, n_blocks * sizeof(conga_bgzf_block)));
@@ -1125,6 +1131,12 @@ int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bz_blocks.p, blocks, n_blocks * sizeof(conga_bgzf_block), hipMemcpyHostToDevice, st));
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bz_off.p, out_off.data(), n_blocks * 8, hipMemcpyHostToDevice, st));
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bz_seg.p, segments, n_segments * sizeof(conga_bam_segment), hipMemcpyHostToDevice, st));
+	double ms_alloc_upload = 0;
+	if (timing) {
+		HIP_TRY(ctx, hipStreamSynchronize(st));
+		ms_alloc_upload = ms_since(t_begin);
+	}
+	const auto t_inflate = std::chrono::steady_clock::now();
 	hipLaunchKernelGGL(bgzf_inflate_kernel, dim3(lanes / 64), dim3(64), 0, st, (uint32_t) n_blocks, ptr<uint8_t>(ctx->d_bz_in),
 			ptr<conga_bgzf_block>(ctx->d_bz_blocks), ptr<uint64_t>(ctx->d_bz_off), ptr<uint8_t>(ctx->d_bz_out),
 			ptr<InflateScratch>(ctx->d_bz_scratch), ptr<uint32_t>(ctx->d_bz_crc), ptr<uint8_t>(ctx->d_bz_status));
@@ -1142,6 +1154,12 @@ int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const
 	w.pos = nullptr;
 	w.mapq = nullptr;
 	const int wgrid = (int) ((n_segments + 63) / 64);
+	double ms_inflate = 0;
+	if (timing) {
+		HIP_TRY(ctx, hipStreamSynchronize(st));
+		ms_inflate = ms_since(t_inflate);
+	}
+	const auto t_walk = std::chrono::steady_clock::now();
 	hipLaunchKernelGGL(bam_walk_kernel<false>, dim3(wgrid), dim3(64), 0, st, w);
 	std::vector<uint8_t> status(n_blocks), bad(n_segments);
 	std::vector<uint32_t> count(n_segments);
@@ -1193,6 +1211,10 @@ int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const
 		if (flag)
 			ctx->wrap_risk = true;
 	}
+	if (timing)
+		fprintf(stderr, "\n[timing] conga_reads_bgzf: %zu blocks, %.1f MB -> %.1f MB, %zu start points, %llu reads: buffers + upload %.1f ms, "
+				"inflate %.1f ms, walks + checks %.1f ms\n", n_blocks, n_bytes / 1e6, total / 1e6, n_segments, (unsigned long long) n_new,
+				ms_alloc_upload, ms_inflate, ms_since(t_walk));
 	h.device_fed = true;
 	h.n_reads += (int64_t) n_new;
 	ctx->n_reads_total += (int64_t) n_new;

@@ -548,8 +548,8 @@ public:
 	// The target's stretch of the file for conga_reads_bgzf: from the block of its first record through the block in
 	// which the next target with records begins (so that the walk sees a record that ends this target; to the end of the
 	// file for the last one), the table of those blocks, and one start point per distinct linear-index offset.
-	bool device_plan(int tid, int64_t chrom_len, std::vector<uint8_t> *bytes, std::vector<conga_bgzf_block> *blocks,
-			std::vector<conga_bam_segment> *segments, std::string *err) override
+	bool device_plan(int tid, int64_t chrom_len, uint64_t min_piece_bytes, std::vector<uint8_t> *bytes,
+			std::vector<conga_bgzf_block> *blocks, std::vector<conga_bam_segment> *segments, std::string *err) override
 	{
 		if (tid < 0 || tid >= (int) linear_.size() || ref_beg_[(size_t) tid] == 0)
 			return false;
@@ -571,6 +571,10 @@ public:
 		uint64_t stop = (uint64_t) st.st_size;
 		if (c_end && c_end + 65536 + 18 < stop)
 			stop = c_end + 65536 + 18; // enough for the whole block that starts at c_end
+		if (stop - c_lo < min_piece_bytes) { // (nothing has been read yet)
+			fclose(f);
+			return false;
+		}
 		const uint64_t kMaxPiece = 6ull << 30;
 		if (const char *e = getenv("CONGA_GPU_BAM_MAX_MB")) {
 			if (stop - c_lo > (uint64_t) atoll(e) << 20) {

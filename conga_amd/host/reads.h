@@ -50,9 +50,9 @@ public:
 	}
 	// What conga_reads_bgzf (include/conga_hip.h) needs to decode the same records on the GPU: the BGZF blocks that hold
 	// target tid, as they are in the file, and start points from the index's linear offsets.  false with an empty *err: not
-	// available (no index, not a BAM, too large for one piece) -- decode on the host.
-	virtual bool device_plan(int tid, int64_t chrom_len, std::vector<uint8_t> *bytes, std::vector<conga_bgzf_block> *blocks,
-			std::vector<conga_bam_segment> *segments, std::string *err)
+	// available (no index, not a BAM, a piece of the file smaller than min_piece_bytes or too large) -- decode on the host.
+	virtual bool device_plan(int tid, int64_t chrom_len, uint64_t min_piece_bytes, std::vector<uint8_t> *bytes,
+			std::vector<conga_bgzf_block> *blocks, std::vector<conga_bam_segment> *segments, std::string *err)
 	{
 		return false;
 	}

@@ -301,12 +301,13 @@ def test_cli_bam_decoded_on_the_gpu_matches_the_host_decoders(tmp_path, oracle):
         r = subprocess.run([CONGA] + base + ["--out", out], cwd=d, capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr[-2000:]
         return r, [open(os.path.join(d, "%s_%s.bed" % (out, k)), "rb").read() for k in ("svs", "dels", "dups")]
-    r_gpu, gpu = cli("gpu")
-    assert "decoding on the host" not in r_gpu.stderr
+    r_gpu, gpu = cli("gpu", CONGA_GPU_BAM="1", CONGA_TIMING="1")  # (by default only pieces of >= 32 768 blocks go this way)
+    assert "decoding on the host" not in r_gpu.stderr and r_gpu.stderr.count("conga_reads_bgzf:") == 3
     r_host, host = cli("host", CONGA_GPU_BAM="0")
     assert gpu == host and gpu[1].count(b"\n") > 50
     for rr in (r_gpu, r_host):
-        assert [ln for ln in rr.stderr.splitlines() if "reads," in ln] == ["-->counting reads (%d reads, 0 split-reads)" % len(x[2]) for x in reads]
+        import re
+        assert [int(m) for m in re.findall(r"\((\d+) reads, 0 split-reads\)", rr.stderr)] == [len(x[2]) for x in reads]
     # the oracle on the same records
     want = [os.path.join(d, "want_%s.bed" % k) for k in ("svs", "dels", "dups")]
     first = True
@@ -336,7 +337,7 @@ def test_cli_bam_decoded_on_the_gpu_matches_the_host_decoders(tmp_path, oracle):
         lin[w] = lin[min(n_intv - 1, w + 7)]
     struct.pack_into("<%dQ" % n_intv, bai, at, *lin)
     open(os.path.join(d, "r.bam.bai"), "wb").write(bytes(bai))
-    r_bad, bad = cli("bad", CONGA_BAM_SEGMENTS="6")
+    r_bad, bad = cli("bad", CONGA_BAM_SEGMENTS="6", CONGA_GPU_BAM="1")
     assert "decoding on the host" in r_bad.stderr and bad == gpu
 
 
