@@ -40,6 +40,10 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(uint32_t n_blocks, con
 		const conga_bgzf_block *__restrict__ blocks, const uint64_t *__restrict__ out_off, uint8_t *__restrict__ out,
 		InflateScratch *scratch, const uint32_t *__restrict__ crc_table, uint8_t *__restrict__ status)
 {
+	__shared__ uint32_t s_crc[256]; // (the byte-wise CRC looks one entry up per byte)
+	for (int i = threadIdx.x; i < 256; i += blockDim.x)
+		s_crc[i] = crc_table[i];
+	__syncthreads();
 	const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x, lanes = gridDim.x * blockDim.x;
 	for (uint32_t b = lane; b < n_blocks; b += lanes) {
 		const conga_bgzf_block bl = blocks[b];
@@ -47,7 +51,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(uint32_t n_blocks, con
 		uint8_t st = kBgzfOk;
 		if (!conga_host::inflate_core::inflate_block_stream(scratch[lane], bytes + bl.data_off, bl.data_len, dst, bl.inflated_len))
 			st = kBgzfRefused;
-		else if (crc32_bytes(crc_table, dst, bl.inflated_len) != bl.crc32)
+		else if (crc32_bytes(s_crc, dst, bl.inflated_len) != bl.crc32)
 			st = kBgzfCrc;
 		status[b] = st;
 	}

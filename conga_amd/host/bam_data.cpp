@@ -97,13 +97,13 @@ int64_t count_reads_bam(conga_ctx *ctx, read_source *src, int chr_index_bam, int
 		// (conga_reads_bgzf); anything that does not check out falls through to the host decoders below.  One lane per
 		// block takes ~0.1 s for a block however many there are, so it only pays with tens of thousands of blocks in a call
 		// (a chromosome of a deep sample: the default asks for 1.3 GB of file; measured: 45 000 blocks in 0.17 s = 17 GB/s inflated, against ~5 GB/s for 16 cores).
-		std::vector<uint8_t> bytes;
+		file_piece bytes;
 		std::vector<conga_bgzf_block> blocks;
 		std::vector<conga_bam_segment> segments;
 		const uint64_t min_piece = gpu_bam != nullptr ? 0 : (uint64_t) 32768 * 40000; // ~32 768 blocks of a typical BAM (1.3 GB)
 		if (src->device_plan(chr_index_bam, chrom_len, min_piece, &bytes, &blocks, &segments, &err)) {
 			uint64_t n_new = 0;
-			const int rc = conga_reads_bgzf(ctx, bytes.data(), bytes.size(), blocks.data(), blocks.size(), segments.data(), segments.size(),
+			const int rc = conga_reads_bgzf(ctx, bytes.data, bytes.size, blocks.data(), blocks.size(), segments.data(), segments.size(),
 					chr_index_bam, &n_new);
 			if (rc == CONGA_OK)
 				return (int64_t) n_new;

@@ -548,7 +548,7 @@ public:
 	// The target's stretch of the file for conga_reads_bgzf: from the block of its first record through the block in
 	// which the next target with records begins (so that the walk sees a record that ends this target; to the end of the
 	// file for the last one), the table of those blocks, and one start point per distinct linear-index offset.
-	bool device_plan(int tid, int64_t chrom_len, uint64_t min_piece_bytes, std::vector<uint8_t> *bytes,
+	bool device_plan(int tid, int64_t chrom_len, uint64_t min_piece_bytes, file_piece *bytes,
 			std::vector<conga_bgzf_block> *blocks, std::vector<conga_bam_segment> *segments, std::string *err) override
 	{
 		if (tid < 0 || tid >= (int) linear_.size() || ref_beg_[(size_t) tid] == 0)
@@ -585,24 +585,22 @@ public:
 			fclose(f);
 			return false;
 		}
-		bytes->resize((size_t) (stop - c_lo));
-		const bool read_ok = fseeko(f, (off_t) c_lo, SEEK_SET) == 0 && fread(bytes->data(), 1, bytes->size(), f) == bytes->size();
 		fclose(f);
-		if (!read_ok)
+		if (!bytes->open(path_, c_lo, stop))
 			return false;
 		// block table
 		blocks->clear();
 		std::vector<uint64_t> file_off, inflated_off; // per kept block
 		uint64_t total = 0;
 		size_t at = 0;
-		while (at + 18 <= bytes->size()) {
-			const uint8_t *h = bytes->data() + at;
+		while (at + 18 <= bytes->size) {
+			const uint8_t *h = bytes->data + at;
 			if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) {
 				*err = "not a BGZF block";
 				return false;
 			}
 			const unsigned xlen = h[10] | (h[11] << 8);
-			if (at + 12 + xlen > bytes->size())
+			if (at + 12 + xlen > bytes->size)
 				break;
 			int bsize = -1;
 			for (unsigned i = 0; i + 4 <= xlen;) {
@@ -616,7 +614,7 @@ public:
 				*err = "BGZF block without BC field";
 				return false;
 			}
-			if (at + (size_t) bsize + 1 > bytes->size())
+			if (at + (size_t) bsize + 1 > bytes->size)
 				break; // the piece ends inside this block (only behind c_end)
 			const size_t cdata = (size_t) bsize + 1 - 12 - xlen - 8;
 			conga_bgzf_block b;

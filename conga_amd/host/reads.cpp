@@ -170,6 +170,31 @@ private:
 
 } // namespace
 
+file_piece::~file_piece()
+{
+	if (map && map != MAP_FAILED)
+		munmap(map, map_len);
+}
+
+bool file_piece::open(const std::string &path, uint64_t from, uint64_t to)
+{
+	const int fd = ::open(path.c_str(), O_RDONLY);
+	if (fd < 0)
+		return false;
+	const uint64_t page = (uint64_t) sysconf(_SC_PAGESIZE), base = from & ~(page - 1);
+	map_len = (size_t) (to - base);
+	map = mmap(nullptr, map_len, PROT_READ, MAP_PRIVATE, fd, (off_t) base);
+	close(fd);
+	if (map == MAP_FAILED) {
+		map = nullptr;
+		return false;
+	}
+	(void) madvise(map, map_len, MADV_SEQUENTIAL);
+	data = (const uint8_t *) map + (from - base);
+	size = (size_t) (to - from);
+	return true;
+}
+
 namespace {
 std::atomic<int> g_reader_share{1};
 }

@@ -28,6 +28,19 @@ struct full_batch {
 	size_t n_reads, n_bytes; // filled by next_full
 };
 
+// A stretch of a file, memory-mapped (the page cache is the only copy on the host; the GPU upload reads from it).
+struct file_piece {
+	const uint8_t *data = nullptr;
+	size_t size = 0;
+	void *map = nullptr;
+	size_t map_len = 0;
+	file_piece() {}
+	file_piece(const file_piece &) = delete;
+	file_piece &operator=(const file_piece &) = delete;
+	~file_piece();
+	bool open(const std::string &path, uint64_t from, uint64_t to);
+};
+
 class read_source {
 public:
 	virtual ~read_source() {}
@@ -51,7 +64,7 @@ public:
 	// What conga_reads_bgzf (include/conga_hip.h) needs to decode the same records on the GPU: the BGZF blocks that hold
 	// target tid, as they are in the file, and start points from the index's linear offsets.  false with an empty *err: not
 	// available (no index, not a BAM, a piece of the file smaller than min_piece_bytes or too large) -- decode on the host.
-	virtual bool device_plan(int tid, int64_t chrom_len, uint64_t min_piece_bytes, std::vector<uint8_t> *bytes,
+	virtual bool device_plan(int tid, int64_t chrom_len, uint64_t min_piece_bytes, file_piece *bytes,
 			std::vector<conga_bgzf_block> *blocks, std::vector<conga_bam_segment> *segments, std::string *err)
 	{
 		return false;
