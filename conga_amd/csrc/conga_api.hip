@@ -1069,7 +1069,7 @@ int conga_reads_commit(conga_ctx *ctx, size_t n)
 }
 
 int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const conga_bgzf_block *blocks, size_t n_blocks,
-		const conga_bam_segment *segments, size_t n_segments, int32_t ref_id, uint64_t *n_appended)
+		const conga_bam_segment *segments, size_t n_segments, uint64_t *reads_per_chrom)
 {
 	if (!ctx || !bytes || !blocks || !segments || n_blocks == 0 || n_segments == 0 || n_blocks > (size_t) 1 << 28
 			|| n_segments > (size_t) 1 << 28)
@@ -1078,9 +1078,13 @@ int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const
 		return fail(ctx, CONGA_ERR_INVALID, "conga_reads_bgzf: no chromosome open");
 	if (ctx->staging_cur >= 0)
 		return fail(ctx, CONGA_ERR_INVALID, "conga_reads_bgzf: a staging buffer is handed out and not committed");
-	HostSlot &h = ctx->slots.back();
-	if (h.n_reads != 0)
-		return fail(ctx, CONGA_ERR_INVALID, "conga_reads_bgzf: the chromosome already has reads (one call per chromosome)");
+	const int n_chrom = (int) ctx->slots.size();
+	const int first_chrom = segments[0].chrom;
+	if (first_chrom < 0 || first_chrom >= n_chrom)
+		return fail(ctx, CONGA_ERR_INVALID, "conga_reads_bgzf: no such chromosome");
+	for (int c = first_chrom; c < n_chrom; c++)
+		if (ctx->slots[(size_t) c].n_reads != 0)
+			return fail(ctx, CONGA_ERR_INVALID, "conga_reads_bgzf: a chromosome from the first named one on already has reads");
 	// the inflated stream: the blocks' payloads one behind the other
 	std::vector<uint64_t> out_off(n_blocks);
 	uint64_t total = 0;
@@ -1093,8 +1097,12 @@ int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const
 	}
 	for (size_t k = 0; k < n_segments; k++) {
 		const conga_bam_segment &sg = segments[k];
-		if (sg.start > total || sg.pos_lo > sg.pos_hi || (k && (sg.pos_lo != segments[k - 1].pos_hi || sg.start < segments[k - 1].start)))
-			return fail(ctx, CONGA_ERR_INVALID, "conga_reads_bgzf: segments must be ordered and tile the chromosome");
+		const bool same = k && sg.chrom == segments[k - 1].chrom;
+		if (sg.start > total || sg.pos_lo > sg.pos_hi || sg.chrom < first_chrom || sg.chrom >= n_chrom || sg.ref_id < 0
+				|| (k && sg.chrom < segments[k - 1].chrom)
+				|| (same && (sg.pos_lo != segments[k - 1].pos_hi || sg.start < segments[k - 1].start || sg.ref_id != segments[k - 1].ref_id))
+				|| (!same && sg.pos_lo != 0) || (int64_t) sg.pos_hi > ctx->slots[(size_t) sg.chrom].L)
+			return fail(ctx, CONGA_ERR_INVALID, "conga_reads_bgzf: segments must be grouped by chromosome, ordered, and tile each one");
 	}
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	hipStream_t st = ctx->stream;
@@ -1146,7 +1154,6 @@ int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const
 	w.stream_len = total;
 	w.segments = ptr<conga_bam_segment>(ctx->d_bz_seg);
 	w.n_segments = (uint32_t) n_segments;
-	w.ref_id = ref_id;
 	w.count = ptr<uint32_t>(ctx->d_bz_cnt);
 	w.v_first = ptr<uint64_t>(ctx->d_bz_first);
 	w.v_stop = ptr<uint64_t>(ctx->d_bz_stop);
@@ -1176,14 +1183,16 @@ int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const
 			return fail(ctx, CONGA_ERR_DATA, status[b] == kBgzfCrc ? "conga_reads_bgzf: a block fails its CRC32"
 					: "conga_reads_bgzf: a block does not inflate to its recorded size");
 	std::vector<uint64_t> write_at(n_segments);
+	std::vector<int64_t> per_chrom((size_t) n_chrom, 0);
 	uint64_t n_new = 0;
 	for (size_t k = 0; k < n_segments; k++) {
 		if (bad[k])
 			return fail(ctx, CONGA_ERR_DATA, "conga_reads_bgzf: a start point does not lead along whole BAM records");
-		if (k + 1 < n_segments && v_stop[k] != v_first[k + 1])
+		if (k + 1 < n_segments && segments[k + 1].chrom == segments[k].chrom && v_stop[k] != v_first[k + 1])
 			return fail(ctx, CONGA_ERR_DATA, "conga_reads_bgzf: the start points do not line up with the records");
 		write_at[k] = (uint64_t) ctx->n_reads_total + n_new;
 		n_new += count[k];
+		per_chrom[(size_t) segments[k].chrom] += count[k];
 	}
 	if ((uint64_t) ctx->n_reads_total + n_new >= 0xFFFFFFF0ull)
 		return fail(ctx, CONGA_ERR_RANGE, "conga_reads_bgzf: more than 2^32 reads in one context");
@@ -1216,13 +1225,23 @@ int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const
 		fprintf(stderr, "\n[timing] conga_reads_bgzf: %zu blocks, %.1f MB -> %.1f MB, %zu start points, %llu reads: buffers + upload %.1f ms, "
 				"inflate %.1f ms, walks + checks %.1f ms\n", n_blocks, n_bytes / 1e6, total / 1e6, n_segments, (unsigned long long) n_new,
 				ms_alloc_upload, ms_inflate, ms_since(t_walk));
-	h.device_fed = true;
-	h.n_reads += (int64_t) n_new;
+	// the tuples of a context lie in chromosome order: every chromosome from the first named one on gets its place
+	{
+		int64_t at = ctx->n_reads_total;
+		for (int c = first_chrom; c < n_chrom; c++) {
+			HostSlot &hc = ctx->slots[(size_t) c];
+			hc.read_off = at;
+			hc.n_reads = per_chrom[(size_t) c];
+			hc.device_fed = hc.device_fed || per_chrom[(size_t) c] > 0;
+			at += hc.n_reads;
+		}
+	}
 	ctx->n_reads_total += (int64_t) n_new;
 	ctx->layout_dirty = true;
 	ctx->computed = false;
-	if (n_appended)
-		*n_appended = n_new;
+	if (reads_per_chrom)
+		for (int c = 0; c < n_chrom; c++)
+			reads_per_chrom[c] = (uint64_t) ctx->slots[(size_t) c].n_reads;
 	return CONGA_OK;
 }
 

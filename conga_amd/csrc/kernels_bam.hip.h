@@ -62,7 +62,6 @@ struct BamWalkArgs {
 	uint64_t stream_len;
 	const conga_bam_segment *segments;
 	uint32_t n_segments;
-	int32_t ref_id;
 	// per segment
 	uint32_t *count;        // records it owns (pass 1)
 	uint64_t *v_first;      // where it found its first own record (or where it stopped, if it owns none)
@@ -101,9 +100,9 @@ template <bool WRITE> __global__ __launch_bounds__(64) void bam_walk_kernel(BamW
 		const int32_t ref = load_i32(r + 4), p = load_i32(r + 8);
 		const uint64_t here = at;
 		at += 4 + (uint64_t) block_size;
-		if (ref >= 0 && ref < a.ref_id)
+		if (ref >= 0 && ref < sg.ref_id)
 			continue; // (the tail of the previous target in front of this one's first record)
-		if (ref != a.ref_id || p >= sg.pos_hi) {
+		if (ref != sg.ref_id || p >= sg.pos_hi) {
 			stop = here;
 			if (first == kNone)
 				first = here;

@@ -53,6 +53,9 @@ void engine_check(conga_ctx *ctx, int rc, const char *what)
 	}
 }
 
+// ~32 768 blocks of a typical BAM: below that one lane per block does not pay
+constexpr uint64_t kGpuBamMinPiece = (uint64_t) 32768 * 40000;
+
 // count_reads_bam (bam_data.c:192-221), producer side: records go straight into the pinned staging ring.
 // With split reads enabled (--rp and --dups) every record is also handed over whole (split_read.c:206-354).
 int64_t count_reads_bam(conga_ctx *ctx, read_source *src, int chr_index_bam, int64_t chrom_len, bool split_reads)
@@ -100,13 +103,14 @@ int64_t count_reads_bam(conga_ctx *ctx, read_source *src, int chr_index_bam, int
 		file_piece bytes;
 		std::vector<conga_bgzf_block> blocks;
 		std::vector<conga_bam_segment> segments;
-		const uint64_t min_piece = gpu_bam != nullptr ? 0 : (uint64_t) 32768 * 40000; // ~32 768 blocks of a typical BAM (1.3 GB)
-		if (src->device_plan(chr_index_bam, chrom_len, min_piece, &bytes, &blocks, &segments, &err)) {
-			uint64_t n_new = 0;
+		const uint64_t min_piece = gpu_bam != nullptr ? 0 : kGpuBamMinPiece;
+		const int chrom = conga_chrom_count(ctx) - 1; // the chromosome begun last
+		if (src->device_plan({device_target{chr_index_bam, chrom_len, chrom}}, min_piece, &bytes, &blocks, &segments, &err)) {
+			std::vector<uint64_t> per_chrom((size_t) chrom + 1, 0);
 			const int rc = conga_reads_bgzf(ctx, bytes.data, bytes.size, blocks.data(), blocks.size(), segments.data(), segments.size(),
-					chr_index_bam, &n_new);
+					per_chrom.data());
 			if (rc == CONGA_OK)
-				return (int64_t) n_new;
+				return (int64_t) per_chrom[(size_t) chrom];
 			if (rc != CONGA_ERR_DATA)
 				engine_check(ctx, rc, "conga_reads_bgzf");
 			fprintf(stderr, "\n[CONGA] decoding on the host: %s\n", conga_last_error(ctx));
@@ -189,6 +193,39 @@ struct worker_timing {
 	double ms_create = 0, ms_reads = 0, ms_compute = 0, ms_fetch = 0;
 };
 
+// The known SVs of the chromosome begun last and, when there are any, its mappability rows
+// (likelihood.c:319-336,352-356; load_mappability_regions, svs.c:317-377, runs only for chromosomes that have SVs).
+void attach_intervals(conga_ctx *ctx, const parameters *params, const bed_index &map_bed, const chrom_svs &cs)
+{
+	std::vector<int32_t> s, e;
+	auto hand_over = [&](char type, const std::vector<sv_row> &rows) {
+		s.resize(rows.size());
+		e.resize(rows.size());
+		for (size_t i = 0; i < rows.size(); i++) {
+			s[i] = rows[i].start;
+			e[i] = rows[i].end;
+		}
+		engine_check(ctx, conga_intervals(ctx, type, s.data(), e.data(), rows.size()), "conga_intervals");
+	};
+	hand_over(CONGA_DELETION, cs.dels);
+	hand_over(CONGA_DUPLICATION, cs.dups);
+	if (params->have_map && cs.dels.size() + cs.dups.size() > 0) {
+		auto it = map_bed.rows.find(cs.chr_name);
+		std::vector<int32_t> ms, me;
+		const float *mv = nullptr;
+		if (it != map_bed.rows.end()) {
+			ms.resize(it->second.size());
+			me.resize(it->second.size());
+			for (size_t i = 0; i < it->second.size(); i++) {
+				ms[i] = it->second[i].start;
+				me[i] = it->second[i].end;
+			}
+			mv = map_bed.values.at(cs.chr_name).data();
+		}
+		engine_check(ctx, conga_mappability(ctx, ms.data(), me.data(), mv, ms.size()), "conga_mappability");
+	}
+}
+
 // The work of one context: stage every chromosome of `mine` (annotation order), one batch compute, fetch.
 // One host thread per context, one context per GPU; chromosomes are independent in the
 // reference (bam_data.c:269-339), so no worker ever needs another's data.
@@ -219,7 +256,42 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 	const auto t_loop = now();
 
 	std::string err;
-	for (chrom_job *job : mine) {
+	std::vector<uint64_t> gpu_counts; // reads per chromosome when all of this worker's chromosomes were decoded on the GPU at once
+	const char *gpu_bam = getenv("CONGA_GPU_BAM"); // 0: never, 1: always, unset: when it pays
+	if (!split_reads && !mine.empty() && (gpu_bam == nullptr || atoi(gpu_bam) != 0)) {
+		// All chromosomes of this context in ONE decode on the GPU (conga_reads_bgzf): a low-coverage genome is tens of
+		// thousands of BGZF blocks as a whole, not per chromosome.  The chromosomes are opened (with their intervals and
+		// tracks) first, then the file's stretch goes up as it is.
+		std::vector<device_target> targets;
+		for (size_t i = 0; i < mine.size(); i++)
+			targets.push_back(device_target{mine[i]->chr_index_bam, mine[i]->L, (int) i});
+		file_piece bytes;
+		std::vector<conga_bgzf_block> blocks;
+		std::vector<conga_bam_segment> segments;
+		if (src->device_plan(targets, gpu_bam != nullptr ? 0 : kGpuBamMinPiece, &bytes, &blocks, &segments, &err)) {
+			for (chrom_job *job : mine) {
+				std::vector<uint8_t> gc_hist_w, gc_like_w;
+				gc_window_arrays(this_sonic, job->chr_index, &gc_hist_w, &gc_like_w);
+				engine_check(ctx, conga_chrom_begin(ctx, job->L, gc_hist_w.data(), gc_like_w.data(), (int64_t) gc_hist_w.size()),
+						"conga_chrom_begin");
+				attach_intervals(ctx, params, map_bed, job->cs);
+			}
+			gpu_counts.assign(mine.size(), 0);
+			const int rc = conga_reads_bgzf(ctx, bytes.data, bytes.size, blocks.data(), blocks.size(), segments.data(), segments.size(),
+					gpu_counts.data());
+			if (rc != CONGA_OK) {
+				if (rc != CONGA_ERR_DATA)
+					engine_check(ctx, rc, "conga_reads_bgzf");
+				fprintf(stderr, "\n[CONGA] decoding on the host: %s\n", conga_last_error(ctx));
+				gpu_counts.clear();
+				engine_check(ctx, conga_reset(ctx), "conga_reset");
+			}
+		}
+		err.clear();
+	}
+	for (size_t job_index = 0; job_index < mine.size(); job_index++) {
+		chrom_job *job = mine[job_index];
+		const bool on_gpu = !gpu_counts.empty(); // opened, equipped and filled above: only the progress text is left
 		progress out = {buffered ? &job->messages : nullptr};
 		if (!buffered && !job->messages.empty()) {
 			fputs(job->messages.c_str(), stderr); // what the selection pass had to say before this chromosome
@@ -230,12 +302,13 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 		out.say("\n");
 		out.say("Reading BAM [%s] - Chromosome: %s", src->sample_name().c_str(), src->target_name(job->chr_index_bam).c_str());
 
-		// init_rd_per_chr + the GC side of calc_mean_per_chr (read_distribution.c:12-18,63-73)
-		std::vector<uint8_t> gc_hist_w, gc_like_w;
-		gc_window_arrays(this_sonic, job->chr_index, &gc_hist_w, &gc_like_w);
-		engine_check(ctx, conga_chrom_begin(ctx, L, gc_hist_w.data(), gc_like_w.data(), (int64_t) gc_hist_w.size()),
-				"conga_chrom_begin");
-
+		if (!on_gpu) {
+			// init_rd_per_chr + the GC side of calc_mean_per_chr (read_distribution.c:12-18,63-73)
+			std::vector<uint8_t> gc_hist_w, gc_like_w;
+			gc_window_arrays(this_sonic, job->chr_index, &gc_hist_w, &gc_like_w);
+			engine_check(ctx, conga_chrom_begin(ctx, L, gc_hist_w.data(), gc_like_w.data(), (int64_t) gc_hist_w.size()),
+					"conga_chrom_begin");
+		}
 		if (split_reads) {
 			// readReferenceSeq (common.c:423-463) and the satellite annotation (bam_data.c:96-97,207)
 			out.say("\nReading the Reference Genome");
@@ -247,7 +320,7 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 					this_sonic->sat_end[job->chr_index].data(), this_sonic->sat_start[job->chr_index].size()), "conga_satellites");
 		}
 		out.say("\n-->counting reads");
-		const int64_t cnt_reads = count_reads_bam(ctx, src, job->chr_index_bam, L, split_reads);
+		const int64_t cnt_reads = on_gpu ? (int64_t) gpu_counts[job_index] : count_reads_bam(ctx, src, job->chr_index_bam, L, split_reads);
 		out.say(" (%lld reads, %ld split-reads)\n", (long long) cnt_reads, 0L);
 
 		// find_SVs, loading half (likelihood.c:319-336); the rows were picked by the selection pass
@@ -255,35 +328,10 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 		out.say("\nLoading known SVs");
 		out.say("(%d DELS, %d DUPS in chromosome %s - larger than the threshold %d)\n", (int) cs.dels.size(), (int) cs.dups.size(),
 				cs.chr_name.c_str(), params->min_sv_size);
-		std::vector<int32_t> s, e;
-		auto hand_over = [&](char type, const std::vector<sv_row> &rows) {
-			s.resize(rows.size());
-			e.resize(rows.size());
-			for (size_t i = 0; i < rows.size(); i++) {
-				s[i] = rows[i].start;
-				e[i] = rows[i].end;
-			}
-			engine_check(ctx, conga_intervals(ctx, type, s.data(), e.data(), rows.size()), "conga_intervals");
-		};
-		hand_over(CONGA_DELETION, cs.dels);
-		hand_over(CONGA_DUPLICATION, cs.dups);
-		if (params->have_map && cs.dels.size() + cs.dups.size() > 0) {
-			// load_mappability_regions (svs.c:317-377) runs only for chromosomes that have SVs (likelihood.c:332-356)
+		if (params->have_map && cs.dels.size() + cs.dups.size() > 0)
 			out.say("Finding mappability for each region\n");
-			auto it = map_bed.rows.find(cs.chr_name);
-			std::vector<int32_t> ms, me;
-			const float *mv = nullptr;
-			if (it != map_bed.rows.end()) {
-				ms.resize(it->second.size());
-				me.resize(it->second.size());
-				for (size_t i = 0; i < it->second.size(); i++) {
-					ms[i] = it->second[i].start;
-					me[i] = it->second[i].end;
-				}
-				mv = map_bed.values.at(cs.chr_name).data();
-			}
-			engine_check(ctx, conga_mappability(ctx, ms.data(), me.data(), mv, ms.size()), "conga_mappability");
-		}
+		if (!on_gpu)
+			attach_intervals(ctx, params, map_bed, cs);
 		job->staged = true;
 	}
 	wt->ms_reads = ms_since(t_loop);

@@ -545,47 +545,46 @@ public:
 		return true;
 	}
 
-	// The target's stretch of the file for conga_reads_bgzf: from the block of its first record through the block in
-	// which the next target with records begins (so that the walk sees a record that ends this target; to the end of the
-	// file for the last one), the table of those blocks, and one start point per distinct linear-index offset.
-	bool device_plan(int tid, int64_t chrom_len, uint64_t min_piece_bytes, file_piece *bytes,
+	// The targets' stretch of the file for conga_reads_bgzf: from the block of the first record of the first of them in
+	// the file through the block in which the next target with records behind the last of them begins (so that the walk
+	// sees a record that ends it; to the end of the file when there is none), the table of those blocks, and for every
+	// target one start point per distinct linear-index offset.
+	bool device_plan(const std::vector<device_target> &targets, uint64_t min_piece_bytes, file_piece *bytes,
 			std::vector<conga_bgzf_block> *blocks, std::vector<conga_bam_segment> *segments, std::string *err) override
 	{
-		if (tid < 0 || tid >= (int) linear_.size() || ref_beg_[(size_t) tid] == 0)
+		if (targets.empty() || linear_.empty())
 			return false;
-		const uint64_t c_lo = ref_beg_[(size_t) tid] >> 16;
-		uint64_t c_end = 0; // file offset behind the last block to take; 0: the end of the file
-		for (size_t t = (size_t) tid + 1; t < ref_beg_.size(); t++)
+		uint64_t c_lo = ~0ull;
+		int last_tid = -1;
+		bool any = false;
+		for (const device_target &t : targets) {
+			if (t.tid < 0 || t.tid >= (int) linear_.size() || t.chrom_len <= 0 || t.chrom_len > INT32_MAX)
+				return false;
+			if (ref_beg_[(size_t) t.tid] == 0)
+				continue; // no records: no start points, it gets no reads
+			any = true;
+			c_lo = std::min(c_lo, ref_beg_[(size_t) t.tid] >> 16);
+			last_tid = std::max(last_tid, t.tid);
+		}
+		if (!any)
+			return false;
+		uint64_t c_end = 0; // file offset of the last block to take; 0: to the end of the file
+		for (size_t t = (size_t) last_tid + 1; t < ref_beg_.size(); t++)
 			if (ref_beg_[t] != 0) {
-				c_end = ref_beg_[t] >> 16; // (the block at c_end itself is added below)
+				c_end = ref_beg_[t] >> 16;
 				break;
 			}
-		FILE *f = fopen(path_.c_str(), "rb");
-		if (!f)
-			return false;
 		struct stat st;
-		if (fstat(fileno(f), &st) != 0 || (uint64_t) st.st_size <= c_lo) {
-			fclose(f);
+		if (stat(path_.c_str(), &st) != 0 || (uint64_t) st.st_size <= c_lo)
 			return false;
-		}
 		uint64_t stop = (uint64_t) st.st_size;
 		if (c_end && c_end + 65536 + 18 < stop)
 			stop = c_end + 65536 + 18; // enough for the whole block that starts at c_end
-		if (stop - c_lo < min_piece_bytes) { // (nothing has been read yet)
-			fclose(f);
-			return false;
-		}
-		const uint64_t kMaxPiece = 6ull << 30;
-		if (const char *e = getenv("CONGA_GPU_BAM_MAX_MB")) {
-			if (stop - c_lo > (uint64_t) atoll(e) << 20) {
-				fclose(f);
-				return false;
-			}
-		} else if (stop - c_lo > kMaxPiece) {
-			fclose(f);
-			return false;
-		}
-		fclose(f);
+		uint64_t max_piece = 6ull << 30;
+		if (const char *e = getenv("CONGA_GPU_BAM_MAX_MB"))
+			max_piece = (uint64_t) atoll(e) << 20;
+		if (stop - c_lo < min_piece_bytes || stop - c_lo > max_piece)
+			return false; // (nothing has been read yet)
 		if (!bytes->open(path_, c_lo, stop))
 			return false;
 		// block table
@@ -643,42 +642,47 @@ public:
 				*out = inflated_off[k] + u;
 				return true;
 			}
-			if (u == 0 && k <= file_off.size()) { // an empty block (not kept): the next one's start
+			if (u == 0) { // an empty block (not kept): the next one's start
 				*out = k < file_off.size() ? inflated_off[k] : total;
 				return true;
 			}
 			return false;
 		};
-		// start points
-		std::vector<uint64_t> lin = linear_[(size_t) tid];
-		const size_t n_win = std::min(lin.size(), (size_t) ((chrom_len + 16383) >> 14));
-		lin.resize(n_win);
-		for (size_t w = 1; w < n_win; w++)
-			if (lin[w] == 0 || lin[w] < lin[w - 1])
-				lin[w] = lin[w - 1];
+		// start points, target by target
 		segments->clear();
-		conga_bam_segment first;
-		first.pos_lo = 0;
-		first.pos_hi = (int32_t) chrom_len;
-		if (!absolute(ref_beg_[(size_t) tid], &first.start))
-			return false;
-		segments->push_back(first);
-		uint64_t prev_v = ref_beg_[(size_t) tid];
-		for (size_t w = 1; w < n_win; w++) {
-			if (lin[w] == 0 || lin[w] == prev_v || lin[w] < prev_v)
+		for (const device_target &t : targets) {
+			if (ref_beg_[(size_t) t.tid] == 0)
 				continue;
-			conga_bam_segment sg;
-			if (!absolute(lin[w], &sg.start))
+			std::vector<uint64_t> lin = linear_[(size_t) t.tid];
+			const size_t n_win = std::min(lin.size(), (size_t) ((t.chrom_len + 16383) >> 14));
+			lin.resize(n_win);
+			for (size_t w = 1; w < n_win; w++)
+				if (lin[w] == 0 || lin[w] < lin[w - 1])
+					lin[w] = lin[w - 1];
+			conga_bam_segment first;
+			first.pos_lo = 0;
+			first.pos_hi = (int32_t) t.chrom_len;
+			first.ref_id = t.tid;
+			first.chrom = t.chrom;
+			if (!absolute(ref_beg_[(size_t) t.tid], &first.start))
 				return false;
-			sg.pos_lo = (int32_t) (w << 14);
-			sg.pos_hi = (int32_t) chrom_len;
-			if ((int64_t) sg.pos_lo >= chrom_len)
-				break;
-			segments->back().pos_hi = sg.pos_lo;
-			segments->push_back(sg);
-			prev_v = lin[w];
+			segments->push_back(first);
+			uint64_t prev_v = ref_beg_[(size_t) t.tid];
+			for (size_t w = 1; w < n_win; w++) {
+				if (lin[w] == 0 || lin[w] <= prev_v)
+					continue;
+				conga_bam_segment sg = first;
+				if (!absolute(lin[w], &sg.start))
+					return false;
+				sg.pos_lo = (int32_t) (w << 14);
+				if ((int64_t) sg.pos_lo >= t.chrom_len)
+					break;
+				segments->back().pos_hi = sg.pos_lo;
+				segments->push_back(sg);
+				prev_v = lin[w];
+			}
 		}
-		return true;
+		return !segments->empty();
 	}
 
 	bool next_full(full_batch *fb, std::string *err) override

@@ -41,6 +41,12 @@ struct file_piece {
 	bool open(const std::string &path, uint64_t from, uint64_t to);
 };
 
+struct device_target {
+	int tid;           // in the BAM header
+	int64_t chrom_len; // from the annotation
+	int chrom;         // index of the chromosome in the engine context
+};
+
 class read_source {
 public:
 	virtual ~read_source() {}
@@ -61,10 +67,11 @@ public:
 	{
 		return false;
 	}
-	// What conga_reads_bgzf (include/conga_hip.h) needs to decode the same records on the GPU: the BGZF blocks that hold
-	// target tid, as they are in the file, and start points from the index's linear offsets.  false with an empty *err: not
+	// What conga_reads_bgzf (include/conga_hip.h) needs to decode the same records on the GPU: the stretch of the file that
+	// holds the targets (in the order of their chromosomes in the context), as it is, the table of its BGZF blocks, and start
+	// points from the index's linear offsets.  false with an empty *err: not
 	// available (no index, not a BAM, a piece of the file smaller than min_piece_bytes or too large) -- decode on the host.
-	virtual bool device_plan(int tid, int64_t chrom_len, uint64_t min_piece_bytes, file_piece *bytes,
+	virtual bool device_plan(const std::vector<device_target> &targets, uint64_t min_piece_bytes, file_piece *bytes,
 			std::vector<conga_bgzf_block> *blocks, std::vector<conga_bam_segment> *segments, std::string *err)
 	{
 		return false;

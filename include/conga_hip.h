@@ -199,18 +199,22 @@ int conga_mappability(conga_ctx *ctx, const int32_t *start, const int32_t *end, 
 int conga_intervals(conga_ctx *ctx, char type, const int32_t *start, const int32_t *end, size_t n);
 
 /* ---- count_reads_bam with the BAM decode on the device -------------------------------------------------------
- * Instead of decoded tuples the caller hands over the BGZF blocks that hold one target's records exactly as they are
- * in the file, the table of those blocks, and start points taken from the .bai's linear index (16 kb windows).  The
- * engine inflates the blocks (one GPU lane per block, the decoder of conga_amd/host/inflate_core.h, CRC32 checked) and
- * walks the records (one lane per start point), and appends (pos, mapq) of the records with refID == ref_id and
- * 0 <= pos < chrom_len to the chromosome begun last -- the records `sam_itr_queryi(idx, tid, 0, L)` + `sam_itr_next`
- * hand to count_reads_bam (bam_data.c:192-221, 293) -- in file order, without the tuples ever being on the host.
+ * Instead of decoded tuples the caller hands over a stretch of the BAM file exactly as it is on disk, the table of
+ * its BGZF blocks, and start points taken from the .bai's linear index (16 kb windows).  The engine inflates the blocks
+ * (one GPU lane per block, the decoder of conga_amd/host/inflate_core.h, CRC32 checked) and walks the records (one lane
+ * per start point), and gives every chromosome named by the start points its reads: (pos, mapq) of the records with
+ * refID == ref_id and 0 <= pos < pos_hi of its last segment -- the records `sam_itr_queryi(idx, tid, 0, L)` +
+ * `sam_itr_next` hand to count_reads_bam (bam_data.c:192-221, 293) -- in file order, without the tuples ever being on
+ * the host.  One call may serve several chromosomes of a batch context (a whole low-coverage genome is one launch).
  *   blocks[i]   : one BGZF block with a non-empty payload, in file order
  *   segments[k] : `start` = offset, in the concatenation of the inflated blocks, of a record boundary at or in front
- *                 of the first record whose position is >= pos_lo; the segment owns the records with
- *                 pos_lo <= pos < pos_hi.  Segments are in order and tile [0, chrom_len).
- * The engine verifies that every segment stops exactly where the next one found its first record; if not, or if a
- * block fails its checks, it returns CONGA_ERR_DATA and has appended nothing.  Not for --rp (no sequences kept). */
+ *                 of the first record of target `ref_id` whose position is >= pos_lo; the segment owns the records with
+ *                 pos_lo <= pos < pos_hi.  `chrom` = index of the chromosome (conga_chrom_select) the records go to.
+ *                 Segments are grouped by ascending `chrom`; those of one chromosome are in order and tile [0, L).
+ * No chromosome from the first named one on may have reads yet (the tuples of a context are laid out in chromosome
+ * order); chromosomes in between that are not named get none.  The engine verifies that every segment stops exactly
+ * where the next one of its chromosome found its first record; if not, or if a block fails its checks, it returns
+ * CONGA_ERR_DATA and has changed nothing.  Not for --rp (no sequences kept). */
 typedef struct conga_bgzf_block {
 	uint64_t data_off;     /* of the raw deflate data inside `bytes` */
 	uint32_t data_len;
@@ -221,9 +225,11 @@ typedef struct conga_bgzf_block {
 typedef struct conga_bam_segment {
 	uint64_t start;
 	int32_t pos_lo, pos_hi;
+	int32_t ref_id;        /* refID of the target in the BAM header */
+	int32_t chrom;         /* chromosome of the context */
 } conga_bam_segment;
 int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const conga_bgzf_block *blocks, size_t n_blocks,
-		const conga_bam_segment *segments, size_t n_segments, int32_t ref_id, uint64_t *n_appended);
+		const conga_bam_segment *segments, size_t n_segments, uint64_t *reads_per_chrom /* [conga_chrom_count()] or NULL */);
 
 /* ---- split-read evidence: find_split_reads / read_SplitReads / count_ReadPairs on the device --------------
  * Used when the reference would run its split-read path (`--rp` given AND `--dups` given: svdepth.c:57,
