@@ -61,6 +61,17 @@ class ReadStaging(C.Structure):
     _fields_ = [("pos", C.POINTER(C.c_int32)), ("mapq", C.POINTER(C.c_uint8)), ("capacity", C.c_size_t)]
 
 
+class BgzfBlock(C.Structure):
+    """conga_bgzf_block (conga_reads_bgzf)."""
+    _fields_ = [("data_off", C.c_uint64), ("data_len", C.c_uint32), ("inflated_len", C.c_uint32), ("crc32", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+class BamSegment(C.Structure):
+    """conga_bam_segment (conga_reads_bgzf)."""
+    _fields_ = [("start", C.c_uint64), ("pos_lo", C.c_int32), ("pos_hi", C.c_int32), ("ref_id", C.c_int32), ("chrom", C.c_int32)]
+
+
 class ChromStats(C.Structure):
     _fields_ = [("reads_committed", C.c_int64), ("reads_counted", C.c_int64),
                 ("reads_out_of_range", C.c_int64), ("rd_sum", C.c_int64), ("mean", C.c_float),

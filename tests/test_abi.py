@@ -29,6 +29,7 @@ def test_abi_version_and_struct_sizes(capi):
     assert lib.conga_abi_version() == 3
     assert capi.RESULT_DTYPE.itemsize == 64
     assert ctypes.sizeof(capi.Opts) == 32
+    assert ctypes.sizeof(capi.BgzfBlock) == 24 and ctypes.sizeof(capi.BamSegment) == 24
 
 
 def test_strerror(capi):
