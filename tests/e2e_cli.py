@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--input", choices=("bam", "tuples"), default="bam",
                     help="tuples: the read-tuple container (decoded pos / mapq per chromosome) instead of a BAM -- what "
                          "is left of the wall time is file read, PCIe staging, compute and the output writer")
+    ap.add_argument("--decode", choices=("default", "both"), default="default",
+                    help="both: run the same input a second time with CONGA_GPU_BAM=0 (host decoders only)")
     ap.add_argument("--bai", type=int, default=1, help="write the .bai too (0: the reader then goes through the file front to back)")
     ap.add_argument("--gpus", default="1", help="comma list of `conga --gpus` values to run on the same input (contexts "
                     "share the device when there are fewer devices)")
@@ -48,22 +50,25 @@ def main():
     synth.write_bed(os.path.join(d, "dels.bed"), [(c.name, s, e) for c in cs for s, e in zip(c.del_start, c.del_end)])
     runs = {}
     first_bytes = None
-    for g in [int(x) for x in a.gpus.split(",")]:
+    variants = [(int(x), {}) for x in a.gpus.split(",")]
+    if a.decode == "both":       # the same input once more with the host decoders only
+        variants.append((variants[0][0], {"CONGA_GPU_BAM": "0"}))
+    for g, extra_env in variants:
         t0 = time.time()
         r = subprocess.run([os.path.join(ROOT, "conga_amd", "host", "conga"), "-i", reads_file, "--out", "got", "--ref", "none.fa",
                             "--sonic", "a.cga", "--dels", "dels.bed", "--gpus", str(g)], cwd=d, capture_output=True, text=True,
-                           env=dict(os.environ, CONGA_TIMING="1"))
+                           env=dict(os.environ, CONGA_TIMING="1", **extra_env))
         t_cli = time.time() - t0
         assert r.returncode == 0, r.stderr[-2000:]
-        runs[g] = round(t_cli, 3)
+        runs["%d%s" % (g, " host-decode" if extra_env else "")] = round(t_cli, 3)
         got = [open(os.path.join(d, "got_%s.bed" % k), "rb").read() for k in ("svs", "dels")]
         if first_bytes is None:
             first_bytes = got
         assert got == first_bytes, "--gpus %d changed the output files" % g
         for line in r.stderr.splitlines():
             if "[timing" in line:
-                print("--gpus %d %s" % (g, line), file=sys.stderr)
-    t_cli = runs[int(a.gpus.split(",")[0])]
+                print("--gpus %d%s %s" % (g, " CONGA_GPU_BAM=0" if extra_env else "", line), file=sys.stderr)
+    t_cli = runs[a.gpus.split(",")[0]]
     ok = None
     if a.check:
         paths = [os.path.join(d, "want_%s.bed" % k) for k in ("svs", "dels")]
