@@ -82,8 +82,8 @@ import zlib
 _BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
 
 
-def _bgzf_block(data):
-    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+def _bgzf_block(data, level=6, strategy=0):
+    co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
     cdata = co.compress(data) + co.flush()
     bsize = len(cdata) + 25  # 12 header + 6 extra + cdata + 8 trailer - 1
     return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize)
@@ -113,13 +113,14 @@ def write_fasta(path, chroms, width=60, index=True):
                 f.write("\t".join(str(x) for x in r) + "\n")
 
 
-def write_bam(path, sample, chroms, read_len=100, unplaced=0, block_payload=60000, records=None, index=False):
+def write_bam(path, sample, chroms, read_len=100, unplaced=0, block_payload=60000, records=None, index=False, level=6, strategy=0):
     """chroms: list of (name, length, pos int32[n] sorted, mapq uint8[n][, flag uint16[n]]).
     Every record gets a `read_len`M CIGAR, an all-A sequence and quality 30; `unplaced` unmapped records
     (refID -1) are appended at the end, as in a real coordinate-sorted BAM.
     records: optional {chrom name: (l_qseq int32[n], codes uint8[], qual uint8[], off uint64[n])} with one 4-bit
     base code per byte -- then every record carries its own sequence, qualities and an <l>M CIGAR.
-    index=True also writes path + '.bai' (bins with one merged chunk each + the 16 kb linear index)."""
+    index=True also writes path + '.bai' (bins with one merged chunk each + the 16 kb linear index).
+    level / strategy: zlib's, for the BGZF blocks (0: stored blocks; zlib.Z_FIXED: fixed-Huffman blocks ...)."""
     text = "@HD\tVN:1.6\tSO:coordinate\n"
     for c in chroms:
         text += "@SQ\tSN:%s\tLN:%d\n" % (c[0], c[1])
@@ -141,7 +142,7 @@ def write_bam(path, sample, chroms, read_len=100, unplaced=0, block_payload=6000
         def flush(final=False):
             nonlocal out
             while len(out) >= block_payload or (final and len(out)):
-                f.write(_bgzf_block(bytes(out[:block_payload])))
+                f.write(_bgzf_block(bytes(out[:block_payload]), level, strategy))
                 out = out[block_payload:]
 
         def voffset():

@@ -342,6 +342,34 @@ def test_cli_bam_decoded_on_the_gpu_matches_the_host_decoders(tmp_path, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("payload,level,strategy", [
+    (65280, 0, 0),      # stored blocks
+    (60000, 9, 0),      # dynamic Huffman, best compression
+    (60000, 6, 4),      # zlib.Z_FIXED: fixed-Huffman blocks
+    (60000, 6, 2),      # zlib.Z_HUFFMAN_ONLY: literals only
+    (311, 1, 0),        # hundreds of tiny blocks, records and their fields split across them
+])
+def test_gpu_bam_decode_takes_every_kind_of_block(tmp_path, payload, level, strategy):
+    """conga_reads_bgzf on BGZF blocks of every deflate block type and of odd sizes: same output files as the host
+    decoders, and the GPU stage did the work (it does not quietly decline)."""
+    d = str(tmp_path)
+    cs = [synth.make_chrom(n, L, cov=2.0, n_dels=nd, gaps=True) for n, L, nd in (("1", 400_000, 20), ("2", 250_000, 12))]
+    formats.write_bam(os.path.join(d, "r.bam"), "S", [(c.name, c.length, c.pos, c.mapq) for c in cs], index=True,
+                      block_payload=payload, level=level, strategy=strategy, unplaced=3)
+    formats.write_annotation(os.path.join(d, "a.cga"), [(c.name, c.length, c.gc, [], []) for c in cs])
+    synth.write_bed(os.path.join(d, "dels.bed"), [(c.name, s, e) for c in cs for s, e in zip(c.del_start, c.del_end)])
+    outs = {}
+    for tag, env in (("gpu", {"CONGA_GPU_BAM": "1", "CONGA_TIMING": "1"}), ("host", {"CONGA_GPU_BAM": "0"})):
+        r = subprocess.run([CONGA, "-i", "r.bam", "--ref", "r.fa", "--sonic", "a.cga", "--dels", "dels.bed", "--out", tag], cwd=d,
+                           capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-2000:]
+        if tag == "gpu":
+            assert "decoding on the host" not in r.stderr and "conga_reads_bgzf:" in r.stderr, r.stderr[-1500:]
+        outs[tag] = [open(os.path.join(d, "%s_%s.bed" % (tag, k)), "rb").read() for k in ("svs", "dels")]
+    assert outs["gpu"] == outs["host"] and outs["gpu"][1].count(b"\n") > 20
+
+
+@pytest.mark.gpu
 def test_cli_split_reads_rp(tmp_path, oracle):
     """--rp with --dups: FASTA + BAM sequences -> READ_PAIR columns and the `rp > rp_support` rule of _svs.bed
     (likelihood.c:243-279), byte-identical to the oracle."""
