@@ -1,7 +1,8 @@
-// gpu_inflate.hip -- PROTOTYPE, not part of the product: how fast does an MI355X inflate a BAM if every lane simply
+// gpu_inflate.hip -- stand-alone benchmark of the idea behind conga_reads_bgzf's first stage (the product version is
+// bgzf_inflate_kernel in conga_amd/csrc/kernels_bam.hip.h): how fast does an MI355X inflate a BAM if every lane simply
 // runs the host's block decoder (conga_amd/host/inflate_core.h, the same source) on its own BGZF block?
-// No wave cooperation, tables in global scratch, byte stores: the floor of what a GPU-side BGZF stage would do
-// (DESIGN.md section 10).  Every inflated block is checked against its CRC32 on the host.
+// No wave cooperation, tables in global scratch, byte stores.  Every inflated block is checked against its CRC32 on
+// the host.  Measured: 2.9 GB/s inflated with 4 665 blocks in flight, 17.6 GB/s with 44 725.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o gpu_inflate tools/gpu_inflate.hip -lz && ./gpu_inflate file.bam
 #include <hip/hip_runtime.h>
 #include <zlib.h>
