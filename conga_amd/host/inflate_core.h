@@ -24,7 +24,12 @@ namespace inflate_core {
 //   [29]    end of block        [30] pointer to a second-level table        [31] literal
 constexpr uint32_t kValid = 1u << 28, kEnd = 1u << 29, kSub = 1u << 30, kLiteral = 1u << 31;
 constexpr int kLitBits = 10, kDistBits = 8, kPreBits = 7;
-constexpr int kLitSize = (1 << kLitBits) + 288 * 32, kDistSize = (1 << kDistBits) + 32 * 128, kPreSize = 1 << kPreBits;
+// Second-level space: zlib, whose tables are laid out the same way, proves 852 entries in all enough for 286 symbols
+// behind a 9-bit first level and 592 for 30 symbols behind a 6-bit one (enough.c); wider first levels need less behind
+// them.  1024 and 512 second-level entries are comfortably above that; build_table refuses what does not fit and the
+// callers fall back (zlib on the host, the host decoders for the GPU stage).  Small tables matter on the GPU: a decoder
+// scratch per lane, 17 KB instead of 64.
+constexpr int kLitSize = (1 << kLitBits) + 1024, kDistSize = (1 << kDistBits) + 512, kPreSize = 1 << kPreBits;
 
 
 enum { kKindLitLen, kKindDist, kKindPre };
