@@ -89,25 +89,30 @@ template <bool WRITE> __global__ __launch_bounds__(64) void bam_walk_kernel(BamW
 	uint64_t w = WRITE ? a.write_at[k] : 0;
 	bool bad = false;
 	for (;;) {
-		if (at + 4 > a.stream_len)
+		if (at + 12 > a.stream_len)
 			break; // end of the stream (stop stays kNone)
 		const uint8_t *r = a.stream + at;
 		const int32_t block_size = load_i32(r);
-		if (block_size < 32 || at + 4 + (uint64_t) block_size > a.stream_len) {
+		if (block_size < 32) {
 			bad = true;
 			break;
 		}
 		const int32_t ref = load_i32(r + 4), p = load_i32(r + 8);
 		const uint64_t here = at;
-		at += 4 + (uint64_t) block_size;
-		if (ref >= 0 && ref < sg.ref_id)
-			continue; // (the tail of the previous target in front of this one's first record)
-		if (ref != sg.ref_id || p >= sg.pos_hi) {
+		if (!(ref >= 0 && ref < sg.ref_id) && (ref != sg.ref_id || p >= sg.pos_hi)) {
+			// the record that ends the segment; only its first fields are needed (the piece of the file may end inside it)
 			stop = here;
 			if (first == kNone)
 				first = here;
 			break;
 		}
+		if (at + 4 + (uint64_t) block_size > a.stream_len) {
+			bad = true; // a record of this target that is not all there
+			break;
+		}
+		at += 4 + (uint64_t) block_size;
+		if (ref >= 0 && ref < sg.ref_id)
+			continue; // (the tail of the previous target in front of this one's first record)
 		if (p < sg.pos_lo)
 			continue; // starts in front of this segment: the previous one's
 		if (first == kNone)

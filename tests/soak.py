@@ -176,6 +176,9 @@ def main():
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--seconds", type=float, default=0, help="stop after this long (0: run all cases)")
+    ap.add_argument("--bam", action="store_true",
+                    help="the command line on random BAM files (+ .bai): decode on the GPU (conga_reads_bgzf) against the host "
+                         "decoders -- same three output files, same read counts")
     ap.add_argument("--split-reads", action="store_true", help="the --rp path: random references and whole BAM records")
     ap.add_argument("--batch", action="store_true",
                     help="CONGA_FLAG_BATCH: 1..12 random chromosomes per context (one launch per kernel over all of them), "
@@ -188,6 +191,66 @@ def main():
 
     t0 = time.time()
     done = 0
+    if a.bam:
+        import re
+        import subprocess
+        import tempfile
+        import zlib
+        from conga_amd import formats, synth
+        conga = os.path.join(ROOT, "conga_amd", "host", "conga")
+        for i in range(a.cases):
+            rng = np.random.default_rng([a.seed, 11_000_000 + i])
+            d = tempfile.mkdtemp(prefix="conga_soak_bam_")
+            n_chr = int(rng.integers(1, 6))
+            chroms, reads = [], []
+            for k in range(n_chr):
+                L = int(rng.choice([rng.integers(20_000, 100_000), rng.integers(100_000, 2_000_000)]))
+                c = synth.make_chrom(str(k + 1), L, cov=float(rng.choice([0.0, 0.3, 1.0, 4.0])), n_dels=int(rng.integers(0, 30)),
+                                     n_dups=int(rng.integers(0, 8)), gaps=bool(rng.integers(0, 2)), seed=int(rng.integers(1, 1 << 30)))
+                pos = c.pos
+                if len(pos) and rng.random() < 0.5:   # pile-ups on and around window boundaries of the index
+                    w = int(rng.integers(1, max(2, L >> 14))) << 14
+                    extra = np.concatenate([np.full(int(rng.integers(1, 500)), min(w, L - 1)), np.full(int(rng.integers(1, 500)), max(w - 1, 0))])
+                    pos = np.sort(np.concatenate([pos, extra])).astype(np.int32)
+                if len(pos) and rng.random() < 0.4:   # a stretch without reads
+                    lo = int(rng.integers(0, L))
+                    pos = pos[(pos < lo) | (pos > lo + int(rng.integers(1, 200_000)))]
+                chroms.append(c)
+                reads.append((c.name, L, pos, rng.integers(0, 61, len(pos)).astype(np.uint8)))
+            formats.write_bam(os.path.join(d, "r.bam"), "S", reads, index=True, unplaced=int(rng.integers(0, 20)),
+                              block_payload=int(rng.choice([257, 1500, 9000, 40000, 65280])), level=int(rng.integers(0, 10)),
+                              strategy=int(rng.choice([0, 0, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED])))
+            order = rng.permutation(n_chr)              # the annotation lists the chromosomes in its own order
+            formats.write_annotation(os.path.join(d, "a.cga"), [(chroms[j].name, chroms[j].length, chroms[j].gc, [], []) for j in order])
+            synth.write_bed(os.path.join(d, "dels.bed"), [(c.name, s_, e_) for c in chroms for s_, e_ in zip(c.del_start, c.del_end)])
+            synth.write_bed(os.path.join(d, "dups.bed"), [(c.name, s_, e_) for c in chroms for s_, e_ in zip(c.dup_start, c.dup_end)])
+            args = ["-i", "r.bam", "--ref", "r.fa", "--sonic", "a.cga", "--dels", "dels.bed", "--dups", "dups.bed"]
+            if rng.random() < 0.5:
+                args += ["--min-mapq", str(int(rng.integers(0, 60)))]
+            if n_chr > 1 and rng.random() < 0.3:
+                args += ["--first-chr", str(int(rng.integers(0, n_chr))), "--last-chr", str(n_chr - 1)]
+            if rng.random() < 0.3:
+                args += ["--gpus", str(int(rng.integers(2, 4)))]
+            outs = {}
+            for tag, env in (("gpu", {"CONGA_GPU_BAM": "1"}), ("host", {"CONGA_GPU_BAM": "0", "CONGA_BAM_SEGMENTS": str(int(rng.integers(1, 9)))})):
+                r = subprocess.run([conga] + args + ["--out", tag], cwd=d, capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+                if r.returncode != 0 or (tag == "gpu" and "decoding on the host" in r.stderr):
+                    print("FAILED bam case %d (seed %d, %s) in %s:\n%s" % (i, a.seed, tag, d, r.stderr[-1500:]), flush=True)
+                    raise SystemExit(1)
+                files = [open(os.path.join(d, "%s_%s.bed" % (tag, k)), "rb").read() for k in ("svs", "dels", "dups")]
+                outs[tag] = (files, re.findall(r"\((\d+) reads, 0 split-reads\)", r.stderr))
+            if outs["gpu"] != outs["host"]:
+                print("FAILED bam case %d (seed %d): GPU and host decode differ, files in %s" % (i, a.seed, d), flush=True)
+                raise SystemExit(1)
+            import shutil
+            shutil.rmtree(d)
+            done += 1
+            if i % 10 == 9:
+                print("%d bam cases ok, %.0f s" % (done, time.time() - t0), flush=True)
+            if a.seconds and time.time() - t0 > a.seconds:
+                break
+        print("soak: %d random BAMs: decode on the GPU == host decoders (seed %d, %.0f s)" % (done, a.seed, time.time() - t0))
+        return
     if a.split_reads:
         import test_gpu_split_reads as S
         for i in range(a.cases):
