@@ -1112,7 +1112,9 @@ int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const
 		return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
 	};
 	// one decoder scratch (17 KB) per lane; a lane takes several blocks only beyond 131 072 of them (2.2 GB of scratch)
-	const uint32_t lanes = (uint32_t) std::min<size_t>((n_blocks + 63) & ~(size_t) 63, 131072);
+	uint32_t lanes = (uint32_t) std::min<size_t>((n_blocks + 63) & ~(size_t) 63, 131072);
+	if (const char *e = getenv("CONGA_BGZF_LANES")) // (tests: few lanes, several blocks each)
+		lanes = std::min(lanes, (uint32_t) std::max(64, atoi(e) & ~63));
 	TRY(ensure(ctx, ctx->d_bz_in, n_bytes));
 	TRY(ensure(ctx, ctx->d_bz_blocks, n_blocks * sizeof(conga_bgzf_block)));
 	TRY(ensure(ctx, ctx->d_bz_off, n_blocks * 8));
