@@ -36,7 +36,9 @@ __device__ __forceinline__ uint32_t crc32_bytes(const uint32_t *table, const uin
 
 // status[b]: kBgzfOk / kBgzfRefused / kBgzfCrc.  Lanes loop over blocks with the launch's lane count as stride, so the
 // scratch is one decoder per launched lane.
-__global__ __launch_bounds__(64) void bgzf_inflate_kernel(uint32_t n_blocks, const uint8_t *__restrict__ bytes,
+// (Register budget for 4 waves per SIMD: left alone the compiler takes 256 registers, one wave per SIMD, and a genome's
+// 79 000 blocks then need two rounds of 65 536 resident lanes.)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void bgzf_inflate_kernel(uint32_t n_blocks, const uint8_t *__restrict__ bytes,
 		const conga_bgzf_block *__restrict__ blocks, const uint64_t *__restrict__ out_off, uint8_t *__restrict__ out,
 		InflateScratch *scratch, const uint32_t *__restrict__ crc_table, uint8_t *__restrict__ status)
 {
