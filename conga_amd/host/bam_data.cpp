@@ -53,8 +53,13 @@ void engine_check(conga_ctx *ctx, int rc, const char *what)
 	}
 }
 
-// ~32 768 blocks of a typical BAM: below that one lane per block does not pay
-constexpr uint64_t kGpuBamMinPiece = (uint64_t) 32768 * 40000;
+// From how much of the file on the decode goes to the GPU when the environment does not say: one lane per block costs
+// ~0.25 s per call whatever the size (launch floor + upload), a host core inflates and walks a 40 KB block in ~0.37 ms,
+// so the break-even is ~680 blocks, 27 MB of file, per core this worker may use.
+uint64_t gpu_bam_min_piece()
+{
+	return (uint64_t) 27000000 * (uint64_t) std::max(1, usable_cpus() / reader_share());
+}
 
 // count_reads_bam (bam_data.c:192-221), producer side: records go straight into the pinned staging ring.
 // With split reads enabled (--rp and --dups) every record is also handed over whole (split_read.c:206-354).
@@ -99,11 +104,11 @@ int64_t count_reads_bam(conga_ctx *ctx, read_source *src, int chr_index_bam, int
 		// a BAM with an index: its compressed blocks go to the GPU as they are and are inflated and walked there
 		// (conga_reads_bgzf); anything that does not check out falls through to the host decoders below.  One lane per
 		// block takes ~0.1 s for a block however many there are, so it only pays with tens of thousands of blocks in a call
-		// (a chromosome of a deep sample: the default asks for 1.3 GB of file; measured: 45 000 blocks in 0.17 s = 17 GB/s inflated, against ~5 GB/s for 16 cores).
+		// (a whole low-coverage genome, a chromosome of a deep sample: the default asks for 27 MB of file per host core; measured: 45 000 blocks in 0.17 s = 17 GB/s inflated, against ~5 GB/s for 16 cores).
 		file_piece bytes;
 		std::vector<conga_bgzf_block> blocks;
 		std::vector<conga_bam_segment> segments;
-		const uint64_t min_piece = gpu_bam != nullptr ? 0 : kGpuBamMinPiece;
+		const uint64_t min_piece = gpu_bam != nullptr ? 0 : gpu_bam_min_piece();
 		const int chrom = conga_chrom_count(ctx) - 1; // the chromosome begun last
 		if (src->device_plan({device_target{chr_index_bam, chrom_len, chrom}}, min_piece, &bytes, &blocks, &segments, &err)) {
 			std::vector<uint64_t> per_chrom((size_t) chrom + 1, 0);
@@ -268,7 +273,7 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 		file_piece bytes;
 		std::vector<conga_bgzf_block> blocks;
 		std::vector<conga_bam_segment> segments;
-		if (src->device_plan(targets, gpu_bam != nullptr ? 0 : kGpuBamMinPiece, &bytes, &blocks, &segments, &err)) {
+		if (src->device_plan(targets, gpu_bam != nullptr ? 0 : gpu_bam_min_piece(), &bytes, &blocks, &segments, &err)) {
 			for (chrom_job *job : mine) {
 				std::vector<uint8_t> gc_hist_w, gc_like_w;
 				gc_window_arrays(this_sonic, job->chr_index, &gc_hist_w, &gc_like_w);
