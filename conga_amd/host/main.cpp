@@ -160,5 +160,10 @@ int main(int argc, char **argv)
 		username[0] = '\0';
 	fprintf(stderr, "\nThank you %s. I found %d DELs and %d DUPs. Hope to see you again...\n", username, total_dels, total_dups);
 	fclose(logFile);
+	if (getenv("CONGA_CLEAN_EXIT") == nullptr) {
+		// outputs are written and closed: leave without the HIP runtime's and the contexts' teardown (bam_data.cpp)
+		fflush(nullptr);
+		_exit(EXIT_SUCCESS);
+	}
 	return EXIT_SUCCESS;
 }
