@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--input", choices=("bam", "tuples"), default="bam",
                     help="tuples: the read-tuple container (decoded pos / mapq per chromosome) instead of a BAM -- what "
                          "is left of the wall time is file read, PCIe staging, compute and the output writer")
+    ap.add_argument("--repeat", type=int, default=1, help="runs per variant; the fastest is reported")
     ap.add_argument("--decode", choices=("default", "both"), default="default",
                     help="both: run the same input a second time with CONGA_GPU_BAM=0 (host decoders only)")
     ap.add_argument("--bai", type=int, default=1, help="write the .bai too (0: the reader then goes through the file front to back)")
@@ -54,12 +55,16 @@ def main():
     if a.decode == "both":       # the same input once more with the host decoders only
         variants.append((variants[0][0], {"CONGA_GPU_BAM": "0"}))
     for g, extra_env in variants:
-        t0 = time.time()
-        r = subprocess.run([os.path.join(ROOT, "conga_amd", "host", "conga"), "-i", reads_file, "--out", "got", "--ref", "none.fa",
-                            "--sonic", "a.cga", "--dels", "dels.bed", "--gpus", str(g)], cwd=d, capture_output=True, text=True,
-                           env=dict(os.environ, CONGA_TIMING="1", **extra_env))
-        t_cli = time.time() - t0
-        assert r.returncode == 0, r.stderr[-2000:]
+        t_cli = None
+        for _ in range(max(1, a.repeat)):   # best of `--repeat` runs: a 3 GB input makes single runs noisy
+            t0 = time.time()
+            r1 = subprocess.run([os.path.join(ROOT, "conga_amd", "host", "conga"), "-i", reads_file, "--out", "got", "--ref", "none.fa",
+                                 "--sonic", "a.cga", "--dels", "dels.bed", "--gpus", str(g)], cwd=d, capture_output=True, text=True,
+                                env=dict(os.environ, CONGA_TIMING="1", **extra_env))
+            t1 = time.time() - t0
+            assert r1.returncode == 0, r1.stderr[-2000:]
+            if t_cli is None or t1 < t_cli:
+                t_cli, r = t1, r1
         runs["%d%s" % (g, " host-decode" if extra_env else "")] = round(t_cli, 3)
         got = [open(os.path.join(d, "got_%s.bed" % k), "rb").read() for k in ("svs", "dels")]
         if first_bytes is None:
