@@ -123,6 +123,13 @@ void gc_window_arrays(const sonic *s, int chr_index, std::vector<uint8_t> *gc_hi
 	gc_hist_w->resize((size_t) n_win);
 	gc_like_w->resize((size_t) n_win);
 	const std::vector<uint8_t> &g = s->gc[chr_index];
+	if ((int64_t) g.size() == n_win) {
+		// The container holds one rounded percentage per window: (int) round((float) byte) is the byte, and both lookups
+		// of window w read entry w -- the loop below would copy the track twice, one libm-free rounding per window.
+		*gc_hist_w = g;
+		*gc_like_w = g;
+		return;
+	}
 	for (int64_t w = 0; w < n_win; w++) {
 		// The two lookups of the reference for the bases i = w * step of this window:
 		//   read_distribution.c:65-70  sonic_get_gc_content(chr, i, min(i + step, L))   (end clamped to the chromosome)
