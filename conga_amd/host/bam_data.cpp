@@ -273,7 +273,10 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 		file_piece bytes;
 		std::vector<conga_bgzf_block> blocks;
 		std::vector<conga_bam_segment> segments;
+		const auto t_plan = now();
 		if (src->device_plan(targets, gpu_bam != nullptr ? 0 : gpu_bam_min_piece(), &bytes, &blocks, &segments, &err)) {
+			const double ms_plan = ms_since(t_plan);
+			const auto t_open = now();
 			for (chrom_job *job : mine) {
 				std::vector<uint8_t> gc_hist_w, gc_like_w;
 				gc_window_arrays(this_sonic, job->chr_index, &gc_hist_w, &gc_like_w);
@@ -282,6 +285,9 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 				attach_intervals(ctx, params, map_bed, job->cs);
 			}
 			gpu_counts.assign(mine.size(), 0);
+			if (getenv("CONGA_TIMING"))
+				fprintf(stderr, "\n[timing] block table + start points %.1f ms, chromosomes opened (GC tracks, intervals, tracks) %.1f ms\n",
+						ms_plan, ms_since(t_open));
 			const int rc = conga_reads_bgzf(ctx, bytes.data, bytes.size, blocks.data(), blocks.size(), segments.data(), segments.size(),
 					gpu_counts.data());
 			if (rc != CONGA_OK) {
