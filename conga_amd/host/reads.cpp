@@ -192,6 +192,24 @@ bool file_piece::open(const std::string &path, uint64_t from, uint64_t to)
 	(void) madvise(map, map_len, MADV_SEQUENTIAL);
 	data = (const uint8_t *) map + (from - base);
 	size = (size_t) (to - from);
+	// Map the pages in now, on every core the process may use: the block-table scan and above all the upload would
+	// otherwise take one page fault per 4 KB on a single thread.
+	const int n_threads = std::min(16, std::max(1, usable_cpus() / reader_share()));
+	if (n_threads > 1 && map_len > (64u << 20)) {
+		std::vector<std::thread> pool;
+		const size_t per = ((map_len / (size_t) n_threads) + page - 1) & ~(size_t) (page - 1);
+		for (int t = 0; t < n_threads; t++)
+			pool.emplace_back([=] {
+				const volatile uint8_t *p = (const volatile uint8_t *) map;
+				const size_t lo = (size_t) t * per, hi = std::min(map_len, lo + per);
+				unsigned sink = 0;
+				for (size_t at = lo; at < hi; at += page)
+					sink += p[at];
+				(void) sink;
+			});
+		for (std::thread &th : pool)
+			th.join();
+	}
 	return true;
 }
 
