@@ -582,7 +582,7 @@ public:
 			stop = c_end + 65536 + 18; // enough for the whole block that starts at c_end
 		uint64_t max_piece = 6ull << 30;
 		if (const char *e = getenv("CONGA_GPU_BAM_MAX_MB"))
-			max_piece = (uint64_t) atoll(e) << 20;
+			max_piece = (uint64_t) (atof(e) * 1048576.0); // (fractions allowed: tests)
 		if (stop - c_lo < min_piece_bytes || stop - c_lo > max_piece)
 			return false; // (nothing has been read yet)
 		if (!bytes->open(path_, c_lo, stop))

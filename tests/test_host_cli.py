@@ -305,6 +305,10 @@ def test_cli_bam_decoded_on_the_gpu_matches_the_host_decoders(tmp_path, oracle):
     assert "decoding on the host" not in r_gpu.stderr and r_gpu.stderr.count("conga_reads_bgzf:") == 1
     r_host, host = cli("host", CONGA_GPU_BAM="0")
     assert gpu == host and gpu[1].count(b"\n") > 50
+    # a piece limit below the whole stretch but above each chromosome's: one GPU call per chromosome instead of one for all
+    size = os.path.getsize(os.path.join(d, "r.bam"))
+    r_each, each = cli("each", CONGA_GPU_BAM="1", CONGA_TIMING="1", CONGA_GPU_BAM_MAX_MB="%.4f" % (size * 0.75 / 1048576))
+    assert each == gpu and r_each.stderr.count("conga_reads_bgzf:") == 3 and "decoding on the host" not in r_each.stderr
     for rr in (r_gpu, r_host):
         import re
         assert [int(m) for m in re.findall(r"\((\d+) reads, 0 split-reads\)", rr.stderr)] == [len(x[2]) for x in reads]
