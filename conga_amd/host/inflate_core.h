@@ -344,21 +344,26 @@ CONGA_INFL_HD inline bool inflate_block_stream(Decoder &dec, const uint8_t *in, 
 				const size_t offset = ((e >> 13) & 0x7FFFu) + b.take((int) ((e >> 8) & 31u));
 				if (offset > (size_t) (op - out))
 					return false;
+				// Eight bytes at a time (up to seven more than `length` are written; there is room).  A match closer than eight
+				// bytes is periodic with its distance: after one period has been copied byte by byte the same bytes are also a
+				// match at twice the distance, so at most three short rounds get it to eight.  (On the GPU the lanes of a wave
+				// wait for the longest inner loop among them: a 258-byte run copied byte by byte was everybody's pace.)
 				const uint8_t *src = op - offset;
-				if (offset >= 8) {
-					uint8_t *d = op;
-					ptrdiff_t left = (ptrdiff_t) length;
-					do {
-						memcpy(d, src, 8);
-						d += 8;
-						src += 8;
-						left -= 8;
-					} while (left > 0);
-				} else if (offset == 1) {
-					memset(op, *src, length);
-				} else {
-					for (size_t i = 0; i < length; i++)
-						op[i] = src[i];
+				uint8_t *d = op;
+				ptrdiff_t left = (ptrdiff_t) length;
+				size_t dist = offset;
+				while (dist < 8 && left > 0) {
+					for (size_t i = 0; i < dist; i++)
+						d[i] = src[i];
+					d += dist;
+					left -= (ptrdiff_t) dist;
+					dist *= 2;
+				}
+				while (left > 0) {
+					memcpy(d, src, 8);
+					d += 8;
+					src += 8;
+					left -= 8;
 				}
 				op += length;
 			}
