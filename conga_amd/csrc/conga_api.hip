@@ -1115,7 +1115,7 @@ int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const
 	uint32_t lanes = (uint32_t) std::min<size_t>((n_blocks + 63) & ~(size_t) 63, 131072);
 	if (const char *e = getenv("CONGA_BGZF_LANES")) // (tests: few lanes, several blocks each)
 		lanes = std::min(lanes, (uint32_t) std::max(64, atoi(e) & ~63));
-	TRY(ensure(ctx, ctx->d_bz_in, n_bytes));
+	TRY(ensure(ctx, ctx->d_bz_in, n_bytes + 64)); // (the decoder reads a few aligned words ahead of its position)
 	TRY(ensure(ctx, ctx->d_bz_blocks, n_blocks * sizeof(conga_bgzf_block)));
 	TRY(ensure(ctx, ctx->d_bz_off, n_blocks * 8));
 	TRY(ensure(ctx, ctx->d_bz_out, (size_t) total + 16));

@@ -158,13 +158,42 @@ struct Bits {
 	uint64_t buf = 0;
 	int cnt = 0; // valid bits in buf; negative once more bits were consumed than the input holds
 
+	// the eight bytes at ip (at least eight are left)
+#if defined(__HIP_DEVICE_COMPILE__)
+	// On the GPU a load is the better part of a microsecond, so the input is read AHEAD: three aligned words slide along
+	// the stream, the newest of them asked for long before its bytes are needed, and next8() only shifts registers.
+	// (Reads up to 24 bytes past ip and 7 in front of the stream's first byte: the caller's buffer has that slack.)
+	const uint8_t *wbase = nullptr;
+	uint64_t w0 = 0, w1 = 0, w2 = 0;
+	__device__ inline uint64_t next8()
+	{
+		size_t off = (size_t) (ip - wbase);
+		if (off >= 16) { // first use, or the stream position jumped (stored block)
+			wbase = (const uint8_t *) ((uintptr_t) ip & ~(uintptr_t) 7);
+			w0 = *reinterpret_cast<const uint64_t *>(wbase);
+			w1 = *reinterpret_cast<const uint64_t *>(wbase + 8);
+			w2 = *reinterpret_cast<const uint64_t *>(wbase + 16);
+			off = (size_t) (ip - wbase);
+		} else if (off >= 8) {
+			w0 = w1;
+			w1 = w2;
+			wbase += 8;
+			w2 = *reinterpret_cast<const uint64_t *>(wbase + 16);
+			off -= 8;
+		}
+		return off ? (w0 >> (8 * off)) | (w1 << (64 - 8 * off)) : w0;
+	}
+#else
+	inline uint64_t next8() { return load64(ip); }
+#endif
+
 	// at least 56 valid bits afterwards, or everything that is left of the input
 	CONGA_INFL_HD inline void refill()
 	{
 		if (cnt < 0)
 			return; // (the caller is about to notice)
 		if (iend - ip >= 8) {
-			buf |= load64(ip) << cnt; // (bits above cnt are the stream's own next bits: or-ing them again later is harmless)
+			buf |= next8() << cnt; // (bits above cnt are the stream's own next bits: or-ing them again later is harmless)
 			ip += (63 - cnt) >> 3;
 			cnt |= 56;
 		} else {
@@ -177,7 +206,7 @@ struct Bits {
 	// the same with at least eight bytes of input left (the caller knows)
 	CONGA_INFL_HD inline void refill_fast()
 	{
-		buf |= load64(ip) << cnt;
+		buf |= next8() << cnt;
 		ip += (63 - cnt) >> 3;
 		cnt |= 56;
 	}
@@ -208,8 +237,110 @@ CONGA_INFL_HD inline uint32_t decode(Bits &b, const uint32_t *table, int first_b
 }
 
 
+// How a block's symbols are turned into bytes is a policy: this one is the sequential decoder (one stream per thread);
+// a GPU wave that decodes one stream with all its lanes brings its own (tools/gpu_inflate_wave.hip).
+struct SequentialSymbols {
+	// 0: the block's end-of-block symbol was reached; -1: the stream is invalid
+	CONGA_INFL_HD static inline int run(Bits &b, const uint32_t *lit, const uint32_t *dist, uint8_t *out, uint8_t *&op, uint8_t *oend)
+	{
+		// ---- the block's symbols.  One refill covers a whole length / distance pair: 15 + 5 + 15 + 13 = 48 bits.
+		for (bool end_of_block = false; !end_of_block;) {
+			// Fast trips: with 16 bytes of input ahead neither refill of a trip can run dry (each takes 7 bytes at most), and
+			// with 274 bytes of room neither three literals nor a 258-byte match copied in eight-byte steps can run over:
+			// no bounds checks inside.
+			while ((b.iend - b.ip) >= 16 && (oend - op) >= 274) {
+				b.refill_fast();
+				uint32_t e = decode(b, lit, kLitBits);
+				if (e & kLiteral) {
+					*op++ = (uint8_t) (e >> 13);
+					e = decode(b, lit, kLitBits);
+					if (e & kLiteral) {
+						*op++ = (uint8_t) (e >> 13);
+						e = decode(b, lit, kLitBits);
+						if (e & kLiteral) {
+							*op++ = (uint8_t) (e >> 13);
+							continue;
+						}
+					}
+					b.refill_fast();
+				}
+				if (!(e & kValid))
+					return -1;
+				if (e & kEnd) {
+					end_of_block = true;
+					break;
+				}
+				const size_t length = ((e >> 13) & 0x7FFFu) + b.take((int) ((e >> 8) & 31u));
+				e = decode(b, dist, kDistBits);
+				if (!(e & kValid))
+					return -1;
+				const size_t offset = ((e >> 13) & 0x7FFFu) + b.take((int) ((e >> 8) & 31u));
+				if (offset > (size_t) (op - out))
+					return -1;
+				// Eight bytes at a time (up to seven more than `length` are written; there is room).  A match closer than eight
+				// bytes is periodic with its distance: after one period has been copied byte by byte the same bytes are also a
+				// match at twice the distance, so at most three short rounds get it to eight.  (On the GPU the lanes of a wave
+				// wait for the longest inner loop among them: a 258-byte run copied byte by byte was everybody's pace.)
+				const uint8_t *src = op - offset;
+				uint8_t *d = op;
+				ptrdiff_t left = (ptrdiff_t) length;
+				size_t dist = offset;
+				while (dist < 8 && left > 0) {
+					for (size_t i = 0; i < dist; i++)
+						d[i] = src[i];
+					d += dist;
+					left -= (ptrdiff_t) dist;
+					dist *= 2;
+				}
+				while (left > 0) {
+					memcpy(d, src, 8);
+					d += 8;
+					src += 8;
+					left -= 8;
+				}
+				op += length;
+			}
+			if (end_of_block)
+				break;
+			// One careful trip (the ends of the input and of the output)
+			if (b.cnt < 0)
+				return -1;
+			b.refill();
+			uint32_t e = decode(b, lit, kLitBits);
+			if (e & kLiteral) {
+				if (op == oend)
+					return -1;
+				*op++ = (uint8_t) (e >> 13);
+				continue;
+			}
+			if (!(e & kValid))
+				return -1;
+			if (e & kEnd)
+				break;
+			const size_t length = ((e >> 13) & 0x7FFFu) + b.take((int) ((e >> 8) & 31u));
+			e = decode(b, dist, kDistBits);
+			if (!(e & kValid))
+				return -1;
+			const size_t offset = ((e >> 13) & 0x7FFFu) + b.take((int) ((e >> 8) & 31u));
+			if (b.cnt < 0 || offset > (size_t) (op - out) || length > (size_t) (oend - op))
+				return -1;
+			const uint8_t *src = op - offset;
+			for (size_t i = 0; i < length; i++)
+				op[i] = src[i];
+			op += length;
+		}
+		return 0;
+	}
+	CONGA_INFL_HD static inline void stored(uint8_t *op, const uint8_t *from, uint32_t len)
+	{
+		if (len)
+			memcpy(op, from, len);
+	}
+};
+
 // The decoder proper; `dec` is scratch (tables) owned by the calling thread.
-CONGA_INFL_HD inline bool inflate_block_stream(Decoder &dec, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len)
+template <typename Symbols>
+CONGA_INFL_HD inline bool inflate_block_stream_t(Decoder &dec, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len)
 {
 	Bits b;
 	b.ip = in;
@@ -237,8 +368,7 @@ CONGA_INFL_HD inline bool inflate_block_stream(Decoder &dec, const uint8_t *in, 
 			b.ip += 4;
 			if ((len ^ nlen) != 0xFFFFu || (size_t) (b.iend - b.ip) < len || (size_t) (oend - op) < len)
 				return false;
-			if (len)
-				memcpy(op, b.ip, len);
+			Symbols::stored(op, b.ip, len);
 			op += len;
 			b.ip += len;
 			if (final_block)
@@ -310,98 +440,19 @@ CONGA_INFL_HD inline bool inflate_block_stream(Decoder &dec, const uint8_t *in, 
 			return false;
 		}
 
-		// ---- the block's symbols.  One refill covers a whole length / distance pair: 15 + 5 + 15 + 13 = 48 bits.
-		for (bool end_of_block = false; !end_of_block;) {
-			// Fast trips: with 16 bytes of input ahead neither refill of a trip can run dry (each takes 7 bytes at most), and
-			// with 274 bytes of room neither three literals nor a 258-byte match copied in eight-byte steps can run over:
-			// no bounds checks inside.
-			while ((b.iend - b.ip) >= 16 && (oend - op) >= 274) {
-				b.refill_fast();
-				uint32_t e = decode(b, lit, kLitBits);
-				if (e & kLiteral) {
-					*op++ = (uint8_t) (e >> 13);
-					e = decode(b, lit, kLitBits);
-					if (e & kLiteral) {
-						*op++ = (uint8_t) (e >> 13);
-						e = decode(b, lit, kLitBits);
-						if (e & kLiteral) {
-							*op++ = (uint8_t) (e >> 13);
-							continue;
-						}
-					}
-					b.refill_fast();
-				}
-				if (!(e & kValid))
-					return false;
-				if (e & kEnd) {
-					end_of_block = true;
-					break;
-				}
-				const size_t length = ((e >> 13) & 0x7FFFu) + b.take((int) ((e >> 8) & 31u));
-				e = decode(b, dist, kDistBits);
-				if (!(e & kValid))
-					return false;
-				const size_t offset = ((e >> 13) & 0x7FFFu) + b.take((int) ((e >> 8) & 31u));
-				if (offset > (size_t) (op - out))
-					return false;
-				// Eight bytes at a time (up to seven more than `length` are written; there is room).  A match closer than eight
-				// bytes is periodic with its distance: after one period has been copied byte by byte the same bytes are also a
-				// match at twice the distance, so at most three short rounds get it to eight.  (On the GPU the lanes of a wave
-				// wait for the longest inner loop among them: a 258-byte run copied byte by byte was everybody's pace.)
-				const uint8_t *src = op - offset;
-				uint8_t *d = op;
-				ptrdiff_t left = (ptrdiff_t) length;
-				size_t dist = offset;
-				while (dist < 8 && left > 0) {
-					for (size_t i = 0; i < dist; i++)
-						d[i] = src[i];
-					d += dist;
-					left -= (ptrdiff_t) dist;
-					dist *= 2;
-				}
-				while (left > 0) {
-					memcpy(d, src, 8);
-					d += 8;
-					src += 8;
-					left -= 8;
-				}
-				op += length;
-			}
-			if (end_of_block)
-				break;
-			// One careful trip (the ends of the input and of the output)
-			if (b.cnt < 0)
-				return false;
-			b.refill();
-			uint32_t e = decode(b, lit, kLitBits);
-			if (e & kLiteral) {
-				if (op == oend)
-					return false;
-				*op++ = (uint8_t) (e >> 13);
-				continue;
-			}
-			if (!(e & kValid))
-				return false;
-			if (e & kEnd)
-				break;
-			const size_t length = ((e >> 13) & 0x7FFFu) + b.take((int) ((e >> 8) & 31u));
-			e = decode(b, dist, kDistBits);
-			if (!(e & kValid))
-				return false;
-			const size_t offset = ((e >> 13) & 0x7FFFu) + b.take((int) ((e >> 8) & 31u));
-			if (b.cnt < 0 || offset > (size_t) (op - out) || length > (size_t) (oend - op))
-				return false;
-			const uint8_t *src = op - offset;
-			for (size_t i = 0; i < length; i++)
-				op[i] = src[i];
-			op += length;
-		}
+		if (Symbols::run(b, lit, dist, out, op, oend) != 0)
+			return false;
 		if (final_block)
 			break;
 	}
 	return b.cnt >= 0 && op == oend;
 }
 
+
+CONGA_INFL_HD inline bool inflate_block_stream(Decoder &dec, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len)
+{
+	return inflate_block_stream_t<SequentialSymbols>(dec, in, in_len, out, out_len);
+}
 
 } // namespace inflate_core
 } // namespace conga_host

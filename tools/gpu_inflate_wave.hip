@@ -1,3 +1,6 @@
+// gpu_inflate_wave.hip -- PROTOTYPE of the next step: one BGZF block per WAVE.  All 64 lanes run
+// the block decoder of conga_amd/host/inflate_core.h in lockstep on the same stream (tables in LDS, no divergence);
+// a literal is stored by lane 0, a match is copied by all lanes.  Derived from
 // gpu_inflate.hip -- stand-alone benchmark of the idea behind conga_reads_bgzf's first stage (the product version is
 // bgzf_inflate_kernel in conga_amd/csrc/kernels_bam.hip.h): how fast does an MI355X inflate a BAM if every lane simply
 // runs the host's block decoder (conga_amd/host/inflate_core.h, the same source) on its own BGZF block?
@@ -16,17 +19,76 @@
 
 #include "../conga_amd/host/inflate_core.h"
 
-using conga_host::inflate_core::Decoder;
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+using namespace conga_host::inflate_core;
+
+// the bytes this wave has written are read back by its match copies: loads that bypass the L1 (stores go through to L2)
+__device__ __forceinline__ uint8_t load_written(const uint8_t *p)
+{
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct WaveSymbols {
+	__device__ static inline int run(Bits &b, const uint32_t *lit, const uint32_t *dist, uint8_t *out, uint8_t *&op, uint8_t *oend)
+	{
+		const int lane = threadIdx.x & 63;
+		for (;;) {
+			if (b.cnt < 0)
+				return -1;
+			b.refill();
+			uint32_t e = decode(b, lit, kLitBits);
+			if (e & kLiteral) { // (the same for every lane: no divergence)
+				if (op == oend)
+					return -1;
+				if (lane == 0)
+					*op = (uint8_t) (e >> 13);
+				op++;
+				continue;
+			}
+			if (!(e & kValid))
+				return -1;
+			if (e & kEnd)
+				return 0;
+			const size_t length = ((e >> 13) & 0x7FFFu) + b.take((int) ((e >> 8) & 31u));
+			e = decode(b, dist, kDistBits);
+			if (!(e & kValid))
+				return -1;
+			const size_t offset = ((e >> 13) & 0x7FFFu) + b.take((int) ((e >> 8) & 31u));
+			if (b.cnt < 0 || offset > (size_t) (op - out) || length > (size_t) (oend - op))
+				return -1;
+			// everything this wave stored so far has to be in L2 before the copy reads it there: wait for the stores'
+			// acknowledgements (s_waitcnt vmcnt(0); a release fence at agent scope also writes L2 back -- microseconds)
+			__builtin_amdgcn_s_waitcnt(0x0F70);
+			const uint8_t *src = op - offset;
+			for (size_t k = (size_t) lane; k < length; k += 64)
+				op[k] = load_written(src + (offset >= length ? k : k % offset));
+			op += length;
+		}
+	}
+	__device__ static inline void stored(uint8_t *op, const uint8_t *from, uint32_t len)
+	{
+		for (uint32_t k = threadIdx.x & 63; k < len; k += 64)
+			op[k] = from[k];
+	}
+};
 
 __global__ __launch_bounds__(64) void inflate_kernel(int n_blocks, const uint8_t *in, const uint64_t *c_off, const uint32_t *c_len,
 		uint8_t *out, const uint64_t *o_off, const uint32_t *o_len, Decoder *scratch, uint8_t *ok)
 {
-	const int t = blockIdx.x * blockDim.x + threadIdx.x;
-	if (t >= n_blocks)
-		return;
-	ok[t] = conga_host::inflate_core::inflate_block_stream(scratch[t], in + c_off[t], c_len[t], out + o_off[t], o_len[t]) ? 1 : 0;
+	__shared__ __attribute__((aligned(16))) unsigned char dec_raw[sizeof(Decoder)]; // the wave's tables
+	Decoder &dec = *reinterpret_cast<Decoder *>(dec_raw);
+	(void) scratch;
+	for (int t = blockIdx.x; t < n_blocks; t += gridDim.x) {
+		if (threadIdx.x == 0)
+			dec.fixed_ready = false;
+		__builtin_amdgcn_wave_barrier();
+		const bool good = inflate_block_stream_t<WaveSymbols>(dec, in + c_off[t], c_len[t], out + o_off[t], o_len[t]);
+		if (threadIdx.x == 0)
+			ok[t] = good ? 1 : 0;
+		__builtin_amdgcn_wave_barrier();
+	}
 }
 
 int main(int argc, char **argv)
@@ -91,9 +153,8 @@ int main(int argc, char **argv)
 	CHECK(hipMalloc(&d_o_off, (size_t) n * 8));
 	CHECK(hipMalloc(&d_c_len, (size_t) n * 4));
 	CHECK(hipMalloc(&d_o_len, (size_t) n * 4));
-	CHECK(hipMalloc(&d_scratch, (size_t) n * sizeof(Decoder)));
-	CHECK(hipMemset(d_scratch, 0, (size_t) n * sizeof(Decoder)));
-	printf("decoder scratch: %.1f KB per lane, %.2f GB\n", sizeof(Decoder) / 1e3, (double) n * sizeof(Decoder) / 1e9);
+	CHECK(hipMalloc(&d_scratch, sizeof(Decoder)));
+	printf("tables: %.1f KB of LDS per wave\n", sizeof(Decoder) / 1e3);
 	auto t0 = std::chrono::steady_clock::now();
 	CHECK(hipMemcpy(d_in, file.data(), size, hipMemcpyHostToDevice));
 	auto t1 = std::chrono::steady_clock::now();
@@ -107,7 +168,7 @@ int main(int argc, char **argv)
 	float best = 1e30f;
 	for (int rep = 0; rep < 3; rep++) {
 		CHECK(hipEventRecord(e0));
-		hipLaunchKernelGGL(inflate_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, n, d_in, d_c_off, d_c_len, d_out, d_o_off, d_o_len, d_scratch, d_ok);
+		hipLaunchKernelGGL(inflate_kernel, dim3(n < 256 * 9 ? n : 256 * 9), dim3(64), 0, 0, n, d_in, d_c_off, d_c_len, d_out, d_o_off, d_o_len, d_scratch, d_ok);
 		CHECK(hipEventRecord(e1));
 		CHECK(hipEventSynchronize(e1));
 		float ms;
