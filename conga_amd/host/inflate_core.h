@@ -331,8 +331,9 @@ struct SequentialSymbols {
 		}
 		return 0;
 	}
-	CONGA_INFL_HD static inline void stored(uint8_t *op, const uint8_t *from, uint32_t len)
+	CONGA_INFL_HD static inline void stored(uint8_t *out, uint8_t *op, const uint8_t *from, uint32_t len)
 	{
+		(void) out;
 		if (len)
 			memcpy(op, from, len);
 	}
@@ -368,7 +369,7 @@ CONGA_INFL_HD inline bool inflate_block_stream_t(Decoder &dec, const uint8_t *in
 			b.ip += 4;
 			if ((len ^ nlen) != 0xFFFFu || (size_t) (b.iend - b.ip) < len || (size_t) (oend - op) < len)
 				return false;
-			Symbols::stored(op, b.ip, len);
+			Symbols::stored(out, op, b.ip, len);
 			op += len;
 			b.ip += len;
 			if (final_block)

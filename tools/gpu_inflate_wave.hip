@@ -67,8 +67,9 @@ struct WaveSymbols {
 			op += length;
 		}
 	}
-	__device__ static inline void stored(uint8_t *op, const uint8_t *from, uint32_t len)
+	__device__ static inline void stored(uint8_t *out, uint8_t *op, const uint8_t *from, uint32_t len)
 	{
+		(void) out;
 		for (uint32_t k = threadIdx.x & 63; k < len; k += 64)
 			op[k] = from[k];
 	}
