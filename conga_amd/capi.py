@@ -37,7 +37,8 @@ KERNEL_NAMES = ("ingest", "depth_tile", "expected_table", "paint", "interval_red
 EXPORTS = (
     "conga_create", "conga_destroy", "conga_strerror", "conga_last_error", "conga_abi_version",
     "conga_device_count", "conga_reset", "conga_chrom_count", "conga_chrom_select", "conga_chrom_begin", "conga_reads_staging", "conga_reads_commit",
-    "conga_reads_bgzf",
+    "conga_reads_bgzf", "conga_host_alloc", "conga_host_free", "conga_sample_reads", "conga_sample_begin",
+    "conga_sample_chrom", "conga_sample_fetch",
     "conga_mappability", "conga_intervals", "conga_reference", "conga_satellites", "conga_split_reads_staging",
     "conga_split_reads_commit", "conga_split_support", "conga_chrom_compute",
     "conga_chrom_fetch", "conga_chrom_finish", "conga_results_device", "conga_results_copy",
@@ -132,6 +133,20 @@ def load():
     L.conga_reads_staging.argtypes = [vp, C.POINTER(ReadStaging)]
     L.conga_reads_commit.restype = C.c_int
     L.conga_reads_commit.argtypes = [vp, sz]
+    L.conga_reads_bgzf.restype = C.c_int
+    L.conga_reads_bgzf.argtypes = [vp, vp, sz, C.POINTER(BgzfBlock), sz, C.POINTER(BamSegment), sz, C.POINTER(C.c_uint64)]
+    L.conga_host_alloc.restype = vp
+    L.conga_host_alloc.argtypes = [vp, sz]
+    L.conga_host_free.restype = None
+    L.conga_host_free.argtypes = [vp, vp]
+    L.conga_sample_reads.restype = C.c_int
+    L.conga_sample_reads.argtypes = [vp, vp, vp, vp, C.c_int]
+    L.conga_sample_begin.restype = C.c_int
+    L.conga_sample_begin.argtypes = [vp]
+    L.conga_sample_chrom.restype = C.c_int
+    L.conga_sample_chrom.argtypes = [vp, C.c_int]
+    L.conga_sample_fetch.restype = C.c_int
+    L.conga_sample_fetch.argtypes = [vp, vp, sz, vp, C.POINTER(ChromStats)]
     L.conga_mappability.restype = C.c_int
     L.conga_mappability.argtypes = [vp, vp, vp, vp, sz]
     L.conga_intervals.restype = C.c_int
@@ -193,9 +208,11 @@ class Context:
         self.batch = bool(flags & FLAG_BATCH)
         self._meta = []   # per chromosome: [length, n_dels, n_dups]
         self._cur = -1
+        self._pinned = []
 
     def close(self):
         if getattr(self, "_h", None):
+            self.host_free_all()
             self._lib.conga_destroy(self._h)
             self._h = None
 
@@ -271,6 +288,59 @@ class Context:
             off += k
             if n == 0:
                 break
+
+    # -- cohort mode: the next sample's reads behind the same layout ----------------------------
+    def host_alloc(self, n, dtype):
+        """A pinned host array (conga_host_alloc) as numpy; freed with the context (or by host_free)."""
+        dt = np.dtype(dtype)
+        nbytes = max(int(n) * dt.itemsize, 1)
+        p = self._lib.conga_host_alloc(self._h, nbytes)
+        if not p:
+            raise CongaError(CONGA_ERR_NOMEM, self._lib.conga_last_error(self._h).decode())
+        self._pinned.append(p)
+        buf = (C.c_uint8 * nbytes).from_address(p)
+        return np.frombuffer(buf, dtype=dt, count=int(n))
+
+    def host_free_all(self):
+        for p in self._pinned:
+            self._lib.conga_host_free(self._h, p)
+        self._pinned = []
+
+    def sample_reads(self, pos, mapq, chrom_off):
+        """Replaces the reads of every chromosome; pos / mapq / chrom_off are passed as they are (no copy: the caller
+        keeps them alive and unchanged until the next fetch / sync).  Pinned arrays (host_alloc) go at PCIe rate."""
+        if pos.dtype != np.int32 or mapq.dtype != np.uint8 or chrom_off.dtype != np.uint64:
+            raise TypeError("sample_reads takes int32 pos, uint8 mapq, uint64 chrom_off")
+        self._check(self._lib.conga_sample_reads(self._h, pos.ctypes.data, mapq.ctypes.data, chrom_off.ctypes.data,
+                                                 len(chrom_off) - 1))
+
+    def sample_begin(self):
+        self._check(self._lib.conga_sample_begin(self._h))
+
+    def sample_chrom(self, index):
+        self._check(self._lib.conga_sample_chrom(self._h, index))
+
+    def sample_fetch(self, records=None, expected=None, want_stats=False):
+        """Every chromosome's records in one call -> (records RESULT_DTYPE[n_records], E float32[n_chrom, 101], stats|None)."""
+        n, nc = self.n_records, len(self._meta)
+        if records is None:
+            records = np.zeros(n, dtype=RESULT_DTYPE)
+        if expected is None:
+            expected = np.zeros((nc, 101), dtype=np.float32)
+        st = (ChromStats * nc)() if want_stats else None
+        self._check(self._lib.conga_sample_fetch(self._h, records.ctypes.data if n else None, n, expected.ctypes.data, st))
+        return records, expected, st
+
+    def reads_bgzf(self, data, blocks, segments):
+        """conga_reads_bgzf: a stretch of a BAM file as it is on disk + its block table + start points.
+        blocks: [(data_off, data_len, inflated_len, crc32)], segments: [(start, pos_lo, pos_hi, ref_id, chrom)].
+        -> reads per chromosome"""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        bl = (BgzfBlock * len(blocks))(*[BgzfBlock(*b, 0) for b in blocks])
+        sg = (BamSegment * len(segments))(*[BamSegment(*x) for x in segments])
+        per = (C.c_uint64 * max(self.chrom_count(), 1))()
+        self._check(self._lib.conga_reads_bgzf(self._h, data.ctypes.data, len(data), bl, len(blocks), sg, len(segments), per))
+        return list(per)[:self.chrom_count()]
 
     def mappability(self, start, end, val):
         s = np.ascontiguousarray(start, dtype=np.int32)

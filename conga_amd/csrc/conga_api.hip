@@ -82,7 +82,9 @@ struct conga_ctx {
 	int32_t step = 100, tile_len = 0;
 	std::vector<HostSlot> slots;
 	int cur = -1; // selected slot
-	bool layout_dirty = true;
+	bool layout_dirty = true; // chromosomes, GC arrays, intervals, tracks or split-read inputs changed: prepare_layout()
+	bool sample_dirty = true; // only the read tuples changed (another sample behind the same layout): prepare_sample()
+	int read_target = -1;     // chromosome conga_reads_commit() appends to; -1: the one begun last
 
 	// reads
 	int64_t n_reads_total = 0;
@@ -93,6 +95,7 @@ struct conga_ctx {
 	uint32_t tuple_chunks = 0, tuple_chunks_per_block = 1; // geometry of the tuple pass (prepare)
 	int small_cur = 0, small_cur_next = 0;
 	bool arena_zeroed[2] = {false, false};
+	bool layout_dense = false;   // formulation prepare_layout() laid the tracks out for (track_painted depends on it)
 	bool wrap_risk = false;      // some position may hold more than 32767 reads: only the dense kernels reproduce the `short` wrap
 	bool depth_resident = false; // read_depth[] of the last compute is in d_rd
 	Staging staging[kStagingRing];
@@ -109,7 +112,12 @@ struct conga_ctx {
 	bool sr_staged = false;
 
 	// device buffers
-	DevBuf d_pos, d_mapq, d_tile_start, d_small_scratch, d_item_r0, d_item_r1, d_item_row0, d_item_row1, d_item_rt_off, d_block_home, d_item_lo, d_rd, d_gc_hist, d_gc_like, d_slots, d_small, d_map, d_winner,
+	DevBuf d_head; // per sample: [Slot table | TupleBlockHome table], one upload from h_head; d_slots / d_block_home point into it
+	void *h_head = nullptr;
+	size_t h_head_cap = 0;
+	hipEvent_t ev_head = nullptr; // the upload from h_head
+	bool head_in_flight = false;
+	DevBuf d_pos, d_mapq, d_tile_start, d_small_scratch, d_item_slot, d_item_row0, d_item_row1, d_item_rt_off, d_block_home, d_item_lo, d_rd, d_gc_hist, d_gc_like, d_slots, d_small, d_map, d_winner,
 			d_map_start, d_map_end, d_map_val, d_iv_start, d_iv_end, d_iv_type, d_iv_slot, d_iv_has_map, d_order,
 			d_expected, d_item_off, d_item_len, d_item_iv, d_item_has_map, d_item_first, d_map_part,
 			d_support, d_results, d_bases, d_row_tile, d_depth_blocks, d_support_base, d_ref, d_sat_start, d_sat_end, d_sr_pos,
@@ -253,8 +261,93 @@ bool batch_mode(const conga_ctx *ctx)
 	return (ctx->opts.flags & CONGA_FLAG_BATCH) != 0;
 }
 
-// Lay the batch out in the concatenated buffers and upload everything that is not a read tuple.
-int prepare(conga_ctx *ctx)
+// What depends on the read tuples of the sample and on nothing else: where each chromosome's tuples lie, and the
+// geometry of the pass over them.  One small upload from a pinned block, no wait: this is all that stands between
+// "another sample's tuples are in HBM" and the kernels when the layout is unchanged (a cohort against one call set).
+int prepare_sample(conga_ctx *ctx)
+{
+	const int n_slots = (int) ctx->slots.size();
+	drop_graph(ctx); // sizes and grids below are baked into a captured step
+	// the tuples lie in chromosome order (both producers append that way)
+	{
+		int64_t at = 0;
+		for (HostSlot &h : ctx->slots) {
+			h.read_off = at;
+			at += h.n_reads;
+		}
+	}
+	ctx->tuple_chunks = (uint32_t) ((ctx->n_reads_total + kTupleChunk - 1) / kTupleChunk);
+	int blocks = ctx->n_cu * ctx->tuple_blocks_per_cu;
+	if (const char *e = getenv("CONGA_TUPLE_BLOCKS_PER_CU")) // tuning knob
+		blocks = ctx->n_cu * std::max(1, atoi(e));
+	ctx->tuple_chunks_per_block = std::max<uint32_t>(1, (ctx->tuple_chunks + (uint32_t) blocks - 1) / (uint32_t) blocks);
+	const uint32_t grid = (ctx->tuple_chunks + ctx->tuple_chunks_per_block - 1) / ctx->tuple_chunks_per_block;
+	const size_t n_homes = std::max<uint32_t>(grid, 1);
+	const size_t homes_at = ((size_t) std::max(n_slots, 1) * sizeof(Slot) + 255) & ~(size_t) 255;
+	const size_t bytes = homes_at + n_homes * sizeof(TupleBlockHome);
+	if (bytes > ctx->h_head_cap) {
+		if (ctx->head_in_flight)
+			HIP_TRY(ctx, hipEventSynchronize(ctx->ev_head));
+		ctx->head_in_flight = false;
+		if (ctx->h_head)
+			(void) hipHostFree(ctx->h_head);
+		ctx->h_head = nullptr;
+		ctx->h_head_cap = 0;
+		const size_t cap = bytes + bytes / 2 + 4096;
+		HIP_TRY(ctx, hipHostMalloc(&ctx->h_head, cap, hipHostMallocDefault));
+		ctx->h_head_cap = cap;
+	}
+	TRY(ensure(ctx, ctx->d_head, bytes));
+	if (ctx->head_in_flight) { // the previous sample's upload still reads the pinned block
+		HIP_TRY(ctx, hipEventSynchronize(ctx->ev_head));
+		ctx->head_in_flight = false;
+	}
+	Slot *dslots = static_cast<Slot *>(ctx->h_head);
+	for (int s = 0; s < n_slots; s++) {
+		const HostSlot &h = ctx->slots[s];
+		Slot &d = dslots[s];
+		d.L = h.L;
+		d.rd_off = h.rd_off;
+		d.read_off = h.read_off;
+		d.n_reads = h.n_reads;
+		d.gc_off = h.gc_off;
+		d.n_win = h.n_win;
+		d.tile0 = h.tile0;
+		d.n_tiles = h.n_tiles;
+		d.tidx_off = h.tidx_off;
+	}
+	// tuple pass: contiguous runs of 1024-tuple chunks per workgroup, and the chromosome each run starts in
+	TupleBlockHome *homes = reinterpret_cast<TupleBlockHome *>(static_cast<char *>(ctx->h_head) + homes_at);
+	int s = 0;
+	for (uint32_t b = 0; b < (uint32_t) n_homes; b++) {
+		TupleBlockHome &bh = homes[b];
+		memset(&bh, 0, sizeof bh);
+		bh.sl.r0 = 1; // empty range
+		bh.slot = -1;
+		const int64_t base = (int64_t) b * ctx->tuple_chunks_per_block * kTupleChunk;
+		while (s + 1 < n_slots && ctx->slots[s + 1].read_off <= base)
+			s++;
+		const HostSlot &h = ctx->slots[s];
+		if (base >= h.read_off && base + kTupleChunk <= h.read_off + h.n_reads) { // first chunk inside one chromosome
+			bh.sl.r0 = (uint32_t) h.read_off;
+			bh.sl.r1 = (uint32_t) (h.read_off + h.n_reads);
+			bh.sl.L = (int32_t) h.L;
+			bh.sl.gc_off = (uint32_t) h.gc_off;
+			bh.slot = s;
+		}
+	}
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_head.p, ctx->h_head, bytes, hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipEventRecord(ctx->ev_head, ctx->stream));
+	ctx->head_in_flight = true;
+	ctx->d_slots.p = ctx->d_head.p;
+	ctx->d_block_home.p = static_cast<char *>(ctx->d_head.p) + homes_at;
+	ctx->sample_dirty = false;
+	return CONGA_OK;
+}
+
+// Lay the batch out in the concatenated buffers and upload everything that is not a read tuple and does not depend on
+// the tuples: with the same chromosomes, intervals and tracks it is done once for any number of samples.
+int prepare_layout(conga_ctx *ctx)
 {
 	const int n_slots = (int) ctx->slots.size();
 	drop_graph(ctx); // buffers, sizes and grids below are baked into the captured step
@@ -266,7 +359,6 @@ int prepare(conga_ctx *ctx)
 	ctx->any_map_painted = false;
 	ctx->any_map_rows = false;
 	ctx->support_given = false;
-	std::vector<Slot> dslots(n_slots);
 	for (int s = 0; s < n_slots; s++) {
 		HostSlot &h = ctx->slots[s];
 		h.rd_off = rd_off;
@@ -275,16 +367,6 @@ int prepare(conga_ctx *ctx)
 		h.tidx_off = tile0 + s;
 		h.iv0 = iv0;
 		h.map_row_off = map_rows;
-		Slot &d = dslots[s];
-		d.L = h.L;
-		d.rd_off = h.rd_off;
-		d.read_off = h.read_off;
-		d.n_reads = h.n_reads;
-		d.gc_off = h.gc_off;
-		d.n_win = h.n_win;
-		d.tile0 = h.tile0;
-		d.n_tiles = h.n_tiles;
-		d.tidx_off = h.tidx_off;
 		rd_off += (h.L + kDepthMaxTile - 1) & ~(int64_t) (kDepthMaxTile - 1); // whole tiles: 4 KiB-aligned regions
 		gc_off += (h.n_win + 15) & ~(int64_t) 15;
 		tile0 += h.n_tiles;
@@ -307,38 +389,10 @@ int prepare(conga_ctx *ctx)
 	ctx->total_gc = gc_off;
 	ctx->total_tiles = tile0;
 	ctx->n_iv = iv0;
+	ctx->layout_dense = dense_formulation(ctx);
+	ctx->sample_dirty = true; // the Slot table carries layout offsets too
+	TRY(prepare_sample(ctx)); // (gc_bases_kernel below reads the Slot table)
 
-	TRY(upload(ctx, ctx->d_slots, dslots.data(), dslots.size() * sizeof(Slot)));
-	{
-		// tuple pass geometry: contiguous runs of 1024-tuple chunks per workgroup, and the chromosome each run starts in
-		ctx->tuple_chunks = (uint32_t) ((ctx->n_reads_total + kTupleChunk - 1) / kTupleChunk);
-		int blocks = ctx->n_cu * ctx->tuple_blocks_per_cu;
-		if (const char *e = getenv("CONGA_TUPLE_BLOCKS_PER_CU")) // tuning knob
-			blocks = ctx->n_cu * std::max(1, atoi(e));
-		ctx->tuple_chunks_per_block = std::max<uint32_t>(1, (ctx->tuple_chunks + (uint32_t) blocks - 1) / (uint32_t) blocks);
-		const uint32_t grid = (ctx->tuple_chunks + ctx->tuple_chunks_per_block - 1) / ctx->tuple_chunks_per_block;
-		std::vector<TupleBlockHome> homes(std::max<uint32_t>(grid, 1));
-		int s = 0;
-		for (uint32_t b = 0; b < grid; b++) {
-			TupleBlockHome &bh = homes[b];
-			memset(&bh, 0, sizeof bh);
-			bh.sl.r0 = 1; // empty range
-			bh.slot = -1;
-			const int64_t base = (int64_t) b * ctx->tuple_chunks_per_block * kTupleChunk;
-			while (s + 1 < n_slots && ctx->slots[s + 1].read_off <= base)
-				s++;
-			const HostSlot &h = ctx->slots[s];
-			if (base >= h.read_off && base + kTupleChunk <= h.read_off + h.n_reads) { // first chunk inside one chromosome
-				bh.sl.r0 = (uint32_t) h.read_off;
-				bh.sl.r1 = (uint32_t) (h.read_off + h.n_reads);
-				bh.sl.L = (int32_t) h.L;
-				bh.sl.gc_off = (uint32_t) h.gc_off;
-				bh.slot = s;
-			}
-		}
-		TRY(upload(ctx, ctx->d_block_home, homes.data(), homes.size() * sizeof(TupleBlockHome)));
-		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // `homes` dies here
-	}
 	{
 		// depth workgroups: contiguous tile ranges that never cross a chromosome, dispatched in genome order
 		std::vector<DepthBlock> blocks;
@@ -538,7 +592,8 @@ int prepare(conga_ctx *ctx)
 		// reduce work items: [start, min(end, L)) cut into kItemLen pieces
 		std::vector<int64_t> item_off;
 		std::vector<int32_t> item_len, item_iv, item_lo;
-		std::vector<uint32_t> item_r0, item_r1, item_row0, item_row1, item_rt_off;
+		std::vector<int32_t> item_slot;
+		std::vector<uint32_t> item_row0, item_row1, item_rt_off;
 		std::vector<uint8_t> item_has_map;
 		item_off.reserve(n + n / 2);
 		item_len.reserve(n + n / 2);
@@ -554,8 +609,7 @@ int prepare(conga_ctx *ctx)
 				item_iv.push_back((int32_t) i);
 				item_has_map.push_back(iv_has_map[i]);
 				item_lo.push_back((int32_t) a);
-				item_r0.push_back((uint32_t) h.read_off);
-				item_r1.push_back((uint32_t) (h.read_off + h.n_reads));
+				item_slot.push_back(iv_slot[i]);
 				item_row0.push_back((uint32_t) h.map_row_off);
 				item_row1.push_back((uint32_t) (h.map_row_off + (int64_t) h.map_start.size()));
 				item_rt_off.push_back((uint32_t) h.row_tile_off);
@@ -576,8 +630,7 @@ int prepare(conga_ctx *ctx)
 		TRY(upload(ctx, ctx->d_item_iv, item_iv.data(), item_iv.size() * 4));
 		TRY(upload(ctx, ctx->d_item_has_map, item_has_map.data(), item_has_map.size()));
 		TRY(upload(ctx, ctx->d_item_lo, item_lo.data(), item_lo.size() * 4));
-		TRY(upload(ctx, ctx->d_item_r0, item_r0.data(), item_r0.size() * 4));
-		TRY(upload(ctx, ctx->d_item_r1, item_r1.data(), item_r1.size() * 4));
+		TRY(upload(ctx, ctx->d_item_slot, item_slot.data(), item_slot.size() * 4));
 		TRY(upload(ctx, ctx->d_item_row0, item_row0.data(), item_row0.size() * 4));
 		TRY(upload(ctx, ctx->d_item_row1, item_row1.data(), item_row1.size() * 4));
 		TRY(upload(ctx, ctx->d_item_rt_off, item_rt_off.data(), item_rt_off.size() * 4));
@@ -644,7 +697,9 @@ void reset_slots(conga_ctx *ctx)
 	ctx->sr_bytes_total = 0;
 	ctx->sr_staged = false;
 	ctx->staging_cur = -1;
+	ctx->read_target = -1;
 	ctx->layout_dirty = true;
+	ctx->sample_dirty = true;
 	ctx->computed = false;
 }
 
@@ -861,7 +916,8 @@ conga_ctx *conga_create(int device, const conga_opts *opts, int *status)
 	}
 	if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess)
 		return bail(CONGA_ERR_HIP);
-	if (hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming) != hipSuccess)
+	if (hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming) != hipSuccess
+			|| hipEventCreateWithFlags(&ctx->ev_head, hipEventDisableTiming) != hipSuccess)
 		return bail(CONGA_ERR_HIP);
 	if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess
 			|| hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess
@@ -896,9 +952,10 @@ void conga_destroy(conga_ctx *ctx)
 		(void) hipEventDestroy(ctx->ev_counted);
 	if (ctx->ev_join)
 		(void) hipEventDestroy(ctx->ev_join);
-	DevBuf *bufs[] = {&ctx->d_pos, &ctx->d_mapq, &ctx->d_tile_start, &ctx->d_small_scratch, &ctx->d_item_r0,
-			&ctx->d_item_r1, &ctx->d_item_row0, &ctx->d_item_row1, &ctx->d_item_rt_off, &ctx->d_block_home, &ctx->d_item_lo, &ctx->d_rd, &ctx->d_gc_hist, &ctx->d_gc_like,
-			&ctx->d_slots, &ctx->d_small, &ctx->d_map, &ctx->d_winner, &ctx->d_map_start, &ctx->d_map_end,
+	// (d_slots and d_block_home are views into d_head)
+	DevBuf *bufs[] = {&ctx->d_pos, &ctx->d_mapq, &ctx->d_tile_start, &ctx->d_small_scratch, &ctx->d_item_slot,
+			&ctx->d_head, &ctx->d_item_row0, &ctx->d_item_row1, &ctx->d_item_rt_off, &ctx->d_item_lo, &ctx->d_rd, &ctx->d_gc_hist, &ctx->d_gc_like,
+			&ctx->d_small, &ctx->d_map, &ctx->d_winner, &ctx->d_map_start, &ctx->d_map_end,
 			&ctx->d_map_val, &ctx->d_iv_start, &ctx->d_iv_end, &ctx->d_iv_type, &ctx->d_iv_slot, &ctx->d_iv_has_map,
 			&ctx->d_order, &ctx->d_bz_in, &ctx->d_bz_blocks, &ctx->d_bz_off, &ctx->d_bz_out, &ctx->d_bz_status, &ctx->d_bz_scratch,
 			&ctx->d_bz_crc, &ctx->d_bz_seg, &ctx->d_bz_cnt, &ctx->d_bz_first, &ctx->d_bz_stop, &ctx->d_bz_bad, &ctx->d_bz_at, &ctx->d_bz_flag, &ctx->d_expected, &ctx->d_item_off, &ctx->d_item_len, &ctx->d_item_iv,
@@ -925,6 +982,10 @@ void conga_destroy(conga_ctx *ctx)
 	}
 	if (ctx->h_small)
 		(void) hipHostFree(ctx->h_small);
+	if (ctx->h_head)
+		(void) hipHostFree(ctx->h_head);
+	if (ctx->ev_head)
+		(void) hipEventDestroy(ctx->ev_head);
 	if (ctx->h_results)
 		(void) hipHostFree(ctx->h_results);
 	if (ctx->ev_done)
@@ -987,6 +1048,7 @@ int conga_chrom_begin(conga_ctx *ctx, int64_t chrom_len, const uint8_t *gc_hist_
 		h.gc_like.assign(gc_like_w, gc_like_w + n_win);
 	ctx->slots.push_back(std::move(h));
 	ctx->cur = (int) ctx->slots.size() - 1;
+	ctx->read_target = -1; // reads stream into the chromosome begun last
 	ctx->layout_dirty = true;
 	ctx->computed = false;
 	return CONGA_OK;
@@ -1039,7 +1101,8 @@ int conga_reads_commit(conga_ctx *ctx, size_t n)
 		return fail(ctx, CONGA_ERR_INVALID, "conga_reads_commit: call conga_reads_staging first");
 	if (n > kStagingTuples)
 		return fail(ctx, CONGA_ERR_INVALID, "conga_reads_commit: n exceeds the staging capacity");
-	HostSlot &h = ctx->slots.back(); // reads stream into the chromosome begun last (BAM order)
+	// reads stream into the chromosome begun last (BAM order), or the one conga_sample_chrom() named
+	HostSlot &h = ctx->read_target >= 0 ? ctx->slots[(size_t) ctx->read_target] : ctx->slots.back();
 	if (n && h.device_fed)
 		return fail(ctx, CONGA_ERR_INVALID, "conga_reads_commit: this chromosome's reads came from conga_reads_bgzf");
 	if ((uint64_t) ctx->n_reads_total + n >= 0xFFFFFFF0ull)
@@ -1063,8 +1126,118 @@ int conga_reads_commit(conga_ctx *ctx, size_t n)
 	h.n_reads += (int64_t) n;
 	ctx->n_reads_total += (int64_t) n;
 	ctx->staging_next = (ctx->staging_next + 1) % kStagingRing;
-	ctx->layout_dirty = true;
+	ctx->sample_dirty = true;
 	ctx->computed = false;
+	return CONGA_OK;
+}
+
+// ---- cohort mode: another sample's reads behind the layout the context already holds ------------------------------
+
+void *conga_host_alloc(conga_ctx *ctx, size_t bytes)
+{
+	if (!ctx || bytes == 0 || hipSetDevice(ctx->device) != hipSuccess)
+		return nullptr;
+	void *p = nullptr;
+	if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+		(void) hipGetLastError();
+		ctx->err = "conga_host_alloc: hipHostMalloc failed";
+		return nullptr;
+	}
+	return p;
+}
+
+void conga_host_free(conga_ctx *ctx, void *p)
+{
+	if (!ctx || !p)
+		return;
+	(void) hipSetDevice(ctx->device);
+	(void) hipHostFree(p);
+}
+
+namespace {
+
+// Forget the reads of every chromosome; chromosomes, GC arrays, intervals, tracks and the device layout stay.
+int drop_reads(conga_ctx *ctx, const char *who)
+{
+	if (ctx->slots.empty())
+		return fail(ctx, CONGA_ERR_INVALID, std::string(who) + ": no chromosome open");
+	if (ctx->staging_cur >= 0)
+		return fail(ctx, CONGA_ERR_INVALID, std::string(who) + ": a staging buffer is handed out and not committed");
+	if (ctx->n_sr_total > 0)
+		return fail(ctx, CONGA_ERR_INVALID, std::string(who) + ": not with split reads (their records belong to one sample)");
+	for (HostSlot &h : ctx->slots) {
+		h.read_off = 0;
+		h.n_reads = 0;
+		h.device_fed = false;
+		h.tail_val = 0;
+		h.tail_len = 0;
+	}
+	ctx->n_reads_total = 0;
+	ctx->wrap_risk = false;
+	ctx->depth_resident = false;
+	ctx->sample_dirty = true;
+	ctx->computed = false;
+	return CONGA_OK;
+}
+
+} // namespace
+
+int conga_sample_begin(conga_ctx *ctx)
+{
+	if (!ctx)
+		return CONGA_ERR_INVALID;
+	TRY(drop_reads(ctx, "conga_sample_begin"));
+	ctx->read_target = 0;
+	return CONGA_OK;
+}
+
+int conga_sample_chrom(conga_ctx *ctx, int index)
+{
+	if (!ctx)
+		return CONGA_ERR_INVALID;
+	if (index < 0 || index >= (int) ctx->slots.size())
+		return fail(ctx, CONGA_ERR_INVALID, "conga_sample_chrom: no such chromosome");
+	if (ctx->staging_cur >= 0)
+		return fail(ctx, CONGA_ERR_INVALID, "conga_sample_chrom: a staging buffer is handed out and not committed");
+	// the tuples of a context lie in chromosome order: no later chromosome may have reads yet
+	for (size_t c = (size_t) index + 1; c < ctx->slots.size(); c++)
+		if (ctx->slots[c].n_reads != 0)
+			return fail(ctx, CONGA_ERR_INVALID, "conga_sample_chrom: a later chromosome already has reads (ascending order only)");
+	ctx->read_target = index;
+	return CONGA_OK;
+}
+
+int conga_sample_reads(conga_ctx *ctx, const int32_t *pos, const uint8_t *mapq, const uint64_t *chrom_off, int n_chrom)
+{
+	if (!ctx || !chrom_off)
+		return CONGA_ERR_INVALID;
+	if (n_chrom != (int) ctx->slots.size())
+		return fail(ctx, CONGA_ERR_INVALID, "conga_sample_reads: n_chrom differs from the chromosomes the context holds");
+	const uint64_t total = chrom_off[n_chrom];
+	if (chrom_off[0] != 0 || (total && (!pos || !mapq)))
+		return fail(ctx, CONGA_ERR_INVALID, "conga_sample_reads: chrom_off must start at 0 and the arrays must be given");
+	for (int c = 0; c < n_chrom; c++)
+		if (chrom_off[c + 1] < chrom_off[c])
+			return fail(ctx, CONGA_ERR_INVALID, "conga_sample_reads: chrom_off must not decrease");
+	if (total >= 0xFFFFFFF0ull)
+		return fail(ctx, CONGA_ERR_RANGE, "conga_sample_reads: more than 2^32 reads in one context");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	TRY(drop_reads(ctx, "conga_sample_reads"));
+	ctx->read_target = -1;
+	if (total * 4 > ctx->d_pos.cap || total > ctx->d_mapq.cap) {
+		const size_t want = std::max((size_t) total + (size_t) total / 8, (size_t) 1 << 22); // (samples of a cohort differ a little)
+		TRY(ensure(ctx, ctx->d_pos, want * 4));
+		TRY(ensure(ctx, ctx->d_mapq, want));
+	}
+	if (total) {
+		// Straight from the caller's arrays: from pinned memory (conga_host_alloc) this is one DMA each at the link's
+		// rate, ordered on the context's stream behind whatever still reads the previous sample's tuples.
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pos.p, pos, (size_t) total * 4, hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->d_mapq.p, mapq, (size_t) total, hipMemcpyHostToDevice, ctx->stream));
+	}
+	for (int c = 0; c < n_chrom; c++)
+		ctx->slots[(size_t) c].n_reads = (int64_t) (chrom_off[c + 1] - chrom_off[c]);
+	ctx->n_reads_total = (int64_t) total;
 	return CONGA_OK;
 }
 
@@ -1239,7 +1412,7 @@ int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const
 		}
 	}
 	ctx->n_reads_total += (int64_t) n_new;
-	ctx->layout_dirty = true;
+	ctx->sample_dirty = true;
 	ctx->computed = false;
 	if (reads_per_chrom)
 		for (int c = 0; c < n_chrom; c++)
@@ -1443,8 +1616,10 @@ int conga_chrom_compute(conga_ctx *ctx)
 	if (ctx->staging_cur >= 0)
 		return fail(ctx, CONGA_ERR_INVALID, "conga_chrom_compute: a staging buffer is handed out and not committed");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
-	if (ctx->layout_dirty)
-		TRY(prepare(ctx));
+	if (ctx->layout_dirty || ctx->layout_dense != dense_formulation(ctx))
+		TRY(prepare_layout(ctx));
+	else if (ctx->sample_dirty)
+		TRY(prepare_sample(ctx));
 	if (ctx->n_reads_total == 0) {
 		TRY(ensure(ctx, ctx->d_pos, 256));
 		TRY(ensure(ctx, ctx->d_mapq, 256));
@@ -1561,8 +1736,8 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 		CountArgs c;
 		c.pos = ptr<int32_t>(ctx->d_pos);
 		c.mapq = ptr<uint8_t>(ctx->d_mapq);
-		c.item_r0 = ptr<uint32_t>(ctx->d_item_r0);
-		c.item_r1 = ptr<uint32_t>(ctx->d_item_r1);
+		c.item_slot = ptr<int32_t>(ctx->d_item_slot);
+		c.slots = dslots;
 		c.item_lo = ptr<int32_t>(ctx->d_item_lo);
 		c.item_len = ptr<int32_t>(ctx->d_item_len);
 		c.item_iv = ptr<int32_t>(ctx->d_item_iv);
@@ -1839,6 +2014,26 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 	return CONGA_OK;
 }
 
+// The tuple pass looks for runs of equal positions long enough to wrap the reference's `short` depth counter
+// (kStatusWrapRisk, kernels.hip.h).  Reads that came through conga_sample_reads() have no other guard, and the finding
+// arrives with the results: the records just computed then count reads where the reference counts modulo 2^16, so the
+// step is computed once more in the dense formulation, which reproduces the wrap.  Called at every point where the host
+// waits for a compute (fetch, conga_sync).
+int settle_wrap_risk(conga_ctx *ctx)
+{
+	if (!ctx->computed || ctx->depth_resident || ctx->wrap_risk || !ctx->h_small)
+		return CONGA_OK;
+	bool risk = false;
+	for (size_t s = 0; s < ctx->slots.size(); s++)
+		risk = risk || (ctx->h_small[s].status & kStatusWrapRisk) != 0;
+	if (!risk)
+		return CONGA_OK;
+	ctx->wrap_risk = true;
+	TRY(conga_chrom_compute(ctx));
+	HIP_TRY(ctx, hipEventSynchronize(ctx->ev_done));
+	return CONGA_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -1855,6 +2050,7 @@ int conga_chrom_fetch(conga_ctx *ctx, conga_result *dels, conga_result *dups, fl
 		return fail(ctx, CONGA_ERR_INVALID, "conga_chrom_fetch: no chromosome selected");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	HIP_TRY(ctx, hipEventSynchronize(ctx->ev_done));
+	TRY(settle_wrap_risk(ctx));
 	const Small &sb = ctx->h_small[ctx->cur];
 	if (sb.status & kStatusUnsorted)
 		return fail(ctx, CONGA_ERR_UNSORTED,
@@ -1921,6 +2117,32 @@ int conga_chrom_finish(conga_ctx *ctx, conga_result *dels, conga_result *dups, f
 	return conga_chrom_fetch(ctx, dels, dups, expected_rd, stats);
 }
 
+int conga_sample_fetch(conga_ctx *ctx, conga_result *records, size_t n_records, float *expected_rd, conga_chrom_stats *stats)
+{
+	if (!ctx)
+		return CONGA_ERR_INVALID;
+	if (!ctx->computed)
+		return fail(ctx, CONGA_ERR_INVALID, "conga_sample_fetch: nothing computed");
+	if (n_records != (size_t) ctx->n_iv || (n_records && !records))
+		return fail(ctx, CONGA_ERR_INVALID, "conga_sample_fetch: n_records differs from the intervals the context holds");
+	const int keep = ctx->cur;
+	// per chromosome through the one-chromosome fetch: same checks, same un-permutation, records laid out one
+	// chromosome behind the other (deletions, then duplications) -- the order of conga_results_device()
+	for (int c = 0; c < (int) ctx->slots.size(); c++) {
+		const HostSlot &h = ctx->slots[(size_t) c];
+		ctx->cur = c;
+		const size_t nd = h.iv_start[0].size();
+		const int rc = conga_chrom_fetch(ctx, records + h.iv0, records + h.iv0 + nd, expected_rd ? expected_rd + (size_t) c * kGcBins : nullptr,
+				stats ? stats + c : nullptr);
+		if (rc != CONGA_OK) {
+			ctx->cur = keep;
+			return rc;
+		}
+	}
+	ctx->cur = keep;
+	return CONGA_OK;
+}
+
 int conga_results_device(conga_ctx *ctx, void **dev_ptr, size_t *n_records)
 {
 	if (!ctx || !dev_ptr)
@@ -1970,6 +2192,7 @@ int conga_sync(conga_ctx *ctx)
 		return CONGA_ERR_INVALID;
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	TRY(settle_wrap_risk(ctx));
 	return CONGA_OK;
 }
 

@@ -30,6 +30,13 @@ constexpr int kWave = 64;
 constexpr int kGcBins = 101; // read_distribution.c:51-52
 
 constexpr uint32_t kStatusUnsorted = 1u; // Small.status bits
+constexpr uint32_t kStatusWrapRisk = 2u; // some base of this chromosome may hold more than 32767 read starts (tuple pass)
+// The tuple pass looks for runs of equal positions the way the commit path does on the host (conga_api.hip:
+// note_equal_runs): the thread that holds tuples 4..7 of a 1024-tuple chunk compares tuple 3 with the one kWrapProbe
+// further on.  A run of 32768 equal positions [j, j + 32768) contains a whole chunk [i, i + 1024) with i <= j + 1023,
+// and i + 3 + kWrapProbe <= j + 31746 lies inside the run too: the pair is equal and the chunk lies inside one
+// chromosome (the plain path).  Conservative: runs from 30721 on may be flagged.
+constexpr uint32_t kWrapProbe = 30720;
 enum { CNT_COUNTED = 0, CNT_OUT_OF_RANGE, CNT_SR_ELEMENTS, CNT_SR_MAPPINGS, CNT_SR_DEL_ROWS, CNT_SR_DUP_ROWS, CNT_N };
 
 // One chromosome of the batch.  Offsets are in elements of the respective concatenated buffer.
@@ -294,6 +301,8 @@ __device__ __forceinline__ TupleRegs load_tuples(const TupleArgs &a, uint32_t ch
 	}
 	if ((threadIdx.x & (kWave - 1)) == 0 && i0 > 0)
 		r.pv = a.pos[i0 - 1];
+	else if (threadIdx.x == 1 && i0 - 1 + kWrapProbe < a.n_total)
+		r.pv = a.pos[i0 - 1 + kWrapProbe]; // the wrap probe's far end (this lane's `pv` is otherwise unused)
 	return r;
 }
 
@@ -329,6 +338,9 @@ template <bool MASKED> __device__ __forceinline__ GcRegs ingest_chunk_inside(con
 		unsorted |= mine[e] & (!MASKED | (i0 + e != sl.r0)) & (p[e] < p[e - 1]);
 	if (unsorted)
 		atomicOr(&a.small[home].status, kStatusUnsorted);
+	// wrap probe (kWrapProbe above): thread 1 holds tuple base + 3 in `prev` and tuple base + 3 + kWrapProbe in r.pv
+	if (!MASKED && threadIdx.x == 1 && (uint64_t) base + 3u + kWrapProbe < (uint64_t) sl.r1 && prev == r.pv)
+		atomicOr(&a.small[home].status, kStatusWrapRisk);
 	bool in[4];
 	int n_out = 0;
 #pragma unroll
@@ -472,8 +484,8 @@ __global__ __launch_bounds__(kTupleBlock, 8) void ingest_tuples_kernel(TupleArgs
 struct CountArgs {
 	const int32_t *pos;
 	const uint8_t *mapq;
-	const uint32_t *item_r0; // tuple index range of the item's chromosome
-	const uint32_t *item_r1;
+	const int32_t *item_slot; // the item's chromosome: its tuple index range comes from the Slot table, which is
+	const Slot *slots;        // the only thing that changes when another sample's reads are put behind the same layout
 	const int32_t *item_lo;  // first base, chromosome coordinates
 	const int32_t *item_len;
 	const int32_t *item_iv;
@@ -492,8 +504,9 @@ __device__ __forceinline__ void interval_count_body(const CountArgs &a, int64_t 
 	if (have) {
 		lo = a.item_lo[item];
 		hi = lo + a.item_len[item];
-		a0 = b0 = a.item_r0[item];
-		a1 = b1 = a.item_r1[item];
+		const Slot &sl = a.slots[a.item_slot[item]];
+		a0 = b0 = (uint32_t) sl.read_off;
+		a1 = b1 = (uint32_t) (sl.read_off + sl.n_reads);
 	}
 	while (__any(a0 < a1 || b0 < b1)) {
 		const uint32_t ma = a0 + ((a1 - a0) >> 1), mb = b0 + ((b1 - b0) >> 1);

@@ -47,6 +47,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 		s_crc[i] = crc_table[i];
 	__syncthreads();
 	const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x, lanes = gridDim.x * blockDim.x;
+	// the scratch is raw hipMalloc memory (a member initialiser never runs on the device, and the allocator recycles
+	// blocks): the fixed-code tables count as built only once THIS launch has built them
+	scratch[lane].fixed_ready = false;
 	for (uint32_t b = lane; b < n_blocks; b += lanes) {
 		const conga_bgzf_block bl = blocks[b];
 		uint8_t *dst = out + out_off[b];

@@ -171,9 +171,27 @@ struct chrom_job {
 	int worker = 0;
 	std::string messages;  // progress lines of the reference, in its order (held back when several workers run)
 	chrom_svs cs;
-	conga_chrom_stats st;
+	conga_chrom_stats st{};
 	bool staged = false;
+	bool counts_pending = false; // `messages` holds the placeholders below instead of the two counts of bam_data.c:218
 };
+
+// count_reads_bam's closing line prints the reads that passed `qual > mq_threshold` and the running number of split-read
+// elements (bam_data.c:201-218, split_read.c:14).  Both are known exactly once the engine has computed, so with a MAPQ
+// threshold or with split reads the chromosome's lines are held back and these two marks are filled in afterwards.
+constexpr char kMarkReads = '\x01', kMarkSplit = '\x02';
+
+void fill_counts(std::string *text, long long reads, long split_reads)
+{
+	for (size_t i = 0; i < text->size(); i++) {
+		const char c = (*text)[i];
+		if (c != kMarkReads && c != kMarkSplit)
+			continue;
+		const std::string v = (c == kMarkReads) ? std::to_string(reads) : std::to_string(split_reads);
+		text->replace(i, 1, v);
+		i += v.size() - 1;
+	}
+}
 
 // Where the reference's stderr progress lines go: straight out with one worker, into the job's buffer with several
 // (they are then printed in annotation order once every worker is done).
@@ -251,6 +269,8 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 	opts.min_read_length = params->min_read_length;
 	// the reference's split-read gate: `!no_sr && dup_file` (svdepth.c:57, bam_data.c:207,306,331, likelihood.c:344)
 	const bool split_reads = !params->no_sr && params->have_dups;
+	// (the caller passes buffered = true whenever the counts of the closing line are not known while reading)
+	const bool counts_known_now = params->mq_threshold < 0 && !split_reads;
 	int status = 0;
 	conga_ctx *ctx = conga_create(device, &opts, &status);
 	if (!ctx) {
@@ -304,6 +324,7 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 		chrom_job *job = mine[job_index];
 		const bool on_gpu = !gpu_counts.empty(); // opened, equipped and filled above: only the progress text is left
 		progress out = {buffered ? &job->messages : nullptr};
+		job->counts_pending = !counts_known_now;
 		if (!buffered && !job->messages.empty()) {
 			fputs(job->messages.c_str(), stderr); // what the selection pass had to say before this chromosome
 			job->messages.clear();
@@ -332,7 +353,10 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 		}
 		out.say("\n-->counting reads");
 		const int64_t cnt_reads = on_gpu ? (int64_t) gpu_counts[job_index] : count_reads_bam(ctx, src, job->chr_index_bam, L, split_reads);
-		out.say(" (%lld reads, %ld split-reads)\n", (long long) cnt_reads, 0L);
+		if (counts_known_now)
+			out.say(" (%lld reads, %ld split-reads)\n", (long long) cnt_reads, 0L); // every record counts, no split reads
+		else
+			out.say(" (%c reads, %c split-reads)\n", kMarkReads, kMarkSplit);
 
 		// find_SVs, loading half (likelihood.c:319-336); the rows were picked by the selection pass
 		chrom_svs &cs = job->cs;
@@ -481,8 +505,22 @@ int read_bam(parameters *params, sonic *this_sonic)
 
 	const auto t_work = now();
 	std::vector<worker_timing> wt((size_t) n_workers);
+	const bool hold_lines = params->mq_threshold >= 0 || (!params->no_sr && params->have_dups);
+	auto print_held_lines = [&]() {
+		long split_total = 0; // split_read_count is never reset between chromosomes (split_read.c:14)
+		for (chrom_job &j : jobs) {
+			split_total += (long) j.st.split_elements;
+			if (j.counts_pending)
+				fill_counts(&j.messages, (long long) j.st.reads_counted, split_total);
+			fputs(j.messages.c_str(), stderr);
+		}
+		if (!jobs.empty())
+			fprintf(stderr, "\nCalculating Likelihoods\n");
+	};
 	if (n_workers == 1) {
-		run_worker(params, this_sonic, src.get(), params->device, false, map_bed, mine[0], true, &wt[0]);
+		run_worker(params, this_sonic, src.get(), params->device, hold_lines, map_bed, mine[0], !hold_lines, &wt[0]);
+		if (hold_lines)
+			print_held_lines();
 	} else {
 		set_reader_share(n_workers); // each worker's BAM reader gets its share of the inflate threads
 		std::vector<std::thread> threads;
@@ -498,10 +536,7 @@ int read_bam(parameters *params, sonic *this_sonic)
 		}
 		for (std::thread &t : threads)
 			t.join();
-		for (const chrom_job &j : jobs)
-			fputs(j.messages.c_str(), stderr);
-		if (!jobs.empty())
-			fprintf(stderr, "\nCalculating Likelihoods\n");
+		print_held_lines();
 	}
 	if (!pending.empty())
 		fputs(pending.c_str(), stderr);

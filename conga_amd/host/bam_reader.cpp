@@ -257,6 +257,10 @@ private:
 			memcpy(&t->crc, t->cdata.data() + cdata, 4);
 			memcpy(&t->isize, t->cdata.data() + cdata + 4, 4);
 			t->cdata.resize((size_t) cdata);
+			if (t->isize > 65536u) { // the BGZF limit: anything larger is a damaged (or hostile) trailer, not an allocation size
+				err_ = "bad BGZF block (ISIZE above 64 KiB)";
+				return false;
+			}
 			if (t->isize == 0)
 				continue;
 			*out = t;
@@ -756,6 +760,18 @@ private:
 			*err = path_ + ": not a BAM file" + (bgzf_.error().empty() ? "" : " (" + bgzf_.error() + ")");
 			return false;
 		}
+		// sizes come from the file: bound them by what the file can hold (deflate expands at most 1032 : 1) before allocating
+		uint64_t file_bytes = 0;
+		{
+			struct stat sb;
+			if (stat(path_.c_str(), &sb) == 0 && sb.st_size > 0)
+				file_bytes = (uint64_t) sb.st_size;
+		}
+		const uint64_t most = file_bytes ? file_bytes * 1032u + 64u : (uint64_t) INT32_MAX;
+		if ((uint64_t) l_text > most) {
+			*err = path_ + ": BAM header text longer than the file can hold";
+			return false;
+		}
 		std::string text((size_t) l_text, '\0');
 		if (!bgzf_.read(&text[0], (size_t) l_text) || !bgzf_.read(&n_ref, 4) || n_ref < 0) {
 			*err = path_ + ": truncated BAM header";
@@ -764,7 +780,7 @@ private:
 		names_.clear();
 		for (int i = 0; i < n_ref; i++) {
 			int32_t l_name, l_ref;
-			if (!bgzf_.read(&l_name, 4) || l_name <= 0) {
+			if (!bgzf_.read(&l_name, 4) || l_name <= 0 || (uint64_t) l_name > most) {
 				*err = path_ + ": truncated BAM header";
 				return false;
 			}

@@ -275,7 +275,7 @@ struct SequentialSymbols {
 				if (!(e & kValid))
 					return -1;
 				const size_t offset = ((e >> 13) & 0x7FFFu) + b.take((int) ((e >> 8) & 31u));
-				if (offset > (size_t) (op - out))
+				if (offset > (size_t) (op - out) || length > 258) // (no table built by build_table yields more than 258)
 					return -1;
 				// Eight bytes at a time (up to seven more than `length` are written; there is room).  A match closer than eight
 				// bytes is periodic with its distance: after one period has been copied byte by byte the same bytes are also a

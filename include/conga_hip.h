@@ -30,6 +30,11 @@
  *                         conga_chrom_compute() -- each kernel is launched once over the whole batch --
  *                         then conga_chrom_select(i) + conga_chrom_fetch() per chromosome.  This is
  *                         the form that fills an MI355X; results are identical.
+ *   cohort (batch + conga_sample_*)  the chromosomes, GC arrays, intervals and tracks are handed over once; every further
+ *                         sample only replaces the read tuples (conga_sample_reads, or conga_sample_begin + the staging
+ *                         ring) and is computed and fetched as before.  The reference runs one process per sample and
+ *                         re-reads the annotation and the call set each time (svdepth.c:47-66); genotyping a cohort
+ *                         against one call set is its use case (README.md:1-20).
  */
 #ifndef CONGA_HIP_H_
 #define CONGA_HIP_H_
@@ -41,7 +46,7 @@
 extern "C" {
 #endif
 
-#define CONGA_ABI_VERSION 3
+#define CONGA_ABI_VERSION 4
 
 typedef struct conga_ctx conga_ctx;
 
@@ -198,6 +203,35 @@ int conga_mappability(conga_ctx *ctx, const int32_t *start, const int32_t *end, 
  * CONGA_DELETION or CONGA_DUPLICATION.  Copies the arrays; once per type per chromosome. */
 int conga_intervals(conga_ctx *ctx, char type, const int32_t *start, const int32_t *end, size_t n);
 
+/* ---- cohort mode: the next sample's reads behind the same layout ----------------------------------------------
+ * The consumer side of count_reads_bam (bam_data.c:192-221) for the second and every further sample of a cohort: the
+ * reads of ALL chromosomes the context holds are replaced, everything else (chromosomes, GC arrays, intervals, tracks,
+ * the device layout that conga_chrom_compute() prepared) stays.  Not with split reads.
+ *
+ * conga_sample_reads: pos / mapq hold the sample's (bam1_core_t.pos, bam1_core_t.qual) tuples, chromosome 0's first,
+ * then chromosome 1's, ... each in BAM order; chromosome c owns [chrom_off[c], chrom_off[c + 1]) (n_chrom + 1 entries,
+ * n_chrom == conga_chrom_count()).  The copies into HBM are enqueued on the context's stream and the call returns: the
+ * arrays must stay unchanged until the next conga_chrom_fetch / conga_sample_fetch / conga_sync of this context has
+ * returned.  From pinned memory (conga_host_alloc) the copy runs at the PCIe link's rate with no staging copy; pageable
+ * memory works, slower.  The tuple-space formulation's guard against a wrapping `short` depth counter runs on the
+ * device for such reads (see CONGA_FLAG_MATERIALIZE_DEPTH): a sample that needs the dense kernels is recomputed with
+ * them inside the fetch (or conga_sync) that follows -- a caller that reads the records on the device
+ * (CONGA_FLAG_RESULTS_ON_DEVICE) calls conga_sync() first.
+ *
+ * conga_sample_begin / conga_sample_chrom: the same through the staging ring, for a decoder that produces one
+ * chromosome after the other: begin drops every chromosome's reads and makes chromosome 0 the target of
+ * conga_reads_commit(); conga_sample_chrom(i) moves the target on (ascending only). */
+void *conga_host_alloc(conga_ctx *ctx, size_t bytes); /* pinned host memory (hipHostMalloc); NULL on failure */
+void conga_host_free(conga_ctx *ctx, void *p);
+int conga_sample_reads(conga_ctx *ctx, const int32_t *pos, const uint8_t *mapq, const uint64_t *chrom_off, int n_chrom);
+int conga_sample_begin(conga_ctx *ctx);
+int conga_sample_chrom(conga_ctx *ctx, int index);
+/* conga_chrom_fetch for every chromosome in one call: records[] receives conga_chrom_count() groups one behind the
+ * other (chromosome order; a chromosome's deletions, then its duplications -- the order of conga_results_device()),
+ * n_records must be the total; expected_rd (may be NULL) receives 101 floats per chromosome, stats (may be NULL) one
+ * entry per chromosome. */
+int conga_sample_fetch(conga_ctx *ctx, conga_result *records, size_t n_records, float *expected_rd, conga_chrom_stats *stats);
+
 /* ---- count_reads_bam with the BAM decode on the device -------------------------------------------------------
  * Instead of decoded tuples the caller hands over a stretch of the BAM file exactly as it is on disk, the table of
  * its BGZF blocks, and start points taken from the .bai's linear index (16 kb windows).  The engine inflates the blocks
@@ -288,7 +322,7 @@ int conga_results_copy(conga_ctx *ctx, void *dst_device, size_t dst_bytes);
 int conga_set_profile(conga_ctx *ctx, int on);
 /* hipStream_t of this context (as void*), e.g. to record HIP events around conga_chrom_compute(). */
 void *conga_stream(conga_ctx *ctx);
-/* Blocks until the context's stream is idle. */
+/* Blocks until the context's stream is idle (and settles the wrap guard of conga_sample_reads, see there). */
 int conga_sync(conga_ctx *ctx);
 /* Test hooks: copy bam_info.read_depth (int16[chrom_len]) / bam_info.mappability (float[chrom_len])
  * of the last compute back to the host.  After a tuple-space compute conga_copy_read_depth() first builds

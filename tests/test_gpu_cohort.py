@@ -1,0 +1,238 @@
+"""Cohort mode (conga_sample_reads / conga_sample_begin + the staging ring / conga_sample_fetch): further samples behind
+a layout that was handed over once give exactly what a fresh context gives, and what the oracle gives.
+
+The reference runs one process per sample (svdepth.c:47-66); per sample its hot path is count_reads_bam ->
+calc_mean_per_chr -> find_SVs (bam_data.c:192-221, read_distribution.c:49-84, likelihood.c:311-371), which is what each
+case below is checked against.
+"""
+import numpy as np
+import pytest
+
+from conga_amd import synth
+from test_gpu_parity import assert_records, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=["tuple_space", "dense"])
+def formulation(request, capi):
+    capi.EXTRA_FLAGS = capi.FLAG_MATERIALIZE_DEPTH if request.param == "dense" else 0
+    yield request.param
+    capi.EXTRA_FLAGS = 0
+
+
+def layout(with_map):
+    """Three chromosomes with their intervals (and tracks); the reads of `chroms` are sample 0."""
+    specs = (("7", 900_000, 40, 9), ("9", 400_123, 25, 4), ("11", 1_300_000, 50, 12))
+    chroms = []
+    for name, L, nd, nu in specs:
+        c = synth.make_chrom(name, L, cov=1.0, n_dels=nd, n_dups=nu, mappability=with_map, gaps=(L > 1_000_000))
+        ds, de = synth.kept_sorted(c.del_start, c.del_end)
+        us, ue = synth.kept_sorted(c.dup_start, c.dup_end)
+        chroms.append((c, ds, de, us, ue))
+    return chroms
+
+
+def sample_reads_of(chroms, sample, cov, empty=None, mapq_floor=None):
+    """Another individual's reads on the same chromosomes (same GC track, other seed and coverage)."""
+    out = []
+    for k, (c, *_rest) in enumerate(chroms):
+        rng = np.random.default_rng([sample, k, 77])
+        pos, mapq = synth.make_reads(c.length, c.gc, c.step, cov, 100, rng)
+        if empty == k:
+            pos, mapq = pos[:0], mapq[:0]
+        if mapq_floor is not None:
+            mapq = np.maximum(mapq, mapq_floor).astype(np.uint8)
+        out.append((pos, mapq))
+    return out
+
+
+def open_layout(ctx, chroms, with_map):
+    for c, ds, de, us, ue in chroms:
+        ctx.chrom_begin(c.length, c.gc)
+        if with_map:
+            ctx.mappability(c.map_start, c.map_end, c.map_val)
+        ctx.intervals("D", ds, de)
+        ctx.intervals("E", us, ue)
+
+
+def pinned_sample(ctx, reads):
+    n = sum(len(p) for p, _ in reads)
+    pos, mapq = ctx.host_alloc(max(n, 1), np.int32), ctx.host_alloc(max(n, 1), np.uint8)
+    off = np.zeros(len(reads) + 1, np.uint64)
+    at = 0
+    for k, (p, m) in enumerate(reads):
+        pos[at:at + len(p)] = p
+        mapq[at:at + len(p)] = m
+        at += len(p)
+        off[k + 1] = at
+    return pos, mapq, off
+
+
+def check_against_oracle(oracle, chroms, reads, recs, E, with_map, mq=-1):
+    at = 0
+    for k, ((c, ds, de, us, ue), (pos, mapq)) in enumerate(zip(chroms, reads)):
+        rows = (c.map_start, c.map_end, c.map_val) if with_map else None
+        want = run_oracle(oracle, c.length, c.gc, pos, mapq, ds, de, us, ue, mq=mq, rows=rows)
+        assert np.array_equal(E[k].view(np.uint32), want["E"].view(np.uint32)), "expected_read_depth of chromosome %d" % k
+        assert_records(recs[at:at + len(ds)], want["dels"], with_map)
+        assert_records(recs[at + len(ds):at + len(ds) + len(us)], want["dups"], with_map)
+        at += len(ds) + len(us)
+    assert at == len(recs)
+
+
+@pytest.mark.parametrize("with_map", [False, True])
+def test_samples_behind_one_layout(capi, oracle, with_map):
+    chroms = layout(with_map)
+    samples = [[(c.pos, c.mapq) for c, *_ in chroms],
+               sample_reads_of(chroms, 1, 3.0),
+               sample_reads_of(chroms, 2, 0.3, empty=1),      # one chromosome without a read
+               sample_reads_of(chroms, 3, 1.0)]
+    with capi.Context(device=0, flags=capi.FLAG_BATCH) as ctx:
+        open_layout(ctx, chroms, with_map)
+        for si, reads in enumerate(samples):
+            pos, mapq, off = pinned_sample(ctx, reads)
+            ctx.sample_reads(pos, mapq, off)
+            ctx.compute()
+            recs, E, st = ctx.sample_fetch(want_stats=True)
+            check_against_oracle(oracle, chroms, reads, recs, E, with_map)
+            for k, (p, _m) in enumerate(reads):
+                assert st[k].reads_committed == len(p) and st[k].reads_counted == len(p)
+            # ... and exactly what a context that never saw another sample gives
+            with capi.Context(device=0, flags=capi.FLAG_BATCH) as fresh:
+                for (c, ds, de, us, ue), (p, m) in zip(chroms, reads):
+                    fresh.chrom_begin(c.length, c.gc)
+                    fresh.reads(p, m)
+                    if with_map:
+                        fresh.mappability(c.map_start, c.map_end, c.map_val)
+                    fresh.intervals("D", ds, de)
+                    fresh.intervals("E", us, ue)
+                fresh.compute()
+                want = b"".join(d.tobytes() + u.tobytes() for d, u, _e, _s in fresh.fetch_all())
+            assert recs.tobytes() == want, "sample %d differs from a fresh context's records" % si
+            # the one-chromosome fetch still works behind a sample
+            ctx.select(1)
+            d1, u1 = ctx.fetch()[:2]
+            a = len(chroms[0][1]) + len(chroms[0][3])
+            assert d1.tobytes() + u1.tobytes() == recs[a:a + len(d1) + len(u1)].tobytes()
+
+
+def test_sample_through_the_staging_ring(capi, oracle):
+    """conga_sample_begin + conga_sample_chrom: the decoder's route (one chromosome after the other through
+    conga_reads_staging / conga_reads_commit), with a MAPQ threshold."""
+    chroms = layout(False)
+    reads = sample_reads_of(chroms, 5, 2.0, empty=0)
+    with capi.Context(device=0, flags=capi.FLAG_BATCH, mq_threshold=10) as ctx:
+        open_layout(ctx, chroms, False)
+        ctx.sample_begin()
+        for k, (p, m) in enumerate(reads):
+            ctx.sample_chrom(k)
+            ctx.reads(p, m)
+        ctx.compute()
+        recs, E, _ = ctx.sample_fetch()
+        check_against_oracle(oracle, chroms, reads, recs, E, False, mq=10)
+        # descending order is refused, and so is a wrong chromosome count
+        with pytest.raises(capi.CongaError):
+            ctx.sample_chrom(0)
+        with pytest.raises(capi.CongaError):
+            ctx.sample_reads(np.zeros(1, np.int32), np.zeros(1, np.uint8), np.zeros(2, np.uint64))
+
+
+def test_sample_with_a_pile_up_wraps_like_a_short(capi, oracle, formulation):
+    """40 000 reads on one base wrap read_depth's `short` (common.h:91, bam_data.c:213).  Reads that arrive through
+    conga_sample_reads are only looked at on the device: the tuple pass flags the run and the fetch recomputes in the
+    dense formulation."""
+    chroms = layout(False)
+    reads = sample_reads_of(chroms, 9, 1.0)
+    c1 = chroms[1][0]
+    hot = int(chroms[1][1][3]) + 17   # inside the fourth deletion of chromosome 1
+    p, m = reads[1]
+    p = np.sort(np.concatenate([p, np.full(40_000, hot, np.int32)])).astype(np.int32)
+    m = np.full(len(p), 60, np.uint8)
+    reads[1] = (p, m)
+    with capi.Context(device=0, flags=capi.FLAG_BATCH) as ctx:
+        open_layout(ctx, chroms, False)
+        pos, mapq, off = pinned_sample(ctx, reads)
+        ctx.sample_reads(pos, mapq, off)
+        ctx.compute()
+        recs, E, st = ctx.sample_fetch(want_stats=True)
+        assert st[1].depth_materialized == 1
+        check_against_oracle(oracle, chroms, reads, recs, E, False)
+        rd, _ = oracle.count_reads(c1.length, p, m, -1)
+        assert rd[hot] < 0  # the case does wrap
+        # the next, harmless sample goes back to tuple space (unless the dense formulation is forced)
+        reads2 = sample_reads_of(chroms, 10, 1.0)
+        pos2, mapq2, off2 = pinned_sample(ctx, reads2)
+        ctx.sample_reads(pos2, mapq2, off2)
+        ctx.compute()
+        recs2, E2, st2 = ctx.sample_fetch(want_stats=True)
+        assert st2[1].depth_materialized == (1 if formulation == "dense" else 0)
+        check_against_oracle(oracle, chroms, reads2, recs2, E2, False)
+
+
+# ---- conga_reads_bgzf called in process (the command-line tests run it in fresh subprocesses only) ---------------------
+def bgzf_table(raw):
+    """[(data_off, data_len, inflated_len, crc32)] of the non-empty blocks of a BGZF file + their inflated bytes."""
+    import struct
+    import zlib
+    blocks, stream, at = [], bytearray(), 0
+    while at < len(raw):
+        xlen = struct.unpack_from("<H", raw, at + 10)[0]
+        assert raw[at + 12:at + 16] == b"BC\x02\x00" and xlen == 6
+        bsize = struct.unpack_from("<H", raw, at + 16)[0] + 1
+        data_off, data_len = at + 18, bsize - 18 - 8
+        crc, isize = struct.unpack_from("<II", raw, at + bsize - 8)
+        if isize:
+            blocks.append((data_off, data_len, isize, crc))
+            stream += zlib.decompress(bytes(raw[data_off:data_off + data_len]), -15)
+        at += bsize
+    return blocks, bytes(stream)
+
+
+@pytest.mark.parametrize("strategy", ["fixed", "default"])
+def test_reads_bgzf_in_process_on_recycled_device_memory(capi, tmp_path, strategy, formulation):
+    """The decoders' scratch is raw device memory: fixed-Huffman blocks (BTYPE 1) must decode right even when the
+    allocator hands back memory full of 0xFF (the `fixed_ready` flag was read uninitialised)."""
+    import struct
+    import zlib
+    import torch
+    from conga_amd import formats
+    junk = [torch.full((n,), 255, dtype=torch.uint8, device="cuda") for n in (1 << 20, 3 << 20, 17 << 20, 64 << 20)]
+    torch.cuda.synchronize()
+    del junk
+    torch.cuda.empty_cache()  # back to the HIP allocator, contents intact
+
+    cs = [synth.make_chrom(n, L, cov=2.0, n_dels=nd, gaps=False) for n, L, nd in (("1", 300_000, 15), ("2", 200_000, 10))]
+    path = str(tmp_path / "r.bam")
+    formats.write_bam(path, "S", [(c.name, c.length, c.pos, c.mapq) for c in cs], index=True, block_payload=20_000,
+                      strategy=zlib.Z_FIXED if strategy == "fixed" else 0, unplaced=2)
+    raw = np.fromfile(path, np.uint8)
+    blocks, stream = bgzf_table(raw.tobytes())
+    # the first record lies behind the header: magic, l_text, text, n_ref, then (l_name, name, l_ref) per reference
+    l_text = struct.unpack_from("<i", stream, 4)[0]
+    at = 8 + l_text
+    n_ref = struct.unpack_from("<i", stream, at)[0]
+    at += 4
+    for _ in range(n_ref):
+        l_name = struct.unpack_from("<i", stream, at)[0]
+        at += 4 + l_name + 4
+    segments = [(at, 0, cs[0].length, 0, 0), (at, 0, cs[1].length, 1, 1)]
+    with capi.Context(device=0, flags=capi.FLAG_BATCH) as ctx:
+        for c in cs:
+            ds, de = synth.kept_sorted(c.del_start, c.del_end)
+            ctx.chrom_begin(c.length, c.gc)
+            ctx.intervals("D", ds, de)
+        per = ctx.reads_bgzf(raw, blocks, segments)
+        assert per == [len(c.pos) for c in cs]
+        ctx.compute()
+        got = ctx.fetch_all()
+    with capi.Context(device=0, flags=capi.FLAG_BATCH) as ctx:
+        for c in cs:
+            ds, de = synth.kept_sorted(c.del_start, c.del_end)
+            ctx.chrom_begin(c.length, c.gc)
+            ctx.reads(c.pos, c.mapq)
+            ctx.intervals("D", ds, de)
+        ctx.compute()
+        want = ctx.fetch_all()
+    for (gd, _gu, gE, gs), (wd, _wu, wE, ws) in zip(got, want):
+        assert gd.tobytes() == wd.tobytes() and gE.tobytes() == wE.tobytes() and gs.reads_counted == ws.reads_counted
