@@ -1,26 +1,34 @@
 #!/usr/bin/env python3
 """bench.py -- CNV intervals genotyped per second on the read-depth / likelihood hot path.
 
-Workload at N=1 (BASELINE.json configs[1]): the full 1000G-Phase-3-sized deletion set (~42k rows
-before the min-size filter) over the 22 GRCh37 autosomes against a 1x synthetic sample.  A "step"
-is one pass of the whole hot path over that sample: for every chromosome, read tuples (already
-resident in HBM) -> GC-stratified depth sums -> expected_read_depth[101] -> per-interval observed
-depth, serial-float expected chain, 3-state log-likelihoods, c-score and CN -> result records
-gathered on rank 0.  Host-side BAM decoding and BED parsing are outside the timed region.
+A "step" is one SAMPLE through the whole hot path, on the path the metric is defined on ("the timed kernel
+path starts from decoded tuples in pinned memory"; the producer seam is count_reads_bam, bam_data.c:192-221):
 
-Formulation: the library default (`--formulation auto`) works in tuple space (SURVEY.md section 8d,
-"sparse reformulation"): read_depth[i] is a count of read starts, so the GC sums are a histogram over
-the kept reads and an interval's observed depth is the number of kept reads that start inside it --
-identical results (asserted against the oracle on the whole genome below), 5 bytes per read of HBM
-traffic instead of 4+ bytes per base.  `--formulation dense` forces the reference's formulation
-(read_depth[] materialised in HBM); at N=1 a short dense leg runs after the timed region so that the
-line carries both: `roofline` (dominant HBM-bound kernel of the timed path), `roofline_dense`
-(depth_tile_kernel, the most HBM-intensive kernel of the library) and `dense_equivalent` (the dense
-formulation's algorithmic bytes divided by the measured step time, as SURVEY.md 8d asks).
+    the sample's decoded (pos, mapq) tuples in pinned host memory
+      -> HBM over PCIe (conga_sample_reads)
+      -> GC-stratified depth sums -> expected_read_depth[101] -> per-interval observed depth, serial-float expected
+         chain, 3-state log-likelihoods, c-score, CN (conga_chrom_compute: two launches)
+      -> the result records in host memory (conga_sample_fetch)
 
-Multi-GPU: one process per GPU (torchrun), chromosomes sharded LPT across ranks, no data-path
-collective, one RCCL gather of the fixed-size result records per step.  Default scaling is weak:
-N ranks genotype N samples (22 N chromosome units); `--scaling strong` splits ONE sample.
+The annotation, the call set and the tracks are the same for every sample of a cohort, so they are handed over once
+(the library's cohort mode) and every step only brings new tuples; successive steps rotate over three different
+samples and three contexts, so that the copy of sample k + 1 runs beside the kernels and the fetch of sample k (the
+records of every step are fetched; nothing is cached between steps).  `value` is the steady-state rate of that loop.
+Also on the line:
+  single_sample   the same step unpipelined (copy, kernels, fetch one after the other), its latency
+  kernel_only     the kernels alone on tuples already in HBM (round 1's `value`), rotating over the three resident
+                  samples so that every launch streams from HBM, not from the 256 MiB Infinity Cache
+  roofline        the HBM-bound kernel of the step (ingest_tuples_kernel) timed with HIP events on its own stream in that
+                  rotation; step_bound = the PCIe copy that bounds the step itself
+  roofline_dense  the reference's dense formulation (read_depth[] materialised), depth_tile_kernel
+  configs         short legs for BASELINE configs[2] (dels + dups + mappability) and configs[4] (5x, --rp split reads)
+  cpu_baseline    the oracle (serial port of the reference's loops), 1 thread, same workload; its records are compared
+                  with the HIP path's at full size in the same run (cn_concordance is computed from that comparison)
+
+Multi-GPU (`--gpus N` under torch.distributed.run, one process per GPU): chromosomes are sharded LPT across ranks, no
+data-path collective, one RCCL gather of the fixed-size result records per step.  The default at N > 1 is STRONG
+scaling -- one whole-genome sample per step sharded over the N GPUs, which is what BASELINE configs[3] names; the
+line also carries a `weak` leg (N samples per step, one per rank's worth of chromosomes).
 
 Prints ONE JSON line on rank 0.
 """
@@ -37,7 +45,9 @@ sys.path.insert(0, ROOT)
 
 from conga_amd import capi, shard, synth  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md, Chip-level parameters)
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md, Chip-level parameters)
+PCIE_PEAK_GBS = 64.0    # PCIe Gen5 x16, one direction, raw
+N_ROTATE = 3            # samples (and contexts) the timed loop rotates over: 3 x 157 MB of tuples > 256 MiB of Infinity Cache
 
 
 def parse_args():
@@ -45,7 +55,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--scaling", choices=("auto", "weak", "strong"), default="auto",
+                    help="auto = strong at N > 1 (configs[3]: one sample sharded over the GPUs); the other one runs as a leg")
     ap.add_argument("--config", choices=("dels", "dels+dups+map"), default="dels",
                     help="dels = BASELINE configs[1]; dels+dups+map = configs[2]")
     ap.add_argument("--cov", type=float, default=1.0)
@@ -54,25 +65,30 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="lower bound of CPU-baseline work (oracle, 1 thread); 0 disables the leg")
     ap.add_argument("--chroms", type=str, default="", help="comma list of chromosome names (debug)")
-    ap.add_argument("--results-on-device", action="store_true",
-                    help="CONGA_FLAG_RESULTS_ON_DEVICE at N=1 too (what every rank of a multi-GPU run does)")
     ap.add_argument("--no-dense-leg", dest="dense_leg", action="store_false",
                     help="skip the dense-formulation leg that follows the timed region at N=1")
+    ap.add_argument("--no-config-legs", dest="config_legs", action="store_false",
+                    help="skip the configs[2] / configs[4] legs that follow the timed region at N=1")
+    ap.add_argument("--rp-chroms", type=str, default="19,20,21,22",
+                    help="chromosomes of the configs[4] (--rp) leg; 'all' = the whole genome (21 GB of read records)")
     ap.add_argument("--dist-selftest", action="store_true",
                     help="run the multi-rank code path (RCCL process group, device-resident records, gather) with the "
                          "ranks there are, even one -- a one-GPU check of the path the driver runs at N > 1")
     return ap.parse_args()
 
 
-def build_units(args, world):
-    """(sample, chromosome) units and their owner rank."""
+# ---------------------------------------------------------------------------------------------------------------------
+# workload
+# ---------------------------------------------------------------------------------------------------------------------
+def build_units(args, world, scaling, config):
+    """(sample, chromosome) units of ONE step and their owner rank."""
     chroms = synth.GRCH37_AUTOSOMES
     if args.chroms:
         keep = set(args.chroms.split(","))
         chroms = tuple(c for c in chroms if c[0] in keep)
-    n_dups = synth.N_DUPS_GENOME if args.config != "dels" else 0
+    n_dups = synth.N_DUPS_GENOME if config != "dels" else 0
     plan = synth.genome_plan(chroms, synth.N_DELS_GENOME, n_dups)
-    n_samples = world if args.scaling == "weak" else 1
+    n_samples = world if scaling == "weak" else 1
     units = []
     for sample in range(n_samples):
         for name, length, nd, nu in plan:
@@ -84,27 +100,51 @@ def build_units(args, world):
     return units
 
 
-def make_unit(u, args):
-    """Generate one chromosome's inputs on the host."""
+def make_unit(u, args, config):
+    """One chromosome's layout (GC track, intervals, track rows) and the reads of N_ROTATE different samples on it."""
     c = synth.make_chrom(u["name"], u["length"], cov=args.cov, n_dels=u["n_dels"], n_dups=u["n_dups"],
-                         seed=synth.BASE_SEED + 1000 * u["sample"], mappability=(args.config != "dels"))
+                         seed=synth.BASE_SEED + 1000 * u["sample"], mappability=(config != "dels"))
     ds, de = synth.kept_sorted(c.del_start, c.del_end)
     us, ue = synth.kept_sorted(c.dup_start, c.dup_end)
-    u.update(chrom=c, ds=ds, de=de, us=us, ue=ue, n_iv=len(ds) + len(us), n_reads=len(c.pos),
+    reads = [(c.pos, c.mapq)]
+    for j in range(1, N_ROTATE):   # other individuals: same chromosome, other reads
+        rng = np.random.default_rng([synth.BASE_SEED + 1000 * u["sample"] + j, int(u["name"]), 99])
+        reads.append(synth.make_reads(c.length, c.gc, c.step, args.cov, 100, rng))
+    u.update(chrom=c, ds=ds, de=de, us=us, ue=ue, n_iv=len(ds) + len(us), reads=reads, n_reads=len(c.pos),
              sum_len=int((de.astype(np.int64) - ds).sum() + (ue.astype(np.int64) - us).sum()))
     return u
 
 
-def upload_unit(u, ctx):
-    """Make one chromosome resident in HBM behind the rank's batch context (the BAM loop's hand-over)."""
-    c = u["chrom"]
-    u["index"] = ctx.chrom_begin(c.length, c.gc)
-    ctx.reads(c.pos, c.mapq)
-    if c.map_start is not None:
-        ctx.mappability(c.map_start, c.map_end, c.map_val)
-    ctx.intervals("D", u["ds"], u["de"])
-    if u["n_dups"]:
-        ctx.intervals("E", u["us"], u["ue"])
+def open_layout(ctx, mine):
+    """The part of a cohort job that is handed over once: chromosomes, GC arrays, intervals, tracks."""
+    for i, u in enumerate(mine):
+        c = u["chrom"]
+        u["index"] = ctx.chrom_begin(c.length, c.gc)
+        assert u["index"] == i
+        if c.map_start is not None:
+            ctx.mappability(c.map_start, c.map_end, c.map_val)
+        ctx.intervals("D", u["ds"], u["de"])
+        if len(u["us"]):
+            ctx.intervals("E", u["us"], u["ue"])
+
+
+def pinned_samples(ctx, mine):
+    """[(pos, mapq, chrom_off)] per rotation slot: this rank's chromosomes' tuples one behind the other in pinned
+    host memory -- where a decoder would have left them."""
+    out = []
+    for j in range(N_ROTATE):
+        n = sum(len(u["reads"][j][0]) for u in mine)
+        pos, mapq = ctx.host_alloc(max(n, 1), np.int32), ctx.host_alloc(max(n, 1), np.uint8)
+        off = np.zeros(len(mine) + 1, np.uint64)
+        at = 0
+        for k, u in enumerate(mine):
+            p, m = u["reads"][j]
+            pos[at:at + len(p)] = p
+            mapq[at:at + len(p)] = m
+            at += len(p)
+            off[k + 1] = at
+        out.append((pos, mapq, off))
+    return out
 
 
 def depth_kernel_bytes(units):
@@ -114,16 +154,14 @@ def depth_kernel_bytes(units):
     total = 0
     for u in units:
         L, n = u["length"], u["n_reads"]
-        n_win = (L + 99) // 100
-        n_tiles = (L + 2047) // 2048
-        total += 2 * L + 5 * n + n_win + 4 * (n_tiles + 1)
+        total += 2 * L + 5 * n + (L + 99) // 100 + 4 * ((L + 2047) // 2048 + 1)
     return total
 
 
-def tuple_kernel_bytes(units):
+def tuple_kernel_bytes(units, j=0):
     """Algorithmic bytes of one ingest_tuples launch over these chromosomes: every tuple read
     once (int32 pos + uint8 mapq) and each GC byte at most once."""
-    return sum(5 * u["n_reads"] + (u["length"] + 99) // 100 for u in units)
+    return sum(5 * len(u["reads"][j][0]) + (u["length"] + 99) // 100 for u in units)
 
 
 def dense_reference_bytes(u, with_map):
@@ -135,41 +173,224 @@ def dense_reference_bytes(u, with_map):
     return b
 
 
-def cpu_baseline(mine, ctx, args):
-    """The oracle (a serial port of the reference's loops) timed on this host, 1 thread, on a bounded
-    sample of the same workload; its results double as a full-size parity check of the HIP path."""
+def compare_records(got, want, what, with_map):
+    """The parity bar of BASELINE.json on one chromosome's records; -> number of intervals whose CN call agrees."""
+    assert np.array_equal(got["observed"], want["observed"]), "observed mismatch " + what
+    assert np.array_equal(got["expected"].view(np.uint32), want["expected"].view(np.uint32)), "expected_rd bits " + what
+    for k in ("lhomo", "lhetero", "lnone"):
+        assert np.allclose(got[k], want[k], rtol=0, atol=1e-6, equal_nan=True), k + " " + what
+    assert np.allclose(got["score"], want["score"], rtol=1e-6, atol=1e-6, equal_nan=True), "score " + what
+    if with_map:
+        assert np.allclose(got["mappability"], want["mappability"], rtol=0, atol=1e-6, equal_nan=True), "mappability " + what
+    same = int(np.count_nonzero(got["cn"] == want["cn"]))
+    assert same == len(want), "CN mismatch " + what
+    return same
+
+
+def cpu_baseline(mine, recs, E, args, with_map):
+    """The oracle (a serial port of the reference's loops) timed on this host, 1 thread, on a bounded sample of the
+    same workload (rotation slot 0); its results double as a full-size parity check of the HIP path's records."""
     from oracle import oracle as O
     O.lib()
-    todo = sorted(mine, key=lambda u: u["length"])
-    t_cpu, n_iv, names = 0.0, 0, []
-    for u in todo:
+    first = np.cumsum([0] + [u["n_iv"] for u in mine])
+    todo = sorted(range(len(mine)), key=lambda i: mine[i]["length"])
+    t_cpu, n_iv, same, names = 0.0, 0, 0, []
+    for i in todo:
+        u = mine[i]
         c = u["chrom"]
+        pos, mapq = u["reads"][0]
         t0 = time.perf_counter()
-        rd, _ = O.count_reads(c.length, c.pos, c.mapq, -1)
-        E, _, _ = O.calc_mean_per_chr(rd, c.gc)
+        rd, _ = O.count_reads(c.length, pos, mapq, -1)
+        Eo, _, _ = O.calc_mean_per_chr(rd, c.gc)
         m = O.paint_mappability(c.length, c.map_start, c.map_end, c.map_val) if c.map_start is not None else None
-        od = O.find_depths(rd, m, c.gc, E, "D", O.make_svs(u["ds"], u["de"]))
-        ou = O.find_depths(rd, m, c.gc, E, "E", O.make_svs(u["us"], u["ue"]))
+        od = O.find_depths(rd, m, c.gc, Eo, "D", O.make_svs(u["ds"], u["de"]))
+        ou = O.find_depths(rd, m, c.gc, Eo, "E", O.make_svs(u["us"], u["ue"]))
         t_cpu += time.perf_counter() - t0
         n_iv += u["n_iv"]
         names.append(u["name"])
         # parity at full size (the oracle is the checker here, never the thing measured above)
-        ctx.select(u["index"])
-        dels, dups, Eg, _ = ctx.fetch()
-        assert np.array_equal(Eg.view(np.uint32), E.view(np.uint32)), "expected_read_depth mismatch"
-        for got, want in ((dels, od), (dups, ou)):
-            assert np.array_equal(got["observed"], want["observed"]), "observed mismatch chr" + u["name"]
-            assert np.array_equal(got["expected"].view(np.uint32), want["expected"].view(np.uint32))
-            assert np.array_equal(got["cn"], want["cn"]), "CN mismatch chr" + u["name"]
-            assert np.allclose(got["lnone"], want["lnone"], rtol=0, atol=1e-6)
-            assert np.allclose(got["score"], want["score"], rtol=0, atol=1e-6)
+        assert np.array_equal(E[i].view(np.uint32), Eo.view(np.uint32)), "expected_read_depth mismatch chr" + u["name"]
+        a, nd = int(first[i]), len(u["ds"])
+        same += compare_records(recs[a:a + nd], od, "chr" + u["name"] + " dels", with_map)
+        same += compare_records(recs[a + nd:a + u["n_iv"]], ou, "chr" + u["name"] + " dups", with_map)
         if t_cpu >= args.cpu_seconds:
             break
     return dict(value=n_iv / t_cpu, unit="intervals/s", cores=1, kind="port",
-                sample="chromosomes %s of the same workload (%d intervals, %.1f s, oracle/conga_oracle.c, "
-                       "results compared with the HIP path)" % (",".join(names), n_iv, t_cpu))
+                sample="chromosomes %s of the same workload (%d intervals, %.1f s, oracle/conga_oracle.c through ctypes, "
+                       "every record compared with the HIP path's)" % (",".join(names), n_iv, t_cpu)), same / max(n_iv, 1)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# one measured leg: layout once, then K pipelined steps
+# ---------------------------------------------------------------------------------------------------------------------
+class Leg:
+    """Three contexts behind one layout on this rank's GPU, three pinned samples, and the step loop."""
+
+    def __init__(self, args, env, scaling, config, flags_extra=0):
+        self.args, self.env, self.scaling, self.config = args, env, scaling, config
+        world, rank = env["world"], env["rank"]
+        self.units = build_units(args, world, scaling, config)
+        self.mine = [make_unit(u, args, config) for u in self.units if u["owner"] == rank]
+        self.with_map = config != "dels"
+        flags = capi.FLAG_BATCH | flags_extra | (capi.FLAG_MATERIALIZE_DEPTH if args.formulation == "dense" else 0)
+        if env["dist_on"]:
+            flags |= capi.FLAG_RESULTS_ON_DEVICE  # the records travel device-to-device into the RCCL gather, not over PCIe
+        self.ctxs = [capi.Context(device=env["local_rank"], flags=flags) for _ in range(N_ROTATE)]
+        for c in self.ctxs:
+            open_layout(c, self.mine)
+        self.samples = pinned_samples(self.ctxs[0], self.mine)
+        self.n_iv_mine = sum(u["n_iv"] for u in self.mine)
+        self.rec = capi.RESULT_DTYPE.itemsize
+        self.out = [np.zeros(self.n_iv_mine, dtype=capi.RESULT_DTYPE) for _ in range(N_ROTATE)]
+        self.E = [np.zeros((len(self.mine), 101), np.float32) for _ in range(N_ROTATE)]
+        self.total_iv = self.n_iv_mine
+        if env["dist_on"]:
+            self._dist_setup()
+
+    def _dist_setup(self):
+        import torch
+        import torch.distributed as dist
+        env = self.env
+        t = torch.tensor([self.n_iv_mine * self.rec], dtype=torch.int64, device=env["gather_dev"])
+        all_b = [torch.zeros_like(t) for _ in range(env["world"])]
+        dist.all_gather(all_b, t)
+        self.bytes_per_rank = [int(x.item()) for x in all_b]
+        self.total_iv = sum(self.bytes_per_rank) // self.rec
+        pad = max(max(self.bytes_per_rank), 1)
+        dev = env["dev"]
+        # one padded send buffer per context; rank 0 receives into per-context buffers and brings them to the host
+        self.packed = [torch.zeros(pad, dtype=torch.uint8, device=dev) for _ in range(N_ROTATE)]
+        self.recv = [[torch.empty(pad, dtype=torch.uint8, device=env["gather_dev"]) for _ in range(env["world"])]
+                     if env["rank"] == 0 else None for _ in range(N_ROTATE)]
+        self.host_recv = [torch.empty((env["world"], pad), dtype=torch.uint8).pin_memory() if env["rank"] == 0 else None
+                          for _ in range(N_ROTATE)]
+        self.ext = [None if env["rehearsal"] else torch.cuda.ExternalStream(c.stream(), device=dev) for c in self.ctxs]
+
+    # -- one step, in two halves so that the copy of step k + 1 is in flight while step k finishes
+    def enqueue(self, k):
+        c = self.ctxs[k % N_ROTATE]
+        c.sample_reads(*self.samples[k % N_ROTATE])   # pinned host -> HBM, asynchronous
+        c.compute()                                   # the whole hot path for this rank's chromosomes, asynchronous
+
+    def finish(self, k):
+        j = k % N_ROTATE
+        c = self.ctxs[j]
+        if not self.env["dist_on"]:
+            c.sample_fetch(self.out[j], self.E[j])    # waits for the kernels; records into host memory
+            return
+        import torch
+        import torch.distributed as dist
+        env = self.env
+        c.sync()                                      # (settles the wrap guard before the records are read on the device)
+        c.results_copy(self.packed[j].data_ptr(), self.n_iv_mine * self.rec)
+        if env["rehearsal"]:                          # one GPU, gloo: host tensors
+            c.sync()
+            dist.gather(self.packed[j].cpu(), self.recv[j], dst=0)
+            return
+        with torch.cuda.stream(self.ext[j]):          # RCCL over xGMI, ordered behind the copy on the context's stream
+            dist.gather(self.packed[j], self.recv[j], dst=0)
+            if env["rank"] == 0:
+                for r in range(env["world"]):
+                    self.host_recv[j][r].copy_(self.recv[j][r], non_blocking=True)
+        if env["rank"] == 0:
+            self.ext[j].synchronize()                 # the gathered records are in (pinned) host memory
+
+    def run(self, n, pipelined=True):
+        if pipelined:
+            self.enqueue(0)
+            for k in range(1, n):
+                self.enqueue(k)
+                self.finish(k - 1)
+            self.finish(n - 1)
+        else:
+            for k in range(n):
+                self.enqueue(k)
+                self.finish(k)
+
+    def timed(self, steps, warmup, pipelined=True):
+        """-> seconds for exactly `steps` steps, max over ranks, bracketed by barrier + synchronize."""
+        import torch
+        env = self.env
+        if warmup:
+            self.run(warmup, pipelined)
+        env["barrier"]()
+        t0 = time.perf_counter()
+        self.run(steps, pipelined)
+        env["barrier"]()
+        elapsed = time.perf_counter() - t0
+        if env["dist_on"]:
+            import torch.distributed as dist
+            t = torch.tensor([elapsed], dtype=torch.float64, device=env["gather_dev"])
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed
+
+    def kernel_only(self, steps, rotate=True):
+        """The kernels alone on resident tuples (what round 1 reported as `value`): compute + sync per step."""
+        for c in self.ctxs:
+            c.compute()
+            c.sync()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            c = self.ctxs[k % N_ROTATE if rotate else 0]
+            c.compute()
+            c.sync()
+        return (time.perf_counter() - t0) / steps
+
+    def profile_kernels(self, reps=4, rotate=True):
+        """Per-kernel device time from HIP events recorded on the context's own stream (CONGA_FLAG_PROFILE)."""
+        ctxs = self.ctxs if rotate else self.ctxs[:1]
+        for c in ctxs:
+            c.set_profile(True)
+        kms = np.zeros(len(capi.KERNEL_NAMES))
+        n, dense_ran = 0, False
+        for _ in range(reps):
+            for c in ctxs:
+                c.compute()
+                c.select(0)
+                st = c.fetch()[3]
+                kms += np.array(st.kernel_ms[:len(capi.KERNEL_NAMES)])
+                dense_ran = bool(st.depth_materialized)
+                n += 1
+        for c in ctxs:
+            c.set_profile(False)
+        return kms / n, dense_ran
+
+    def close(self):
+        for c in self.ctxs:
+            c.close()
+
+
+def traffic_of(name):
+    tpath = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(tpath):
+        return None, None
+    t = json.load(open(tpath))
+    return t.get("hbm_bytes_per_launch"), t.get("campaign")
+
+
+def roofline_of(kernel, ms, nbytes, kms, traffic_file, regime):
+    achieved = nbytes / (max(ms, 1e-9) * 1e-3) / 1e9
+    traffic, campaign = traffic_of(traffic_file)
+    return dict(bound="hbm", kernel=kernel, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=round(achieved / HBM_PEAK_GBS, 4), algorithmic_bytes_per_launch=int(nbytes),
+                avg_launch_ms=round(float(ms), 5), traffic=traffic,
+                traffic_source="profiles/%s (rocprofv3 --pmc campaign %s; not measured in this run)" % (traffic_file, campaign),
+                regime=regime, kernel_ms_per_step={k: round(float(v), 4) for k, v in zip(capi.KERNEL_NAMES, kms)})
+
+
+def workload_text(leg, args, config):
+    per_sample = leg.total_iv // max(leg.env["world"] if leg.scaling == "weak" else 1, 1)
+    what = {"dels": "BASELINE configs[1]", "dels+dups+map": "BASELINE configs[2]"}[config]
+    if leg.env["world"] > 1 and leg.scaling == "strong":
+        what = "BASELINE configs[3] (the configs[1] sample sharded by chromosome over %d GPUs)" % leg.env["world"]
+    return ("%s: GRCh37 autosomes 1-22, %d deletion rows%s (%d intervals kept >= 1000 bp per sample)%s, %.1fx synthetic "
+            "samples, 100-bp GC windows; one step = one sample: tuples in pinned host memory -> records in host memory" % (
+                what, synth.N_DELS_GENOME, "" if config == "dels" else " + %d duplication rows" % synth.N_DUPS_GENOME,
+                per_sample, "" if config == "dels" else ", 100-mer-like mappability track", args.cov))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
     # stdout carries exactly one JSON line: anything a library prints there while the job runs (RCCL prints a version
@@ -208,182 +429,108 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
 
-    units = build_units(args, world)
-    flags = capi.FLAG_BATCH | (capi.FLAG_MATERIALIZE_DEPTH if args.formulation == "dense" else 0)
-    if dist_on or args.results_on_device:
-        flags |= capi.FLAG_RESULTS_ON_DEVICE  # the records travel device-to-device into the RCCL gather, not over PCIe
-    ctx = capi.Context(device=local_rank, flags=flags)  # every chromosome of this rank, one launch per kernel
-    mine = [make_unit(u, args) for u in units if u["owner"] == rank]
-    for u in mine:
-        upload_unit(u, ctx)
-    ctx.sync()
-    rec = capi.RESULT_DTYPE.itemsize
-    bytes_per_rank = [sum((u["n_dels"] + u["n_dups"]) * rec for u in units if u["owner"] == r) for r in range(world)]
-    # interval counts after the min-size filter are only known to the owner: exchange them once
-    my_bytes = sum(u["n_iv"] for u in mine) * rec
-    if dist_on:
-        t = torch.tensor([my_bytes], dtype=torch.int64, device=gather_dev)
-        all_b = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(all_b, t)
-        bytes_per_rank = [int(x.item()) for x in all_b]
-    else:
-        bytes_per_rank = [my_bytes]
-    # Two sets of gather buffers, used alternately, padded to the largest contribution so that they go into the RCCL
-    # gather as they are (no per-step allocation, no extra copy).  The gather of step k is asynchronous and overlaps the
-    # compute of step k + 1; before step k + 2 copies its records into the same buffer, the context's stream is made to
-    # wait for the event recorded behind gather k.
-    pad = max(max(bytes_per_rank), 1)
-    packed2 = [torch.zeros(pad, dtype=torch.uint8, device=dev) for _ in range(2)]
-    recv2 = [[torch.empty(pad, dtype=torch.uint8, device=gather_dev) for _ in range(world)] if (rank == 0 and dist_on) else None
-             for _ in range(2)]
-    gathered_ev = [None, None]
-    ext_stream = torch.cuda.ExternalStream(ctx.stream(), device=dev) if (dist_on and not rehearsal) else None
-    total_iv = sum(bytes_per_rank) // rec
-    step_no = [0]
-
-    def step():
-        slot = step_no[0] & 1
-        packed = packed2[slot]
-        step_no[0] += 1
-        if ext_stream is not None and gathered_ev[slot] is not None:
-            ext_stream.wait_event(gathered_ev[slot])      # the gather that read this buffer two steps ago is done
-        ctx.compute()                               # whole hot path for this rank's chromosomes, async
-        if dist_on:
-            ctx.results_copy(packed.data_ptr(), my_bytes)   # records stay on the device for the RCCL gather
-        ctx.sync()                                  # N=1: the records are in pinned host memory now
-        if not dist_on:
-            return [packed[:0]]
-        if rehearsal:                               # one GPU, gloo: host tensors
-            send = packed.cpu()
-            dist.gather(send, recv2[slot], dst=0)
-        else:
-            dist.gather(packed, recv2[slot], dst=0)  # RCCL over xGMI; ordered behind the host-side sync above
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(dev))
-            gathered_ev[slot] = ev
-        if rank != 0:
-            return None
-        return [recv2[slot][r][:bytes_per_rank[r]] for r in range(world)]
-
     def barrier():
         if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        gathered = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist_on:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    env = dict(rank=rank, world=world, local_rank=local_rank, dev=dev, gather_dev=gather_dev, dist_on=dist_on,
+               rehearsal=rehearsal, barrier=barrier)
+    scaling = args.scaling if args.scaling != "auto" else ("strong" if world > 1 else "weak")
+
+    leg = Leg(args, env, scaling, args.config)
+    elapsed = leg.timed(args.steps, args.warmup)
     ms_per_step = 1e3 * elapsed / args.steps
+    samples_per_step = world if scaling == "weak" else 1
 
     out = None
     if rank == 0:
         if dist_on:
-            got = sum(g.numel() for g in gathered) // rec
-            assert got == total_iv, (got, total_iv)
-            if args.dist_selftest:
-                # the gathered bytes are the records the context holds (un-permuted fetch order = results_copy order)
-                ctx.compute()
-                ctx.sync()
-                want = b""
-                for u in sorted(mine, key=lambda x: x["index"]):
-                    ctx.select(u["index"])
-                    dels, dups = ctx.fetch()[:2]
-                    want += dels.tobytes() + dups.tobytes()
-                have = gathered[0].cpu().numpy().tobytes()
+            got = sum(leg.bytes_per_rank) // leg.rec
+            assert got == leg.total_iv
+            if args.dist_selftest and not rehearsal:
+                # the gathered bytes are the records the context holds (fetch order = results_copy order)
+                j = (args.steps - 1) % N_ROTATE
+                want = leg.ctxs[j].sample_fetch()[0].tobytes()
+                have = leg.host_recv[j][0][:leg.bytes_per_rank[0]].numpy().tobytes()
                 assert have == want, "gathered records differ from the fetched ones"
+        mine = leg.mine
+        reads_step = int(sum(len(u["reads"][0][0]) for u in mine))
+        h2d_bytes = 5 * reads_step
+        cfg = dict(workload=workload_text(leg, args, args.config), samples_per_step=samples_per_step,
+                   chromosomes_per_sample=len(leg.units) // samples_per_step, intervals_per_step=int(leg.total_iv),
+                   reads_per_step_rank0=reads_step, rotation="%d samples x %d contexts" % (N_ROTATE, N_ROTATE),
+                   parallelism="chromosome-sharded x%d, one RCCL gather per step" % world)
+        out = dict(metric="CNV intervals genotyped/sec (1000G Phase-3 set); CN-call concordance vs ref",
+                   value=round(leg.total_iv * args.steps / elapsed, 1), unit="intervals/s", n_gpus=world,
+                   steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
+                   higher_is_better=True, scaling=scaling, vs_baseline=None,
+                   dtype="i32+f32/f64",  # counts, serial float32 chain, double scores
+                   data="synthetic", config=cfg)
 
-        # ---- roofline of the dominant HBM-bound kernel: HIP events recorded on the context's own stream around
-        # every kernel (CONGA_FLAG_PROFILE), same resident inputs, one launch per kernel per compute
-        def profile_kernels(c, reps=10):
-            c.set_profile(True)
-            kms = np.zeros(len(capi.KERNEL_NAMES))
-            dense_ran = False
-            for _ in range(reps):
-                c.compute()
-                c.select(0)
-                st = c.fetch()[3]
-                kms += np.array(st.kernel_ms[:len(capi.KERNEL_NAMES)])
-                dense_ran = bool(st.depth_materialized)
-            c.set_profile(False)
-            return kms / reps, dense_ran
+    # ---- the same step unpipelined, and the kernels alone (all ranks take part: the step contains a gather)
+    single_s = leg.timed(max(3, min(args.steps, 10)), 1, pipelined=False) / max(3, min(args.steps, 10))
+    if rank == 0:
+        out["single_sample"] = dict(ms_per_step=round(1e3 * single_s, 4), value=round(leg.total_iv / single_s, 1),
+                                    note="copy, kernels and fetch of one sample one after the other (latency of a step)")
+        h2d = dict(bound="pcie-h2d", bytes_per_step=h2d_bytes, achieved=round(h2d_bytes / (ms_per_step * 1e-3) / 1e9, 2),
+                   peak=PCIE_PEAK_GBS, unit="GB/s", note="5 bytes per read (int32 pos + uint8 mapq) over PCIe Gen5 x16 per step")
+        h2d["frac"] = round(h2d["achieved"] / PCIE_PEAK_GBS, 4)
+        out["step_bound"] = h2d
 
-        def traffic_of(name):
-            tpath = os.path.join(ROOT, "profiles", name)
-            return json.load(open(tpath)).get("hbm_bytes_per_launch") if os.path.exists(tpath) else None
-
-        def roofline_of(kernel, ms, nbytes, kms, traffic):
-            achieved = nbytes / (max(ms, 1e-9) * 1e-3) / 1e9
-            return dict(bound="hbm", kernel=kernel, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 4), algorithmic_bytes_per_launch=int(nbytes),
-                        avg_launch_ms=round(float(ms), 5), traffic=traffic,
-                        kernel_ms_per_step={k: round(float(v), 4) for k, v in zip(capi.KERNEL_NAMES, kms)})
-
-        kms, dense_ran = profile_kernels(ctx)
+    if rank == 0 and not dist_on:
+        ko_rot = leg.kernel_only(max(args.steps, 12), rotate=True)
+        ko_one = leg.kernel_only(max(args.steps, 12), rotate=False)
+        out["kernel_only"] = dict(value=round(leg.total_iv / ko_rot, 1), ms_per_step=round(1e3 * ko_rot, 4),
+                                  regime="tuples resident in HBM, %d samples rotated (%.0f MB between reuses > 256 MiB "
+                                         "Infinity Cache)" % (N_ROTATE, N_ROTATE * tuple_kernel_bytes(mine) / 1e6),
+                                  one_sample_replayed=dict(value=round(leg.total_iv / ko_one, 1), ms_per_step=round(1e3 * ko_one, 4),
+                                                           regime="one resident sample replayed (fits the Infinity Cache)"),
+                                  note="round 1's `value`: no PCIe copy in the step")
+        kms, dense_ran = leg.profile_kernels(rotate=True)
+        regime = "HBM-streaming: %d resident samples rotated, %.0f MB between reuses" % (N_ROTATE, N_ROTATE * tuple_kernel_bytes(mine) / 1e6)
         if dense_ran:
-            roofline = roofline_of("depth_tile_kernel", kms[1], depth_kernel_bytes(mine), kms,
-                                   traffic_of("depth_tile_traffic.json"))
+            roofline = roofline_of("depth_tile_kernel", kms[1], depth_kernel_bytes(mine), kms, "depth_tile_traffic.json", regime)
         else:
             # the serial-float chain is latency-bound ("report its time separately"); the HBM-bound
             # kernel of the tuple-space path is the one pass over the tuples
-            roofline = roofline_of("ingest_tuples_kernel", kms[0], tuple_kernel_bytes(mine), kms,
-                                   traffic_of("ingest_tuples_traffic.json"))
+            roofline = roofline_of("ingest_tuples_kernel", kms[0], tuple_kernel_bytes(mine), kms, "ingest_tuples_traffic.json", regime)
             roofline["chain_ms"] = round(float(kms[6]), 4)
-
+            k1, _ = leg.profile_kernels(rotate=False)
+            roofline["cache_resident"] = dict(avg_launch_ms=round(float(k1[0]), 5),
+                                              achieved=round(tuple_kernel_bytes(mine) / (max(k1[0], 1e-9) * 1e-3) / 1e9, 1),
+                                              regime="one sample replayed: fits the 256 MiB Infinity Cache (round 1's figure)")
+        out["roofline"] = roofline
+        out["formulation"] = "dense" if dense_ran else "tuple-space"
+        out["dtype"] = "i16/i32+f32/f64" if dense_ran else "i32+f32/f64"
         dense = sum(dense_reference_bytes(u, args.config != "dels") for u in mine)
-        cfg = dict(workload=("BASELINE configs[1]: GRCh37 autosomes 1-22, %d deletion rows (%d kept >= 1000 bp)%s, "
-                             "%.1fx synthetic sample, 100-bp GC windows" % (
-                                 synth.N_DELS_GENOME, total_iv // max(world if args.scaling == "weak" else 1, 1),
-                                 "" if args.config == "dels" else " + dups + 100-mer-like mappability track",
-                                 args.cov)),
-                   samples=world if args.scaling == "weak" else 1, chromosomes_per_sample=len(units) // max(
-                       world if args.scaling == "weak" else 1, 1),
-                   intervals_per_step=int(total_iv), reads_rank0=int(sum(u["n_reads"] for u in mine)),
-                   parallelism="chromosome-sharded x%d, one RCCL gather per step" % world,
-                   dense_reference_bytes_rank0=int(dense))
-        out = dict(metric="CNV intervals genotyped/sec (1000G Phase-3 set); CN-call concordance vs ref",
-                   value=round(total_iv * args.steps / elapsed, 1), unit="intervals/s", n_gpus=world,
-                   steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
-                   higher_is_better=True, scaling=args.scaling, vs_baseline=None,
-                   dtype="i16/i32+f32/f64" if dense_ran else "i32+f32/f64",  # counts, serial float32 chain, double scores
-                   data="synthetic", config=cfg, roofline=roofline,
-                   formulation="dense" if dense_ran else "tuple-space",
-                   dense_equivalent=dict(bytes=int(dense), achieved=round(dense / (ms_per_step * 1e-3) / 1e9, 1),
-                                         unit="GB/s", x_hbm_peak=round(dense / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
-                                         note="SURVEY.md 8d dense-formulation bytes / measured step time; above 1.0 "
-                                              "only because the tuple-space formulation never moves them"))
-        if world == 1:
-            # never `value`: the same pass fed from host buffers (pageable numpy -> pinned ring -> H2D over PCIe,
-            # layout upload, compute), i.e. what a caller holding decoded tuples in host memory sees
-            t1 = time.perf_counter()
-            ctx.reset()
-            for u in mine:
-                upload_unit(u, ctx)
-            ctx.compute()
-            ctx.sync()
-            out["host_buffers_inclusive"] = dict(value=round(total_iv / (time.perf_counter() - t1), 1),
-                                                 unit="intervals/s", note="one pass incl. PCIe staging; not the metric")
-        if world == 1 and not dense_ran and args.dense_leg:
-            # the reference's dense formulation on the same resident inputs: a second context with
-            # CONGA_FLAG_MATERIALIZE_DEPTH, a few steps, and the roofline of its depth_tile kernel
+        out["dense_equivalent"] = dict(bytes=int(dense), achieved=round(dense / ko_rot / 1e9, 1), unit="GB/s",
+                                       x_hbm_peak=round(dense / ko_rot / 1e9 / HBM_PEAK_GBS, 3),
+                                       note="SURVEY.md 8d dense-formulation bytes / kernel_only step time; above 1.0 only "
+                                            "because the tuple-space formulation never moves them")
+    elif rank == 0:
+        out["roofline"] = dict(bound="hbm", kernel="ingest_tuples_kernel", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s",
+                               frac=None, traffic=None, note="per-kernel timing is taken at N=1 (see BENCH at --gpus 1)")
+
+    # ---- N > 1: the other scaling as a leg of its own
+    if world > 1 and args.scaling == "auto":
+        other = "weak" if scaling == "strong" else "strong"
+        leg.close()
+        leg2 = Leg(args, env, other, args.config)
+        e2 = leg2.timed(args.steps, args.warmup)
+        if rank == 0:
+            out[other] = dict(scaling=other, samples_per_step=world if other == "weak" else 1, intervals_per_step=int(leg2.total_iv),
+                              ms_per_step=round(1e3 * e2 / args.steps, 4), value=round(leg2.total_iv * args.steps / e2, 1))
+        leg2.close()
+        leg = None
+
+    if rank == 0 and world == 1 and not dist_on:
+        mine = leg.mine
+        if not dense_ran and args.dense_leg:
+            # the reference's dense formulation on the same inputs: a context with CONGA_FLAG_MATERIALIZE_DEPTH
             dctx = capi.Context(device=local_rank, flags=capi.FLAG_BATCH | capi.FLAG_MATERIALIZE_DEPTH)
-            for u in mine:
-                c = u["chrom"]
-                dctx.chrom_begin(c.length, c.gc)
-                dctx.reads(c.pos, c.mapq)
-                if c.map_start is not None:
-                    dctx.mappability(c.map_start, c.map_end, c.map_val)
-                dctx.intervals("D", u["ds"], u["de"])
-                if u["n_dups"]:
-                    dctx.intervals("E", u["us"], u["ue"])
+            open_layout(dctx, mine)
+            dctx.sample_reads(*leg.samples[0])
             for _ in range(3):
                 dctx.compute()
             dctx.sync()
@@ -392,26 +539,40 @@ def main():
                 dctx.compute()
                 dctx.sync()
             d_ms = (time.perf_counter() - t1) / 5 * 1e3
-            dk, _ = profile_kernels(dctx, reps=5)
-            out["roofline_dense"] = roofline_of("depth_tile_kernel", dk[1], depth_kernel_bytes(mine), dk,
-                                                traffic_of("depth_tile_traffic.json"))
+            dctx.set_profile(True)
+            dk = np.zeros(len(capi.KERNEL_NAMES))
+            for _ in range(5):
+                dctx.compute()
+                dctx.select(0)
+                dk += np.array(dctx.fetch()[3].kernel_ms[:len(capi.KERNEL_NAMES)])
+            dk /= 5
+            dctx.set_profile(False)
+            out["roofline_dense"] = roofline_of("depth_tile_kernel", dk[1], depth_kernel_bytes(mine), dk, "depth_tile_traffic.json",
+                                                "5.9 GB written per launch (beyond any cache); resident tuples")
             out["roofline_dense"]["ms_per_step"] = round(d_ms, 4)
-            out["roofline_dense"]["value"] = round(total_iv / (d_ms * 1e-3), 1)
+            out["roofline_dense"]["value"] = round(leg.total_iv / (d_ms * 1e-3), 1)
             # both formulations must give the same records
-            ctx.compute()
-            ctx.sync()
-            for u in mine:
-                ctx.select(u["index"])
-                dctx.select(u["index"])
-                g1, g2 = ctx.fetch(), dctx.fetch()
-                assert g1[0].tobytes() == g2[0].tobytes() and g1[1].tobytes() == g2[1].tobytes(), \
-                    "tuple-space and dense records differ on chr" + u["name"]
+            c0 = leg.ctxs[0]
+            c0.sample_reads(*leg.samples[0])
+            c0.compute()
+            g1 = c0.sample_fetch()[0]
+            dctx.compute()
+            g2 = dctx.sample_fetch()[0]
+            assert g1.tobytes() == g2.tobytes(), "tuple-space and dense records differ"
             dctx.close()
-        if world == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(mine, ctx, args)
-            out["cn_concordance"] = 1.0  # asserted bit-exact against the oracle on the cpu_baseline sample
+        if args.cpu_seconds > 0:
+            c0 = leg.ctxs[0]
+            c0.sample_reads(*leg.samples[0])
+            c0.compute()
+            recs, E, _ = c0.sample_fetch()
+            out["cpu_baseline"], out["cn_concordance"] = cpu_baseline(mine, recs, E, args, leg.with_map)
+        leg.close()
+        leg = None
+        if args.config_legs and args.config == "dels":
+            out["configs"] = config_legs(args, env)
 
-    ctx.close()
+    if leg is not None:
+        leg.close()
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
@@ -419,6 +580,41 @@ def main():
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     os.close(json_fd)
+
+
+def config_legs(args, env):
+    """Short driver-run legs for the other single-GPU configurations of BASELINE.json."""
+    legs = {}
+    # ---- configs[2]: dels + dups together with the 100-mer mappability track
+    steps = max(5, min(args.steps, 10))
+    leg = Leg(args, env, "weak", "dels+dups+map")
+    e = leg.timed(steps, 2)
+    ko = leg.kernel_only(steps)
+    kms, _ = leg.profile_kernels(reps=2)
+    rows = int(sum(len(u["chrom"].map_start) for u in leg.mine))
+    r = roofline_of("ingest_tuples_kernel", kms[0], tuple_kernel_bytes(leg.mine), kms, "ingest_tuples_traffic.json",
+                    "HBM-streaming: %d resident samples rotated" % N_ROTATE)
+    r["chain_ms"] = round(float(kms[6]), 4)
+    legs["configs[2]"] = dict(workload=workload_text(leg, args, "dels+dups+map"), intervals_per_step=int(leg.total_iv),
+                              track_rows=rows, ms_per_step=round(1e3 * e / steps, 4), value=round(leg.total_iv * steps / e, 1),
+                              kernel_only=dict(ms_per_step=round(1e3 * ko, 4), value=round(leg.total_iv / ko, 1)), roofline=r)
+    if args.cpu_seconds > 0:
+        c0 = leg.ctxs[0]
+        c0.sample_reads(*leg.samples[0])
+        c0.compute()
+        recs, E, _ = c0.sample_fetch()
+        small = argparse.Namespace(**vars(args))
+        small.cpu_seconds = min(args.cpu_seconds, 4.0)
+        legs["configs[2]"]["cpu_baseline"], legs["configs[2]"]["cn_concordance"] = cpu_baseline(leg.mine, recs, E, small, True)
+    leg.close()
+    # ---- configs[4]: 5x with the split-read path (--rp with --dups)
+    try:
+        from conga_amd import rp_bench
+    except ImportError:
+        rp_bench = None
+    if rp_bench is not None:
+        legs["configs[4]"] = rp_bench.leg(args, env)
+    return legs
 
 
 if __name__ == "__main__":
