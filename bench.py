@@ -244,6 +244,11 @@ class Leg:
         self.out = [np.zeros(self.n_iv_mine, dtype=capi.RESULT_DTYPE) for _ in range(N_ROTATE)]
         self.E = [np.zeros((len(self.mine), 101), np.float32) for _ in range(N_ROTATE)]
         self.total_iv = self.n_iv_mine
+        # handing the layout over is not a step: every context prepares its device layout here, once
+        for j, c in enumerate(self.ctxs):
+            c.sample_reads(*self.samples[j])
+            c.compute()
+            c.sync()
         if env["dist_on"]:
             self._dist_setup()
 
@@ -357,6 +362,15 @@ class Leg:
         return kms / n, dense_ran
 
     def close(self):
+        # torch's caching allocators record an event on every stream a block was used on when the block is freed: the
+        # tensors that travelled on the contexts' streams have to go before those streams do
+        if self.env["dist_on"]:
+            import gc
+            import torch
+            torch.cuda.synchronize()
+            self.packed = self.recv = self.host_recv = self.ext = None
+            gc.collect()
+            torch.cuda.empty_cache()
         for c in self.ctxs:
             c.close()
 
