@@ -69,7 +69,7 @@ def parse_args():
                     help="skip the dense-formulation leg that follows the timed region at N=1")
     ap.add_argument("--no-config-legs", dest="config_legs", action="store_false",
                     help="skip the configs[2] / configs[4] legs that follow the timed region at N=1")
-    ap.add_argument("--rp-chroms", type=str, default="19,20,21,22",
+    ap.add_argument("--rp-chroms", type=str, default="20,21,22",
                     help="chromosomes of the configs[4] (--rp) leg; 'all' = the whole genome (21 GB of read records)")
     ap.add_argument("--dist-selftest", action="store_true",
                     help="run the multi-rank code path (RCCL process group, device-resident records, gather) with the "
@@ -492,7 +492,7 @@ def main():
         h2d["frac"] = round(h2d["achieved"] / PCIE_PEAK_GBS, 4)
         out["step_bound"] = h2d
 
-    if rank == 0 and not dist_on:
+    if rank == 0:
         ko_rot = leg.kernel_only(max(args.steps, 12), rotate=True)
         ko_one = leg.kernel_only(max(args.steps, 12), rotate=False)
         out["kernel_only"] = dict(value=round(leg.total_iv / ko_rot, 1), ms_per_step=round(1e3 * ko_rot, 4),
@@ -514,6 +514,8 @@ def main():
             roofline["cache_resident"] = dict(avg_launch_ms=round(float(k1[0]), 5),
                                               achieved=round(tuple_kernel_bytes(mine) / (max(k1[0], 1e-9) * 1e-3) / 1e9, 1),
                                               regime="one sample replayed: fits the 256 MiB Infinity Cache (round 1's figure)")
+        if world > 1:
+            roofline["note"] = "rank 0's share of the chromosomes"
         out["roofline"] = roofline
         out["formulation"] = "dense" if dense_ran else "tuple-space"
         out["dtype"] = "i16/i32+f32/f64" if dense_ran else "i32+f32/f64"
@@ -522,10 +524,6 @@ def main():
                                        x_hbm_peak=round(dense / ko_rot / 1e9 / HBM_PEAK_GBS, 3),
                                        note="SURVEY.md 8d dense-formulation bytes / kernel_only step time; above 1.0 only "
                                             "because the tuple-space formulation never moves them")
-    elif rank == 0:
-        out["roofline"] = dict(bound="hbm", kernel="ingest_tuples_kernel", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s",
-                               frac=None, traffic=None, note="per-kernel timing is taken at N=1 (see BENCH at --gpus 1)")
-
     # ---- N > 1: the other scaling as a leg of its own
     if world > 1 and args.scaling == "auto":
         other = "weak" if scaling == "strong" else "strong"

@@ -62,6 +62,7 @@ struct HostSlot {
 	std::vector<int32_t> sat_start, sat_end; // sorted, disjoint
 	int64_t sr_off = 0, n_sr = 0;           // this chromosome's records in the split-read arrays
 	int64_t ref_off = 0, sat_off = 0;
+	uint64_t ref_version = 0;               // stamps every conga_reference(): the 10-mer index is rebuilt only for new text
 	// filled by prepare()
 	int64_t rd_off = 0, gc_off = 0, tile0 = 0, tidx_off = 0, iv0 = 0, map_row_off = 0, row_tile_off = 0;
 };
@@ -105,6 +106,10 @@ struct conga_ctx {
 	// layout totals (prepare)
 	int64_t total_L = 0, total_tiles = 0, total_gc = 0, n_iv = 0, n_items = 0, n_chain_x = 0, n_chain_a = 0, n_chain_b = 0, n_depth_blocks = 0;
 	bool gc_like_distinct = false, any_map = false, support_given = false, any_sr = false;
+	int sr_first_slot = 0, sr_last_slot = 0;  // first / last chromosome with split-read records and a reference
+	int n_sr_slots = 0;                       // chromosomes with split-read records and a reference (one SplitSlot each)
+	uint64_t ref_stamp = 0;                   // source of HostSlot::ref_version
+	std::vector<uint64_t> index_sig;          // what the resident 10-mer indexes were built from (slot, length, version)
 	bool any_map_painted = false; // some chromosome's track is painted into d_map by compute (dense formulation / unsorted rows)
 	bool any_map_rows = false;    // some chromosome's track is summed in row space (sorted rows, tuple-space formulation)
 	int64_t n_sr_total = 0, sr_bytes_total = 0;
@@ -121,7 +126,7 @@ struct conga_ctx {
 			d_map_start, d_map_end, d_map_val, d_iv_start, d_iv_end, d_iv_type, d_iv_slot, d_iv_has_map, d_order,
 			d_expected, d_item_off, d_item_len, d_item_iv, d_item_has_map, d_item_first, d_map_part,
 			d_support, d_results, d_bases, d_row_tile, d_depth_blocks, d_support_base, d_ref, d_sat_start, d_sat_end, d_sr_pos,
-			d_sr_mapq, d_sr_flag, d_sr_lq, d_sr_off, d_sr_data, d_kmer_count, d_kmer_offset, d_kmer_cursor, d_kmer_pos,
+			d_sr_mapq, d_sr_flag, d_sr_lq, d_sr_off, d_sr_data, d_kmer_count, d_kmer_offset, d_kmer_cursor, d_kmer_pos, d_sr_slots,
 			// conga_reads_bgzf: compressed blocks, their table, the inflated stream, the decoders' scratch, the walk's per-segment results
 			d_bz_in, d_bz_blocks, d_bz_off, d_bz_out, d_bz_status, d_bz_scratch, d_bz_crc, d_bz_seg, d_bz_cnt, d_bz_first, d_bz_stop,
 			d_bz_bad, d_bz_at, d_bz_flag;
@@ -497,42 +502,92 @@ int prepare_layout(conga_ctx *ctx)
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	}
 
-	// ---- split-read inputs: reference sequences and satellite intervals, concatenated
+	// ---- split-read inputs: reference sequences and satellite intervals, concatenated, and the 10-mer indexes.
+	// An index depends on the chromosome's sequence only: it is built here, once, for all chromosomes in three launches,
+	// and stays resident (4 bytes per base) -- a compute only maps reads against it.
 	ctx->any_sr = false;
+	ctx->n_sr_slots = 0;
 	{
 		int64_t ref_off = 0, sat_off = 0;
-		for (HostSlot &h : ctx->slots) {
+		std::vector<SplitSlot> sslots;
+		std::vector<uint64_t> sig;
+		for (int s = 0; s < n_slots; s++) {
+			HostSlot &h = ctx->slots[s];
 			h.ref_off = ref_off;
 			h.sat_off = sat_off;
 			if (h.n_sr > 0 && !h.ref.empty()) {
 				ctx->any_sr = true;
+				SplitSlot sl;
+				memset(&sl, 0, sizeof sl);
+				sl.sr_off = h.sr_off;
+				sl.n_sr = h.n_sr;
+				sl.ref_off = ref_off;
+				sl.L = h.L;
+				sl.kpos_off = ref_off; // (one index entry per base at most: the reference's own layout serves)
+				sl.kidx = (int32_t) sslots.size();
+				sl.sat_off = (int32_t) sat_off;
+				sl.n_sat = (int32_t) h.sat_start.size();
+				sl.iv0 = (int32_t) h.iv0;
+				sl.n_dels = (int32_t) h.iv_start[0].size();
+				sl.n_dups = (int32_t) h.iv_start[1].size();
+				sl.slot = s;
+				sslots.push_back(sl);
+				sig.push_back((uint64_t) s);
+				sig.push_back((uint64_t) h.ref.size());
+				sig.push_back(h.ref_version);
 				ref_off += ((int64_t) h.ref.size() + 255) & ~(int64_t) 255;
 				sat_off += (int64_t) h.sat_start.size();
 			}
 		}
+		ctx->n_sr_slots = (int) sslots.size();
 		if (ctx->any_sr) {
-			TRY(ensure(ctx, ctx->d_ref, (size_t) ref_off + 256));
+			ctx->sr_first_slot = sslots.front().slot;
+			ctx->sr_last_slot = sslots.back().slot;
+			const size_t ns = sslots.size();
+			for (size_t k = 1; k < ns; k++) // the records of the chromosomes follow each other in the arrays (commit order)
+				if (sslots[k].sr_off != sslots[k - 1].sr_off + sslots[k - 1].n_sr)
+					return fail(ctx, CONGA_ERR_INVALID, "split-read records must be committed chromosome by chromosome");
 			TRY(ensure(ctx, ctx->d_sat_start, std::max<size_t>((size_t) sat_off, 1) * 4));
 			TRY(ensure(ctx, ctx->d_sat_end, std::max<size_t>((size_t) sat_off, 1) * 4));
-			int64_t max_L = 0;
 			for (const HostSlot &h : ctx->slots) {
-				if (h.n_sr == 0 || h.ref.empty())
+				if (h.n_sr == 0 || h.ref.empty() || h.sat_start.empty())
 					continue;
-				max_L = std::max(max_L, h.L);
-				HIP_TRY(ctx, hipMemcpyAsync(ptr<uint8_t>(ctx->d_ref) + h.ref_off, h.ref.data(), h.ref.size(),
+				HIP_TRY(ctx, hipMemcpyAsync(ptr<int32_t>(ctx->d_sat_start) + h.sat_off, h.sat_start.data(), h.sat_start.size() * 4,
 						hipMemcpyHostToDevice, ctx->stream));
-				if (!h.sat_start.empty()) {
-					HIP_TRY(ctx, hipMemcpyAsync(ptr<int32_t>(ctx->d_sat_start) + h.sat_off, h.sat_start.data(),
-							h.sat_start.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-					HIP_TRY(ctx, hipMemcpyAsync(ptr<int32_t>(ctx->d_sat_end) + h.sat_off, h.sat_end.data(),
-							h.sat_end.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-				}
+				HIP_TRY(ctx, hipMemcpyAsync(ptr<int32_t>(ctx->d_sat_end) + h.sat_off, h.sat_end.data(), h.sat_end.size() * 4,
+						hipMemcpyHostToDevice, ctx->stream));
 			}
-			TRY(ensure(ctx, ctx->d_kmer_count, (size_t) kKmerBuckets * 4));
-			TRY(ensure(ctx, ctx->d_kmer_cursor, (size_t) kKmerBuckets * 4));
-			TRY(ensure(ctx, ctx->d_kmer_offset, ((size_t) kKmerBuckets + 1) * 4));
-			TRY(ensure(ctx, ctx->d_kmer_pos, (size_t) max_L * 4));
-			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+			TRY(upload(ctx, ctx->d_sr_slots, sslots.data(), ns * sizeof(SplitSlot)));
+			if (sig != ctx->index_sig) {
+				TRY(ensure(ctx, ctx->d_ref, (size_t) ref_off + 256));
+				TRY(ensure(ctx, ctx->d_kmer_pos, (size_t) ref_off * 4 + 256));
+				TRY(ensure(ctx, ctx->d_kmer_count, ns * (size_t) kKmerBuckets * 4));
+				TRY(ensure(ctx, ctx->d_kmer_cursor, ns * (size_t) kKmerBuckets * 4));
+				TRY(ensure(ctx, ctx->d_kmer_offset, ns * ((size_t) kKmerBuckets + 1) * 4));
+				int64_t max_L = 0;
+				for (const HostSlot &h : ctx->slots) {
+					if (h.n_sr == 0 || h.ref.empty())
+						continue;
+					max_L = std::max(max_L, h.L);
+					HIP_TRY(ctx, hipMemcpyAsync(ptr<uint8_t>(ctx->d_ref) + h.ref_off, h.ref.data(), h.ref.size(), hipMemcpyHostToDevice,
+							ctx->stream));
+				}
+				HIP_TRY(ctx, hipMemsetAsync(ctx->d_kmer_count.p, 0, ns * (size_t) kKmerBuckets * 4, ctx->stream));
+				HIP_TRY(ctx, hipMemsetAsync(ctx->d_kmer_cursor.p, 0, ns * (size_t) kKmerBuckets * 4, ctx->stream));
+				const int gx = (int) std::min<int64_t>((max_L + 255) / 256, (int64_t) ctx->n_cu * 8);
+				const SplitSlot *dss = ptr<SplitSlot>(ctx->d_sr_slots);
+				hipLaunchKernelGGL(kmer_index_kernel<false>, dim3(gx, (unsigned) ns), dim3(256), 0, ctx->stream, ptr<uint8_t>(ctx->d_ref), dss,
+						ptr<uint32_t>(ctx->d_kmer_count), ptr<uint32_t>(ctx->d_kmer_offset), ptr<uint32_t>(ctx->d_kmer_cursor),
+						ptr<int32_t>(ctx->d_kmer_pos));
+				hipLaunchKernelGGL(kmer_offsets_kernel, dim3((unsigned) ns), dim3(1024), 0, ctx->stream, ptr<uint32_t>(ctx->d_kmer_count),
+						ptr<uint32_t>(ctx->d_kmer_offset));
+				hipLaunchKernelGGL(kmer_index_kernel<true>, dim3(gx, (unsigned) ns), dim3(256), 0, ctx->stream, ptr<uint8_t>(ctx->d_ref), dss,
+						ptr<uint32_t>(ctx->d_kmer_count), ptr<uint32_t>(ctx->d_kmer_offset), ptr<uint32_t>(ctx->d_kmer_cursor),
+						ptr<int32_t>(ctx->d_kmer_pos));
+				HIP_TRY(ctx, hipGetLastError());
+				ctx->index_sig = sig;
+			}
+			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // (`sslots` and the satellite vectors are read by the uploads)
 		}
 	}
 
@@ -962,7 +1017,7 @@ void conga_destroy(conga_ctx *ctx)
 			&ctx->d_item_has_map, &ctx->d_item_first, &ctx->d_map_part, &ctx->d_support, &ctx->d_results,
 			&ctx->d_bases, &ctx->d_row_tile, &ctx->d_depth_blocks, &ctx->d_support_base, &ctx->d_ref, &ctx->d_sat_start, &ctx->d_sat_end,
 			&ctx->d_sr_pos, &ctx->d_sr_mapq, &ctx->d_sr_flag, &ctx->d_sr_lq, &ctx->d_sr_off, &ctx->d_sr_data,
-			&ctx->d_kmer_count, &ctx->d_kmer_offset, &ctx->d_kmer_cursor, &ctx->d_kmer_pos};
+			&ctx->d_kmer_count, &ctx->d_kmer_offset, &ctx->d_kmer_cursor, &ctx->d_kmer_pos, &ctx->d_sr_slots};
 	for (DevBuf *b : bufs)
 		free_buf(*b);
 	for (auto &s : ctx->staging) {
@@ -1486,6 +1541,7 @@ int conga_reference(conga_ctx *ctx, const char *seq, int64_t len)
 		const unsigned char c = (unsigned char) seq[i];
 		h.ref[(size_t) i] = (c >= 'a' && c <= 'z') ? (uint8_t) (c - 32) : c;
 	}
+	h.ref_version = ++ctx->ref_stamp;
 	ctx->layout_dirty = true;
 	ctx->computed = false;
 	return CONGA_OK;
@@ -1696,7 +1752,7 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 	ctx->arena_zeroed[ctx->small_cur] = false; // dirty from here on
 	// The Small blocks are final after expected_table unless split-read kernels add their counters later: that
 	// kernel then writes the pinned host copy itself (pinned host memory is device-visible) and the copy at the end goes away.
-	const bool small_by_kernel = !(ctx->any_sr && ctx->n_iv > 0);
+	const bool small_by_kernel = !ctx->any_sr;
 	// Scoring inside the chain kernel: possible when nothing the score needs is produced beside the chain.
 	const bool fused_score = !dense && !ctx->any_map_painted && ctx->n_iv > 0;
 
@@ -1867,50 +1923,36 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 		else
 			HIP_TRY(ctx, hipMemsetAsync(ctx->d_support.p, 0, (size_t) ctx->n_iv * 4, st));
 	}
-	// split-read evidence, chromosome by chromosome (k-mer index -> half-read mapping -> pairing -> support)
-	if (ctx->any_sr && ctx->n_iv > 0) {
-		for (int s = 0; s < n_slots; s++) {
-			const HostSlot &h = ctx->slots[s];
-			const size_t nd = h.iv_start[0].size(), nu = h.iv_start[1].size();
-			if (h.n_sr == 0 || h.ref.empty() || nd + nu == 0)
-				continue; // count_ReadPairs runs only for chromosomes with SVs (likelihood.c:332-348)
-			const uint8_t *ref = ptr<uint8_t>(ctx->d_ref) + h.ref_off;
-			uint32_t *cnt = ptr<uint32_t>(ctx->d_kmer_count), *cur = ptr<uint32_t>(ctx->d_kmer_cursor);
-			uint32_t *off = ptr<uint32_t>(ctx->d_kmer_offset);
-			int32_t *kpos = ptr<int32_t>(ctx->d_kmer_pos);
-			HIP_TRY(ctx, hipMemsetAsync(cnt, 0, (size_t) kKmerBuckets * 4, st));
-			HIP_TRY(ctx, hipMemsetAsync(cur, 0, (size_t) kKmerBuckets * 4, st));
-			const int grid = (int) std::min<int64_t>((h.L + 255) / 256, (int64_t) ctx->n_cu * 8);
-			hipLaunchKernelGGL(kmer_index_kernel<false>, dim3(grid), dim3(256), 0, st, ref, h.L, cnt, off, cur, kpos);
-			hipLaunchKernelGGL(kmer_offsets_kernel, dim3(1), dim3(1024), 0, st, cnt, off);
-			hipLaunchKernelGGL(kmer_index_kernel<true>, dim3(grid), dim3(256), 0, st, ref, h.L, cnt, off, cur, kpos);
-			SplitArgs a;
-			a.pos = ptr<int32_t>(ctx->d_sr_pos) + h.sr_off;
-			a.mapq = ptr<uint8_t>(ctx->d_sr_mapq) + h.sr_off;
-			a.flag = ptr<uint16_t>(ctx->d_sr_flag) + h.sr_off;
-			a.l_qseq = ptr<int32_t>(ctx->d_sr_lq) + h.sr_off;
-			a.data_off = ptr<uint64_t>(ctx->d_sr_off) + h.sr_off;
-			a.data = ptr<uint8_t>(ctx->d_sr_data);
-			a.n_reads = h.n_sr;
-			a.ref = ref;
-			a.L = h.L;
-			a.sat_start = ptr<int32_t>(ctx->d_sat_start) + h.sat_off;
-			a.sat_end = ptr<int32_t>(ctx->d_sat_end) + h.sat_off;
-			a.n_sat = (int32_t) h.sat_start.size();
-			a.offset = off;
-			a.positions = kpos;
-			a.iv_start = ptr<int32_t>(ctx->d_iv_start);
-			a.iv_end = ptr<int32_t>(ctx->d_iv_end);
-			a.iv0 = (int32_t) h.iv0;
-			a.n_dels = (int32_t) nd;
-			a.n_dups = (int32_t) nu;
-			a.support = ptr<int32_t>(ctx->d_support);
-			a.mq_threshold = ctx->opts.mq_threshold;
-			a.min_read_length = ctx->opts.min_read_length;
-			a.counters = small[s].counters;
-			const int sgrid = (int) std::min<int64_t>((h.n_sr + 3) / 4, (int64_t) ctx->n_cu * 8);
-			hipLaunchKernelGGL(split_read_kernel, dim3(sgrid), dim3(256), 0, st, a);
-		}
+	// split-read evidence: half-read mapping against the resident 10-mer indexes -> pairing -> support, every chromosome's
+	// records in one launch (count_ReadPairs runs only for chromosomes with SVs, likelihood.c:332-348: the others have no
+	// interval to add to)
+	if (ctx->any_sr && ctx->n_sr_total > 0) {
+		SplitBatchArgs g;
+		memset(&g, 0, sizeof g);
+		g.base.pos = ptr<int32_t>(ctx->d_sr_pos);
+		g.base.mapq = ptr<uint8_t>(ctx->d_sr_mapq);
+		g.base.flag = ptr<uint16_t>(ctx->d_sr_flag);
+		g.base.l_qseq = ptr<int32_t>(ctx->d_sr_lq);
+		g.base.data_off = ptr<uint64_t>(ctx->d_sr_off);
+		g.base.data = ptr<uint8_t>(ctx->d_sr_data);
+		const HostSlot &last = ctx->slots[(size_t) ctx->sr_last_slot];
+		g.base.n_reads = last.sr_off + last.n_sr; // end of the last chromosome that takes part
+		g.base.ref = ptr<uint8_t>(ctx->d_ref);
+		g.base.sat_start = ptr<int32_t>(ctx->d_sat_start);
+		g.base.sat_end = ptr<int32_t>(ctx->d_sat_end);
+		g.base.offset = ptr<uint32_t>(ctx->d_kmer_offset);
+		g.base.positions = ptr<int32_t>(ctx->d_kmer_pos);
+		g.base.iv_start = ptr<int32_t>(ctx->d_iv_start);
+		g.base.iv_end = ptr<int32_t>(ctx->d_iv_end);
+		g.base.support = ptr<int32_t>(ctx->d_support);
+		g.base.mq_threshold = ctx->opts.mq_threshold;
+		g.base.min_read_length = ctx->opts.min_read_length;
+		g.slots = ptr<SplitSlot>(ctx->d_sr_slots);
+		g.n_slots = ctx->n_sr_slots;
+		g.small = small;
+		const int64_t first = ctx->slots[(size_t) ctx->sr_first_slot].sr_off;
+		const int sgrid = (int) std::min<int64_t>((g.base.n_reads - first + 3) / 4, (int64_t) ctx->n_cu * 8);
+		hipLaunchKernelGGL(split_read_kernel, dim3(sgrid), dim3(256), 0, st, g, first);
 	}
 
 	if (ctx->n_iv > 0) {

@@ -2119,11 +2119,33 @@ template <typename F> __device__ __forceinline__ int kmer_hash(F base_at)
 	return (int) v;
 }
 
-// K6 count / fill passes of build_hash_table (split_read.c:357-442): every position whose 10-mer is ACGT-only
-template <bool FILL> __global__ __launch_bounds__(256) void kmer_index_kernel(const uint8_t *__restrict__ ref, int64_t len,
-		uint32_t *__restrict__ count, const uint32_t *__restrict__ offset, uint32_t *__restrict__ cursor,
-		int32_t *__restrict__ positions)
+// One chromosome's share of a batched split-read launch: where its records, its reference, its satellites, its 10-mer
+// index and its known SVs lie in the concatenated arrays.
+struct SplitSlot {
+	int64_t sr_off, n_sr; // records (in pos / mapq / flag / l_qseq / data_off)
+	int64_t ref_off, L;
+	int64_t kpos_off;     // in the positions of the 10-mer indexes
+	int32_t kidx;         // which offset table (4^10 + 1 entries each; counts and cursors: 4^10 each)
+	int32_t sat_off, n_sat;
+	int32_t iv0, n_dels, n_dups;
+	int32_t slot;         // chromosome of the batch (its Small block takes the counters)
+	int32_t pad;
+};
+
+// K6 count / fill passes of build_hash_table (split_read.c:357-442): every position whose 10-mer is ACGT-only.
+// One launch for all chromosomes (blockIdx.y); the index depends on the reference sequence only, so it is built once per
+// layout and stays in HBM (4 bytes per base) for every compute that follows.
+template <bool FILL> __global__ __launch_bounds__(256) void kmer_index_kernel(const uint8_t *__restrict__ ref_base,
+		const SplitSlot *__restrict__ slots, uint32_t *__restrict__ count_base, const uint32_t *__restrict__ offset_base,
+		uint32_t *__restrict__ cursor_base, int32_t *__restrict__ positions_base)
 {
+	const SplitSlot sl = slots[blockIdx.y];
+	const uint8_t *ref = ref_base + sl.ref_off;
+	const int64_t len = sl.L;
+	uint32_t *count = count_base + (int64_t) sl.kidx * kKmerBuckets;
+	const uint32_t *offset = offset_base + (int64_t) sl.kidx * (kKmerBuckets + 1);
+	uint32_t *cursor = cursor_base + (int64_t) sl.kidx * kKmerBuckets;
+	int32_t *positions = positions_base + sl.kpos_off;
 	const int64_t stride = (int64_t) gridDim.x * blockDim.x;
 	for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i + kKmerLen <= len; i += stride) {
 		const int h = kmer_hash([&](int k) { return ref[i + k]; });
@@ -2137,11 +2159,13 @@ template <bool FILL> __global__ __launch_bounds__(256) void kmer_index_kernel(co
 }
 
 // init_hash_table: buckets with count == 0 or >= MAX_SR_HIT are dropped; exclusive scan of the kept counts.
-// One workgroup of 1024 threads, 1024 buckets each.
-__global__ __launch_bounds__(1024) void kmer_offsets_kernel(const uint32_t *__restrict__ count, uint32_t *__restrict__ offset)
+// One workgroup of 1024 threads per chromosome (blockIdx.x), 1024 buckets per thread.
+__global__ __launch_bounds__(1024) void kmer_offsets_kernel(const uint32_t *__restrict__ count_base, uint32_t *__restrict__ offset_base)
 {
 	__shared__ uint32_t part[1024];
 	constexpr int kPer = kKmerBuckets / 1024;
+	const uint32_t *count = count_base + (int64_t) blockIdx.x * kKmerBuckets;
+	uint32_t *offset = offset_base + (int64_t) blockIdx.x * (kKmerBuckets + 1);
 	const int t = threadIdx.x;
 	uint32_t sum = 0;
 	for (int k = 0; k < kPer; k++) {
@@ -2256,29 +2280,51 @@ __device__ __forceinline__ int split_scan_bucket(const SplitArgs &a, const uint8
 	return size;
 }
 
-// find_split_reads + read_SplitReads + determine_SvType + count_ReadPairs, one wave per read.  A read is a dozen
-// dependent trips to HBM (record -> sequence -> bucket bounds -> bucket -> reference, per half), so the register budget
-// is set for 8 waves per SIMD: at the 98 registers the compiler would otherwise take, 4 waves fit and the launch is 10 %
-// slower (the few spilled values are off the inner loops).
-__global__ __launch_bounds__(256, 8) void split_read_kernel(SplitArgs a)
-{
-	__shared__ uint8_t s_str[4][kSrMaxHalf], s_rev[4][kSrMaxHalf], s_qual[4][2 * kSrMaxHalf];
-	__shared__ int32_t s_hit_pos[4][kMaxMapping];
-	__shared__ char s_hit_orient[4][kMaxMapping];
-	const int wv = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
-	uint8_t *str = s_str[wv], *rev = s_rev[wv], *ql = s_qual[wv];
-	int32_t *hit_pos = s_hit_pos[wv];
-	char *hit_orient = s_hit_orient[wv];
-	const int64_t n_waves = (int64_t) gridDim.x * 4;
-	unsigned long long n_elem = 0, n_map = 0, n_del = 0, n_dup = 0;
+struct SplitBatchArgs {
+	SplitArgs base;          // the concatenated arrays; the per-chromosome members are filled in per SplitSlot
+	const SplitSlot *slots;  // chromosomes with split-read records, in record order
+	int32_t n_slots;
+	Small *small;
+};
 
-	for (int64_t r = (int64_t) blockIdx.x * 4 + wv; r < a.n_reads; r += n_waves) {
+__device__ __forceinline__ SplitArgs split_view(const SplitBatchArgs &g, const SplitSlot &sl)
+{
+	SplitArgs a = g.base;
+	a.pos += sl.sr_off;
+	a.mapq += sl.sr_off;
+	a.flag += sl.sr_off;
+	a.l_qseq += sl.sr_off;
+	a.data_off += sl.sr_off;
+	a.n_reads = sl.n_sr;
+	a.ref += sl.ref_off;
+	a.L = sl.L;
+	a.sat_start += sl.sat_off;
+	a.sat_end += sl.sat_off;
+	a.n_sat = sl.n_sat;
+	a.offset += (int64_t) sl.kidx * (kKmerBuckets + 1);
+	a.positions += sl.kpos_off;
+	a.iv0 = sl.iv0;
+	a.n_dels = sl.n_dels;
+	a.n_dups = sl.n_dups;
+	a.counters = g.small[sl.slot].counters;
+	return a;
+}
+
+// find_split_reads + read_SplitReads + determine_SvType + count_ReadPairs for one read, by one wave.  A read is a dozen
+// dependent trips to HBM (record -> sequence -> bucket bounds -> bucket -> reference, per half), so the register budget
+// of the kernel below is set for 8 waves per SIMD: at the 98 registers the compiler would otherwise take, 4 waves fit and
+// the launch is 10 % slower (the few spilled values are off the inner loops).
+__device__ __forceinline__ void split_read_one(const SplitArgs &a, int64_t r, uint8_t *str, uint8_t *rev, uint8_t *ql, int32_t *hit_pos,
+		char *hit_orient, int lane, unsigned long long &n_elem, unsigned long long &n_map, unsigned long long &n_del,
+		unsigned long long &n_dup)
+{
+	{
 		const int l = a.l_qseq[r], p = a.pos[r], q = a.mapq[r], fl = a.flag[r];
 		// gate of count_reads_bam (bam_data.c:205-207) and find_split_reads' pos == 0 (split_read.c:216)
 		if (!(q > a.mq_threshold) || !(l > a.min_read_length) || (fl & (0x100 | 0x800 | 0x400 | 0x200)) != 0)
-			continue;
+			return;
 		if (p == 0 || l > 2 * kSrMaxHalf - 2 || is_satellite_dev(a, p, (int64_t) p + 20))
-			continue;
+			return;
 		const uint8_t *sq = a.data + a.data_off[r];
 		const uint8_t *qq = sq + (l + 1) / 2;
 		const int half = l / 2;
@@ -2390,16 +2436,45 @@ __global__ __launch_bounds__(256, 8) void split_read_kernel(SplitArgs a)
 			}
 		}
 	}
-	if (lane == 0) {
-		if (n_elem)
-			atomicAdd(&a.counters[CNT_SR_ELEMENTS], n_elem);
-		if (n_map)
-			atomicAdd(&a.counters[CNT_SR_MAPPINGS], n_map);
-		if (n_del)
-			atomicAdd(&a.counters[CNT_SR_DEL_ROWS], n_del);
-		if (n_dup)
-			atomicAdd(&a.counters[CNT_SR_DUP_ROWS], n_dup);
+}
+
+// All chromosomes' records in ONE launch, one wave per read; the records of a chromosome are consecutive, so a wave
+// moves from SplitSlot to SplitSlot as its read index grows and flushes its counters into the chromosome it leaves.
+__global__ __launch_bounds__(256, 8) void split_read_kernel(SplitBatchArgs g, int64_t first_read)
+{
+	__shared__ uint8_t s_str[4][kSrMaxHalf], s_rev[4][kSrMaxHalf], s_qual[4][2 * kSrMaxHalf];
+	__shared__ int32_t s_hit_pos[4][kMaxMapping];
+	__shared__ char s_hit_orient[4][kMaxMapping];
+	const int wv = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+	const int64_t n_waves = (int64_t) gridDim.x * 4;
+	unsigned long long n_elem = 0, n_map = 0, n_del = 0, n_dup = 0;
+	int cur = 0;
+	SplitSlot sl = g.slots[0];
+	SplitArgs a = split_view(g, sl);
+	auto flush = [&]() {
+		if (lane == 0) {
+			if (n_elem)
+				atomicAdd(&a.counters[CNT_SR_ELEMENTS], n_elem);
+			if (n_map)
+				atomicAdd(&a.counters[CNT_SR_MAPPINGS], n_map);
+			if (n_del)
+				atomicAdd(&a.counters[CNT_SR_DEL_ROWS], n_del);
+			if (n_dup)
+				atomicAdd(&a.counters[CNT_SR_DUP_ROWS], n_dup);
+		}
+		n_elem = n_map = n_del = n_dup = 0;
+	};
+	for (int64_t r = first_read + (int64_t) blockIdx.x * 4 + wv; r < g.base.n_reads; r += n_waves) {
+		if (r >= sl.sr_off + sl.n_sr) { // (wave-uniform)
+			flush();
+			do
+				sl = g.slots[++cur];
+			while (r >= sl.sr_off + sl.n_sr); // never runs off the table: r < n_reads = the last slot's end
+			a = split_view(g, sl);
+		}
+		split_read_one(a, r - sl.sr_off, s_str[wv], s_rev[wv], s_qual[wv], s_hit_pos[wv], s_hit_orient[wv], lane, n_elem, n_map, n_del, n_dup);
 	}
+	flush();
 }
 
 } // namespace conga

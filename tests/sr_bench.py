@@ -3,7 +3,6 @@
 every BAM record handed over, next to the CPU oracle on a bounded sample.  Not the bench line (bench.py is); this
 path is built for parity, this tool says what it costs."""
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -15,34 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from conga_amd import capi, synth  # noqa: E402
 
-CODE = np.full(256, 15, np.uint8)
-for ch, v in ((b"A", 1), (b"C", 2), (b"G", 4), (b"T", 8)):
-    CODE[ch[0]] = v
-
-
-def stage_uniform(ctx, pos, mapq, flag, codes2d, qual2d):
-    """Vectorised version of capi.Context.split_reads for reads of one length."""
-    lib, h = ctx._lib, ctx._h
-    n, l = codes2d.shape
-    half = (l + 1) // 2
-    need = half + l
-    packed = np.empty((n, need), np.uint8)
-    c = codes2d if l % 2 == 0 else np.concatenate([codes2d, np.zeros((n, 1), np.uint8)], axis=1)
-    packed[:, :half] = (c[:, 0::2] << 4) | c[:, 1::2]
-    packed[:, half:] = qual2d
-    stg = capi.SplitStaging()
-    i = 0
-    while i < n:
-        ctx._check(lib.conga_split_reads_staging(h, C.byref(stg)))
-        k = int(min(n - i, stg.capacity_reads, stg.capacity_bytes // need))
-        np.ctypeslib.as_array(stg.data, shape=(stg.capacity_bytes,))[:k * need] = packed[i:i + k].reshape(-1)
-        np.ctypeslib.as_array(stg.data_off, shape=(stg.capacity_reads,))[:k] = np.arange(k, dtype=np.uint64) * need
-        np.ctypeslib.as_array(stg.pos, shape=(stg.capacity_reads,))[:k] = pos[i:i + k]
-        np.ctypeslib.as_array(stg.mapq, shape=(stg.capacity_reads,))[:k] = mapq[i:i + k]
-        np.ctypeslib.as_array(stg.flag, shape=(stg.capacity_reads,))[:k] = flag[i:i + k]
-        np.ctypeslib.as_array(stg.l_qseq, shape=(stg.capacity_reads,))[:k] = l
-        ctx._check(lib.conga_split_reads_commit(h, k, k * need))
-        i += k
+from conga_amd.rp_bench import CODE, stage_uniform  # noqa: E402
 
 
 def main():
