@@ -620,12 +620,19 @@ def config_legs(args, env):
         legs["configs[2]"]["cpu_baseline"], legs["configs[2]"]["cn_concordance"] = cpu_baseline(leg.mine, recs, E, small, True)
     leg.close()
     # ---- configs[4]: 5x with the split-read path (--rp with --dups)
-    try:
-        from conga_amd import rp_bench
-    except ImportError:
-        rp_bench = None
+    from conga_amd import rp_bench
     if rp_bench is not None:
-        legs["configs[4]"] = rp_bench.leg(args, env)
+        legs["configs[4]"], smp = rp_bench.leg(args, env)
+        if args.cpu_seconds > 0:
+            from oracle import oracle as O
+            t0 = time.perf_counter()
+            O.split_read_rows(smp["ref"], smp["sat_s"], smp["sat_e"], smp["pos"], smp["mapq"], smp["flag"], smp["lq"], smp["off"],
+                              smp["codes"], smp["qual"], -1, 60)
+            t_cpu = time.perf_counter() - t0
+            legs["configs[4]"]["cpu_baseline"] = dict(
+                value=round(len(smp["pos"]) / t_cpu, 1), unit="records/s", cores=1, kind="port",
+                sample="first %d records of chromosome %s through oracle/conga_oracle_sr.c (%.1f s, includes one build of the "
+                       "chromosome's 10-mer index)" % (len(smp["pos"]), smp["name"], t_cpu))
     return legs
 
 

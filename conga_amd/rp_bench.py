@@ -120,7 +120,7 @@ def bucket_bytes_per_read(chroms):
 
 
 def leg(args, env):
-    """-> dict for bench.py's `configs["configs[4]"]`."""
+    """-> (dict for bench.py's `configs["configs[4]"]`, a bounded sample of the records for the caller's CPU baseline)."""
     names = [n for n, _ in synth.GRCH37_AUTOSOMES] if args.rp_chroms == "all" else args.rp_chroms.split(",")
     if args.chroms:
         names = [n for n in names if n in set(args.chroms.split(","))] or args.chroms.split(",")[-1:]
@@ -188,16 +188,10 @@ def leg(args, env):
                              frac=round(alg / max(sr_ms, 1e-6) / 1e6 / 8000.0, 4), traffic=None,
                              note="latency-bound: ~14 dependent trips to HBM per read (record -> sequence -> bucket bounds -> "
                                   "bucket -> reference, per half); launch time = step with records - step without"))
-    if args.cpu_seconds > 0:
-        from oracle import oracle as O
-        ch = min(chroms, key=lambda c: c["L"])
-        k = min(20_000, len(ch["pos"]))
-        off = np.arange(k, dtype=np.uint64) * READ_LEN
-        t0 = time.perf_counter()
-        rows, counts = O.split_read_rows(ch["ref"].tobytes(), ch["sat_s"], ch["sat_e"], ch["pos"][:k], ch["mapq"][:k], ch["flag"][:k],
-                                         np.full(k, READ_LEN, np.int32), off, ch["codes"][:k].reshape(-1), ch["qual"][:k].reshape(-1), -1, 60)
-        t_cpu = time.perf_counter() - t0
-        out["cpu_baseline"] = dict(value=round(k / t_cpu, 1), unit="records/s", cores=1, kind="port",
-                                   sample="first %d records of chromosome %s through oracle/conga_oracle_sr.c (%.1f s, includes one "
-                                          "build of the chromosome's 10-mer index)" % (k, ch["name"], t_cpu))
-    return out
+    # a bounded sample for the caller's CPU baseline (bench.py runs the oracle; nothing in this package does)
+    ch = min(chroms, key=lambda c: c["L"])
+    k = min(20_000, len(ch["pos"]))
+    sample = dict(name=ch["name"], ref=ch["ref"].tobytes(), sat_s=ch["sat_s"], sat_e=ch["sat_e"], pos=ch["pos"][:k], mapq=ch["mapq"][:k],
+                  flag=ch["flag"][:k], lq=np.full(k, READ_LEN, np.int32), off=np.arange(k, dtype=np.uint64) * READ_LEN,
+                  codes=ch["codes"][:k].reshape(-1).copy(), qual=ch["qual"][:k].reshape(-1).copy())
+    return out, sample

@@ -197,3 +197,31 @@ def test_split_read_oracle_on_planted_junctions(oracle):
     # with the threshold at 11 the carry-over read loses its second element only
     _, counts11 = oracle.split_read_rows(bytes(ref), [], [], pos, mapq, flag, lq, off, seq, qual, mq_threshold=11)
     assert counts11[0] == 7
+
+
+@pytest.mark.parametrize("mq,min_len", [(-1, 60), (20, 60), (35, 75)])
+def test_split_read_oracle_matches_the_python_restatement(oracle, mq, min_len):
+    """oracle/conga_oracle_sr.c against tests/sr_restatement.py (written independently from the reference's text) on a
+    case with junction reads, a repeat, an N block, a dropped 61 000-hit bucket, satellites, every flag, short and odd
+    read lengths and per-base qualities: same rows (as a multiset), same counters, same support columns."""
+    import sr_restatement as R
+    from test_gpu_split_reads import make_case
+    c = make_case(seed=11, L=330_000, n_normal=700)
+    rows, counts = oracle.split_read_rows(c["ref"], c["sat_s"], c["sat_e"], c["pos"], c["mapq"], c["flag"], c["lq"], c["off"],
+                                          c["codes"], c["qual"], mq, min_len)
+    reads = []
+    for i in range(len(c["pos"])):
+        o, l = int(c["off"][i]), int(c["lq"][i])
+        reads.append((int(c["pos"][i]), int(c["mapq"][i]), int(c["flag"][i]), c["codes"][o:o + l], c["qual"][o:o + l]))
+    sats = list(zip(c["sat_s"].tolist(), c["sat_e"].tolist()))
+    want_rows, want_counts = R.split_read_rows(c["ref"].decode(), sats, reads, mq, min_len)
+    assert tuple(int(x) for x in counts) == want_counts
+    got = sorted((r["sv_type"].decode(), int(r["left_end"]), int(r["right_start"])) for r in rows)
+    assert got == sorted(want_rows)
+    od = oracle.make_svs([d[0] for d in c["dels"]], [d[1] for d in c["dels"]])
+    ou = oracle.make_svs([d[0] for d in c["dups"]], [d[1] for d in c["dups"]])
+    oracle.count_read_pairs(rows, od, ou)
+    border, rp = R.count_read_pairs(want_rows, c["dels"], c["dups"])
+    assert od["border_rp"].tolist() == border and ou["rp"].tolist() == rp
+    if mq == -1:
+        assert want_counts[0] > 500 and len(want_rows) > 10 and sum(border) > 5 and sum(rp) > 5
