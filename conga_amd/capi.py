@@ -37,7 +37,7 @@ KERNEL_NAMES = ("ingest", "depth_tile", "expected_table", "paint", "interval_red
 EXPORTS = (
     "conga_create", "conga_destroy", "conga_strerror", "conga_last_error", "conga_abi_version",
     "conga_device_count", "conga_reset", "conga_chrom_count", "conga_chrom_select", "conga_chrom_begin", "conga_reads_staging", "conga_reads_commit",
-    "conga_reads_bgzf", "conga_host_alloc", "conga_host_free", "conga_sample_reads", "conga_sample_begin",
+    "conga_reads_bgzf", "conga_inflate_blocks", "conga_host_alloc", "conga_host_free", "conga_sample_reads", "conga_sample_begin",
     "conga_sample_chrom", "conga_sample_fetch",
     "conga_mappability", "conga_intervals", "conga_reference", "conga_satellites", "conga_split_reads_staging",
     "conga_split_reads_commit", "conga_split_support", "conga_chrom_compute",
@@ -135,6 +135,8 @@ def load():
     L.conga_reads_commit.argtypes = [vp, sz]
     L.conga_reads_bgzf.restype = C.c_int
     L.conga_reads_bgzf.argtypes = [vp, vp, sz, C.POINTER(BgzfBlock), sz, C.POINTER(BamSegment), sz, C.POINTER(C.c_uint64)]
+    L.conga_inflate_blocks.restype = C.c_int
+    L.conga_inflate_blocks.argtypes = [vp, vp, sz, C.POINTER(BgzfBlock), sz, vp, sz, vp, C.POINTER(C.c_double)]
     L.conga_host_alloc.restype = vp
     L.conga_host_alloc.argtypes = [vp, sz]
     L.conga_host_free.restype = None
@@ -341,6 +343,18 @@ class Context:
         per = (C.c_uint64 * max(self.chrom_count(), 1))()
         self._check(self._lib.conga_reads_bgzf(self._h, data.ctypes.data, len(data), bl, len(blocks), sg, len(segments), per))
         return list(per)[:self.chrom_count()]
+
+    def inflate_blocks(self, data, blocks, want_out=True):
+        """conga_inflate_blocks -> (payloads uint8[], status uint8[n_blocks], kernel_ms)"""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        bl = (BgzfBlock * len(blocks))(*[BgzfBlock(*b, 0) for b in blocks])
+        total = sum(b[2] for b in blocks)
+        out = np.zeros(total if want_out else 0, np.uint8)
+        status = np.zeros(len(blocks), np.uint8)
+        ms = C.c_double(0)
+        self._check(self._lib.conga_inflate_blocks(self._h, data.ctypes.data, len(data), bl, len(blocks),
+                                                   out.ctypes.data if want_out else None, len(out), status.ctypes.data, C.byref(ms)))
+        return out, status, ms.value
 
     def mappability(self, start, end, val):
         s = np.ascontiguousarray(start, dtype=np.int32)

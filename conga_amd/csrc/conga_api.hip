@@ -129,7 +129,7 @@ struct conga_ctx {
 			d_sr_mapq, d_sr_flag, d_sr_lq, d_sr_off, d_sr_data, d_kmer_count, d_kmer_offset, d_kmer_cursor, d_kmer_pos, d_sr_slots,
 			// conga_reads_bgzf: compressed blocks, their table, the inflated stream, the decoders' scratch, the walk's per-segment results
 			d_bz_in, d_bz_blocks, d_bz_off, d_bz_out, d_bz_status, d_bz_scratch, d_bz_crc, d_bz_seg, d_bz_cnt, d_bz_first, d_bz_stop,
-			d_bz_bad, d_bz_at, d_bz_flag;
+			d_bz_bad, d_bz_at, d_bz_flag, d_bz_x2n;
 
 	// pinned read-back
 	Small *h_small = nullptr;
@@ -841,6 +841,63 @@ int launch_dense_depth(conga_ctx *ctx, Small *small, bool timed)
 	return CONGA_OK;
 }
 
+// the byte-wise CRC-32 table (polynomial 0xEDB88320), once per context
+int ensure_crc_table(conga_ctx *ctx)
+{
+	if (ctx->d_bz_crc.p)
+		return CONGA_OK;
+	uint32_t table[256];
+	for (uint32_t i = 0; i < 256; i++) {
+		uint32_t c = i;
+		for (int k = 0; k < 8; k++)
+			c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+		table[i] = c;
+	}
+	TRY(upload(ctx, ctx->d_bz_crc, table, sizeof table));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // (`table` is on the stack)
+	return CONGA_OK;
+}
+
+// BGZF inflate of the blocks described in d_bz_blocks / d_bz_off: d_bz_in -> d_bz_out, one status byte per block.
+// Default: one block per WAVE (inflate_wave.hip.h).  CONGA_BGZF_KERNEL=lane: the host decoder's source one block per
+// lane (round 1's kernel, kept for comparison); `lanes` sizes its per-lane scratch.
+int launch_inflate(conga_ctx *ctx, size_t n_blocks, uint32_t lanes)
+{
+	hipStream_t st = ctx->stream;
+	const char *which = getenv("CONGA_BGZF_KERNEL");
+	if (which && strcmp(which, "lane") == 0) {
+		TRY(ensure(ctx, ctx->d_bz_scratch, (size_t) lanes * sizeof(InflateScratch)));
+		hipLaunchKernelGGL(bgzf_inflate_kernel, dim3(lanes / 64), dim3(64), 0, st, (uint32_t) n_blocks, ptr<uint8_t>(ctx->d_bz_in),
+				ptr<conga_bgzf_block>(ctx->d_bz_blocks), ptr<uint64_t>(ctx->d_bz_off), ptr<uint8_t>(ctx->d_bz_out),
+				ptr<InflateScratch>(ctx->d_bz_scratch), ptr<uint32_t>(ctx->d_bz_crc), ptr<uint8_t>(ctx->d_bz_status));
+		return CONGA_OK;
+	}
+	if (!ctx->d_bz_x2n.p) {
+		// x^(2^k) mod P for the CRC-32 polynomial, reflected (bit 31 = x^0): the wave combines its lanes' partial CRCs with them
+		uint32_t x2n[32];
+		auto mul = [](uint32_t a, uint32_t b) {
+			uint32_t p = 0;
+			for (int k = 0; k < 32; k++) {
+				if ((a >> (31 - k)) & 1u)
+					p ^= b;
+				b = (b & 1u) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
+			}
+			return p;
+		};
+		x2n[0] = 0x40000000u; // x
+		for (int k = 1; k < 32; k++)
+			x2n[k] = mul(x2n[k - 1], x2n[k - 1]);
+		TRY(upload(ctx, ctx->d_bz_x2n, x2n, sizeof x2n));
+		HIP_TRY(ctx, hipStreamSynchronize(st)); // (`x2n` is on the stack)
+	}
+	// one resident round of workgroups (8 per CU), blocks round robin over their waves
+	const size_t groups = std::min<size_t>((n_blocks + iw::kWavesPerGroup - 1) / iw::kWavesPerGroup, (size_t) ctx->n_cu * 8);
+	hipLaunchKernelGGL(iw::bgzf_inflate_wave_kernel, dim3((unsigned) groups), dim3(64 * iw::kWavesPerGroup), 0, st, (uint32_t) n_blocks,
+			ptr<uint8_t>(ctx->d_bz_in), ptr<conga_bgzf_block>(ctx->d_bz_blocks), ptr<uint64_t>(ctx->d_bz_off), ptr<uint8_t>(ctx->d_bz_out),
+			ptr<uint32_t>(ctx->d_bz_crc), ptr<uint32_t>(ctx->d_bz_x2n), ptr<uint8_t>(ctx->d_bz_status));
+	return CONGA_OK;
+}
+
 } // namespace
 
 // =============================================================================================
@@ -1013,7 +1070,7 @@ void conga_destroy(conga_ctx *ctx)
 			&ctx->d_small, &ctx->d_map, &ctx->d_winner, &ctx->d_map_start, &ctx->d_map_end,
 			&ctx->d_map_val, &ctx->d_iv_start, &ctx->d_iv_end, &ctx->d_iv_type, &ctx->d_iv_slot, &ctx->d_iv_has_map,
 			&ctx->d_order, &ctx->d_bz_in, &ctx->d_bz_blocks, &ctx->d_bz_off, &ctx->d_bz_out, &ctx->d_bz_status, &ctx->d_bz_scratch,
-			&ctx->d_bz_crc, &ctx->d_bz_seg, &ctx->d_bz_cnt, &ctx->d_bz_first, &ctx->d_bz_stop, &ctx->d_bz_bad, &ctx->d_bz_at, &ctx->d_bz_flag, &ctx->d_expected, &ctx->d_item_off, &ctx->d_item_len, &ctx->d_item_iv,
+			&ctx->d_bz_crc, &ctx->d_bz_x2n, &ctx->d_bz_seg, &ctx->d_bz_cnt, &ctx->d_bz_first, &ctx->d_bz_stop, &ctx->d_bz_bad, &ctx->d_bz_at, &ctx->d_bz_flag, &ctx->d_expected, &ctx->d_item_off, &ctx->d_item_len, &ctx->d_item_iv,
 			&ctx->d_item_has_map, &ctx->d_item_first, &ctx->d_map_part, &ctx->d_support, &ctx->d_results,
 			&ctx->d_bases, &ctx->d_row_tile, &ctx->d_depth_blocks, &ctx->d_support_base, &ctx->d_ref, &ctx->d_sat_start, &ctx->d_sat_end,
 			&ctx->d_sr_pos, &ctx->d_sr_mapq, &ctx->d_sr_flag, &ctx->d_sr_lq, &ctx->d_sr_off, &ctx->d_sr_data,
@@ -1343,12 +1400,11 @@ int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const
 	uint32_t lanes = (uint32_t) std::min<size_t>((n_blocks + 63) & ~(size_t) 63, 131072);
 	if (const char *e = getenv("CONGA_BGZF_LANES")) // (tests: few lanes, several blocks each)
 		lanes = std::min(lanes, (uint32_t) std::max(64, atoi(e) & ~63));
-	TRY(ensure(ctx, ctx->d_bz_in, n_bytes + 64)); // (the decoder reads a few aligned words ahead of its position)
+	TRY(ensure(ctx, ctx->d_bz_in, n_bytes + 512)); // (the decoders read ahead of their position: up to 64 dwords)
 	TRY(ensure(ctx, ctx->d_bz_blocks, n_blocks * sizeof(conga_bgzf_block)));
 	TRY(ensure(ctx, ctx->d_bz_off, n_blocks * 8));
 	TRY(ensure(ctx, ctx->d_bz_out, (size_t) total + 16));
 	TRY(ensure(ctx, ctx->d_bz_status, n_blocks));
-	TRY(ensure(ctx, ctx->d_bz_scratch, (size_t) lanes * sizeof(InflateScratch)));
 	TRY(ensure(ctx, ctx->d_bz_seg, n_segments * sizeof(conga_bam_segment)));
 	TRY(ensure(ctx, ctx->d_bz_cnt, n_segments * 4));
 	TRY(ensure(ctx, ctx->d_bz_first, n_segments * 8));
@@ -1356,16 +1412,7 @@ int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const
 	TRY(ensure(ctx, ctx->d_bz_bad, n_segments));
 	TRY(ensure(ctx, ctx->d_bz_at, n_segments * 8));
 	TRY(ensure(ctx, ctx->d_bz_flag, 4));
-	if (!ctx->d_bz_crc.p) {
-		uint32_t table[256];
-		for (uint32_t i = 0; i < 256; i++) {
-			uint32_t c = i;
-			for (int k = 0; k < 8; k++)
-				c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-			table[i] = c;
-		}
-		TRY(upload(ctx, ctx->d_bz_crc, table, sizeof table));
-	}
+	TRY(ensure_crc_table(ctx));
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bz_in.p, bytes, n_bytes, hipMemcpyHostToDevice, st));
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bz_blocks.p, blocks, n_blocks * sizeof(conga_bgzf_block), hipMemcpyHostToDevice, st));
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bz_off.p, out_off.data(), n_blocks * 8, hipMemcpyHostToDevice, st));
@@ -1376,9 +1423,7 @@ int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const
 		ms_alloc_upload = ms_since(t_begin);
 	}
 	const auto t_inflate = std::chrono::steady_clock::now();
-	hipLaunchKernelGGL(bgzf_inflate_kernel, dim3(lanes / 64), dim3(64), 0, st, (uint32_t) n_blocks, ptr<uint8_t>(ctx->d_bz_in),
-			ptr<conga_bgzf_block>(ctx->d_bz_blocks), ptr<uint64_t>(ctx->d_bz_off), ptr<uint8_t>(ctx->d_bz_out),
-			ptr<InflateScratch>(ctx->d_bz_scratch), ptr<uint32_t>(ctx->d_bz_crc), ptr<uint8_t>(ctx->d_bz_status));
+	TRY(launch_inflate(ctx, n_blocks, lanes));
 	BamWalkArgs w;
 	w.stream = ptr<uint8_t>(ctx->d_bz_out);
 	w.stream_len = total;
@@ -1472,6 +1517,51 @@ int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const
 	if (reads_per_chrom)
 		for (int c = 0; c < n_chrom; c++)
 			reads_per_chrom[c] = (uint64_t) ctx->slots[(size_t) c].n_reads;
+	return CONGA_OK;
+}
+
+int conga_inflate_blocks(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const conga_bgzf_block *blocks, size_t n_blocks,
+		uint8_t *out, size_t out_bytes, uint8_t *status, double *kernel_ms)
+{
+	if (!ctx || !bytes || !blocks || !status || n_blocks == 0 || n_blocks > (size_t) 1 << 28)
+		return CONGA_ERR_INVALID;
+	std::vector<uint64_t> out_off(n_blocks);
+	uint64_t total = 0;
+	for (size_t b = 0; b < n_blocks; b++) {
+		const conga_bgzf_block &bl = blocks[b];
+		if (bl.data_off > n_bytes || (uint64_t) bl.data_len > n_bytes - bl.data_off || bl.inflated_len == 0 || bl.inflated_len > 65536u)
+			return fail(ctx, CONGA_ERR_INVALID, "conga_inflate_blocks: block outside the byte range, empty or larger than 64 KiB");
+		out_off[b] = total;
+		total += bl.inflated_len;
+	}
+	if (out && out_bytes < total)
+		return fail(ctx, CONGA_ERR_INVALID, "conga_inflate_blocks: output buffer too small");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	hipStream_t st = ctx->stream;
+	uint32_t lanes = (uint32_t) std::min<size_t>((n_blocks + 63) & ~(size_t) 63, 131072);
+	TRY(ensure(ctx, ctx->d_bz_in, n_bytes + 512));
+	TRY(ensure(ctx, ctx->d_bz_blocks, n_blocks * sizeof(conga_bgzf_block)));
+	TRY(ensure(ctx, ctx->d_bz_off, n_blocks * 8));
+	TRY(ensure(ctx, ctx->d_bz_out, (size_t) total + 16));
+	TRY(ensure(ctx, ctx->d_bz_status, n_blocks));
+	TRY(ensure_crc_table(ctx));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bz_in.p, bytes, n_bytes, hipMemcpyHostToDevice, st));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bz_blocks.p, blocks, n_blocks * sizeof(conga_bgzf_block), hipMemcpyHostToDevice, st));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bz_off.p, out_off.data(), n_blocks * 8, hipMemcpyHostToDevice, st));
+	HIP_TRY(ctx, hipMemsetAsync(ctx->d_bz_status.p, 0xFF, n_blocks, st));
+	HIP_TRY(ctx, hipEventRecord(ctx->ev_k0[0], st));
+	TRY(launch_inflate(ctx, n_blocks, lanes));
+	HIP_TRY(ctx, hipEventRecord(ctx->ev_k1[0], st));
+	HIP_TRY(ctx, hipMemcpyAsync(status, ctx->d_bz_status.p, n_blocks, hipMemcpyDeviceToHost, st));
+	if (out)
+		HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_bz_out.p, (size_t) total, hipMemcpyDeviceToHost, st));
+	HIP_TRY(ctx, hipStreamSynchronize(st));
+	HIP_TRY(ctx, hipGetLastError());
+	if (kernel_ms) {
+		float ms = 0.0f;
+		HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_k0[0], ctx->ev_k1[0]));
+		*kernel_ms = ms;
+	}
 	return CONGA_OK;
 }
 

@@ -1,0 +1,625 @@
+// inflate_wave.hip.h -- BGZF inflate for gfx950: one BGZF block per WAVE, sixty-four symbols' worth of stream per trip.
+//
+// The producer side of count_reads_bam (bam_data.c:192-221) is htslib's BGZF reader in the reference (bam_data.c:253-259,
+// 293,201); with conga_reads_bgzf the compressed blocks are inflated here.  Written against RFC 1951 for a wave64
+// machine, not derived from any CPU inflater:
+//
+// * A Huffman stream is serial only in WHERE the next symbol starts.  WHAT a symbol is, given its first bit, needs
+//   nothing but the tables.  So every trip lane i decodes the whole symbol that would start at bit `ibit + i` of the
+//   stream -- literal / end of block, or a length with its extra bits, its distance code and that one's extra bits: at
+//   most 48 bits, every lane has a 64-bit view -- with its own look-ups in the wave's tables in LDS.  The sixty-four
+//   results sit in registers, and the true chain of symbol starts (0, 0 + bits[0], ...) is then followed with
+//   v_readlane: no memory in the serial part at all.  A trip retires every literal up to the first match (their lanes
+//   store their bytes side by side: ballot mask + mbcnt gives each its place) and that match, copied by all lanes.
+//   One trip to LDS per ~9 symbols instead of one per symbol.
+// * Tables: 16-bit entries, two levels (9-bit root for literals / lengths, 7-bit for distances), built by the wave for
+//   every deflate block: code lengths -> per-length ballots give every symbol its canonical code without a serial
+//   pass; the width of each second-level table follows from the canonical ranges, so there is no atomic anywhere.
+// * The output goes to HBM (L2) as it is produced.  A match reads what the wave wrote before: stores are waited for
+//   (s_waitcnt vmcnt(0)) only when the match reaches into bytes stored since the last wait, and the read-back loads
+//   bypass the L1 (it is write-through and may hold a line from before the store).
+// * The block's CRC32 is checked by the wave as well: sixty-four contiguous pieces, one per lane, byte-wise with the table
+//   in LDS, combined by multiplying with x^(8 * bytes behind the piece) mod P (the CRC is linear over GF(2)).
+//
+// 4.4 KB of LDS per wave (tables + builder scratch) and a 1 KB CRC table per workgroup of four waves: eight workgroups
+// per CU, 32 waves.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/conga_hip.h"
+
+namespace conga {
+namespace iw {
+
+constexpr int kLitRoot = 9, kDistRoot = 7, kPreRoot = 7;
+// zlib's enough.c proves 852 entries sufficient for 286 symbols behind a 9-bit root and 592 for 30 behind a 6-bit one;
+// a wider root needs no more second-level space than a narrower one.  The builder refuses what does not fit.
+constexpr int kLitCap = 864, kDistCap = 128 + 528;
+constexpr int kMaxLens = 320;
+
+// entry: [3:0] bits consumed at this level (0: no codeword here); [5:4] kind; [15:6] value
+enum : uint32_t { kLiteral = 0, kSymbol = 1, kEndOfBlock = 2, kSubTable = 3 };
+
+struct WaveLds {
+	uint16_t lit[kLitCap];
+	uint16_t dist[kDistCap];
+	uint16_t sorted[288 + 32]; // builder: symbols in canonical order (by length, then value)
+	uint8_t lens[kMaxLens];    // code lengths of the block being set up (literal/length alphabet, then distances)
+	uint8_t pre[1 << kPreRoot]; // code-length code: [2:0] bits, [7:3] symbol -- 5 + 3 bits are enough for 19 symbols of <= 7 bits
+};
+
+__device__ __forceinline__ uint32_t uni(uint32_t v)
+{
+	return (uint32_t) __builtin_amdgcn_readfirstlane((int) v);
+}
+
+// LDS traffic between the lanes of ONE wave: the hardware runs a wave's LDS instructions in order; this keeps the
+// compiler from moving them across.
+__device__ __forceinline__ void wave_sync()
+{
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ uint32_t lane_id()
+{
+	return threadIdx.x & 63u;
+}
+
+__device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t shift)
+{
+	return __builtin_amdgcn_alignbit(hi, lo, shift); // ({hi, lo} >> shift[4:0])[31:0]
+}
+
+// bytes this wave stored are read back from L2: loads that do not stop at the (write-through) L1
+__device__ __forceinline__ uint32_t load_written_u8(const uint8_t *p)
+{
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t load_written_u32(const uint32_t *p)
+{
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- the stream, read uniformly (block headers, code lengths) ---------------------------------------------------------
+// 64 consecutive dwords of the input live in one register across the wave; a field is two v_readlane and a funnel shift.
+struct Window {
+	const uint32_t *in32; // 4-byte aligned base of the block's data
+	uint32_t d0;          // first dword held
+	uint32_t w;           // lane i holds in32[d0 + i]
+	__device__ __forceinline__ void load(uint32_t dword)
+	{
+		d0 = dword;
+		w = in32[d0 + lane_id()];
+	}
+	// the next n <= 25 bits at bit offset `ibit` (uniform)
+	__device__ __forceinline__ uint32_t peek(uint32_t ibit, uint32_t n)
+	{
+		uint32_t d = (ibit >> 5) - d0;
+		if (d >= 63u) { // (also when the position moved backwards: never happens)
+			load(ibit >> 5);
+			d = 0;
+		}
+		const uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) w, (int) d);
+		const uint32_t hi = (uint32_t) __builtin_amdgcn_readlane((int) w, (int) d + 1);
+		return alignbit(hi, lo, ibit & 31u) & ((1u << n) - 1u);
+	}
+};
+
+// ---- tables --------------------------------------------------------------------------------------------------------
+// Canonical Huffman code of lens[0..n) (RFC 1951 3.2.2) as a two-level table indexed by the next bits of the stream,
+// least significant bit first.  kind_of(sym) -> entry without the bit count.  false: over-subscribed, incomplete beyond
+// what zlib lets pass (a single one-bit code), or more second-level space than `cap` holds.
+template <int ROOT, typename EntryOf>
+__device__ __forceinline__ bool build_table(const uint8_t *lens, int n, uint16_t *table, int cap, uint16_t *sorted, bool allow_incomplete,
+		EntryOf entry_of)
+{
+	const uint32_t lane = lane_id();
+	// how many symbols of each length: one ballot per length and 64 symbols
+	uint32_t count[16], first[16], offs[16];
+#pragma unroll
+	for (int L = 0; L < 16; L++)
+		count[L] = 0;
+	for (int base = 0; base < n; base += 64) {
+		const int i = base + (int) lane;
+		const uint32_t len = i < n ? lens[i] : 0u;
+#pragma unroll
+		for (int L = 1; L < 16; L++)
+			count[L] += (uint32_t) __popcll(__ballot(len == (uint32_t) L));
+	}
+	int left = 1, max_len = 0;
+	uint32_t code = 0, at = 0;
+	count[0] = 0;
+#pragma unroll
+	for (int L = 1; L < 16; L++) {
+		left = (left << 1) - (int) count[L];
+		if (left < 0)
+			return false;
+		if (count[L])
+			max_len = L;
+		code = (code + count[L - 1]) << 1;
+		first[L] = code; // first canonical code of this length
+		offs[L] = at;    // its place in `sorted`
+		at += count[L];
+	}
+	if (left > 0 && max_len != 0 && (!allow_incomplete || max_len != 1))
+		return false;
+	// canonical order: a symbol's rank among those of its length is the number of equal-length symbols in front of it
+	uint32_t next[16];
+#pragma unroll
+	for (int L = 1; L < 16; L++)
+		next[L] = offs[L];
+	for (int base = 0; base < n; base += 64) {
+		const int i = base + (int) lane;
+		const uint32_t len = i < n ? lens[i] : 0u;
+#pragma unroll
+		for (int L = 1; L < 16; L++) {
+			const unsigned long long m = __ballot(len == (uint32_t) L);
+			if (len == (uint32_t) L)
+				sorted[next[L] + __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u))] = (uint16_t) i;
+			next[L] += (uint32_t) __popcll(m);
+		}
+	}
+	constexpr int kRootSize = 1 << ROOT;
+	// second-level tables: root slot p (stream order = bit-reversed prefix P) needs one iff a code longer than ROOT starts
+	// with P; the codes of length L are the range [first[L], first[L] + count[L]), so its prefixes are a range too
+	uint32_t my_sb[(kRootSize + 63) / 64], my_start[(kRootSize + 63) / 64];
+	uint32_t mine = 0;
+#pragma unroll
+	for (int k = 0; k < (kRootSize + 63) / 64; k++) {
+		const uint32_t p = lane * (uint32_t) ((kRootSize + 63) / 64) + (uint32_t) k; // consecutive slots per lane: the scan below is in slot order
+		const uint32_t P = __brev(p) >> (32 - ROOT);
+		uint32_t sb = 0;
+#pragma unroll
+		for (int L = ROOT + 1; L < 16; L++)
+			if (count[L] && P >= (first[L] >> (L - ROOT)) && P <= ((first[L] + count[L] - 1u) >> (L - ROOT)))
+				sb = (uint32_t) (L - ROOT);
+		if (p >= (uint32_t) kRootSize)
+			sb = 0;
+		my_sb[k] = sb;
+		my_start[k] = mine;
+		mine += sb ? 1u << sb : 0u;
+	}
+	uint32_t incl = mine; // inclusive scan over the lanes
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t v = (uint32_t) __shfl_up((int) incl, o, 64);
+		if (lane >= (uint32_t) o)
+			incl += v;
+	}
+	const uint32_t total = uni((uint32_t) __shfl((int) incl, 63, 64));
+	if ((uint32_t) kRootSize + total > (uint32_t) cap)
+		return false;
+	wave_sync();
+	for (uint32_t j = lane; j < (uint32_t) kRootSize + total; j += 64)
+		table[j] = 0;
+	wave_sync();
+#pragma unroll
+	for (int k = 0; k < (kRootSize + 63) / 64; k++) {
+		const uint32_t p = lane * (uint32_t) ((kRootSize + 63) / 64) + (uint32_t) k;
+		if (my_sb[k])
+			table[p] = (uint16_t) (my_sb[k] | (kSubTable << 4) | (((uint32_t) kRootSize + (incl - mine) + my_start[k]) << 6));
+	}
+	wave_sync();
+	// every symbol fills the slots its codeword (and any bits behind it) leads to
+	const uint32_t n_coded = at;
+	for (uint32_t r = lane; r < n_coded; r += 64) {
+		const uint32_t sym = sorted[r];
+		const uint32_t len = lens[sym];
+		// canonical code of rank r: first[len] + (r - offs[len]); both per-length arrays are indexed without a scratch array
+		uint32_t f = 0, o = 0;
+#pragma unroll
+		for (int L = 1; L < 16; L++)
+			if (len == (uint32_t) L) {
+				f = first[L];
+				o = offs[L];
+			}
+		const uint32_t rev = __brev(f + (r - o)) >> (32u - len);
+		const uint32_t e = entry_of(sym);
+		if (len <= (uint32_t) ROOT) {
+			for (uint32_t j = rev; j < (uint32_t) kRootSize; j += 1u << len)
+				table[j] = (uint16_t) (e | len);
+		} else {
+			const uint32_t ptr = table[rev & (uint32_t) (kRootSize - 1)];
+			const uint32_t start = ptr >> 6, sb = ptr & 15u, l2 = len - (uint32_t) ROOT;
+			for (uint32_t j = rev >> ROOT; j < (1u << sb); j += 1u << l2)
+				table[start + j] = (uint16_t) (e | l2);
+		}
+	}
+	wave_sync();
+	return true;
+}
+
+__device__ __forceinline__ uint32_t lit_entry(uint32_t sym)
+{
+	if (sym < 256u)
+		return (kLiteral << 4) | (sym << 6);
+	if (sym == 256u)
+		return kEndOfBlock << 4;
+	return (kSymbol << 4) | ((sym - 257u) << 6); // 286, 287 (fixed code only) decode to length symbols 29, 30: refused when met
+}
+
+// ---- one deflate block's symbols ---------------------------------------------------------------------------------------
+struct Stream {
+	const uint32_t *in32; // 4-byte aligned
+	uint32_t ibit;        // next bit (from in32)
+	uint32_t end_bit;     // first bit behind the block's data
+	uint8_t *out;
+	uint32_t opos, out_len;
+	uint32_t safe_pos;    // every byte below is known to have reached L2
+};
+
+// 0: end-of-block symbol reached; -1: the stream is invalid
+__device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t)
+{
+	const uint32_t lane = lane_id();
+	for (;;) {
+		if (s.ibit > s.end_bit)
+			return -1;
+		// this lane's 64-bit view of the stream from bit ibit + lane on
+		const uint32_t b = s.ibit + lane;
+		const uint32_t *p = s.in32 + (b >> 5);
+		const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+		const uint32_t sh = b & 31u;
+		const uint32_t lo = alignbit(w1, w0, sh), hi = alignbit(w2, w1, sh);
+		const uint64_t v = ((uint64_t) hi << 32) | lo;
+		// the literal / length code that would start here
+		uint32_t e = t.lit[lo & ((1u << kLitRoot) - 1u)];
+		uint32_t n1 = e & 15u, kind = (e >> 4) & 3u, val = e >> 6;
+		if (__any(kind == kSubTable)) {
+			if (kind == kSubTable) {
+				e = t.lit[val + ((lo >> kLitRoot) & ((1u << n1) - 1u))];
+				n1 = (e & 15u) ? (uint32_t) kLitRoot + (e & 15u) : 0u;
+				kind = (e >> 4) & 3u;
+				val = e >> 6;
+			}
+		}
+		bool bad = n1 == 0u;
+		// ... as a length: its extra bits, the distance code behind them and that one's extra bits
+		const uint32_t ls = kind == kSymbol ? val : 0u; // (<= 30: the shifts below stay in range)
+		const uint32_t eb = (ls < 8u || ls >= 28u) ? 0u : (ls >> 2) - 1u;
+		const uint32_t lbase = ls < 8u ? 3u + ls : ls >= 28u ? 258u : 3u + ((4u + (ls & 3u)) << eb);
+		const uint64_t v1 = v >> n1;
+		const uint32_t length = lbase + ((uint32_t) v1 & ((1u << eb) - 1u));
+		const uint64_t v2 = v1 >> eb;
+		uint32_t ed = t.dist[(uint32_t) v2 & ((1u << kDistRoot) - 1u)];
+		uint32_t n2 = ed & 15u, dval = ed >> 6;
+		if (__any(kind == kSymbol && ((ed >> 4) & 3u) == kSubTable)) {
+			if (((ed >> 4) & 3u) == kSubTable) {
+				ed = t.dist[dval + (((uint32_t) v2 >> kDistRoot) & ((1u << n2) - 1u))];
+				n2 = (ed & 15u) ? (uint32_t) kDistRoot + (ed & 15u) : 0u;
+				dval = ed >> 6;
+			}
+		}
+		const uint32_t deb = dval < 4u ? 0u : (dval >> 1) - 1u;
+		const uint32_t dbase = dval < 4u ? 1u + dval : 1u + ((2u + (dval & 1u)) << deb);
+		const uint64_t v3 = v2 >> n2;
+		const uint32_t dist = dbase + ((uint32_t) v3 & ((1u << deb) - 1u));
+		uint32_t bits = n1;
+		uint32_t payload = val; // literal byte
+		if (kind == kSymbol) {
+			bad = bad || n2 == 0u || ls > 28u || dval > 29u;
+			bits = n1 + eb + n2 + deb;
+			payload = length;
+		}
+		// [7:0] bits of the whole symbol, [9:8] kind (3: no valid symbol starts here), [31:16] literal byte / match length
+		const uint32_t word = bad ? (3u << 8) : (bits | (kind << 8) | (payload << 16));
+
+		// the chain of true symbol starts, from bit 0 of the window; stops in front of the first symbol that is not a literal
+		uint32_t pos = 0, special = 0;
+		unsigned long long lits = 0;
+		bool has_special = false;
+		while (pos < 64u) {
+			const uint32_t w = (uint32_t) __builtin_amdgcn_readlane((int) word, (int) pos);
+			if ((w >> 8) & 3u) {
+				special = w;
+				has_special = true;
+				break;
+			}
+			lits |= 1ull << pos;
+			pos += w & 0xFFu;
+		}
+		const uint32_t n_lits = (uint32_t) __popcll(lits);
+		if (s.opos + n_lits > s.out_len)
+			return -1;
+		if ((lits >> lane) & 1ull)
+			s.out[s.opos + __builtin_amdgcn_mbcnt_hi((uint32_t) (lits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) lits, 0u))] = (uint8_t) (word >> 16);
+		s.opos += n_lits;
+		if (has_special) {
+			const uint32_t sk = (special >> 8) & 3u;
+			if (sk == 3u)
+				return -1;
+			if (sk == kEndOfBlock) {
+				s.ibit += pos + (special & 0xFFu);
+				return s.ibit > s.end_bit ? -1 : 0;
+			}
+			const uint32_t len = special >> 16;
+			const uint32_t d = (uint32_t) __builtin_amdgcn_readlane((int) dist, (int) pos);
+			if (d > s.opos || s.opos + len > s.out_len)
+				return -1;
+			const uint32_t src = s.opos - d;
+			if (src + (d < len ? d : len) > s.safe_pos) { // reaches into bytes stored since the last wait
+				asm volatile("" ::: "memory");
+				__builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the stores are acknowledged by L2
+				asm volatile("" ::: "memory");
+				s.safe_pos = s.opos;
+			}
+			if (d >= len) {
+				for (uint32_t k = lane; k < len; k += 64u)
+					s.out[s.opos + k] = (uint8_t) load_written_u8(s.out + src + k);
+			} else { // the match overlaps itself: it repeats its first d bytes
+				const float inv = 1.0f / (float) d;
+				for (uint32_t k = lane; k < len; k += 64u) {
+					uint32_t q = (uint32_t) ((float) k * inv);
+					int32_t r = (int32_t) (k - q * d);
+					if (r < 0)
+						r += (int32_t) d;
+					else if ((uint32_t) r >= d)
+						r -= (int32_t) d;
+					s.out[s.opos + k] = (uint8_t) load_written_u8(s.out + src + (uint32_t) r);
+				}
+			}
+			s.opos += len;
+			pos += special & 0xFFu;
+		}
+		s.ibit += pos;
+	}
+}
+
+// ---- CRC-32 (reflected, polynomial 0xEDB88320) over GF(2) ---------------------------------------------------------------
+// a(x) * b(x) mod P in the reflected representation (bit 31 = x^0)
+__device__ __forceinline__ uint32_t gf_mul(uint32_t a, uint32_t b)
+{
+	uint32_t p = 0;
+#pragma unroll 8
+	for (int k = 0; k < 32; k++) {
+		p ^= b & (0u - ((a >> (31 - k)) & 1u));
+		b = (b >> 1) ^ (0xEDB88320u & (0u - (b & 1u)));
+	}
+	return p;
+}
+
+// x^(8 n) mod P; x2n[k] = x^(2^k) mod P
+__device__ __forceinline__ uint32_t gf_x8n(uint32_t n_bytes, const uint32_t *x2n)
+{
+	uint32_t p = 0x80000000u; // 1
+	uint32_t n = n_bytes;
+	for (int k = 3; n; k++, n >>= 1)
+		if (n & 1u)
+			p = gf_mul(x2n[k], p);
+	return p;
+}
+
+// CRC32 of out[0..n) by the whole wave (every lane gets the result)
+__device__ __forceinline__ uint32_t wave_crc32(const uint8_t *out, uint32_t n, const uint32_t *crc_table /* LDS */, const uint32_t *x2n)
+{
+	const uint32_t lane = lane_id();
+	const uint32_t piece = ((n + 63u) / 64u + 3u) & ~3u;
+	const uint32_t lo = min(lane * piece, n), hi = min(lo + piece, n);
+	uint32_t c = lane == 0u ? 0xFFFFFFFFu : 0u; // the register's start value travels with the first piece
+	uint32_t i = lo;
+	for (; i < hi && ((uintptr_t) (out + i) & 3u); i++)
+		c = crc_table[(c ^ load_written_u8(out + i)) & 0xFFu] ^ (c >> 8);
+	for (; i + 4u <= hi; i += 4u) {
+		const uint32_t w = load_written_u32(reinterpret_cast<const uint32_t *>(out + i));
+		c ^= w;
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+			c = crc_table[c & 0xFFu] ^ (c >> 8);
+	}
+	for (; i < hi; i++)
+		c = crc_table[(c ^ load_written_u8(out + i)) & 0xFFu] ^ (c >> 8);
+	// shift every piece's register over the bytes behind it and add up
+	c = gf_mul(c, gf_x8n(n - hi, x2n));
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1)
+		c ^= (uint32_t) __shfl_xor((int) c, o, 64);
+	return c ^ 0xFFFFFFFFu;
+}
+
+enum { kStatusOk = 0, kStatusRefused = 1, kStatusCrc = 2 };
+
+// One whole BGZF block (a raw deflate stream of one or more deflate blocks) by one wave.
+__device__ __forceinline__ int inflate_block(WaveLds &t, const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len)
+{
+	const uint32_t lane = lane_id();
+	Stream s;
+	const uint32_t mis = (uint32_t) ((uintptr_t) in & 3u);
+	s.in32 = reinterpret_cast<const uint32_t *>(in - mis);
+	s.ibit = mis * 8u;
+	s.end_bit = (mis + in_len) * 8u;
+	s.out = out;
+	s.opos = 0;
+	s.out_len = out_len;
+	s.safe_pos = 0;
+	Window win;
+	win.in32 = s.in32;
+	win.load(0);
+	for (;;) {
+		if (s.ibit + 3u > s.end_bit)
+			return kStatusRefused;
+		const uint32_t hdr = win.peek(s.ibit, 3);
+		s.ibit += 3;
+		const uint32_t final_block = hdr & 1u, type = hdr >> 1;
+		if (type == 0u) {
+			// stored: LEN / NLEN at the next byte boundary, then LEN bytes as they are
+			s.ibit = (s.ibit + 7u) & ~7u;
+			if (s.ibit + 32u > s.end_bit)
+				return kStatusRefused;
+			const uint32_t ln = win.peek(s.ibit, 16), nl = win.peek(s.ibit + 16u, 16);
+			s.ibit += 32u;
+			if ((ln ^ nl) != 0xFFFFu || s.ibit + 8u * ln > s.end_bit || s.opos + ln > s.out_len)
+				return kStatusRefused;
+			const uint8_t *from = reinterpret_cast<const uint8_t *>(s.in32) + (s.ibit >> 3);
+			for (uint32_t k = lane; k < ln; k += 64u)
+				s.out[s.opos + k] = from[k];
+			s.opos += ln;
+			s.ibit += 8u * ln;
+		} else if (type == 1u || type == 2u) {
+			int n_lit, n_dist;
+			if (type == 1u) {
+				n_lit = 288;
+				n_dist = 32; // (30 and 31 never occur in valid data: refused when met)
+				for (uint32_t i = lane; i < 288u + 32u; i += 64u)
+					t.lens[i] = (uint8_t) (i < 144u ? 8 : i < 256u ? 9 : i < 280u ? 7 : i < 288u ? 8 : 5);
+				wave_sync();
+			} else {
+				if (s.ibit + 14u > s.end_bit)
+					return kStatusRefused;
+				const uint32_t h = win.peek(s.ibit, 14);
+				s.ibit += 14u;
+				n_lit = (int) (h & 31u) + 257;
+				n_dist = (int) ((h >> 5) & 31u) + 1;
+				const int n_pre = (int) (h >> 10) + 4;
+				if (n_lit > 286 || n_dist > 30)
+					return kStatusRefused;
+				// the code-length code: 3 bits each, in the order of RFC 1951 3.2.7
+				const uint8_t kOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+				if (lane < 19u)
+					t.lens[lane] = 0;
+				wave_sync();
+				for (int i = 0; i < n_pre; i++) {
+					const uint32_t x = win.peek(s.ibit, 3);
+					s.ibit += 3u;
+					if (lane == 0u)
+						t.lens[kOrder[i]] = (uint8_t) x;
+				}
+				wave_sync();
+				if (s.ibit > s.end_bit)
+					return kStatusRefused;
+				// its table: 7-bit root, no second level (no code is longer than 7 bits); byte entries
+				{
+					const uint32_t len = lane < 19u ? t.lens[lane] : 0u;
+					uint32_t cnt[8], fst[8];
+					int left = 1;
+					uint32_t code = 0;
+					cnt[0] = 0;
+					bool any = false;
+#pragma unroll
+					for (int L = 1; L < 8; L++) {
+						cnt[L] = (uint32_t) __popcll(__ballot(len == (uint32_t) L));
+						left = (left << 1) - (int) cnt[L];
+						code = (code + cnt[L - 1]) << 1;
+						fst[L] = code;
+						any = any || cnt[L];
+					}
+					if (left != 0 || !any) // the code-length code has to be complete (zlib's rule)
+						return kStatusRefused;
+					for (uint32_t j = lane; j < (1u << kPreRoot); j += 64u)
+						t.pre[j] = 0;
+					wave_sync();
+					uint32_t rank = 0, f = 0;
+#pragma unroll
+					for (int L = 1; L < 8; L++) {
+						const unsigned long long m = __ballot(len == (uint32_t) L);
+						if (len == (uint32_t) L) {
+							rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
+							f = fst[L];
+						}
+					}
+					if (len) {
+						const uint32_t rev = __brev(f + rank) >> (32u - len);
+						for (uint32_t j = rev; j < (1u << kPreRoot); j += 1u << len)
+							t.pre[j] = (uint8_t) (len | (lane << 3));
+					}
+					wave_sync();
+				}
+				// the code lengths of both alphabets, run-length coded with that code (uniform, serial: a few hundred symbols)
+				int k = 0;
+				const int n_all = n_lit + n_dist;
+				uint32_t prev = 0;
+				while (k < n_all) {
+					if (s.ibit > s.end_bit)
+						return kStatusRefused;
+					const uint32_t bits14 = win.peek(s.ibit, 14);
+					const uint32_t pe = uni(t.pre[bits14 & ((1u << kPreRoot) - 1u)]);
+					const uint32_t pl = pe & 7u, sym = pe >> 3;
+					if (pl == 0u)
+						return kStatusRefused;
+					s.ibit += pl;
+					if (sym < 16u) {
+						if (lane == 0u)
+							t.lens[k] = (uint8_t) sym;
+						prev = sym;
+						k++;
+						continue;
+					}
+					const uint32_t x = bits14 >> pl;
+					uint32_t rep, val = 0;
+					if (sym == 16u) {
+						if (k == 0)
+							return kStatusRefused;
+						val = prev;
+						rep = 3u + (x & 3u);
+						s.ibit += 2u;
+					} else if (sym == 17u) {
+						rep = 3u + (x & 7u);
+						s.ibit += 3u;
+					} else {
+						rep = 11u + (x & 127u);
+						s.ibit += 7u;
+					}
+					if (k + (int) rep > n_all)
+						return kStatusRefused;
+					for (uint32_t j = lane; j < rep; j += 64u)
+						t.lens[k + (int) j] = (uint8_t) val;
+					prev = val;
+					k += (int) rep;
+				}
+				wave_sync();
+				if (s.ibit > s.end_bit || t.lens[256] == 0) // (no end-of-block code)
+					return kStatusRefused;
+			}
+			if (!build_table<kLitRoot>(t.lens, n_lit, t.lit, kLitCap, t.sorted, true, [](uint32_t sym) { return lit_entry(sym); }))
+				return kStatusRefused;
+			if (!build_table<kDistRoot>(t.lens + n_lit, n_dist, t.dist, kDistCap, t.sorted, true,
+					[](uint32_t sym) { return (kSymbol << 4) | (sym << 6); }))
+				return kStatusRefused;
+			if (run_symbols(s, t) != 0)
+				return kStatusRefused;
+			win.d0 = 0xFFFFFF00u; // (the position moved on behind the window's back: force a reload)
+		} else
+			return kStatusRefused;
+		if (final_block)
+			break;
+	}
+	return (s.ibit <= s.end_bit && s.opos == s.out_len) ? kStatusOk : kStatusRefused;
+}
+
+constexpr int kWavesPerGroup = 4;
+
+// status[b]: kStatusOk / kStatusRefused / kStatusCrc.  Waves take blocks round robin.
+__global__ __launch_bounds__(64 * kWavesPerGroup, 8) void bgzf_inflate_wave_kernel(uint32_t n_blocks, const uint8_t *__restrict__ bytes,
+		const conga_bgzf_block *__restrict__ blocks, const uint64_t *__restrict__ out_off, uint8_t *out,
+		const uint32_t *__restrict__ crc_table, const uint32_t *__restrict__ x2n, uint8_t *__restrict__ status)
+{
+	__shared__ WaveLds lds[kWavesPerGroup];
+	__shared__ uint32_t s_crc[256];
+	__shared__ uint32_t s_x2n[32];
+	for (int i = threadIdx.x; i < 256; i += blockDim.x)
+		s_crc[i] = crc_table[i];
+	if (threadIdx.x < 32)
+		s_x2n[threadIdx.x] = x2n[threadIdx.x];
+	__syncthreads();
+	const uint32_t wave = threadIdx.x >> 6;
+	const uint32_t n_waves = gridDim.x * kWavesPerGroup;
+	for (uint32_t b = blockIdx.x * kWavesPerGroup + wave; b < n_blocks; b += n_waves) {
+		const conga_bgzf_block bl = blocks[b];
+		uint8_t *dst = out + out_off[b];
+		int st = inflate_block(lds[wave], bytes + bl.data_off, bl.data_len, dst, bl.inflated_len);
+		if (st == kStatusOk) {
+			asm volatile("" ::: "memory");
+			__builtin_amdgcn_s_waitcnt(0x0F70); // every store of the block has reached L2
+			asm volatile("" ::: "memory");
+			if (wave_crc32(dst, bl.inflated_len, s_crc, s_x2n) != bl.crc32)
+				st = kStatusCrc;
+		}
+		if (lane_id() == 0u)
+			status[b] = (uint8_t) st;
+		wave_sync();
+	}
+}
+
+} // namespace iw
+} // namespace conga

@@ -19,6 +19,7 @@
 
 #include "../../include/conga_hip.h"
 #include "../host/inflate_core.h"
+#include "inflate_wave.hip.h"
 
 namespace conga {
 

@@ -265,6 +265,13 @@ typedef struct conga_bam_segment {
 int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const conga_bgzf_block *blocks, size_t n_blocks,
 		const conga_bam_segment *segments, size_t n_segments, uint64_t *reads_per_chrom /* [conga_chrom_count()] or NULL */);
 
+/* Test / tool hook: the first stage of conga_reads_bgzf alone.  Inflates the blocks on the device and copies their payloads
+ * (one behind the other) to `out` (may be NULL); status[b]: 0 inflated and CRC32 right, 1 refused (not a valid deflate stream
+ * of the recorded size), 2 CRC32 mismatch.  kernel_ms (may be NULL): device time of the inflate launch.  Any bytes will do:
+ * no BAM structure is assumed. */
+int conga_inflate_blocks(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const conga_bgzf_block *blocks, size_t n_blocks,
+		uint8_t *out, size_t out_bytes, uint8_t *status, double *kernel_ms);
+
 /* ---- split-read evidence: find_split_reads / read_SplitReads / count_ReadPairs on the device --------------
  * Used when the reference would run its split-read path (`--rp` given AND `--dups` given: svdepth.c:57,
  * bam_data.c:207,306,331, likelihood.c:344).  For the chromosome begun last, hand over

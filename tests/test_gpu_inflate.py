@@ -1,0 +1,128 @@
+"""The BGZF inflate stage of conga_reads_bgzf alone (conga_inflate_blocks), against zlib: the reference's BAM loop reads
+through htslib's BGZF layer (bam_data.c:253-259,293,201), which inflates every block with zlib and checks its CRC32.
+Every deflate block type, zlib level and strategy, tiny and full blocks, long repeats (overlapping matches), long
+Huffman codes (second-level tables), damaged streams and wrong CRCs."""
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def deflate(data, level=6, strategy=0):
+    co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+    return co.compress(data) + co.flush()
+
+
+def pack(streams):
+    """-> (bytes, [(data_off, data_len, inflated_len, crc32)]) with some junk between the streams (odd alignments)."""
+    raw, blocks = bytearray(b"\x01\x02\x03"), []
+    for k, (comp, plain) in enumerate(streams):
+        blocks.append((len(raw), len(comp), len(plain), zlib.crc32(plain) & 0xFFFFFFFF))
+        raw += comp + b"\xEE" * (k % 4)
+    return np.frombuffer(bytes(raw), np.uint8), blocks
+
+
+def payloads(rng):
+    """Plain texts that exercise different corners of deflate."""
+    out = []
+    out.append(bytes(rng.integers(0, 256, 65280, dtype=np.uint8)))                           # incompressible: stored blocks
+    out.append(bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), 65280)))                   # 2-bit entropy
+    out.append(b"A" * 65280)                                                                   # distance 1, length 258 runs
+    out.append(b"abcde" * 13056)                                                               # overlapping matches, distance 5
+    out.append(bytes(rng.integers(0, 256, 7, dtype=np.uint8)))                                # tiny
+    out.append(b"x")
+    # BAM-like records: fixed fields, a running name, packed bases, noisy qualities
+    rec = bytearray()
+    for i in range(290):
+        rec += struct.pack("<iiiBBHHHIiii", 220, 3, 1_000_000 + 37 * i, 12, 60, 4681, 1, 0, 100, -1, -1, 0)
+        rec += b"read%07d\x00" % i + struct.pack("<I", 100 << 4)
+        rec += bytes(rng.integers(0, 256, 50, dtype=np.uint8) & 0x33 | 0x11)
+        rec += bytes(rng.integers(2, 41, 100, dtype=np.uint8))
+    out.append(bytes(rec[:65280]))
+    # a skewed alphabet of 256 symbols: code lengths up to 15 (second-level tables on the literal side)
+    p = 0.5 ** np.arange(1, 257, dtype=np.float64)
+    p[20:] = p[20] / 236
+    out.append(bytes(rng.choice(256, 60000, p=p / p.sum()).astype(np.uint8)))
+    # far matches with many different distances (second-level tables on the distance side)
+    base = bytes(rng.integers(0, 256, 30000, dtype=np.uint8))
+    far = bytearray(base)
+    for _ in range(600):
+        a = int(rng.integers(0, len(far) - 40))
+        far += far[a:a + int(rng.integers(3, 40))]
+    out.append(bytes(far[:65280]))
+    out.append(b"".join(b"%d\t%d\tchr%d\n" % (i * 7919 % 100003, i, i % 23) for i in range(4000))[:65000])   # text
+    return out
+
+
+def test_every_kind_of_stream_matches_zlib(capi):
+    rng = np.random.default_rng(5)
+    streams = []
+    for plain in payloads(rng):
+        for level, strategy in ((1, 0), (6, 0), (9, 0), (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE), (0, 0), (4, zlib.Z_FILTERED)):
+            streams.append((deflate(plain, level, strategy), plain))
+    # several deflate blocks in one stream (a full flush in the middle, and a stored block between two dynamic ones)
+    a, b, c = payloads(np.random.default_rng(6))[1][:20000], bytes(rng.integers(0, 256, 3000, dtype=np.uint8)), b"tail" * 2000
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    multi = co.compress(a) + co.flush(zlib.Z_FULL_FLUSH) + co.compress(b) + co.flush(zlib.Z_SYNC_FLUSH) + co.compress(c) + co.flush()
+    streams.append((multi, a + b + c))
+    data, blocks = pack(streams)
+    with capi.Context(device=0) as ctx:
+        out, status, _ms = ctx.inflate_blocks(data, blocks)
+    assert status.tolist() == [0] * len(blocks), [i for i, s in enumerate(status) if s]
+    at = 0
+    for k, (_comp, plain) in enumerate(streams):
+        assert out[at:at + len(plain)].tobytes() == plain, "stream %d" % k
+        at += len(plain)
+
+
+def test_damaged_streams_are_refused_not_believed(capi):
+    rng = np.random.default_rng(8)
+    plain = payloads(rng)[6]
+    good = deflate(plain)
+    streams, want = [], []
+    for k in range(60):   # a flipped bit somewhere: refused, or decoded to something whose CRC32 is wrong
+        bad = bytearray(good)
+        bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        streams.append((bytes(bad), plain))
+    streams.append((good[:len(good) // 2], plain))             # truncated
+    streams.append((good, plain + b"!"))                       # recorded size too large
+    streams.append((good, plain[:-1]))                         # ... too small
+    streams.append((b"\x07" + good, plain))                    # reserved block type 3
+    data, blocks = pack(streams)
+    blocks.append((blocks[0][0], len(good), len(plain), 0x12345678))   # right stream, wrong CRC... on a damaged copy
+    blocks.append((len(data) - len(b"\xEE" * 3) - len(good) - 1 + 1, len(good), len(plain), zlib.crc32(plain) & 0xFFFFFFFF))
+    with capi.Context(device=0) as ctx:
+        _out, status, _ = ctx.inflate_blocks(data, blocks)
+        # whatever zlib accepts with the right size and CRC must be accepted here too, and nothing else
+        for k, (off, n, isz, crc) in enumerate(blocks):
+            try:
+                got = zlib.decompress(data[off:off + n].tobytes(), -15)
+                ok = len(got) == isz and (zlib.crc32(got) & 0xFFFFFFFF) == crc
+            except zlib.error:
+                ok = False
+            assert (status[k] == 0) == ok, (k, int(status[k]), ok)
+        assert (status != 0).sum() >= 55
+        # the undamaged stream still decodes in the same call, after all that
+        out, st, _ = ctx.inflate_blocks(*pack([(good, plain)]))
+        assert st.tolist() == [0] and out.tobytes() == plain
+
+
+def test_many_blocks_round_robin_over_the_waves(capi):
+    """More blocks than resident waves, of very different sizes: every wave takes several in turn (LDS tables and the
+    input window are set up again per block)."""
+    rng = np.random.default_rng(11)
+    kinds = payloads(rng)
+    streams = []
+    for k in range(9000):
+        plain = kinds[k % len(kinds)]
+        a = int(rng.integers(0, max(len(plain) - 10, 1)))
+        plain = plain[a:a + int(rng.integers(1, 3000))]
+        streams.append((deflate(plain, int(rng.integers(1, 10))), plain))
+    data, blocks = pack(streams)
+    with capi.Context(device=0) as ctx:
+        out, status, ms = ctx.inflate_blocks(data, blocks)
+    assert not status.any()
+    assert out.tobytes() == b"".join(p for _c, p in streams)
