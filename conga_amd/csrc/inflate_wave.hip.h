@@ -49,6 +49,19 @@ struct WaveLds {
 	uint8_t pre[1 << kPreRoot]; // code-length code: [2:0] bits, [7:3] symbol -- 5 + 3 bits are enough for 19 symbols of <= 7 bits
 };
 
+#ifdef IW_PROF
+// tools/inflate_prof.hip: where a wave's time goes (s_memtime ticks per phase, summed per wave; lane 0 adds them up)
+enum { P_VIEW = 0, P_WALK, P_LITS, P_MATCH_WAIT, P_MATCH_COPY, P_TABLES, P_CRC, P_TRIPS, P_MATCHES, P_WAITS, P_SYMS, P_N };
+__device__ unsigned long long g_prof[P_N];
+#define IW_T0() unsigned long long t_prof_ = __builtin_readcyclecounter()
+#define IW_LAP(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); prof[k] += n_ - t_prof_; t_prof_ = n_; } while (0)
+#define IW_ADD(k, v) (prof[k] += (v))
+#else
+#define IW_T0() do { } while (0)
+#define IW_LAP(k) do { } while (0)
+#define IW_ADD(k, v) do { } while (0)
+#endif
+
 __device__ __forceinline__ uint32_t uni(uint32_t v)
 {
 	return (uint32_t) __builtin_amdgcn_readfirstlane((int) v);
@@ -250,104 +263,164 @@ struct Stream {
 	uint32_t safe_pos;    // every byte below is known to have reached L2
 };
 
+// Base value and number of extra bits of the length symbols 257..285 (index 0..28; 29, 30: the fixed code's 286, 287,
+// refused) and of the distance symbols 0..29 (30, 31: refused) -- RFC 1951 3.2.5 -- computed, not tabulated by hand.
+struct Luts {
+	uint16_t len[32];  // base | extra << 9 ; 0xFFFF: not a symbol
+	uint32_t dist[32]; // base | extra << 16 ; 0xFFFFFFFF: not a symbol
+};
+
+__device__ __forceinline__ void fill_luts(Luts &l, uint32_t i /* 0..31 */)
+{
+	const uint32_t eb = (i < 8u || i >= 28u) ? 0u : (i >> 2) - 1u;
+	const uint32_t lbase = i < 8u ? 3u + i : i == 28u ? 258u : 3u + ((4u + (i & 3u)) << eb);
+	l.len[i] = i <= 28u ? (uint16_t) (lbase | (eb << 9)) : (uint16_t) 0xFFFFu;
+	const uint32_t deb = i < 4u ? 0u : (i >> 1) - 1u;
+	const uint32_t dbase = i < 4u ? 1u + i : 1u + ((2u + (i & 1u)) << deb);
+	l.dist[i] = i <= 29u ? (dbase | (deb << 16)) : 0xFFFFFFFFu;
+}
+
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_add(uint32_t v)
+{
+	return v + (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, CTRL, ROW_MASK, 0xF, false);
+}
+
+// inclusive prefix sum over the wave: row_shr 1/2/4/8 inside each 16-lane row, row_bcast:15 / :31 across the rows
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+	v = dpp_add<0x111, 0xF>(v);
+	v = dpp_add<0x112, 0xF>(v);
+	v = dpp_add<0x114, 0xF>(v);
+	v = dpp_add<0x118, 0xF>(v);
+	v = dpp_add<0x142, 0xA>(v);
+	v = dpp_add<0x143, 0xC>(v);
+	return v;
+}
+
 // 0: end-of-block symbol reached; -1: the stream is invalid
-__device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t)
+__device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Luts &luts
+#ifdef IW_PROF
+		, unsigned long long *prof
+#endif
+)
 {
 	const uint32_t lane = lane_id();
+	// the stream's state is the same in every lane: kept in scalar registers (readfirstlane tells the compiler)
+	uint32_t ibit = uni(s.ibit), opos = uni(s.opos), safe_pos = uni(s.safe_pos);
+	const uint32_t end_bit = uni(s.end_bit), out_len = uni(s.out_len);
+	const uint32_t *in32 = s.in32;
+	auto leave = [&](int rc) {
+		s.ibit = ibit;
+		s.opos = opos;
+		s.safe_pos = safe_pos;
+		return rc;
+	};
+	// 64 consecutive dwords of the input sit in one register across the wave (lane i: dword d0 + i); a lane's view is
+	// three ds_bpermute (the LDS crossbar, no memory) and two funnel shifts, and the register is refilled with one
+	// coalesced load every ~1900 bits
+	uint32_t d0 = uni(ibit >> 5);
+	uint32_t wreg = in32[d0 + lane];
 	for (;;) {
-		if (s.ibit > s.end_bit)
-			return -1;
+		IW_T0();
+		if (ibit > end_bit)
+			return leave(-1);
+		uint32_t dd = (ibit >> 5) - d0;
+		if (dd > 59u) {
+			d0 = ibit >> 5;
+			wreg = in32[d0 + lane];
+			dd = 0;
+		}
 		// this lane's 64-bit view of the stream from bit ibit + lane on
-		const uint32_t b = s.ibit + lane;
-		const uint32_t *p = s.in32 + (b >> 5);
-		const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+		const uint32_t b = (ibit & 31u) + lane;
+		const uint32_t at = (dd + (b >> 5)) << 2;
+		const uint32_t w0 = (uint32_t) __builtin_amdgcn_ds_bpermute((int) at, (int) wreg);
+		const uint32_t w1 = (uint32_t) __builtin_amdgcn_ds_bpermute((int) at + 4, (int) wreg);
+		const uint32_t w2 = (uint32_t) __builtin_amdgcn_ds_bpermute((int) at + 8, (int) wreg);
 		const uint32_t sh = b & 31u;
 		const uint32_t lo = alignbit(w1, w0, sh), hi = alignbit(w2, w1, sh);
-		const uint64_t v = ((uint64_t) hi << 32) | lo;
-		// the literal / length code that would start here
-		uint32_t e = t.lit[lo & ((1u << kLitRoot) - 1u)];
-		uint32_t n1 = e & 15u, kind = (e >> 4) & 3u, val = e >> 6;
-		if (__any(kind == kSubTable)) {
-			if (kind == kSubTable) {
-				e = t.lit[val + ((lo >> kLitRoot) & ((1u << n1) - 1u))];
-				n1 = (e & 15u) ? (uint32_t) kLitRoot + (e & 15u) : 0u;
-				kind = (e >> 4) & 3u;
-				val = e >> 6;
-			}
-		}
-		bool bad = n1 == 0u;
+		// the literal / length code that would start here (second level read by every lane: some lane nearly always needs it)
+		const uint32_t e1 = t.lit[lo & ((1u << kLitRoot) - 1u)];
+		const bool sub1 = ((e1 >> 4) & 3u) == kSubTable;
+		const uint32_t e2 = t.lit[sub1 ? (e1 >> 6) + ((lo >> kLitRoot) & ((1u << (e1 & 15u)) - 1u)) : 0u];
+		const uint32_t e = sub1 ? e2 : e1;
+		const uint32_t n1 = (e & 15u) ? (e & 15u) + (sub1 ? (uint32_t) kLitRoot : 0u) : 0u;
+		const uint32_t kind = (e >> 4) & 3u, val = e >> 6;
 		// ... as a length: its extra bits, the distance code behind them and that one's extra bits
-		const uint32_t ls = kind == kSymbol ? val : 0u; // (<= 30: the shifts below stay in range)
-		const uint32_t eb = (ls < 8u || ls >= 28u) ? 0u : (ls >> 2) - 1u;
-		const uint32_t lbase = ls < 8u ? 3u + ls : ls >= 28u ? 258u : 3u + ((4u + (ls & 3u)) << eb);
-		const uint64_t v1 = v >> n1;
-		const uint32_t length = lbase + ((uint32_t) v1 & ((1u << eb) - 1u));
-		const uint64_t v2 = v1 >> eb;
-		uint32_t ed = t.dist[(uint32_t) v2 & ((1u << kDistRoot) - 1u)];
-		uint32_t n2 = ed & 15u, dval = ed >> 6;
-		if (__any(kind == kSymbol && ((ed >> 4) & 3u) == kSubTable)) {
-			if (((ed >> 4) & 3u) == kSubTable) {
-				ed = t.dist[dval + (((uint32_t) v2 >> kDistRoot) & ((1u << n2) - 1u))];
-				n2 = (ed & 15u) ? (uint32_t) kDistRoot + (ed & 15u) : 0u;
-				dval = ed >> 6;
-			}
-		}
-		const uint32_t deb = dval < 4u ? 0u : (dval >> 1) - 1u;
-		const uint32_t dbase = dval < 4u ? 1u + dval : 1u + ((2u + (dval & 1u)) << deb);
-		const uint64_t v3 = v2 >> n2;
-		const uint32_t dist = dbase + ((uint32_t) v3 & ((1u << deb) - 1u));
-		uint32_t bits = n1;
-		uint32_t payload = val; // literal byte
-		if (kind == kSymbol) {
-			bad = bad || n2 == 0u || ls > 28u || dval > 29u;
-			bits = n1 + eb + n2 + deb;
-			payload = length;
-		}
-		// [7:0] bits of the whole symbol, [9:8] kind (3: no valid symbol starts here), [31:16] literal byte / match length
-		const uint32_t word = bad ? (3u << 8) : (bits | (kind << 8) | (payload << 16));
+		const uint32_t ll = luts.len[kind == kSymbol ? val & 31u : 0u];
+		const uint32_t eb = (ll >> 9) & 7u;
+		const uint64_t v = ((uint64_t) hi << 32) | lo;
+		const uint32_t length = (ll & 511u) + ((uint32_t) (v >> n1) & ((1u << eb) - 1u));
+		const uint32_t r2 = (uint32_t) (v >> (n1 + eb)); // distance code (<= 15 bits) and its extra bits (<= 13)
+		const uint32_t d1 = t.dist[r2 & ((1u << kDistRoot) - 1u)];
+		const bool subd = ((d1 >> 4) & 3u) == kSubTable;
+		const uint32_t d2 = t.dist[subd ? (d1 >> 6) + ((r2 >> kDistRoot) & ((1u << (d1 & 15u)) - 1u)) : 0u];
+		const uint32_t ed = subd ? d2 : d1;
+		const uint32_t n2 = (ed & 15u) ? (ed & 15u) + (subd ? (uint32_t) kDistRoot : 0u) : 0u;
+		const uint32_t dl = luts.dist[(ed >> 6) & 31u];
+		const uint32_t deb = (dl >> 16) & 15u;
+		const uint32_t dist = (dl & 0xFFFFu) + ((r2 >> n2) & ((1u << deb) - 1u));
+		const bool is_lit = kind == kLiteral, is_match = kind == kSymbol;
+		const bool bad = n1 == 0u || (is_match && (n2 == 0u || ll == 0xFFFFu || dl == 0xFFFFFFFFu));
+		const uint32_t bits = is_match ? n1 + eb + n2 + deb : n1;
+		const uint32_t nxt = lane + bits;                        // where the symbol behind this one starts
+		const uint32_t produced = bad ? 0u : is_lit ? 1u : is_match ? length : 0u;
+		IW_LAP(P_VIEW);
 
-		// the chain of true symbol starts, from bit 0 of the window; stops in front of the first symbol that is not a literal
-		uint32_t pos = 0, special = 0;
-		unsigned long long lits = 0;
-		bool has_special = false;
-		while (pos < 64u) {
-			const uint32_t w = (uint32_t) __builtin_amdgcn_readlane((int) word, (int) pos);
-			if ((w >> 8) & 3u) {
-				special = w;
-				has_special = true;
+		// The chain of true symbol starts, from lane 0 on: J = "start of the next symbol" is doubled (J <- J o J) while the
+		// lanes known to be starts mark the lane their J points at (ds_permute pushes a flag there): after round k the first
+		// 2^(k+1) starts are known.  An end-of-block or invalid symbol ends the chain.
+		uint32_t J = (!bad && (is_lit || is_match) && nxt < 64u) ? nxt : 64u;
+		uint32_t on_chain = lane == 0u ? 1u : 0u;
+		for (;;) {
+			const bool push = on_chain && J < 64u;
+			on_chain |= (uint32_t) __builtin_amdgcn_ds_permute(push ? (int) (J << 2) : 0, push ? 1 : 0);
+			const uint32_t jj = (uint32_t) __builtin_amdgcn_ds_bpermute((int) ((J & 63u) << 2), (int) J);
+			J = J < 64u ? jj : 64u;
+			if (uni(J) >= 64u)
 				break;
-			}
-			lits |= 1ull << pos;
-			pos += w & 0xFFu;
 		}
-		const uint32_t n_lits = (uint32_t) __popcll(lits);
-		if (s.opos + n_lits > s.out_len)
-			return -1;
-		if ((lits >> lane) & 1ull)
-			s.out[s.opos + __builtin_amdgcn_mbcnt_hi((uint32_t) (lits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) lits, 0u))] = (uint8_t) (word >> 16);
-		s.opos += n_lits;
-		if (has_special) {
-			const uint32_t sk = (special >> 8) & 3u;
-			if (sk == 3u)
-				return -1;
-			if (sk == kEndOfBlock) {
-				s.ibit += pos + (special & 0xFFu);
-				return s.ibit > s.end_bit ? -1 : 0;
-			}
-			const uint32_t len = special >> 16;
-			const uint32_t d = (uint32_t) __builtin_amdgcn_readlane((int) dist, (int) pos);
-			if (d > s.opos || s.opos + len > s.out_len)
-				return -1;
-			const uint32_t src = s.opos - d;
-			if (src + (d < len ? d : len) > s.safe_pos) { // reaches into bytes stored since the last wait
+		const unsigned long long chain = __ballot(on_chain != 0u);
+		const unsigned long long bad_m = chain & __ballot(bad);
+		if (bad_m)
+			return leave(-1);
+		const unsigned long long match_m = chain & __ballot(is_match);
+		const bool ends = (chain & __ballot(kind == kEndOfBlock)) != 0ull;
+		IW_LAP(P_WALK);
+		// where every start's bytes go
+		const uint32_t mine = on_chain ? produced : 0u;
+		const uint32_t incl = wave_incl_scan(mine);
+		const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
+		const uint32_t last = 63u - (uint32_t) __builtin_clzll(chain);
+		const uint32_t advance = (uint32_t) __builtin_amdgcn_readlane((int) nxt, (int) last);
+		IW_ADD(P_TRIPS, 1);
+		IW_ADD(P_SYMS, (uint32_t) __popcll(chain));
+		if (opos + total > out_len)
+			return leave(-1);
+		if (on_chain && is_lit)
+			s.out[opos + incl - 1u] = (uint8_t) val;
+		IW_LAP(P_LITS);
+		unsigned long long mm = match_m;
+		while (mm) {
+			const uint32_t i = (uint32_t) __builtin_ctzll(mm);
+			mm &= mm - 1ull;
+			const uint32_t len = (uint32_t) __builtin_amdgcn_readlane((int) produced, (int) i);
+			const uint32_t d = (uint32_t) __builtin_amdgcn_readlane((int) dist, (int) i);
+			const uint32_t to = opos + (uint32_t) __builtin_amdgcn_readlane((int) incl, (int) i) - len;
+			if (d > to)
+				return leave(-1);
+			const uint32_t src = to - d;
+			if (src + (d < len ? d : len) > safe_pos) { // reaches into bytes stored since the last wait
 				asm volatile("" ::: "memory");
 				__builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the stores are acknowledged by L2
 				asm volatile("" ::: "memory");
-				s.safe_pos = s.opos;
+				safe_pos = to;
+				IW_ADD(P_WAITS, 1);
 			}
+			IW_LAP(P_MATCH_WAIT);
+			IW_ADD(P_MATCHES, 1);
 			if (d >= len) {
 				for (uint32_t k = lane; k < len; k += 64u)
-					s.out[s.opos + k] = (uint8_t) load_written_u8(s.out + src + k);
+					s.out[to + k] = (uint8_t) load_written_u8(s.out + src + k);
 			} else { // the match overlaps itself: it repeats its first d bytes
 				const float inv = 1.0f / (float) d;
 				for (uint32_t k = lane; k < len; k += 64u) {
@@ -357,13 +430,15 @@ __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t)
 						r += (int32_t) d;
 					else if ((uint32_t) r >= d)
 						r -= (int32_t) d;
-					s.out[s.opos + k] = (uint8_t) load_written_u8(s.out + src + (uint32_t) r);
+					s.out[to + k] = (uint8_t) load_written_u8(s.out + src + (uint32_t) r);
 				}
 			}
-			s.opos += len;
-			pos += special & 0xFFu;
+			IW_LAP(P_MATCH_COPY);
 		}
-		s.ibit += pos;
+		opos += total;
+		ibit += advance;
+		if (ends)
+			return leave(ibit > end_bit ? -1 : 0);
 	}
 }
 
@@ -421,7 +496,11 @@ __device__ __forceinline__ uint32_t wave_crc32(const uint8_t *out, uint32_t n, c
 enum { kStatusOk = 0, kStatusRefused = 1, kStatusCrc = 2 };
 
 // One whole BGZF block (a raw deflate stream of one or more deflate blocks) by one wave.
-__device__ __forceinline__ int inflate_block(WaveLds &t, const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len)
+__device__ __forceinline__ int inflate_block(WaveLds &t, const Luts &luts, const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len
+#ifdef IW_PROF
+		, unsigned long long *prof
+#endif
+)
 {
 	const uint32_t lane = lane_id();
 	Stream s;
@@ -571,13 +650,20 @@ __device__ __forceinline__ int inflate_block(WaveLds &t, const uint8_t *in, uint
 				if (s.ibit > s.end_bit || t.lens[256] == 0) // (no end-of-block code)
 					return kStatusRefused;
 			}
+			IW_T0();
 			if (!build_table<kLitRoot>(t.lens, n_lit, t.lit, kLitCap, t.sorted, true, [](uint32_t sym) { return lit_entry(sym); }))
 				return kStatusRefused;
 			if (!build_table<kDistRoot>(t.lens + n_lit, n_dist, t.dist, kDistCap, t.sorted, true,
 					[](uint32_t sym) { return (kSymbol << 4) | (sym << 6); }))
 				return kStatusRefused;
-			if (run_symbols(s, t) != 0)
+			IW_LAP(P_TABLES);
+#ifdef IW_PROF
+			if (run_symbols(s, t, luts, prof) != 0)
 				return kStatusRefused;
+#else
+			if (run_symbols(s, t, luts) != 0)
+				return kStatusRefused;
+#endif
 			win.d0 = 0xFFFFFF00u; // (the position moved on behind the window's back: force a reload)
 		} else
 			return kStatusRefused;
@@ -597,17 +683,26 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, 8) void bgzf_inflate_wave_kern
 	__shared__ WaveLds lds[kWavesPerGroup];
 	__shared__ uint32_t s_crc[256];
 	__shared__ uint32_t s_x2n[32];
+	__shared__ Luts s_luts;
+	if (threadIdx.x < 32)
+		fill_luts(s_luts, threadIdx.x);
 	for (int i = threadIdx.x; i < 256; i += blockDim.x)
 		s_crc[i] = crc_table[i];
 	if (threadIdx.x < 32)
 		s_x2n[threadIdx.x] = x2n[threadIdx.x];
 	__syncthreads();
-	const uint32_t wave = threadIdx.x >> 6;
+	const uint32_t wave = uni(threadIdx.x >> 6); // (uniform by construction; said so, everything per block stays in scalar registers)
 	const uint32_t n_waves = gridDim.x * kWavesPerGroup;
 	for (uint32_t b = blockIdx.x * kWavesPerGroup + wave; b < n_blocks; b += n_waves) {
 		const conga_bgzf_block bl = blocks[b];
 		uint8_t *dst = out + out_off[b];
-		int st = inflate_block(lds[wave], bytes + bl.data_off, bl.data_len, dst, bl.inflated_len);
+#ifdef IW_PROF
+		unsigned long long prof[P_N] = {};
+		int st = inflate_block(lds[wave], s_luts, bytes + bl.data_off, bl.data_len, dst, bl.inflated_len, prof);
+		IW_T0();
+#else
+		int st = inflate_block(lds[wave], s_luts, bytes + bl.data_off, bl.data_len, dst, bl.inflated_len);
+#endif
 		if (st == kStatusOk) {
 			asm volatile("" ::: "memory");
 			__builtin_amdgcn_s_waitcnt(0x0F70); // every store of the block has reached L2
@@ -615,6 +710,12 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, 8) void bgzf_inflate_wave_kern
 			if (wave_crc32(dst, bl.inflated_len, s_crc, s_x2n) != bl.crc32)
 				st = kStatusCrc;
 		}
+		IW_LAP(P_CRC);
+#ifdef IW_PROF
+		if (lane_id() == 0u)
+			for (int k = 0; k < P_N; k++)
+				atomicAdd(&g_prof[k], prof[k]);
+#endif
 		if (lane_id() == 0u)
 			status[b] = (uint8_t) st;
 		wave_sync();
