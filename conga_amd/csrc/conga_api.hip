@@ -12,7 +12,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -130,6 +134,12 @@ struct conga_ctx {
 			// conga_reads_bgzf: compressed blocks, their table, the inflated stream, the decoders' scratch, the walk's per-segment results
 			d_bz_in, d_bz_blocks, d_bz_off, d_bz_out, d_bz_status, d_bz_scratch, d_bz_crc, d_bz_seg, d_bz_cnt, d_bz_first, d_bz_stop,
 			d_bz_bad, d_bz_at, d_bz_flag, d_bz_x2n;
+
+	// conga_reads_bgzf: the file's bytes go up through a ring of pinned pieces filled by host threads, inflate launches follow
+	uint8_t *h_bz_ring = nullptr;
+	hipEvent_t ev_bz_slot[8] = {};
+	hipStream_t bz_copy = nullptr, bz_kernel[3] = {};
+	hipEvent_t ev_bz_kernel[3] = {};
 
 	// pinned read-back
 	Small *h_small = nullptr;
@@ -858,44 +868,199 @@ int ensure_crc_table(conga_ctx *ctx)
 	return CONGA_OK;
 }
 
-// BGZF inflate of the blocks described in d_bz_blocks / d_bz_off: d_bz_in -> d_bz_out, one status byte per block.
+// BGZF inflate of blocks [b0, b0 + n) of d_bz_blocks / d_bz_off on stream `st`: d_bz_in -> d_bz_out, one status byte per block.
 // Default: one block per WAVE (inflate_wave.hip.h).  CONGA_BGZF_KERNEL=lane: the host decoder's source one block per
 // lane (round 1's kernel, kept for comparison); `lanes` sizes its per-lane scratch.
-int launch_inflate(conga_ctx *ctx, size_t n_blocks, uint32_t lanes)
+bool lane_kernel_asked()
 {
-	hipStream_t st = ctx->stream;
 	const char *which = getenv("CONGA_BGZF_KERNEL");
-	if (which && strcmp(which, "lane") == 0) {
+	return which && strcmp(which, "lane") == 0;
+}
+
+int ensure_x2n(conga_ctx *ctx)
+{
+	if (ctx->d_bz_x2n.p)
+		return CONGA_OK;
+	// x^(2^k) mod P for the CRC-32 polynomial, reflected (bit 31 = x^0): the wave combines its lanes' partial CRCs with them
+	uint32_t x2n[32];
+	auto mul = [](uint32_t a, uint32_t b) {
+		uint32_t p = 0;
+		for (int k = 0; k < 32; k++) {
+			if ((a >> (31 - k)) & 1u)
+				p ^= b;
+			b = (b & 1u) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
+		}
+		return p;
+	};
+	x2n[0] = 0x40000000u; // x
+	for (int k = 1; k < 32; k++)
+		x2n[k] = mul(x2n[k - 1], x2n[k - 1]);
+	TRY(upload(ctx, ctx->d_bz_x2n, x2n, sizeof x2n));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // (`x2n` is on the stack)
+	return CONGA_OK;
+}
+
+int launch_inflate(conga_ctx *ctx, size_t n_blocks, uint32_t lanes, hipStream_t st = nullptr, size_t b0 = 0)
+{
+	if (!st)
+		st = ctx->stream;
+	if (lane_kernel_asked()) {
 		TRY(ensure(ctx, ctx->d_bz_scratch, (size_t) lanes * sizeof(InflateScratch)));
 		hipLaunchKernelGGL(bgzf_inflate_kernel, dim3(lanes / 64), dim3(64), 0, st, (uint32_t) n_blocks, ptr<uint8_t>(ctx->d_bz_in),
-				ptr<conga_bgzf_block>(ctx->d_bz_blocks), ptr<uint64_t>(ctx->d_bz_off), ptr<uint8_t>(ctx->d_bz_out),
-				ptr<InflateScratch>(ctx->d_bz_scratch), ptr<uint32_t>(ctx->d_bz_crc), ptr<uint8_t>(ctx->d_bz_status));
+				ptr<conga_bgzf_block>(ctx->d_bz_blocks) + b0, ptr<uint64_t>(ctx->d_bz_off) + b0, ptr<uint8_t>(ctx->d_bz_out),
+				ptr<InflateScratch>(ctx->d_bz_scratch), ptr<uint32_t>(ctx->d_bz_crc), ptr<uint8_t>(ctx->d_bz_status) + b0);
 		return CONGA_OK;
 	}
-	if (!ctx->d_bz_x2n.p) {
-		// x^(2^k) mod P for the CRC-32 polynomial, reflected (bit 31 = x^0): the wave combines its lanes' partial CRCs with them
-		uint32_t x2n[32];
-		auto mul = [](uint32_t a, uint32_t b) {
-			uint32_t p = 0;
-			for (int k = 0; k < 32; k++) {
-				if ((a >> (31 - k)) & 1u)
-					p ^= b;
-				b = (b & 1u) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
-			}
-			return p;
-		};
-		x2n[0] = 0x40000000u; // x
-		for (int k = 1; k < 32; k++)
-			x2n[k] = mul(x2n[k - 1], x2n[k - 1]);
-		TRY(upload(ctx, ctx->d_bz_x2n, x2n, sizeof x2n));
-		HIP_TRY(ctx, hipStreamSynchronize(st)); // (`x2n` is on the stack)
-	}
+	TRY(ensure_x2n(ctx));
 	// one resident round of workgroups (8 per CU), blocks round robin over their waves
 	const size_t groups = std::min<size_t>((n_blocks + iw::kWavesPerGroup - 1) / iw::kWavesPerGroup, (size_t) ctx->n_cu * 8);
 	hipLaunchKernelGGL(iw::bgzf_inflate_wave_kernel, dim3((unsigned) groups), dim3(64 * iw::kWavesPerGroup), 0, st, (uint32_t) n_blocks,
-			ptr<uint8_t>(ctx->d_bz_in), ptr<conga_bgzf_block>(ctx->d_bz_blocks), ptr<uint64_t>(ctx->d_bz_off), ptr<uint8_t>(ctx->d_bz_out),
-			ptr<uint32_t>(ctx->d_bz_crc), ptr<uint32_t>(ctx->d_bz_x2n), ptr<uint8_t>(ctx->d_bz_status));
+			ptr<uint8_t>(ctx->d_bz_in), ptr<conga_bgzf_block>(ctx->d_bz_blocks) + b0, ptr<uint64_t>(ctx->d_bz_off) + b0,
+			ptr<uint8_t>(ctx->d_bz_out), ptr<uint32_t>(ctx->d_bz_crc), ptr<uint32_t>(ctx->d_bz_x2n), ptr<uint8_t>(ctx->d_bz_status) + b0);
 	return CONGA_OK;
+}
+
+// The file's bytes to HBM and the inflate of their blocks, overlapped.  A pageable hipMemcpy of gigabytes runs at the rate
+// of ONE staging thread inside the runtime (~18 GB/s measured); here host threads copy 16 MB pieces of the caller's bytes
+// (the page cache behind an mmap) into a ring of pinned buffers, each piece goes up at the link's rate as soon as it is
+// full, and every 128 MB of pieces the inflate of the blocks they complete is launched on one of three streams, so that
+// copying in, copying up and inflating all run at once.  Ends with ctx->stream waiting for every launch.
+// blocks[] must be in file order (data_off ascending); the caller falls back to the plain form otherwise.
+constexpr size_t kBzPiece = (size_t) 16 << 20;
+constexpr int kBzSlots = 6, kBzPiecesPerLaunch = 8;
+
+int upload_and_inflate_overlapped(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const conga_bgzf_block *blocks, size_t n_blocks)
+{
+	if (!ctx->h_bz_ring) {
+		HIP_TRY(ctx, hipHostMalloc((void **) &ctx->h_bz_ring, kBzPiece * kBzSlots, hipHostMallocDefault));
+		HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->bz_copy, hipStreamNonBlocking));
+		for (int k = 0; k < kBzSlots; k++)
+			HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_bz_slot[k], hipEventDisableTiming));
+		for (int k = 0; k < 3; k++) {
+			HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->bz_kernel[k], hipStreamNonBlocking));
+			HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_bz_kernel[k], hipEventDisableTiming));
+		}
+	}
+	TRY(ensure_x2n(ctx));
+	size_t piece = kBzPiece; // (tests: small pieces, so that a small file goes through every part of this)
+	if (const char *e = getenv("CONGA_BGZF_PIECE_KB"))
+		piece = std::min(kBzPiece, std::max<size_t>(4096, (size_t) atol(e) << 10));
+	const size_t n_pieces = (n_bytes + piece - 1) / piece;
+	// everything enqueued on ctx->stream so far (tables, buffers grown) comes first
+	HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+	HIP_TRY(ctx, hipStreamWaitEvent(ctx->bz_copy, ctx->ev_fork, 0));
+	for (int k = 0; k < 3; k++)
+		HIP_TRY(ctx, hipStreamWaitEvent(ctx->bz_kernel[k], ctx->ev_fork, 0));
+
+	std::mutex mu;
+	std::condition_variable cv;
+	std::vector<uint8_t> filled(n_pieces, 0);
+	size_t issued = 0;       // pieces whose copy up has been enqueued (their slot's event is recorded)
+	bool failed = false;
+	std::atomic<size_t> next_piece{0};
+	const int device = ctx->device;
+	auto worker = [&]() {
+		(void) hipSetDevice(device);
+		for (;;) {
+			const size_t c = next_piece.fetch_add(1);
+			if (c >= n_pieces)
+				return;
+			if (c >= (size_t) kBzSlots) { // the slot still holds piece c - kBzSlots until that one's copy up is done
+				{
+					std::unique_lock<std::mutex> lk(mu);
+					cv.wait(lk, [&] { return failed || issued > c - kBzSlots; });
+					if (failed)
+						return;
+				}
+				if (hipEventSynchronize(ctx->ev_bz_slot[c % kBzSlots]) != hipSuccess) {
+					std::lock_guard<std::mutex> g(mu);
+					failed = true;
+					cv.notify_all();
+					return;
+				}
+			}
+			const size_t at = c * piece, len = std::min(piece, n_bytes - at);
+			memcpy(ctx->h_bz_ring + (c % kBzSlots) * kBzPiece, bytes + at, len);
+			{
+				std::lock_guard<std::mutex> g(mu);
+				filled[c] = 1;
+			}
+			cv.notify_all();
+		}
+	};
+	int n_threads = (int) std::min<size_t>(n_pieces, std::min<unsigned>(std::max(2u, std::thread::hardware_concurrency() / 2), (unsigned) kBzSlots));
+	if (const char *e = getenv("CONGA_BGZF_COPY_THREADS"))
+		n_threads = std::max(1, std::min(atoi(e), kBzSlots));
+	std::vector<std::thread> threads;
+	for (int t = 0; t < n_threads; t++)
+		threads.emplace_back(worker);
+
+	int rc = CONGA_OK;
+	size_t b_done = 0; // blocks launched so far
+	int launches = 0;
+	for (size_t c = 0; c < n_pieces && rc == CONGA_OK; c++) {
+		{
+			std::unique_lock<std::mutex> lk(mu);
+			cv.wait(lk, [&] { return failed || filled[c]; });
+			if (failed)
+				rc = fail(ctx, CONGA_ERR_HIP, "conga_reads_bgzf: waiting for a pinned piece failed");
+		}
+		if (rc != CONGA_OK)
+			break;
+		const size_t at = c * piece, len = std::min(piece, n_bytes - at);
+		hipError_t e = hipMemcpyAsync(ptr<uint8_t>(ctx->d_bz_in) + at, ctx->h_bz_ring + (c % kBzSlots) * kBzPiece, len, hipMemcpyHostToDevice,
+				ctx->bz_copy);
+		if (e == hipSuccess)
+			e = hipEventRecord(ctx->ev_bz_slot[c % kBzSlots], ctx->bz_copy);
+		if (e != hipSuccess)
+			rc = fail(ctx, CONGA_ERR_HIP, std::string("conga_reads_bgzf: copy up: ") + hipGetErrorString(e));
+		{
+			std::lock_guard<std::mutex> g(mu);
+			issued = c + 1;
+			if (rc != CONGA_OK)
+				failed = true;
+		}
+		cv.notify_all();
+		if (rc != CONGA_OK)
+			break;
+		const bool last = c + 1 == n_pieces;
+		if ((c + 1) % kBzPiecesPerLaunch == 0 || last) {
+			// the blocks that are complete with the bytes up to here
+			const size_t have = at + len;
+			size_t b1 = b_done;
+			while (b1 < n_blocks && blocks[b1].data_off + blocks[b1].data_len <= have)
+				b1++;
+			if (last)
+				b1 = n_blocks;
+			if (b1 > b_done) {
+				hipStream_t ks = ctx->bz_kernel[launches % 3];
+				e = hipStreamWaitEvent(ks, ctx->ev_bz_slot[c % kBzSlots], 0);
+				if (e != hipSuccess)
+					rc = fail(ctx, CONGA_ERR_HIP, std::string("conga_reads_bgzf: ") + hipGetErrorString(e));
+				else
+					rc = launch_inflate(ctx, b1 - b_done, 0, ks, b_done);
+				launches++;
+				b_done = b1;
+			}
+		}
+	}
+	if (rc != CONGA_OK) {
+		std::lock_guard<std::mutex> g(mu);
+		failed = true;
+	}
+	cv.notify_all();
+	for (std::thread &t : threads)
+		t.join();
+	// ctx->stream goes on behind every launch (and the copy stream, for the case of no launch at all)
+	for (int k = 0; k < 3; k++) {
+		(void) hipEventRecord(ctx->ev_bz_kernel[k], ctx->bz_kernel[k]);
+		(void) hipStreamWaitEvent(ctx->stream, ctx->ev_bz_kernel[k], 0);
+	}
+	(void) hipEventRecord(ctx->ev_fork2, ctx->bz_copy);
+	(void) hipStreamWaitEvent(ctx->stream, ctx->ev_fork2, 0);
+	if (rc == CONGA_OK)
+		HIP_TRY(ctx, hipGetLastError());
+	return rc;
 }
 
 } // namespace
@@ -1096,6 +1261,19 @@ void conga_destroy(conga_ctx *ctx)
 		(void) hipHostFree(ctx->h_small);
 	if (ctx->h_head)
 		(void) hipHostFree(ctx->h_head);
+	if (ctx->h_bz_ring)
+		(void) hipHostFree(ctx->h_bz_ring);
+	for (hipEvent_t e : ctx->ev_bz_slot)
+		if (e)
+			(void) hipEventDestroy(e);
+	for (hipEvent_t e : ctx->ev_bz_kernel)
+		if (e)
+			(void) hipEventDestroy(e);
+	if (ctx->bz_copy)
+		(void) hipStreamDestroy(ctx->bz_copy);
+	for (hipStream_t q : ctx->bz_kernel)
+		if (q)
+			(void) hipStreamDestroy(q);
 	if (ctx->ev_head)
 		(void) hipEventDestroy(ctx->ev_head);
 	if (ctx->h_results)
@@ -1413,17 +1591,29 @@ int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const
 	TRY(ensure(ctx, ctx->d_bz_at, n_segments * 8));
 	TRY(ensure(ctx, ctx->d_bz_flag, 4));
 	TRY(ensure_crc_table(ctx));
-	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bz_in.p, bytes, n_bytes, hipMemcpyHostToDevice, st));
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bz_blocks.p, blocks, n_blocks * sizeof(conga_bgzf_block), hipMemcpyHostToDevice, st));
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bz_off.p, out_off.data(), n_blocks * 8, hipMemcpyHostToDevice, st));
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bz_seg.p, segments, n_segments * sizeof(conga_bam_segment), hipMemcpyHostToDevice, st));
-	double ms_alloc_upload = 0;
-	if (timing) {
-		HIP_TRY(ctx, hipStreamSynchronize(st));
-		ms_alloc_upload = ms_since(t_begin);
+	// the bytes and their inflate: overlapped (pinned pieces, several launches) for a piece of the file worth it and blocks in
+	// file order; otherwise one copy, one launch
+	bool in_order = true;
+	for (size_t b = 1; b < n_blocks && in_order; b++)
+		in_order = blocks[b].data_off >= blocks[b - 1].data_off + blocks[b - 1].data_len;
+	const char *ov = getenv("CONGA_BGZF_OVERLAP"); // (0 / 1 forces; tests run both forms on small files)
+	const bool overlapped = !lane_kernel_asked() && in_order && (ov ? atoi(ov) != 0 : n_bytes >= ((size_t) 96 << 20));
+	double ms_alloc_upload = 0, ms_inflate = 0;
+	auto t_inflate = std::chrono::steady_clock::now();
+	if (overlapped) {
+		TRY(upload_and_inflate_overlapped(ctx, bytes, n_bytes, blocks, n_blocks));
+	} else {
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bz_in.p, bytes, n_bytes, hipMemcpyHostToDevice, st));
+		if (timing) {
+			HIP_TRY(ctx, hipStreamSynchronize(st));
+			ms_alloc_upload = ms_since(t_begin);
+			t_inflate = std::chrono::steady_clock::now();
+		}
+		TRY(launch_inflate(ctx, n_blocks, lanes));
 	}
-	const auto t_inflate = std::chrono::steady_clock::now();
-	TRY(launch_inflate(ctx, n_blocks, lanes));
 	BamWalkArgs w;
 	w.stream = ptr<uint8_t>(ctx->d_bz_out);
 	w.stream_len = total;
@@ -1437,7 +1627,6 @@ int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const
 	w.pos = nullptr;
 	w.mapq = nullptr;
 	const int wgrid = (int) ((n_segments + 63) / 64);
-	double ms_inflate = 0;
 	if (timing) {
 		HIP_TRY(ctx, hipStreamSynchronize(st));
 		ms_inflate = ms_since(t_inflate);
@@ -1497,9 +1686,10 @@ int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const
 			ctx->wrap_risk = true;
 	}
 	if (timing)
-		fprintf(stderr, "\n[timing] conga_reads_bgzf: %zu blocks, %.1f MB -> %.1f MB, %zu start points, %llu reads: buffers + upload %.1f ms, "
-				"inflate %.1f ms, walks + checks %.1f ms\n", n_blocks, n_bytes / 1e6, total / 1e6, n_segments, (unsigned long long) n_new,
-				ms_alloc_upload, ms_inflate, ms_since(t_walk));
+		fprintf(stderr, "\n[timing] conga_reads_bgzf: %zu blocks, %.1f MB -> %.1f MB, %zu start points, %llu reads: %s %.1f ms, "
+				"%s %.1f ms, walks + checks %.1f ms\n", n_blocks, n_bytes / 1e6, total / 1e6, n_segments, (unsigned long long) n_new,
+				overlapped ? "buffers" : "buffers + upload", overlapped ? ms_since(t_begin) - ms_inflate - ms_since(t_walk) : ms_alloc_upload,
+				overlapped ? "upload + inflate (overlapped)" : "inflate", ms_inflate, ms_since(t_walk));
 	// the tuples of a context lie in chromosome order: every chromosome from the first named one on gets its place
 	{
 		int64_t at = ctx->n_reads_total;

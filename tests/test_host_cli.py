@@ -305,6 +305,13 @@ def test_cli_bam_decoded_on_the_gpu_matches_the_host_decoders(tmp_path, oracle):
     assert "decoding on the host" not in r_gpu.stderr and r_gpu.stderr.count("conga_reads_bgzf:") == 1
     r_host, host = cli("host", CONGA_GPU_BAM="0")
     assert gpu == host and gpu[1].count(b"\n") > 50
+    # the overlapped form of the upload (pinned pieces filled by host threads, one inflate launch per 8 pieces), forced onto
+    # this small file with 8 KB pieces, and the plain form; the round-1 kernel (one block per lane) once more
+    for tag, env in (("ovl", dict(CONGA_BGZF_OVERLAP="1", CONGA_BGZF_PIECE_KB="8")), ("ovl1", dict(CONGA_BGZF_OVERLAP="1", CONGA_BGZF_PIECE_KB="8", CONGA_BGZF_COPY_THREADS="1")),
+                     ("plain", dict(CONGA_BGZF_OVERLAP="0")), ("lane", dict(CONGA_BGZF_KERNEL="lane"))):
+        r_x, x = cli(tag, CONGA_GPU_BAM="1", CONGA_TIMING="1", **env)
+        assert x == gpu and "decoding on the host" not in r_x.stderr and r_x.stderr.count("conga_reads_bgzf:") == 1, tag
+        assert ("overlapped" in r_x.stderr) == tag.startswith("ovl"), tag
     # a piece limit below the whole stretch but above each chromosome's: one GPU call per chromosome instead of one for all
     size = os.path.getsize(os.path.join(d, "r.bam"))
     r_each, each = cli("each", CONGA_GPU_BAM="1", CONGA_TIMING="1", CONGA_GPU_BAM_MAX_MB="%.4f" % (size * 0.75 / 1048576))
