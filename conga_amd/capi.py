@@ -26,6 +26,7 @@ FLAG_PROFILE = 0x2
 FLAG_BATCH = 0x4
 FLAG_MATERIALIZE_DEPTH = 0x8
 FLAG_RESULTS_ON_DEVICE = 0x10
+FLAG_EXPECT_BGZF = 0x20
 
 DELETION = "D"
 DUPLICATION = "E"

@@ -137,7 +137,9 @@ struct conga_ctx {
 
 	// conga_reads_bgzf: the file's bytes go up through a ring of pinned pieces filled by host threads, inflate launches follow
 	uint8_t *h_bz_ring = nullptr;
-	hipEvent_t ev_bz_slot[8] = {};
+	hipEvent_t ev_bz_slot[12] = {};
+	std::thread bz_ring_maker; // allocates the ring in the background (CONGA_FLAG_EXPECT_BGZF)
+	bool bz_ring_failed = false;
 	hipStream_t bz_copy = nullptr, bz_kernel[3] = {};
 	hipEvent_t ev_bz_kernel[3] = {};
 
@@ -926,22 +928,42 @@ int launch_inflate(conga_ctx *ctx, size_t n_blocks, uint32_t lanes, hipStream_t 
 // full, and every 128 MB of pieces the inflate of the blocks they complete is launched on one of three streams, so that
 // copying in, copying up and inflating all run at once.  Ends with ctx->stream waiting for every launch.
 // blocks[] must be in file order (data_off ascending); the caller falls back to the plain form otherwise.
-constexpr size_t kBzPiece = (size_t) 16 << 20;
-constexpr int kBzSlots = 6, kBzPiecesPerLaunch = 8;
+constexpr size_t kBzPiece = (size_t) 8 << 20;
+constexpr int kBzSlots = 12, kBzPiecesPerLaunch = 16;
+
+// the pinned ring, its events and the streams of the overlapped upload (96 MB of pinned memory take ~50 ms to get: with
+// CONGA_FLAG_EXPECT_BGZF conga_create() does this on a thread of its own while the caller is still reading its index)
+void make_bz_ring(conga_ctx *ctx)
+{
+	bool ok = hipSetDevice(ctx->device) == hipSuccess
+			&& hipHostMalloc((void **) &ctx->h_bz_ring, kBzPiece * kBzSlots, hipHostMallocDefault) == hipSuccess
+			&& hipStreamCreateWithFlags(&ctx->bz_copy, hipStreamNonBlocking) == hipSuccess;
+	for (int k = 0; ok && k < kBzSlots; k++)
+		ok = hipEventCreateWithFlags(&ctx->ev_bz_slot[k], hipEventDisableTiming) == hipSuccess;
+	for (int k = 0; ok && k < 3; k++)
+		ok = hipStreamCreateWithFlags(&ctx->bz_kernel[k], hipStreamNonBlocking) == hipSuccess
+				&& hipEventCreateWithFlags(&ctx->ev_bz_kernel[k], hipEventDisableTiming) == hipSuccess;
+	if (!ok) {
+		(void) hipGetLastError();
+		ctx->bz_ring_failed = true;
+	}
+}
 
 int upload_and_inflate_overlapped(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const conga_bgzf_block *blocks, size_t n_blocks)
 {
-	if (!ctx->h_bz_ring) {
-		HIP_TRY(ctx, hipHostMalloc((void **) &ctx->h_bz_ring, kBzPiece * kBzSlots, hipHostMallocDefault));
-		HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->bz_copy, hipStreamNonBlocking));
-		for (int k = 0; k < kBzSlots; k++)
-			HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_bz_slot[k], hipEventDisableTiming));
-		for (int k = 0; k < 3; k++) {
-			HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->bz_kernel[k], hipStreamNonBlocking));
-			HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_bz_kernel[k], hipEventDisableTiming));
-		}
-	}
+	const bool timing = getenv("CONGA_TIMING") != nullptr;
+	const auto t0 = std::chrono::steady_clock::now();
+	auto ms_since = [](std::chrono::steady_clock::time_point t) {
+		return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+	};
+	if (ctx->bz_ring_maker.joinable())
+		ctx->bz_ring_maker.join();
+	if (!ctx->h_bz_ring && !ctx->bz_ring_failed)
+		make_bz_ring(ctx);
+	if (ctx->bz_ring_failed || !ctx->h_bz_ring)
+		return fail(ctx, CONGA_ERR_NOMEM, "conga_reads_bgzf: no pinned staging ring");
 	TRY(ensure_x2n(ctx));
+	const double ms_ring = ms_since(t0);
 	size_t piece = kBzPiece; // (tests: small pieces, so that a small file goes through every part of this)
 	if (const char *e = getenv("CONGA_BGZF_PIECE_KB"))
 		piece = std::min(kBzPiece, std::max<size_t>(4096, (size_t) atol(e) << 10));
@@ -988,7 +1010,7 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const uint8_t *bytes, size_t n
 			cv.notify_all();
 		}
 	};
-	int n_threads = (int) std::min<size_t>(n_pieces, std::min<unsigned>(std::max(2u, std::thread::hardware_concurrency() / 2), (unsigned) kBzSlots));
+	int n_threads = (int) std::min<size_t>(n_pieces, std::min<unsigned>(std::max(2u, std::thread::hardware_concurrency() * 3 / 4), (unsigned) kBzSlots));
 	if (const char *e = getenv("CONGA_BGZF_COPY_THREADS"))
 		n_threads = std::max(1, std::min(atoi(e), kBzSlots));
 	std::vector<std::thread> threads;
@@ -1051,6 +1073,9 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const uint8_t *bytes, size_t n
 	cv.notify_all();
 	for (std::thread &t : threads)
 		t.join();
+	if (timing)
+		fprintf(stderr, "\n[timing] overlapped upload: pinned ring + streams %.1f ms, %zu pieces by %d threads enqueued after %.1f ms, %d inflate launches\n",
+				ms_ring, n_pieces, n_threads, ms_since(t0), launches);
 	// ctx->stream goes on behind every launch (and the copy stream, for the case of no launch at all)
 	for (int k = 0; k < 3; k++) {
 		(void) hipEventRecord(ctx->ev_bz_kernel[k], ctx->bz_kernel[k]);
@@ -1205,6 +1230,8 @@ conga_ctx *conga_create(int device, const conga_opts *opts, int *status)
 	for (int k = 0; k < CONGA_K_COUNT; k++)
 		if (hipEventCreate(&ctx->ev_k0[k]) != hipSuccess || hipEventCreate(&ctx->ev_k1[k]) != hipSuccess)
 			return bail(CONGA_ERR_HIP);
+	if (ctx->opts.flags & CONGA_FLAG_EXPECT_BGZF)
+		ctx->bz_ring_maker = std::thread(make_bz_ring, ctx);
 	*status = CONGA_OK;
 	return ctx;
 }
@@ -1213,6 +1240,8 @@ void conga_destroy(conga_ctx *ctx)
 {
 	if (!ctx)
 		return;
+	if (ctx->bz_ring_maker.joinable())
+		ctx->bz_ring_maker.join();
 	(void) hipSetDevice(ctx->device);
 	if (ctx->stream)
 		(void) hipStreamSynchronize(ctx->stream);
@@ -1591,6 +1620,7 @@ int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const
 	TRY(ensure(ctx, ctx->d_bz_at, n_segments * 8));
 	TRY(ensure(ctx, ctx->d_bz_flag, 4));
 	TRY(ensure_crc_table(ctx));
+	const double ms_buffers = ms_since(t_begin);
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bz_blocks.p, blocks, n_blocks * sizeof(conga_bgzf_block), hipMemcpyHostToDevice, st));
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bz_off.p, out_off.data(), n_blocks * 8, hipMemcpyHostToDevice, st));
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bz_seg.p, segments, n_segments * sizeof(conga_bam_segment), hipMemcpyHostToDevice, st));
@@ -1688,7 +1718,7 @@ int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const
 	if (timing)
 		fprintf(stderr, "\n[timing] conga_reads_bgzf: %zu blocks, %.1f MB -> %.1f MB, %zu start points, %llu reads: %s %.1f ms, "
 				"%s %.1f ms, walks + checks %.1f ms\n", n_blocks, n_bytes / 1e6, total / 1e6, n_segments, (unsigned long long) n_new,
-				overlapped ? "buffers" : "buffers + upload", overlapped ? ms_since(t_begin) - ms_inflate - ms_since(t_walk) : ms_alloc_upload,
+				overlapped ? "buffers" : "buffers + upload", overlapped ? ms_buffers : ms_alloc_upload,
 				overlapped ? "upload + inflate (overlapped)" : "inflate", ms_inflate, ms_since(t_walk));
 	// the tuples of a context lie in chromosome order: every chromosome from the first named one on gets its place
 	{

@@ -266,6 +266,12 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 	opts.mq_threshold = params->mq_threshold;
 	opts.gc_step = this_sonic->gc_step;
 	opts.flags = CONGA_FLAG_BATCH;
+	{
+		const char *gb = getenv("CONGA_GPU_BAM"); // (the decode may go to the GPU: let the engine get its staging ring meanwhile)
+		if (params->no_sr || !params->have_dups)
+			if (gb == nullptr || atoi(gb) != 0)
+				opts.flags |= CONGA_FLAG_EXPECT_BGZF;
+	}
 	opts.min_read_length = params->min_read_length;
 	// the reference's split-read gate: `!no_sr && dup_file` (svdepth.c:57, bam_data.c:207,306,331, likelihood.c:344)
 	const bool split_reads = !params->no_sr && params->have_dups;

@@ -193,14 +193,20 @@ def bgzf_table(raw):
 def test_reads_bgzf_in_process_on_recycled_device_memory(capi, tmp_path, strategy, formulation):
     """The decoders' scratch is raw device memory: fixed-Huffman blocks (BTYPE 1) must decode right even when the
     allocator hands back memory full of 0xFF (the `fixed_ready` flag was read uninitialised)."""
+    import ctypes
     import struct
     import zlib
-    import torch
     from conga_amd import formats
-    junk = [torch.full((n,), 255, dtype=torch.uint8, device="cuda") for n in (1 << 20, 3 << 20, 17 << 20, 64 << 20)]
-    torch.cuda.synchronize()
-    del junk
-    torch.cuda.empty_cache()  # back to the HIP allocator, contents intact
+    hip = ctypes.CDLL("libamdhip64.so")   # the runtime the library itself uses: blocks freed here are what it gets next
+    junk = []
+    for n in (1 << 20, 3 << 20, 17 << 20, 64 << 20, 2 << 20):
+        p = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(n)) == 0
+        assert hip.hipMemset(p, 0xFF, ctypes.c_size_t(n)) == 0
+        junk.append(p)
+    assert hip.hipDeviceSynchronize() == 0
+    for p in junk:
+        assert hip.hipFree(p) == 0   # back to the allocator, contents intact
 
     cs = [synth.make_chrom(n, L, cov=2.0, n_dels=nd, gaps=False) for n, L, nd in (("1", 300_000, 15), ("2", 200_000, 10))]
     path = str(tmp_path / "r.bam")
