@@ -277,13 +277,21 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 	const bool split_reads = !params->no_sr && params->have_dups;
 	// (the caller passes buffered = true whenever the counts of the closing line are not known while reading)
 	const bool counts_known_now = params->mq_threshold < 0 && !split_reads;
+	// The engine context (HIP runtime, streams, the staging ring) is made on a thread of its own while this one reads the
+	// BAM's block table: neither needs the other.
 	int status = 0;
-	conga_ctx *ctx = conga_create(device, &opts, &status);
-	if (!ctx) {
-		fprintf(stderr, "\n[CONGA ENGINE ERROR] cannot create a context on HIP device %d: %s\n", device, conga_strerror(status));
-		exit(CONGA_EXIT_COMMON);
-	}
-	wt->ms_create = ms_since(t_create);
+	conga_ctx *ctx = nullptr;
+	std::thread creator([&] { ctx = conga_create(device, &opts, &status); });
+	auto need_ctx = [&]() {
+		if (!creator.joinable())
+			return;
+		creator.join();
+		if (!ctx) {
+			fprintf(stderr, "\n[CONGA ENGINE ERROR] cannot create a context on HIP device %d: %s\n", device, conga_strerror(status));
+			exit(CONGA_EXIT_COMMON);
+		}
+		wt->ms_create = ms_since(t_create);
+	};
 	const auto t_loop = now();
 
 	std::string err;
@@ -300,8 +308,10 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 		std::vector<conga_bgzf_block> blocks;
 		std::vector<conga_bam_segment> segments;
 		const auto t_plan = now();
-		if (src->device_plan(targets, gpu_bam != nullptr ? 0 : gpu_bam_min_piece(), &bytes, &blocks, &segments, &err)) {
-			const double ms_plan = ms_since(t_plan);
+		const bool planned = src->device_plan(targets, gpu_bam != nullptr ? 0 : gpu_bam_min_piece(), &bytes, &blocks, &segments, &err);
+		const double ms_plan = ms_since(t_plan);
+		need_ctx();
+		if (planned) {
 			const auto t_open = now();
 			for (chrom_job *job : mine) {
 				std::vector<uint8_t> gc_hist_w, gc_like_w;
@@ -326,6 +336,7 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 		}
 		err.clear();
 	}
+	need_ctx();
 	for (size_t job_index = 0; job_index < mine.size(); job_index++) {
 		chrom_job *job = mine[job_index];
 		const bool on_gpu = !gpu_counts.empty(); // opened, equipped and filled above: only the progress text is left
@@ -509,6 +520,7 @@ int read_bam(parameters *params, sonic *this_sonic)
 			mine[(size_t) j.worker].push_back(&j); // annotation order within a worker
 	}
 
+	const double ms_select = ms_since(t_start) - ms_inputs;
 	const auto t_work = now();
 	std::vector<worker_timing> wt((size_t) n_workers);
 	const bool hold_lines = params->mq_threshold >= 0 || (!params->no_sr && params->have_dups);
@@ -565,8 +577,9 @@ int read_bam(parameters *params, sonic *this_sonic)
 	if (timing) {
 		if (n_workers == 1)
 			fprintf(stderr, "\n[timing] open + BED parsing %.1f ms, engine create %.1f ms, chromosome loop (annotation, read decode + "
-					"staging, intervals) %.1f ms, layout + compute %.1f ms, fetch + output %.1f ms, total %.1f ms\n", ms_inputs,
-					wt[0].ms_create, wt[0].ms_reads, wt[0].ms_compute, wt[0].ms_fetch + ms_output, ms_since(t_start));
+					"staging, intervals) %.1f ms, layout + compute %.1f ms, fetch + output %.1f ms, total %.1f ms (selection %.1f ms, worker "
+					"%.1f ms)\n", ms_inputs, wt[0].ms_create, wt[0].ms_reads, wt[0].ms_compute, wt[0].ms_fetch + ms_output, ms_since(t_start),
+					ms_select, ms_work);
 		else {
 			fprintf(stderr, "\n[timing] open + BED parsing %.1f ms, %d workers %.1f ms, output %.1f ms, total %.1f ms\n", ms_inputs,
 					n_workers, ms_work, ms_output, ms_since(t_start));

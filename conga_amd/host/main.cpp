@@ -6,8 +6,10 @@
 #include <ctime>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
+#include "../../include/conga_hip.h"
 #include "annotation.h"
 #include "bam_data.h"
 #include "cmdline.h"
@@ -82,6 +84,17 @@ int main(int argc, char **argv)
 		return EXIT_SUCCESS;
 	}
 
+	// Bringing the HIP runtime up is the better part of a tenth of a second and needs nothing from the inputs: it starts now,
+	// on a thread of its own, while the annotation, the BED files and the BAM index are read.  (exit() on an input error
+	// waits for it: leaving while the runtime initialises is not safe.)
+	if (!params.dump_reads) {
+		static std::thread warm;
+		warm = std::thread([] { (void) conga_device_count(); });
+		atexit([] {
+			if (warm.joinable())
+				warm.join();
+		});
+	}
 	std::string err;
 	std::unique_ptr<sonic> this_sonic(sonic_load(params.sonic_file, &err));
 	if (!this_sonic) {
