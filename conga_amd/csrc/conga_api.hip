@@ -138,7 +138,6 @@ struct conga_ctx {
 	// conga_reads_bgzf: the file's bytes go up through a ring of pinned pieces filled by host threads, inflate launches follow
 	uint8_t *h_bz_ring = nullptr;
 	hipEvent_t ev_bz_slot[12] = {};
-	std::thread bz_ring_maker; // allocates the ring in the background (CONGA_FLAG_EXPECT_BGZF)
 	bool bz_ring_failed = false;
 	hipStream_t bz_copy = nullptr, bz_kernel[3] = {};
 	hipEvent_t ev_bz_kernel[3] = {};
@@ -932,7 +931,8 @@ constexpr size_t kBzPiece = (size_t) 8 << 20;
 constexpr int kBzSlots = 12, kBzPiecesPerLaunch = 16;
 
 // the pinned ring, its events and the streams of the overlapped upload (96 MB of pinned memory take ~50 ms to get: with
-// CONGA_FLAG_EXPECT_BGZF conga_create() does this on a thread of its own while the caller is still reading its index)
+// CONGA_FLAG_EXPECT_BGZF conga_create() does this, and a caller that creates its context on a thread of its own -- the
+// conga executable does, while it reads the BAM's block table -- never waits for it)
 void make_bz_ring(conga_ctx *ctx)
 {
 	bool ok = hipSetDevice(ctx->device) == hipSuccess
@@ -956,8 +956,6 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const uint8_t *bytes, size_t n
 	auto ms_since = [](std::chrono::steady_clock::time_point t) {
 		return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
 	};
-	if (ctx->bz_ring_maker.joinable())
-		ctx->bz_ring_maker.join();
 	if (!ctx->h_bz_ring && !ctx->bz_ring_failed)
 		make_bz_ring(ctx);
 	if (ctx->bz_ring_failed || !ctx->h_bz_ring)
@@ -1231,7 +1229,7 @@ conga_ctx *conga_create(int device, const conga_opts *opts, int *status)
 		if (hipEventCreate(&ctx->ev_k0[k]) != hipSuccess || hipEventCreate(&ctx->ev_k1[k]) != hipSuccess)
 			return bail(CONGA_ERR_HIP);
 	if (ctx->opts.flags & CONGA_FLAG_EXPECT_BGZF)
-		ctx->bz_ring_maker = std::thread(make_bz_ring, ctx);
+		make_bz_ring(ctx); // (a failure shows when the ring is asked for)
 	*status = CONGA_OK;
 	return ctx;
 }
@@ -1240,8 +1238,6 @@ void conga_destroy(conga_ctx *ctx)
 {
 	if (!ctx)
 		return;
-	if (ctx->bz_ring_maker.joinable())
-		ctx->bz_ring_maker.join();
 	(void) hipSetDevice(ctx->device);
 	if (ctx->stream)
 		(void) hipStreamSynchronize(ctx->stream);

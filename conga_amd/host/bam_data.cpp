@@ -493,7 +493,8 @@ int read_bam(parameters *params, sonic *this_sonic)
 	// ---- chromosomes -> contexts: longest-processing-time-first on L + 2 * sum(interval length), the cost model of
 	// conga_amd/shard.py.  Worker k drives HIP device (--device + k) modulo the visible devices.
 	int n_workers = std::max(1, std::min(params->n_gpus, (int) std::max<size_t>(jobs.size(), 1)));
-	const int n_dev = conga_device_count();
+	// (with one worker nothing here needs the HIP runtime yet: it is still coming up on its own thread, main.cpp)
+	const int n_dev = n_workers > 1 ? conga_device_count() : 1;
 	if (n_workers > 1 && n_dev > 0 && n_dev < n_workers)
 		fprintf(stderr, "\n[CONGA] --gpus %d with %d visible HIP device(s): contexts share devices\n", n_workers, n_dev);
 	std::vector<std::vector<chrom_job *>> mine((size_t) n_workers);

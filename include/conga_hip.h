@@ -85,8 +85,8 @@ typedef enum conga_status {
                                           records on the device (conga_results_device / conga_results_copy: the
                                           multi-GPU gather over xGMI). */
 
-#define CONGA_FLAG_EXPECT_BGZF 0x20u   /* conga_reads_bgzf() will be called: conga_create() gets its pinned staging ring (96 MB)
-                                          on a thread of its own, so that the call does not wait for it */
+#define CONGA_FLAG_EXPECT_BGZF 0x20u   /* conga_reads_bgzf() will be called: conga_create() gets its pinned staging ring (96 MB,
+                                          ~50 ms) instead of the first such call */
 
 /* SV types, as the reference's DELETION / DUPLICATION (common.h:12-13) */
 #define CONGA_DELETION 'D'
