@@ -978,6 +978,7 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const uint8_t *bytes, size_t n
 	size_t issued = 0;       // pieces whose copy up has been enqueued (their slot's event is recorded)
 	bool failed = false;
 	std::atomic<size_t> next_piece{0};
+	std::atomic<long long> us_copy{0}, us_wait{0}; // (CONGA_TIMING: what the host threads spent copying and waiting for a free slot)
 	const int device = ctx->device;
 	auto worker = [&]() {
 		(void) hipSetDevice(device);
@@ -985,6 +986,7 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const uint8_t *bytes, size_t n
 			const size_t c = next_piece.fetch_add(1);
 			if (c >= n_pieces)
 				return;
+			const auto tw = std::chrono::steady_clock::now();
 			if (c >= (size_t) kBzSlots) { // the slot still holds piece c - kBzSlots until that one's copy up is done
 				{
 					std::unique_lock<std::mutex> lk(mu);
@@ -1000,7 +1002,10 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const uint8_t *bytes, size_t n
 				}
 			}
 			const size_t at = c * piece, len = std::min(piece, n_bytes - at);
+			const auto tc = std::chrono::steady_clock::now();
 			memcpy(ctx->h_bz_ring + (c % kBzSlots) * kBzPiece, bytes + at, len);
+			us_wait += (long long) std::chrono::duration<double, std::micro>(tc - tw).count();
+			us_copy += (long long) std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tc).count();
 			{
 				std::lock_guard<std::mutex> g(mu);
 				filled[c] = 1;
@@ -1057,7 +1062,7 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const uint8_t *bytes, size_t n
 				e = hipStreamWaitEvent(ks, ctx->ev_bz_slot[c % kBzSlots], 0);
 				if (e != hipSuccess)
 					rc = fail(ctx, CONGA_ERR_HIP, std::string("conga_reads_bgzf: ") + hipGetErrorString(e));
-				else
+				else if (!getenv("CONGA_BGZF_UPLOAD_ONLY")) // (measurement switch: the copy up alone; the call then fails its checks)
 					rc = launch_inflate(ctx, b1 - b_done, 0, ks, b_done);
 				launches++;
 				b_done = b1;
@@ -1072,8 +1077,9 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const uint8_t *bytes, size_t n
 	for (std::thread &t : threads)
 		t.join();
 	if (timing)
-		fprintf(stderr, "\n[timing] overlapped upload: pinned ring + streams %.1f ms, %zu pieces by %d threads enqueued after %.1f ms, %d inflate launches\n",
-				ms_ring, n_pieces, n_threads, ms_since(t0), launches);
+		fprintf(stderr, "\n[timing] overlapped upload: pinned ring + streams %.1f ms, %zu pieces by %d threads enqueued after %.1f ms (threads: %.1f ms "
+				"copying, %.1f ms waiting for a free slot, each), %d inflate launches\n", ms_ring, n_pieces, n_threads, ms_since(t0),
+				us_copy / 1e3 / n_threads, us_wait / 1e3 / n_threads, launches);
 	// ctx->stream goes on behind every launch (and the copy stream, for the case of no launch at all)
 	for (int k = 0; k < 3; k++) {
 		(void) hipEventRecord(ctx->ev_bz_kernel[k], ctx->bz_kernel[k]);

@@ -94,6 +94,13 @@ __device__ __forceinline__ uint32_t load_written_u32(const uint32_t *p)
 {
 	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// eight bytes at ANY address (global memory takes unaligned dword accesses), past the L1 like the loads above
+__device__ __forceinline__ uint64_t load_written_u64_unaligned(const uint8_t *p)
+{
+	uint64_t v;
+	asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+	return v;
+}
 
 // ---- the stream, read uniformly (block headers, code lengths) ---------------------------------------------------------
 // 64 consecutive dwords of the input live in one register across the wave; a field is two v_readlane and a funnel shift.
@@ -399,7 +406,39 @@ __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Lu
 		if (on_chain && is_lit)
 			s.out[opos + incl - 1u] = (uint8_t) val;
 		IW_LAP(P_LITS);
+		// Short matches whose source lies wholly in bytes known to be in L2 are copied by their own lanes, all at once: one
+		// 8-byte load each (any alignment), then the bytes stored as dword / short / byte pieces.  At zlib's fast levels these
+		// are most matches (3..8 bytes, found by hash anywhere in the 32 KB behind).
 		unsigned long long mm = match_m;
+		{
+			const uint32_t to_l = opos + incl - produced, src_l = to_l - dist;
+			const bool fast = on_chain && is_match && produced <= 8u && dist >= produced && dist <= to_l && src_l + produced <= safe_pos;
+			const unsigned long long fast_m = __ballot(fast);
+			if (fast_m) {
+				if (fast) {
+					const uint64_t v8 = load_written_u64_unaligned(s.out + src_l);
+					uint8_t *q = s.out + to_l;
+					uint32_t done = 0;
+					if (produced >= 4u) {
+						*reinterpret_cast<uint32_t *>(q) = (uint32_t) v8; // (unaligned dword stores are fine in global memory)
+						done = 4;
+					}
+					if (produced == 8u) {
+						*reinterpret_cast<uint32_t *>(q + 4) = (uint32_t) (v8 >> 32);
+						done = 8;
+					}
+					if ((produced - done) & 2u) {
+						*reinterpret_cast<uint16_t *>(q + done) = (uint16_t) (v8 >> (8u * done));
+						done += 2;
+					}
+					if ((produced - done) & 1u)
+						q[done] = (uint8_t) (v8 >> (8u * done));
+				}
+				IW_ADD(P_MATCHES, (uint32_t) __popcll(fast_m));
+				mm &= ~fast_m;
+			}
+		}
+		IW_LAP(P_MATCH_COPY);
 		while (mm) {
 			const uint32_t i = (uint32_t) __builtin_ctzll(mm);
 			mm &= mm - 1ull;
