@@ -1535,7 +1535,10 @@ int conga_sample_reads(conga_ctx *ctx, const int32_t *pos, const uint8_t *mapq, 
 	if (n_chrom != (int) ctx->slots.size())
 		return fail(ctx, CONGA_ERR_INVALID, "conga_sample_reads: n_chrom differs from the chromosomes the context holds");
 	const uint64_t total = chrom_off[n_chrom];
-	if (chrom_off[0] != 0 || (total && (!pos || !mapq)))
+	// With the default threshold (-1: cmdline.c:188-194) every read passes `qual > mq_threshold` (bam_data.c:205) whatever its
+	// MAPQ: the bytes are never looked at, so they are not sent either (4 bytes per read over PCIe instead of 5) and may be NULL.
+	const bool need_mapq = ctx->opts.mq_threshold >= 0;
+	if (chrom_off[0] != 0 || (total && (!pos || (need_mapq && !mapq))))
 		return fail(ctx, CONGA_ERR_INVALID, "conga_sample_reads: chrom_off must start at 0 and the arrays must be given");
 	for (int c = 0; c < n_chrom; c++)
 		if (chrom_off[c + 1] < chrom_off[c])
@@ -1554,7 +1557,8 @@ int conga_sample_reads(conga_ctx *ctx, const int32_t *pos, const uint8_t *mapq, 
 		// Straight from the caller's arrays: from pinned memory (conga_host_alloc) this is one DMA each at the link's
 		// rate, ordered on the context's stream behind whatever still reads the previous sample's tuples.
 		HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pos.p, pos, (size_t) total * 4, hipMemcpyHostToDevice, ctx->stream));
-		HIP_TRY(ctx, hipMemcpyAsync(ctx->d_mapq.p, mapq, (size_t) total, hipMemcpyHostToDevice, ctx->stream));
+		if (need_mapq)
+			HIP_TRY(ctx, hipMemcpyAsync(ctx->d_mapq.p, mapq, (size_t) total, hipMemcpyHostToDevice, ctx->stream));
 	}
 	for (int c = 0; c < n_chrom; c++)
 		ctx->slots[(size_t) c].n_reads = (int64_t) (chrom_off[c + 1] - chrom_off[c]);
