@@ -159,9 +159,10 @@ def depth_kernel_bytes(units):
 
 
 def tuple_kernel_bytes(units, j=0):
-    """Algorithmic bytes of one ingest_tuples launch over these chromosomes: every tuple read
-    once (int32 pos + uint8 mapq) and each GC byte at most once."""
-    return sum(5 * len(u["reads"][j][0]) + (u["length"] + 99) // 100 for u in units)
+    """Algorithmic bytes of one ingest_tuples launch over these chromosomes: every position read
+    once (int32; the MAPQ bytes are not read with the default threshold, under which every read counts) and each GC byte
+    at most once."""
+    return sum(4 * len(u["reads"][j][0]) + (u["length"] + 99) // 100 for u in units)
 
 
 def dense_reference_bytes(u, with_map):

@@ -288,14 +288,19 @@ __device__ __forceinline__ TupleRegs load_tuples(const TupleArgs &a, uint32_t ch
 	const uint32_t i0 = chunk * (uint32_t) kTupleChunk + threadIdx.x * 4;
 	if (chunk >= n_chunks || i0 >= a.n_total)
 		return r;
+	// (with a threshold below 0 every MAPQ passes `qual > mq_threshold`, bam_data.c:205: the bytes are not read -- they may not
+	// even have been sent, conga_sample_reads)
+	const bool want_mq = a.mq_threshold >= 0;
 	if (i0 + 4 <= a.n_total) {
 		r.q = *reinterpret_cast<const int4 *>(a.pos + i0);
-		r.mq = *reinterpret_cast<const uint32_t *>(a.mapq + i0);
+		if (want_mq)
+			r.mq = *reinterpret_cast<const uint32_t *>(a.mapq + i0);
 	} else { // the lane that holds the ragged end of the batch: element by element, zeros behind the last tuple
 		int32_t t[4] = {0, 0, 0, 0};
 		for (uint32_t e = 0; i0 + e < a.n_total; e++) {
 			t[e] = a.pos[i0 + e];
-			r.mq |= (uint32_t) a.mapq[i0 + e] << (8 * e);
+			if (want_mq)
+				r.mq |= (uint32_t) a.mapq[i0 + e] << (8 * e);
 		}
 		r.q = make_int4(t[0], t[1], t[2], t[3]);
 	}
