@@ -312,10 +312,10 @@ class Context:
     def sample_reads(self, pos, mapq, chrom_off):
         """Replaces the reads of every chromosome; pos / mapq / chrom_off are passed as they are (no copy: the caller
         keeps them alive and unchanged until the next fetch / sync).  Pinned arrays (host_alloc) go at PCIe rate."""
-        if pos.dtype != np.int32 or mapq.dtype != np.uint8 or chrom_off.dtype != np.uint64:
-            raise TypeError("sample_reads takes int32 pos, uint8 mapq, uint64 chrom_off")
-        self._check(self._lib.conga_sample_reads(self._h, pos.ctypes.data, mapq.ctypes.data, chrom_off.ctypes.data,
-                                                 len(chrom_off) - 1))
+        if pos.dtype != np.int32 or (mapq is not None and mapq.dtype != np.uint8) or chrom_off.dtype != np.uint64:
+            raise TypeError("sample_reads takes int32 pos, uint8 mapq (or None when mq_threshold < 0), uint64 chrom_off")
+        self._check(self._lib.conga_sample_reads(self._h, pos.ctypes.data, None if mapq is None else mapq.ctypes.data,
+                                                 chrom_off.ctypes.data, len(chrom_off) - 1))
 
     def sample_begin(self):
         self._check(self._lib.conga_sample_begin(self._h))

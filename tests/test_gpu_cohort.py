@@ -117,6 +117,26 @@ def test_samples_behind_one_layout(capi, oracle, with_map):
             assert d1.tobytes() + u1.tobytes() == recs[a:a + len(d1) + len(u1)].tobytes()
 
 
+def test_mapq_may_stay_at_home_under_the_default_threshold(capi, oracle):
+    """`qual > -1` holds for every read (bam_data.c:205, cmdline.c:188-194): conga_sample_reads takes mapq = NULL then and sends
+    4 bytes per read; with a real threshold the bytes are required."""
+    chroms = layout(False)
+    reads = sample_reads_of(chroms, 21, 1.5)
+    with capi.Context(device=0, flags=capi.FLAG_BATCH) as ctx:
+        open_layout(ctx, chroms, False)
+        pos, _mapq, off = pinned_sample(ctx, reads)
+        ctx.sample_reads(pos, None, off)
+        ctx.compute()
+        recs, E, st = ctx.sample_fetch(want_stats=True)
+        check_against_oracle(oracle, chroms, reads, recs, E, False)
+        assert [int(x.reads_counted) for x in st] == [len(p) for p, _ in reads]
+    with capi.Context(device=0, flags=capi.FLAG_BATCH, mq_threshold=0) as ctx:
+        open_layout(ctx, chroms, False)
+        pos, _mapq, off = pinned_sample(ctx, reads)
+        with pytest.raises(capi.CongaError):
+            ctx.sample_reads(pos, None, off)
+
+
 def test_sample_through_the_staging_ring(capi, oracle):
     """conga_sample_begin + conga_sample_chrom: the decoder's route (one chromosome after the other through
     conga_reads_staging / conga_reads_commit), with a MAPQ threshold."""
