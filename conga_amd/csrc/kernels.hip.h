@@ -2222,18 +2222,31 @@ struct SplitArgs {
 	unsigned long long *counters;
 };
 
-// sonic_is_satellite(chr, a, b): any satellite interval overlapping [a, b)
+// sonic_is_satellite(chr, a, b): any satellite interval overlapping [a, b).  The intervals are sorted and disjoint
+// (conga_satellites merges them), the question is the same in every lane of the wave: a 64-ary search -- every lane looks at
+// one pivot per round, one trip to memory per round instead of one per halving (a chromosome's few dozen to few thousand
+// satellites: one or two rounds instead of five to twelve dependent loads; the path asks up to five times per read).
 __device__ __forceinline__ int is_satellite_dev(const SplitArgs &a, int64_t lo_, int64_t hi_)
 {
-	int lo = 0, hi = a.n_sat;
-	while (lo < hi) { // first interval with end > lo_
-		const int mid = (lo + hi) >> 1;
-		if ((int64_t) a.sat_end[mid] <= lo_)
-			lo = mid + 1;
-		else
-			hi = mid;
+	const int lane = threadIdx.x & (kWave - 1);
+	int lo = 0, hi = a.n_sat; // the first interval with end > lo_ lies in [lo, hi] (hi: none)
+	while (hi - lo > kWave) {
+		const int stride = (hi - lo + kWave - 1) / kWave;
+		const int last = min(lo + (lane + 1) * stride, hi) - 1; // last interval of this lane's run [lo + lane * stride, ...)
+		const bool behind = lo + lane * stride < hi && (int64_t) a.sat_end[last] <= lo_; // the whole run ends at or before lo_
+		const int k = (int) __popcll(__ballot(behind)); // ends ascend: the runs that lie behind are the first k
+		const int nlo = min(lo + k * stride, hi);
+		hi = min(nlo + stride, hi);
+		lo = nlo;
 	}
-	return (lo < a.n_sat && (int64_t) a.sat_start[lo] < hi_) ? 1 : 0;
+	const int i = lo + lane;
+	const bool in = i < hi;
+	const int32_t e = in ? a.sat_end[i] : 0, st = in ? a.sat_start[i] : 0;
+	const unsigned long long m = __ballot(in && (int64_t) e > lo_);
+	if (!m) // (none in this run: the next run's first interval, if any, starts even further right -- but it may still start below hi_)
+		return (hi < a.n_sat && (int64_t) a.sat_start[hi] < hi_) ? 1 : 0;
+	const int j = (int) __builtin_ctzll(m);
+	return (int64_t) __builtin_amdgcn_readlane(st, j) < hi_ ? 1 : 0;
 }
 
 // almostPerfect_match_seq_ref for one orientation (split_read.c:116-129 / 164-180): scan the seed's bucket, keep hits
