@@ -249,11 +249,32 @@ void attach_intervals(conga_ctx *ctx, const parameters *params, const bed_index 
 	}
 }
 
+// An engine context that outlives one input (read_bam_cohort): what it holds, so that the next sample can tell whether the
+// layout is the same (then only the reads are replaced) or has to be handed over again.
+struct kept_engine {
+	conga_ctx *ctx = nullptr;
+	std::string layout_key;
+};
+
+std::string layout_key_of(const std::vector<chrom_job *> &mine)
+{
+	std::string key;
+	for (const chrom_job *j : mine) {
+		key += j->cs.chr_name + ":" + std::to_string(j->L) + ":" + std::to_string(j->cs.dels.size()) + ":" + std::to_string(j->cs.dups.size());
+		if (!j->cs.dels.empty())
+			key += ":" + std::to_string(j->cs.dels.front().start) + "-" + std::to_string(j->cs.dels.back().end);
+		if (!j->cs.dups.empty())
+			key += ":" + std::to_string(j->cs.dups.front().start) + "-" + std::to_string(j->cs.dups.back().end);
+		key += ";";
+	}
+	return key;
+}
+
 // The work of one context: stage every chromosome of `mine` (annotation order), one batch compute, fetch.
 // One host thread per context, one context per GPU; chromosomes are independent in the
 // reference (bam_data.c:269-339), so no worker ever needs another's data.
 void run_worker(const parameters *params, const sonic *this_sonic, read_source *src, int device, bool buffered,
-		const bed_index &map_bed, std::vector<chrom_job *> &mine, bool announce_compute, worker_timing *wt)
+		const bed_index &map_bed, std::vector<chrom_job *> &mine, bool announce_compute, worker_timing *wt, kept_engine *keep = nullptr)
 {
 	auto now = [] { return std::chrono::steady_clock::now(); };
 	auto ms_since = [&](std::chrono::steady_clock::time_point t) {
@@ -280,8 +301,14 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 	// The engine context (HIP runtime, streams, the staging ring) is made on a thread of its own while this one reads the
 	// BAM's block table: neither needs the other.
 	int status = 0;
-	conga_ctx *ctx = nullptr;
-	std::thread creator([&] { ctx = conga_create(device, &opts, &status); });
+	conga_ctx *ctx = keep ? keep->ctx : nullptr;
+	// a kept context whose chromosomes, intervals and tracks are the ones this sample needs: only the reads change
+	bool same_layout = ctx != nullptr && !split_reads && !mine.empty() && keep->layout_key == layout_key_of(mine);
+	if (ctx != nullptr && !same_layout)
+		engine_check(ctx, conga_reset(ctx), "conga_reset");
+	std::thread creator;
+	if (!ctx)
+		creator = std::thread([&] { ctx = conga_create(device, &opts, &status); });
 	auto need_ctx = [&]() {
 		if (!creator.joinable())
 			return;
@@ -313,13 +340,16 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 		need_ctx();
 		if (planned) {
 			const auto t_open = now();
-			for (chrom_job *job : mine) {
-				std::vector<uint8_t> gc_hist_w, gc_like_w;
-				gc_window_arrays(this_sonic, job->chr_index, &gc_hist_w, &gc_like_w);
-				engine_check(ctx, conga_chrom_begin(ctx, job->L, gc_hist_w.data(), gc_like_w.data(), (int64_t) gc_hist_w.size()),
-						"conga_chrom_begin");
-				attach_intervals(ctx, params, map_bed, job->cs);
-			}
+			if (same_layout)
+				engine_check(ctx, conga_sample_begin(ctx), "conga_sample_begin"); // the layout stays, the reads go
+			else
+				for (chrom_job *job : mine) {
+					std::vector<uint8_t> gc_hist_w, gc_like_w;
+					gc_window_arrays(this_sonic, job->chr_index, &gc_hist_w, &gc_like_w);
+					engine_check(ctx, conga_chrom_begin(ctx, job->L, gc_hist_w.data(), gc_like_w.data(), (int64_t) gc_hist_w.size()),
+							"conga_chrom_begin");
+					attach_intervals(ctx, params, map_bed, job->cs);
+				}
 			gpu_counts.assign(mine.size(), 0);
 			if (getenv("CONGA_TIMING"))
 				fprintf(stderr, "\n[timing] block table + start points %.1f ms, chromosomes opened (GC tracks, intervals, tracks) %.1f ms\n",
@@ -332,11 +362,14 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 				fprintf(stderr, "\n[CONGA] decoding on the host: %s\n", conga_last_error(ctx));
 				gpu_counts.clear();
 				engine_check(ctx, conga_reset(ctx), "conga_reset");
+				same_layout = false;
 			}
 		}
 		err.clear();
 	}
 	need_ctx();
+	if (same_layout && gpu_counts.empty())
+		engine_check(ctx, conga_sample_begin(ctx), "conga_sample_begin"); // (host decoders: the staging ring, chromosome by chromosome)
 	for (size_t job_index = 0; job_index < mine.size(); job_index++) {
 		chrom_job *job = mine[job_index];
 		const bool on_gpu = !gpu_counts.empty(); // opened, equipped and filled above: only the progress text is left
@@ -351,7 +384,9 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 		out.say("\n");
 		out.say("Reading BAM [%s] - Chromosome: %s", src->sample_name().c_str(), src->target_name(job->chr_index_bam).c_str());
 
-		if (!on_gpu) {
+		if (!on_gpu && same_layout)
+			engine_check(ctx, conga_sample_chrom(ctx, (int) job_index), "conga_sample_chrom");
+		else if (!on_gpu) {
 			// init_rd_per_chr + the GC side of calc_mean_per_chr (read_distribution.c:12-18,63-73)
 			std::vector<uint8_t> gc_hist_w, gc_like_w;
 			gc_window_arrays(this_sonic, job->chr_index, &gc_hist_w, &gc_like_w);
@@ -382,7 +417,7 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 				cs.chr_name.c_str(), params->min_sv_size);
 		if (params->have_map && cs.dels.size() + cs.dups.size() > 0)
 			out.say("Finding mappability for each region\n");
-		if (!on_gpu)
+		if (!on_gpu && !same_layout)
 			attach_intervals(ctx, params, map_bed, cs);
 		job->staged = true;
 	}
@@ -410,13 +445,77 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 	// Everything is fetched.  The process is about to end, and giving gigabytes of device and pinned memory back one
 	// allocation at a time is a quarter of a second the operating system does for nothing: the context is left to it
 	// (CONGA_CLEAN_EXIT=1: tear down in order, for leak checkers).
-	if (getenv("CONGA_CLEAN_EXIT") != nullptr)
+	if (keep) {
+		keep->ctx = ctx; // (the next sample's)
+		keep->layout_key = split_reads ? std::string() : layout_key_of(mine);
+	} else if (getenv("CONGA_CLEAN_EXIT") != nullptr)
 		conga_destroy(ctx);
 }
+
+int read_bam_with(parameters *params, sonic *this_sonic, kept_engine *keep);
 
 } // namespace
 
 int read_bam(parameters *params, sonic *this_sonic)
+{
+	return read_bam_with(params, this_sonic, nullptr);
+}
+
+int read_bam_cohort(parameters *params, sonic *this_sonic)
+{
+	// the list: one BAM per line, optionally a tab (or blanks) and the sample's output prefix; '#' starts a comment
+	std::vector<std::pair<std::string, std::string>> samples;
+	{
+		FILE *f = fopen(params->cohort_file.c_str(), "r");
+		if (!f)
+			print_error("[CONGA INPUT ERROR] Unable to open file " + params->cohort_file + " in read mode.");
+		char line[8192];
+		while (fgets(line, sizeof line, f)) {
+			char *save = nullptr;
+			const char *bam = strtok_r(line, " \t\r\n", &save);
+			if (!bam || bam[0] == '#')
+				continue;
+			const char *prefix = strtok_r(nullptr, " \t\r\n", &save);
+			std::string out;
+			if (prefix)
+				out = prefix;
+			else { // <--out>.<file name without directory and .bam>
+				std::string stem = bam;
+				const size_t slash = stem.rfind('/');
+				if (slash != std::string::npos)
+					stem.erase(0, slash + 1);
+				if (stem.size() > 4 && stem.compare(stem.size() - 4, 4, ".bam") == 0)
+					stem.erase(stem.size() - 4);
+				out = params->outdir + params->outprefix + "." + stem;
+			}
+			samples.emplace_back(bam, out);
+		}
+		fclose(f);
+	}
+	if (samples.empty())
+		print_error("[CONGA INPUT ERROR] " + params->cohort_file + " names no BAM file.");
+	kept_engine keep;
+	const std::string outdir = params->outdir, outprefix = params->outprefix;
+	for (size_t k = 0; k < samples.size(); k++) {
+		params->bam_file = samples[k].first;
+		params->outdir.clear(); // (a prefix from the list is taken as it is; the default one already carries --out's directory)
+		params->outprefix = samples[k].second;
+		fprintf(stderr, "\n[CONGA] sample %zu of %zu: %s\n", k + 1, samples.size(), params->bam_file.c_str());
+		// several contexts (--gpus N) are made per sample; one context is kept from sample to sample
+		const int rc = read_bam_with(params, this_sonic, params->n_gpus == 1 ? &keep : nullptr);
+		if (rc != 0)
+			return rc;
+	}
+	params->outdir = outdir;
+	params->outprefix = outprefix;
+	if (keep.ctx && getenv("CONGA_CLEAN_EXIT") != nullptr)
+		conga_destroy(keep.ctx);
+	return 0;
+}
+
+namespace {
+
+int read_bam_with(parameters *params, sonic *this_sonic, kept_engine *keep)
 {
 	FILE *fpDel = nullptr, *fpDup = nullptr, *fpSVs = nullptr;
 
@@ -537,7 +636,7 @@ int read_bam(parameters *params, sonic *this_sonic)
 			fprintf(stderr, "\nCalculating Likelihoods\n");
 	};
 	if (n_workers == 1) {
-		run_worker(params, this_sonic, src.get(), params->device, hold_lines, map_bed, mine[0], !hold_lines, &wt[0]);
+		run_worker(params, this_sonic, src.get(), params->device, hold_lines, map_bed, mine[0], !hold_lines, &wt[0], keep);
 		if (hold_lines)
 			print_held_lines();
 	} else {
@@ -599,5 +698,7 @@ int read_bam(parameters *params, sonic *this_sonic)
 	fclose(fpSVs);
 	return 0;
 }
+
+} // namespace
 
 } // namespace conga_host

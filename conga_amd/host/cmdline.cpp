@@ -23,7 +23,7 @@
 namespace conga_host {
 
 namespace {
-enum { OPT_FIRST_CHROM = 10001, OPT_LAST_CHROM = 10002, OPT_DEVICE = 10003, OPT_DUMP = 10004, OPT_DUMP_READS = 10005, OPT_DUMP_MAP = 10006, OPT_GPUS = 10007 };
+enum { OPT_FIRST_CHROM = 10001, OPT_LAST_CHROM = 10002, OPT_DEVICE = 10003, OPT_DUMP = 10004, OPT_DUMP_READS = 10005, OPT_DUMP_MAP = 10006, OPT_GPUS = 10007, OPT_COHORT = 10008 };
 }
 
 void print_help(void)
@@ -93,6 +93,7 @@ int parse_cmd_line(int argc, char **argv, parameters *params)
 		{"device", required_argument, 0, OPT_DEVICE},
 		{"gpus", required_argument, 0, OPT_GPUS},
 		{"dump-intervals", required_argument, 0, OPT_DUMP},
+		{"cohort", required_argument, 0, OPT_COHORT},
 		{"dump-reads", no_argument, 0, OPT_DUMP_READS},
 		{"dump-mappability", required_argument, 0, OPT_DUMP_MAP},
 		{0, 0, 0, 0}};
@@ -132,6 +133,7 @@ int parse_cmd_line(int argc, char **argv, parameters *params)
 		case OPT_LAST_CHROM: params->last_chrom = atoi(optarg); break;
 		case OPT_DEVICE: params->device = atoi(optarg); break;
 		case OPT_GPUS: params->n_gpus = std::max(1, atoi(optarg)); break;
+		case OPT_COHORT: params->cohort_file = optarg; break;
 		case OPT_DUMP: params->dump_intervals_chr = optarg; break;
 		case OPT_DUMP_READS: params->dump_reads = true; break;
 		case OPT_DUMP_MAP: params->dump_mappability_chr = optarg; break;

@@ -164,7 +164,7 @@ int main(int argc, char **argv)
 		return EXIT_SUCCESS;
 	}
 
-	const int rc = read_bam(&params, this_sonic.get());
+	const int rc = params.cohort_file.empty() ? read_bam(&params, this_sonic.get()) : read_bam_cohort(&params, this_sonic.get());
 	if (rc != 0)
 		return rc;
 

@@ -35,6 +35,9 @@ struct parameters {
 	int n_gpus = 1;                  // --gpus N : N contexts (one host thread + one HIP device each), chromosomes sharded longest-first
 	std::string dump_intervals_chr;  // --dump-intervals CHR : print the kept, sorted SV rows and exit (no GPU)
 	std::string dump_mappability_chr; // --dump-mappability CHR : print the parsed mappability rows of CHR and exit (no GPU)
+	std::string cohort_file;         // --cohort FILE : one BAM per line (optionally: tab, output prefix); every sample is genotyped
+	                                 // in this one process against the same call set -- the engine context, its device layout
+	                                 // and the HIP runtime are kept from sample to sample (cohort mode of include/conga_hip.h)
 	bool dump_reads = false;         // --dump-reads : per chromosome, count and checksums of the records the BAM loop would count (no GPU)
 };
 

@@ -547,3 +547,48 @@ def test_fast_bed_parser_equals_the_literal_fgets_strtok_reader(tmp_path, oracle
     # and the interval side agrees with the oracle's reader too
     svs = oracle.sort_svs(oracle.load_known_SVs(os.path.join(d, "m.bed"), "1", 1000))
     assert outs[("0", "m.bed", "1", "iv")] == ["DEL\t1\t%d\t%d" % (s, e) for s, e in zip(svs["start"], svs["end"])]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("decode", ["gpu", "host"])
+def test_cli_cohort_keeps_the_engine_and_every_byte(tmp_path, decode):
+    """`--cohort list` (an extension: the reference is started once per sample, svdepth.c:16-74): several BAMs in one process,
+    the engine context kept from sample to sample -- the layout too when the samples select the same chromosomes
+    (conga_sample_begin), handed over again when they do not.  Every sample's three files are those of its own run."""
+    d = str(tmp_path)
+    specs = [("1", 500_000, 30, 8), ("2", 300_000, 20, 5), ("3", 200_000, 12, 3)]
+    cs = [synth.make_chrom(n, L, cov=1.0, n_dels=nd, n_dups=nu, mappability=True, gaps=False) for n, L, nd, nu in specs]
+    formats.write_annotation(os.path.join(d, "a.cga"), [(c.name, c.length, c.gc, [], []) for c in cs])
+    synth.write_bed(os.path.join(d, "dels.bed"), [(c.name, s, e) for c in cs for s, e in zip(c.del_start, c.del_end)])
+    synth.write_bed(os.path.join(d, "dups.bed"), [(c.name, s, e) for c in cs for s, e in zip(c.dup_start, c.dup_end)])
+    synth.write_bed(os.path.join(d, "map.bed"), [(c.name, s, e, "%g" % v) for c in cs for s, e, v in zip(c.map_start, c.map_end, c.map_val)])
+    samples = []
+    for k, (cov, drop) in enumerate([(1.0, None), (3.0, None), (0.5, "2"), (2.0, None)]):  # the third sample lacks chromosome 2
+        chroms = []
+        for ci, c in enumerate(cs):
+            if c.name == drop:
+                continue
+            rng = np.random.default_rng([k, ci, 5])
+            pos, mapq = synth.make_reads(c.length, c.gc, c.step, cov, 100, rng)
+            chroms.append((c.name, c.length, pos, mapq))
+        formats.write_bam(os.path.join(d, "s%d.bam" % k), "S%d" % k, chroms, index=True, block_payload=20_000, unplaced=2)
+        samples.append("s%d.bam" % k)
+    with open(os.path.join(d, "list.txt"), "w") as f:
+        f.write("# BAM [prefix]\n%s\n%s\tnamed/two\n\n%s\n%s\n" % tuple(samples))
+    os.mkdir(os.path.join(d, "named"))
+    common = ["--ref", "r.fa", "--sonic", "a.cga", "--dels", "dels.bed", "--dups", "dups.bed", "--mappability", "map.bed"]
+    env = dict(os.environ, CONGA_GPU_BAM="1" if decode == "gpu" else "0", CONGA_TIMING="1")
+    r = subprocess.run([CONGA, "--cohort", "list.txt", "--out", "co"] + common, cwd=d, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    if decode == "gpu":
+        assert r.stderr.count("conga_reads_bgzf:") == 4 and "decoding on the host" not in r.stderr
+    prefixes = ["co.s0", "named/two", "co.s2", "co.s3"]
+    for k, bam in enumerate(samples):
+        one = subprocess.run([CONGA, "-i", bam, "--out", "one%d" % k] + common, cwd=d, capture_output=True, text=True, timeout=600, env=env)
+        assert one.returncode == 0, one.stderr[-2000:]
+        for kind in ("svs", "dels", "dups"):
+            got = open(os.path.join(d, "%s_%s.bed" % (prefixes[k], kind)), "rb").read()
+            want = open(os.path.join(d, "one%d_%s.bed" % (k, kind)), "rb").read()
+            assert got == want and got.count(b"\n") > 5, (k, kind)
+    # the samples differ (it is not one sample's files four times)
+    assert open(os.path.join(d, "co.s0_dels.bed"), "rb").read() != open(os.path.join(d, "co.s3_dels.bed"), "rb").read()
