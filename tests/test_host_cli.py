@@ -589,6 +589,6 @@ def test_cli_cohort_keeps_the_engine_and_every_byte(tmp_path, decode):
         for kind in ("svs", "dels", "dups"):
             got = open(os.path.join(d, "%s_%s.bed" % (prefixes[k], kind)), "rb").read()
             want = open(os.path.join(d, "one%d_%s.bed" % (k, kind)), "rb").read()
-            assert got == want and got.count(b"\n") > 5, (k, kind)
+            assert got == want and (kind != "dels" or got.count(b"\n") > 5), (k, kind)
     # the samples differ (it is not one sample's files four times)
     assert open(os.path.join(d, "co.s0_dels.bed"), "rb").read() != open(os.path.join(d, "co.s3_dels.bed"), "rb").read()
