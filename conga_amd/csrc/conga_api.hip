@@ -1212,8 +1212,9 @@ conga_ctx *conga_create(int device, const conga_opts *opts, int *status)
 		// the tuple pass hands each workgroup a contiguous run of chunks and sizes the grid to one resident wave of
 		// workgroups: a workgroup that had to wait for a free slot would double the launch time
 		int occ = 8;
-		for (const void *k : {(const void *) ingest_tuples_kernel, (const void *) tuple_pass_kernel<false>,
-				(const void *) tuple_pass_kernel<true>}) {
+		for (const void *k : {(const void *) ingest_tuples_kernel<false>, (const void *) ingest_tuples_kernel<true>,
+				(const void *) tuple_pass_kernel<false, false>, (const void *) tuple_pass_kernel<true, false>,
+				(const void *) tuple_pass_kernel<false, true>, (const void *) tuple_pass_kernel<true, true>}) {
 			int n = 0;
 			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, kTupleBlock, 0) == hipSuccess && n > 0)
 				occ = std::min(occ, n);
@@ -2165,12 +2166,19 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 			const int grid = (int) ((a.n_chunks + a.chunks_per_block - 1) / a.chunks_per_block);
 			if (fuse && (want_count || want_rows)) {
 				const int cb = want_count ? count_grid : 0, mb = want_rows ? map_grid : 0;
-				if (mb)
-					hipLaunchKernelGGL(tuple_pass_kernel<true>, dim3(grid + cb + mb), dim3(kTupleBlock), 0, st, a, c, cb, mr, mb, grid);
+				const bool all = a.mq_threshold < 0; // every read counts: the variant that never looks at the MAPQ bytes
+				if (mb && all)
+					hipLaunchKernelGGL((tuple_pass_kernel<true, true>), dim3(grid + cb + mb), dim3(kTupleBlock), 0, st, a, c, cb, mr, mb, grid);
+				else if (mb)
+					hipLaunchKernelGGL((tuple_pass_kernel<true, false>), dim3(grid + cb + mb), dim3(kTupleBlock), 0, st, a, c, cb, mr, mb, grid);
+				else if (all)
+					hipLaunchKernelGGL((tuple_pass_kernel<false, true>), dim3(grid + cb), dim3(kTupleBlock), 0, st, a, c, cb, mr, 0, grid);
 				else
-					hipLaunchKernelGGL(tuple_pass_kernel<false>, dim3(grid + cb), dim3(kTupleBlock), 0, st, a, c, cb, mr, 0, grid);
-			} else
-				hipLaunchKernelGGL(ingest_tuples_kernel, dim3(grid), dim3(kTupleBlock), 0, st, a);
+					hipLaunchKernelGGL((tuple_pass_kernel<false, false>), dim3(grid + cb), dim3(kTupleBlock), 0, st, a, c, cb, mr, 0, grid);
+			} else if (a.mq_threshold < 0)
+				hipLaunchKernelGGL(ingest_tuples_kernel<true>, dim3(grid), dim3(kTupleBlock), 0, st, a);
+			else
+				hipLaunchKernelGGL(ingest_tuples_kernel<false>, dim3(grid), dim3(kTupleBlock), 0, st, a);
 		}
 	} else if (!unsorted_mode) {
 		TRY(launch_dense_depth(ctx, small, true));

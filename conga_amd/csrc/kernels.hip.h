@@ -279,7 +279,8 @@ struct TupleRegs { // one chunk's share of a lane: four tuples and, for lane 0 o
 	int32_t pv;
 };
 
-__device__ __forceinline__ TupleRegs load_tuples(const TupleArgs &a, uint32_t chunk, uint32_t n_chunks)
+// ALL: the threshold is below 0, every read counts (cmdline.c:188-194): the MAPQ bytes are neither read nor tested.
+template <bool ALL> __device__ __forceinline__ TupleRegs load_tuples(const TupleArgs &a, uint32_t chunk, uint32_t n_chunks)
 {
 	TupleRegs r;
 	r.q = make_int4(0, 0, 0, 0);
@@ -290,7 +291,7 @@ __device__ __forceinline__ TupleRegs load_tuples(const TupleArgs &a, uint32_t ch
 		return r;
 	// (with a threshold below 0 every MAPQ passes `qual > mq_threshold`, bam_data.c:205: the bytes are not read -- they may not
 	// even have been sent, conga_sample_reads)
-	const bool want_mq = a.mq_threshold >= 0;
+	constexpr bool want_mq = !ALL;
 	if (i0 + 4 <= a.n_total) {
 		r.q = *reinterpret_cast<const int4 *>(a.pos + i0);
 		if (want_mq)
@@ -320,7 +321,7 @@ struct GcRegs { // stage 1 -> stage 2 of a chunk: the GC bins of a lane's four t
 
 // Stage 1: checks, read filter, window index, and the four GC-byte loads -- issued, not waited for.
 // MASKED: only the tuples with index in [lo, hi) belong to chromosome `home` (a chunk that straddles two).
-template <bool MASKED> __device__ __forceinline__ GcRegs ingest_chunk_inside(const TupleArgs &a, const TupleSlot &sl, int home,
+template <bool MASKED, bool ALL> __device__ __forceinline__ GcRegs ingest_chunk_inside(const TupleArgs &a, const TupleSlot &sl, int home,
 		uint32_t base, const TupleRegs &r, float inv_step, int &kept, uint32_t lo = 0, uint32_t hi = 0)
 {
 	const int lane = threadIdx.x & (kWave - 1);
@@ -360,7 +361,7 @@ template <bool MASKED> __device__ __forceinline__ GcRegs ingest_chunk_inside(con
 	out.kmask = 0;
 #pragma unroll
 	for (int e = 0; e < 4; e++) {
-		const bool k = in[e] && (int) ((r.mq >> (8 * e)) & 0xFFu) > a.mq_threshold;
+		const bool k = ALL ? in[e] : in[e] && (int) ((r.mq >> (8 * e)) & 0xFFu) > a.mq_threshold;
 		// the usual 100-base window: one multiply-high (p < 2^31: floor(p / 100) = (p * 0x51EB851F) >> 37)
 		const uint32_t q = (step == 100u) ? (__umulhi((uint32_t) p[e], 0x51EB851Fu) >> 5)
 				: (step == 1u) ? (uint32_t) p[e] : div_tile((uint32_t) p[e], step, inv_step);
@@ -384,13 +385,13 @@ __device__ __forceinline__ void ingest_chunk_count(const GcRegs &r, uint32_t *my
 			atomicAdd(&my_hist[r.g[e]], 1u);
 }
 
-__device__ __forceinline__ void ingest_tuples_body(const TupleArgs &a, uint32_t block, uint32_t *hist, uint32_t &kept_block)
+template <bool ALL> __device__ __forceinline__ void ingest_tuples_body(const TupleArgs &a, uint32_t block, uint32_t *hist, uint32_t &kept_block)
 {
 	const uint32_t c0 = block * a.chunks_per_block;
 	const uint32_t c1 = min(c0 + a.chunks_per_block, a.n_chunks);
 	const TupleBlockHome bh = a.block_home[block]; // in flight with the tuple loads below
 	// software pipeline over the workgroup's chunks: tuples two chunks ahead, GC bytes one chunk ahead
-	TupleRegs t1 = load_tuples(a, c0, c1), t2 = load_tuples(a, c0 + 1, c1); // in flight while the histogram is cleared
+	TupleRegs t1 = load_tuples<ALL>(a, c0, c1), t2 = load_tuples<ALL>(a, c0 + 1, c1); // in flight while the histogram is cleared
 	for (int k = threadIdx.x; k < kHistCopies * kGcBins; k += kTupleBlock)
 		hist[k] = 0;
 	if (threadIdx.x == 0)
@@ -431,7 +432,7 @@ __device__ __forceinline__ void ingest_tuples_body(const TupleArgs &a, uint32_t 
 	for (uint32_t c = c0; c < c1; c++) {
 		const TupleRegs cur = t1;
 		t1 = t2;
-		t2 = load_tuples(a, c + 2, c1);
+		t2 = load_tuples<ALL>(a, c + 2, c1);
 		const uint32_t base = c * (uint32_t) kTupleChunk;
 		if (!(base >= hs.r0 && (uint64_t) base + kTupleChunk <= (uint64_t) hs.r1)) { // chunk not inside `home`
 			ingest_chunk_count(pend, my_hist); // the previous chunk still belongs to the old chromosome
@@ -452,7 +453,7 @@ __device__ __forceinline__ void ingest_tuples_body(const TupleArgs &a, uint32_t 
 				const uint32_t to = min(chunk_end, hs.r1);
 				if (from == base && to == base + (uint32_t) kTupleChunk)
 					break; // the whole chunk lies in this chromosome after all: the plain path below
-				const GcRegs g = ingest_chunk_inside<true>(a, hs, home, base, cur, inv_step, kept, from, to);
+				const GcRegs g = ingest_chunk_inside<true, ALL>(a, hs, home, base, cur, inv_step, kept, from, to);
 				ingest_chunk_count(g, my_hist);
 				from = to;
 				if (from >= chunk_end)
@@ -462,7 +463,7 @@ __device__ __forceinline__ void ingest_tuples_body(const TupleArgs &a, uint32_t 
 			if (from != base)
 				continue; // handled chromosome by chromosome
 		}
-		const GcRegs g = ingest_chunk_inside<false>(a, hs, home, base, cur, inv_step, kept); // GC loads of this chunk go out ...
+		const GcRegs g = ingest_chunk_inside<false, ALL>(a, hs, home, base, cur, inv_step, kept); // GC loads of this chunk go out ...
 		ingest_chunk_count(pend, my_hist);                                                  // ... before the previous chunk's are used
 		pend = g;
 	}
@@ -471,11 +472,11 @@ __device__ __forceinline__ void ingest_tuples_body(const TupleArgs &a, uint32_t 
 		flush();
 }
 
-__global__ __launch_bounds__(kTupleBlock, 8) void ingest_tuples_kernel(TupleArgs a)
+template <bool ALL> __global__ __launch_bounds__(kTupleBlock, 8) void ingest_tuples_kernel(TupleArgs a)
 {
 	__shared__ uint32_t hist[kHistCopies * kGcBins];
 	__shared__ uint32_t kept_block;
-	ingest_tuples_body(a, blockIdx.x, hist, kept_block);
+	ingest_tuples_body<ALL>(a, blockIdx.x, hist, kept_block);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -672,7 +673,7 @@ __global__ __launch_bounds__(256) void interval_map_rows_kernel(MapRowsArgs a)
 // K0' and K4' in one launch (the step is launch-gap-bound: every dependent launch costs ~10 us on this stack, and a
 // second stream's event dependency costs more than it hides): the first count_blocks workgroups search and count,
 // the rest stream the tuples.  The two halves touch disjoint outputs and only read the tuples.
-template <bool MAP_ROWS> __global__ __launch_bounds__(kTupleBlock, 8) void tuple_pass_kernel(TupleArgs a, CountArgs c,
+template <bool MAP_ROWS, bool ALL> __global__ __launch_bounds__(kTupleBlock, 8) void tuple_pass_kernel(TupleArgs a, CountArgs c,
 		int count_blocks, MapRowsArgs m, int map_blocks, int ingest_blocks)
 {
 	__shared__ uint32_t hist[kHistCopies * kGcBins];
@@ -681,7 +682,7 @@ template <bool MAP_ROWS> __global__ __launch_bounds__(kTupleBlock, 8) void tuple
 	// for a slot behind the (short) search workgroups would stretch the launch by a whole workgroup lifetime.
 	const int b = (int) blockIdx.x;
 	if (b < ingest_blocks)
-		ingest_tuples_body(a, (uint32_t) b, hist, kept_block);
+		ingest_tuples_body<ALL>(a, (uint32_t) b, hist, kept_block);
 	else if (b < ingest_blocks + count_blocks)
 		interval_count_body(c, (int64_t) (b - ingest_blocks));
 	else if (MAP_ROWS)

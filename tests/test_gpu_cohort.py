@@ -217,7 +217,13 @@ def test_reads_bgzf_in_process_on_recycled_device_memory(capi, tmp_path, strateg
     import struct
     import zlib
     from conga_amd import formats
-    hip = ctypes.CDLL("libamdhip64.so")   # the runtime the library itself uses: blocks freed here are what it gets next
+    # the HIP runtime the library itself is linked against (the one already mapped into this process; torch ships another):
+    # blocks freed through it are what the library's next hipMalloc gets
+    capi.load()
+    paths = sorted({line.split()[-1] for line in open("/proc/self/maps") if "libamdhip64" in line},
+                   key=lambda q: ("/opt/rocm" not in q, q))
+    assert paths, "libconga_hip.so is loaded, so a HIP runtime must be"
+    hip = ctypes.CDLL(paths[0])
     junk = []
     for n in (1 << 20, 3 << 20, 17 << 20, 64 << 20, 2 << 20):
         p = ctypes.c_void_p()
