@@ -266,10 +266,15 @@ class Leg:
         dev = env["dev"]
         # one padded send buffer per context; rank 0 receives into per-context buffers and brings them to the host
         self.packed = [torch.zeros(pad, dtype=torch.uint8, device=dev) for _ in range(N_ROTATE)]
-        self.recv = [[torch.empty(pad, dtype=torch.uint8, device=env["gather_dev"]) for _ in range(env["world"])]
-                     if env["rank"] == 0 else None for _ in range(N_ROTATE)]
+        # rank 0 receives into the rows of ONE tensor per context (one copy to the host for all ranks) ...
+        self.recv_all = [torch.empty((env["world"], pad), dtype=torch.uint8, device=env["gather_dev"]) if env["rank"] == 0 else None
+                         for _ in range(N_ROTATE)]
+        self.recv = [[self.recv_all[j][r] for r in range(env["world"])] if env["rank"] == 0 else None for j in range(N_ROTATE)]
         self.host_recv = [torch.empty((env["world"], pad), dtype=torch.uint8).pin_memory() if env["rank"] == 0 else None
                           for _ in range(N_ROTATE)]
+        # ... and waits for a step's gather + copy one step later (drain() at the end of a run), so that their latency lies
+        # beside the next step instead of in front of it
+        self.in_flight = [None] * N_ROTATE
         self.ext = [None if env["rehearsal"] else torch.cuda.ExternalStream(c.stream(), device=dev) for c in self.ctxs]
 
     # -- one step, in two halves so that the copy of step k + 1 is in flight while step k finishes
@@ -293,13 +298,24 @@ class Leg:
             c.sync()
             dist.gather(self.packed[j].cpu(), self.recv[j], dst=0)
             return
+        prev = self.in_flight[(k - 1) % N_ROTATE] if k > 0 else None
+        if prev is not None:
+            prev.synchronize()                        # the previous step's gathered records are in (pinned) host memory
+            self.in_flight[(k - 1) % N_ROTATE] = None
         with torch.cuda.stream(self.ext[j]):          # RCCL over xGMI, ordered behind the copy on the context's stream
             dist.gather(self.packed[j], self.recv[j], dst=0)
             if env["rank"] == 0:
-                for r in range(env["world"]):
-                    self.host_recv[j][r].copy_(self.recv[j][r], non_blocking=True)
-        if env["rank"] == 0:
-            self.ext[j].synchronize()                 # the gathered records are in (pinned) host memory
+                self.host_recv[j].copy_(self.recv_all[j], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.ext[j])
+                self.in_flight[j] = ev
+
+    def drain(self):
+        if self.env["dist_on"] and not self.env["rehearsal"]:
+            for j, ev in enumerate(self.in_flight):
+                if ev is not None:
+                    ev.synchronize()
+                    self.in_flight[j] = None
 
     def run(self, n, pipelined=True):
         if pipelined:
@@ -312,6 +328,8 @@ class Leg:
             for k in range(n):
                 self.enqueue(k)
                 self.finish(k)
+                self.drain()
+        self.drain()
 
     def timed(self, steps, warmup, pipelined=True):
         """-> seconds for exactly `steps` steps, max over ranks, bracketed by barrier + synchronize."""
@@ -369,7 +387,8 @@ class Leg:
             import gc
             import torch
             torch.cuda.synchronize()
-            self.packed = self.recv = self.host_recv = self.ext = None
+            self.packed = self.recv = self.recv_all = self.host_recv = self.ext = None
+            self.in_flight = [None] * N_ROTATE
             gc.collect()
             torch.cuda.empty_cache()
         for c in self.ctxs:
