@@ -935,13 +935,16 @@ constexpr int kBzSlots = 12, kBzPiecesPerLaunch = 16;
 // conga executable does, while it reads the BAM's block table -- never waits for it)
 void make_bz_ring(conga_ctx *ctx)
 {
+	int prio_low = 0, prio_high = 0; // (numerically lower = more urgent)
+	(void) hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+	const bool prio = getenv("CONGA_BGZF_NO_PRIORITY") == nullptr;
 	bool ok = hipSetDevice(ctx->device) == hipSuccess
 			&& hipHostMalloc((void **) &ctx->h_bz_ring, kBzPiece * kBzSlots, hipHostMallocDefault) == hipSuccess
-			&& hipStreamCreateWithFlags(&ctx->bz_copy, hipStreamNonBlocking) == hipSuccess;
+			&& hipStreamCreateWithPriority(&ctx->bz_copy, hipStreamNonBlocking, prio ? prio_high : 0) == hipSuccess;
 	for (int k = 0; ok && k < kBzSlots; k++)
 		ok = hipEventCreateWithFlags(&ctx->ev_bz_slot[k], hipEventDisableTiming) == hipSuccess;
 	for (int k = 0; ok && k < 3; k++)
-		ok = hipStreamCreateWithFlags(&ctx->bz_kernel[k], hipStreamNonBlocking) == hipSuccess
+		ok = hipStreamCreateWithPriority(&ctx->bz_kernel[k], hipStreamNonBlocking, prio ? prio_low : 0) == hipSuccess
 				&& hipEventCreateWithFlags(&ctx->ev_bz_kernel[k], hipEventDisableTiming) == hipSuccess;
 	if (!ok) {
 		(void) hipGetLastError();
