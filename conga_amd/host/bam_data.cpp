@@ -249,6 +249,64 @@ void attach_intervals(conga_ctx *ctx, const parameters *params, const bed_index 
 	}
 }
 
+// What the decode on the GPU needs from one BAM, got ready ahead of time (read_bam_cohort does it for sample k + 1 on a
+// thread of its own while sample k is on the GPU): the opened file and, for the chromosomes the run will select in their
+// order, the mapped stretch of the file with its block table and start points (bam_reader.cpp: device_plan).
+struct planned_input {
+	std::unique_ptr<read_source> src;
+	std::vector<device_target> targets;
+	file_piece bytes;
+	std::vector<conga_bgzf_block> blocks;
+	std::vector<conga_bam_segment> segments;
+	bool planned = false;
+	double ms_plan = 0;
+};
+
+bool gpu_decode_wanted(const parameters *params)
+{
+	const char *gpu_bam = getenv("CONGA_GPU_BAM"); // 0: never, 1: always, unset: when it pays
+	const bool split_reads = !params->no_sr && params->have_dups;
+	return !split_reads && (gpu_bam == nullptr || atoi(gpu_bam) != 0);
+}
+
+// the chromosomes read_bam will work on, in its order (bam_data.c:269-291): (annotation index, BAM target)
+std::vector<std::pair<int, int>> select_chromosomes(const parameters *params, const sonic *this_sonic, const read_source &src)
+{
+	std::vector<std::pair<int, int>> sel;
+	for (int chr_index = 0; chr_index < this_sonic->number_of_chromosomes; chr_index++) {
+		if (chr_index < params->first_chrom)
+			chr_index = params->first_chrom;
+		if (chr_index > params->last_chrom || chr_index >= this_sonic->number_of_chromosomes)
+			break;
+		const std::string &name = this_sonic->chromosome_names[chr_index];
+		if (name.find('X') != std::string::npos || name.find('Y') != std::string::npos)
+			continue;
+		const int tid = find_chr_index_bam(name, src);
+		if (tid != -1)
+			sel.emplace_back(chr_index, tid);
+	}
+	return sel;
+}
+
+std::unique_ptr<planned_input> plan_input(const parameters *params, const sonic *this_sonic, const std::string &path)
+{
+	std::unique_ptr<planned_input> p(new planned_input);
+	std::string err;
+	p->src.reset(open_reads(path, &err));
+	if (!p->src || !gpu_decode_wanted(params) || params->n_gpus != 1)
+		return p; // (an input that does not open is reported by the run itself)
+	const auto sel = select_chromosomes(params, this_sonic, *p->src);
+	for (size_t i = 0; i < sel.size(); i++)
+		p->targets.push_back(device_target{sel[i].second, this_sonic->chromosome_lengths[sel[i].first], (int) i});
+	if (p->targets.empty())
+		return p;
+	const auto t0 = std::chrono::steady_clock::now();
+	const char *gpu_bam = getenv("CONGA_GPU_BAM");
+	p->planned = p->src->device_plan(p->targets, gpu_bam != nullptr ? 0 : gpu_bam_min_piece(), &p->bytes, &p->blocks, &p->segments, &err);
+	p->ms_plan = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	return p;
+}
+
 // An engine context that outlives one input (read_bam_cohort): what it holds, so that the next sample can tell whether the
 // layout is the same (then only the reads are replaced) or has to be handed over again.
 struct kept_engine {
@@ -274,7 +332,8 @@ std::string layout_key_of(const std::vector<chrom_job *> &mine)
 // One host thread per context, one context per GPU; chromosomes are independent in the
 // reference (bam_data.c:269-339), so no worker ever needs another's data.
 void run_worker(const parameters *params, const sonic *this_sonic, read_source *src, int device, bool buffered,
-		const bed_index &map_bed, std::vector<chrom_job *> &mine, bool announce_compute, worker_timing *wt, kept_engine *keep = nullptr)
+		const bed_index &map_bed, std::vector<chrom_job *> &mine, bool announce_compute, worker_timing *wt, kept_engine *keep = nullptr,
+		planned_input *pre = nullptr)
 {
 	auto now = [] { return std::chrono::steady_clock::now(); };
 	auto ms_since = [&](std::chrono::steady_clock::time_point t) {
@@ -331,12 +390,20 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 		std::vector<device_target> targets;
 		for (size_t i = 0; i < mine.size(); i++)
 			targets.push_back(device_target{mine[i]->chr_index_bam, mine[i]->L, (int) i});
-		file_piece bytes;
-		std::vector<conga_bgzf_block> blocks;
-		std::vector<conga_bam_segment> segments;
+		file_piece own_bytes;
+		std::vector<conga_bgzf_block> own_blocks;
+		std::vector<conga_bam_segment> own_segments;
 		const auto t_plan = now();
-		const bool planned = src->device_plan(targets, gpu_bam != nullptr ? 0 : gpu_bam_min_piece(), &bytes, &blocks, &segments, &err);
-		const double ms_plan = ms_since(t_plan);
+		// planned ahead (cohort) for exactly these chromosomes in this order? then that plan is the one
+		bool use_pre = pre != nullptr && pre->targets.size() == targets.size();
+		for (size_t i = 0; use_pre && i < targets.size(); i++)
+			use_pre = pre->targets[i].tid == targets[i].tid && pre->targets[i].chrom_len == targets[i].chrom_len && pre->targets[i].chrom == targets[i].chrom;
+		const bool planned = use_pre ? pre->planned
+				: src->device_plan(targets, gpu_bam != nullptr ? 0 : gpu_bam_min_piece(), &own_bytes, &own_blocks, &own_segments, &err);
+		file_piece &bytes = use_pre ? pre->bytes : own_bytes;
+		std::vector<conga_bgzf_block> &blocks = use_pre ? pre->blocks : own_blocks;
+		std::vector<conga_bam_segment> &segments = use_pre ? pre->segments : own_segments;
+		const double ms_plan = use_pre ? pre->ms_plan : ms_since(t_plan);
 		need_ctx();
 		if (planned) {
 			const auto t_open = now();
@@ -452,7 +519,7 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 		conga_destroy(ctx);
 }
 
-int read_bam_with(parameters *params, sonic *this_sonic, kept_engine *keep);
+int read_bam_with(parameters *params, sonic *this_sonic, kept_engine *keep, planned_input *pre = nullptr);
 
 } // namespace
 
@@ -496,13 +563,21 @@ int read_bam_cohort(parameters *params, sonic *this_sonic)
 		print_error("[CONGA INPUT ERROR] " + params->cohort_file + " names no BAM file.");
 	kept_engine keep;
 	const std::string outdir = params->outdir, outprefix = params->outprefix;
+	// the next sample's file is opened, mapped and its block table read while this sample is on the GPU
+	std::unique_ptr<planned_input> ahead = plan_input(params, this_sonic, samples[0].first);
 	for (size_t k = 0; k < samples.size(); k++) {
+		std::unique_ptr<planned_input> mine_now = std::move(ahead);
+		std::thread planner;
+		if (k + 1 < samples.size())
+			planner = std::thread([&, k] { ahead = plan_input(params, this_sonic, samples[k + 1].first); });
 		params->bam_file = samples[k].first;
 		params->outdir.clear(); // (a prefix from the list is taken as it is; the default one already carries --out's directory)
 		params->outprefix = samples[k].second;
 		fprintf(stderr, "\n[CONGA] sample %zu of %zu: %s\n", k + 1, samples.size(), params->bam_file.c_str());
 		// several contexts (--gpus N) are made per sample; one context is kept from sample to sample
-		const int rc = read_bam_with(params, this_sonic, params->n_gpus == 1 ? &keep : nullptr);
+		const int rc = read_bam_with(params, this_sonic, params->n_gpus == 1 ? &keep : nullptr, mine_now.get());
+		if (planner.joinable())
+			planner.join();
 		if (rc != 0)
 			return rc;
 	}
@@ -515,7 +590,7 @@ int read_bam_cohort(parameters *params, sonic *this_sonic)
 
 namespace {
 
-int read_bam_with(parameters *params, sonic *this_sonic, kept_engine *keep)
+int read_bam_with(parameters *params, sonic *this_sonic, kept_engine *keep, planned_input *pre)
 {
 	FILE *fpDel = nullptr, *fpDup = nullptr, *fpSVs = nullptr;
 
@@ -547,7 +622,7 @@ int read_bam_with(parameters *params, sonic *this_sonic, kept_engine *keep)
 
 	// ---- inputs (bam_data.c:253-267); the BED files are parsed once instead of once per chromosome
 	std::string err;
-	std::unique_ptr<read_source> src(open_reads(params->bam_file, &err));
+	std::unique_ptr<read_source> src(pre && pre->src ? pre->src.release() : open_reads(params->bam_file, &err));
 	if (!src)
 		print_error(err);
 	bed_index dels_bed, dups_bed, map_bed;
@@ -636,7 +711,7 @@ int read_bam_with(parameters *params, sonic *this_sonic, kept_engine *keep)
 			fprintf(stderr, "\nCalculating Likelihoods\n");
 	};
 	if (n_workers == 1) {
-		run_worker(params, this_sonic, src.get(), params->device, hold_lines, map_bed, mine[0], !hold_lines, &wt[0], keep);
+		run_worker(params, this_sonic, src.get(), params->device, hold_lines, map_bed, mine[0], !hold_lines, &wt[0], keep, pre);
 		if (hold_lines)
 			print_held_lines();
 	} else {
