@@ -17,6 +17,8 @@
 #include <condition_variable>
 #include <mutex>
 #include <thread>
+
+#include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -952,7 +954,31 @@ void make_bz_ring(conga_ctx *ctx)
 	}
 }
 
-int upload_and_inflate_overlapped(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const conga_bgzf_block *blocks, size_t n_blocks)
+// where the compressed bytes are: in the caller's memory, or in a file (read with pread: no mapping, no page faults)
+struct ByteSource {
+	const uint8_t *bytes = nullptr;
+	int fd = -1;
+	uint64_t file_off = 0;
+	bool fetch(size_t at, void *dst, size_t n) const
+	{
+		if (bytes) {
+			memcpy(dst, bytes + at, n);
+			return true;
+		}
+		uint8_t *p = static_cast<uint8_t *>(dst);
+		while (n) {
+			const ssize_t got = pread(fd, p, n, (off_t) (file_off + at));
+			if (got <= 0)
+				return false;
+			p += got;
+			at += (size_t) got;
+			n -= (size_t) got;
+		}
+		return true;
+	}
+};
+
+int upload_and_inflate_overlapped(conga_ctx *ctx, const ByteSource &src, size_t n_bytes, const conga_bgzf_block *blocks, size_t n_blocks)
 {
 	const bool timing = getenv("CONGA_TIMING") != nullptr;
 	const auto t0 = std::chrono::steady_clock::now();
@@ -1006,14 +1032,18 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const uint8_t *bytes, size_t n
 			}
 			const size_t at = c * piece, len = std::min(piece, n_bytes - at);
 			const auto tc = std::chrono::steady_clock::now();
-			memcpy(ctx->h_bz_ring + (c % kBzSlots) * kBzPiece, bytes + at, len);
+			const bool got = src.fetch(at, ctx->h_bz_ring + (c % kBzSlots) * kBzPiece, len);
 			us_wait += (long long) std::chrono::duration<double, std::micro>(tc - tw).count();
 			us_copy += (long long) std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tc).count();
 			{
 				std::lock_guard<std::mutex> g(mu);
 				filled[c] = 1;
+				if (!got)
+					failed = true; // (a file that ends early)
 			}
 			cv.notify_all();
+			if (!got)
+				return;
 		}
 	};
 	int n_threads = (int) std::min<size_t>(n_pieces, std::min<unsigned>(std::max(2u, std::thread::hardware_concurrency() * 3 / 4), (unsigned) kBzSlots));
@@ -1570,11 +1600,44 @@ int conga_sample_reads(conga_ctx *ctx, const int32_t *pos, const uint8_t *mapq, 
 	return CONGA_OK;
 }
 
+} // extern "C"
+
+namespace {
+int reads_bgzf_from(conga_ctx *ctx, const ByteSource &src, size_t n_bytes, const conga_bgzf_block *blocks, size_t n_blocks,
+		const conga_bam_segment *segments, size_t n_segments, uint64_t *reads_per_chrom);
+}
+
+extern "C" {
+
 int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const conga_bgzf_block *blocks, size_t n_blocks,
 		const conga_bam_segment *segments, size_t n_segments, uint64_t *reads_per_chrom)
 {
-	if (!ctx || !bytes || !blocks || !segments || n_blocks == 0 || n_segments == 0 || n_blocks > (size_t) 1 << 28
-			|| n_segments > (size_t) 1 << 28)
+	if (!ctx || !bytes)
+		return CONGA_ERR_INVALID;
+	ByteSource src;
+	src.bytes = bytes;
+	return reads_bgzf_from(ctx, src, n_bytes, blocks, n_blocks, segments, n_segments, reads_per_chrom);
+}
+
+int conga_reads_bgzf_fd(conga_ctx *ctx, int fd, uint64_t file_off, size_t n_bytes, const conga_bgzf_block *blocks, size_t n_blocks,
+		const conga_bam_segment *segments, size_t n_segments, uint64_t *reads_per_chrom)
+{
+	if (!ctx || fd < 0)
+		return CONGA_ERR_INVALID;
+	ByteSource src;
+	src.fd = fd;
+	src.file_off = file_off;
+	return reads_bgzf_from(ctx, src, n_bytes, blocks, n_blocks, segments, n_segments, reads_per_chrom);
+}
+
+} // extern "C"
+
+namespace {
+
+int reads_bgzf_from(conga_ctx *ctx, const ByteSource &src, size_t n_bytes, const conga_bgzf_block *blocks, size_t n_blocks,
+		const conga_bam_segment *segments, size_t n_segments, uint64_t *reads_per_chrom)
+{
+	if (!blocks || !segments || n_blocks == 0 || n_segments == 0 || n_blocks > (size_t) 1 << 28 || n_segments > (size_t) 1 << 28)
 		return CONGA_ERR_INVALID;
 	if (ctx->slots.empty())
 		return fail(ctx, CONGA_ERR_INVALID, "conga_reads_bgzf: no chromosome open");
@@ -1643,10 +1706,20 @@ int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const
 	const bool overlapped = !lane_kernel_asked() && in_order && (ov ? atoi(ov) != 0 : n_bytes >= ((size_t) 96 << 20));
 	double ms_alloc_upload = 0, ms_inflate = 0;
 	auto t_inflate = std::chrono::steady_clock::now();
+	std::vector<uint8_t> whole; // (a small piece of a file: read in one go)
 	if (overlapped) {
-		TRY(upload_and_inflate_overlapped(ctx, bytes, n_bytes, blocks, n_blocks));
+		TRY(upload_and_inflate_overlapped(ctx, src, n_bytes, blocks, n_blocks));
 	} else {
+		const uint8_t *bytes = src.bytes;
+		if (!bytes) {
+			whole.resize(n_bytes);
+			if (!src.fetch(0, whole.data(), n_bytes))
+				return fail(ctx, CONGA_ERR_INVALID, "conga_reads_bgzf_fd: the file ends inside the piece");
+			bytes = whole.data();
+		}
 		HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bz_in.p, bytes, n_bytes, hipMemcpyHostToDevice, st));
+		if (!src.bytes)
+			HIP_TRY(ctx, hipStreamSynchronize(st)); // (`whole` must outlive the copy)
 		if (timing) {
 			HIP_TRY(ctx, hipStreamSynchronize(st));
 			ms_alloc_upload = ms_since(t_begin);
@@ -1749,6 +1822,10 @@ int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const
 			reads_per_chrom[c] = (uint64_t) ctx->slots[(size_t) c].n_reads;
 	return CONGA_OK;
 }
+
+} // namespace
+
+extern "C" {
 
 int conga_inflate_blocks(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const conga_bgzf_block *blocks, size_t n_blocks,
 		uint8_t *out, size_t out_bytes, uint8_t *status, double *kernel_ms)

@@ -112,7 +112,9 @@ int64_t count_reads_bam(conga_ctx *ctx, read_source *src, int chr_index_bam, int
 		const int chrom = conga_chrom_count(ctx) - 1; // the chromosome begun last
 		if (src->device_plan({device_target{chr_index_bam, chrom_len, chrom}}, min_piece, &bytes, &blocks, &segments, &err)) {
 			std::vector<uint64_t> per_chrom((size_t) chrom + 1, 0);
-			const int rc = conga_reads_bgzf(ctx, bytes.data, bytes.size, blocks.data(), blocks.size(), segments.data(), segments.size(),
+			const int rc = bytes.data ? conga_reads_bgzf(ctx, bytes.data, bytes.size, blocks.data(), blocks.size(), segments.data(), segments.size(),
+					per_chrom.data())
+					: conga_reads_bgzf_fd(ctx, bytes.fd, bytes.file_off, bytes.size, blocks.data(), blocks.size(), segments.data(), segments.size(),
 					per_chrom.data());
 			if (rc == CONGA_OK)
 				return (int64_t) per_chrom[(size_t) chrom];
@@ -421,7 +423,9 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 			if (getenv("CONGA_TIMING"))
 				fprintf(stderr, "\n[timing] block table + start points %.1f ms, chromosomes opened (GC tracks, intervals, tracks) %.1f ms\n",
 						ms_plan, ms_since(t_open));
-			const int rc = conga_reads_bgzf(ctx, bytes.data, bytes.size, blocks.data(), blocks.size(), segments.data(), segments.size(),
+			const int rc = bytes.data ? conga_reads_bgzf(ctx, bytes.data, bytes.size, blocks.data(), blocks.size(), segments.data(), segments.size(),
+					gpu_counts.data())
+					: conga_reads_bgzf_fd(ctx, bytes.fd, bytes.file_off, bytes.size, blocks.data(), blocks.size(), segments.data(), segments.size(),
 					gpu_counts.data());
 			if (rc != CONGA_OK) {
 				if (rc != CONGA_ERR_DATA)

@@ -174,6 +174,39 @@ file_piece::~file_piece()
 {
 	if (map && map != MAP_FAILED)
 		munmap(map, map_len);
+	if (fd >= 0)
+		close(fd);
+}
+
+bool file_piece::open_fd(const std::string &path, uint64_t from, uint64_t to)
+{
+	fd = ::open(path.c_str(), O_RDONLY);
+	if (fd < 0)
+		return false;
+	file_off = from;
+	size = (size_t) (to - from);
+	data = nullptr;
+	return true;
+}
+
+bool file_piece::read_at(uint64_t off, void *dst, size_t n) const
+{
+	if (off > size || n > size - off)
+		return false;
+	if (data) {
+		memcpy(dst, data + off, n);
+		return true;
+	}
+	uint8_t *p = static_cast<uint8_t *>(dst);
+	while (n) {
+		const ssize_t got = pread(fd, p, n, (off_t) (file_off + off));
+		if (got <= 0)
+			return false;
+		p += got;
+		off += (uint64_t) got;
+		n -= (size_t) got;
+	}
+	return true;
 }
 
 bool file_piece::open(const std::string &path, uint64_t from, uint64_t to)

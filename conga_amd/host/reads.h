@@ -30,10 +30,14 @@ struct full_batch {
 
 // A stretch of a file, memory-mapped (the page cache is the only copy on the host; the GPU upload reads from it).
 struct file_piece {
-	const uint8_t *data = nullptr;
+	const uint8_t *data = nullptr; // the mapped bytes (open), or nullptr when only the descriptor is held (open_fd)
 	size_t size = 0;
 	void *map = nullptr;
 	size_t map_len = 0;
+	int fd = -1;                   // open_fd: the file, read with pread -- no mapping, no page faults, nothing to unmap
+	uint64_t file_off = 0;         // of the piece's first byte
+	bool open_fd(const std::string &path, uint64_t from, uint64_t to);
+	bool read_at(uint64_t off, void *dst, size_t n) const; // n bytes at `off` of the PIECE (either form)
 	file_piece() {}
 	file_piece(const file_piece &) = delete;
 	file_piece &operator=(const file_piece &) = delete;

@@ -269,6 +269,12 @@ typedef struct conga_bam_segment {
 int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const conga_bgzf_block *blocks, size_t n_blocks,
 		const conga_bam_segment *segments, size_t n_segments, uint64_t *reads_per_chrom /* [conga_chrom_count()] or NULL */);
 
+/* The same with the bytes still in the file: [file_off, file_off + n_bytes) of the open descriptor `fd` is read with pread
+ * straight into the pinned pieces that go up (no mapping of the file, no page faults, no copy in between); blocks[].data_off
+ * are relative to file_off, as they are to `bytes` above. */
+int conga_reads_bgzf_fd(conga_ctx *ctx, int fd, uint64_t file_off, size_t n_bytes, const conga_bgzf_block *blocks, size_t n_blocks,
+		const conga_bam_segment *segments, size_t n_segments, uint64_t *reads_per_chrom /* [conga_chrom_count()] or NULL */);
+
 /* Test / tool hook: the first stage of conga_reads_bgzf alone.  Inflates the blocks on the device and copies their payloads
  * (one behind the other) to `out` (may be NULL); status[b]: 0 inflated and CRC32 right, 1 refused (not a valid deflate stream
  * of the recorded size), 2 CRC32 mismatch.  kernel_ms (may be NULL): device time of the inflate launch.  Any bytes will do:

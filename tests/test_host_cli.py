@@ -308,7 +308,8 @@ def test_cli_bam_decoded_on_the_gpu_matches_the_host_decoders(tmp_path, oracle):
     # the overlapped form of the upload (pinned pieces filled by host threads, one inflate launch per 8 pieces), forced onto
     # this small file with 8 KB pieces, and the plain form; the round-1 kernel (one block per lane) once more
     for tag, env in (("ovl", dict(CONGA_BGZF_OVERLAP="1", CONGA_BGZF_PIECE_KB="8")), ("ovl1", dict(CONGA_BGZF_OVERLAP="1", CONGA_BGZF_PIECE_KB="8", CONGA_BGZF_COPY_THREADS="1")),
-                     ("plain", dict(CONGA_BGZF_OVERLAP="0")), ("lane", dict(CONGA_BGZF_KERNEL="lane"))):
+                     ("plain", dict(CONGA_BGZF_OVERLAP="0")), ("lane", dict(CONGA_BGZF_KERNEL="lane")),
+                     ("mapped", dict(CONGA_BAM_MMAP="1")), ("ovlmap", dict(CONGA_BAM_MMAP="1", CONGA_BGZF_OVERLAP="1", CONGA_BGZF_PIECE_KB="8"))):
         r_x, x = cli(tag, CONGA_GPU_BAM="1", CONGA_TIMING="1", **env)
         assert x == gpu and "decoding on the host" not in r_x.stderr and r_x.stderr.count("conga_reads_bgzf:") == 1, tag
         assert ("overlapped" in r_x.stderr) == tag.startswith("ovl"), tag
