@@ -916,10 +916,27 @@ int launch_inflate(conga_ctx *ctx, size_t n_blocks, uint32_t lanes, hipStream_t 
 	}
 	TRY(ensure_x2n(ctx));
 	// one resident round of workgroups (8 per CU), blocks round robin over their waves
-	const size_t groups = std::min<size_t>((n_blocks + iw::kWavesPerGroup - 1) / iw::kWavesPerGroup, (size_t) ctx->n_cu * 8);
-	hipLaunchKernelGGL(iw::bgzf_inflate_wave_kernel, dim3((unsigned) groups), dim3(64 * iw::kWavesPerGroup), 0, st, (uint32_t) n_blocks,
-			ptr<uint8_t>(ctx->d_bz_in), ptr<conga_bgzf_block>(ctx->d_bz_blocks) + b0, ptr<uint64_t>(ctx->d_bz_off) + b0,
-			ptr<uint8_t>(ctx->d_bz_out), ptr<uint32_t>(ctx->d_bz_crc), ptr<uint32_t>(ctx->d_bz_x2n), ptr<uint8_t>(ctx->d_bz_status) + b0);
+	static const int variant = getenv("CONGA_BGZF_VARIANT") ? atoi(getenv("CONGA_BGZF_VARIANT")) : 0;
+	const size_t groups = std::min<size_t>((n_blocks + iw::kWavesPerGroup - 1) / iw::kWavesPerGroup, (size_t) ctx->n_cu * ((variant & 2) ? 7 : 8));
+	auto launch = [&](auto kernel) {
+		hipLaunchKernelGGL(kernel, dim3((unsigned) groups), dim3(64 * iw::kWavesPerGroup), 0, st, (uint32_t) n_blocks,
+				ptr<uint8_t>(ctx->d_bz_in), ptr<conga_bgzf_block>(ctx->d_bz_blocks) + b0, ptr<uint64_t>(ctx->d_bz_off) + b0,
+				ptr<uint8_t>(ctx->d_bz_out), ptr<uint32_t>(ctx->d_bz_crc), ptr<uint32_t>(ctx->d_bz_x2n), ptr<uint8_t>(ctx->d_bz_status) + b0);
+	};
+	if (variant == 1)
+		launch(iw::bgzf_inflate_wave_kernel<1>);
+	else if (variant == 2)
+		launch(iw::bgzf_inflate_wave_kernel<2>);
+	else if (variant == 3)
+		launch(iw::bgzf_inflate_wave_kernel<3>);
+	else if (variant == 4)
+		launch(iw::bgzf_inflate_wave_kernel<4>);
+	else if (variant == 5)
+		launch(iw::bgzf_inflate_wave_kernel<5>);
+	else if (variant == 13)
+		launch(iw::bgzf_inflate_wave_kernel<13>);
+	else
+		launch(iw::bgzf_inflate_wave_kernel<0>);
 	return CONGA_OK;
 }
 
@@ -1179,10 +1196,20 @@ conga_ctx *conga_create(int device, const conga_opts *opts, int *status)
 	if (!status)
 		status = &st_dummy;
 	int n = 0;
+	// CONGA_TIMING: where the creation's time goes (the first call of a process brings the HIP runtime up)
+	const bool say = getenv("CONGA_TIMING") != nullptr;
+	auto t_last = std::chrono::steady_clock::now();
+	double t_part[5] = {0, 0, 0, 0, 0};
+	auto lap = [&](int k) {
+		const auto now = std::chrono::steady_clock::now();
+		t_part[k] += std::chrono::duration<double, std::milli>(now - t_last).count();
+		t_last = now;
+	};
 	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) {
 		*status = CONGA_ERR_NO_DEVICE;
 		return nullptr;
 	}
+	lap(0);
 	conga_ctx *ctx = new (std::nothrow) conga_ctx();
 	if (!ctx) {
 		*status = CONGA_ERR_NOMEM;
@@ -1237,6 +1264,7 @@ conga_ctx *conga_create(int device, const conga_opts *opts, int *status)
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
 		ctx->n_cu = prop.multiProcessorCount;
+	lap(1);
 	{
 		// the depth kernel keeps a histogram per workgroup, so its grid is exactly one resident wave of workgroups
 		int nb = 0;
@@ -1254,6 +1282,7 @@ conga_ctx *conga_create(int device, const conga_opts *opts, int *status)
 		}
 		ctx->tuple_blocks_per_cu = occ;
 	}
+	lap(2);
 	if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess)
 		return bail(CONGA_ERR_HIP);
 	if (hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming) != hipSuccess
@@ -1268,8 +1297,13 @@ conga_ctx *conga_create(int device, const conga_opts *opts, int *status)
 	for (int k = 0; k < CONGA_K_COUNT; k++)
 		if (hipEventCreate(&ctx->ev_k0[k]) != hipSuccess || hipEventCreate(&ctx->ev_k1[k]) != hipSuccess)
 			return bail(CONGA_ERR_HIP);
+	lap(3);
 	if (ctx->opts.flags & CONGA_FLAG_EXPECT_BGZF)
 		make_bz_ring(ctx); // (a failure shows when the ring is asked for)
+	lap(4);
+	if (say)
+		fprintf(stderr, "[timing] conga_create: device count %.1f ms, device + properties %.1f ms, occupancy queries (code object load) %.1f ms, "
+				"streams + events %.1f ms, pinned ring + its streams %.1f ms\n", t_part[0], t_part[1], t_part[2], t_part[3], t_part[4]);
 	*status = CONGA_OK;
 	return ctx;
 }

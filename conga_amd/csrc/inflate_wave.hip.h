@@ -85,21 +85,32 @@ __device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t 
 	return __builtin_amdgcn_alignbit(hi, lo, shift); // ({hi, lo} >> shift[4:0])[31:0]
 }
 
+// the stream and the output are in global memory, and the types say so: the symbol loop may be a function of its own, where
+// nothing else would tell the compiler (generic pointers become flat_ instructions, which count on both wait counters)
+typedef __attribute__((address_space(1))) uint8_t *GBytes;
+typedef __attribute__((address_space(1))) const uint8_t *GConstBytes;
+typedef __attribute__((address_space(1))) const uint32_t *GWords;
+
 // bytes this wave stored are read back from L2: loads that do not stop at the (write-through) L1
-__device__ __forceinline__ uint32_t load_written_u8(const uint8_t *p)
+template <typename P> __device__ __forceinline__ uint32_t load_written_u8(P p)
 {
 	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ uint32_t load_written_u32(const uint32_t *p)
+template <typename P> __device__ __forceinline__ uint32_t load_written_u32(P p)
 {
 	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // eight bytes at ANY address (global memory takes unaligned dword accesses), past the L1 like the loads above
-__device__ __forceinline__ uint64_t load_written_u64_unaligned(const uint8_t *p)
+template <typename P> __device__ __forceinline__ uint64_t load_written_u64_unaligned(P p)
 {
 	uint64_t v;
 	asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
 	return v;
+}
+// the same as a load the compiler knows about (it places the wait in front of the first use, which may be a whole trip later)
+template <typename P> __device__ __forceinline__ uint64_t load_written_u64_unaligned_async(P p)
+{
+	return __hip_atomic_load((__attribute__((address_space(1))) const uint64_t *) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- the stream, read uniformly (block headers, code lengths) ---------------------------------------------------------
@@ -262,10 +273,10 @@ __device__ __forceinline__ uint32_t lit_entry(uint32_t sym)
 
 // ---- one deflate block's symbols ---------------------------------------------------------------------------------------
 struct Stream {
-	const uint32_t *in32; // 4-byte aligned
+	GWords in32;          // 4-byte aligned
 	uint32_t ibit;        // next bit (from in32)
 	uint32_t end_bit;     // first bit behind the block's data
-	uint8_t *out;
+	GBytes out;
 	uint32_t opos, out_len;
 	uint32_t safe_pos;    // every byte below is known to have reached L2
 };
@@ -305,6 +316,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 }
 
 // 0: end-of-block symbol reached; -1: the stream is invalid
+template <int V>
 __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Luts &luts
 #ifdef IW_PROF
 		, unsigned long long *prof
@@ -315,7 +327,7 @@ __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Lu
 	// the stream's state is the same in every lane: kept in scalar registers (readfirstlane tells the compiler)
 	uint32_t ibit = uni(s.ibit), opos = uni(s.opos), safe_pos = uni(s.safe_pos);
 	const uint32_t end_bit = uni(s.end_bit), out_len = uni(s.out_len);
-	const uint32_t *in32 = s.in32;
+	const GWords in32 = s.in32;
 	auto leave = [&](int rc) {
 		s.ibit = ibit;
 		s.opos = opos;
@@ -325,8 +337,44 @@ __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Lu
 	// 64 consecutive dwords of the input sit in one register across the wave (lane i: dword d0 + i); a lane's view is
 	// three ds_bpermute (the LDS crossbar, no memory) and two funnel shifts, and the register is refilled with one
 	// coalesced load every ~1900 bits
+	// (loaded and waited for in one piece of assembly: a load the compiler tracks would make it wait for everything in
+	// flight at the top of every trip, because the register MAY have been refilled)
+	auto load_window = [&](uint32_t dword) {
+		uint32_t w;
+		const GWords at = in32 + dword + lane;
+		asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(at) : "memory");
+		return w;
+	};
 	uint32_t d0 = uni(ibit >> 5);
-	uint32_t wreg = in32[d0 + lane];
+	uint32_t wreg = load_window(d0);
+	// n <= 8 bytes of v to out[to..): dword / short / byte pieces (unaligned dword stores are fine in global memory)
+	auto store_pieces = [&](uint64_t v8, uint32_t to, uint32_t n) {
+		const GBytes q = s.out + to;
+		uint32_t done = 0;
+		if (n >= 4u) {
+			*(__attribute__((address_space(1))) uint32_t *) q = (uint32_t) v8;
+			done = 4;
+		}
+		if (n == 8u) {
+			*(__attribute__((address_space(1))) uint32_t *) (q + 4) = (uint32_t) (v8 >> 32);
+			done = 8;
+		}
+		if ((n - done) & 2u) {
+			*(__attribute__((address_space(1))) uint16_t *) (q + done) = (uint16_t) (v8 >> (8u * done));
+			done += 2;
+		}
+		if ((n - done) & 1u)
+			q[done] = (uint8_t) (v8 >> (8u * done));
+	};
+	uint64_t pend_v = 0;
+	uint32_t pend_to = 0, pend_n = 0; // this lane's short match of the trip before, loaded and not yet stored (V & 8)
+	auto flush_pending = [&]() {
+		if (__ballot(pend_n != 0u)) {
+			if (pend_n)
+				store_pieces(pend_v, pend_to, pend_n);
+			pend_n = 0;
+		}
+	};
 	for (;;) {
 		IW_T0();
 		if (ibit > end_bit)
@@ -334,7 +382,7 @@ __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Lu
 		uint32_t dd = (ibit >> 5) - d0;
 		if (dd > 59u) {
 			d0 = ibit >> 5;
-			wreg = in32[d0 + lane];
+			wreg = load_window(d0);
 			dd = 0;
 		}
 		// this lane's 64-bit view of the stream from bit ibit + lane on
@@ -377,16 +425,30 @@ __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Lu
 		// lanes known to be starts mark the lane their J points at (ds_permute pushes a flag there): after round k the first
 		// 2^(k+1) starts are known.  An end-of-block or invalid symbol ends the chain.
 		uint32_t J = (!bad && (is_lit || is_match) && nxt < 64u) ? nxt : 64u;
-		uint32_t on_chain = lane == 0u ? 1u : 0u;
-		for (;;) {
-			const bool push = on_chain && J < 64u;
-			on_chain |= (uint32_t) __builtin_amdgcn_ds_permute(push ? (int) (J << 2) : 0, push ? 1 : 0);
-			const uint32_t jj = (uint32_t) __builtin_amdgcn_ds_bpermute((int) ((J & 63u) << 2), (int) J);
-			J = J < 64u ? jj : 64u;
-			if (uni(J) >= 64u)
-				break;
+		uint32_t on_chain;
+		unsigned long long chain;
+		if ((V & 1) == 0) {
+			on_chain = lane == 0u ? 1u : 0u;
+			for (;;) {
+				const bool push = on_chain && J < 64u;
+				on_chain |= (uint32_t) __builtin_amdgcn_ds_permute(push ? (int) (J << 2) : 0, push ? 1 : 0);
+				const uint32_t jj = (uint32_t) __builtin_amdgcn_ds_bpermute((int) ((J & 63u) << 2), (int) J);
+				J = J < 64u ? jj : 64u;
+				if (uni(J) >= 64u)
+					break;
+			}
+			chain = __ballot(on_chain != 0u);
+		} else {
+			// one v_readlane and four scalar instructions per symbol: the vector unit, which is what the waves of a SIMD
+			// compete for, sees one instruction per symbol
+			chain = 0;
+			uint32_t cur = 0;
+			do {
+				chain |= 1ull << cur;
+				cur = (uint32_t) __builtin_amdgcn_readlane((int) J, (int) cur);
+			} while (cur < 64u);
+			on_chain = (uint32_t) ((chain >> lane) & 1ull);
 		}
-		const unsigned long long chain = __ballot(on_chain != 0u);
 		const unsigned long long bad_m = chain & __ballot(bad);
 		if (bad_m)
 			return leave(-1);
@@ -403,6 +465,8 @@ __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Lu
 		IW_ADD(P_SYMS, (uint32_t) __popcll(chain));
 		if (opos + total > out_len)
 			return leave(-1);
+		if (V & 8)
+			flush_pending();
 		if (on_chain && is_lit)
 			s.out[opos + incl - 1u] = (uint8_t) val;
 		IW_LAP(P_LITS);
@@ -414,26 +478,24 @@ __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Lu
 			const uint32_t to_l = opos + incl - produced, src_l = to_l - dist;
 			const bool fast = on_chain && is_match && produced <= 8u && dist >= produced && dist <= to_l && src_l + produced <= safe_pos;
 			const unsigned long long fast_m = __ballot(fast);
-			if (fast_m) {
-				if (fast) {
-					const uint64_t v8 = load_written_u64_unaligned(s.out + src_l);
-					uint8_t *q = s.out + to_l;
-					uint32_t done = 0;
-					if (produced >= 4u) {
-						*reinterpret_cast<uint32_t *>(q) = (uint32_t) v8; // (unaligned dword stores are fine in global memory)
-						done = 4;
+			if (V & 8) {
+				// (V & 8) the bytes are asked for now and stored one trip later, behind the next trip's look-ups and walk: the load's
+				// way to L2 and back is not waited for.  Nothing can ask for these bytes in between: they lie above safe_pos
+				// until a wait moves it, and every such wait comes behind a flush.
+				if (fast_m) {
+					if (fast) {
+						pend_v = load_written_u64_unaligned_async(s.out + src_l);
+						pend_to = to_l;
+						pend_n = produced;
 					}
-					if (produced == 8u) {
-						*reinterpret_cast<uint32_t *>(q + 4) = (uint32_t) (v8 >> 32);
-						done = 8;
-					}
-					if ((produced - done) & 2u) {
-						*reinterpret_cast<uint16_t *>(q + done) = (uint16_t) (v8 >> (8u * done));
-						done += 2;
-					}
-					if ((produced - done) & 1u)
-						q[done] = (uint8_t) (v8 >> (8u * done));
+					IW_ADD(P_MATCHES, (uint32_t) __popcll(fast_m));
+					mm &= ~fast_m;
+					if (mm)
+						flush_pending();
 				}
+			} else if (fast_m) {
+				if (fast)
+					store_pieces(load_written_u64_unaligned(s.out + src_l), to_l, produced);
 				IW_ADD(P_MATCHES, (uint32_t) __popcll(fast_m));
 				mm &= ~fast_m;
 			}
@@ -476,9 +538,46 @@ __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Lu
 		}
 		opos += total;
 		ibit += advance;
-		if (ends)
+		if (ends) {
+			if (V & 8)
+				flush_pending();
 			return leave(ibit > end_bit ? -1 : 0);
+		}
 	}
+}
+
+// The symbol loop as a function of its own (V & 4): its registers are then allocated for the loop alone, not together with
+// everything a block's set-up keeps alive around it.  Arguments and results travel in registers; the tables are named by
+// their LDS addresses, so that the accesses stay ds_ instructions.
+struct SymbolsOut {
+	uint32_t ibit, opos, safe_pos;
+	int rc;
+};
+typedef __attribute__((address_space(3))) const WaveLds *LdsTables;
+typedef __attribute__((address_space(3))) const Luts *LdsLuts;
+
+template <int V>
+__device__ __attribute__((noinline)) SymbolsOut run_symbols_call(GWords in32, GBytes out, uint32_t ibit, uint32_t end_bit, uint32_t opos,
+		uint32_t out_len, uint32_t safe_pos, uint32_t tables_at, uint32_t luts_at)
+{
+	Stream s;
+	const uint64_t in_u = (uint64_t) uni((uint32_t) (uintptr_t) in32) | ((uint64_t) uni((uint32_t) ((uintptr_t) in32 >> 32)) << 32);
+	const uint64_t out_u = (uint64_t) uni((uint32_t) (uintptr_t) out) | ((uint64_t) uni((uint32_t) ((uintptr_t) out >> 32)) << 32);
+	s.in32 = (GWords) in_u;
+	s.out = (GBytes) out_u;
+	s.ibit = ibit;
+	s.end_bit = end_bit;
+	s.opos = opos;
+	s.out_len = out_len;
+	s.safe_pos = safe_pos;
+	const WaveLds &t = *(const WaveLds *) (LdsTables) (uintptr_t) uni(tables_at);
+	const Luts &luts = *(const Luts *) (LdsLuts) (uintptr_t) uni(luts_at);
+	SymbolsOut o;
+	o.rc = run_symbols<V>(s, t, luts);
+	o.ibit = s.ibit;
+	o.opos = s.opos;
+	o.safe_pos = s.safe_pos;
+	return o;
 }
 
 // ---- CRC-32 (reflected, polynomial 0xEDB88320) over GF(2) ---------------------------------------------------------------
@@ -535,6 +634,7 @@ __device__ __forceinline__ uint32_t wave_crc32(const uint8_t *out, uint32_t n, c
 enum { kStatusOk = 0, kStatusRefused = 1, kStatusCrc = 2 };
 
 // One whole BGZF block (a raw deflate stream of one or more deflate blocks) by one wave.
+template <int V>
 __device__ __forceinline__ int inflate_block(WaveLds &t, const Luts &luts, const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len
 #ifdef IW_PROF
 		, unsigned long long *prof
@@ -544,15 +644,15 @@ __device__ __forceinline__ int inflate_block(WaveLds &t, const Luts &luts, const
 	const uint32_t lane = lane_id();
 	Stream s;
 	const uint32_t mis = (uint32_t) ((uintptr_t) in & 3u);
-	s.in32 = reinterpret_cast<const uint32_t *>(in - mis);
+	s.in32 = (GWords) (in - mis);
 	s.ibit = mis * 8u;
 	s.end_bit = (mis + in_len) * 8u;
-	s.out = out;
+	s.out = (GBytes) out;
 	s.opos = 0;
 	s.out_len = out_len;
 	s.safe_pos = 0;
 	Window win;
-	win.in32 = s.in32;
+	win.in32 = reinterpret_cast<const uint32_t *>(in - mis);
 	win.load(0);
 	for (;;) {
 		if (s.ibit + 3u > s.end_bit)
@@ -569,7 +669,7 @@ __device__ __forceinline__ int inflate_block(WaveLds &t, const Luts &luts, const
 			s.ibit += 32u;
 			if ((ln ^ nl) != 0xFFFFu || s.ibit + 8u * ln > s.end_bit || s.opos + ln > s.out_len)
 				return kStatusRefused;
-			const uint8_t *from = reinterpret_cast<const uint8_t *>(s.in32) + (s.ibit >> 3);
+			const GConstBytes from = (GConstBytes) s.in32 + (s.ibit >> 3);
 			for (uint32_t k = lane; k < ln; k += 64u)
 				s.out[s.opos + k] = from[k];
 			s.opos += ln;
@@ -697,10 +797,18 @@ __device__ __forceinline__ int inflate_block(WaveLds &t, const Luts &luts, const
 				return kStatusRefused;
 			IW_LAP(P_TABLES);
 #ifdef IW_PROF
-			if (run_symbols(s, t, luts, prof) != 0)
+			if (run_symbols<V>(s, t, luts, prof) != 0)
 				return kStatusRefused;
 #else
-			if (run_symbols(s, t, luts) != 0)
+			if (V & 4) {
+				const SymbolsOut o = run_symbols_call<V>(s.in32, s.out, s.ibit, s.end_bit, s.opos, s.out_len, s.safe_pos,
+						(uint32_t) (uintptr_t) (LdsTables) &t, (uint32_t) (uintptr_t) (LdsLuts) &luts);
+				s.ibit = o.ibit;
+				s.opos = o.opos;
+				s.safe_pos = o.safe_pos;
+				if (o.rc != 0)
+					return kStatusRefused;
+			} else if (run_symbols<V>(s, t, luts) != 0)
 				return kStatusRefused;
 #endif
 			win.d0 = 0xFFFFFF00u; // (the position moved on behind the window's back: force a reload)
@@ -715,7 +823,8 @@ __device__ __forceinline__ int inflate_block(WaveLds &t, const Luts &luts, const
 constexpr int kWavesPerGroup = 4;
 
 // status[b]: kStatusOk / kStatusRefused / kStatusCrc.  Waves take blocks round robin.
-__global__ __launch_bounds__(64 * kWavesPerGroup, 8) void bgzf_inflate_wave_kernel(uint32_t n_blocks, const uint8_t *__restrict__ bytes,
+template <int V>
+__global__ __launch_bounds__(64 * kWavesPerGroup, (V & 2) ? 7 : 8) void bgzf_inflate_wave_kernel(uint32_t n_blocks, const uint8_t *__restrict__ bytes,
 		const conga_bgzf_block *__restrict__ blocks, const uint64_t *__restrict__ out_off, uint8_t *out,
 		const uint32_t *__restrict__ crc_table, const uint32_t *__restrict__ x2n, uint8_t *__restrict__ status)
 {
@@ -737,10 +846,10 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, 8) void bgzf_inflate_wave_kern
 		uint8_t *dst = out + out_off[b];
 #ifdef IW_PROF
 		unsigned long long prof[P_N] = {};
-		int st = inflate_block(lds[wave], s_luts, bytes + bl.data_off, bl.data_len, dst, bl.inflated_len, prof);
+		int st = inflate_block<V>(lds[wave], s_luts, bytes + bl.data_off, bl.data_len, dst, bl.inflated_len, prof);
 		IW_T0();
 #else
-		int st = inflate_block(lds[wave], s_luts, bytes + bl.data_off, bl.data_len, dst, bl.inflated_len);
+		int st = inflate_block<V>(lds[wave], s_luts, bytes + bl.data_off, bl.data_len, dst, bl.inflated_len);
 #endif
 		if (st == kStatusOk) {
 			asm volatile("" ::: "memory");

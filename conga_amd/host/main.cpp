@@ -21,6 +21,18 @@ using namespace conga_host;
 
 int main(int argc, char **argv)
 {
+	// CONGA_T0_NS (tools/e2e_quick.sh): the caller's clock just before the process was started -- what of a run's wall time lies
+	// in front of main and behind _exit is then visible
+	auto since_t0 = [](const char *what) {
+		const char *t0 = getenv("CONGA_T0_NS");
+		if (!t0 || !getenv("CONGA_TIMING"))
+			return;
+		struct timespec ts;
+		clock_gettime(CLOCK_REALTIME, &ts);
+		const long long now = (long long) ts.tv_sec * 1000000000ll + ts.tv_nsec;
+		fprintf(stderr, "[timing] %s: %.1f ms after the caller's clock\n", what, (double) (now - atoll(t0)) * 1e-6);
+	};
+	since_t0("main entered");
 	time_t rawtime;
 	time(&rawtime);
 	struct tm *timeinfo = localtime(&rawtime);
@@ -164,6 +176,7 @@ int main(int argc, char **argv)
 		return EXIT_SUCCESS;
 	}
 
+	since_t0("inputs read");
 	const int rc = params.cohort_file.empty() ? read_bam(&params, this_sonic.get()) : read_bam_cohort(&params, this_sonic.get());
 	if (rc != 0)
 		return rc;
@@ -175,6 +188,7 @@ int main(int argc, char **argv)
 	fclose(logFile);
 	if (getenv("CONGA_CLEAN_EXIT") == nullptr) {
 		// outputs are written and closed: leave without the HIP runtime's and the contexts' teardown (bam_data.cpp)
+		since_t0("leaving");
 		fflush(nullptr);
 		_exit(EXIT_SUCCESS);
 	}

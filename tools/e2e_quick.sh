@@ -23,7 +23,7 @@ fi
 cd $D
 for i in 1 2 3; do
   t0=$(date +%s%N)
-  env CONGA_TIMING=1 "$@" ${GRAFT_REPO_ROOT:-/root/repo}/conga_amd/host/conga -i r.bam --ref r.fa --sonic a.cga --dels dels.bed --out o$i > run$i.log 2>&1 || { echo "conga failed"; tail -5 run$i.log; }
+  env CONGA_TIMING=1 CONGA_T0_NS=$t0 "$@" ${GRAFT_REPO_ROOT:-/root/repo}/conga_amd/host/conga -i r.bam --ref r.fa --sonic a.cga --dels dels.bed --out o$i > run$i.log 2>&1 || { echo "conga failed"; tail -5 run$i.log; }
   t1=$(date +%s%N)
   grep -a "timing" run$i.log || true
   echo "wall $(( (t1 - t0) / 1000000 )) ms"
@@ -32,8 +32,8 @@ md5sum o1_dels.bed o2_dels.bed o3_dels.bed
 # the same genome as a cohort of four (the same BAM four times): one process, the engine kept from sample to sample
 printf "r.bam\tc0\nr.bam\tc1\nr.bam\tc2\nr.bam\tc3\n" > list.txt
 t0=$(date +%s%N)
-env CONGA_TIMING=1 "$@" ${GRAFT_REPO_ROOT:-/root/repo}/conga_amd/host/conga --cohort list.txt --ref r.fa --sonic a.cga --dels dels.bed --out co > cohort.log 2>&1 || { echo "cohort failed"; tail -5 cohort.log; }
+env CONGA_TIMING=1 CONGA_T0_NS=$t0 "$@" ${GRAFT_REPO_ROOT:-/root/repo}/conga_amd/host/conga --cohort list.txt --ref r.fa --sonic a.cga --dels dels.bed --out co > cohort.log 2>&1 || { echo "cohort failed"; tail -5 cohort.log; }
 t1=$(date +%s%N)
-grep -a "timing\] open" cohort.log || true
+grep -a "timing\] open\|caller" cohort.log || true
 echo "cohort of 4: wall $(( (t1 - t0) / 1000000 )) ms"
 md5sum c0_dels.bed c3_dels.bed

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--cov", type=float, default=1.0)
     ap.add_argument("--level", type=int, default=1)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--kernels", default="wave,lane")
     ap.add_argument("--sizes", default="64,1000,8000,0", help="block counts to time (0 = all)")
     a = ap.parse_args()
     lens = dict(synth.GRCH37_AUTOSOMES)
@@ -50,7 +51,7 @@ def main():
             sel = blocks if n == 0 else blocks[:n]
             hi = sel[-1][0] + sel[-1][1] + 8
             inflated = sum(b[2] for b in sel)
-            for kernel in ("wave", "lane"):
+            for kernel in a.kernels.split(","):
                 os.environ["CONGA_BGZF_KERNEL"] = kernel
                 best = 1e30
                 for _ in range(a.reps):

@@ -10,6 +10,9 @@
 #include <vector>
 
 #include "../conga_amd/csrc/inflate_wave.hip.h"
+#ifndef IW_VARIANT
+#define IW_VARIANT 0
+#endif
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -85,18 +88,22 @@ int main(int argc, char **argv)
 	hipEvent_t e0, e1;
 	CHECK(hipEventCreate(&e0));
 	CHECK(hipEventCreate(&e1));
-	for (int rep = 0; rep < 2; rep++) {
+	for (int rep = 0; rep < 3; rep++) {
+#ifdef IW_PROF
 		unsigned long long zero[conga::iw::P_N] = {};
 		CHECK(hipMemcpyToSymbol(HIP_SYMBOL(conga::iw::g_prof), zero, sizeof zero));
+#endif
 		const unsigned groups = (unsigned) std::min<size_t>((n + 3) / 4, 256 * 8);
 		CHECK(hipEventRecord(e0));
-		hipLaunchKernelGGL(conga::iw::bgzf_inflate_wave_kernel, dim3(groups), dim3(256), 0, 0, n, d_in, d_blocks, d_off, d_out, d_crc, d_x2n, d_status);
+		hipLaunchKernelGGL(conga::iw::bgzf_inflate_wave_kernel<IW_VARIANT>, dim3(groups), dim3(256), 0, 0, n, d_in, d_blocks, d_off, d_out, d_crc, d_x2n, d_status);
 		CHECK(hipEventRecord(e1));
 		CHECK(hipEventSynchronize(e1));
 		float ms;
 		CHECK(hipEventElapsedTime(&ms, e0, e1));
+#ifdef IW_PROF
 		unsigned long long p[conga::iw::P_N];
 		CHECK(hipMemcpyFromSymbol(p, HIP_SYMBOL(conga::iw::g_prof), sizeof p));
+#endif
 		std::vector<uint8_t> st(n);
 		CHECK(hipMemcpy(st.data(), d_status, n, hipMemcpyDeviceToHost));
 		size_t bad = 0;
@@ -104,6 +111,7 @@ int main(int argc, char **argv)
 			bad += s != 0;
 		const char *names[] = {"view+lookup", "walk", "literal stores", "match wait", "match copy", "tables", "crc"};
 		printf("%u blocks, %.1f MB inflated, %.2f ms (%.1f GB/s), %zu not ok\n", n, total / 1e6, ms, total / ms / 1e6, bad);
+#ifdef IW_PROF
 		printf("  per block: %.0f trips, %.0f symbols (%.2f per trip), %.0f matches, %.0f store waits\n", (double) p[conga::iw::P_TRIPS] / n,
 				(double) p[conga::iw::P_SYMS] / n, (double) p[conga::iw::P_SYMS] / (double) p[conga::iw::P_TRIPS], (double) p[conga::iw::P_MATCHES] / n,
 				(double) p[conga::iw::P_WAITS] / n);
@@ -112,6 +120,7 @@ int main(int argc, char **argv)
 			sum += p[k];
 		for (int k = 0; k < 7; k++)
 			printf("  %-16s %10.0f ticks per block (%.1f %%)  %.0f per trip\n", names[k], (double) p[k] / n, 100.0 * p[k] / sum, (double) p[k] / (double) p[conga::iw::P_TRIPS]);
+#endif
 	}
 	return 0;
 }
