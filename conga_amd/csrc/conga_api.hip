@@ -916,27 +916,10 @@ int launch_inflate(conga_ctx *ctx, size_t n_blocks, uint32_t lanes, hipStream_t 
 	}
 	TRY(ensure_x2n(ctx));
 	// one resident round of workgroups (8 per CU), blocks round robin over their waves
-	static const int variant = getenv("CONGA_BGZF_VARIANT") ? atoi(getenv("CONGA_BGZF_VARIANT")) : 0;
-	const size_t groups = std::min<size_t>((n_blocks + iw::kWavesPerGroup - 1) / iw::kWavesPerGroup, (size_t) ctx->n_cu * ((variant & 2) ? 7 : 8));
-	auto launch = [&](auto kernel) {
-		hipLaunchKernelGGL(kernel, dim3((unsigned) groups), dim3(64 * iw::kWavesPerGroup), 0, st, (uint32_t) n_blocks,
-				ptr<uint8_t>(ctx->d_bz_in), ptr<conga_bgzf_block>(ctx->d_bz_blocks) + b0, ptr<uint64_t>(ctx->d_bz_off) + b0,
-				ptr<uint8_t>(ctx->d_bz_out), ptr<uint32_t>(ctx->d_bz_crc), ptr<uint32_t>(ctx->d_bz_x2n), ptr<uint8_t>(ctx->d_bz_status) + b0);
-	};
-	if (variant == 1)
-		launch(iw::bgzf_inflate_wave_kernel<1>);
-	else if (variant == 2)
-		launch(iw::bgzf_inflate_wave_kernel<2>);
-	else if (variant == 3)
-		launch(iw::bgzf_inflate_wave_kernel<3>);
-	else if (variant == 4)
-		launch(iw::bgzf_inflate_wave_kernel<4>);
-	else if (variant == 5)
-		launch(iw::bgzf_inflate_wave_kernel<5>);
-	else if (variant == 13)
-		launch(iw::bgzf_inflate_wave_kernel<13>);
-	else
-		launch(iw::bgzf_inflate_wave_kernel<0>);
+	const size_t groups = std::min<size_t>((n_blocks + iw::kWavesPerGroup - 1) / iw::kWavesPerGroup, (size_t) ctx->n_cu * 8);
+	hipLaunchKernelGGL(iw::bgzf_inflate_wave_kernel, dim3((unsigned) groups), dim3(64 * iw::kWavesPerGroup), 0, st, (uint32_t) n_blocks,
+			ptr<uint8_t>(ctx->d_bz_in), ptr<conga_bgzf_block>(ctx->d_bz_blocks) + b0, ptr<uint64_t>(ctx->d_bz_off) + b0,
+			ptr<uint8_t>(ctx->d_bz_out), ptr<uint32_t>(ctx->d_bz_crc), ptr<uint32_t>(ctx->d_bz_x2n), ptr<uint8_t>(ctx->d_bz_status) + b0);
 	return CONGA_OK;
 }
 

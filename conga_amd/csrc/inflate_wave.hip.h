@@ -38,8 +38,50 @@ constexpr int kLitRoot = 9, kDistRoot = 7, kPreRoot = 7;
 constexpr int kLitCap = 864, kDistCap = 128 + 528;
 constexpr int kMaxLens = 320;
 
-// entry: [3:0] bits consumed at this level (0: no codeword here); [5:4] kind; [15:6] value
-enum : uint32_t { kLiteral = 0, kSymbol = 1, kEndOfBlock = 2, kSubTable = 3 };
+// Table entries are 16 bits and made so that a lane gets from the stream's bits to "where does the symbol behind mine start"
+// in as few instructions as possible -- sixty-four lanes do that every trip, for the eight that turn out to be symbols.
+// An entry holds the WHOLE length of its codeword, also behind a second-level table, and the number of extra bits that
+// follow it; the base values of lengths and distances (needed only for the lanes that turn out to be symbols) come from
+// two small tables afterwards.
+struct LitFormat {
+	// [3:0] codeword length n1; [6:4] extra bits of a length symbol (0 for a literal); [7] length symbol;
+	// [15:8] literal byte / index of the length symbol (0..28).  [7] = 0 and [6:4] != 0: something that ends a chain --
+	enum : uint32_t { kEob = 0x10, kSub = 0x20, kHoleTag = 0x30 };
+	// kEob | n1: end of block; kSub | bits indexing the second-level table | (its offset behind the root / 2) << 8;
+	// kHoleTag: no codeword leads here (or one of the two that must not occur)
+	static constexpr uint32_t hole = kHoleTag;
+	__device__ static uint32_t entry(uint32_t sym, uint32_t len)
+	{
+		if (sym < 256u)
+			return len | (sym << 8);
+		if (sym == 256u)
+			return len | kEob;
+		const uint32_t i = sym - 257u;
+		if (i > 28u)
+			return hole; // 286, 287: in the fixed code, never in valid data
+		const uint32_t eb = (i < 8u || i == 28u) ? 0u : (i >> 2) - 1u;
+		return len | (eb << 4) | 0x80u | (i << 8);
+	}
+	// (second-level tables have 2^sb >= 2 entries each and follow one another behind the root: every offset is even)
+	__device__ static uint32_t pointer(uint32_t sb, uint32_t rel) { return sb | kSub | ((rel >> 1) << 8); }
+	__device__ static uint32_t pointer_start(uint32_t ptr) { return (ptr >> 8) << 1; }
+	__device__ static uint32_t pointer_bits(uint32_t ptr) { return ptr & 15u; }
+};
+struct DistFormat {
+	// [15:14] = 0: [4:0] codeword length + extra bits, [8:5] extra bits, [13:9] distance symbol (0..29)
+	// [15:14] = 1: [3:0] bits indexing the second-level table, [13:4] its offset behind the root;  [15:14] = 2: no codeword
+	static constexpr uint32_t hole = 0x8000u;
+	__device__ static uint32_t entry(uint32_t sym, uint32_t len)
+	{
+		if (sym > 29u)
+			return hole; // 30, 31: in the fixed code, never in valid data
+		const uint32_t deb = sym < 4u ? 0u : (sym >> 1) - 1u;
+		return (len + deb) | (deb << 5) | (sym << 9);
+	}
+	__device__ static uint32_t pointer(uint32_t sb, uint32_t rel) { return sb | (rel << 4) | 0x4000u; }
+	__device__ static uint32_t pointer_start(uint32_t ptr) { return (ptr >> 4) & 1023u; }
+	__device__ static uint32_t pointer_bits(uint32_t ptr) { return ptr & 15u; }
+};
 
 struct WaveLds {
 	uint16_t lit[kLitCap];
@@ -107,11 +149,7 @@ template <typename P> __device__ __forceinline__ uint64_t load_written_u64_unali
 	asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
 	return v;
 }
-// the same as a load the compiler knows about (it places the wait in front of the first use, which may be a whole trip later)
-template <typename P> __device__ __forceinline__ uint64_t load_written_u64_unaligned_async(P p)
-{
-	return __hip_atomic_load((__attribute__((address_space(1))) const uint64_t *) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+
 
 // ---- the stream, read uniformly (block headers, code lengths) ---------------------------------------------------------
 // 64 consecutive dwords of the input live in one register across the wave; a field is two v_readlane and a funnel shift.
@@ -142,9 +180,8 @@ struct Window {
 // Canonical Huffman code of lens[0..n) (RFC 1951 3.2.2) as a two-level table indexed by the next bits of the stream,
 // least significant bit first.  kind_of(sym) -> entry without the bit count.  false: over-subscribed, incomplete beyond
 // what zlib lets pass (a single one-bit code), or more second-level space than `cap` holds.
-template <int ROOT, typename EntryOf>
-__device__ __forceinline__ bool build_table(const uint8_t *lens, int n, uint16_t *table, int cap, uint16_t *sorted, bool allow_incomplete,
-		EntryOf entry_of)
+template <int ROOT, typename Fmt>
+__device__ __forceinline__ bool build_table(const uint8_t *lens, int n, uint16_t *table, int cap, uint16_t *sorted, bool allow_incomplete)
 {
 	const uint32_t lane = lane_id();
 	// how many symbols of each length: one ballot per length and 64 symbols
@@ -224,13 +261,13 @@ __device__ __forceinline__ bool build_table(const uint8_t *lens, int n, uint16_t
 		return false;
 	wave_sync();
 	for (uint32_t j = lane; j < (uint32_t) kRootSize + total; j += 64)
-		table[j] = 0;
+		table[j] = (uint16_t) Fmt::hole;
 	wave_sync();
 #pragma unroll
 	for (int k = 0; k < (kRootSize + 63) / 64; k++) {
 		const uint32_t p = lane * (uint32_t) ((kRootSize + 63) / 64) + (uint32_t) k;
 		if (my_sb[k])
-			table[p] = (uint16_t) (my_sb[k] | (kSubTable << 4) | (((uint32_t) kRootSize + (incl - mine) + my_start[k]) << 6));
+			table[p] = (uint16_t) Fmt::pointer(my_sb[k], (incl - mine) + my_start[k]);
 	}
 	wave_sync();
 	// every symbol fills the slots its codeword (and any bits behind it) leads to
@@ -247,28 +284,19 @@ __device__ __forceinline__ bool build_table(const uint8_t *lens, int n, uint16_t
 				o = offs[L];
 			}
 		const uint32_t rev = __brev(f + (r - o)) >> (32u - len);
-		const uint32_t e = entry_of(sym);
+		const uint32_t e = Fmt::entry(sym, len);
 		if (len <= (uint32_t) ROOT) {
 			for (uint32_t j = rev; j < (uint32_t) kRootSize; j += 1u << len)
-				table[j] = (uint16_t) (e | len);
+				table[j] = (uint16_t) e;
 		} else {
 			const uint32_t ptr = table[rev & (uint32_t) (kRootSize - 1)];
-			const uint32_t start = ptr >> 6, sb = ptr & 15u, l2 = len - (uint32_t) ROOT;
+			const uint32_t start = (uint32_t) kRootSize + Fmt::pointer_start(ptr), sb = Fmt::pointer_bits(ptr), l2 = len - (uint32_t) ROOT;
 			for (uint32_t j = rev >> ROOT; j < (1u << sb); j += 1u << l2)
-				table[start + j] = (uint16_t) (e | l2);
+				table[start + j] = (uint16_t) e;
 		}
 	}
 	wave_sync();
 	return true;
-}
-
-__device__ __forceinline__ uint32_t lit_entry(uint32_t sym)
-{
-	if (sym < 256u)
-		return (kLiteral << 4) | (sym << 6);
-	if (sym == 256u)
-		return kEndOfBlock << 4;
-	return (kSymbol << 4) | ((sym - 257u) << 6); // 286, 287 (fixed code only) decode to length symbols 29, 30: refused when met
 }
 
 // ---- one deflate block's symbols ---------------------------------------------------------------------------------------
@@ -284,18 +312,18 @@ struct Stream {
 // Base value and number of extra bits of the length symbols 257..285 (index 0..28; 29, 30: the fixed code's 286, 287,
 // refused) and of the distance symbols 0..29 (30, 31: refused) -- RFC 1951 3.2.5 -- computed, not tabulated by hand.
 struct Luts {
-	uint16_t len[32];  // base | extra << 9 ; 0xFFFF: not a symbol
-	uint32_t dist[32]; // base | extra << 16 ; 0xFFFFFFFF: not a symbol
+	uint16_t len[32];  // base value of length symbol 257 + i
+	uint16_t dist[32]; // base value of distance symbol i
 };
 
 __device__ __forceinline__ void fill_luts(Luts &l, uint32_t i /* 0..31 */)
 {
 	const uint32_t eb = (i < 8u || i >= 28u) ? 0u : (i >> 2) - 1u;
 	const uint32_t lbase = i < 8u ? 3u + i : i == 28u ? 258u : 3u + ((4u + (i & 3u)) << eb);
-	l.len[i] = i <= 28u ? (uint16_t) (lbase | (eb << 9)) : (uint16_t) 0xFFFFu;
+	l.len[i] = (uint16_t) lbase;
 	const uint32_t deb = i < 4u ? 0u : (i >> 1) - 1u;
 	const uint32_t dbase = i < 4u ? 1u + i : 1u + ((2u + (i & 1u)) << deb);
-	l.dist[i] = i <= 29u ? (dbase | (deb << 16)) : 0xFFFFFFFFu;
+	l.dist[i] = (uint16_t) dbase; // (<= 24 577; the entries of symbols that do not exist are never asked for: their codewords are holes)
 }
 
 template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_add(uint32_t v)
@@ -316,7 +344,6 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 }
 
 // 0: end-of-block symbol reached; -1: the stream is invalid
-template <int V>
 __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Luts &luts
 #ifdef IW_PROF
 		, unsigned long long *prof
@@ -348,31 +375,16 @@ __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Lu
 	uint32_t d0 = uni(ibit >> 5);
 	uint32_t wreg = load_window(d0);
 	// n <= 8 bytes of v to out[to..): dword / short / byte pieces (unaligned dword stores are fine in global memory)
+	// 3 <= n <= 8 bytes of v8 to out[to..): the first four and the last four as dwords (they may overlap: the same bytes), or a
+	// short and a byte (unaligned dword stores are fine in global memory)
 	auto store_pieces = [&](uint64_t v8, uint32_t to, uint32_t n) {
 		const GBytes q = s.out + to;
-		uint32_t done = 0;
 		if (n >= 4u) {
 			*(__attribute__((address_space(1))) uint32_t *) q = (uint32_t) v8;
-			done = 4;
-		}
-		if (n == 8u) {
-			*(__attribute__((address_space(1))) uint32_t *) (q + 4) = (uint32_t) (v8 >> 32);
-			done = 8;
-		}
-		if ((n - done) & 2u) {
-			*(__attribute__((address_space(1))) uint16_t *) (q + done) = (uint16_t) (v8 >> (8u * done));
-			done += 2;
-		}
-		if ((n - done) & 1u)
-			q[done] = (uint8_t) (v8 >> (8u * done));
-	};
-	uint64_t pend_v = 0;
-	uint32_t pend_to = 0, pend_n = 0; // this lane's short match of the trip before, loaded and not yet stored (V & 8)
-	auto flush_pending = [&]() {
-		if (__ballot(pend_n != 0u)) {
-			if (pend_n)
-				store_pieces(pend_v, pend_to, pend_n);
-			pend_n = 0;
+			*(__attribute__((address_space(1))) uint32_t *) (q + (n - 4u)) = (uint32_t) (v8 >> (8u * (n - 4u)));
+		} else {
+			*(__attribute__((address_space(1))) uint16_t *) q = (uint16_t) v8;
+			q[2] = (uint8_t) (v8 >> 16);
 		}
 	};
 	for (;;) {
@@ -393,67 +405,55 @@ __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Lu
 		const uint32_t w2 = (uint32_t) __builtin_amdgcn_ds_bpermute((int) at + 8, (int) wreg);
 		const uint32_t sh = b & 31u;
 		const uint32_t lo = alignbit(w1, w0, sh), hi = alignbit(w2, w1, sh);
-		// the literal / length code that would start here (second level read by every lane: some lane nearly always needs it)
+		// the literal / length code that would start here (second level read by every lane: some lane nearly always needs it;
+		// a lane that does not reads some other entry of the wave's tables and drops it)
 		const uint32_t e1 = t.lit[lo & ((1u << kLitRoot) - 1u)];
-		const bool sub1 = ((e1 >> 4) & 3u) == kSubTable;
-		const uint32_t e2 = t.lit[sub1 ? (e1 >> 6) + ((lo >> kLitRoot) & ((1u << (e1 & 15u)) - 1u)) : 0u];
+		const bool sub1 = (e1 & 0xF0u) == LitFormat::kSub;
+		const uint32_t e2 = t.lit[(1u << kLitRoot) + ((e1 >> 8) << 1) + ((lo >> kLitRoot) & ((1u << (e1 & 15u)) - 1u))];
 		const uint32_t e = sub1 ? e2 : e1;
-		const uint32_t n1 = (e & 15u) ? (e & 15u) + (sub1 ? (uint32_t) kLitRoot : 0u) : 0u;
-		const uint32_t kind = (e >> 4) & 3u, val = e >> 6;
-		// ... as a length: its extra bits, the distance code behind them and that one's extra bits
-		const uint32_t ll = luts.len[kind == kSymbol ? val & 31u : 0u];
-		const uint32_t eb = (ll >> 9) & 7u;
-		const uint64_t v = ((uint64_t) hi << 32) | lo;
-		const uint32_t length = (ll & 511u) + ((uint32_t) (v >> n1) & ((1u << eb) - 1u));
-		const uint32_t r2 = (uint32_t) (v >> (n1 + eb)); // distance code (<= 15 bits) and its extra bits (<= 13)
+		const uint32_t n1 = e & 15u, eb = (e >> 4) & 7u; // (eb: of a literal 0; of an entry that ends the chain, not used)
+		const bool is_match = (e & 0x80u) != 0u;
+		const bool special = ((e & 0xF0u) - 0x10u) < 0x30u; // end of block / hole
+		// ... as a length: its extra bits, the distance code behind them and that one's extra bits (<= 15 + 13 bits from bit n1 + eb <= 20)
+		const uint32_t r2 = alignbit(hi, lo, n1 + eb);
 		const uint32_t d1 = t.dist[r2 & ((1u << kDistRoot) - 1u)];
-		const bool subd = ((d1 >> 4) & 3u) == kSubTable;
-		const uint32_t d2 = t.dist[subd ? (d1 >> 6) + ((r2 >> kDistRoot) & ((1u << (d1 & 15u)) - 1u)) : 0u];
+		const bool subd = (d1 & 0xC000u) == 0x4000u;
+		const uint32_t d2 = t.dist[(1u << kDistRoot) + ((d1 >> 4) & 1023u) + ((r2 >> kDistRoot) & ((1u << (d1 & 15u)) - 1u))];
 		const uint32_t ed = subd ? d2 : d1;
-		const uint32_t n2 = (ed & 15u) ? (ed & 15u) + (subd ? (uint32_t) kDistRoot : 0u) : 0u;
-		const uint32_t dl = luts.dist[(ed >> 6) & 31u];
-		const uint32_t deb = (dl >> 16) & 15u;
-		const uint32_t dist = (dl & 0xFFFFu) + ((r2 >> n2) & ((1u << deb) - 1u));
-		const bool is_lit = kind == kLiteral, is_match = kind == kSymbol;
-		const bool bad = n1 == 0u || (is_match && (n2 == 0u || ll == 0xFFFFu || dl == 0xFFFFFFFFu));
-		const uint32_t bits = is_match ? n1 + eb + n2 + deb : n1;
-		const uint32_t nxt = lane + bits;                        // where the symbol behind this one starts
-		const uint32_t produced = bad ? 0u : is_lit ? 1u : is_match ? length : 0u;
+		// base values: asked for now, needed behind the walk
+		const uint32_t lbase = luts.len[(e >> 8) & 31u];
+		const uint32_t dbase = luts.dist[(ed >> 9) & 31u];
+		const uint32_t bits = max(is_match ? n1 + eb + (ed & 31u) : n1, 1u); // (never 0 by construction; the walk below must move)
+		const uint32_t nxt = lane + bits; // where the symbol behind this one starts
 		IW_LAP(P_VIEW);
 
 		// The chain of true symbol starts, from lane 0 on: J = "start of the next symbol" is doubled (J <- J o J) while the
 		// lanes known to be starts mark the lane their J points at (ds_permute pushes a flag there): after round k the first
 		// 2^(k+1) starts are known.  An end-of-block or invalid symbol ends the chain.
-		uint32_t J = (!bad && (is_lit || is_match) && nxt < 64u) ? nxt : 64u;
-		uint32_t on_chain;
-		unsigned long long chain;
-		if ((V & 1) == 0) {
-			on_chain = lane == 0u ? 1u : 0u;
-			for (;;) {
-				const bool push = on_chain && J < 64u;
-				on_chain |= (uint32_t) __builtin_amdgcn_ds_permute(push ? (int) (J << 2) : 0, push ? 1 : 0);
-				const uint32_t jj = (uint32_t) __builtin_amdgcn_ds_bpermute((int) ((J & 63u) << 2), (int) J);
-				J = J < 64u ? jj : 64u;
-				if (uni(J) >= 64u)
-					break;
-			}
-			chain = __ballot(on_chain != 0u);
-		} else {
-			// one v_readlane and four scalar instructions per symbol: the vector unit, which is what the waves of a SIMD
-			// compete for, sees one instruction per symbol
-			chain = 0;
+		uint32_t J = special ? 64u : min(nxt, 64u);
+		// one v_readlane and four scalar instructions per symbol: the vector unit, which is what the waves of a SIMD
+		// compete for, sees one instruction per symbol.  (Pointer doubling over the LDS crossbar -- J <- J o J while the known
+		// starts push a flag to the lane their J names -- needs four rounds of nine vector instructions for the same.)
+		unsigned long long chain = 0;
+		{
 			uint32_t cur = 0;
 			do {
 				chain |= 1ull << cur;
 				cur = (uint32_t) __builtin_amdgcn_readlane((int) J, (int) cur);
 			} while (cur < 64u);
-			on_chain = (uint32_t) ((chain >> lane) & 1ull);
 		}
-		const unsigned long long bad_m = chain & __ballot(bad);
-		if (bad_m)
+		const bool on_chain = ((chain >> lane) & 1ull) != 0ull;
+		// a hole, or a length whose distance is one: the stream is invalid (a hole ends the chain, a bad distance is met on it)
+		const bool bad = (e & 0xF0u) == LitFormat::kHoleTag || (is_match && (ed & 0x8000u) != 0u);
+		if (chain & __ballot(bad))
 			return leave(-1);
 		const unsigned long long match_m = chain & __ballot(is_match);
-		const bool ends = (chain & __ballot(kind == kEndOfBlock)) != 0ull;
+		const bool ends = (chain & __ballot((e & 0xF0u) == LitFormat::kEob)) != 0ull;
+		const bool is_lit = (e & 0xF0u) == 0u;
+		const uint32_t val = e >> 8;
+		const uint32_t deb = (ed >> 5) & 15u;
+		const uint32_t dist = dbase + ((r2 >> ((ed & 31u) - deb)) & ((1u << deb) - 1u));
+		const uint32_t produced = is_match ? lbase + ((lo >> n1) & ((1u << eb) - 1u)) : is_lit ? 1u : 0u;
 		IW_LAP(P_WALK);
 		// where every start's bytes go
 		const uint32_t mine = on_chain ? produced : 0u;
@@ -465,8 +465,6 @@ __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Lu
 		IW_ADD(P_SYMS, (uint32_t) __popcll(chain));
 		if (opos + total > out_len)
 			return leave(-1);
-		if (V & 8)
-			flush_pending();
 		if (on_chain && is_lit)
 			s.out[opos + incl - 1u] = (uint8_t) val;
 		IW_LAP(P_LITS);
@@ -478,22 +476,7 @@ __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Lu
 			const uint32_t to_l = opos + incl - produced, src_l = to_l - dist;
 			const bool fast = on_chain && is_match && produced <= 8u && dist >= produced && dist <= to_l && src_l + produced <= safe_pos;
 			const unsigned long long fast_m = __ballot(fast);
-			if (V & 8) {
-				// (V & 8) the bytes are asked for now and stored one trip later, behind the next trip's look-ups and walk: the load's
-				// way to L2 and back is not waited for.  Nothing can ask for these bytes in between: they lie above safe_pos
-				// until a wait moves it, and every such wait comes behind a flush.
-				if (fast_m) {
-					if (fast) {
-						pend_v = load_written_u64_unaligned_async(s.out + src_l);
-						pend_to = to_l;
-						pend_n = produced;
-					}
-					IW_ADD(P_MATCHES, (uint32_t) __popcll(fast_m));
-					mm &= ~fast_m;
-					if (mm)
-						flush_pending();
-				}
-			} else if (fast_m) {
+			if (fast_m) {
 				if (fast)
 					store_pieces(load_written_u64_unaligned(s.out + src_l), to_l, produced);
 				IW_ADD(P_MATCHES, (uint32_t) __popcll(fast_m));
@@ -538,15 +521,12 @@ __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Lu
 		}
 		opos += total;
 		ibit += advance;
-		if (ends) {
-			if (V & 8)
-				flush_pending();
+		if (ends)
 			return leave(ibit > end_bit ? -1 : 0);
-		}
 	}
 }
 
-// The symbol loop as a function of its own (V & 4): its registers are then allocated for the loop alone, not together with
+// The symbol loop as a function of its own: its registers are then allocated for the loop alone, not together with
 // everything a block's set-up keeps alive around it.  Arguments and results travel in registers; the tables are named by
 // their LDS addresses, so that the accesses stay ds_ instructions.
 struct SymbolsOut {
@@ -556,7 +536,6 @@ struct SymbolsOut {
 typedef __attribute__((address_space(3))) const WaveLds *LdsTables;
 typedef __attribute__((address_space(3))) const Luts *LdsLuts;
 
-template <int V>
 __device__ __attribute__((noinline)) SymbolsOut run_symbols_call(GWords in32, GBytes out, uint32_t ibit, uint32_t end_bit, uint32_t opos,
 		uint32_t out_len, uint32_t safe_pos, uint32_t tables_at, uint32_t luts_at)
 {
@@ -573,7 +552,7 @@ __device__ __attribute__((noinline)) SymbolsOut run_symbols_call(GWords in32, GB
 	const WaveLds &t = *(const WaveLds *) (LdsTables) (uintptr_t) uni(tables_at);
 	const Luts &luts = *(const Luts *) (LdsLuts) (uintptr_t) uni(luts_at);
 	SymbolsOut o;
-	o.rc = run_symbols<V>(s, t, luts);
+	o.rc = run_symbols(s, t, luts);
 	o.ibit = s.ibit;
 	o.opos = s.opos;
 	o.safe_pos = s.safe_pos;
@@ -634,7 +613,6 @@ __device__ __forceinline__ uint32_t wave_crc32(const uint8_t *out, uint32_t n, c
 enum { kStatusOk = 0, kStatusRefused = 1, kStatusCrc = 2 };
 
 // One whole BGZF block (a raw deflate stream of one or more deflate blocks) by one wave.
-template <int V>
 __device__ __forceinline__ int inflate_block(WaveLds &t, const Luts &luts, const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len
 #ifdef IW_PROF
 		, unsigned long long *prof
@@ -790,26 +768,24 @@ __device__ __forceinline__ int inflate_block(WaveLds &t, const Luts &luts, const
 					return kStatusRefused;
 			}
 			IW_T0();
-			if (!build_table<kLitRoot>(t.lens, n_lit, t.lit, kLitCap, t.sorted, true, [](uint32_t sym) { return lit_entry(sym); }))
+			if (!build_table<kLitRoot, LitFormat>(t.lens, n_lit, t.lit, kLitCap, t.sorted, true))
 				return kStatusRefused;
-			if (!build_table<kDistRoot>(t.lens + n_lit, n_dist, t.dist, kDistCap, t.sorted, true,
-					[](uint32_t sym) { return (kSymbol << 4) | (sym << 6); }))
+			if (!build_table<kDistRoot, DistFormat>(t.lens + n_lit, n_dist, t.dist, kDistCap, t.sorted, true))
 				return kStatusRefused;
 			IW_LAP(P_TABLES);
 #ifdef IW_PROF
-			if (run_symbols<V>(s, t, luts, prof) != 0)
+			if (run_symbols(s, t, luts, prof) != 0)
 				return kStatusRefused;
 #else
-			if (V & 4) {
-				const SymbolsOut o = run_symbols_call<V>(s.in32, s.out, s.ibit, s.end_bit, s.opos, s.out_len, s.safe_pos,
+			{
+				const SymbolsOut o = run_symbols_call(s.in32, s.out, s.ibit, s.end_bit, s.opos, s.out_len, s.safe_pos,
 						(uint32_t) (uintptr_t) (LdsTables) &t, (uint32_t) (uintptr_t) (LdsLuts) &luts);
 				s.ibit = o.ibit;
 				s.opos = o.opos;
 				s.safe_pos = o.safe_pos;
 				if (o.rc != 0)
 					return kStatusRefused;
-			} else if (run_symbols<V>(s, t, luts) != 0)
-				return kStatusRefused;
+			}
 #endif
 			win.d0 = 0xFFFFFF00u; // (the position moved on behind the window's back: force a reload)
 		} else
@@ -823,8 +799,7 @@ __device__ __forceinline__ int inflate_block(WaveLds &t, const Luts &luts, const
 constexpr int kWavesPerGroup = 4;
 
 // status[b]: kStatusOk / kStatusRefused / kStatusCrc.  Waves take blocks round robin.
-template <int V>
-__global__ __launch_bounds__(64 * kWavesPerGroup, (V & 2) ? 7 : 8) void bgzf_inflate_wave_kernel(uint32_t n_blocks, const uint8_t *__restrict__ bytes,
+__global__ __launch_bounds__(64 * kWavesPerGroup, 8) void bgzf_inflate_wave_kernel(uint32_t n_blocks, const uint8_t *__restrict__ bytes,
 		const conga_bgzf_block *__restrict__ blocks, const uint64_t *__restrict__ out_off, uint8_t *out,
 		const uint32_t *__restrict__ crc_table, const uint32_t *__restrict__ x2n, uint8_t *__restrict__ status)
 {
@@ -846,10 +821,10 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, (V & 2) ? 7 : 8) void bgzf_inf
 		uint8_t *dst = out + out_off[b];
 #ifdef IW_PROF
 		unsigned long long prof[P_N] = {};
-		int st = inflate_block<V>(lds[wave], s_luts, bytes + bl.data_off, bl.data_len, dst, bl.inflated_len, prof);
+		int st = inflate_block(lds[wave], s_luts, bytes + bl.data_off, bl.data_len, dst, bl.inflated_len, prof);
 		IW_T0();
 #else
-		int st = inflate_block<V>(lds[wave], s_luts, bytes + bl.data_off, bl.data_len, dst, bl.inflated_len);
+		int st = inflate_block(lds[wave], s_luts, bytes + bl.data_off, bl.data_len, dst, bl.inflated_len);
 #endif
 		if (st == kStatusOk) {
 			asm volatile("" ::: "memory");

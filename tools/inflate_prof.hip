@@ -10,9 +10,6 @@
 #include <vector>
 
 #include "../conga_amd/csrc/inflate_wave.hip.h"
-#ifndef IW_VARIANT
-#define IW_VARIANT 0
-#endif
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -95,7 +92,7 @@ int main(int argc, char **argv)
 #endif
 		const unsigned groups = (unsigned) std::min<size_t>((n + 3) / 4, 256 * 8);
 		CHECK(hipEventRecord(e0));
-		hipLaunchKernelGGL(conga::iw::bgzf_inflate_wave_kernel<IW_VARIANT>, dim3(groups), dim3(256), 0, 0, n, d_in, d_blocks, d_off, d_out, d_crc, d_x2n, d_status);
+		hipLaunchKernelGGL(conga::iw::bgzf_inflate_wave_kernel, dim3(groups), dim3(256), 0, 0, n, d_in, d_blocks, d_off, d_out, d_crc, d_x2n, d_status);
 		CHECK(hipEventRecord(e1));
 		CHECK(hipEventSynchronize(e1));
 		float ms;
