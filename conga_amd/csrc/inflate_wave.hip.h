@@ -93,7 +93,7 @@ struct WaveLds {
 
 #ifdef IW_PROF
 // tools/inflate_prof.hip: where a wave's time goes (s_memtime ticks per phase, summed per wave; lane 0 adds them up)
-enum { P_VIEW = 0, P_WALK, P_LITS, P_MATCH_WAIT, P_MATCH_COPY, P_TABLES, P_CRC, P_TRIPS, P_MATCHES, P_WAITS, P_SYMS, P_N };
+enum { P_VIEW = 0, P_WALK, P_LITS, P_MATCH_WAIT, P_MATCH_COPY, P_TABLES, P_CRC, P_TRIPS, P_MATCHES, P_WAITS, P_SYMS, P_SLOW, P_SLOW_BYTES, P_SLOW_LONG, P_SLOW_OVERLAP, P_N };
 __device__ unsigned long long g_prof[P_N];
 #define IW_T0() unsigned long long t_prof_ = __builtin_readcyclecounter()
 #define IW_LAP(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); prof[k] += n_ - t_prof_; t_prof_ = n_; } while (0)
@@ -413,7 +413,6 @@ __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Lu
 		const uint32_t e = sub1 ? e2 : e1;
 		const uint32_t n1 = e & 15u, eb = (e >> 4) & 7u; // (eb: of a literal 0; of an entry that ends the chain, not used)
 		const bool is_match = (e & 0x80u) != 0u;
-		const bool special = ((e & 0xF0u) - 0x10u) < 0x30u; // end of block / hole
 		// ... as a length: its extra bits, the distance code behind them and that one's extra bits (<= 15 + 13 bits from bit n1 + eb <= 20)
 		const uint32_t r2 = alignbit(hi, lo, n1 + eb);
 		const uint32_t d1 = t.dist[r2 & ((1u << kDistRoot) - 1u)];
@@ -430,7 +429,8 @@ __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Lu
 		// The chain of true symbol starts, from lane 0 on: J = "start of the next symbol" is doubled (J <- J o J) while the
 		// lanes known to be starts mark the lane their J points at (ds_permute pushes a flag there): after round k the first
 		// 2^(k+1) starts are known.  An end-of-block or invalid symbol ends the chain.
-		uint32_t J = special ? 64u : min(nxt, 64u);
+		const uint32_t cls = e & 0xF0u;
+		const unsigned long long eob_m = __ballot(cls == LitFormat::kEob), hole_m = __ballot(cls == LitFormat::kHoleTag);
 		// one v_readlane and four scalar instructions per symbol: the vector unit, which is what the waves of a SIMD
 		// compete for, sees one instruction per symbol.  (Pointer doubling over the LDS crossbar -- J <- J o J while the known
 		// starts push a flag to the lane their J names -- needs four rounds of nine vector instructions for the same.)
@@ -439,17 +439,22 @@ __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Lu
 			uint32_t cur = 0;
 			do {
 				chain |= 1ull << cur;
-				cur = (uint32_t) __builtin_amdgcn_readlane((int) J, (int) cur);
+				cur = (uint32_t) __builtin_amdgcn_readlane((int) nxt, (int) cur);
 			} while (cur < 64u);
 		}
-		const bool on_chain = ((chain >> lane) & 1ull) != 0ull;
+		// an end-of-block symbol or a hole ends the chain where it stands (the walk went on behind it: cut)
+		{
+			const unsigned long long stop = chain & (eob_m | hole_m);
+			if (stop)
+				chain &= (2ull << __builtin_ctzll(stop)) - 1ull;
+		}
+		const bool on_chain = __builtin_amdgcn_inverse_ballot_w64(chain);
 		// a hole, or a length whose distance is one: the stream is invalid (a hole ends the chain, a bad distance is met on it)
-		const bool bad = (e & 0xF0u) == LitFormat::kHoleTag || (is_match && (ed & 0x8000u) != 0u);
-		if (chain & __ballot(bad))
-			return leave(-1);
 		const unsigned long long match_m = chain & __ballot(is_match);
-		const bool ends = (chain & __ballot((e & 0xF0u) == LitFormat::kEob)) != 0ull;
-		const bool is_lit = (e & 0xF0u) == 0u;
+		if ((chain & hole_m) | (match_m & __ballot((ed & 0x8000u) != 0u)))
+			return leave(-1);
+		const bool ends = (chain & eob_m) != 0ull;
+		const bool is_lit = cls == 0u;
 		const uint32_t val = e >> 8;
 		const uint32_t deb = (ed >> 5) & 15u;
 		const uint32_t dist = dbase + ((r2 >> ((ed & 31u) - deb)) & ((1u << deb) - 1u));
@@ -474,7 +479,8 @@ __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Lu
 		unsigned long long mm = match_m;
 		{
 			const uint32_t to_l = opos + incl - produced, src_l = to_l - dist;
-			const bool fast = on_chain && is_match && produced <= 8u && dist >= produced && dist <= to_l && src_l + produced <= safe_pos;
+			// (a distance that reaches in front of the output makes src_l wrap: far above safe_pos, and the loop below refuses it)
+			const bool fast = on_chain && is_match && produced <= 8u && dist >= produced && src_l + produced <= safe_pos;
 			const unsigned long long fast_m = __ballot(fast);
 			if (fast_m) {
 				if (fast)
@@ -502,6 +508,10 @@ __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Lu
 			}
 			IW_LAP(P_MATCH_WAIT);
 			IW_ADD(P_MATCHES, 1);
+			IW_ADD(P_SLOW, 1);
+			IW_ADD(P_SLOW_BYTES, len);
+			IW_ADD(P_SLOW_LONG, len > 8u ? 1 : 0);
+			IW_ADD(P_SLOW_OVERLAP, d < len ? 1 : 0);
 			if (d >= len) {
 				for (uint32_t k = lane; k < len; k += 64u)
 					s.out[to + k] = (uint8_t) load_written_u8(s.out + src + k);
@@ -526,6 +536,7 @@ __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Lu
 	}
 }
 
+#ifndef IW_PROF
 // The symbol loop as a function of its own: its registers are then allocated for the loop alone, not together with
 // everything a block's set-up keeps alive around it.  Arguments and results travel in registers; the tables are named by
 // their LDS addresses, so that the accesses stay ds_ instructions.
@@ -558,6 +569,8 @@ __device__ __attribute__((noinline)) SymbolsOut run_symbols_call(GWords in32, GB
 	o.safe_pos = s.safe_pos;
 	return o;
 }
+
+#endif
 
 // ---- CRC-32 (reflected, polynomial 0xEDB88320) over GF(2) ---------------------------------------------------------------
 // a(x) * b(x) mod P in the reflected representation (bit 31 = x^0)

@@ -8,7 +8,7 @@ for flags in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 $flags -o /tmp/iwexp $R/tools/inflate_prof.hip 2>/dev/null
   echo "== $flags"
   case "$flags" in
-  *IW_PROF*) timeout -k 10 120 /tmp/iwexp $B 1 | tail -9; timeout -k 10 120 /tmp/iwexp $B 8000 | tail -9 ;;
+  *IW_PROF*) timeout -k 10 120 /tmp/iwexp $B 1 | tail -10; timeout -k 10 120 /tmp/iwexp $B 8000 | tail -10 ;;
   *) timeout -k 10 120 /tmp/iwexp $B | grep -v "^  " | tail -1; timeout -k 10 120 /tmp/iwexp $B 8000 | grep -v "^  " | tail -1 ;;
   esac
 done

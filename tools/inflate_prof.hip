@@ -112,6 +112,9 @@ int main(int argc, char **argv)
 		printf("  per block: %.0f trips, %.0f symbols (%.2f per trip), %.0f matches, %.0f store waits\n", (double) p[conga::iw::P_TRIPS] / n,
 				(double) p[conga::iw::P_SYMS] / n, (double) p[conga::iw::P_SYMS] / (double) p[conga::iw::P_TRIPS], (double) p[conga::iw::P_MATCHES] / n,
 				(double) p[conga::iw::P_WAITS] / n);
+		printf("  per block: %.0f matches one after the other (%.0f longer than 8 bytes, %.0f overlapping themselves), %.0f bytes\n",
+				(double) p[conga::iw::P_SLOW] / n, (double) p[conga::iw::P_SLOW_LONG] / n, (double) p[conga::iw::P_SLOW_OVERLAP] / n,
+				(double) p[conga::iw::P_SLOW_BYTES] / n);
 		unsigned long long sum = 0;
 		for (int k = 0; k < 7; k++)
 			sum += p[k];
