@@ -675,7 +675,10 @@ public:
 			std::sort(starts.begin(), starts.end());
 			starts.erase(std::unique(starts.begin(), starts.end()), starts.end());
 			const int n_threads = std::min(16, std::max(1, usable_cpus() / reader_share()));
-			if (n_threads > 1 && starts.size() >= (size_t) n_threads * 4 && bytes->size > (64u << 20)) {
+			// (CONGA_BAM_PARALLEL_MIN_KB: the tests walk small files in parts too)
+			const char *min_kb = getenv("CONGA_BAM_PARALLEL_MIN_KB");
+			const size_t min_bytes = min_kb ? (size_t) atoll(min_kb) << 10 : (size_t) 64 << 20;
+			if (n_threads > 1 && starts.size() >= (size_t) n_threads * 4 && bytes->size > min_bytes) {
 				std::vector<size_t> cut{0}; // piece offsets of the parts' starts
 				for (int k = 1; k < n_threads; k++)
 					cut.push_back((size_t) (starts[starts.size() * (size_t) k / (size_t) n_threads] - c_lo));
@@ -697,6 +700,8 @@ public:
 				if (walked)
 					for (size_t k = 0; k < parts; k++)
 						all.insert(all.end(), got[k].begin(), got[k].end());
+				if (getenv("CONGA_TIMING"))
+					fprintf(stderr, "[timing] block table: %zu parts walked side by side%s\n", parts, walked ? "" : " (a part did not arrive at the next one's start: walked from the front instead)");
 			}
 		}
 		if (!walked) {

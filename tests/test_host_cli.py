@@ -309,10 +309,13 @@ def test_cli_bam_decoded_on_the_gpu_matches_the_host_decoders(tmp_path, oracle):
     # this small file with 8 KB pieces, and the plain form; the round-1 kernel (one block per lane) once more
     for tag, env in (("ovl", dict(CONGA_BGZF_OVERLAP="1", CONGA_BGZF_PIECE_KB="8")), ("ovl1", dict(CONGA_BGZF_OVERLAP="1", CONGA_BGZF_PIECE_KB="8", CONGA_BGZF_COPY_THREADS="1")),
                      ("plain", dict(CONGA_BGZF_OVERLAP="0")), ("lane", dict(CONGA_BGZF_KERNEL="lane")),
-                     ("mapped", dict(CONGA_BAM_MMAP="1")), ("ovlmap", dict(CONGA_BAM_MMAP="1", CONGA_BGZF_OVERLAP="1", CONGA_BGZF_PIECE_KB="8"))):
+                     ("mapped", dict(CONGA_BAM_MMAP="1")), ("ovlmap", dict(CONGA_BAM_MMAP="1", CONGA_BGZF_OVERLAP="1", CONGA_BGZF_PIECE_KB="8")),
+                     # the block table walked in parts from block starts the index knows (as for files above 64 MB), read with pread and mapped
+                     ("parts", dict(CONGA_BAM_PARALLEL_MIN_KB="0")), ("partsmap", dict(CONGA_BAM_PARALLEL_MIN_KB="0", CONGA_BAM_MMAP="1"))):
         r_x, x = cli(tag, CONGA_GPU_BAM="1", CONGA_TIMING="1", **env)
         assert x == gpu and "decoding on the host" not in r_x.stderr and r_x.stderr.count("conga_reads_bgzf:") == 1, tag
         assert ("overlapped" in r_x.stderr) == tag.startswith("ovl"), tag
+        assert ("parts walked side by side\n" in r_x.stderr) == tag.startswith("parts"), (tag, r_x.stderr[-1500:])
     # a piece limit below the whole stretch but above each chromosome's: one GPU call per chromosome instead of one for all
     size = os.path.getsize(os.path.join(d, "r.bam"))
     r_each, each = cli("each", CONGA_GPU_BAM="1", CONGA_TIMING="1", CONGA_GPU_BAM_MAX_MB="%.4f" % (size * 0.75 / 1048576))
@@ -346,12 +349,24 @@ def test_cli_bam_decoded_on_the_gpu_matches_the_host_decoders(tmp_path, oracle):
     (n_intv,) = struct.unpack_from("<i", bai, at)
     at += 4
     lin = list(struct.unpack_from("<%dQ" % n_intv, bai, at))
+    lin0 = list(lin)
     for w in range(n_intv // 2, n_intv):
         lin[w] = lin[min(n_intv - 1, w + 7)]
     struct.pack_into("<%dQ" % n_intv, bai, at, *lin)
     open(os.path.join(d, "r.bam.bai"), "wb").write(bytes(bai))
     r_bad, bad = cli("bad", CONGA_BAM_SEGMENTS="6", CONGA_GPU_BAM="1")
     assert "decoding on the host" in r_bad.stderr and bad == gpu
+    # one linear offset that is not a block's start at all: the part of the block table that starts there does not find a
+    # block (or does not arrive at the next part's start), the table is walked from the front, and whatever the GPU stage
+    # makes of that start point, the files are right
+    lin2 = list(lin0)
+    used = [w for w in range(n_intv) if lin0[w] != 0]
+    for w in used[len(used) // 3: 2 * len(used) // 3]:
+        lin2[w] = lin0[w] + (3 << 16)
+    struct.pack_into("<%dQ" % n_intv, bai, at, *lin2)
+    open(os.path.join(d, "r.bam.bai"), "wb").write(bytes(bai))
+    r_odd, odd = cli("odd", CONGA_GPU_BAM="1", CONGA_TIMING="1", CONGA_BAM_PARALLEL_MIN_KB="0")
+    assert odd == gpu and "walked from the front instead" in r_odd.stderr, r_odd.stderr[-1500:]
 
 
 @pytest.mark.gpu
