@@ -2256,12 +2256,13 @@ __device__ __forceinline__ int is_satellite_dev(const SplitArgs &a, int64_t lo_,
 // read's own locus) are then compared by the whole wave, lane j on base j -- one coalesced load of the reference per 64
 // bases instead of one lane walking the bases with a dependent load each (which was 85 % of this path's time).
 // Hits are recorded in bucket order, as the reference's scan finds them.
-// [b0, b1): the seed's bucket; p_first: this lane's entry of its first 64 positions, fetched by the caller (the forward
-// and the reverse-complement scan of a half ask for their bucket bounds, and then for their first positions, together:
-// two trips to HBM instead of four).
+// [b0, b1): the seed's bucket; p_first: this lane's entry of its first 64 positions, fetched by the caller (all four scans
+// of a read -- two halves, forward and reverse complement -- ask for their bucket bounds, and then for their first
+// positions, together).  refw: the reference under the read, [win_lo, win_lo + win_len), fetched with the record's
+// sequence: the candidate that is the read's own locus -- nearly every candidate -- is compared without a trip to memory.
 __device__ __forceinline__ int split_scan_bucket(const SplitArgs &a, const uint8_t *str, int n, int anchor, int dist_max,
 		char orient, int size, int32_t *hit_pos, char *hit_orient, int lane, bool stop_past_max, uint32_t b0, uint32_t b1,
-		int p_first)
+		int p_first, const uint8_t *refw, int win_lo, int win_len)
 {
 	for (uint32_t base = b0; base < b1; base += kWave) {
 		const uint32_t k = base + lane;
@@ -2279,11 +2280,19 @@ __device__ __forceinline__ int split_scan_bucket(const SplitArgs &a, const uint8
 			cand &= cand - 1ull;
 			const int pc = __builtin_amdgcn_readlane(p, src);
 			int dist = 0;
-			for (int j0 = 0; j0 < n; j0 += kWave) {
-				const int j = j0 + lane;
-				const int64_t at = (int64_t) pc + j;
-				const bool mism = j < n && (at >= a.L || a.ref[at] != str[j]); // hammingDistance (common.c:278-287)
-				dist += __popcll(__ballot(mism));
+			if (pc >= win_lo && pc + n <= win_lo + win_len) { // (wave-uniform) under the read: from LDS
+				const uint8_t *w = refw + (pc - win_lo);
+				for (int j0 = 0; j0 < n; j0 += kWave) {
+					const int j = j0 + lane;
+					dist += __popcll(__ballot(j < n && w[j] != str[j])); // (bases behind the chromosome's end are 0 here: a mismatch)
+				}
+			} else {
+				for (int j0 = 0; j0 < n; j0 += kWave) {
+					const int j = j0 + lane;
+					const int64_t at = (int64_t) pc + j;
+					const bool mism = j < n && (at >= a.L || a.ref[at] != str[j]); // hammingDistance (common.c:278-287)
+					dist += __popcll(__ballot(mism));
+				}
 			}
 			if (dist <= dist_max) {
 				if (size < kMaxMapping && lane == 0) {
@@ -2329,31 +2338,102 @@ __device__ __forceinline__ SplitArgs split_view(const SplitBatchArgs &g, const S
 	return a;
 }
 
-// find_split_reads + read_SplitReads + determine_SvType + count_ReadPairs for one read, by one wave.  A read is a dozen
-// dependent trips to HBM (record -> sequence -> bucket bounds -> bucket -> reference, per half), so the register budget
-// of the kernel below is set for 8 waves per SIMD: at the 98 registers the compiler would otherwise take, 4 waves fit and
-// the launch is 10 % slower (the few spilled values are off the inner loops).
-__device__ __forceinline__ void split_read_one(const SplitArgs &a, int64_t r, uint8_t *str, uint8_t *rev, uint8_t *ql, int32_t *hit_pos,
-		char *hit_orient, int lane, unsigned long long &n_elem, unsigned long long &n_map, unsigned long long &n_del,
+// find_split_reads + read_SplitReads + determine_SvType + count_ReadPairs for one read, by one wave.  A read is a chain
+// of dependent trips to HBM, and the launch is as long as that chain times the reads a wave gets, so the function is laid
+// out by trips: (1) the record's fields and where its data lies; (2) qualities, sequence and the reference under the read
+// in one go, the satellite question about the read's start travelling with them; (3) the bucket bounds of all four seeds
+// (two halves, forward and reverse complement); (4) the first 64 positions of the four buckets.  The candidate that is
+// the read's own locus is compared with the reference fetched in (2).  (Round 2's first version: record -> data offset ->
+// qualities -> satellite search -> per half: sequence -> bucket bounds -> positions -> reference, and two more satellite
+// searches per mapping: ~22 trips.)  The register budget of the kernel below is set for 8 waves per SIMD.
+__device__ __forceinline__ void split_read_one(const SplitArgs &a, int64_t r, uint8_t *bases, uint8_t *rev, uint8_t *ql, uint8_t *refw,
+		int32_t *hit_pos, char *hit_orient, int lane, unsigned long long &n_elem, unsigned long long &n_map, unsigned long long &n_del,
 		unsigned long long &n_dup)
 {
 	{
 		const int l = a.l_qseq[r], p = a.pos[r], q = a.mapq[r], fl = a.flag[r];
+		const uint64_t d_off = a.data_off[r];
 		// gate of count_reads_bam (bam_data.c:205-207) and find_split_reads' pos == 0 (split_read.c:216)
 		if (!(q > a.mq_threshold) || !(l > a.min_read_length) || (fl & (0x100 | 0x800 | 0x400 | 0x200)) != 0)
 			return;
-		if (p == 0 || l > 2 * kSrMaxHalf - 2 || is_satellite_dev(a, p, (int64_t) p + 20))
+		if (p == 0 || l > 2 * kSrMaxHalf - 2)
 			return;
-		const uint8_t *sq = a.data + a.data_off[r];
+		const uint8_t *sq = a.data + d_off;
 		const uint8_t *qq = sq + (l + 1) / 2;
 		const int half = l / 2;
+		// trip 2: the first 128 bases' worth of everything is asked for before anything is waited for
+		auto letter = [](int code) -> uint8_t { return code == 1 ? 'A' : code == 2 ? 'C' : code == 4 ? 'G' : code == 8 ? 'T' : 'N'; }; // bam_seqi
+		const int i0 = lane, i1 = lane + kWave;
+		uint8_t q0 = 0, q1 = 0, s0 = 0, s1 = 0, r0b = 0, r1b = 0;
+		if (i0 < l) {
+			q0 = qq[i0];
+			s0 = sq[i0 >> 1];
+			r0b = ((int64_t) p + i0 < a.L) ? a.ref[(int64_t) p + i0] : (uint8_t) 0;
+		}
+		if (i1 < l) {
+			q1 = qq[i1];
+			s1 = sq[i1 >> 1];
+			r1b = ((int64_t) p + i1 < a.L) ? a.ref[(int64_t) p + i1] : (uint8_t) 0;
+		}
+		const int sat = is_satellite_dev(a, p, (int64_t) p + 20);
+		if (sat)
+			return;
 		__builtin_amdgcn_wave_barrier();
-		for (int i = lane; i < l; i += kWave)
+		if (i0 < l) {
+			ql[i0] = q0;
+			bases[i0] = letter((i0 & 1) ? (s0 & 0xF) : (s0 >> 4));
+			refw[i0] = r0b;
+		}
+		if (i1 < l) {
+			ql[i1] = q1;
+			bases[i1] = letter((i1 & 1) ? (s1 & 0xF) : (s1 >> 4));
+			refw[i1] = r1b;
+		}
+		for (int i = lane + 2 * kWave; i < l; i += kWave) { // (reads above 128 bases)
+			const uint8_t sb = sq[i >> 1];
 			ql[i] = qq[i];
+			bases[i] = letter((i & 1) ? (sb & 0xF) : (sb >> 4));
+			refw[i] = ((int64_t) p + i < a.L) ? a.ref[(int64_t) p + i] : (uint8_t) 0;
+		}
 		__builtin_amdgcn_wave_barrier();
+		// trips 3 and 4: the seeds of both halves in both orientations.  Element 1 maps bases [l/2, l), element 2 bases [0, l/2);
+		// the reverse complement's seed is the complement of the half's last ten bases, read backwards.
+		auto comp = [](uint8_t c) -> uint8_t { return c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'G' ? 'C' : c == 'C' ? 'G' : 'N'; };
+		uint32_t bk0[2][2] = {{0, 0}, {0, 0}}, bk1[2][2] = {{0, 0}, {0, 0}}; // [element][forward, reverse]: the seed's bucket (a seed with a letter outside ACGT has none)
+#pragma unroll
+		for (int e = 0; e < 2; e++) {
+			const int from = (e == 0) ? half : 0, n = (e == 0) ? l - half : half;
+			if (n < kKmerLen)
+				continue;
+			// both seeds' hashes (split_read.c:37-49: two bits per base, (c & 6) >> 1, first base in the highest bits) by forty
+			// lanes: lane j < 20 holds bit 19 - j of the forward seed's hash, lane 20 + j that of the reverse complement's
+			// (complementing a base flips bit 1 of its code: A 0 <-> T 2, C 1 <-> G 3); two ballots instead of twenty serial steps
+			const int j = lane < 20 ? lane : lane - 20, k = j >> 1;
+			const uint8_t c = lane < 40 ? bases[lane < 20 ? from + k : from + n - 1 - k] : (uint8_t) 'A';
+			const uint32_t code = (((uint32_t) c & 6u) >> 1) ^ (lane < 20 ? 0u : 2u);
+			const unsigned long long bit_m = __ballot(lane < 40 && ((code >> (1 - (j & 1))) & 1u) != 0u);
+			const unsigned long long bad_m = __ballot(lane < 40 && !is_dna_letter(c));
+			const int h_fwd = (bad_m & 0xFFFFFull) ? -1 : (int) (__brev((uint32_t) bit_m & 0xFFFFFu) >> 12);
+			const int h_rev = ((bad_m >> 20) & 0xFFFFFull) ? -1 : (int) (__brev((uint32_t) (bit_m >> 20) & 0xFFFFFu) >> 12);
+			if (h_fwd >= 0) {
+				bk0[e][0] = a.offset[h_fwd];
+				bk1[e][0] = a.offset[h_fwd + 1];
+			}
+			if (h_rev >= 0) {
+				bk0[e][1] = a.offset[h_rev];
+				bk1[e][1] = a.offset[h_rev + 1];
+			}
+		}
+		int p_first[2][2];
+#pragma unroll
+		for (int e = 0; e < 2; e++)
+#pragma unroll
+			for (int o = 0; o < 2; o++)
+				p_first[e][o] = (bk0[e][o] + (uint32_t) lane < bk1[e][o]) ? a.positions[bk0[e][o] + lane] : 0;
 
 		float avg = 0.0f;
-		for (int e = 0; e < 2; e++) {
+#pragma unroll 1
+		for (int e = 0; e < 2; e++) { // (one copy of the code: the two elements' copies side by side cost 50 more registers)
 			// element 1: anchor pos, maps bases [l/2, l); element 2: anchor pos + l/2, maps [0, l/2)
 			const int from = (e == 0) ? half : 0, n = (e == 0) ? l - half : half;
 			const int anchor = (e == 0) ? p : p + half;
@@ -2380,33 +2460,23 @@ __device__ __forceinline__ void split_read_one(const SplitArgs &a, int64_t r, ui
 			if ((int) floorf(avg) < a.mq_threshold)
 				break; // element 1 dropped -> element 2 never created; element 2 dropped -> done
 			n_elem++;
-			__builtin_amdgcn_wave_barrier();
-			for (int i = lane; i < n; i += kWave) {
-				const int b = from + i;
-				const int code = (b & 1) ? (sq[b >> 1] & 0xF) : (sq[b >> 1] >> 4); // bam_seqi
-				const uint8_t c = code == 1 ? 'A' : code == 2 ? 'C' : code == 4 ? 'G' : code == 8 ? 'T' : 'N';
-				str[i] = c;
-				rev[n - i - 1] = c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'G' ? 'C' : c == 'C' ? 'G' : 'N';
-			}
-			__builtin_amdgcn_wave_barrier();
 			if (n < kKmerLen)
 				continue;
+			const uint8_t *str = bases + from;
+			__builtin_amdgcn_wave_barrier();
+			for (int i = lane; i < n; i += kWave)
+				rev[n - i - 1] = comp(str[i]);
+			__builtin_amdgcn_wave_barrier();
 			const int dist_max = (int) (0.05 * (double) n);
-			const int h_fwd = kmer_hash([&](int k) { return str[k]; }), h_rev = kmer_hash([&](int k) { return rev[k]; });
-			uint32_t f0 = 0, f1 = 0, r0 = 0, r1 = 0; // (a seed with a letter outside ACGT has no bucket)
-			if (h_fwd >= 0) {
-				f0 = a.offset[h_fwd];
-				f1 = a.offset[h_fwd + 1];
+			int size = 0;
+#pragma unroll 1
+			for (int o = 0; o < 2 && size < kMaxMapping; o++) { // forward, then the reverse complement
+				const uint32_t b0 = e ? (o ? bk0[1][1] : bk0[1][0]) : (o ? bk0[0][1] : bk0[0][0]);
+				const uint32_t b1 = e ? (o ? bk1[1][1] : bk1[1][0]) : (o ? bk1[0][1] : bk1[0][0]);
+				const int pf = e ? (o ? p_first[1][1] : p_first[1][0]) : (o ? p_first[0][1] : p_first[0][0]);
+				size = split_scan_bucket(a, o ? rev : str, n, anchor, dist_max, o ? 'R' : 'F', size, hit_pos, hit_orient, lane, o != 0, b0, b1, pf,
+						refw, p, l);
 			}
-			if (h_rev >= 0) {
-				r0 = a.offset[h_rev];
-				r1 = a.offset[h_rev + 1];
-			}
-			const int p_fwd = (f0 + (uint32_t) lane < f1) ? a.positions[f0 + lane] : 0;
-			const int p_rev = (r0 + (uint32_t) lane < r1) ? a.positions[r0 + lane] : 0;
-			int size = split_scan_bucket(a, str, n, anchor, dist_max, 'F', 0, hit_pos, hit_orient, lane, false, f0, f1, p_fwd);
-			if (size < kMaxMapping)
-				size = split_scan_bucket(a, rev, n, anchor, dist_max, 'R', size, hit_pos, hit_orient, lane, true, r0, r1, p_rev);
 			__builtin_amdgcn_wave_barrier();
 			if (!(size > 0 && size < kMaxMapping))
 				continue;
@@ -2417,8 +2487,9 @@ __device__ __forceinline__ void split_read_one(const SplitArgs &a, int64_t r, ui
 			for (int m = 0; m < size; m++) {
 				const int posMap = hit_pos[m];
 				const char orient = hit_orient[m];
-				if (is_satellite_dev(a, anchor, (int64_t) anchor + 1) + is_satellite_dev(a, posMap, (int64_t) posMap + 1) != 0)
-					continue;
+				// read_SplitReads drops a row for any of these reasons and nothing else happens to it (bam_data.c:96-125): the
+				// tests that cost nothing come first, the two satellite questions (a search in memory each) last -- nearly every
+				// mapping is the read's own locus (posMap == anchor) and never gets that far
 				if (!(mapq_sr > a.mq_threshold && anchor > 0 && posMap > 0 && anchor < a.L && posMap < a.L))
 					continue;
 				const int lengthSplit = l / 2, lengthRead = l - lengthSplit;
@@ -2432,6 +2503,8 @@ __device__ __forceinline__ void split_read_one(const SplitArgs &a, int64_t r, ui
 				} else
 					continue;
 				if (pos1_2 >= pos2_1 || orient != 'F')
+					continue;
+				if (is_satellite_dev(a, anchor, (int64_t) anchor + 1) + is_satellite_dev(a, posMap, (int64_t) posMap + 1) != 0)
 					continue;
 				const bool is_del = (anchor < posMap && e == 0) || (anchor > posMap && e == 1);
 				const int left_end = pos1_2 - kSoftclipWindow, right_start = pos2_1 + kSoftclipWindow;
@@ -2459,12 +2532,14 @@ __device__ __forceinline__ void split_read_one(const SplitArgs &a, int64_t r, ui
 
 // All chromosomes' records in ONE launch, one wave per read; the records of a chromosome are consecutive, so a wave
 // moves from SplitSlot to SplitSlot as its read index grows and flushes its counters into the chromosome it leaves.
-__global__ __launch_bounds__(256, 8) void split_read_kernel(SplitBatchArgs g, int64_t first_read)
+template <int kWavesPerSimd> __global__ __launch_bounds__(256, kWavesPerSimd) void split_read_kernel(SplitBatchArgs g, int64_t first_read)
 {
-	__shared__ uint8_t s_str[4][kSrMaxHalf], s_rev[4][kSrMaxHalf], s_qual[4][2 * kSrMaxHalf];
+	__shared__ uint8_t s_bases[4][2 * kSrMaxHalf], s_rev[4][kSrMaxHalf], s_qual[4][2 * kSrMaxHalf], s_refw[4][2 * kSrMaxHalf];
 	__shared__ int32_t s_hit_pos[4][kMaxMapping];
 	__shared__ char s_hit_orient[4][kMaxMapping];
-	const int wv = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+	// (the wave's number is the same in all its lanes; said so, everything that belongs to the read -- its index, length,
+	// position, the halves' bounds, the buckets' bounds -- lives in scalar registers instead of one vector register each)
+	const int wv = __builtin_amdgcn_readfirstlane((int) (threadIdx.x / kWave)), lane = threadIdx.x & (kWave - 1);
 	const int64_t n_waves = (int64_t) gridDim.x * 4;
 	unsigned long long n_elem = 0, n_map = 0, n_del = 0, n_dup = 0;
 	int cur = 0;
@@ -2491,7 +2566,7 @@ __global__ __launch_bounds__(256, 8) void split_read_kernel(SplitBatchArgs g, in
 			while (r >= sl.sr_off + sl.n_sr); // never runs off the table: r < n_reads = the last slot's end
 			a = split_view(g, sl);
 		}
-		split_read_one(a, r - sl.sr_off, s_str[wv], s_rev[wv], s_qual[wv], s_hit_pos[wv], s_hit_orient[wv], lane, n_elem, n_map, n_del, n_dup);
+		split_read_one(a, r - sl.sr_off, s_bases[wv], s_rev[wv], s_qual[wv], s_refw[wv], s_hit_pos[wv], s_hit_orient[wv], lane, n_elem, n_map, n_del, n_dup);
 	}
 	flush();
 }

@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""The configs[4] leg of bench.py alone (conga_amd/rp_bench.py): split-read stage time on chromosomes --rp-chroms."""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from conga_amd import rp_bench  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rp-chroms", default="20,21,22")
+ap.add_argument("--chroms", default="")
+ap.add_argument("--steps", type=int, default=5)
+a = ap.parse_args()
+out, _ = rp_bench.leg(a, dict(local_rank=0))
+print(json.dumps({k: out[k] for k in ("records", "ms_per_step", "split_read_stage_ms", "records_per_s", "split_elements", "split_mappings",
+                                      "split_rows", "supported_dups", "supported_dels", "first_compute_ms")}))
