@@ -2372,16 +2372,8 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 		g.n_slots = ctx->n_sr_slots;
 		g.small = small;
 		const int64_t first = ctx->slots[(size_t) ctx->sr_first_slot].sr_off;
-		static const int sr_waves = getenv("CONGA_SR_WAVES") ? atoi(getenv("CONGA_SR_WAVES")) : 8;
-		const int sgrid = (int) std::min<int64_t>((g.base.n_reads - first + 3) / 4, (int64_t) ctx->n_cu * sr_waves);
-		if (sr_waves == 4)
-			hipLaunchKernelGGL(split_read_kernel<4>, dim3(sgrid), dim3(256), 0, st, g, first);
-		else if (sr_waves == 5)
-			hipLaunchKernelGGL(split_read_kernel<5>, dim3(sgrid), dim3(256), 0, st, g, first);
-		else if (sr_waves == 6)
-			hipLaunchKernelGGL(split_read_kernel<6>, dim3(sgrid), dim3(256), 0, st, g, first);
-		else
-			hipLaunchKernelGGL(split_read_kernel<8>, dim3(sgrid), dim3(256), 0, st, g, first);
+		const int sgrid = (int) std::min<int64_t>((g.base.n_reads - first + 3) / 4, (int64_t) ctx->n_cu * 8);
+		hipLaunchKernelGGL(split_read_kernel, dim3(sgrid), dim3(256), 0, st, g, first);
 	}
 
 	if (ctx->n_iv > 0) {

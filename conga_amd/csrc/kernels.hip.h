@@ -2452,8 +2452,12 @@ __device__ __forceinline__ void split_read_one(const SplitArgs &a, int64_t r, ui
 				for (int c0 = from; c0 < from + n; c0 += kWave) {
 					const float mine = (c0 + lane < from + n) ? (float) ql[c0 + lane] : 0.0f;
 					const int cnt = min(kWave, from + n - c0);
-					for (int j = 0; j < cnt; j++)
-						avg = avg + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), j));
+					// (eight adds per turn of the loop; the lanes behind the half hold +0.0, and x + 0.0 is x for the x >= 0 met here)
+					for (int j = 0; j < cnt; j += 8) {
+#pragma unroll
+						for (int u = 0; u < 8; u++)
+							avg = avg + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), j + u));
+					}
 				}
 			}
 			avg = avg / (float) n;
@@ -2532,7 +2536,10 @@ __device__ __forceinline__ void split_read_one(const SplitArgs &a, int64_t r, ui
 
 // All chromosomes' records in ONE launch, one wave per read; the records of a chromosome are consecutive, so a wave
 // moves from SplitSlot to SplitSlot as its read index grows and flushes its counters into the chromosome it leaves.
-template <int kWavesPerSimd> __global__ __launch_bounds__(256, kWavesPerSimd) void split_read_kernel(SplitBatchArgs g, int64_t first_read)
+// Measured at 8, 6 and 5 waves per SIMD (64 / 80 / 96 registers, 46 / 31 / 14 of them spilled): 14.5 / 14.4 / 15.0 ms for the
+// 6.56 M records of the bench leg -- the launch is bound by instructions (770 vector + 650 scalar per read), not by the
+// waves in flight.
+__global__ __launch_bounds__(256, 8) void split_read_kernel(SplitBatchArgs g, int64_t first_read)
 {
 	__shared__ uint8_t s_bases[4][2 * kSrMaxHalf], s_rev[4][kSrMaxHalf], s_qual[4][2 * kSrMaxHalf], s_refw[4][2 * kSrMaxHalf];
 	__shared__ int32_t s_hit_pos[4][kMaxMapping];

@@ -186,8 +186,9 @@ def leg(args, env):
                roofline=dict(bound="hbm", kernel="split_read_kernel", algorithmic_bytes_per_launch=int(alg),
                              avg_launch_ms=round(sr_ms, 3), achieved=round(alg / max(sr_ms, 1e-6) / 1e6, 1), peak=8000.0, unit="GB/s",
                              frac=round(alg / max(sr_ms, 1e-6) / 1e6 / 8000.0, 4), traffic=None,
-                             note="latency-bound: ~14 dependent trips to HBM per read (record -> sequence -> bucket bounds -> "
-                                  "bucket -> reference, per half); launch time = step with records - step without"))
+                             note="instruction-bound: ~770 vector + 650 scalar instructions and ~5 dependent trips to HBM per read "
+                                  "(fields -> qualities + sequence + reference -> bucket bounds -> buckets); launch time = step with "
+                                  "records - step without"))
     # a bounded sample for the caller's CPU baseline (bench.py runs the oracle; nothing in this package does)
     ch = min(chroms, key=lambda c: c["L"])
     k = min(20_000, len(ch["pos"]))
