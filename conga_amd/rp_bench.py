@@ -72,7 +72,7 @@ def make_rp_chrom(name, length, n_dels, n_dups, cov, seed=synth.BASE_SEED):
         for s, e in zip(s_arr[pick], e_arr[pick]):
             for k in rng.integers(25, 76, 3):
                 a, b = (int(e), int(s)) if is_dup else (int(s), int(e))  # dup: ...end | start...; del: ...start | end...
-                if a - k > 0 and b + READ_LEN - k < length:
+                if a - k > 0 and a - k + READ_LEN < length and b + READ_LEN - k < length:
                     jpos.append(a - k)
                     jleft.append(a)
                     jright.append(b)
