@@ -9,12 +9,16 @@
 //   stream -- literal / end of block, or a length with its extra bits, its distance code and that one's extra bits: at
 //   most 48 bits, every lane has a 64-bit view -- with its own look-ups in the wave's tables in LDS.  The sixty-four
 //   results sit in registers, and the true chain of symbol starts (0, 0 + bits[0], ...) is then followed with
-//   v_readlane: no memory in the serial part at all.  A trip retires every literal up to the first match (their lanes
-//   store their bytes side by side: ballot mask + mbcnt gives each its place) and that match, copied by all lanes.
-//   One trip to LDS per ~9 symbols instead of one per symbol.
+//   v_readlane and scalar code: no memory in the serial part at all.  A trip retires EVERY symbol on the chain: a prefix
+//   sum over the bytes they produce gives the literals their places (one masked byte store) and the matches their
+//   destinations; short matches are copied by their own lanes all at once, the others one after the other by all lanes.
+//   One trip to LDS per ~8 symbols instead of one per symbol.
 // * Tables: 16-bit entries, two levels (9-bit root for literals / lengths, 7-bit for distances), built by the wave for
 //   every deflate block: code lengths -> per-length ballots give every symbol its canonical code without a serial
 //   pass; the width of each second-level table follows from the canonical ranges, so there is no atomic anywhere.
+//   An entry holds the whole codeword length and the count of extra bits behind it (LitFormat / DistFormat below):
+//   the vector unit is what bounds this kernel, and that is what sixty-four lanes compute for the eight that count.
+// * The symbol loop is a function of its own (run_symbols_call): 32 VGPRs and no spill, whatever the set-up around it keeps.
 // * The output goes to HBM (L2) as it is produced.  A match reads what the wave wrote before: stores are waited for
 //   (s_waitcnt vmcnt(0)) only when the match reaches into bytes stored since the last wait, and the read-back loads
 //   bypass the L1 (it is write-through and may hold a line from before the store).
