@@ -941,8 +941,10 @@ void make_bz_ring(conga_ctx *ctx)
 	(void) hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
 	const bool prio = getenv("CONGA_BGZF_NO_PRIORITY") == nullptr;
 	bool ok = hipSetDevice(ctx->device) == hipSuccess
-			&& hipHostMalloc((void **) &ctx->h_bz_ring, kBzPiece * kBzSlots, hipHostMallocDefault) == hipSuccess
-			&& hipStreamCreateWithPriority(&ctx->bz_copy, hipStreamNonBlocking, prio ? prio_high : 0) == hipSuccess;
+			&& hipHostMalloc((void **) &ctx->h_bz_ring, kBzPiece * kBzSlots, hipHostMallocDefault) == hipSuccess;
+	if (ok && ctx->bz_copy) // (the ring was given back, conga_release_staging: streams and events are still there)
+		return;
+	ok = ok && hipStreamCreateWithPriority(&ctx->bz_copy, hipStreamNonBlocking, prio ? prio_high : 0) == hipSuccess;
 	for (int k = 0; ok && k < kBzSlots; k++)
 		ok = hipEventCreateWithFlags(&ctx->ev_bz_slot[k], hipEventDisableTiming) == hipSuccess;
 	for (int k = 0; ok && k < 3; k++)
@@ -1133,6 +1135,21 @@ extern "C" {
 int conga_abi_version(void)
 {
 	return CONGA_ABI_VERSION;
+}
+
+int conga_release_staging(conga_ctx *ctx)
+{
+	if (!ctx)
+		return CONGA_ERR_INVALID;
+	if (!ctx->h_bz_ring)
+		return CONGA_OK;
+	if (hipSetDevice(ctx->device) != hipSuccess)
+		return CONGA_ERR_HIP;
+	if (ctx->bz_copy)
+		(void) hipStreamSynchronize(ctx->bz_copy); // (every piece has long gone up: conga_reads_bgzf* returns behind its checks)
+	uint8_t *ring = ctx->h_bz_ring;
+	ctx->h_bz_ring = nullptr;
+	return hipHostFree(ring) == hipSuccess ? CONGA_OK : CONGA_ERR_HIP;
 }
 
 int conga_device_count(void)

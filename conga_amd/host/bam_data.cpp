@@ -314,6 +314,7 @@ std::unique_ptr<planned_input> plan_input(const parameters *params, const sonic 
 struct kept_engine {
 	conga_ctx *ctx = nullptr;
 	std::string layout_key;
+	bool last_sample = false; // no BAM behind this one: the pinned staging can go while the context computes
 };
 
 std::string layout_key_of(const std::vector<chrom_job *> &mine)
@@ -342,6 +343,14 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 		return std::chrono::duration<double, std::milli>(now() - t).count();
 	};
 	const auto t_create = now();
+	struct joined_thread {
+		std::thread t;
+		~joined_thread()
+		{
+			if (t.joinable())
+				t.join();
+		}
+	} releaser;
 	conga_opts opts;
 	memset(&opts, 0, sizeof opts);
 	opts.struct_size = sizeof opts;
@@ -434,6 +443,11 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 				gpu_counts.clear();
 				engine_check(ctx, conga_reset(ctx), "conga_reset");
 				same_layout = false;
+			} else if (!keep || keep->last_sample) {
+				// the last BAM is in: its 96 MB of pinned staging go back now, beside the compute, instead of being taken down
+				// with the process (which costs the driver four times as long, tools/exitcost.hip)
+				conga_ctx *c = ctx;
+				releaser.t = std::thread([c] { (void) conga_release_staging(c); });
 			}
 		}
 		err.clear();
@@ -577,6 +591,7 @@ int read_bam_cohort(parameters *params, sonic *this_sonic)
 		params->bam_file = samples[k].first;
 		params->outdir.clear(); // (a prefix from the list is taken as it is; the default one already carries --out's directory)
 		params->outprefix = samples[k].second;
+		keep.last_sample = k + 1 == samples.size();
 		fprintf(stderr, "\n[CONGA] sample %zu of %zu: %s\n", k + 1, samples.size(), params->bam_file.c_str());
 		// several contexts (--gpus N) are made per sample; one context is kept from sample to sample
 		const int rc = read_bam_with(params, this_sonic, params->n_gpus == 1 ? &keep : nullptr, mine_now.get());

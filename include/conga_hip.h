@@ -275,6 +275,12 @@ int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const
 int conga_reads_bgzf_fd(conga_ctx *ctx, int fd, uint64_t file_off, size_t n_bytes, const conga_bgzf_block *blocks, size_t n_blocks,
 		const conga_bam_segment *segments, size_t n_segments, uint64_t *reads_per_chrom /* [conga_chrom_count()] or NULL */);
 
+/* Gives the pinned staging of conga_reads_bgzf* (96 MB) back to the system; the next call makes it again.  A caller that is
+ * done reading -- the conga executable after its last BAM -- calls this, from a thread of its own if it likes, while the
+ * context computes: pinned memory that is still there when the process ends is taken down by the driver at four times the
+ * cost.  Must not run beside a conga_reads_bgzf* call of the same context. */
+int conga_release_staging(conga_ctx *ctx);
+
 /* Test / tool hook: the first stage of conga_reads_bgzf alone.  Inflates the blocks on the device and copies their payloads
  * (one behind the other) to `out` (may be NULL); status[b]: 0 inflated and CRC32 right, 1 refused (not a valid deflate stream
  * of the recorded size), 2 CRC32 mismatch.  kernel_ms (may be NULL): device time of the inflate launch.  Any bytes will do:

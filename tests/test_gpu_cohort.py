@@ -268,3 +268,42 @@ def test_reads_bgzf_in_process_on_recycled_device_memory(capi, tmp_path, strateg
         want = ctx.fetch_all()
     for (gd, _gu, gE, gs), (wd, _wu, wE, ws) in zip(got, want):
         assert gd.tobytes() == wd.tobytes() and gE.tobytes() == wE.tobytes() and gs.reads_counted == ws.reads_counted
+
+
+def test_release_staging_between_two_overlapped_uploads(capi, tmp_path, monkeypatch):
+    """conga_release_staging gives the pinned ring of the overlapped upload back; the next conga_reads_bgzf makes it again and
+    decodes the same reads (the conga executable releases it beside the compute of its last sample)."""
+    import struct
+    from conga_amd import formats
+    monkeypatch.setenv("CONGA_BGZF_OVERLAP", "1")
+    monkeypatch.setenv("CONGA_BGZF_PIECE_KB", "8")
+    cs = [synth.make_chrom(n, L, cov=2.0, n_dels=nd, gaps=False) for n, L, nd in (("1", 300_000, 15), ("2", 200_000, 10))]
+    path = str(tmp_path / "r.bam")
+    formats.write_bam(path, "S", [(c.name, c.length, c.pos, c.mapq) for c in cs], index=True, block_payload=20_000, unplaced=2)
+    raw = np.fromfile(path, np.uint8)
+    blocks, stream = bgzf_table(raw.tobytes())
+    l_text = struct.unpack_from("<i", stream, 4)[0]
+    at = 8 + l_text
+    n_ref = struct.unpack_from("<i", stream, at)[0]
+    at += 4
+    for _ in range(n_ref):
+        l_name = struct.unpack_from("<i", stream, at)[0]
+        at += 4 + l_name + 4
+    segments = [(at, 0, cs[0].length, 0, 0), (at, 0, cs[1].length, 1, 1)]
+    results = []
+    with capi.Context(device=0, flags=capi.FLAG_BATCH) as ctx:
+        ctx.release_staging()   # nothing to give back yet: fine
+        for c in cs:
+            ds, de = synth.kept_sorted(c.del_start, c.del_end)
+            ctx.chrom_begin(c.length, c.gc)
+            ctx.intervals("D", ds, de)
+        for _ in range(2):
+            assert ctx.reads_bgzf(raw, blocks, segments) == [len(c.pos) for c in cs]
+            ctx.release_staging()
+            ctx.release_staging()
+            ctx.compute()
+            results.append(ctx.fetch_all())
+            ctx.sample_begin()
+    for (ad, _au, aE, ast), (bd, _bu, bE, bst) in zip(*results):
+        assert ad.tobytes() == bd.tobytes() and aE.tobytes() == bE.tobytes() and ast.reads_counted == bst.reads_counted
+        assert ast.reads_counted > 0
