@@ -143,6 +143,14 @@ struct conga_ctx {
 	bool bz_ring_failed = false;
 	hipStream_t bz_copy = nullptr, bz_kernel[3] = {};
 	hipEvent_t ev_bz_kernel[3] = {};
+	bool bz_shared = false; // the inflate launches go to `stream2` and `stream` (made with the lowest priority for that)
+	int n_bz_streams = 0;
+	// ... and to a third stream of their own from the second call on: made by a thread that the first call leaves behind
+	// (15-20 ms that no caller waits for)
+	std::thread bz_third_maker;
+	std::atomic<bool> bz_third_ready{false};
+	hipStream_t bz_third = nullptr;
+	hipEvent_t ev_bz_third = nullptr;
 
 	// pinned read-back
 	Small *h_small = nullptr;
@@ -930,7 +938,18 @@ int launch_inflate(conga_ctx *ctx, size_t n_blocks, uint32_t lanes, hipStream_t 
 // copying in, copying up and inflating all run at once.  Ends with ctx->stream waiting for every launch.
 // blocks[] must be in file order (data_off ascending); the caller falls back to the plain form otherwise.
 constexpr size_t kBzPiece = (size_t) 8 << 20;
-constexpr int kBzSlots = 12, kBzPiecesPerLaunch = 16;
+constexpr int kBzMaxSlots = 12, kBzMaxStreams = 3, kBzPiecesPerLaunch = 16;
+// how many of them are used (CONGA_BGZF_SLOTS / CONGA_BGZF_STREAMS: measurement switches)
+int bz_slots()
+{
+	static const int n = getenv("CONGA_BGZF_SLOTS") ? std::max(2, std::min(atoi(getenv("CONGA_BGZF_SLOTS")), kBzMaxSlots)) : kBzMaxSlots;
+	return n;
+}
+int bz_streams_wanted()
+{
+	static const int n = getenv("CONGA_BGZF_STREAMS") ? std::max(1, std::min(atoi(getenv("CONGA_BGZF_STREAMS")), kBzMaxStreams)) : kBzMaxStreams;
+	return n;
+}
 
 // the pinned ring, its events and the streams of the overlapped upload (96 MB of pinned memory take ~50 ms to get: with
 // CONGA_FLAG_EXPECT_BGZF conga_create() does this, and a caller that creates its context on a thread of its own -- the
@@ -941,14 +960,25 @@ void make_bz_ring(conga_ctx *ctx)
 	(void) hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
 	const bool prio = getenv("CONGA_BGZF_NO_PRIORITY") == nullptr;
 	bool ok = hipSetDevice(ctx->device) == hipSuccess
-			&& hipHostMalloc((void **) &ctx->h_bz_ring, kBzPiece * kBzSlots, hipHostMallocDefault) == hipSuccess;
+			&& hipHostMalloc((void **) &ctx->h_bz_ring, kBzPiece * (size_t) bz_slots(), hipHostMallocDefault) == hipSuccess;
 	if (ok && ctx->bz_copy) // (the ring was given back, conga_release_staging: streams and events are still there)
 		return;
 	ok = ok && hipStreamCreateWithPriority(&ctx->bz_copy, hipStreamNonBlocking, prio ? prio_high : 0) == hipSuccess;
-	for (int k = 0; ok && k < kBzSlots; k++)
+	for (int k = 0; ok && k < bz_slots(); k++)
 		ok = hipEventCreateWithFlags(&ctx->ev_bz_slot[k], hipEventDisableTiming) == hipSuccess;
-	for (int k = 0; ok && k < 3; k++)
-		ok = hipStreamCreateWithPriority(&ctx->bz_kernel[k], hipStreamNonBlocking, prio ? prio_low : 0) == hipSuccess
+	// The inflate launches need streams BELOW the copy stream's priority (equal priorities: the pieces go up at 22 GB/s beside
+	// the kernels instead of 50; copy high / kernels normal: the stage takes 116 ms instead of 93).  A stream costs 15-20 ms to
+	// make on this platform, so the context's own two streams -- made with the lowest priority, conga_create -- take the
+	// launches (two streams instead of three dedicated ones: +3 ms for the stage, -50 ms for the creation).
+	// CONGA_STREAMS_NORMAL=1: the context's streams at the default priority and three streams of their own for the inflate.
+	if (ctx->bz_shared) {
+		ctx->bz_kernel[0] = ctx->stream2;
+		ctx->bz_kernel[1] = ctx->stream;
+		ctx->n_bz_streams = std::min(2, bz_streams_wanted());
+	} else
+		ctx->n_bz_streams = bz_streams_wanted();
+	for (int k = 0; ok && k < ctx->n_bz_streams; k++)
+		ok = (ctx->bz_shared || hipStreamCreateWithPriority(&ctx->bz_kernel[k], hipStreamNonBlocking, prio ? prio_low : 0) == hipSuccess)
 				&& hipEventCreateWithFlags(&ctx->ev_bz_kernel[k], hipEventDisableTiming) == hipSuccess;
 	if (!ok) {
 		(void) hipGetLastError();
@@ -1000,9 +1030,16 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const ByteSource &src, size_t 
 	// everything enqueued on ctx->stream so far (tables, buffers grown) comes first
 	HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
 	HIP_TRY(ctx, hipStreamWaitEvent(ctx->bz_copy, ctx->ev_fork, 0));
-	for (int k = 0; k < 3; k++)
+	for (int k = 0; k < ctx->n_bz_streams; k++)
 		HIP_TRY(ctx, hipStreamWaitEvent(ctx->bz_kernel[k], ctx->ev_fork, 0));
 
+	if (ctx->bz_shared && ctx->n_bz_streams == 2 && ctx->bz_third_ready.load(std::memory_order_acquire) && bz_streams_wanted() > 2) {
+		ctx->bz_third_maker.join();
+		ctx->bz_kernel[2] = ctx->bz_third;
+		ctx->ev_bz_kernel[2] = ctx->ev_bz_third;
+		ctx->n_bz_streams = 3;
+	}
+	const int kBzSlots = bz_slots();
 	std::mutex mu;
 	std::condition_variable cv;
 	std::vector<uint8_t> filled(n_pieces, 0);
@@ -1093,7 +1130,7 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const ByteSource &src, size_t 
 			if (last)
 				b1 = n_blocks;
 			if (b1 > b_done) {
-				hipStream_t ks = ctx->bz_kernel[launches % 3];
+				hipStream_t ks = ctx->bz_kernel[launches % ctx->n_bz_streams];
 				e = hipStreamWaitEvent(ks, ctx->ev_bz_slot[c % kBzSlots], 0);
 				if (e != hipSuccess)
 					rc = fail(ctx, CONGA_ERR_HIP, std::string("conga_reads_bgzf: ") + hipGetErrorString(e));
@@ -1116,12 +1153,22 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const ByteSource &src, size_t 
 				"copying, %.1f ms waiting for a free slot, each), %d inflate launches\n", ms_ring, n_pieces, n_threads, ms_since(t0),
 				us_copy / 1e3 / n_threads, us_wait / 1e3 / n_threads, launches);
 	// ctx->stream goes on behind every launch (and the copy stream, for the case of no launch at all)
-	for (int k = 0; k < 3; k++) {
+	for (int k = 0; k < ctx->n_bz_streams; k++) {
 		(void) hipEventRecord(ctx->ev_bz_kernel[k], ctx->bz_kernel[k]);
 		(void) hipStreamWaitEvent(ctx->stream, ctx->ev_bz_kernel[k], 0);
 	}
 	(void) hipEventRecord(ctx->ev_fork2, ctx->bz_copy);
 	(void) hipStreamWaitEvent(ctx->stream, ctx->ev_fork2, 0);
+	if (ctx->bz_shared && ctx->n_bz_streams == 2 && !ctx->bz_third_maker.joinable() && bz_streams_wanted() > 2) {
+		const int device = ctx->device;
+		ctx->bz_third_maker = std::thread([ctx, device] {
+			int lo = 0, hi = 0;
+			if (hipSetDevice(device) == hipSuccess && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess
+					&& hipStreamCreateWithPriority(&ctx->bz_third, hipStreamNonBlocking, lo) == hipSuccess
+					&& hipEventCreateWithFlags(&ctx->ev_bz_third, hipEventDisableTiming) == hipSuccess)
+				ctx->bz_third_ready.store(true, std::memory_order_release);
+		});
+	}
 	if (rc == CONGA_OK)
 		HIP_TRY(ctx, hipGetLastError());
 	return rc;
@@ -1283,12 +1330,19 @@ conga_ctx *conga_create(int device, const conga_opts *opts, int *status)
 		ctx->tuple_blocks_per_cu = occ;
 	}
 	lap(2);
-	if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess)
+	// (lowest priority: these two streams also take the inflate launches of conga_reads_bgzf*, which must rank below its
+	// copy stream -- make_bz_ring; among themselves and against other contexts' streams nothing changes)
+	ctx->bz_shared = getenv("CONGA_STREAMS_NORMAL") == nullptr;
+	int prio_low = 0, prio_high = 0;
+	(void) hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+	if (!ctx->bz_shared)
+		prio_low = 0;
+	if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_low) != hipSuccess)
 		return bail(CONGA_ERR_HIP);
 	if (hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming) != hipSuccess
 			|| hipEventCreateWithFlags(&ctx->ev_head, hipEventDisableTiming) != hipSuccess)
 		return bail(CONGA_ERR_HIP);
-	if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess
+	if (hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_low) != hipSuccess
 			|| hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess
 			|| hipEventCreateWithFlags(&ctx->ev_fork2, hipEventDisableTiming) != hipSuccess
 			|| hipEventCreateWithFlags(&ctx->ev_counted, hipEventDisableTiming) != hipSuccess
@@ -1370,9 +1424,17 @@ void conga_destroy(conga_ctx *ctx)
 			(void) hipEventDestroy(e);
 	if (ctx->bz_copy)
 		(void) hipStreamDestroy(ctx->bz_copy);
-	for (hipStream_t q : ctx->bz_kernel)
-		if (q)
-			(void) hipStreamDestroy(q);
+	if (ctx->bz_third_maker.joinable())
+		ctx->bz_third_maker.join();
+	if (ctx->bz_shared) { // (two of them are `stream2` and `stream`, destroyed as such; the event of the third is in ev_bz_kernel when it was taken up)
+		if (ctx->bz_third)
+			(void) hipStreamDestroy(ctx->bz_third);
+		if (ctx->ev_bz_third && ctx->ev_bz_kernel[2] != ctx->ev_bz_third)
+			(void) hipEventDestroy(ctx->ev_bz_third);
+	} else
+		for (hipStream_t q : ctx->bz_kernel)
+			if (q)
+				(void) hipStreamDestroy(q);
 	if (ctx->ev_head)
 		(void) hipEventDestroy(ctx->ev_head);
 	if (ctx->h_results)
