@@ -483,8 +483,10 @@ __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Lu
 		unsigned long long mm = match_m;
 		{
 			const uint32_t to_l = opos + incl - produced, src_l = to_l - dist;
-			// (a distance that reaches in front of the output makes src_l wrap: far above safe_pos, and the loop below refuses it)
-			const bool fast = on_chain && is_match && produced <= 8u && dist >= produced && src_l + produced <= safe_pos;
+			// (dist <= to_l is tested on its own: a distance that reaches up to eight bytes in front of the output makes src_l wrap
+			// and src_l + produced wrap back below safe_pos -- damaged streams do that, tests/test_gpu_inflate.py's fuzz found it;
+			// the loop below refuses such a match)
+			const bool fast = on_chain && is_match && produced <= 8u && dist >= produced && dist <= to_l && src_l + produced <= safe_pos;
 			const unsigned long long fast_m = __ballot(fast);
 			if (fast_m) {
 				if (fast)

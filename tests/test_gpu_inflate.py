@@ -126,3 +126,52 @@ def test_many_blocks_round_robin_over_the_waves(capi):
         out, status, ms = ctx.inflate_blocks(data, blocks)
     assert not status.any()
     assert out.tobytes() == b"".join(p for _c, p in streams)
+
+
+def test_damage_fuzz_agrees_with_zlib_on_what_is_a_stream(capi):
+    """A few thousand damaged streams of every kind (flipped bits, flipped bytes in the block headers, truncations, spliced
+    and random bytes): the kernel accepts exactly what zlib inflates to the recorded size with the recorded CRC32, refuses
+    the rest, and comes back (a table with holes, a distance past the output's start or a code that never ends must end the
+    wave's walk, not spin it)."""
+    rng = np.random.default_rng(20261004)
+    kinds = payloads(rng)
+    streams = []
+    for k in range(3600):
+        plain = kinds[k % len(kinds)]
+        a = int(rng.integers(0, max(len(plain) - 10, 1)))
+        plain = plain[a:a + int(rng.integers(1, 6000))]
+        good = deflate(plain, int(rng.integers(1, 10)), int(rng.choice([0, 0, 0, 2, 3, 4])))
+        bad = bytearray(good)
+        how = k % 6
+        if how == 0:      # one flipped bit anywhere
+            bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        elif how == 1:    # a flipped bit in the first bytes: block type, code-length code, the tables themselves
+            bad[int(rng.integers(0, min(len(bad), 40)))] ^= 1 << int(rng.integers(0, 8))
+        elif how == 2:    # a few flipped bytes
+            for _ in range(int(rng.integers(1, 5))):
+                bad[int(rng.integers(0, len(bad)))] = int(rng.integers(0, 256))
+        elif how == 3:    # cut short
+            del bad[int(rng.integers(0, len(bad))):]
+            bad += b"\x00" if not bad else b""
+        elif how == 4:    # another stream's tail spliced in
+            other = deflate(kinds[(k + 3) % len(kinds)][:3000], 6)
+            cut = int(rng.integers(1, len(bad) + 1))
+            bad = bad[:cut] + other[int(rng.integers(0, len(other))):]
+        else:             # noise behind a dynamic-block header (BTYPE 2) or all noise
+            noise = bytes(rng.integers(0, 256, int(rng.integers(4, 400)), dtype=np.uint8))
+            bad = bytearray((b"\x05" if k % 12 == 5 else b"") + noise)
+        streams.append((bytes(bad), plain))
+    data, blocks = pack(streams)
+    want = []
+    for off, n, isz, crc in blocks:
+        try:
+            got = zlib.decompress(data[off:off + n].tobytes(), -15)
+            want.append(len(got) == isz and (zlib.crc32(got) & 0xFFFFFFFF) == crc)
+        except zlib.error:
+            want.append(False)
+    with capi.Context(device=0) as ctx:
+        _out, status, _ = ctx.inflate_blocks(data, blocks, want_out=False)
+    got = status == 0
+    wrong = [k for k in range(len(blocks)) if bool(got[k]) != want[k]]
+    assert not wrong, (len(wrong), wrong[:10], [int(status[k]) for k in wrong[:10]])
+    assert 0 < sum(want) < len(want) // 2   # (a flipped bit sometimes lands where it changes nothing that is checked... rarely)
