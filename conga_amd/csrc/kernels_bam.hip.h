@@ -119,8 +119,13 @@ template <bool WRITE> __global__ __launch_bounds__(64) void bam_walk_kernel(BamW
 		at += 4 + (uint64_t) block_size;
 		if (ref >= 0 && ref < sg.ref_id)
 			continue; // (the tail of the previous target in front of this one's first record)
-		if (p < sg.pos_lo)
+		if (p < sg.pos_lo) {
+			if (first != kNone) { // behind a record of this segment: the file is not sorted by position -- not this decoder's to judge
+				bad = true;
+				break;
+			}
 			continue; // starts in front of this segment: the previous one's
+		}
 		if (first == kNone)
 			first = here;
 		if (p < 0)

@@ -3,6 +3,7 @@
 byte for byte against the oracle's writer (likelihood.c:172-288, bam_data.c:235-249)."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -608,3 +609,14 @@ def test_cli_cohort_keeps_the_engine_and_every_byte(tmp_path, decode):
             assert got == want and (kind != "dels" or got.count(b"\n") > 5), (k, kind)
     # the samples differ (it is not one sample's files four times)
     assert open(os.path.join(d, "co.s0_dels.bed"), "rb").read() != open(os.path.join(d, "co.s3_dels.bed"), "rb").read()
+
+
+@pytest.mark.gpu
+def test_cli_damaged_bam_records_gpu_and_host_decoders_agree():
+    """Records with a damaged block_size, refID, pos, l_read_name, n_cigar, l_seq or flag, and random bytes, in a BAM whose
+    blocks still check out (tools/bam_fuzz.py): the run that decodes on the GPU ends the way the run on the host decoders
+    ends -- same exit code, same files -- and neither dies of a signal (a record out of position order is refused by the GPU
+    walk and reported by the host path, not dropped)."""
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bam_fuzz.py")
+    r = subprocess.run([sys.executable, tool, "40", "20261004"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "disagreements or crashes 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
