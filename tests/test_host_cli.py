@@ -620,3 +620,6 @@ def test_cli_damaged_bam_records_gpu_and_host_decoders_agree():
     tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bam_fuzz.py")
     r = subprocess.run([sys.executable, tool, "40", "20261004"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "disagreements or crashes 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    # ... and the container of a deflated BAM: block headers, BSIZE, XLEN, deflate bytes and bits, CRC32, ISIZE, truncation
+    r = subprocess.run([sys.executable, tool, "24", "20261005", "container"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "disagreements or crashes 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

@@ -29,11 +29,12 @@ def blocks_of(raw):
 
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    container = len(sys.argv) > 3 and sys.argv[3] == "container"   # damage the BGZF container of a deflated BAM instead of records
     d = tempfile.mkdtemp(prefix="conga_bamfuzz_")
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 77)
     cs = [synth.make_chrom(n, L, cov=2.0, n_dels=nd, gaps=True) for n, L, nd in (("1", 500_000, 20), ("2", 300_000, 12))]
     formats.write_bam(os.path.join(d, "good.bam"), "S", [(c.name, c.length, c.pos, c.mapq) for c in cs], index=True, block_payload=30000,
-                      level=0, unplaced=3)
+                      level=6 if container else 0, unplaced=3)
     formats.write_annotation(os.path.join(d, "a.cga"), [(c.name, c.length, c.gc, [], []) for c in cs])
     synth.write_bed(os.path.join(d, "dels.bed"), [(c.name, s, e) for c in cs for s, e in zip(c.del_start, c.del_end)])
     good = bytearray(open(os.path.join(d, "good.bam"), "rb").read())
@@ -52,8 +53,43 @@ def main():
     kinds = ["block_size", "refid", "pos", "l_read_name", "n_cigar", "l_seq", "flag", "random byte", "random run", "block_size small"]
     summary = {}
     bad = 0
+    ckinds = ["header byte", "bsize", "deflate byte", "crc", "isize", "xlen", "truncate", "deflate bit"]
     for case in range(n_cases):
         raw = bytearray(good)
+        if container:
+            kind = ckinds[case % len(ckinds)]
+            bi = int(rng.integers(0, len(blks) - 1))
+            at, bsize = blks[bi]
+            if kind == "header byte":
+                raw[at + int(rng.integers(0, 18))] = int(rng.integers(0, 256))
+            elif kind == "bsize":
+                struct.pack_into("<H", raw, at + 16, int(rng.integers(0, 65536)))
+            elif kind == "deflate byte":
+                raw[int(rng.integers(at + 18, at + bsize - 8))] = int(rng.integers(0, 256))
+            elif kind == "deflate bit":
+                raw[int(rng.integers(at + 18, at + bsize - 8))] ^= 1 << int(rng.integers(0, 8))
+            elif kind == "crc":
+                raw[at + bsize - 8 + int(rng.integers(0, 4))] ^= 0xFF
+            elif kind == "isize":
+                struct.pack_into("<I", raw, at + bsize - 4, int(rng.choice([0, 1, 65536, 70000, 0xFFFFFFFF, 29999])))
+            elif kind == "xlen":
+                struct.pack_into("<H", raw, at + 10, int(rng.choice([0, 4, 8, 100, 65535])))
+            else:
+                del raw[int(rng.integers(at, len(raw))):]
+            bam = "c%d.bam" % case
+            open(os.path.join(d, bam), "wb").write(bytes(raw))
+            open(os.path.join(d, bam + ".bai"), "wb").write(bai)
+            rg, fg = run(bam, "g%d" % case, True)
+            rh, fh = run(bam, "h%d" % case, False)
+            same = rg.returncode == rh.returncode and fg == fh
+            key = (kind, rg.returncode, rh.returncode, same, "decoding on the host" in rg.stderr)
+            summary[key] = summary.get(key, 0) + 1
+            if rg.returncode < 0 or rh.returncode < 0 or not same:
+                bad += 1
+                print("CASE", case, kind, "gpu rc", rg.returncode, "host rc", rh.returncode, "same files", fg == fh)
+                print("  gpu:", rg.stderr.strip().splitlines()[-2:])
+                print("  host:", rh.stderr.strip().splitlines()[-2:])
+            continue
         kind = kinds[case % len(kinds)]
         # a data block that holds records (not the first: the header), stored deflate: 5 bytes of block header, then the payload
         bi = int(rng.integers(1, len(blks) - 2))
