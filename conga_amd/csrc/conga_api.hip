@@ -2112,7 +2112,8 @@ int conga_split_reads_commit(conga_ctx *ctx, size_t n_reads, size_t n_bytes)
 	HostSlot &h = ctx->slots.back();
 	for (size_t i = 0; i < n_reads; i++) {
 		const int32_t l = st.l_qseq[i];
-		if (l < 0 || st.data_off[i] + (uint64_t) (l + 1) / 2 + (uint64_t) l > n_bytes)
+		const uint64_t need = (uint64_t) (l < 0 ? 0 : l + 1) / 2 + (uint64_t) (l < 0 ? 0 : l);
+		if (l < 0 || st.data_off[i] > n_bytes || need > n_bytes - st.data_off[i]) // (no sum that could wrap)
 			return fail(ctx, CONGA_ERR_RANGE, "conga_split_reads_commit: record block outside the committed bytes");
 		st.data_off[i] += (uint64_t) ctx->sr_bytes_total; // rebase into the device arena
 	}

@@ -113,3 +113,32 @@ def test_without_reference_or_reads_nothing_is_counted(capi):
         assert st.split_elements == 0 and np.all(dels["border_rp"] == 0)
         with pytest.raises(capi.CongaError):
             ctx.reference(b"ACGT")  # wrong length
+
+
+def test_records_that_cannot_be_are_refused_or_ignored(capi):
+    """What a caller must not be able to do to the device: a record block that lies outside the committed bytes (also one
+    whose offset makes the sum wrap) is refused at commit; records with a negative position, a position behind the
+    chromosome's end or an absurd length are carried and never looked up."""
+    import ctypes as C
+    c = make_case(n_normal=300)
+    ds, de = np.array([100_000], np.int32), np.array([103_000], np.int32)
+    gc = np.full((c["L"] + 99) // 100, 40, np.uint8)
+    with capi.Context(device=0) as ctx:
+        ctx.chrom_begin(c["L"], gc)
+        ctx.reads(c["pos"], c["mapq"])
+        ctx.reference(c["ref"])
+        ctx.satellites(np.zeros(0, np.int32), np.zeros(0, np.int32))
+        for off in (1 << 40, (1 << 64) - 40, 1000):
+            stg = capi.SplitStaging()
+            ctx._check(ctx._lib.conga_split_reads_staging(ctx._h, C.byref(stg)))
+            stg.pos[0], stg.mapq[0], stg.flag[0], stg.l_qseq[0] = 1000, 60, 0, 100
+            stg.data_off[0] = off
+            assert ctx._lib.conga_split_reads_commit(ctx._h, 1, 150) != 0   # 100 bases need 150 bytes from `off` on
+        pos = c["pos"].copy()
+        pos[0::7] = -5
+        pos[1::7] = c["L"] + 17
+        pos[2::7] = 2_000_000_000
+        ctx.split_reads(pos, c["mapq"], c["flag"], c["lq"], c["codes"], c["qual"], c["off"])
+        ctx.intervals("D", ds, de)
+        dels, _, _, st = ctx.finish()
+        assert st.split_elements > 0
