@@ -30,6 +30,7 @@ def blocks_of(raw):
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     container = len(sys.argv) > 3 and sys.argv[3] == "container"   # damage the BGZF container of a deflated BAM instead of records
+    index = len(sys.argv) > 3 and sys.argv[3] == "index"           # damage the .bai instead
     d = tempfile.mkdtemp(prefix="conga_bamfuzz_")
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 77)
     cs = [synth.make_chrom(n, L, cov=2.0, n_dels=nd, gaps=True) for n, L, nd in (("1", 500_000, 20), ("2", 300_000, 12))]
@@ -56,6 +57,31 @@ def main():
     ckinds = ["header byte", "bsize", "deflate byte", "crc", "isize", "xlen", "truncate", "deflate bit"]
     for case in range(n_cases):
         raw = bytearray(good)
+        if index:
+            kind = ["byte", "int32", "int64", "truncate"][case % 4]
+            ix = bytearray(bai)
+            if kind == "byte":
+                ix[int(rng.integers(0, len(ix)))] = int(rng.integers(0, 256))
+            elif kind == "int32":
+                struct.pack_into("<i", ix, int(rng.integers(0, len(ix) - 4)), int(rng.choice([-1, 0, 1, 1 << 20, 0x7fffffff, -5])))
+            elif kind == "int64":
+                struct.pack_into("<Q", ix, int(rng.integers(0, len(ix) - 8)), int(rng.choice([0, 1 << 16, (1 << 63) - 1, 12345 << 16, len(good) << 16])))
+            else:
+                del ix[int(rng.integers(0, len(ix))):]
+            bam = "c%d.bam" % case
+            open(os.path.join(d, bam), "wb").write(bytes(raw))
+            open(os.path.join(d, bam + ".bai"), "wb").write(bytes(ix))
+            rg, fg = run(bam, "g%d" % case, True)
+            rh, fh = run(bam, "h%d" % case, False)
+            same = rg.returncode == rh.returncode and fg == fh
+            key = (kind, rg.returncode, rh.returncode, same, "decoding on the host" in rg.stderr)
+            summary[key] = summary.get(key, 0) + 1
+            if rg.returncode < 0 or rh.returncode < 0 or not same:
+                bad += 1
+                print("CASE", case, kind, "gpu rc", rg.returncode, "host rc", rh.returncode, "same files", fg == fh)
+                print("  gpu:", rg.stderr.strip().splitlines()[-2:])
+                print("  host:", rh.stderr.strip().splitlines()[-2:])
+            continue
         if container:
             kind = ckinds[case % len(ckinds)]
             bi = int(rng.integers(0, len(blks) - 1))
