@@ -937,7 +937,13 @@ int launch_inflate(conga_ctx *ctx, size_t n_blocks, uint32_t lanes, hipStream_t 
 // full, and every 128 MB of pieces the inflate of the blocks they complete is launched on one of three streams, so that
 // copying in, copying up and inflating all run at once.  Ends with ctx->stream waiting for every launch.
 // blocks[] must be in file order (data_off ascending); the caller falls back to the plain form otherwise.
-constexpr size_t kBzPiece = (size_t) 8 << 20;
+// a slot of the ring (CONGA_BGZF_SLOT_MB: measurement switch; pieces are at most a slot)
+size_t bz_slot_bytes()
+{
+	static const size_t n = getenv("CONGA_BGZF_SLOT_MB") ? (size_t) std::max(1, std::min(atoi(getenv("CONGA_BGZF_SLOT_MB")), 64)) << 20 : (size_t) 8 << 20;
+	return n;
+}
+#define kBzPiece bz_slot_bytes()
 constexpr int kBzMaxSlots = 12, kBzMaxStreams = 3, kBzPiecesPerLaunch = 16;
 // how many of them are used (CONGA_BGZF_SLOTS / CONGA_BGZF_STREAMS: measurement switches)
 int bz_slots()
@@ -1027,6 +1033,8 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const ByteSource &src, size_t 
 	if (const char *e = getenv("CONGA_BGZF_PIECE_KB"))
 		piece = std::min(kBzPiece, std::max<size_t>(4096, (size_t) atol(e) << 10));
 	const size_t n_pieces = (n_bytes + piece - 1) / piece;
+	// (sixteen pieces per launch; slots above 8 MB: 128 MB per launch)
+	const size_t pieces_per_launch = piece <= ((size_t) 8 << 20) ? (size_t) kBzPiecesPerLaunch : std::max<size_t>(1, ((size_t) 128 << 20) / piece);
 	// everything enqueued on ctx->stream so far (tables, buffers grown) comes first
 	HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
 	HIP_TRY(ctx, hipStreamWaitEvent(ctx->bz_copy, ctx->ev_fork, 0));
@@ -1121,7 +1129,7 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const ByteSource &src, size_t 
 		if (rc != CONGA_OK)
 			break;
 		const bool last = c + 1 == n_pieces;
-		if ((c + 1) % kBzPiecesPerLaunch == 0 || last) {
+		if ((c + 1) % pieces_per_launch == 0 || last) {
 			// the blocks that are complete with the bytes up to here
 			const size_t have = at + len;
 			size_t b1 = b_done;
