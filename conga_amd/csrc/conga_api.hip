@@ -1028,25 +1028,32 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const ByteSource &src, size_t 
 	if (ctx->bz_ring_failed || !ctx->h_bz_ring)
 		return fail(ctx, CONGA_ERR_NOMEM, "conga_reads_bgzf: no pinned staging ring");
 	TRY(ensure_x2n(ctx));
-	const double ms_ring = ms_since(t0);
-	size_t piece = kBzPiece; // (tests: small pieces, so that a small file goes through every part of this)
-	if (const char *e = getenv("CONGA_BGZF_PIECE_KB"))
-		piece = std::min(kBzPiece, std::max<size_t>(4096, (size_t) atol(e) << 10));
-	const size_t n_pieces = (n_bytes + piece - 1) / piece;
-	// (sixteen pieces per launch; slots above 8 MB: 128 MB per launch)
-	const size_t pieces_per_launch = piece <= ((size_t) 8 << 20) ? (size_t) kBzPiecesPerLaunch : std::max<size_t>(1, ((size_t) 128 << 20) / piece);
-	// everything enqueued on ctx->stream so far (tables, buffers grown) comes first
-	HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-	HIP_TRY(ctx, hipStreamWaitEvent(ctx->bz_copy, ctx->ev_fork, 0));
-	for (int k = 0; k < ctx->n_bz_streams; k++)
-		HIP_TRY(ctx, hipStreamWaitEvent(ctx->bz_kernel[k], ctx->ev_fork, 0));
-
+	// the third launch stream, if the thread the first call left behind has made it (before anything below counts streams)
 	if (ctx->bz_shared && ctx->n_bz_streams == 2 && ctx->bz_third_ready.load(std::memory_order_acquire) && bz_streams_wanted() > 2) {
 		ctx->bz_third_maker.join();
 		ctx->bz_kernel[2] = ctx->bz_third;
 		ctx->ev_bz_kernel[2] = ctx->ev_bz_third;
 		ctx->n_bz_streams = 3;
 	}
+	const double ms_ring = ms_since(t0);
+	size_t piece = kBzPiece; // (tests: small pieces, so that a small file goes through every part of this)
+	if (const char *e = getenv("CONGA_BGZF_PIECE_KB"))
+		piece = std::min(kBzPiece, std::max<size_t>(4096, (size_t) atol(e) << 10));
+	const size_t n_pieces = (n_bytes + piece - 1) / piece;
+	// Launch size: a launch lasts at least one block's 4.4 ms and the launches of a stream follow one another, so with two
+	// launch streams (the first call of a context, make_bz_ring) 128 MB per launch -- 3 440 blocks, 42 % of the waves the
+	// machine holds -- left it half empty: 97 ms for the stage against 86-93 with 256 MB (32 MB: 248 ms, 64: 143, 384: 96);
+	// with three streams 128 MB fill it.  (Small test pieces: sixteen per launch.  CONGA_BGZF_LAUNCH_MB: measurement switch.)
+	size_t pieces_per_launch = piece < kBzPiece ? (size_t) kBzPiecesPerLaunch
+			: std::max<size_t>(1, ((size_t) (ctx->n_bz_streams >= 3 ? 128 : 256) << 20) / piece);
+	if (const char *e = getenv("CONGA_BGZF_LAUNCH_MB"))
+		pieces_per_launch = std::max<size_t>(1, ((size_t) std::max(1, atoi(e)) << 20) / piece);
+	// everything enqueued on ctx->stream so far (tables, buffers grown) comes first
+	HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+	HIP_TRY(ctx, hipStreamWaitEvent(ctx->bz_copy, ctx->ev_fork, 0));
+	for (int k = 0; k < ctx->n_bz_streams; k++)
+		HIP_TRY(ctx, hipStreamWaitEvent(ctx->bz_kernel[k], ctx->ev_fork, 0));
+
 	const int kBzSlots = bz_slots();
 	std::mutex mu;
 	std::condition_variable cv;
