@@ -5,7 +5,7 @@ namespace conga_host {
 int total_dels = 0;
 int total_dups = 0;
 
-void output_SVs(const parameters *params, const chrom_svs &svs, FILE *fpSVs, FILE *fp_del, FILE *fp_dup)
+void output_SVs(const parameters *params, const chrom_svs &svs, FILE *fpSVs, FILE *fp_del, FILE *fp_dup, FILE *progress)
 {
 	const char *chr = svs.chr_name.c_str();
 	const bool with_map = params->have_map;
@@ -65,9 +65,10 @@ void output_SVs(const parameters *params, const chrom_svs &svs, FILE *fpSVs, FIL
 		}
 	}
 
-	fprintf(stderr, "\nFound %d DELs - %d DUPs\n\n", sv_cnt_del, sv_cnt_dup);
-	total_dels += sv_cnt_del;
-	total_dups += sv_cnt_dup;
+	fprintf(progress ? progress : stderr, "\nFound %d DELs - %d DUPs\n\n", sv_cnt_del, sv_cnt_dup);
+	// (chromosomes are formatted side by side, bam_data.cpp: the totals are added atomically)
+	__atomic_fetch_add(&total_dels, sv_cnt_del, __ATOMIC_RELAXED);
+	__atomic_fetch_add(&total_dups, sv_cnt_dup, __ATOMIC_RELAXED);
 }
 
 } // namespace conga_host

@@ -21,6 +21,7 @@ struct chrom_svs {
 };
 
 // output_SVs (likelihood.c:172-288): same rows, same format strings, same filters.
-void output_SVs(const parameters *params, const chrom_svs &svs, FILE *fpSVs, FILE *fp_del, FILE *fp_dup);
+// progress: where the "Found n DELs - m DUPs" line goes (NULL: stderr)
+void output_SVs(const parameters *params, const chrom_svs &svs, FILE *fpSVs, FILE *fp_del, FILE *fp_dup, FILE *progress = nullptr);
 
 } // namespace conga_host
