@@ -1751,7 +1751,7 @@ __device__ __forceinline__ void chain_block_body(const ChainArgs &a, int64_t blo
 	constexpr int W = 8;
 	constexpr int SW = 256 * W; // windows per step
 	const int lane = threadIdx.x & (kWave - 1);
-	const int wid = threadIdx.x / kWave;
+	const int wid = __builtin_amdgcn_readfirstlane((int) (threadIdx.x / kWave)); // (uniform in the wave; said so, it and what follows from it are scalars)
 	const int gl = threadIdx.x; // lane inside the group = the workgroup
 	const bool have = block < count;
 	ChainInterval ci = {0, 0, 0, 0, 0, 1, a.gc_like, 0};
@@ -1919,7 +1919,8 @@ template <bool LDS_TABLES> __device__ __forceinline__ void chain_serial_lanes(co
 	// lane (dword k of lane l at [k * 64 + l]: conflict-free), and the next 64 are already in registers.  No global
 	// load inside the trip loop: one that the loop top has to wait for (every fourth trip, with the words fetched one
 	// at a time) cost more than the arithmetic of the trip.
-	uint32_t *col = reinterpret_cast<uint32_t *>(stage) + (threadIdx.x / kWave) * (kWave * 16) + (threadIdx.x & (kWave - 1));
+	uint32_t *col = reinterpret_cast<uint32_t *>(stage) + __builtin_amdgcn_readfirstlane((int) (threadIdx.x / kWave)) * (kWave * 16)
+			+ (threadIdx.x & (kWave - 1));
 	// window indices and positions stay below 2^31 + step: 32-bit arithmetic throughout the trip loop
 	const uint32_t w_end32 = (uint32_t) w_end, n_win32 = (uint32_t) n_win;
 	uint32_t w = (uint32_t) ci.w_first;
@@ -1997,7 +1998,7 @@ template <bool LDS_TABLES> __device__ __forceinline__ void chain_serial_lanes(co
 	// in LDS, then four neighbouring lanes write one record's four 16-byte quarters, sixteen records (1 KiB) per
 	// instruction.
 	const int lane = threadIdx.x & (kWave - 1);
-	uint4 *my_stage = stage + (size_t) (threadIdx.x / kWave) * kWave * 4; // this wave's 64 records
+	uint4 *my_stage = stage + (size_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x / kWave)) * kWave * 4; // this wave's 64 records
 	if (have) {
 		a.expected[ci.iv] = s;
 		const conga_result r = score_interval(a.score, ci.iv, s);
@@ -2060,7 +2061,7 @@ __global__ __launch_bounds__(256, 5) void interval_chain_kernel(ChainArgs a)
 		// Classes A and B share workgroups: one wave of each of the first n_a workgroups takes a long chain (class A,
 		// the slot rotates so that they land on different SIMDs), every other wave takes four class-B chains.  Packing
 		// four long chains into one workgroup put them on one CU, whose SIMDs then ran 1.5x the work of the others.
-		const int wid = threadIdx.x / kWave;
+		const int wid = __builtin_amdgcn_readfirstlane((int) (threadIdx.x / kWave)); // (the wave's number: a scalar, and so are the chains it picks)
 		float *sE_wave = sE + wid * 4 * (kGcBins + 3);
 		const int a_slot = b & 3;
 		if (b < (int) a.n_a && wid == a_slot)
