@@ -1240,7 +1240,7 @@ __global__ __launch_bounds__(256) void paint_winner_kernel(const int32_t *__rest
 {
 	// one wave per row; lanes stride over the row's bases
 	const int lane = threadIdx.x & (kWave - 1);
-	const int64_t wave = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+	const int64_t wave = (int64_t) blockIdx.x * (blockDim.x / kWave) + __builtin_amdgcn_readfirstlane((int) (threadIdx.x / kWave));
 	const int64_t n_waves = (int64_t) gridDim.x * blockDim.x / kWave;
 	for (int64_t r = wave; r < m; r += n_waves) {
 		int64_t s = start[r], e = end[r];
@@ -1292,7 +1292,8 @@ struct ReduceArgs {
 __global__ __launch_bounds__(256) void interval_reduce_kernel(ReduceArgs a)
 {
 	const int lane = threadIdx.x & (kWave - 1);
-	const int64_t item = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+	// (the wave's item: the same in all its lanes -- said so, its bounds are scalars and their loads scalar loads)
+	const int64_t item = (int64_t) blockIdx.x * (blockDim.x / kWave) + __builtin_amdgcn_readfirstlane((int) (threadIdx.x / kWave));
 	if (item >= a.n_items)
 		return; // wave-uniform
 	const int64_t s = a.item_off[item], e = s + a.item_len[item];
