@@ -589,10 +589,13 @@ public:
 			max_piece = (uint64_t) (atof(e) * 1048576.0); // (fractions allowed: tests)
 		if (stop - c_lo < min_piece_bytes || stop - c_lo > max_piece)
 			return false; // (nothing has been read yet)
-		// The bytes are not mapped: the table below needs 26 bytes of every block and the upload reads the file into pinned
-		// memory with pread (conga_reads_bgzf_fd) -- no page faults (750 000 of them for a 3 GB stretch), nothing to unmap.
-		// CONGA_BAM_MMAP=1: the mapped form (every page touched on all cores first).
-		if (getenv("CONGA_BAM_MMAP") != nullptr ? !bytes->open(path_, c_lo, stop) : !bytes->open_fd(path_, c_lo, stop))
+		// The stretch is mapped and its pages touched on all cores (this runs beside the HIP runtime's start, or beside the
+		// sample before in a cohort): the upload's host threads then fill the pinned pieces at memcpy's pace -- 10 ms each
+		// against 30-40 ms with pread (conga_reads_bgzf_fd: no mapping, 26 bytes of every block read for the table below),
+		// and the pieces are up after 60 ms instead of 80-90 (profiles/r02c_upload_mmap_vs_pread.log).
+		// CONGA_BAM_MMAP=0: the pread form.
+		const char *mm = getenv("CONGA_BAM_MMAP");
+		if ((mm == nullptr || atoi(mm) != 0) ? !bytes->open(path_, c_lo, stop) : !bytes->open_fd(path_, c_lo, stop))
 			return false;
 		// ---- block table.  A BGZF file is a chain (every header says where the next block starts), but the index knows
 		// thousands of block starts along it: the stretch is cut at some of them and every part is walked by its own thread;

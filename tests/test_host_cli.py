@@ -310,9 +310,10 @@ def test_cli_bam_decoded_on_the_gpu_matches_the_host_decoders(tmp_path, oracle):
     # this small file with 8 KB pieces, and the plain form; the round-1 kernel (one block per lane) once more
     for tag, env in (("ovl", dict(CONGA_BGZF_OVERLAP="1", CONGA_BGZF_PIECE_KB="8")), ("ovl1", dict(CONGA_BGZF_OVERLAP="1", CONGA_BGZF_PIECE_KB="8", CONGA_BGZF_COPY_THREADS="1")),
                      ("plain", dict(CONGA_BGZF_OVERLAP="0")), ("lane", dict(CONGA_BGZF_KERNEL="lane")),
-                     ("mapped", dict(CONGA_BAM_MMAP="1")), ("ovlmap", dict(CONGA_BAM_MMAP="1", CONGA_BGZF_OVERLAP="1", CONGA_BGZF_PIECE_KB="8")),
+                     # (the file read with pread instead of mapped)
+                     ("unmapped", dict(CONGA_BAM_MMAP="0")), ("ovlfd", dict(CONGA_BAM_MMAP="0", CONGA_BGZF_OVERLAP="1", CONGA_BGZF_PIECE_KB="8")),
                      # the block table walked in parts from block starts the index knows (as for files above 64 MB), read with pread and mapped
-                     ("parts", dict(CONGA_BAM_PARALLEL_MIN_KB="0")), ("partsmap", dict(CONGA_BAM_PARALLEL_MIN_KB="0", CONGA_BAM_MMAP="1"))):
+                     ("parts", dict(CONGA_BAM_PARALLEL_MIN_KB="0")), ("partsfd", dict(CONGA_BAM_PARALLEL_MIN_KB="0", CONGA_BAM_MMAP="0"))):
         r_x, x = cli(tag, CONGA_GPU_BAM="1", CONGA_TIMING="1", **env)
         assert x == gpu and "decoding on the host" not in r_x.stderr and r_x.stderr.count("conga_reads_bgzf:") == 1, tag
         assert ("overlapped" in r_x.stderr) == tag.startswith("ovl"), tag
