@@ -2131,6 +2131,12 @@ int conga_split_reads_commit(conga_ctx *ctx, size_t n_reads, size_t n_bytes)
 		if (l < 0 || st.data_off[i] > n_bytes || need > n_bytes - st.data_off[i]) // (no sum that could wrap)
 			return fail(ctx, CONGA_ERR_RANGE, "conga_split_reads_commit: record block outside the committed bytes");
 		st.data_off[i] += (uint64_t) ctx->sr_bytes_total; // rebase into the device arena
+		// A negative position is no record of this chromosome (the reference's iterator never returns one), and the kernel would
+		// look up the reference in front of its first base: such a record goes in with the QC-fail bit, which the gate of
+		// find_split_reads' caller (bam_data.c:207, is_proper) drops.  (Here and not in the kernel: `p <= 0` for `p == 0` there
+		// made its launch 18 % longer -- the register allocation of that kernel hangs by a thread.)
+		if (st.pos[i] < 0)
+			st.flag[i] |= 0x200;
 	}
 	const size_t nr = (size_t) ctx->n_sr_total + n_reads, nb = (size_t) ctx->sr_bytes_total + n_bytes;
 	TRY(ensure(ctx, ctx->d_sr_pos, std::max(nr, (size_t) 1 << 20) * 4, true));

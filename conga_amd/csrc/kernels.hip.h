@@ -2358,7 +2358,7 @@ __device__ __forceinline__ void split_read_one(const SplitArgs &a, int64_t r, ui
 		// gate of count_reads_bam (bam_data.c:205-207) and find_split_reads' pos == 0 (split_read.c:216)
 		if (!(q > a.mq_threshold) || !(l > a.min_read_length) || (fl & (0x100 | 0x800 | 0x400 | 0x200)) != 0)
 			return;
-		if (p <= 0 || l > 2 * kSrMaxHalf - 2) // (p == 0: split_read.c:216; a negative position is no record of this chromosome: the reference is never asked for it)
+		if (p == 0 || l > 2 * kSrMaxHalf - 2)
 			return;
 		const uint8_t *sq = a.data + d_off;
 		const uint8_t *qq = sq + (l + 1) / 2;
