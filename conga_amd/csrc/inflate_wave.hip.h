@@ -409,8 +409,10 @@ __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Lu
 		const uint32_t w2 = (uint32_t) __builtin_amdgcn_ds_bpermute((int) at + 8, (int) wreg);
 		const uint32_t sh = b & 31u;
 		const uint32_t lo = alignbit(w1, w0, sh), hi = alignbit(w2, w1, sh);
-		// the literal / length code that would start here (second level read by every lane: some lane nearly always needs it;
-		// a lane that does not reads some other entry of the wave's tables and drops it)
+		// the literal / length code that would start here (second level read by every lane: some lane nearly always needs it.
+		// A lane whose root entry is no pointer forms its second index from that entry's other fields: it reads some other
+		// halfword of LDS -- of this wave's tables, of a neighbour's, or past the workgroup's allocation, where the hardware
+		// returns 0 -- and drops it.  Deliberate: a clamp would be two more vector instructions per trip for nothing.)
 		const uint32_t e1 = t.lit[lo & ((1u << kLitRoot) - 1u)];
 		const bool sub1 = (e1 & 0xF0u) == LitFormat::kSub;
 		const uint32_t e2 = t.lit[(1u << kLitRoot) + ((e1 >> 8) << 1) + ((lo >> kLitRoot) & ((1u << (e1 & 15u)) - 1u))];
