@@ -593,9 +593,11 @@ public:
 		// sample before in a cohort): the upload's host threads then fill the pinned pieces at memcpy's pace -- 10 ms each
 		// against 30-40 ms with pread (conga_reads_bgzf_fd: no mapping, 26 bytes of every block read for the table below),
 		// and the pieces are up after 60 ms instead of 80-90 (profiles/r02c_upload_mmap_vs_pread.log).
-		// CONGA_BAM_MMAP=0: the pread form.
+		// A process that goes on to other samples (`conga --cohort`) has to give the mapping back -- 75 ms of munmap for 3 GB of
+		// touched pages, on its critical path or as TLB shootdowns under the next sample's threads -- and is better off with
+		// pread: ten genomes in 1.76 s against 1.90-1.99 s (map_bam_pieces, bam_data.cpp).  CONGA_BAM_MMAP=0 / 1 decides for both.
 		const char *mm = getenv("CONGA_BAM_MMAP");
-		if ((mm == nullptr || atoi(mm) != 0) ? !bytes->open(path_, c_lo, stop) : !bytes->open_fd(path_, c_lo, stop))
+		if ((mm != nullptr ? atoi(mm) != 0 : map_bam_pieces) ? !bytes->open(path_, c_lo, stop) : !bytes->open_fd(path_, c_lo, stop))
 			return false;
 		// ---- block table.  A BGZF file is a chain (every header says where the next block starts), but the index knows
 		// thousands of block starts along it: the stretch is cut at some of them and every part is walked by its own thread;

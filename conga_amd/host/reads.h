@@ -29,6 +29,9 @@ struct full_batch {
 };
 
 // A stretch of a file, memory-mapped (the page cache is the only copy on the host; the GPU upload reads from it).
+// whether device_plan() maps the stretch of the BAM it hands over (a single run) or leaves it to pread (a cohort)
+extern bool map_bam_pieces;
+
 struct file_piece {
 	const uint8_t *data = nullptr; // the mapped bytes (open), or nullptr when only the descriptor is held (open_fd)
 	size_t size = 0;
