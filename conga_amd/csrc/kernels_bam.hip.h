@@ -78,9 +78,11 @@ struct BamWalkArgs {
 	uint8_t *mapq;
 };
 
+// a little-endian int32 at ANY address: global memory takes unaligned dword accesses (one load instead of four byte loads
+// put together -- a record's fields are what the walk below reads, one lane per segment, every load a cache line of its own)
 __device__ __forceinline__ int32_t load_i32(const uint8_t *p)
 {
-	return (int32_t) ((uint32_t) p[0] | ((uint32_t) p[1] << 8) | ((uint32_t) p[2] << 16) | ((uint32_t) p[3] << 24));
+	return (int32_t) *reinterpret_cast<const uint32_t *>(p);
 }
 
 template <bool WRITE> __global__ __launch_bounds__(64) void bam_walk_kernel(BamWalkArgs a)
@@ -132,7 +134,7 @@ template <bool WRITE> __global__ __launch_bounds__(64) void bam_walk_kernel(BamW
 			continue;
 		if (WRITE) {
 			a.pos[w] = p;
-			a.mapq[w] = r[13];
+			a.mapq[w] = (uint8_t) ((uint32_t) load_i32(r + 12) >> 8); // l_read_name, MAPQ, bin: the byte at 13
 			w++;
 		}
 		n++;
