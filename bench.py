@@ -654,7 +654,62 @@ def config_legs(args, env):
                 value=round(len(smp["pos"]) / t_cpu, 1), unit="records/s", cores=1, kind="port",
                 sample="first %d records of chromosome %s through oracle/conga_oracle_sr.c (%.1f s, includes one build of the "
                        "chromosome's 10-mer index)" % (len(smp["pos"]), smp["name"], t_cpu))
+    legs["bgzf_inflate"] = bgzf_leg(args, env)
     return legs
+
+
+def bgzf_leg(args, env):
+    """The BGZF inflate stage of the BAM route (conga_reads_bgzf's first kernel; SURVEY.md 8f row 1: the producer side of
+    count_reads_bam is htslib's BGZF reader in the reference, bam_data.c:253-259).  A 1x chromosome 21 is written as a BAM with
+    random bases and qualities; its BGZF blocks, some twenty times over in the block table (the same compressed bytes, as many
+    places of their own in the output: ~20 500 blocks, two and a half rounds of the 8 192 waves the machine holds), are inflated
+    and CRC-checked by conga_inflate_blocks.  CPU beside it: zlib on one core, a sample of the same blocks."""
+    import struct
+    import tempfile
+    import zlib
+    from conga_amd import formats
+    lens = dict(synth.GRCH37_AUTOSOMES)
+    c = synth.make_chrom("21", lens["21"], cov=1.0)
+    d = tempfile.mkdtemp(prefix="conga_bench_bgzf_")
+    path = os.path.join(d, "r.bam")
+    formats.write_bam_fast(path, "S", [(c.name, c.length, c.pos, c.mapq)], realistic=True, level=1)
+    raw = np.fromfile(path, np.uint8)
+    os.remove(path)
+    os.rmdir(d)
+    buf, blocks, at = raw.tobytes(), [], 0
+    while at + 18 <= len(buf):
+        bsize = struct.unpack_from("<H", buf, at + 16)[0] + 1
+        crc, isize = struct.unpack_from("<II", buf, at + bsize - 8)
+        if isize:
+            blocks.append((at + 18, bsize - 26, isize, crc))
+        at += bsize
+    times = max(1, round(2.5 * 8192 / max(len(blocks), 1)))   # ~20 500 blocks, as tools/inflate_bench.py's file has (the machine holds 8 192 waves)
+    table = blocks * times
+    inflated = sum(b[2] for b in table)
+    with capi.Context(device=env["local_rank"]) as ctx:
+        best = 1e30
+        for _ in range(4):
+            _o, status, ms = ctx.inflate_blocks(raw, table, want_out=False)
+            assert not status.any(), "a BGZF block of the bench's own BAM did not inflate"
+            best = min(best, ms)
+    out = dict(workload="BGZF blocks of a 1x chromosome 21 (synthetic BAM, random bases and qualities, zlib level 1), %d blocks x %d "
+                        "in the block table = %d blocks, %.1f MB compressed -> %.1f MB inflated per launch; one BGZF block per wave, "
+                        "CRC32 checked on the device" % (len(blocks), times, len(table), len(raw) / 1e6, inflated / 1e6),
+               blocks=len(table), kernel_ms=round(best, 3), value=round(inflated / best / 1e6, 2), unit="GB/s inflated",
+               note="instruction-bound byte work (profiles/r02c_inflate_pmc.txt: the vector unit is busy ~97 % of the launch); as HBM "
+                    "bytes this is under 1 % of the peak.  The rate depends on how the blocks fill the machine's 8 192 waves: three "
+                    "full rounds (24 465 blocks) measure 57.7 GB/s, the whole-genome BAM stage (79 086 blocks in 12 overlapping "
+                    "launches behind the upload) 62.4 GB/s end to end")
+    if args.cpu_seconds > 0:
+        k = min(len(blocks), 400)
+        t0 = time.perf_counter()
+        n = 0
+        for off, ln, isz, _crc in blocks[:k]:
+            n += len(zlib.decompress(buf[off:off + ln], -15))
+        t_cpu = time.perf_counter() - t0
+        out["cpu_baseline"] = dict(value=round(n / t_cpu / 1e9, 3), unit="GB/s inflated", cores=1, kind="zlib",
+                                   sample="%d of the blocks through zlib.decompress (%.2f s; no CRC check)" % (k, t_cpu))
+    return out
 
 
 if __name__ == "__main__":
