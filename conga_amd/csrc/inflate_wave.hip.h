@@ -53,7 +53,7 @@ struct LitFormat {
 	enum : uint32_t { kEob = 0x10, kSub = 0x20, kHoleTag = 0x30 };
 	// kEob | n1: end of block; kSub | bits indexing the second-level table | (its offset behind the root / 2) << 8;
 	// kHoleTag: no codeword leads here (or one of the two that must not occur)
-	static constexpr uint32_t hole = kHoleTag;
+	static constexpr uint32_t hole = kHoleTag | 1u; // (n1 = 1: whatever stands at a position, the symbol behind it starts further on)
 	__device__ static uint32_t entry(uint32_t sym, uint32_t len)
 	{
 		if (sym < 256u)
@@ -428,7 +428,9 @@ __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Lu
 		// base values: asked for now, needed behind the walk
 		const uint32_t lbase = luts.len[(e >> 8) & 31u];
 		const uint32_t dbase = luts.dist[(ed >> 9) & 31u];
-		const uint32_t bits = max(is_match ? n1 + eb + (ed & 31u) : n1, 1u); // (never 0 by construction; the walk below must move)
+		// (never 0: a codeword has a length, and a hole is given one -- LitFormat::hole; the walk below must move)
+		const unsigned long long is_match_m = __ballot(is_match);
+		const uint32_t bits = is_match ? n1 + eb + (ed & 31u) : n1;
 		const uint32_t nxt = lane + bits; // where the symbol behind this one starts
 		IW_LAP(P_VIEW);
 
@@ -456,7 +458,7 @@ __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Lu
 		}
 		const bool on_chain = __builtin_amdgcn_inverse_ballot_w64(chain);
 		// a hole, or a length whose distance is one: the stream is invalid (a hole ends the chain, a bad distance is met on it)
-		const unsigned long long match_m = chain & __ballot(is_match);
+		const unsigned long long match_m = chain & is_match_m;
 		if ((chain & hole_m) | (match_m & __ballot((ed & 0x8000u) != 0u)))
 			return leave(-1);
 		const bool ends = (chain & eob_m) != 0ull;
@@ -464,7 +466,8 @@ __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Lu
 		const uint32_t val = e >> 8;
 		const uint32_t deb = (ed >> 5) & 15u;
 		const uint32_t dist = dbase + ((r2 >> ((ed & 31u) - deb)) & ((1u << deb) - 1u));
-		const uint32_t produced = is_match ? lbase + ((lo >> n1) & ((1u << eb) - 1u)) : is_lit ? 1u : 0u;
+		const bool is_len = __builtin_amdgcn_inverse_ballot_w64(is_match_m); // (the predicate behind the walk: straight from the mask)
+		const uint32_t produced = is_len ? lbase + ((lo >> n1) & ((1u << eb) - 1u)) : is_lit ? 1u : 0u;
 		IW_LAP(P_WALK);
 		// where every start's bytes go
 		const uint32_t mine = on_chain ? produced : 0u;
@@ -488,7 +491,7 @@ __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Lu
 			// (dist <= to_l is tested on its own: a distance that reaches up to eight bytes in front of the output makes src_l wrap
 			// and src_l + produced wrap back below safe_pos -- damaged streams do that, tests/test_gpu_inflate.py's fuzz found it;
 			// the loop below refuses such a match)
-			const bool fast = on_chain && is_match && produced <= 8u && dist >= produced && dist <= to_l && src_l + produced <= safe_pos;
+			const bool fast = on_chain && is_len && produced <= 8u && dist >= produced && dist <= to_l && src_l + produced <= safe_pos;
 			const unsigned long long fast_m = __ballot(fast);
 			if (fast_m) {
 				if (fast)
