@@ -2473,7 +2473,7 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 		g.n_slots = ctx->n_sr_slots;
 		g.small = small;
 		const int64_t first = ctx->slots[(size_t) ctx->sr_first_slot].sr_off;
-		const int sgrid = (int) std::min<int64_t>((g.base.n_reads - first + 3) / 4, (int64_t) ctx->n_cu * 8);
+		const int sgrid = (int) std::min<int64_t>((g.base.n_reads - first + 3) / 4, (int64_t) ctx->n_cu * 7);
 		hipLaunchKernelGGL(split_read_kernel, dim3(sgrid), dim3(256), 0, st, g, first);
 	}
 

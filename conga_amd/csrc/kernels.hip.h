@@ -2538,10 +2538,10 @@ __device__ __forceinline__ void split_read_one(const SplitArgs &a, int64_t r, ui
 
 // All chromosomes' records in ONE launch, one wave per read; the records of a chromosome are consecutive, so a wave
 // moves from SplitSlot to SplitSlot as its read index grows and flushes its counters into the chromosome it leaves.
-// Measured at 8, 6 and 5 waves per SIMD (64 / 80 / 96 registers, 46 / 31 / 14 of them spilled): 14.5 / 14.4 / 15.0 ms for the
-// 6.56 M records of the bench leg -- the launch is bound by instructions (770 vector + 650 scalar per read), not by the
-// waves in flight.
-__global__ __launch_bounds__(256, 8) void split_read_kernel(SplitBatchArgs g, int64_t first_read)
+// Measured at 8, 7, 6 and 5 waves per SIMD (64 / 72 / 80 / 96 registers, 46 / 34 / 31 / 14 of them spilled): 14.5 / 13.6 / 14.4 /
+// 15.0 ms for the 6.56 M records of the bench leg -- the launch is bound by instructions (770 vector + 650 scalar per read)
+// more than by the waves in flight; seven it is.
+__global__ __launch_bounds__(256, 7) void split_read_kernel(SplitBatchArgs g, int64_t first_read)
 {
 	__shared__ uint8_t s_bases[4][2 * kSrMaxHalf], s_rev[4][kSrMaxHalf], s_qual[4][2 * kSrMaxHalf], s_refw[4][2 * kSrMaxHalf];
 	__shared__ int32_t s_hit_pos[4][kMaxMapping];
