@@ -654,7 +654,10 @@ def config_legs(args, env):
                 value=round(len(smp["pos"]) / t_cpu, 1), unit="records/s", cores=1, kind="port",
                 sample="first %d records of chromosome %s through oracle/conga_oracle_sr.c (%.1f s, includes one build of the "
                        "chromosome's 10-mer index)" % (len(smp["pos"]), smp["name"], t_cpu))
-    legs["bgzf_inflate"] = bgzf_leg(args, env)
+    try:
+        legs["bgzf_inflate"] = bgzf_leg(args, env)
+    except (OSError, MemoryError) as e:   # (no room for the 45 MB scratch BAM, say: the headline does not depend on this leg)
+        legs["bgzf_inflate"] = dict(error="%s: %s" % (type(e).__name__, e))
     return legs
 
 
