@@ -40,6 +40,12 @@ def test_one_json_line_with_cpu_baseline():
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "intervals/s" and cb["value"] > 0 and cb["sample"]
     assert out["cn_concordance"] == 1.0
+    # the legs for the other single-GPU configurations ride in the same line, and the BAM route's inflate kernel with them
+    legs = out["configs"]
+    assert set(legs) == {"configs[2]", "configs[4]", "bgzf_inflate"}
+    assert legs["configs[2]"]["cn_concordance"] == 1.0 and legs["configs[4]"]["records_per_s"] > 0
+    bz = legs["bgzf_inflate"]
+    assert bz["unit"] == "GB/s inflated" and bz["value"] > 5 and bz["blocks"] > 16000 and bz["cpu_baseline"]["kind"] == "zlib"
 
 
 @pytest.mark.gpu
