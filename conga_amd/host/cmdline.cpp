@@ -14,7 +14,7 @@
 #define CONGA_VERSION "1.0-mi355x"
 #endif
 #ifndef CONGA_UPDATE
-#define CONGA_UPDATE "round 1"
+#define CONGA_UPDATE "round 2"
 #endif
 #ifndef BUILD_DATE
 #define BUILD_DATE __DATE__
