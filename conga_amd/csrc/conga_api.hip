@@ -1876,7 +1876,11 @@ int reads_bgzf_from(conga_ctx *ctx, const ByteSource &src, size_t n_bytes, const
 	for (size_t k = 0; k < n_segments; k++) {
 		if (bad[k])
 			return fail(ctx, CONGA_ERR_DATA, "conga_reads_bgzf: a start point does not lead along whole BAM records");
-		if (k + 1 < n_segments && segments[k + 1].chrom == segments[k].chrom && v_stop[k] != v_first[k + 1])
+		// the record that ends a segment is the next segment's first -- inside a chromosome, and from a target to the target
+		// that follows it in the file (whatever ends target t is the first record behind it: the first of target t + 1 if that
+		// one has records, and what ends that one's empty walk if it has none)
+		if (k + 1 < n_segments && (segments[k + 1].chrom == segments[k].chrom || segments[k + 1].ref_id == segments[k].ref_id + 1)
+				&& v_stop[k] != v_first[k + 1])
 			return fail(ctx, CONGA_ERR_DATA, "conga_reads_bgzf: the start points do not line up with the records");
 		write_at[k] = (uint64_t) ctx->n_reads_total + n_new;
 		n_new += count[k];

@@ -108,7 +108,16 @@ template <bool WRITE> __global__ __launch_bounds__(64) void bam_walk_kernel(BamW
 		const int32_t ref = load_i32(r + 4), p = load_i32(r + 8);
 		const uint64_t here = at;
 		if (!(ref >= 0 && ref < sg.ref_id) && (ref != sg.ref_id || p >= sg.pos_hi)) {
-			// the record that ends the segment; only its first fields are needed (the piece of the file may end inside it)
+			// the record that ends the segment; only its first fields are needed (the piece of the file may end inside it).
+			// It has to look like one: of this target behind the segment, of a later target, or of the unplaced tail -- a
+			// damaged header in the middle of a target must not pass for the target's end (tools/bam_fuzz.py found that it did:
+			// the reads behind it were left out without a word)
+			const bool plausible = block_size <= (1 << 26)
+					&& (ref == sg.ref_id || (ref > sg.ref_id && ref < (1 << 24) && p >= -1) || (ref == -1 && p >= -1));
+			if (!plausible) {
+				bad = true;
+				break;
+			}
 			stop = here;
 			if (first == kNone)
 				first = here;

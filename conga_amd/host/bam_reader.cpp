@@ -487,21 +487,27 @@ public:
 				}
 				int32_t block_size;
 				uint8_t b[32];
-				if (!bz.read(&block_size, 4) || block_size < 32 || !bz.read(b, 32) || !bz.skip((size_t) block_size - 32)) {
+				if (!bz.read(&block_size, 4) || block_size < 32 || !bz.read(b, 32)) {
 					sg.err = bz.error().empty() ? "truncated BAM record" : bz.error();
 					break;
 				}
 				int32_t ref_id, p;
 				memcpy(&ref_id, b, 4);
 				memcpy(&p, b + 4, 4);
-				if (ref_id >= 0 && ref_id < tid)
-					continue; // (a chunk may begin with the tail of the previous target)
-				if (ref_id != tid || p >= sg.hi) {
+				if (!(ref_id >= 0 && ref_id < tid) && (ref_id != tid || p >= sg.hi)) {
+					// the record that ends the segment: only its first fields count (as for the walk on the GPU, kernels_bam.hip.h:
+					// what lies behind them -- another target's record, the unplaced tail -- is not this target's to judge)
 					sg.v_stop = v;
 					if (sg.v_first == bgzf_reader::kNoOffset)
 						sg.v_first = v;
 					break;
 				}
+				if (!bz.skip((size_t) block_size - 32)) {
+					sg.err = bz.error().empty() ? "truncated BAM record" : bz.error();
+					break;
+				}
+				if (ref_id >= 0 && ref_id < tid)
+					continue; // (a chunk may begin with the tail of the previous target)
 				if (p < sg.lo)
 					continue; // starts in front of this segment: the previous one's
 				if (sg.v_first == bgzf_reader::kNoOffset)
