@@ -624,3 +624,12 @@ def test_cli_damaged_bam_records_gpu_and_host_decoders_agree():
     # ... and the container of a deflated BAM: block headers, BSIZE, XLEN, deflate bytes and bits, CRC32, ISIZE, truncation
     r = subprocess.run([sys.executable, tool, "24", "20261005", "container"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "disagreements or crashes 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_cli_records_of_hundreds_of_kilobytes_decode_alike():
+    """Records that span several BGZF blocks each (reads of 70 000 - 200 000 bases among ordinary ones, tools/long_records.py):
+    the walk on the GPU follows them through the concatenated blocks, the host decoders through their stream: same files."""
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "long_records.py")
+    r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "same: True" in r.stdout and "gpu 0 False" in r.stdout and "host 0 False" in r.stdout, r.stdout + r.stderr[-2000:]
