@@ -180,6 +180,7 @@ def main():
                     help="the command line on random BAM files (+ .bai): decode on the GPU (conga_reads_bgzf) against the host "
                          "decoders -- same three output files, same read counts")
     ap.add_argument("--split-reads", action="store_true", help="the --rp path: random references and whole BAM records")
+    ap.add_argument("--chroms-per-batch", type=int, default=0, help="with --batch: this many chromosomes in every batch (default: 1-12)")
     ap.add_argument("--batch", action="store_true",
                     help="CONGA_FLAG_BATCH: 1..12 random chromosomes per context (one launch per kernel over all of them), "
                          "computed twice, with random chain-class thresholds")
@@ -277,7 +278,7 @@ def main():
         rng = np.random.default_rng([a.seed, 7_000_000 + i])
         step = int(rng.choice([100, 100, 100, 64, 1000]))
         mq = int(rng.choice([-1, -1, 0, 20, 60]))
-        cases = [random_case(rng, step, mq) for _ in range(int(rng.integers(1, 13)))]
+        cases = [random_case(rng, step, mq) for _ in range(a.chroms_per_batch or int(rng.integers(1, 13)))]
         knobs = {}
         if rng.random() < 0.7:  # class boundaries of the chain kernel (conga_api.hip: prepare)
             knobs = dict(CONGA_CHAIN_SERIAL_WINDOWS=str(int(rng.choice([0, 3, 20, 56, 200]))),
