@@ -2191,10 +2191,15 @@ int conga_chrom_compute(conga_ctx *ctx)
 	if (ctx->staging_cur >= 0)
 		return fail(ctx, CONGA_ERR_INVALID, "conga_chrom_compute: a staging buffer is handed out and not committed");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
-	if (ctx->layout_dirty || ctx->layout_dense != dense_formulation(ctx))
+	const auto t_prepare = std::chrono::steady_clock::now();
+	const bool whole_layout = ctx->layout_dirty || ctx->layout_dense != dense_formulation(ctx);
+	if (whole_layout)
 		TRY(prepare_layout(ctx));
 	else if (ctx->sample_dirty)
 		TRY(prepare_sample(ctx));
+	if (whole_layout && getenv("CONGA_TIMING"))
+		fprintf(stderr, "[timing] conga_chrom_compute: layout prepared in %.1f ms (host tables, uploads, GC bases per bin; once per layout)\n",
+				std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_prepare).count());
 	if (ctx->n_reads_total == 0) {
 		TRY(ensure(ctx, ctx->d_pos, 256));
 		TRY(ensure(ctx, ctx->d_mapq, 256));
