@@ -32,7 +32,7 @@ DELETION = "D"
 DUPLICATION = "E"
 
 KERNEL_NAMES = ("ingest", "depth_tile", "expected_table", "paint", "interval_reduce", "interval_score",
-                "interval_chain", "interval_count")
+                "interval_chain", "interval_count", "split_map")
 
 # every symbol include/conga_hip.h declares
 EXPORTS = (
@@ -78,7 +78,7 @@ class ChromStats(C.Structure):
     _fields_ = [("reads_committed", C.c_int64), ("reads_counted", C.c_int64),
                 ("reads_out_of_range", C.c_int64), ("rd_sum", C.c_int64), ("mean", C.c_float),
                 ("n_kernels", C.c_int32), ("rd_per_gc", C.c_int64 * 101), ("window_per_gc", C.c_int64 * 101),
-                ("kernel_ms", C.c_double * 8), ("split_elements", C.c_int64), ("split_mappings", C.c_int64),
+                ("kernel_ms", C.c_double * 12), ("split_elements", C.c_int64), ("split_mappings", C.c_int64),
                 ("split_del_rows", C.c_int64), ("split_dup_rows", C.c_int64),
                 ("depth_materialized", C.c_int32), ("reserved", C.c_int32)]
 

@@ -31,6 +31,8 @@
 #include "../../include/conga_hip.h"
 #include "kernels.hip.h"
 #include "kernels_bam.hip.h"
+#include "kmer_sort.h"
+#include "split_map.hip.h"
 
 using namespace conga;
 
@@ -66,8 +68,10 @@ struct HostSlot {
 	// split-read inputs
 	std::vector<uint8_t> ref;               // upper-cased chromosome sequence
 	std::vector<int32_t> sat_start, sat_end; // sorted, disjoint
-	int64_t sr_off = 0, n_sr = 0;           // this chromosome's records in the split-read arrays
-	int64_t ref_off = 0, sat_off = 0;
+	int64_t sr_off = 0, n_sr = 0;           // this chromosome's records in the split-read arrays (in place: in d_sr_recoff = its tuples' indices)
+	bool sr_inplace = false;                // its records lie in the inflated BAM stream of conga_reads_bgzf
+	int64_t refn_off = 0, kpos_off = 0, sat_off = 0; // where its packed reference / 10-mer index / satellites lie (prepare_layout)
+	int kidx = -1;                          // its offset table; -1: no reference, no part in the split-read launch
 	uint64_t ref_version = 0;               // stamps every conga_reference(): the 10-mer index is rebuilt only for new text
 	// filled by prepare()
 	int64_t rd_off = 0, gc_off = 0, tile0 = 0, tidx_off = 0, iv0 = 0, map_row_off = 0, row_tile_off = 0;
@@ -80,6 +84,7 @@ struct conga_ctx {
 	int n_cu = 256;
 	int depth_blocks_per_cu = 8; // resident depth_tile workgroups per CU (occupancy query)
 	int tuple_blocks_per_cu = 8; // resident workgroups per CU of the tuple pass: its grid is exactly one resident wave of them
+	int split_blocks_per_cu = 8; // ... and of the split-read launch, whose workgroups take work units round robin
 	hipStream_t stream = nullptr;
 	hipStream_t stream2 = nullptr; // runs interval_reduce beside the float chain (both are latency-bound)
 	hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_counted = nullptr, ev_join = nullptr;
@@ -111,9 +116,13 @@ struct conga_ctx {
 
 	// layout totals (prepare)
 	int64_t total_L = 0, total_tiles = 0, total_gc = 0, n_iv = 0, n_items = 0, n_chain_x = 0, n_chain_a = 0, n_chain_b = 0, n_depth_blocks = 0;
-	bool gc_like_distinct = false, any_map = false, support_given = false, any_sr = false;
-	int sr_first_slot = 0, sr_last_slot = 0;  // first / last chromosome with split-read records and a reference
+	bool gc_like_distinct = false, any_map = false, support_given = false;
+	bool any_ref = false;                     // some chromosome has a reference sequence (per layout): the support column exists
+	bool any_sr = false;                      // ... and split-read records (per sample): the split-read launch runs
 	int n_sr_slots = 0;                       // chromosomes with split-read records and a reference (one SplitSlot each)
+	uint32_t sr_units = 0;                    // work units of the split-read launch
+	int64_t refn_words = 0, kpos_total = 0, sat_total = 0; // layout totals of the split-read inputs
+	uint64_t bz_keep_bytes = 0;               // bytes of d_bz_out that hold records in place: the next conga_reads_bgzf goes behind them
 	uint64_t ref_stamp = 0;                   // source of HostSlot::ref_version
 	std::vector<uint64_t> index_sig;          // what the resident 10-mer indexes were built from (slot, length, version)
 	bool any_map_painted = false; // some chromosome's track is painted into d_map by compute (dense formulation / unsorted rows)
@@ -132,7 +141,7 @@ struct conga_ctx {
 			d_map_start, d_map_end, d_map_val, d_iv_start, d_iv_end, d_iv_type, d_iv_slot, d_iv_has_map, d_order,
 			d_expected, d_item_off, d_item_len, d_item_iv, d_item_has_map, d_item_first, d_map_part,
 			d_support, d_results, d_bases, d_row_tile, d_depth_blocks, d_support_base, d_ref, d_sat_start, d_sat_end, d_sr_pos,
-			d_sr_mapq, d_sr_flag, d_sr_lq, d_sr_off, d_sr_data, d_kmer_count, d_kmer_offset, d_kmer_cursor, d_kmer_pos, d_sr_slots,
+			d_sr_mapq, d_sr_flag, d_sr_lq, d_sr_off, d_sr_data, d_sr_recoff, d_refn, d_kmer_keys, d_kmer_sorted, d_kmer_tmp, d_kmer_offset, d_kmer_pos, d_sr_slots,
 			// conga_reads_bgzf: compressed blocks, their table, the inflated stream, the decoders' scratch, the walk's per-segment results
 			d_bz_in, d_bz_blocks, d_bz_off, d_bz_out, d_bz_status, d_bz_scratch, d_bz_crc, d_bz_seg, d_bz_cnt, d_bz_first, d_bz_stop,
 			d_bz_bad, d_bz_at, d_bz_flag, d_bz_x2n;
@@ -310,7 +319,9 @@ int prepare_sample(conga_ctx *ctx)
 	const uint32_t grid = (ctx->tuple_chunks + ctx->tuple_chunks_per_block - 1) / ctx->tuple_chunks_per_block;
 	const size_t n_homes = std::max<uint32_t>(grid, 1);
 	const size_t homes_at = ((size_t) std::max(n_slots, 1) * sizeof(Slot) + 255) & ~(size_t) 255;
-	const size_t bytes = homes_at + n_homes * sizeof(TupleBlockHome);
+	// the split-read launch's table: one SplitSlot per chromosome that has a reference AND records of this sample
+	const size_t sr_at = (homes_at + n_homes * sizeof(TupleBlockHome) + 255) & ~(size_t) 255;
+	const size_t bytes = sr_at + (size_t) std::max(n_slots, 1) * sizeof(SplitSlot);
 	if (bytes > ctx->h_head_cap) {
 		if (ctx->head_in_flight)
 			HIP_TRY(ctx, hipEventSynchronize(ctx->ev_head));
@@ -362,11 +373,42 @@ int prepare_sample(conga_ctx *ctx)
 			bh.slot = s;
 		}
 	}
+	{
+		SplitSlot *ss = reinterpret_cast<SplitSlot *>(static_cast<char *>(ctx->h_head) + sr_at);
+		int k = 0;
+		uint64_t units = 0;
+		for (int c = 0; c < n_slots; c++) {
+			const HostSlot &h = ctx->slots[(size_t) c];
+			if (h.kidx < 0 || h.n_sr <= 0)
+				continue;
+			SplitSlot &sl = ss[k++];
+			memset(&sl, 0, sizeof sl);
+			sl.sr_off = h.sr_off;
+			sl.n_sr = h.n_sr;
+			sl.refn_off = h.refn_off;
+			sl.L = h.L;
+			sl.kpos_off = h.kpos_off;
+			sl.kidx = h.kidx;
+			sl.sat_off = (int32_t) h.sat_off;
+			sl.n_sat = (int32_t) h.sat_start.size();
+			sl.iv0 = (int32_t) h.iv0;
+			sl.n_dels = (int32_t) h.iv_start[0].size();
+			sl.n_dups = (int32_t) h.iv_start[1].size();
+			sl.slot = c;
+			sl.unit0 = (uint32_t) units;
+			sl.inplace = h.sr_inplace ? 1 : 0;
+			units += (uint64_t) ((h.n_sr + kSplitUnitReads - 1) / kSplitUnitReads);
+		}
+		ctx->n_sr_slots = k;
+		ctx->sr_units = (uint32_t) units; // (fewer than 2^32 reads in a context: far fewer units)
+		ctx->any_sr = k > 0;
+	}
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_head.p, ctx->h_head, bytes, hipMemcpyHostToDevice, ctx->stream));
 	HIP_TRY(ctx, hipEventRecord(ctx->ev_head, ctx->stream));
 	ctx->head_in_flight = true;
 	ctx->d_slots.p = ctx->d_head.p;
 	ctx->d_block_home.p = static_cast<char *>(ctx->d_head.p) + homes_at;
+	ctx->d_sr_slots.p = static_cast<char *>(ctx->d_head.p) + sr_at;
 	ctx->sample_dirty = false;
 	return CONGA_OK;
 }
@@ -385,6 +427,27 @@ int prepare_layout(conga_ctx *ctx)
 	ctx->any_map_painted = false;
 	ctx->any_map_rows = false;
 	ctx->support_given = false;
+	// split-read inputs: every chromosome with a reference sequence gets its packed reference (8 bases per dword, kRefPadBases
+	// of code 0 behind it), its 10-mer index (one position per base) and its satellites, whatever records this sample has
+	int64_t refn_words = 0, kpos_total = 0, sat_total = 0;
+	int n_ref = 0;
+	for (int s = 0; s < n_slots; s++) {
+		HostSlot &h = ctx->slots[s];
+		h.kidx = -1;
+		if (!h.ref.empty()) {
+			h.kidx = n_ref++;
+			h.refn_off = refn_words;
+			h.kpos_off = kpos_total;
+			h.sat_off = sat_total;
+			refn_words += ((h.L + kRefPadBases + 7) / 8 + 63) & ~(int64_t) 63;
+			kpos_total += (h.L + 63) & ~(int64_t) 63;
+			sat_total += (int64_t) h.sat_start.size();
+		}
+	}
+	ctx->any_ref = n_ref > 0;
+	ctx->refn_words = refn_words;
+	ctx->kpos_total = kpos_total;
+	ctx->sat_total = sat_total;
 	for (int s = 0; s < n_slots; s++) {
 		HostSlot &h = ctx->slots[s];
 		h.rd_off = rd_off;
@@ -523,93 +586,86 @@ int prepare_layout(conga_ctx *ctx)
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	}
 
-	// ---- split-read inputs: reference sequences and satellite intervals, concatenated, and the 10-mer indexes.
-	// An index depends on the chromosome's sequence only: it is built here, once, for all chromosomes in three launches,
-	// and stays resident (4 bytes per base) -- a compute only maps reads against it.
-	ctx->any_sr = false;
-	ctx->n_sr_slots = 0;
-	{
-		int64_t ref_off = 0, sat_off = 0;
-		std::vector<SplitSlot> sslots;
+	// ---- split-read inputs: satellite intervals, packed references and the 10-mer indexes.  An index depends on the
+	// chromosome's sequence only: it is built here, once per layout (and again only for new text), and stays resident
+	// (4 bytes per base) -- a compute only maps reads against it.
+	if (ctx->any_ref) {
+		TRY(ensure(ctx, ctx->d_sat_start, std::max<size_t>((size_t) ctx->sat_total, 1) * 4));
+		TRY(ensure(ctx, ctx->d_sat_end, std::max<size_t>((size_t) ctx->sat_total, 1) * 4));
 		std::vector<uint64_t> sig;
+		int64_t max_L = 0;
 		for (int s = 0; s < n_slots; s++) {
-			HostSlot &h = ctx->slots[s];
-			h.ref_off = ref_off;
-			h.sat_off = sat_off;
-			if (h.n_sr > 0 && !h.ref.empty()) {
-				ctx->any_sr = true;
-				SplitSlot sl;
-				memset(&sl, 0, sizeof sl);
-				sl.sr_off = h.sr_off;
-				sl.n_sr = h.n_sr;
-				sl.ref_off = ref_off;
-				sl.L = h.L;
-				sl.kpos_off = ref_off; // (one index entry per base at most: the reference's own layout serves)
-				sl.kidx = (int32_t) sslots.size();
-				sl.sat_off = (int32_t) sat_off;
-				sl.n_sat = (int32_t) h.sat_start.size();
-				sl.iv0 = (int32_t) h.iv0;
-				sl.n_dels = (int32_t) h.iv_start[0].size();
-				sl.n_dups = (int32_t) h.iv_start[1].size();
-				sl.slot = s;
-				sslots.push_back(sl);
-				sig.push_back((uint64_t) s);
-				sig.push_back((uint64_t) h.ref.size());
-				sig.push_back(h.ref_version);
-				ref_off += ((int64_t) h.ref.size() + 255) & ~(int64_t) 255;
-				sat_off += (int64_t) h.sat_start.size();
-			}
-		}
-		ctx->n_sr_slots = (int) sslots.size();
-		if (ctx->any_sr) {
-			ctx->sr_first_slot = sslots.front().slot;
-			ctx->sr_last_slot = sslots.back().slot;
-			const size_t ns = sslots.size();
-			for (size_t k = 1; k < ns; k++) // the records of the chromosomes follow each other in the arrays (commit order)
-				if (sslots[k].sr_off != sslots[k - 1].sr_off + sslots[k - 1].n_sr)
-					return fail(ctx, CONGA_ERR_INVALID, "split-read records must be committed chromosome by chromosome");
-			TRY(ensure(ctx, ctx->d_sat_start, std::max<size_t>((size_t) sat_off, 1) * 4));
-			TRY(ensure(ctx, ctx->d_sat_end, std::max<size_t>((size_t) sat_off, 1) * 4));
-			for (const HostSlot &h : ctx->slots) {
-				if (h.n_sr == 0 || h.ref.empty() || h.sat_start.empty())
-					continue;
+			const HostSlot &h = ctx->slots[s];
+			if (h.kidx < 0)
+				continue;
+			max_L = std::max(max_L, h.L);
+			sig.push_back((uint64_t) s);
+			sig.push_back((uint64_t) h.ref.size());
+			sig.push_back(h.ref_version);
+			if (!h.sat_start.empty()) {
 				HIP_TRY(ctx, hipMemcpyAsync(ptr<int32_t>(ctx->d_sat_start) + h.sat_off, h.sat_start.data(), h.sat_start.size() * 4,
 						hipMemcpyHostToDevice, ctx->stream));
 				HIP_TRY(ctx, hipMemcpyAsync(ptr<int32_t>(ctx->d_sat_end) + h.sat_off, h.sat_end.data(), h.sat_end.size() * 4,
 						hipMemcpyHostToDevice, ctx->stream));
 			}
-			TRY(upload(ctx, ctx->d_sr_slots, sslots.data(), ns * sizeof(SplitSlot)));
-			if (sig != ctx->index_sig) {
-				TRY(ensure(ctx, ctx->d_ref, (size_t) ref_off + 256));
-				TRY(ensure(ctx, ctx->d_kmer_pos, (size_t) ref_off * 4 + 256));
-				TRY(ensure(ctx, ctx->d_kmer_count, ns * (size_t) kKmerBuckets * 4));
-				TRY(ensure(ctx, ctx->d_kmer_cursor, ns * (size_t) kKmerBuckets * 4));
-				TRY(ensure(ctx, ctx->d_kmer_offset, ns * ((size_t) kKmerBuckets + 1) * 4));
-				int64_t max_L = 0;
-				for (const HostSlot &h : ctx->slots) {
-					if (h.n_sr == 0 || h.ref.empty())
-						continue;
-					max_L = std::max(max_L, h.L);
-					HIP_TRY(ctx, hipMemcpyAsync(ptr<uint8_t>(ctx->d_ref) + h.ref_off, h.ref.data(), h.ref.size(), hipMemcpyHostToDevice,
-							ctx->stream));
-				}
-				HIP_TRY(ctx, hipMemsetAsync(ctx->d_kmer_count.p, 0, ns * (size_t) kKmerBuckets * 4, ctx->stream));
-				HIP_TRY(ctx, hipMemsetAsync(ctx->d_kmer_cursor.p, 0, ns * (size_t) kKmerBuckets * 4, ctx->stream));
-				const int gx = (int) std::min<int64_t>((max_L + 255) / 256, (int64_t) ctx->n_cu * 8);
-				const SplitSlot *dss = ptr<SplitSlot>(ctx->d_sr_slots);
-				hipLaunchKernelGGL(kmer_index_kernel<false>, dim3(gx, (unsigned) ns), dim3(256), 0, ctx->stream, ptr<uint8_t>(ctx->d_ref), dss,
-						ptr<uint32_t>(ctx->d_kmer_count), ptr<uint32_t>(ctx->d_kmer_offset), ptr<uint32_t>(ctx->d_kmer_cursor),
-						ptr<int32_t>(ctx->d_kmer_pos));
-				hipLaunchKernelGGL(kmer_offsets_kernel, dim3((unsigned) ns), dim3(1024), 0, ctx->stream, ptr<uint32_t>(ctx->d_kmer_count),
-						ptr<uint32_t>(ctx->d_kmer_offset));
-				hipLaunchKernelGGL(kmer_index_kernel<true>, dim3(gx, (unsigned) ns), dim3(256), 0, ctx->stream, ptr<uint8_t>(ctx->d_ref), dss,
-						ptr<uint32_t>(ctx->d_kmer_count), ptr<uint32_t>(ctx->d_kmer_offset), ptr<uint32_t>(ctx->d_kmer_cursor),
-						ptr<int32_t>(ctx->d_kmer_pos));
-				HIP_TRY(ctx, hipGetLastError());
-				ctx->index_sig = sig;
-			}
-			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // (`sslots` and the satellite vectors are read by the uploads)
 		}
+		if (sig != ctx->index_sig) {
+			const auto t_index = std::chrono::steady_clock::now();
+			const size_t n_idx = sig.size() / 3;
+			TRY(ensure(ctx, ctx->d_refn, (size_t) ctx->refn_words * 4 + 256));
+			TRY(ensure(ctx, ctx->d_kmer_pos, (size_t) ctx->kpos_total * 4 + 256));
+			TRY(ensure(ctx, ctx->d_kmer_offset, n_idx * ((size_t) kKmerBuckets + 2) * 4));
+			// scratch of the build, sized for the longest chromosome: its text, a sort key per position, the keys in sorted
+			// order, and what the sort asks for
+			DevBuf text;
+			size_t tmp_bytes = 0;
+			if (kmer_sort_positions(nullptr, &tmp_bytes, nullptr, nullptr, nullptr, (uint32_t) max_L, 21, ctx->stream) != 0)
+				return fail(ctx, CONGA_ERR_HIP, "10-mer index: sizing the sort failed");
+			int rc = ensure(ctx, text, (size_t) max_L + 64);
+			if (rc == CONGA_OK)
+				rc = ensure(ctx, ctx->d_kmer_keys, (size_t) max_L * 4 + 256);
+			if (rc == CONGA_OK)
+				rc = ensure(ctx, ctx->d_kmer_sorted, (size_t) max_L * 4 + 256);
+			if (rc == CONGA_OK)
+				rc = ensure(ctx, ctx->d_kmer_tmp, tmp_bytes + 256);
+			for (int s = 0; s < n_slots && rc == CONGA_OK; s++) {
+				const HostSlot &h = ctx->slots[s];
+				if (h.kidx < 0)
+					continue;
+				hipStream_t st = ctx->stream;
+				uint32_t *refn = ptr<uint32_t>(ctx->d_refn) + h.refn_off;
+				const int64_t n_words = (h.L + kRefPadBases + 7) / 8;
+				hipError_t e = hipMemcpyAsync(text.p, h.ref.data(), (size_t) h.L, hipMemcpyHostToDevice, st);
+				if (e == hipSuccess) {
+					const int gp = (int) std::min<int64_t>((n_words + 255) / 256, (int64_t) ctx->n_cu * 16);
+					hipLaunchKernelGGL(ref_pack_kernel, dim3(gp), dim3(256), 0, st, ptr<uint8_t>(text), h.L, refn, n_words);
+					const int gk = (int) std::min<int64_t>(((h.L + 7) / 8 + 255) / 256, (int64_t) ctx->n_cu * 16);
+					hipLaunchKernelGGL(kmer_key_kernel, dim3(gk), dim3(256), 0, st, refn, h.L, ptr<uint32_t>(ctx->d_kmer_keys));
+					size_t tb = tmp_bytes;
+					if (kmer_sort_positions(ctx->d_kmer_tmp.p, &tb, ptr<uint32_t>(ctx->d_kmer_keys), ptr<uint32_t>(ctx->d_kmer_sorted),
+							ptr<int32_t>(ctx->d_kmer_pos) + h.kpos_off, (uint32_t) h.L, 21, st) != 0)
+						rc = fail(ctx, CONGA_ERR_HIP, "10-mer index: the sort failed");
+					const int gb = (int) std::min<int64_t>((h.L + 256) / 256, (int64_t) ctx->n_cu * 16);
+					hipLaunchKernelGGL(kmer_bounds_kernel, dim3(gb), dim3(256), 0, st, ptr<uint32_t>(ctx->d_kmer_sorted), h.L,
+							ptr<uint32_t>(ctx->d_kmer_offset) + (size_t) h.kidx * ((size_t) kKmerBuckets + 2));
+					e = hipGetLastError();
+				}
+				if (e != hipSuccess && rc == CONGA_OK)
+					rc = fail(ctx, CONGA_ERR_HIP, std::string("10-mer index: ") + hipGetErrorString(e));
+			}
+			(void) hipStreamSynchronize(ctx->stream);
+			free_buf(text);
+			// (the sort's scratch is a few bytes per base of the longest chromosome: given back, the index is built once)
+			free_buf(ctx->d_kmer_keys);
+			free_buf(ctx->d_kmer_sorted);
+			free_buf(ctx->d_kmer_tmp);
+			TRY(rc);
+			ctx->index_sig = sig;
+			if (getenv("CONGA_TIMING"))
+				fprintf(stderr, "[timing] 10-mer indexes of %zu chromosomes (%.0f Mb) built in %.1f ms (once per reference)\n", n_idx,
+						ctx->kpos_total / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_index).count());
+		}
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // (the satellite vectors are read by the uploads)
 	}
 
 	// ---- intervals: slot order, dels then dups inside a slot
@@ -726,7 +782,7 @@ int prepare_layout(conga_ctx *ctx)
 			}
 			TRY(upload(ctx, ctx->d_support_base, support.data(), n * 4));
 		}
-		if (ctx->support_given || ctx->any_sr)
+		if (ctx->support_given || ctx->any_ref)
 			TRY(ensure(ctx, ctx->d_support, n * 4));
 		if (n > ctx->h_results_cap) {
 			if (ctx->h_results)
@@ -772,6 +828,7 @@ void reset_slots(conga_ctx *ctx)
 	ctx->n_sr_total = 0;
 	ctx->sr_bytes_total = 0;
 	ctx->sr_staged = false;
+	ctx->bz_keep_bytes = 0;
 	ctx->staging_cur = -1;
 	ctx->read_target = -1;
 	ctx->layout_dirty = true;
@@ -1343,6 +1400,9 @@ conga_ctx *conga_create(int device, const conga_opts *opts, int *status)
 				occ = std::min(occ, n);
 		}
 		ctx->tuple_blocks_per_cu = occ;
+		int ns = 0;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&ns, split_map_kernel, 256, 0) == hipSuccess && ns > 0)
+			ctx->split_blocks_per_cu = std::min(ns, 8);
 	}
 	lap(2);
 	// (lowest priority: these two streams also take the inflate launches of conga_reads_bgzf*, which must rank below its
@@ -1407,7 +1467,7 @@ void conga_destroy(conga_ctx *ctx)
 			&ctx->d_item_has_map, &ctx->d_item_first, &ctx->d_map_part, &ctx->d_support, &ctx->d_results,
 			&ctx->d_bases, &ctx->d_row_tile, &ctx->d_depth_blocks, &ctx->d_support_base, &ctx->d_ref, &ctx->d_sat_start, &ctx->d_sat_end,
 			&ctx->d_sr_pos, &ctx->d_sr_mapq, &ctx->d_sr_flag, &ctx->d_sr_lq, &ctx->d_sr_off, &ctx->d_sr_data,
-			&ctx->d_kmer_count, &ctx->d_kmer_offset, &ctx->d_kmer_cursor, &ctx->d_kmer_pos, &ctx->d_sr_slots};
+			&ctx->d_sr_recoff, &ctx->d_refn, &ctx->d_kmer_keys, &ctx->d_kmer_sorted, &ctx->d_kmer_tmp, &ctx->d_kmer_offset, &ctx->d_kmer_pos};
 	for (DevBuf *b : bufs)
 		free_buf(*b);
 	for (auto &s : ctx->staging) {
@@ -1629,16 +1689,22 @@ int drop_reads(conga_ctx *ctx, const char *who)
 		return fail(ctx, CONGA_ERR_INVALID, std::string(who) + ": no chromosome open");
 	if (ctx->staging_cur >= 0)
 		return fail(ctx, CONGA_ERR_INVALID, std::string(who) + ": a staging buffer is handed out and not committed");
-	if (ctx->n_sr_total > 0)
-		return fail(ctx, CONGA_ERR_INVALID, std::string(who) + ": not with split reads (their records belong to one sample)");
 	for (HostSlot &h : ctx->slots) {
 		h.read_off = 0;
 		h.n_reads = 0;
 		h.device_fed = false;
 		h.tail_val = 0;
 		h.tail_len = 0;
+		// the split-read records are the sample's too; reference sequences, satellites and the 10-mer indexes are the layout's
+		h.sr_off = 0;
+		h.n_sr = 0;
+		h.sr_inplace = false;
 	}
 	ctx->n_reads_total = 0;
+	ctx->n_sr_total = 0;
+	ctx->sr_bytes_total = 0;
+	ctx->sr_staged = false;
+	ctx->bz_keep_bytes = 0;
 	ctx->wrap_risk = false;
 	ctx->depth_resident = false;
 	ctx->sample_dirty = true;
@@ -1761,6 +1827,14 @@ int reads_bgzf_from(conga_ctx *ctx, const ByteSource &src, size_t n_bytes, const
 	for (int c = first_chrom; c < n_chrom; c++)
 		if (ctx->slots[(size_t) c].n_reads != 0)
 			return fail(ctx, CONGA_ERR_INVALID, "conga_reads_bgzf: a chromosome from the first named one on already has reads");
+	// Split reads (a chromosome named here has a reference sequence): the walk also notes where every kept record starts, and
+	// the split-read launch reads pos / qual / flag / l_qseq, the packed sequence and the qualities (split_read.c:206-354)
+	// where they lie in the inflated stream -- the records never exist on the host.  The stream then has to outlive this
+	// call, so it goes behind what earlier calls left for their chromosomes.
+	bool want_rec = false;
+	for (int c = first_chrom; c < n_chrom; c++)
+		want_rec = want_rec || !ctx->slots[(size_t) c].ref.empty();
+	const uint64_t base = ctx->bz_keep_bytes;
 	// the inflated stream: the blocks' payloads one behind the other
 	std::vector<uint64_t> out_off(n_blocks);
 	uint64_t total = 0;
@@ -1768,7 +1842,7 @@ int reads_bgzf_from(conga_ctx *ctx, const ByteSource &src, size_t n_bytes, const
 		const conga_bgzf_block &bl = blocks[b];
 		if (bl.data_off > n_bytes || (uint64_t) bl.data_len > n_bytes - bl.data_off || bl.inflated_len == 0 || bl.inflated_len > 65536u)
 			return fail(ctx, CONGA_ERR_INVALID, "conga_reads_bgzf: block outside the byte range, empty or larger than 64 KiB");
-		out_off[b] = total;
+		out_off[b] = base + total;
 		total += bl.inflated_len;
 	}
 	for (size_t k = 0; k < n_segments; k++) {
@@ -1794,7 +1868,7 @@ int reads_bgzf_from(conga_ctx *ctx, const ByteSource &src, size_t n_bytes, const
 	TRY(ensure(ctx, ctx->d_bz_in, n_bytes + 512)); // (the decoders read ahead of their position: up to 64 dwords)
 	TRY(ensure(ctx, ctx->d_bz_blocks, n_blocks * sizeof(conga_bgzf_block)));
 	TRY(ensure(ctx, ctx->d_bz_off, n_blocks * 8));
-	TRY(ensure(ctx, ctx->d_bz_out, (size_t) total + 16));
+	TRY(ensure(ctx, ctx->d_bz_out, (size_t) (base + total) + 64, base > 0));
 	TRY(ensure(ctx, ctx->d_bz_status, n_blocks));
 	TRY(ensure(ctx, ctx->d_bz_seg, n_segments * sizeof(conga_bam_segment)));
 	TRY(ensure(ctx, ctx->d_bz_cnt, n_segments * 4));
@@ -1839,8 +1913,10 @@ int reads_bgzf_from(conga_ctx *ctx, const ByteSource &src, size_t n_bytes, const
 		TRY(launch_inflate(ctx, n_blocks, lanes));
 	}
 	BamWalkArgs w;
-	w.stream = ptr<uint8_t>(ctx->d_bz_out);
+	w.stream = ptr<uint8_t>(ctx->d_bz_out) + base;
 	w.stream_len = total;
+	w.rec_off = nullptr;
+	w.rec_base = base;
 	w.segments = ptr<conga_bam_segment>(ctx->d_bz_seg);
 	w.n_segments = (uint32_t) n_segments;
 	w.count = ptr<uint32_t>(ctx->d_bz_cnt);
@@ -1895,6 +1971,10 @@ int reads_bgzf_from(conga_ctx *ctx, const ByteSource &src, size_t n_bytes, const
 			TRY(ensure(ctx, ctx->d_pos, want * 4, true));
 			TRY(ensure(ctx, ctx->d_mapq, want, true));
 		}
+		if (want_rec) {
+			TRY(ensure(ctx, ctx->d_sr_recoff, std::max(total_reads, (size_t) 1 << 22) * 8, true));
+			w.rec_off = ptr<uint64_t>(ctx->d_sr_recoff);
+		}
 		HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bz_at.p, write_at.data(), n_segments * 8, hipMemcpyHostToDevice, st));
 		w.pos = ptr<int32_t>(ctx->d_pos);
 		w.mapq = ptr<uint8_t>(ctx->d_mapq);
@@ -1926,9 +2006,16 @@ int reads_bgzf_from(conga_ctx *ctx, const ByteSource &src, size_t n_bytes, const
 			hc.read_off = at;
 			hc.n_reads = per_chrom[(size_t) c];
 			hc.device_fed = hc.device_fed || per_chrom[(size_t) c] > 0;
+			if (!hc.ref.empty()) { // its split-read records are its tuples' records, in place
+				hc.sr_inplace = true;
+				hc.sr_off = at;
+				hc.n_sr = hc.n_reads;
+			}
 			at += hc.n_reads;
 		}
 	}
+	if (want_rec)
+		ctx->bz_keep_bytes = (base + total + 255) & ~(uint64_t) 255;
 	ctx->n_reads_total += (int64_t) n_new;
 	ctx->sample_dirty = true;
 	ctx->computed = false;
@@ -1958,6 +2045,8 @@ int conga_inflate_blocks(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, c
 	}
 	if (out && out_bytes < total)
 		return fail(ctx, CONGA_ERR_INVALID, "conga_inflate_blocks: output buffer too small");
+	if (ctx->bz_keep_bytes)
+		return fail(ctx, CONGA_ERR_INVALID, "conga_inflate_blocks: the context holds BAM records in place");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	hipStream_t st = ctx->stream;
 	uint32_t lanes = (uint32_t) std::min<size_t>((n_blocks + 63) & ~(size_t) 63, 131072);
@@ -2128,19 +2217,20 @@ int conga_split_reads_commit(conga_ctx *ctx, size_t n_reads, size_t n_bytes)
 		return CONGA_OK;
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	conga_split_staging &st = ctx->sr_stage;
-	HostSlot &h = ctx->slots.back();
+	// records stream into the chromosome begun last (BAM order), or the one conga_sample_chrom() named
+	HostSlot &h = ctx->read_target >= 0 ? ctx->slots[(size_t) ctx->read_target] : ctx->slots.back();
+	if (h.sr_inplace)
+		return fail(ctx, CONGA_ERR_INVALID, "conga_split_reads_commit: this chromosome's records came from conga_reads_bgzf");
+	if (h.n_sr > 0 && h.sr_off + h.n_sr != ctx->n_sr_total)
+		return fail(ctx, CONGA_ERR_INVALID, "conga_split_reads_commit: a chromosome's records must be committed without another's in between");
 	for (size_t i = 0; i < n_reads; i++) {
 		const int32_t l = st.l_qseq[i];
 		const uint64_t need = (uint64_t) (l < 0 ? 0 : l + 1) / 2 + (uint64_t) (l < 0 ? 0 : l);
 		if (l < 0 || st.data_off[i] > n_bytes || need > n_bytes - st.data_off[i]) // (no sum that could wrap)
 			return fail(ctx, CONGA_ERR_RANGE, "conga_split_reads_commit: record block outside the committed bytes");
 		st.data_off[i] += (uint64_t) ctx->sr_bytes_total; // rebase into the device arena
-		// A negative position is no record of this chromosome (the reference's iterator never returns one), and the kernel would
-		// look up the reference in front of its first base: such a record goes in with the QC-fail bit, which the gate of
-		// find_split_reads' caller (bam_data.c:207, is_proper) drops.  (Here and not in the kernel: `p <= 0` for `p == 0` there
-		// made its launch 18 % longer -- the register allocation of that kernel hangs by a thread.)
-		if (st.pos[i] < 0)
-			st.flag[i] |= 0x200;
+		// (a negative position is no record of this chromosome -- the reference's iterator never returns one --: the kernel's
+		// gate drops every position <= 0; find_split_reads returns at pos == 0, split_read.c:216)
 	}
 	const size_t nr = (size_t) ctx->n_sr_total + n_reads, nb = (size_t) ctx->sr_bytes_total + n_bytes;
 	TRY(ensure(ctx, ctx->d_sr_pos, std::max(nr, (size_t) 1 << 20) * 4, true));
@@ -2148,7 +2238,7 @@ int conga_split_reads_commit(conga_ctx *ctx, size_t n_reads, size_t n_bytes)
 	TRY(ensure(ctx, ctx->d_sr_flag, std::max(nr, (size_t) 1 << 20) * 2, true));
 	TRY(ensure(ctx, ctx->d_sr_lq, std::max(nr, (size_t) 1 << 20) * 4, true));
 	TRY(ensure(ctx, ctx->d_sr_off, std::max(nr, (size_t) 1 << 20) * 8, true));
-	TRY(ensure(ctx, ctx->d_sr_data, std::max(nb, (size_t) 64 << 20), true));
+	TRY(ensure(ctx, ctx->d_sr_data, std::max(nb + 64, (size_t) 64 << 20), true)); // (the kernel reads a few bytes past a sequence)
 	hipStream_t s = ctx->stream;
 	const int64_t o = ctx->n_sr_total;
 	HIP_TRY(ctx, hipMemcpyAsync(ptr<int32_t>(ctx->d_sr_pos) + o, st.pos, n_reads * 4, hipMemcpyHostToDevice, s));
@@ -2163,7 +2253,7 @@ int conga_split_reads_commit(conga_ctx *ctx, size_t n_reads, size_t n_bytes)
 	h.n_sr += (int64_t) n_reads;
 	ctx->n_sr_total += (int64_t) n_reads;
 	ctx->sr_bytes_total += (int64_t) n_bytes;
-	ctx->layout_dirty = true;
+	ctx->sample_dirty = true; // (the records are the sample's: the layout -- references, indexes -- is untouched)
 	ctx->computed = false;
 	return CONGA_OK;
 }
@@ -2448,7 +2538,7 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 		}
 	}
 
-	if (ctx->n_iv > 0 && (ctx->support_given || ctx->any_sr)) {
+	if (ctx->n_iv > 0 && (ctx->support_given || ctx->any_ref)) {
 		if (ctx->support_given)
 			HIP_TRY(ctx, hipMemcpyAsync(ctx->d_support.p, ctx->d_support_base.p, (size_t) ctx->n_iv * 4, hipMemcpyDeviceToDevice, st));
 		else
@@ -2457,33 +2547,34 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 	// split-read evidence: half-read mapping against the resident 10-mer indexes -> pairing -> support, every chromosome's
 	// records in one launch (count_ReadPairs runs only for chromosomes with SVs, likelihood.c:332-348: the others have no
 	// interval to add to)
-	if (ctx->any_sr && ctx->n_sr_total > 0) {
-		SplitBatchArgs g;
+	if (ctx->any_sr && ctx->sr_units > 0) {
+		KernelTimer t(ctx, CONGA_K_SPLIT);
+		SplitMapArgs g;
 		memset(&g, 0, sizeof g);
-		g.base.pos = ptr<int32_t>(ctx->d_sr_pos);
-		g.base.mapq = ptr<uint8_t>(ctx->d_sr_mapq);
-		g.base.flag = ptr<uint16_t>(ctx->d_sr_flag);
-		g.base.l_qseq = ptr<int32_t>(ctx->d_sr_lq);
-		g.base.data_off = ptr<uint64_t>(ctx->d_sr_off);
-		g.base.data = ptr<uint8_t>(ctx->d_sr_data);
-		const HostSlot &last = ctx->slots[(size_t) ctx->sr_last_slot];
-		g.base.n_reads = last.sr_off + last.n_sr; // end of the last chromosome that takes part
-		g.base.ref = ptr<uint8_t>(ctx->d_ref);
-		g.base.sat_start = ptr<int32_t>(ctx->d_sat_start);
-		g.base.sat_end = ptr<int32_t>(ctx->d_sat_end);
-		g.base.offset = ptr<uint32_t>(ctx->d_kmer_offset);
-		g.base.positions = ptr<int32_t>(ctx->d_kmer_pos);
-		g.base.iv_start = ptr<int32_t>(ctx->d_iv_start);
-		g.base.iv_end = ptr<int32_t>(ctx->d_iv_end);
-		g.base.support = ptr<int32_t>(ctx->d_support);
-		g.base.mq_threshold = ctx->opts.mq_threshold;
-		g.base.min_read_length = ctx->opts.min_read_length;
+		g.pos = ptr<int32_t>(ctx->d_sr_pos);
+		g.mapq = ptr<uint8_t>(ctx->d_sr_mapq);
+		g.flag = ptr<uint16_t>(ctx->d_sr_flag);
+		g.l_qseq = ptr<int32_t>(ctx->d_sr_lq);
+		g.data_off = ptr<uint64_t>(ctx->d_sr_off);
+		g.data = ptr<uint8_t>(ctx->d_sr_data);
+		g.rec_off = ptr<uint64_t>(ctx->d_sr_recoff);
+		g.stream = ptr<uint8_t>(ctx->d_bz_out);
+		g.refn = ptr<uint32_t>(ctx->d_refn);
+		g.sat_start = ptr<int32_t>(ctx->d_sat_start);
+		g.sat_end = ptr<int32_t>(ctx->d_sat_end);
+		g.offset = ptr<uint32_t>(ctx->d_kmer_offset);
+		g.positions = ptr<int32_t>(ctx->d_kmer_pos);
+		g.iv_start = ptr<int32_t>(ctx->d_iv_start);
+		g.iv_end = ptr<int32_t>(ctx->d_iv_end);
+		g.support = ptr<int32_t>(ctx->d_support);
 		g.slots = ptr<SplitSlot>(ctx->d_sr_slots);
 		g.n_slots = ctx->n_sr_slots;
+		g.n_units = ctx->sr_units;
 		g.small = small;
-		const int64_t first = ctx->slots[(size_t) ctx->sr_first_slot].sr_off;
-		const int sgrid = (int) std::min<int64_t>((g.base.n_reads - first + 3) / 4, (int64_t) ctx->n_cu * 7);
-		hipLaunchKernelGGL(split_read_kernel, dim3(sgrid), dim3(256), 0, st, g, first);
+		g.mq_threshold = ctx->opts.mq_threshold;
+		g.min_read_length = ctx->opts.min_read_length;
+		const int sgrid = (int) std::min<int64_t>((int64_t) ctx->sr_units, (int64_t) ctx->n_cu * ctx->split_blocks_per_cu);
+		hipLaunchKernelGGL(split_map_kernel, dim3(sgrid), dim3(256), 0, st, g);
 	}
 
 	if (ctx->n_iv > 0) {
@@ -2523,7 +2614,7 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 		sa.map_part = ptr<double>(ctx->d_map_part);
 		sa.item_first = ptr<int32_t>(ctx->d_item_first);
 		sa.iv_has_map = ptr<uint8_t>(ctx->d_iv_has_map);
-		sa.support = (ctx->support_given || ctx->any_sr) ? ptr<int32_t>(ctx->d_support) : nullptr;
+		sa.support = (ctx->support_given || ctx->any_ref) ? ptr<int32_t>(ctx->d_support) : nullptr;
 		sa.out = ptr<conga_result>(ctx->d_results);
 		{
 			KernelTimer t(ctx, CONGA_K_CHAIN);

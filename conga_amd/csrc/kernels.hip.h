@@ -2094,490 +2094,6 @@ __global__ __launch_bounds__(256) void interval_score_kernel(ScoreArgs a)
 	a.out[iv] = score_interval(a, iv, a.expected[iv]);
 }
 
-// ===========================================================================================
-// Split-read evidence (--rp with --dups).
-// One launch set per chromosome; this path is a parity case (BASELINE configs[4]), not the bench line.
-// ===========================================================================================
-constexpr int kKmerLen = 10;              // HASHKMERLEN (split_read.h:17)
-constexpr int kKmerBuckets = 1 << 20;     // 4^10
-constexpr int kMaxSrHit = 50000;          // MAX_SR_HIT (split_read.h:12)
-constexpr int kMaxMapping = 100;          // MAX_MAPPING (split_read.h:13)
-constexpr int kSrLookahead = 100000;      // SR_LOOKAHEAD (split_read.c:6)
-constexpr int kSoftclipWindow = 50;       // SOFTCLIP_WRONGMAP_WINDOW (bam_data.h:14)
-constexpr int kWrongmapWindow = 100;      // WRONGMAP_WINDOW (likelihood.h:17)
-constexpr int kWrongmapWindowDel = 5000;  // WRONGMAP_WINDOW_DEL (likelihood.h:18)
-constexpr int kSrMaxHalf = 512;           // char str[512] in find_split_reads (split_read.c:211)
-
-__device__ __forceinline__ bool is_dna_letter(uint8_t c)
-{
-	return c == 'A' || c == 'C' || c == 'G' || c == 'T';
-}
-
-// split_read.c:37-49: two bits per base, (c & 6) >> 1 (A 0, C 1, T 2, G 3); -1 when a base is not ACGT
-template <typename F> __device__ __forceinline__ int kmer_hash(F base_at)
-{
-	uint32_t v = 0;
-#pragma unroll
-	for (int i = 0; i < kKmerLen; i++) {
-		const uint8_t c = base_at(i);
-		if (!is_dna_letter(c))
-			return -1;
-		v = (v << 2) | ((uint32_t) (c & 0x6) >> 1);
-	}
-	return (int) v;
-}
-
-// One chromosome's share of a batched split-read launch: where its records, its reference, its satellites, its 10-mer
-// index and its known SVs lie in the concatenated arrays.
-struct SplitSlot {
-	int64_t sr_off, n_sr; // records (in pos / mapq / flag / l_qseq / data_off)
-	int64_t ref_off, L;
-	int64_t kpos_off;     // in the positions of the 10-mer indexes
-	int32_t kidx;         // which offset table (4^10 + 1 entries each; counts and cursors: 4^10 each)
-	int32_t sat_off, n_sat;
-	int32_t iv0, n_dels, n_dups;
-	int32_t slot;         // chromosome of the batch (its Small block takes the counters)
-	int32_t pad;
-};
-
-// K6 count / fill passes of build_hash_table (split_read.c:357-442): every position whose 10-mer is ACGT-only.
-// One launch for all chromosomes (blockIdx.y); the index depends on the reference sequence only, so it is built once per
-// layout and stays in HBM (4 bytes per base) for every compute that follows.
-template <bool FILL> __global__ __launch_bounds__(256) void kmer_index_kernel(const uint8_t *__restrict__ ref_base,
-		const SplitSlot *__restrict__ slots, uint32_t *__restrict__ count_base, const uint32_t *__restrict__ offset_base,
-		uint32_t *__restrict__ cursor_base, int32_t *__restrict__ positions_base)
-{
-	const SplitSlot sl = slots[blockIdx.y];
-	const uint8_t *ref = ref_base + sl.ref_off;
-	const int64_t len = sl.L;
-	uint32_t *count = count_base + (int64_t) sl.kidx * kKmerBuckets;
-	const uint32_t *offset = offset_base + (int64_t) sl.kidx * (kKmerBuckets + 1);
-	uint32_t *cursor = cursor_base + (int64_t) sl.kidx * kKmerBuckets;
-	int32_t *positions = positions_base + sl.kpos_off;
-	const int64_t stride = (int64_t) gridDim.x * blockDim.x;
-	for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i + kKmerLen <= len; i += stride) {
-		const int h = kmer_hash([&](int k) { return ref[i + k]; });
-		if (h < 0)
-			continue;
-		if (!FILL)
-			atomicAdd(&count[h], 1u);
-		else if (offset[h + 1] > offset[h]) // kept bucket (init_hash_table, split_read.c:444-460)
-			positions[offset[h] + atomicAdd(&cursor[h], 1u)] = (int32_t) i;
-	}
-}
-
-// init_hash_table: buckets with count == 0 or >= MAX_SR_HIT are dropped; exclusive scan of the kept counts.
-// One workgroup of 1024 threads per chromosome (blockIdx.x), 1024 buckets per thread.
-__global__ __launch_bounds__(1024) void kmer_offsets_kernel(const uint32_t *__restrict__ count_base, uint32_t *__restrict__ offset_base)
-{
-	__shared__ uint32_t part[1024];
-	constexpr int kPer = kKmerBuckets / 1024;
-	const uint32_t *count = count_base + (int64_t) blockIdx.x * kKmerBuckets;
-	uint32_t *offset = offset_base + (int64_t) blockIdx.x * (kKmerBuckets + 1);
-	const int t = threadIdx.x;
-	uint32_t sum = 0;
-	for (int k = 0; k < kPer; k++) {
-		const uint32_t c = count[t * kPer + k];
-		sum += (c < (uint32_t) kMaxSrHit) ? c : 0u;
-	}
-	part[t] = sum;
-	__syncthreads();
-	for (int o = 1; o < 1024; o <<= 1) { // Hillis-Steele over the 1024 partial sums
-		const uint32_t v = (t >= o) ? part[t - o] : 0u;
-		__syncthreads();
-		part[t] += v;
-		__syncthreads();
-	}
-	uint32_t run = part[t] - sum;
-	for (int k = 0; k < kPer; k++) {
-		const uint32_t c = count[t * kPer + k];
-		offset[t * kPer + k] = run;
-		run += (c < (uint32_t) kMaxSrHit) ? c : 0u;
-	}
-	if (t == 1023)
-		offset[kKmerBuckets] = run;
-}
-
-struct SplitArgs {
-	// reads of this chromosome: the fields of bam1_t the path touches
-	const int32_t *pos;
-	const uint8_t *mapq;
-	const uint16_t *flag;
-	const int32_t *l_qseq;
-	const uint64_t *data_off; // per read: packed 4-bit sequence ((l + 1) / 2 bytes) followed by l quality bytes
-	const uint8_t *data;
-	int64_t n_reads;
-	// chromosome
-	const uint8_t *ref; // upper-case
-	int64_t L;
-	const int32_t *sat_start; // sorted, disjoint
-	const int32_t *sat_end;
-	int32_t n_sat;
-	// k-mer index
-	const uint32_t *offset;
-	const int32_t *positions;
-	// known SVs of this chromosome
-	const int32_t *iv_start;
-	const int32_t *iv_end;
-	int32_t iv0, n_dels, n_dups;
-	int32_t *support; // [n_iv] rp (dups) / border_rp (dels)
-	int32_t mq_threshold, min_read_length;
-	unsigned long long *counters;
-};
-
-// sonic_is_satellite(chr, a, b): any satellite interval overlapping [a, b).  The intervals are sorted and disjoint
-// (conga_satellites merges them), the question is the same in every lane of the wave: a 64-ary search -- every lane looks at
-// one pivot per round, one trip to memory per round instead of one per halving (a chromosome's few dozen to few thousand
-// satellites: one or two rounds instead of five to twelve dependent loads; the path asks up to five times per read).
-__device__ __forceinline__ int is_satellite_dev(const SplitArgs &a, int64_t lo_, int64_t hi_)
-{
-	const int lane = threadIdx.x & (kWave - 1);
-	int lo = 0, hi = a.n_sat; // the first interval with end > lo_ lies in [lo, hi] (hi: none)
-	while (hi - lo > kWave) {
-		const int stride = (hi - lo + kWave - 1) / kWave;
-		const int last = min(lo + (lane + 1) * stride, hi) - 1; // last interval of this lane's run [lo + lane * stride, ...)
-		const bool behind = lo + lane * stride < hi && (int64_t) a.sat_end[last] <= lo_; // the whole run ends at or before lo_
-		const int k = (int) __popcll(__ballot(behind)); // ends ascend: the runs that lie behind are the first k
-		const int nlo = min(lo + k * stride, hi);
-		hi = min(nlo + stride, hi);
-		lo = nlo;
-	}
-	const int i = lo + lane;
-	const bool in = i < hi;
-	const int32_t e = in ? a.sat_end[i] : 0, st = in ? a.sat_start[i] : 0;
-	const unsigned long long m = __ballot(in && (int64_t) e > lo_);
-	if (!m) // (none in this run: the next run's first interval, if any, starts even further right -- but it may still start below hi_)
-		return (hi < a.n_sat && (int64_t) a.sat_start[hi] < hi_) ? 1 : 0;
-	const int j = (int) __builtin_ctzll(m);
-	return (int64_t) __builtin_amdgcn_readlane(st, j) < hi_ ? 1 : 0;
-}
-
-// almostPerfect_match_seq_ref for one orientation (split_read.c:116-129 / 164-180): scan the seed's bucket, keep hits
-// within SR_LOOKAHEAD of the anchor whose Hamming distance to the reference is <= dist_max.  The bucket is read 64
-// positions at a time (one per lane); the few of them that lie inside the look-ahead window (about one per scan: the
-// read's own locus) are then compared by the whole wave, lane j on base j -- one coalesced load of the reference per 64
-// bases instead of one lane walking the bases with a dependent load each (which was 85 % of this path's time).
-// Hits are recorded in bucket order, as the reference's scan finds them.
-// [b0, b1): the seed's bucket; p_first: this lane's entry of its first 64 positions, fetched by the caller (all four scans
-// of a read -- two halves, forward and reverse complement -- ask for their bucket bounds, and then for their first
-// positions, together).  refw: the reference under the read, [win_lo, win_lo + win_len), fetched with the record's
-// sequence: the candidate that is the read's own locus -- nearly every candidate -- is compared without a trip to memory.
-__device__ __forceinline__ int split_scan_bucket(const SplitArgs &a, const uint8_t *str, int n, int anchor, int dist_max,
-		char orient, int size, int32_t *hit_pos, char *hit_orient, int lane, bool stop_past_max, uint32_t b0, uint32_t b1,
-		int p_first, const uint8_t *refw, int win_lo, int win_len)
-{
-	for (uint32_t base = b0; base < b1; base += kWave) {
-		const uint32_t k = base + lane;
-		int p = 0;
-		bool near = false;
-		if (k < b1) {
-			p = (base == b0) ? p_first : a.positions[k];
-			int d = p - anchor;
-			d = d < 0 ? -d : d;
-			near = d < kSrLookahead;
-		}
-		unsigned long long cand = __ballot(near);
-		while (cand) { // wave-uniform
-			const int src = __ffsll((long long) cand) - 1;
-			cand &= cand - 1ull;
-			const int pc = __builtin_amdgcn_readlane(p, src);
-			int dist = 0;
-			if (pc >= win_lo && pc + n <= win_lo + win_len) { // (wave-uniform) under the read: from LDS
-				const uint8_t *w = refw + (pc - win_lo);
-				for (int j0 = 0; j0 < n; j0 += kWave) {
-					const int j = j0 + lane;
-					dist += __popcll(__ballot(j < n && w[j] != str[j])); // (bases behind the chromosome's end are 0 here: a mismatch)
-				}
-			} else {
-				for (int j0 = 0; j0 < n; j0 += kWave) {
-					const int j = j0 + lane;
-					const int64_t at = (int64_t) pc + j;
-					const bool mism = j < n && (at >= a.L || a.ref[at] != str[j]); // hammingDistance (common.c:278-287)
-					dist += __popcll(__ballot(mism));
-				}
-			}
-			if (dist <= dist_max) {
-				if (size < kMaxMapping && lane == 0) {
-					hit_pos[size] = pc;
-					hit_orient[size] = orient;
-				}
-				size++;
-			}
-		}
-		if (stop_past_max && size > kMaxMapping)
-			break;
-	}
-	return size;
-}
-
-struct SplitBatchArgs {
-	SplitArgs base;          // the concatenated arrays; the per-chromosome members are filled in per SplitSlot
-	const SplitSlot *slots;  // chromosomes with split-read records, in record order
-	int32_t n_slots;
-	Small *small;
-};
-
-__device__ __forceinline__ SplitArgs split_view(const SplitBatchArgs &g, const SplitSlot &sl)
-{
-	SplitArgs a = g.base;
-	a.pos += sl.sr_off;
-	a.mapq += sl.sr_off;
-	a.flag += sl.sr_off;
-	a.l_qseq += sl.sr_off;
-	a.data_off += sl.sr_off;
-	a.n_reads = sl.n_sr;
-	a.ref += sl.ref_off;
-	a.L = sl.L;
-	a.sat_start += sl.sat_off;
-	a.sat_end += sl.sat_off;
-	a.n_sat = sl.n_sat;
-	a.offset += (int64_t) sl.kidx * (kKmerBuckets + 1);
-	a.positions += sl.kpos_off;
-	a.iv0 = sl.iv0;
-	a.n_dels = sl.n_dels;
-	a.n_dups = sl.n_dups;
-	a.counters = g.small[sl.slot].counters;
-	return a;
-}
-
-// find_split_reads + read_SplitReads + determine_SvType + count_ReadPairs for one read, by one wave.  A read is a chain
-// of dependent trips to HBM, and the launch is as long as that chain times the reads a wave gets, so the function is laid
-// out by trips: (1) the record's fields and where its data lies; (2) qualities, sequence and the reference under the read
-// in one go, the satellite question about the read's start travelling with them; (3) the bucket bounds of all four seeds
-// (two halves, forward and reverse complement); (4) the first 64 positions of the four buckets.  The candidate that is
-// the read's own locus is compared with the reference fetched in (2).  (Round 2's first version: record -> data offset ->
-// qualities -> satellite search -> per half: sequence -> bucket bounds -> positions -> reference, and two more satellite
-// searches per mapping: ~22 trips.)  The register budget of the kernel below is set for 8 waves per SIMD.
-__device__ __forceinline__ void split_read_one(const SplitArgs &a, int64_t r, uint8_t *bases, uint8_t *rev, uint8_t *ql, uint8_t *refw,
-		int32_t *hit_pos, char *hit_orient, int lane, unsigned long long &n_elem, unsigned long long &n_map, unsigned long long &n_del,
-		unsigned long long &n_dup)
-{
-	{
-		const int l = a.l_qseq[r], p = a.pos[r], q = a.mapq[r], fl = a.flag[r];
-		const uint64_t d_off = a.data_off[r];
-		// gate of count_reads_bam (bam_data.c:205-207) and find_split_reads' pos == 0 (split_read.c:216)
-		if (!(q > a.mq_threshold) || !(l > a.min_read_length) || (fl & (0x100 | 0x800 | 0x400 | 0x200)) != 0)
-			return;
-		if (p == 0 || l > 2 * kSrMaxHalf - 2)
-			return;
-		const uint8_t *sq = a.data + d_off;
-		const uint8_t *qq = sq + (l + 1) / 2;
-		const int half = l / 2;
-		// trip 2: the first 128 bases' worth of everything is asked for before anything is waited for
-		auto letter = [](int code) -> uint8_t { return code == 1 ? 'A' : code == 2 ? 'C' : code == 4 ? 'G' : code == 8 ? 'T' : 'N'; }; // bam_seqi
-		const int i0 = lane, i1 = lane + kWave;
-		uint8_t q0 = 0, q1 = 0, s0 = 0, s1 = 0, r0b = 0, r1b = 0;
-		if (i0 < l) {
-			q0 = qq[i0];
-			s0 = sq[i0 >> 1];
-			r0b = ((int64_t) p + i0 < a.L) ? a.ref[(int64_t) p + i0] : (uint8_t) 0;
-		}
-		if (i1 < l) {
-			q1 = qq[i1];
-			s1 = sq[i1 >> 1];
-			r1b = ((int64_t) p + i1 < a.L) ? a.ref[(int64_t) p + i1] : (uint8_t) 0;
-		}
-		const int sat = is_satellite_dev(a, p, (int64_t) p + 20);
-		if (sat)
-			return;
-		__builtin_amdgcn_wave_barrier();
-		if (i0 < l) {
-			ql[i0] = q0;
-			bases[i0] = letter((i0 & 1) ? (s0 & 0xF) : (s0 >> 4));
-			refw[i0] = r0b;
-		}
-		if (i1 < l) {
-			ql[i1] = q1;
-			bases[i1] = letter((i1 & 1) ? (s1 & 0xF) : (s1 >> 4));
-			refw[i1] = r1b;
-		}
-		for (int i = lane + 2 * kWave; i < l; i += kWave) { // (reads above 128 bases)
-			const uint8_t sb = sq[i >> 1];
-			ql[i] = qq[i];
-			bases[i] = letter((i & 1) ? (sb & 0xF) : (sb >> 4));
-			refw[i] = ((int64_t) p + i < a.L) ? a.ref[(int64_t) p + i] : (uint8_t) 0;
-		}
-		__builtin_amdgcn_wave_barrier();
-		// trips 3 and 4: the seeds of both halves in both orientations.  Element 1 maps bases [l/2, l), element 2 bases [0, l/2);
-		// the reverse complement's seed is the complement of the half's last ten bases, read backwards.
-		auto comp = [](uint8_t c) -> uint8_t { return c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'G' ? 'C' : c == 'C' ? 'G' : 'N'; };
-		uint32_t bk0[2][2] = {{0, 0}, {0, 0}}, bk1[2][2] = {{0, 0}, {0, 0}}; // [element][forward, reverse]: the seed's bucket (a seed with a letter outside ACGT has none)
-#pragma unroll
-		for (int e = 0; e < 2; e++) {
-			const int from = (e == 0) ? half : 0, n = (e == 0) ? l - half : half;
-			if (n < kKmerLen)
-				continue;
-			// both seeds' hashes (split_read.c:37-49: two bits per base, (c & 6) >> 1, first base in the highest bits) by forty
-			// lanes: lane j < 20 holds bit 19 - j of the forward seed's hash, lane 20 + j that of the reverse complement's
-			// (complementing a base flips bit 1 of its code: A 0 <-> T 2, C 1 <-> G 3); two ballots instead of twenty serial steps
-			const int j = lane < 20 ? lane : lane - 20, k = j >> 1;
-			const uint8_t c = lane < 40 ? bases[lane < 20 ? from + k : from + n - 1 - k] : (uint8_t) 'A';
-			const uint32_t code = (((uint32_t) c & 6u) >> 1) ^ (lane < 20 ? 0u : 2u);
-			const unsigned long long bit_m = __ballot(lane < 40 && ((code >> (1 - (j & 1))) & 1u) != 0u);
-			const unsigned long long bad_m = __ballot(lane < 40 && !is_dna_letter(c));
-			const int h_fwd = (bad_m & 0xFFFFFull) ? -1 : (int) (__brev((uint32_t) bit_m & 0xFFFFFu) >> 12);
-			const int h_rev = ((bad_m >> 20) & 0xFFFFFull) ? -1 : (int) (__brev((uint32_t) (bit_m >> 20) & 0xFFFFFu) >> 12);
-			if (h_fwd >= 0) {
-				bk0[e][0] = a.offset[h_fwd];
-				bk1[e][0] = a.offset[h_fwd + 1];
-			}
-			if (h_rev >= 0) {
-				bk0[e][1] = a.offset[h_rev];
-				bk1[e][1] = a.offset[h_rev + 1];
-			}
-		}
-		int p_first[2][2];
-#pragma unroll
-		for (int e = 0; e < 2; e++)
-#pragma unroll
-			for (int o = 0; o < 2; o++)
-				p_first[e][o] = (bk0[e][o] + (uint32_t) lane < bk1[e][o]) ? a.positions[bk0[e][o] + lane] : 0;
-
-		float avg = 0.0f;
-#pragma unroll 1
-		for (int e = 0; e < 2; e++) { // (one copy of the code: the two elements' copies side by side cost 50 more registers)
-			// element 1: anchor pos, maps bases [l/2, l); element 2: anchor pos + l/2, maps [0, l/2)
-			const int from = (e == 0) ? half : 0, n = (e == 0) ? l - half : half;
-			const int anchor = (e == 0) ? p : p + half;
-			// mean base quality of the mapped half; the accumulator is NOT reset between the two
-			// elements (split_read.c:238-243,307-312), sequential float adds as in the reference
-			// The adds are sequential in the reference.  Element 1 starts from 0: every partial sum is an integer below 2^24,
-			// so the float sum is exact in any order and a wave reduction gives it.  Element 2 starts from element 1's mean (a
-			// fraction): its adds stay in order, 64 qualities per LDS read (one per lane, converted there) handed to every
-			// lane in turn by v_readlane -- two instructions per add instead of a byte read from LDS in front of each.
-			if (e == 0) {
-				int isum = 0;
-				for (int i = from + lane; i < from + n; i += kWave)
-					isum += (int) ql[i];
-				avg = (float) __builtin_amdgcn_readfirstlane(wave_sum_i32(isum)); // (the total is in lane 0)
-			} else {
-				for (int c0 = from; c0 < from + n; c0 += kWave) {
-					const float mine = (c0 + lane < from + n) ? (float) ql[c0 + lane] : 0.0f;
-					const int cnt = min(kWave, from + n - c0);
-					// (eight adds per turn of the loop; the lanes behind the half hold +0.0, and x + 0.0 is x for the x >= 0 met here)
-					for (int j = 0; j < cnt; j += 8) {
-#pragma unroll
-						for (int u = 0; u < 8; u++)
-							avg = avg + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), j + u));
-					}
-				}
-			}
-			avg = avg / (float) n;
-			if ((int) floorf(avg) < a.mq_threshold)
-				break; // element 1 dropped -> element 2 never created; element 2 dropped -> done
-			n_elem++;
-			if (n < kKmerLen)
-				continue;
-			const uint8_t *str = bases + from;
-			__builtin_amdgcn_wave_barrier();
-			for (int i = lane; i < n; i += kWave)
-				rev[n - i - 1] = comp(str[i]);
-			__builtin_amdgcn_wave_barrier();
-			const int dist_max = (int) (0.05 * (double) n);
-			int size = 0;
-#pragma unroll 1
-			for (int o = 0; o < 2 && size < kMaxMapping; o++) { // forward, then the reverse complement
-				const uint32_t b0 = e ? (o ? bk0[1][1] : bk0[1][0]) : (o ? bk0[0][1] : bk0[0][0]);
-				const uint32_t b1 = e ? (o ? bk1[1][1] : bk1[1][0]) : (o ? bk1[0][1] : bk1[0][0]);
-				const int pf = e ? (o ? p_first[1][1] : p_first[1][0]) : (o ? p_first[0][1] : p_first[0][0]);
-				size = split_scan_bucket(a, o ? rev : str, n, anchor, dist_max, o ? 'R' : 'F', size, hit_pos, hit_orient, lane, o != 0, b0, b1, pf,
-						refw, p, l);
-			}
-			__builtin_amdgcn_wave_barrier();
-			if (!(size > 0 && size < kMaxMapping))
-				continue;
-			n_map += (unsigned long long) size;
-			const int mapq_sr = 60 / size;
-			// read_SplitReads / determine_SvType (bam_data.c:29-154) for every mapping, then count_ReadPairs
-			// (likelihood.c:41-94) against this chromosome's SVs
-			for (int m = 0; m < size; m++) {
-				const int posMap = hit_pos[m];
-				const char orient = hit_orient[m];
-				// read_SplitReads drops a row for any of these reasons and nothing else happens to it (bam_data.c:96-125): the
-				// tests that cost nothing come first, the two satellite questions (a search in memory each) last -- nearly every
-				// mapping is the read's own locus (posMap == anchor) and never gets that far
-				if (!(mapq_sr > a.mq_threshold && anchor > 0 && posMap > 0 && anchor < a.L && posMap < a.L))
-					continue;
-				const int lengthSplit = l / 2, lengthRead = l - lengthSplit;
-				int pos1_2, pos2_1;
-				if (anchor < posMap) {
-					pos1_2 = anchor + lengthRead;
-					pos2_1 = posMap;
-				} else if (posMap < anchor) {
-					pos1_2 = posMap + lengthSplit;
-					pos2_1 = anchor;
-				} else
-					continue;
-				if (pos1_2 >= pos2_1 || orient != 'F')
-					continue;
-				if (is_satellite_dev(a, anchor, (int64_t) anchor + 1) + is_satellite_dev(a, posMap, (int64_t) posMap + 1) != 0)
-					continue;
-				const bool is_del = (anchor < posMap && e == 0) || (anchor > posMap && e == 1);
-				const int left_end = pos1_2 - kSoftclipWindow, right_start = pos2_1 + kSoftclipWindow;
-				if (is_del) {
-					n_del++;
-					for (int i = lane; i < a.n_dels; i += kWave) {
-						const int s0 = a.iv_start[a.iv0 + i], e0 = a.iv_end[a.iv0 + i];
-						if (left_end <= s0 + kWrongmapWindow && left_end >= s0 - kWrongmapWindowDel
-								&& right_start >= e0 - kWrongmapWindow && right_start <= e0 + kWrongmapWindowDel)
-							atomicAdd(&a.support[a.iv0 + i], 1);
-					}
-				} else {
-					n_dup++;
-					for (int i = lane; i < a.n_dups; i += kWave) {
-						const int iv = a.iv0 + a.n_dels + i;
-						const int lo = a.iv_start[iv] - kWrongmapWindowDel, hi = a.iv_end[iv] + kWrongmapWindowDel;
-						if (left_end >= lo && left_end <= hi && right_start <= hi && right_start >= lo)
-							atomicAdd(&a.support[iv], 1);
-					}
-				}
-			}
-		}
-	}
-}
-
-// All chromosomes' records in ONE launch, one wave per read; the records of a chromosome are consecutive, so a wave
-// moves from SplitSlot to SplitSlot as its read index grows and flushes its counters into the chromosome it leaves.
-// Measured at 8, 7, 6 and 5 waves per SIMD (64 / 72 / 80 / 96 registers, 46 / 34 / 31 / 14 of them spilled): 14.5 / 13.6 / 14.4 /
-// 15.0 ms for the 6.56 M records of the bench leg -- the launch is bound by instructions (770 vector + 650 scalar per read)
-// more than by the waves in flight; seven it is.
-__global__ __launch_bounds__(256, 7) void split_read_kernel(SplitBatchArgs g, int64_t first_read)
-{
-	__shared__ uint8_t s_bases[4][2 * kSrMaxHalf], s_rev[4][kSrMaxHalf], s_qual[4][2 * kSrMaxHalf], s_refw[4][2 * kSrMaxHalf];
-	__shared__ int32_t s_hit_pos[4][kMaxMapping];
-	__shared__ char s_hit_orient[4][kMaxMapping];
-	// (the wave's number is the same in all its lanes; said so, everything that belongs to the read -- its index, length,
-	// position, the halves' bounds, the buckets' bounds -- lives in scalar registers instead of one vector register each)
-	const int wv = __builtin_amdgcn_readfirstlane((int) (threadIdx.x / kWave)), lane = threadIdx.x & (kWave - 1);
-	const int64_t n_waves = (int64_t) gridDim.x * 4;
-	unsigned long long n_elem = 0, n_map = 0, n_del = 0, n_dup = 0;
-	int cur = 0;
-	SplitSlot sl = g.slots[0];
-	SplitArgs a = split_view(g, sl);
-	auto flush = [&]() {
-		if (lane == 0) {
-			if (n_elem)
-				atomicAdd(&a.counters[CNT_SR_ELEMENTS], n_elem);
-			if (n_map)
-				atomicAdd(&a.counters[CNT_SR_MAPPINGS], n_map);
-			if (n_del)
-				atomicAdd(&a.counters[CNT_SR_DEL_ROWS], n_del);
-			if (n_dup)
-				atomicAdd(&a.counters[CNT_SR_DUP_ROWS], n_dup);
-		}
-		n_elem = n_map = n_del = n_dup = 0;
-	};
-	for (int64_t r = first_read + (int64_t) blockIdx.x * 4 + wv; r < g.base.n_reads; r += n_waves) {
-		if (r >= sl.sr_off + sl.n_sr) { // (wave-uniform)
-			flush();
-			do
-				sl = g.slots[++cur];
-			while (r >= sl.sr_off + sl.n_sr); // never runs off the table: r < n_reads = the last slot's end
-			a = split_view(g, sl);
-		}
-		split_read_one(a, r - sl.sr_off, s_bases[wv], s_rev[wv], s_qual[wv], s_refw[wv], s_hit_pos[wv], s_hit_orient[wv], lane, n_elem, n_map, n_del, n_dup);
-	}
-	flush();
-}
+// (the split-read evidence path -- SURVEY.md section 8 rows a15-a18 -- is split_map.hip.h)
 
 } // namespace conga

@@ -76,13 +76,17 @@ struct BamWalkArgs {
 	const uint64_t *write_at; // pass 2: first tuple of each segment
 	int32_t *pos;
 	uint8_t *mapq;
+	uint64_t *rec_off;      // pass 2, or nullptr: where each kept record starts (rec_base + its offset in `stream`), for the
+	uint64_t rec_base;      // split-read path, which reads the records where they lie (split_map.hip.h)
 };
 
 // a little-endian int32 at ANY address: global memory takes unaligned dword accesses (one load instead of four byte loads
 // put together -- a record's fields are what the walk below reads, one lane per segment, every load a cache line of its own)
 __device__ __forceinline__ int32_t load_i32(const uint8_t *p)
 {
-	return (int32_t) *reinterpret_cast<const uint32_t *>(p);
+	uint32_t v;
+	__builtin_memcpy(&v, p, 4); // (one global_load_dword: the alignment is the compiler's to know)
+	return (int32_t) v;
 }
 
 template <bool WRITE> __global__ __launch_bounds__(64) void bam_walk_kernel(BamWalkArgs a)
@@ -144,6 +148,8 @@ template <bool WRITE> __global__ __launch_bounds__(64) void bam_walk_kernel(BamW
 		if (WRITE) {
 			a.pos[w] = p;
 			a.mapq[w] = (uint8_t) ((uint32_t) load_i32(r + 12) >> 8); // l_read_name, MAPQ, bin: the byte at 13
+			if (a.rec_off)
+				a.rec_off[w] = a.rec_base + here;
 			w++;
 		}
 		n++;

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define CONGA_ABI_VERSION 4
+#define CONGA_ABI_VERSION 5
 
 typedef struct conga_ctx conga_ctx;
 
@@ -134,6 +134,7 @@ enum {
 	CONGA_K_SCORE,        /* serial-float expected chain (short intervals) + likelihoods + CN (K4 chain + K5) */
 	CONGA_K_CHAIN,        /* serial-float expected chain of long intervals, one wave per interval */
 	CONGA_K_COUNT_READS,  /* tuple-space formulation: per-interval count of kept reads (replaces the depth side of K_REDUCE) */
+	CONGA_K_SPLIT,        /* split-read evidence: half-read mapping, pairing, support counts (split_map_kernel) */
 	CONGA_K_COUNT
 };
 
@@ -146,7 +147,7 @@ typedef struct conga_chrom_stats {
 	int32_t n_kernels;          /* CONGA_K_COUNT */
 	int64_t rd_per_gc[101];     /* rd_per_gc_unfiltered (read_distribution.c:52) */
 	int64_t window_per_gc[101]; /* window_per_gc (read_distribution.c:51) */
-	double kernel_ms[8];        /* per-kernel device time of the last compute (CONGA_FLAG_PROFILE), else 0 */
+	double kernel_ms[12];       /* per-kernel device time of the last compute (CONGA_FLAG_PROFILE), else 0 */
 	/* split-read evidence (only when split reads and a reference sequence were given) */
 	int64_t split_elements;     /* split_read_count (split_read.c:14): half-read elements created */
 	int64_t split_mappings;     /* mappings emitted by almostPerfect_match_seq_ref (split_read.c:185-201) */
