@@ -1087,7 +1087,8 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const ByteSource &src, size_t 
 	TRY(ensure_x2n(ctx));
 	// the third launch stream, if the thread the first call left behind has made it (before anything below counts streams)
 	if (ctx->bz_shared && ctx->n_bz_streams == 2 && ctx->bz_third_ready.load(std::memory_order_acquire) && bz_streams_wanted() > 2) {
-		ctx->bz_third_maker.join();
+		if (ctx->bz_third_maker.joinable())
+			ctx->bz_third_maker.join();
 		ctx->bz_kernel[2] = ctx->bz_third;
 		ctx->ev_bz_kernel[2] = ctx->ev_bz_third;
 		ctx->n_bz_streams = 3;
@@ -1116,7 +1117,7 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const ByteSource &src, size_t 
 	std::condition_variable cv;
 	std::vector<uint8_t> filled(n_pieces, 0);
 	size_t issued = 0;       // pieces whose copy up has been enqueued (their slot's event is recorded)
-	bool failed = false;
+	bool failed = false, short_read = false; // (short_read: the file ends inside the piece -- the input's fault, not HIP's)
 	std::atomic<size_t> next_piece{0};
 	std::atomic<long long> us_copy{0}, us_wait{0}; // (CONGA_TIMING: what the host threads spent copying and waiting for a free slot)
 	const int device = ctx->device;
@@ -1150,7 +1151,7 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const ByteSource &src, size_t 
 				std::lock_guard<std::mutex> g(mu);
 				filled[c] = 1;
 				if (!got)
-					failed = true; // (a file that ends early)
+					failed = short_read = true; // (a file that ends early)
 			}
 			cv.notify_all();
 			if (!got)
@@ -1172,7 +1173,8 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const ByteSource &src, size_t 
 			std::unique_lock<std::mutex> lk(mu);
 			cv.wait(lk, [&] { return failed || filled[c]; });
 			if (failed)
-				rc = fail(ctx, CONGA_ERR_HIP, "conga_reads_bgzf: waiting for a pinned piece failed");
+				rc = short_read ? fail(ctx, CONGA_ERR_DATA, "conga_reads_bgzf: the file ends inside the piece that was named")
+						: fail(ctx, CONGA_ERR_HIP, "conga_reads_bgzf: waiting for a pinned piece failed");
 		}
 		if (rc != CONGA_OK)
 			break;
@@ -1231,7 +1233,8 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const ByteSource &src, size_t 
 	}
 	(void) hipEventRecord(ctx->ev_fork2, ctx->bz_copy);
 	(void) hipStreamWaitEvent(ctx->stream, ctx->ev_fork2, 0);
-	if (ctx->bz_shared && ctx->n_bz_streams == 2 && !ctx->bz_third_maker.joinable() && bz_streams_wanted() > 2) {
+	if (ctx->bz_shared && ctx->n_bz_streams == 2 && !ctx->bz_third_maker.joinable() && !ctx->bz_third_ready.load(std::memory_order_acquire)
+			&& bz_streams_wanted() > 2) {
 		const int device = ctx->device;
 		ctx->bz_third_maker = std::thread([ctx, device] {
 			int lo = 0, hi = 0;
@@ -1260,6 +1263,10 @@ int conga_release_staging(conga_ctx *ctx)
 {
 	if (!ctx)
 		return CONGA_ERR_INVALID;
+	// (the thread the first conga_reads_bgzf* left behind to make a third launch stream: a caller that is done reading must not
+	// leave the process while it is inside the runtime)
+	if (ctx->bz_third_maker.joinable())
+		ctx->bz_third_maker.join();
 	if (!ctx->h_bz_ring)
 		return CONGA_OK;
 	if (hipSetDevice(ctx->device) != hipSuccess)
@@ -1899,7 +1906,7 @@ int reads_bgzf_from(conga_ctx *ctx, const ByteSource &src, size_t n_bytes, const
 		if (!bytes) {
 			whole.resize(n_bytes);
 			if (!src.fetch(0, whole.data(), n_bytes))
-				return fail(ctx, CONGA_ERR_INVALID, "conga_reads_bgzf_fd: the file ends inside the piece");
+				return fail(ctx, CONGA_ERR_DATA, "conga_reads_bgzf: the file ends inside the piece that was named");
 			bytes = whole.data();
 		}
 		HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bz_in.p, bytes, n_bytes, hipMemcpyHostToDevice, st));
@@ -1917,6 +1924,7 @@ int reads_bgzf_from(conga_ctx *ctx, const ByteSource &src, size_t n_bytes, const
 	w.stream_len = total;
 	w.rec_off = nullptr;
 	w.rec_base = base;
+	w.check_body = want_rec ? 1u : 0u;
 	w.segments = ptr<conga_bam_segment>(ctx->d_bz_seg);
 	w.n_segments = (uint32_t) n_segments;
 	w.count = ptr<uint32_t>(ctx->d_bz_cnt);
@@ -1951,7 +1959,8 @@ int reads_bgzf_from(conga_ctx *ctx, const ByteSource &src, size_t n_bytes, const
 	uint64_t n_new = 0;
 	for (size_t k = 0; k < n_segments; k++) {
 		if (bad[k])
-			return fail(ctx, CONGA_ERR_DATA, "conga_reads_bgzf: a start point does not lead along whole BAM records");
+			return fail(ctx, CONGA_ERR_DATA, bad[k] == 2 ? "conga_reads_bgzf: the records of a target are not in position order"
+					: "conga_reads_bgzf: a start point does not lead along whole BAM records");
 		// the record that ends a segment is the next segment's first -- inside a chromosome, and from a target to the target
 		// that follows it in the file (whatever ends target t is the first record behind it: the first of target t + 1 if that
 		// one has records, and what ends that one's empty walk if it has none)

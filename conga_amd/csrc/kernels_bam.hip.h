@@ -72,12 +72,15 @@ struct BamWalkArgs {
 	uint32_t *count;        // records it owns (pass 1)
 	uint64_t *v_first;      // where it found its first own record (or where it stopped, if it owns none)
 	uint64_t *v_stop;       // the record that ended it (first record of the next segment / of another target); ~0: end of stream
-	uint8_t *bad;           // a record that cannot be one (block_size < 32 or running past the stream)
+	uint8_t *bad;           // 1: a record that cannot be one (block_size < 32, running past the stream, fields that do not fit it);
+	                        // 2: a record in front of its predecessor (the file is not sorted by position)
 	const uint64_t *write_at; // pass 2: first tuple of each segment
 	int32_t *pos;
 	uint8_t *mapq;
 	uint64_t *rec_off;      // pass 2, or nullptr: where each kept record starts (rec_base + its offset in `stream`), for the
 	uint64_t rec_base;      // split-read path, which reads the records where they lie (split_map.hip.h)
+	uint32_t check_body;    // pass 1: a kept record's name, CIGAR, sequence and qualities must fit its block_size (the host
+	                        // reader calls anything else a corrupt BAM record; the split-read path is about to read them)
 };
 
 // a little-endian int32 at ANY address: global memory takes unaligned dword accesses (one load instead of four byte loads
@@ -99,14 +102,14 @@ template <bool WRITE> __global__ __launch_bounds__(64) void bam_walk_kernel(BamW
 	uint64_t at = sg.start, first = kNone, stop = kNone;
 	uint32_t n = 0;
 	uint64_t w = WRITE ? a.write_at[k] : 0;
-	bool bad = false;
+	uint8_t bad = 0;
 	for (;;) {
 		if (at + 12 > a.stream_len)
 			break; // end of the stream (stop stays kNone)
 		const uint8_t *r = a.stream + at;
 		const int32_t block_size = load_i32(r);
 		if (block_size < 32) {
-			bad = true;
+			bad = 1;
 			break;
 		}
 		const int32_t ref = load_i32(r + 4), p = load_i32(r + 8);
@@ -119,7 +122,7 @@ template <bool WRITE> __global__ __launch_bounds__(64) void bam_walk_kernel(BamW
 			const bool plausible = block_size <= (1 << 26)
 					&& (ref == sg.ref_id || (ref > sg.ref_id && ref < (1 << 24) && p >= -1) || (ref == -1 && p >= -1));
 			if (!plausible) {
-				bad = true;
+				bad = 1;
 				break;
 			}
 			stop = here;
@@ -128,7 +131,7 @@ template <bool WRITE> __global__ __launch_bounds__(64) void bam_walk_kernel(BamW
 			break;
 		}
 		if (at + 4 + (uint64_t) block_size > a.stream_len) {
-			bad = true; // a record of this target that is not all there
+			bad = 1; // a record of this target that is not all there
 			break;
 		}
 		at += 4 + (uint64_t) block_size;
@@ -136,7 +139,7 @@ template <bool WRITE> __global__ __launch_bounds__(64) void bam_walk_kernel(BamW
 			continue; // (the tail of the previous target in front of this one's first record)
 		if (p < sg.pos_lo) {
 			if (first != kNone) { // behind a record of this segment: the file is not sorted by position -- not this decoder's to judge
-				bad = true;
+				bad = 2;
 				break;
 			}
 			continue; // starts in front of this segment: the previous one's
@@ -145,6 +148,15 @@ template <bool WRITE> __global__ __launch_bounds__(64) void bam_walk_kernel(BamW
 			first = here;
 		if (p < 0)
 			continue;
+		if (!WRITE && a.check_body) {
+			const uint32_t names = (uint32_t) load_i32(r + 12), cigars = (uint32_t) load_i32(r + 16);
+			const int32_t l_seq = load_i32(r + 20);
+			const uint64_t l = l_seq > 0 ? (uint64_t) l_seq : 0;
+			if (l_seq < 0 || 32u + (uint64_t) (names & 0xFFu) + 4u * (uint64_t) (cigars & 0xFFFFu) + (l + 1) / 2 + l > (uint64_t) block_size) {
+				bad = 1;
+				break;
+			}
+		}
 		if (WRITE) {
 			a.pos[w] = p;
 			a.mapq[w] = (uint8_t) ((uint32_t) load_i32(r + 12) >> 8); // l_read_name, MAPQ, bin: the byte at 13
@@ -158,7 +170,7 @@ template <bool WRITE> __global__ __launch_bounds__(64) void bam_walk_kernel(BamW
 		a.count[k] = n;
 		a.v_first[k] = first;
 		a.v_stop[k] = stop;
-		a.bad[k] = bad ? 1 : 0;
+		a.bad[k] = bad;
 	}
 }
 

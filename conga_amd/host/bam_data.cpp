@@ -64,7 +64,9 @@ uint64_t gpu_bam_min_piece()
 
 // count_reads_bam (bam_data.c:192-221), producer side: records go straight into the pinned staging ring.
 // With split reads enabled (--rp and --dups) every record is also handed over whole (split_read.c:206-354).
-int64_t count_reads_bam(conga_ctx *ctx, read_source *src, int chr_index_bam, int64_t chrom_len, bool split_reads)
+// `chrom`: the chromosome of the engine context the records go to (the one begun last in a fresh context; any of them when
+// a kept context takes the next sample of a cohort chromosome by chromosome).
+int64_t count_reads_bam(conga_ctx *ctx, read_source *src, int chr_index_bam, int64_t chrom_len, bool split_reads, int chrom)
 {
 	std::string err;
 	if (!src->begin(chr_index_bam, chrom_len, &err)) {
@@ -72,6 +74,31 @@ int64_t count_reads_bam(conga_ctx *ctx, read_source *src, int chr_index_bam, int
 		exit(1);
 	}
 	int64_t cnt = 0;
+	const char *gpu_bam = getenv("CONGA_GPU_BAM"); // 0: never, 1: always, unset: when it pays
+	if (gpu_bam == nullptr || atoi(gpu_bam) != 0) {
+		// a BAM with an index: its compressed blocks go to the GPU as they are and are inflated and walked there
+		// (conga_reads_bgzf); with split reads the engine then reads the records where they lie in HBM.  Anything that does
+		// not check out falls through to the host decoders below.  A launch lasts at least one block's few milliseconds, so it
+		// pays from some size of the piece on (a whole low-coverage genome, a chromosome of a deep sample: the default asks
+		// for 27 MB of file per host core).
+		file_piece bytes;
+		std::vector<conga_bgzf_block> blocks;
+		std::vector<conga_bam_segment> segments;
+		const uint64_t min_piece = gpu_bam != nullptr ? 0 : gpu_bam_min_piece();
+		if (src->device_plan({device_target{chr_index_bam, chrom_len, chrom}}, min_piece, &bytes, &blocks, &segments, &err)) {
+			std::vector<uint64_t> per_chrom((size_t) conga_chrom_count(ctx), 0);
+			const int rc = bytes.data ? conga_reads_bgzf(ctx, bytes.data, bytes.size, blocks.data(), blocks.size(), segments.data(), segments.size(),
+					per_chrom.data())
+					: conga_reads_bgzf_fd(ctx, bytes.fd, bytes.file_off, bytes.size, blocks.data(), blocks.size(), segments.data(), segments.size(),
+					per_chrom.data());
+			if (rc == CONGA_OK)
+				return (int64_t) per_chrom[(size_t) chrom];
+			if (rc != CONGA_ERR_DATA)
+				engine_check(ctx, rc, "conga_reads_bgzf");
+			fprintf(stderr, "\n[CONGA] decoding on the host: %s\n", conga_last_error(ctx));
+		}
+		err.clear();
+	}
 	if (split_reads) {
 		for (;;) {
 			conga_split_staging ss;
@@ -99,31 +126,6 @@ int64_t count_reads_bam(conga_ctx *ctx, read_source *src, int chr_index_bam, int
 				break;
 		}
 		return cnt;
-	}
-	const char *gpu_bam = getenv("CONGA_GPU_BAM"); // 0: never, 1: always, unset: when it pays
-	if (gpu_bam == nullptr || atoi(gpu_bam) != 0) {
-		// a BAM with an index: its compressed blocks go to the GPU as they are and are inflated and walked there
-		// (conga_reads_bgzf); anything that does not check out falls through to the host decoders below.  One lane per
-		// block takes ~0.1 s for a block however many there are, so it only pays with tens of thousands of blocks in a call
-		// (a whole low-coverage genome, a chromosome of a deep sample: the default asks for 27 MB of file per host core; measured: 45 000 blocks in 0.17 s = 17 GB/s inflated, against ~5 GB/s for 16 cores).
-		file_piece bytes;
-		std::vector<conga_bgzf_block> blocks;
-		std::vector<conga_bam_segment> segments;
-		const uint64_t min_piece = gpu_bam != nullptr ? 0 : gpu_bam_min_piece();
-		const int chrom = conga_chrom_count(ctx) - 1; // the chromosome begun last
-		if (src->device_plan({device_target{chr_index_bam, chrom_len, chrom}}, min_piece, &bytes, &blocks, &segments, &err)) {
-			std::vector<uint64_t> per_chrom((size_t) chrom + 1, 0);
-			const int rc = bytes.data ? conga_reads_bgzf(ctx, bytes.data, bytes.size, blocks.data(), blocks.size(), segments.data(), segments.size(),
-					per_chrom.data())
-					: conga_reads_bgzf_fd(ctx, bytes.fd, bytes.file_off, bytes.size, blocks.data(), blocks.size(), segments.data(), segments.size(),
-					per_chrom.data());
-			if (rc == CONGA_OK)
-				return (int64_t) per_chrom[(size_t) chrom];
-			if (rc != CONGA_ERR_DATA)
-				engine_check(ctx, rc, "conga_reads_bgzf");
-			fprintf(stderr, "\n[CONGA] decoding on the host: %s\n", conga_last_error(ctx));
-		}
-		err.clear();
 	}
 	{
 		// a BAM with an index: the whole chromosome decoded by several readers at once (reads.h: read_all)
@@ -268,8 +270,7 @@ struct planned_input {
 bool gpu_decode_wanted(const parameters *params)
 {
 	const char *gpu_bam = getenv("CONGA_GPU_BAM"); // 0: never, 1: always, unset: when it pays
-	const bool split_reads = !params->no_sr && params->have_dups;
-	return !split_reads && (gpu_bam == nullptr || atoi(gpu_bam) != 0);
+	return gpu_bam == nullptr || atoi(gpu_bam) != 0;
 }
 
 // the chromosomes read_bam will work on, in its order (bam_data.c:269-291): (annotation index, BAM target)
@@ -360,9 +361,8 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 	opts.flags = CONGA_FLAG_BATCH;
 	{
 		const char *gb = getenv("CONGA_GPU_BAM"); // (the decode may go to the GPU: let the engine get its staging ring meanwhile)
-		if (params->no_sr || !params->have_dups)
-			if (gb == nullptr || atoi(gb) != 0)
-				opts.flags |= CONGA_FLAG_EXPECT_BGZF;
+		if (gb == nullptr || atoi(gb) != 0)
+			opts.flags |= CONGA_FLAG_EXPECT_BGZF;
 	}
 	opts.min_read_length = params->min_read_length;
 	// the reference's split-read gate: `!no_sr && dup_file` (svdepth.c:57, bam_data.c:207,306,331, likelihood.c:344)
@@ -374,7 +374,8 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 	int status = 0;
 	conga_ctx *ctx = keep ? keep->ctx : nullptr;
 	// a kept context whose chromosomes, intervals and tracks are the ones this sample needs: only the reads change
-	bool same_layout = ctx != nullptr && !split_reads && !mine.empty() && keep->layout_key == layout_key_of(mine);
+	// (with split reads too: the reference sequences, the satellites and the 10-mer indexes built from them are the layout's)
+	bool same_layout = ctx != nullptr && !mine.empty() && keep->layout_key == layout_key_of(mine);
 	if (ctx != nullptr && !same_layout)
 		engine_check(ctx, conga_reset(ctx), "conga_reset");
 	std::thread creator;
@@ -395,7 +396,16 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 	std::string err;
 	std::vector<uint64_t> gpu_counts; // reads per chromosome when all of this worker's chromosomes were decoded on the GPU at once
 	const char *gpu_bam = getenv("CONGA_GPU_BAM"); // 0: never, 1: always, unset: when it pays
-	if (!split_reads && !mine.empty() && (gpu_bam == nullptr || atoi(gpu_bam) != 0)) {
+	// readReferenceSeq (common.c:423-463) and the satellite annotation (bam_data.c:96-97,207) for the chromosome begun last
+	auto hand_over_reference = [&](const chrom_job *job) {
+		std::string ref_seq, ferr;
+		if (!load_fasta_chrom(params->ref_genome, this_sonic->chromosome_names[job->chr_index], job->L, &ref_seq, &ferr))
+			print_error(ferr);
+		engine_check(ctx, conga_reference(ctx, ref_seq.data(), (int64_t) ref_seq.size()), "conga_reference");
+		engine_check(ctx, conga_satellites(ctx, this_sonic->sat_start[job->chr_index].data(),
+				this_sonic->sat_end[job->chr_index].data(), this_sonic->sat_start[job->chr_index].size()), "conga_satellites");
+	};
+	if (!mine.empty() && (gpu_bam == nullptr || atoi(gpu_bam) != 0)) {
 		// All chromosomes of this context in ONE decode on the GPU (conga_reads_bgzf): a low-coverage genome is tens of
 		// thousands of BGZF blocks as a whole, not per chromosome.  The chromosomes are opened (with their intervals and
 		// tracks) first, then the file's stretch goes up as it is.
@@ -427,6 +437,8 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 					gc_window_arrays(this_sonic, job->chr_index, &gc_hist_w, &gc_like_w);
 					engine_check(ctx, conga_chrom_begin(ctx, job->L, gc_hist_w.data(), gc_like_w.data(), (int64_t) gc_hist_w.size()),
 							"conga_chrom_begin");
+					if (split_reads)
+						hand_over_reference(job); // (the engine then keeps the records' places in the inflated stream)
 					attach_intervals(ctx, params, map_bed, job->cs);
 				}
 			gpu_counts.assign(mine.size(), 0);
@@ -465,7 +477,6 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 			fputs(job->messages.c_str(), stderr); // what the selection pass had to say before this chromosome
 			job->messages.clear();
 		}
-		const std::string &name = this_sonic->chromosome_names[job->chr_index];
 		const int64_t L = job->L;
 		out.say("\n");
 		out.say("Reading BAM [%s] - Chromosome: %s", src->sample_name().c_str(), src->target_name(job->chr_index_bam).c_str());
@@ -480,17 +491,13 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 					"conga_chrom_begin");
 		}
 		if (split_reads) {
-			// readReferenceSeq (common.c:423-463) and the satellite annotation (bam_data.c:96-97,207)
 			out.say("\nReading the Reference Genome");
-			std::string ref_seq;
-			if (!load_fasta_chrom(params->ref_genome, name, L, &ref_seq, &err))
-				print_error(err);
-			engine_check(ctx, conga_reference(ctx, ref_seq.data(), (int64_t) ref_seq.size()), "conga_reference");
-			engine_check(ctx, conga_satellites(ctx, this_sonic->sat_start[job->chr_index].data(),
-					this_sonic->sat_end[job->chr_index].data(), this_sonic->sat_start[job->chr_index].size()), "conga_satellites");
+			if (!on_gpu && !same_layout)
+				hand_over_reference(job);
 		}
 		out.say("\n-->counting reads");
-		const int64_t cnt_reads = on_gpu ? (int64_t) gpu_counts[job_index] : count_reads_bam(ctx, src, job->chr_index_bam, L, split_reads);
+		const int64_t cnt_reads = on_gpu ? (int64_t) gpu_counts[job_index]
+				: count_reads_bam(ctx, src, job->chr_index_bam, L, split_reads, (int) job_index);
 		if (counts_known_now)
 			out.say(" (%lld reads, %ld split-reads)\n", (long long) cnt_reads, 0L); // every record counts, no split reads
 		else
@@ -528,12 +535,19 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 		}
 		wt->ms_fetch = ms_since(t_fetch);
 	}
+	if (!keep || keep->last_sample) {
+		// no BAM behind this one: whatever staging the decode on the GPU still holds goes back (a no-op when the releaser above
+		// has done it), and the helper thread its first call left inside the HIP runtime is joined before the process leaves
+		if (releaser.t.joinable())
+			releaser.t.join();
+		(void) conga_release_staging(ctx);
+	}
 	// Everything is fetched.  The process is about to end, and giving gigabytes of device and pinned memory back one
 	// allocation at a time is a quarter of a second the operating system does for nothing: the context is left to it
 	// (CONGA_CLEAN_EXIT=1: tear down in order, for leak checkers).
 	if (keep) {
 		keep->ctx = ctx; // (the next sample's)
-		keep->layout_key = split_reads ? std::string() : layout_key_of(mine);
+		keep->layout_key = layout_key_of(mine);
 	} else if (getenv("CONGA_CLEAN_EXIT") != nullptr)
 		conga_destroy(ctx);
 }

@@ -210,7 +210,8 @@ int conga_intervals(conga_ctx *ctx, char type, const int32_t *start, const int32
 /* ---- cohort mode: the next sample's reads behind the same layout ----------------------------------------------
  * The consumer side of count_reads_bam (bam_data.c:192-221) for the second and every further sample of a cohort: the
  * reads of ALL chromosomes the context holds are replaced, everything else (chromosomes, GC arrays, intervals, tracks,
- * the device layout that conga_chrom_compute() prepared) stays.  Not with split reads.
+ * the device layout that conga_chrom_compute() prepared) stays.  With split reads the records go with the reads (they are the
+ * sample's); the reference sequences, the satellites and the 10-mer indexes built from them are the layout's and stay.
  *
  * conga_sample_reads: pos / mapq hold the sample's (bam1_core_t.pos, bam1_core_t.qual) tuples, chromosome 0's first,
  * then chromosome 1's, ... each in BAM order; chromosome c owns [chrom_off[c], chrom_off[c + 1]) (n_chrom + 1 entries,
@@ -240,7 +241,7 @@ int conga_sample_fetch(conga_ctx *ctx, conga_result *records, size_t n_records, 
 /* ---- count_reads_bam with the BAM decode on the device -------------------------------------------------------
  * Instead of decoded tuples the caller hands over a stretch of the BAM file exactly as it is on disk, the table of
  * its BGZF blocks, and start points taken from the .bai's linear index (16 kb windows).  The engine inflates the blocks
- * (one GPU lane per block, the decoder of conga_amd/host/inflate_core.h, CRC32 checked) and walks the records (one lane
+ * (one BGZF block per wave, conga_amd/csrc/inflate_wave.hip.h, CRC32 checked) and walks the records (one lane
  * per start point), and gives every chromosome named by the start points its reads: (pos, mapq) of the records with
  * refID == ref_id and 0 <= pos < pos_hi of its last segment -- the records `sam_itr_queryi(idx, tid, 0, L)` +
  * `sam_itr_next` hand to count_reads_bam (bam_data.c:192-221, 293) -- in file order, without the tuples ever being on
@@ -253,7 +254,12 @@ int conga_sample_fetch(conga_ctx *ctx, conga_result *records, size_t n_records, 
  * No chromosome from the first named one on may have reads yet (the tuples of a context are laid out in chromosome
  * order); chromosomes in between that are not named get none.  The engine verifies that every segment stops exactly
  * where the next one of its chromosome found its first record; if not, or if a block fails its checks, it returns
- * CONGA_ERR_DATA and has changed nothing.  Not for --rp (no sequences kept). */
+ * CONGA_ERR_DATA and has changed nothing.
+ * Split reads (--rp with --dups): a chromosome named here that has a reference sequence (conga_reference) gets its split-read
+ * records from the same call -- the engine notes where each kept record starts in the inflated stream, keeps the stream, and
+ * find_split_reads' fields (core.pos, core.qual, core.flag, core.l_qseq, bam_get_seq, bam_get_qual: split_read.c:206-354) are
+ * read where they lie in HBM; conga_split_reads_staging / _commit are not called for such a chromosome.  A kept record whose
+ * name, CIGAR, sequence and qualities do not fit its block_size is CONGA_ERR_DATA (the host reader's "corrupt BAM record"). */
 typedef struct conga_bgzf_block {
 	uint64_t data_off;     /* of the raw deflate data inside `bytes` */
 	uint32_t data_len;
@@ -297,8 +303,10 @@ int conga_inflate_blocks(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, c
  *   - every record of the BAM loop with the fields find_split_reads touches (split_read.c:206-354):
  *     core.pos, core.qual, core.flag, core.l_qseq, the packed 4-bit sequence and the base qualities.
  * The gate of bam_data.c:205-207 (mapq, length, flags, satellite) is applied by the engine.
- * conga_chrom_compute() then builds the 10-mer index, maps both halves of every read, pairs them and adds the
- * support counts into conga_result.rp (dups) / border_rp (dels). */
+ * conga_chrom_compute() then builds the 10-mer index (once per reference sequence: it stays resident), maps both halves of
+ * every read, pairs them and adds the support counts into conga_result.rp (dups) / border_rp (dels).
+ * Records go to the chromosome begun last, or to the one conga_sample_chrom() named; a chromosome's records are committed
+ * without another's in between.  A chromosome without a reference sequence takes no part (its records are carried, no more). */
 typedef struct conga_split_staging {
 	int32_t *pos;       /* bam1_core_t.pos */
 	uint8_t *mapq;      /* bam1_core_t.qual */

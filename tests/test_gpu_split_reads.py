@@ -142,3 +142,66 @@ def test_records_that_cannot_be_are_refused_or_ignored(capi):
         ctx.intervals("D", ds, de)
         dels, _, _, st = ctx.finish()
         assert st.split_elements > 0
+
+
+def test_batch_with_a_chromosome_without_reference_in_the_middle(capi, oracle):
+    """Three chromosomes in one batch context, the middle one with records but no conga_reference(): it takes no part in the
+    split-read launch, the other two get exactly what they get alone (their records need not follow each other)."""
+    cases = [make_case(seed=11, n_normal=1500), make_case(seed=12, n_normal=800), make_case(seed=13, n_normal=1200)]
+    alone = []
+    for c in (cases[0], cases[2]):
+        (dels, dups, st), _ = run_both(capi, oracle, c)
+        alone.append((dels["border_rp"].copy(), dups["rp"].copy(), st.split_elements, st.split_mappings))
+    with capi.Context(device=0, flags=capi.FLAG_BATCH) as ctx:
+        for k, c in enumerate(cases):
+            gc = np.full((c["L"] + 99) // 100, 40, np.uint8)
+            ctx.chrom_begin(c["L"], gc)
+            ctx.reads(c["pos"], c["mapq"])
+            if k != 1:
+                ctx.reference(c["ref_lower"])
+                ctx.satellites(c["sat_s"], c["sat_e"])
+            ctx.split_reads(c["pos"], c["mapq"], c["flag"], c["lq"], c["codes"], c["qual"], c["off"])
+            ctx.intervals("D", np.array([d[0] for d in c["dels"]], np.int32), np.array([d[1] for d in c["dels"]], np.int32))
+            ctx.intervals("E", np.array([d[0] for d in c["dups"]], np.int32), np.array([d[1] for d in c["dups"]], np.int32))
+        ctx.compute()
+        res = ctx.fetch_all()
+    for k, want in ((0, alone[0]), (2, alone[1])):
+        dels, dups, _E, st = res[k]
+        assert np.array_equal(dels["border_rp"], want[0]) and np.array_equal(dups["rp"], want[1])
+        assert (st.split_elements, st.split_mappings) == want[2:]
+    dels, dups, _E, st = res[1]
+    assert st.split_elements == 0 and np.all(dels["border_rp"] == 0) and np.all(dups["rp"] == 0)
+
+
+def test_next_sample_of_a_cohort_brings_its_records_the_indexes_stay(capi, oracle):
+    """conga_sample_begin with split reads: the reference sequences and the 10-mer indexes are the layout's, the records the
+    sample's.  Sample B behind sample A in one context equals sample B alone; A again equals A."""
+    a = make_case(seed=21, n_normal=2500)
+    b = make_case(seed=21, n_normal=2500)
+    keep = np.arange(len(b["pos"])) % 4 != 2
+    per_base = np.repeat(keep, b["lq"])
+    lq = b["lq"][keep]
+    b.update(pos=b["pos"][keep], mapq=b["mapq"][keep], flag=b["flag"][keep], lq=lq, codes=b["codes"][per_base], qual=b["qual"][per_base],
+             off=np.concatenate([[0], np.cumsum(lq)[:-1]]).astype(np.uint64))
+    want = {}
+    for name, c in (("a", a), ("b", b)):
+        (dels, dups, st), _ = run_both(capi, oracle, c)
+        want[name] = (dels["border_rp"].copy(), dups["rp"].copy(), st.split_elements, st.split_mappings, st.split_del_rows, st.split_dup_rows)
+    assert want["a"][2] != want["b"][2]
+    ds, de = np.array([d[0] for d in a["dels"]], np.int32), np.array([d[1] for d in a["dels"]], np.int32)
+    us, ue = np.array([d[0] for d in a["dups"]], np.int32), np.array([d[1] for d in a["dups"]], np.int32)
+    gc = np.full((a["L"] + 99) // 100, 40, np.uint8)
+    with capi.Context(device=0, flags=capi.FLAG_BATCH) as ctx:
+        ctx.chrom_begin(a["L"], gc)
+        ctx.reference(a["ref_lower"])
+        ctx.satellites(a["sat_s"], a["sat_e"])
+        ctx.intervals("D", ds, de)
+        ctx.intervals("E", us, ue)
+        for name, c in (("a", a), ("b", b), ("a", a)):
+            ctx._check(ctx._lib.conga_sample_begin(ctx._h))
+            ctx.reads(c["pos"], c["mapq"])
+            ctx.split_reads(c["pos"], c["mapq"], c["flag"], c["lq"], c["codes"], c["qual"], c["off"])
+            ctx.compute()
+            dels, dups, _E, st = ctx.fetch_all()[0]
+            got = (dels["border_rp"], dups["rp"], st.split_elements, st.split_mappings, st.split_del_rows, st.split_dup_rows)
+            assert np.array_equal(got[0], want[name][0]) and np.array_equal(got[1], want[name][1]) and got[2:] == want[name][2:], name

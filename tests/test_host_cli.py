@@ -14,8 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CONGA = os.path.join(ROOT, "conga_amd", "host", "conga")
 
 
-def run(args, cwd):
-    return subprocess.run([CONGA] + args, cwd=cwd, capture_output=True, text=True, timeout=600)
+def run(args, cwd, env=None):
+    return subprocess.run([CONGA] + args, cwd=cwd, capture_output=True, text=True, timeout=600, env=env)
 
 
 def make_inputs(d, with_bam=True):
@@ -404,12 +404,14 @@ def test_gpu_bam_decode_takes_every_kind_of_block(tmp_path, payload, level, stra
 @pytest.mark.gpu
 def test_cli_split_reads_rp(tmp_path, oracle):
     """--rp with --dups: FASTA + BAM sequences -> READ_PAIR columns and the `rp > rp_support` rule of _svs.bed
-    (likelihood.c:243-279), byte-identical to the oracle."""
+    (likelihood.c:243-279), byte-identical to the oracle -- with the records handed over by the host decoders, read in place
+    from the stream the GPU inflated (one call for all chromosomes, one per chromosome), and for the samples of a cohort."""
     from test_gpu_split_reads import make_case
     d = str(tmp_path)
-    c = make_case(seed=5, L=300_000, n_normal=4000)
+    c = make_case(seed=5, L=400_000, n_normal=4000)    # (every planted SV inside the chromosome: the decode on the GPU leaves a file
+    # with records behind the annotation's chromosome end to the host decoders)
     # one chromosome with the planted junctions plus a plain one
-    plain = synth.make_chrom("2", 120_000, cov=2.0, n_dels=8, n_dups=3, gaps=False)
+    plain = synth.make_chrom("2", 120_000, cov=6.0, n_dels=8, n_dups=3, gaps=False)
     gc1 = np.full((c["L"] + 99) // 100, 41, np.uint8)
     formats.write_annotation(os.path.join(d, "a.cga"), [("1", c["L"], gc1, c["sat_s"][:2], c["sat_e"][:2]),
                                                           ("2", plain.length, plain.gc, [], [])])
@@ -428,13 +430,57 @@ def test_cli_split_reads_rp(tmp_path, oracle):
     qual2 = np.full(len(codes2), 30, np.uint8)
     formats.write_bam(os.path.join(d, "r.bam"), "S1",
                       [("1", c["L"], c["pos"], c["mapq"], c["flag"]), ("2", plain.length, pos2, mq2)],
-                      records={"1": (c["lq"], c["codes"], c["qual"], c["off"]), "2": (lq2, codes2, qual2, off2)})
+                      records={"1": (c["lq"], c["codes"], c["qual"], c["off"]), "2": (lq2, codes2, qual2, off2)},
+                      index=True, block_payload=30_000, unplaced=3)
     synth.write_bed(os.path.join(d, "dels.bed"), [("1", s, e) for s, e in c["dels"]] + [("2", s, e) for s, e in zip(plain.del_start, plain.del_end)])
     synth.write_bed(os.path.join(d, "dups.bed"), [("1", s, e) for s, e in c["dups"]] + [("2", s, e) for s, e in zip(plain.dup_start, plain.dup_end)])
-    r = run(["-i", "r.bam", "--out", "got", "--ref", "ref.fa", "--sonic", "a.cga", "--dels", "dels.bed", "--dups",
-             "dups.bed", "--rp", "3"], d)
+    common = ["--ref", "ref.fa", "--sonic", "a.cga", "--dels", "dels.bed", "--dups", "dups.bed", "--rp", "3"]
+
+    def files(prefix):
+        return [open(os.path.join(d, "%s_%s.bed" % (prefix, k)), "rb").read() for k in ("svs", "dels", "dups")]
+
+    def counts(stderr):  # count_reads_bam's closing line per chromosome, and the rows paired
+        import re
+        return re.findall(r"\((\d+) reads, (\d+) split-reads\)", stderr), re.findall(r"CONGA paired (\d+) single-end reads", stderr)
+    # the host decoders hand every record over through the pinned staging (conga_split_reads_commit) ...
+    r = run(["-i", "r.bam", "--out", "got"] + common, d, env=dict(os.environ, CONGA_GPU_BAM="0"))
     assert r.returncode == 0, r.stderr[-3000:]
     assert "CONGA paired" in r.stderr
+    # ... the decode on the GPU leaves them where the inflate put them and the split-read stage reads them there
+    # (bam_data.c:201-216 with find_split_reads inside the BAM loop: no record ever exists on the host)
+    r_gpu = run(["-i", "r.bam", "--out", "gpu"] + common, d, env=dict(os.environ, CONGA_GPU_BAM="1", CONGA_TIMING="1"))
+    assert r_gpu.returncode == 0, r_gpu.stderr[-3000:]
+    assert "decoding on the host" not in r_gpu.stderr and r_gpu.stderr.count("conga_reads_bgzf:") == 1
+    assert files("gpu") == files("got") and counts(r_gpu.stderr) == counts(r.stderr) and len(counts(r.stderr)[0]) == 2
+    # one GPU call per chromosome (the piece limit below the whole stretch): the second call's stream goes behind the first's
+    size = os.path.getsize(os.path.join(d, "r.bam"))
+    r_each = run(["-i", "r.bam", "--out", "each"] + common, d,
+                 env=dict(os.environ, CONGA_GPU_BAM="1", CONGA_TIMING="1", CONGA_GPU_BAM_MAX_MB="%.4f" % (size * 0.9 / 1048576)))
+    assert r_each.returncode == 0, r_each.stderr[-3000:]
+    assert r_each.stderr.count("conga_reads_bgzf:") == 2 and "decoding on the host" not in r_each.stderr
+    assert files("each") == files("got") and counts(r_each.stderr) == counts(r.stderr)
+    # a cohort with --rp: the reference sequences and the 10-mer indexes stay with the layout, a sample brings its records
+    keep = np.arange(len(c["pos"])) % 3 != 1            # a second sample: two thirds of the first one's reads
+    lq_b = c["lq"][keep]
+    off_b = np.concatenate([[0], np.cumsum(lq_b)[:-1]]).astype(np.uint64)
+    per_base = np.repeat(keep, c["lq"])
+    formats.write_bam(os.path.join(d, "b.bam"), "S2",
+                      [("1", c["L"], c["pos"][keep], c["mapq"][keep], c["flag"][keep]), ("2", plain.length, pos2[::2], mq2[::2])],
+                      records={"1": (lq_b, c["codes"][per_base], c["qual"][per_base], off_b),
+                               "2": (lq2[::2], codes2.reshape(-1, 100)[::2].reshape(-1), qual2.reshape(-1, 100)[::2].reshape(-1), off2[:len(lq2[::2])])},
+                      index=True, block_payload=30_000)
+    with open(os.path.join(d, "list.txt"), "w") as f:
+        f.write("r.bam\nb.bam\nr.bam\n")
+    for decode in ("1", "0"):
+        env = dict(os.environ, CONGA_GPU_BAM=decode, CONGA_TIMING="1")
+        rc = subprocess.run([CONGA, "--cohort", "list.txt", "--out", "co" + decode] + common, cwd=d, capture_output=True, text=True, timeout=600, env=env)
+        assert rc.returncode == 0, rc.stderr[-3000:]
+        assert rc.stderr.count("10-mer indexes of") == 1, "the indexes are built once for the cohort"
+        one = run(["-i", "b.bam", "--out", "oneb" + decode] + common, d, env=env)
+        assert one.returncode == 0, one.stderr[-3000:]
+        assert files("co%s.r" % decode) == files("got") and files("co%s.b" % decode) == files("oneb" + decode)
+        assert files("oneb" + decode) != files("got")
+    assert files("oneb1") == files("oneb0")
 
     paths = [os.path.join(d, "want_%s.bed" % k) for k in ("svs", "dels", "dups")]
     first = True
@@ -568,7 +614,7 @@ def test_fast_bed_parser_equals_the_literal_fgets_strtok_reader(tmp_path, oracle
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("decode", ["gpu", "host"])
+@pytest.mark.parametrize("decode", ["gpu", "host", "gpu_each"])
 def test_cli_cohort_keeps_the_engine_and_every_byte(tmp_path, decode):
     """`--cohort list` (an extension: the reference is started once per sample, svdepth.c:16-74): several BAMs in one process,
     the engine context kept from sample to sample -- the layout too when the samples select the same chromosomes
@@ -595,11 +641,15 @@ def test_cli_cohort_keeps_the_engine_and_every_byte(tmp_path, decode):
         f.write("# BAM [prefix]\n%s\n%s\tnamed/two\n\n%s\n%s\n" % tuple(samples))
     os.mkdir(os.path.join(d, "named"))
     common = ["--ref", "r.fa", "--sonic", "a.cga", "--dels", "dels.bed", "--dups", "dups.bed", "--mappability", "map.bed"]
-    env = dict(os.environ, CONGA_GPU_BAM="1" if decode == "gpu" else "0", CONGA_TIMING="1")
+    env = dict(os.environ, CONGA_GPU_BAM="0" if decode == "host" else "1", CONGA_TIMING="1")
+    if decode == "gpu_each":
+        # a piece limit below the second (deepest) sample's stretch: that sample goes up chromosome by chromosome into the KEPT
+        # layout (conga_sample_chrom names the chromosome of the context each call feeds), the others in one call each
+        env["CONGA_GPU_BAM_MAX_MB"] = "%.4f" % (os.path.getsize(os.path.join(d, samples[1])) * 0.92 / 1048576)
     r = subprocess.run([CONGA, "--cohort", "list.txt", "--out", "co"] + common, cwd=d, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
-    if decode == "gpu":
-        assert r.stderr.count("conga_reads_bgzf:") == 4 and "decoding on the host" not in r.stderr
+    if decode != "host":
+        assert r.stderr.count("conga_reads_bgzf:") == (4 if decode == "gpu" else 6) and "decoding on the host" not in r.stderr
     prefixes = ["co.s0", "named/two", "co.s2", "co.s3"]
     for k, bam in enumerate(samples):
         one = subprocess.run([CONGA, "-i", bam, "--out", "one%d" % k] + common, cwd=d, capture_output=True, text=True, timeout=600, env=env)
