@@ -21,6 +21,8 @@ Also on the line:
   roofline        the HBM-bound kernel of the step (ingest_tuples_kernel) timed with HIP events on its own stream in that
                   rotation; step_bound = the PCIe copy that bounds the step itself
   roofline_dense  the reference's dense formulation (read_depth[] materialised), depth_tile_kernel
+  end_to_end      `conga --cohort` over whole-genome 1x BAMs written on the spot: first sample, every further sample, with
+                  the decode on the GPU and with the host decoders; zlib + the oracle on one core beside it
   configs         short legs for BASELINE configs[2] (dels + dups + mappability) and configs[4] (5x, --rp split reads)
   cpu_baseline    the oracle (serial port of the reference's loops), 1 thread, same workload; its records are compared
                   with the HIP path's at full size in the same run (cn_concordance is computed from that comparison)
@@ -69,6 +71,8 @@ def parse_args():
                     help="skip the dense-formulation leg that follows the timed region at N=1")
     ap.add_argument("--no-config-legs", dest="config_legs", action="store_false",
                     help="skip the configs[2] / configs[4] legs that follow the timed region at N=1")
+    ap.add_argument("--no-e2e-leg", dest="e2e_leg", action="store_false",
+                    help="skip the end-to-end leg (`conga --cohort` over whole-genome BAMs written into /tmp) that follows the timed region at N=1")
     ap.add_argument("--rp-chroms", type=str, default="20,21,22",
                     help="chromosomes of the configs[4] (--rp) leg; 'all' = the whole genome (21 GB of read records)")
     ap.add_argument("--dist-selftest", action="store_true",
@@ -593,14 +597,22 @@ def main():
             g2 = dctx.sample_fetch()[0]
             assert g1.tobytes() == g2.tobytes(), "tuple-space and dense records differ"
             dctx.close()
+        c0 = leg.ctxs[0]
+        c0.sample_reads(*leg.samples[0])
+        c0.compute()
+        recs, E, _ = c0.sample_fetch()
         if args.cpu_seconds > 0:
-            c0 = leg.ctxs[0]
-            c0.sample_reads(*leg.samples[0])
-            c0.compute()
-            recs, E, _ = c0.sample_fetch()
             out["cpu_baseline"], out["cn_concordance"] = cpu_baseline(mine, recs, E, args, leg.with_map)
+            out["cpu_baseline"]["host_cores"] = os.cpu_count()
         leg.close()
         leg = None
+        if args.e2e_leg and args.config == "dels" and args.formulation == "auto":
+            # ---- end to end from BAM files ("reported separately"): `conga --cohort` over BAMs written on the spot
+            from conga_amd import e2e_bench
+            try:
+                out["end_to_end"] = e2e_bench.leg(args, env, mine, recs, out.get("cpu_baseline", {}).get("value"))
+            except (OSError, MemoryError) as e:   # (no room for 6 GB of scratch BAMs, say: the headline does not depend on this leg)
+                out["end_to_end"] = dict(error="%s: %s" % (type(e).__name__, e))
         if args.config_legs and args.config == "dels":
             out["configs"] = config_legs(args, env)
 

@@ -106,21 +106,49 @@ def open_chrom(ctx, ch):
     ctx.intervals("E", ch["us"], ch["ue"])
 
 
-def bucket_bytes_per_read(chroms):
-    """Bytes of 10-mer index a read's four bucket scans touch on average.  A seed falls into a bucket with probability
-    proportional to its size; over a random ACGT reference with n indexed bases the bucket sizes are Poisson(n / 4^10),
-    whose size-biased mean is n / 4^10 + 1 (checked against the exact histogram of chromosome 21: 591 vs 586 bytes)."""
-    tot, w = 0.0, 0.0
+def write_fasta_fast(path, chroms, width=60):
+    """[(name, uint8[L])] -> FASTA + .fai, whole lines at a time"""
+    fai = []
+    with open(path, "wb") as f:
+        for name, seq in chroms:
+            f.write(b">" + name.encode() + b"\n")
+            fai.append((name, len(seq), f.tell(), width, width + 1))
+            full = len(seq) // width * width
+            lines = np.empty((full // width, width + 1), np.uint8)
+            lines[:, :width] = seq[:full].reshape(-1, width)
+            lines[:, width] = 10
+            f.write(lines.tobytes())
+            if full < len(seq):
+                f.write(seq[full:].tobytes() + b"\n")
+    with open(path + ".fai", "w") as f:
+        for r in fai:
+            f.write("\t".join(str(x) for x in r) + "\n")
+
+
+def split_map_bytes(chroms):
+    """Algorithmic bytes of one split_map_kernel launch over these records: per read the record's place
+    (8) and header fields (16), its packed sequence (l / 2; the qualities are not read with a threshold <= 0), per half read two
+    bucket bounds (2 x 8), two binary searches (4 bytes per probe, log2 of the mean kept bucket) and the reference under ~1.2
+    candidates (l / 4 bytes each, packed codes)."""
+    tot = 0.0
     for ch in chroms:
         n = float(np.count_nonzero(ch["ref"] != ord("N")))
-        reads = len(ch["pos"])
-        tot += reads * 4 * 4.0 * (n / (1 << 20) + 1.0)
-        w += reads
-    return tot / max(w, 1.0)
+        probes = np.ceil(np.log2(n / (1 << 20) + 2.0))
+        tot += len(ch["pos"]) * (8 + 16 + READ_LEN // 2 + 2 * (2 * 8 + 2 * 4 * probes + 1.2 * READ_LEN // 4))
+    return tot
 
 
 def leg(args, env):
-    """-> (dict for bench.py's `configs["configs[4]"]`, a bounded sample of the records for the caller's CPU baseline)."""
+    """-> (dict for bench.py's `configs["configs[4]"]`, a bounded sample of the records for the caller's CPU baseline).
+
+    `value` is the configuration's own path: BGZF bytes of a 5x sample -> the three output files, per further sample of a
+    `conga --cohort --rp` run, the decode on the GPU and the split-read stage reading the records where the inflate left them
+    (bam_data.c:201-216 with find_split_reads inside the BAM loop).  Beside it: the same with the host decoders, and the
+    kernels alone on records resident in HBM (handed over through the C-ABI's pinned staging)."""
+    import os
+    import shutil
+    import tempfile
+    from . import e2e_bench, formats
     names = [n for n, _ in synth.GRCH37_AUTOSOMES] if args.rp_chroms == "all" else args.rp_chroms.split(",")
     if args.chroms:
         names = [n for n in names if n in set(args.chroms.split(","))] or args.chroms.split(",")[-1:]
@@ -148,6 +176,7 @@ def leg(args, env):
             ctx.sync()
         return (time.perf_counter() - t1) / steps
 
+    # ---- the C-ABI's staged route, and the kernels alone on what it left in HBM
     with capi.Context(device=env["local_rank"], flags=capi.FLAG_BATCH) as ctx:
         t0 = time.perf_counter()
         for ch in chroms:
@@ -161,6 +190,15 @@ def leg(args, env):
         t_with = timed(ctx)
         res = ctx.fetch_all()
         st = [r[3] for r in res]
+        # the split-read launch by itself: HIP events around it on the context's stream (CONGA_FLAG_PROFILE)
+        ctx.set_profile(True)
+        k_ms = []
+        for _ in range(steps):
+            ctx.compute()
+            ctx.select(0)
+            k_ms.append(float(ctx.fetch()[3].kernel_ms[capi.KERNEL_NAMES.index("split_map")]))
+        ctx.set_profile(False)
+    sr_ms = float(np.mean(k_ms))
     with capi.Context(device=env["local_rank"], flags=capi.FLAG_BATCH) as ctx:  # the same without the records: depth path only
         for ch in chroms:
             ctx.chrom_begin(ch["L"], ch["gc"])
@@ -172,23 +210,66 @@ def leg(args, env):
     for (d1, u1, _e1, _s1), (d0, u0, _e0, _s0) in zip(res, plain):   # the support columns are all the split reads add
         for k in ("observed", "expected", "cn", "score"):
             assert np.array_equal(d1[k], d0[k], equal_nan=True) and np.array_equal(u1[k], u0[k], equal_nan=True), k
-    sr_ms = 1e3 * (t_with - t_without)
-    bucket = bucket_bytes_per_read(chroms)
-    alg = n_reads * (19 + READ_LEN // 2 + READ_LEN + 16 + bucket + 2 * READ_LEN)   # record, buckets, ~2 reference compares
-    out.update(ms_per_step=round(1e3 * t_with, 3), value=round(n_iv / t_with, 1), unit="intervals/s",
-               records_per_s=round(n_reads / t_with, 1), regime="records resident in HBM (kernels only; the hand-over of "
-               "%.1f GB of records is PCIe: %.0f ms at 54 GB/s)" % (rec_bytes / 1e9, rec_bytes / 54e6),
-               depth_path_ms=round(1e3 * t_without, 3), split_read_stage_ms=round(sr_ms, 3),
+    alg = split_map_bytes(chroms)
+    out.update(kernel_only=dict(ms_per_step=round(1e3 * t_with, 3), value=round(n_iv / t_with, 1), records_per_s=round(n_reads / t_with, 1),
+                                regime="records resident in HBM (staged route), compute + sync per step; depth path alone %.3f ms"
+                                       % (1e3 * t_without)),
                split_elements=int(sum(s.split_elements for s in st)), split_mappings=int(sum(s.split_mappings for s in st)),
                split_rows=int(sum(s.split_del_rows + s.split_dup_rows for s in st)),
                supported_dups=int(sum(int((r[1]["rp"] > 0).sum()) for r in res)),
                supported_dels=int(sum(int((r[0]["border_rp"] > 0).sum()) for r in res)),
-               roofline=dict(bound="hbm", kernel="split_read_kernel", algorithmic_bytes_per_launch=int(alg),
-                             avg_launch_ms=round(sr_ms, 3), achieved=round(alg / max(sr_ms, 1e-6) / 1e6, 1), peak=8000.0, unit="GB/s",
+               roofline=dict(bound="hbm", kernel="split_map_kernel", algorithmic_bytes_per_launch=int(alg),
+                             avg_launch_ms=round(sr_ms, 4), achieved=round(alg / max(sr_ms, 1e-6) / 1e6, 1), peak=8000.0, unit="GB/s",
                              frac=round(alg / max(sr_ms, 1e-6) / 1e6 / 8000.0, 4), traffic=None,
-                             note="instruction-bound: ~770 vector + 650 scalar instructions and ~5 dependent trips to HBM per read "
-                                  "(fields -> qualities + sequence + reference -> bucket bounds -> buckets); launch time = step with "
-                                  "records - step without"))
+                             records_per_s=round(n_reads / (sr_ms * 1e-3), 1),
+                             note="HIP events around the launch on the context's stream (CONGA_FLAG_PROFILE); a lane per half-read "
+                                  "element: dependent 4-byte probes into 10-mer buckets spread over the whole index -- latency- and "
+                                  "request-bound, not a streaming kernel (counters: profiles/)"))
+
+    # ---- the configuration's path: BAM files in, three files out
+    d = tempfile.mkdtemp(prefix="conga_bench_rp_", dir=os.environ.get("CONGA_BENCH_TMP", "/tmp"))
+    try:
+        if not (os.path.exists(e2e_bench.CONGA) and os.path.exists(e2e_bench.BAMWRITE)):
+            raise OSError("conga / tools/bamwrite are not built")
+        half = (READ_LEN + 1) // 2
+        bam_in = []
+        for ch in chroms:
+            c = ch["codes"]
+            bam_in.append((ch["name"], ch["L"], ch["pos"], ch["mapq"], ch["flag"], (c[:, 0::2] << 4) | c[:, 1::2], ch["qual"]))
+            assert bam_in[-1][5].shape[1] == half
+        bam, t_write = e2e_bench.write_bam(d, "rp", bam_in, l_seq=READ_LEN)
+        formats.write_annotation(os.path.join(d, "a.cga"), [(ch["name"], ch["L"], ch["gc"], ch["sat_s"], ch["sat_e"]) for ch in chroms])
+        write_fasta_fast(os.path.join(d, "ref.fa"), [(ch["name"], ch["ref"]) for ch in chroms])
+        synth.write_bed(os.path.join(d, "dels.bed"), [(ch["name"], s, e) for ch in chroms for s, e in zip(ch["ds"], ch["de"])])
+        synth.write_bed(os.path.join(d, "dups.bed"), [(ch["name"], s, e) for ch in chroms for s, e in zip(ch["us"], ch["ue"])])
+        common = ["--ref", "ref.fa", "--sonic", "a.cga", "--dels", "dels.bed", "--dups", "dups.bed", "--rp", "10"]
+        e2e = {}
+        for decode, envx, k in (("gpu", dict(CONGA_GPU_BAM="1"), 4), ("host", dict(CONGA_GPU_BAM="0"), 2)):
+            t1, per, t_k, err = e2e_bench.cohort_times(d, [bam], k, common, dict(envx, CONGA_TIMING="1"), decode, repeats=1)
+            assert "decoding on the host" not in err and err.count("conga_reads_bgzf:") == (k if decode == "gpu" else 0), err[-1500:]
+            e2e[decode] = dict(decode=decode, first_sample_s=round(t1, 3), per_further_sample_ms=round(per, 1), samples=k, wall_s=round(t_k, 3),
+                               intervals_per_s=round(n_iv / (per * 1e-3), 1), records_per_s=round(n_reads / (per * 1e-3), 1))
+        for kind in ("svs", "dels", "dups"):
+            a = open(os.path.join(d, "gpu_s1_%s.bed" % kind), "rb").read()
+            assert a == open(os.path.join(d, "host_s1_%s.bed" % kind), "rb").read() and len(a) > 100, kind
+        # READ_PAIR of every row = the support the staged route of the C-ABI counted
+        at = {"dels": 0, "dups": 1}
+        for kind, col in (("dels", "border_rp"), ("dups", "rp")):
+            rows = open(os.path.join(d, "gpu_s1_%s.bed" % kind)).read().splitlines()[1:]
+            want = np.concatenate([r[at[kind]][col] for r in res])
+            assert np.array_equal(np.array([int(x.split("\t")[5]) for x in rows], np.int32), want), kind
+        per = e2e["gpu"]["per_further_sample_ms"] * 1e-3
+        out.update(ms_per_step=round(1e3 * per, 2), value=round(n_iv / per, 1), unit="intervals/s", records_per_s=round(n_reads / per, 1),
+                   regime="BGZF bytes -> three output files, per further sample of `conga --cohort --rp 10` (%.2f GB BAM written by "
+                          "tools/bamwrite in %.1f s, in the page cache): upload, inflate, record walk, split-read stage on the records "
+                          "in place, depth / likelihood path, output" % (os.path.getsize(bam) / 1e9, t_write),
+                   end_to_end=e2e["gpu"], end_to_end_host_decoders=e2e["host"],
+                   checked="three files byte-identical between the decoders; READ_PAIR of every row equal to the staged route's support")
+    except (OSError, MemoryError) as e:   # (no room for the scratch BAM, say)
+        out.update(ms_per_step=round(1e3 * t_with, 3), value=round(n_iv / t_with, 1), unit="intervals/s",
+                   regime="records resident in HBM (the BAM route could not run: %s: %s)" % (type(e).__name__, e))
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
     # a bounded sample for the caller's CPU baseline (bench.py runs the oracle; nothing in this package does)
     ch = min(chroms, key=lambda c: c["L"])
     k = min(20_000, len(ch["pos"]))

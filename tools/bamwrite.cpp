@@ -28,6 +28,7 @@
 #include <vector>
 
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -68,6 +69,23 @@ struct Chrom {
 	uint64_t serial0 = 0; // number of its first record (read names)
 	size_t rec_size() const { return 4 + 32 + 12 + 4 + (size_t) (l_seq + 1) / 2 + (size_t) l_seq; }
 };
+
+// the cores this process may really use: affinity mask and cgroup CPU quota (a box that shows 256 hardware threads and grants 16)
+int usable_cpus()
+{
+	int n = (int) std::max(1u, std::thread::hardware_concurrency());
+	cpu_set_t set;
+	if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0)
+		n = std::min(n, (int) CPU_COUNT(&set));
+	if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+		char q[32] = "";
+		long long period = -1;
+		if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0)
+			n = std::min(n, (int) std::max(1LL, (atoll(q) + period - 1) / period));
+		fclose(f);
+	}
+	return std::max(n, 1);
+}
 
 uint64_t mix(uint64_t x) // splitmix64
 {
@@ -163,7 +181,7 @@ int main(int argc, char **argv)
 		return 2;
 	}
 	const std::string out_path = argv[1], manifest = argv[2];
-	int level = 1, threads = (int) std::max(1u, std::thread::hardware_concurrency());
+	int level = 1, threads = usable_cpus();
 	size_t payload = 65280;
 	std::string sample = "S";
 	for (int i = 3; i + 1 < argc; i += 2) {
@@ -408,6 +426,7 @@ int main(int argc, char **argv)
 	const uint64_t no_coor = 0;
 	fwrite(&no_coor, 8, 1, bai);
 	fclose(bai);
-	fprintf(stderr, "bamwrite: %llu records, %zu blocks, %.1f MB -> %.1f MB\n", (unsigned long long) serial, n_blocks, total / 1e6, (file_at + 28) / 1e6);
+	fprintf(stderr, "bamwrite: %llu records, %zu blocks, %.1f MB -> %.1f MB, %d threads\n", (unsigned long long) serial, n_blocks, total / 1e6,
+			(file_at + 28) / 1e6, threads);
 	return 0;
 }
