@@ -353,6 +353,25 @@ class Leg:
             elapsed = float(t.item())
         return elapsed
 
+    def single_context(self, steps):
+        """The pipelined step with ONE context (what a cohort driver behind the C-ABI has): sample k + 1 is handed over
+        (conga_sample_reads: its copy runs on the context's second stream into the other pair of tuple buffers), sample k is
+        fetched, sample k + 1 is computed.  -> seconds per step"""
+        c = self.ctxs[0]
+        c.sample_reads(*self.samples[0])
+        c.compute()
+        for k in range(2):   # warm-up
+            c.sample_reads(*self.samples[(k + 1) % N_ROTATE])
+            c.sample_fetch(self.out[0], self.E[0])
+            c.compute()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            c.sample_reads(*self.samples[k % N_ROTATE])
+            c.sample_fetch(self.out[0], self.E[0])
+            c.compute()
+        c.sample_fetch(self.out[0], self.E[0])
+        return (time.perf_counter() - t0) / steps
+
     def kernel_only(self, steps, rotate=True):
         """The kernels alone on resident tuples (what round 1 reported as `value`): compute + sync per step."""
         for c in self.ctxs:
@@ -517,6 +536,11 @@ def main():
         h2d["frac"] = round(h2d["achieved"] / PCIE_PEAK_GBS, 4)
         out["step_bound"] = h2d
 
+    if rank == 0 and not dist_on:
+        sc = leg.single_context(max(args.steps, 12))
+        out["single_context"] = dict(ms_per_step=round(1e3 * sc, 4), value=round(leg.total_iv / sc, 1),
+                                     note="one context, pipelined: conga_sample_reads(k + 1) -> conga_sample_fetch(k) -> "
+                                          "conga_chrom_compute(k + 1); the hand-over is double-buffered inside the context")
     if rank == 0:
         ko_rot = leg.kernel_only(max(args.steps, 12), rotate=True)
         ko_one = leg.kernel_only(max(args.steps, 12), rotate=False)

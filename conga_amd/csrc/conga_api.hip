@@ -171,6 +171,18 @@ struct conga_ctx {
 	bool host_results_valid = false;    // h_results holds the records of the last compute (CONGA_FLAG_RESULTS_ON_DEVICE: not until fetched)
 
 	bool computed = false;
+	// conga_sample_reads() is double-buffered: the next sample's tuples go into the OTHER pair of buffers on stream2 while the
+	// last compute (which reads d_pos / d_mapq) and its fetch are still under way.  `computed_reads` is what that compute ran
+	// on (per chromosome: first tuple, count), for the fetch's statistics and for settle_wrap_risk's second compute.
+	DevBuf d_pos_alt, d_mapq_alt;
+	hipEvent_t ev_reads = nullptr;     // the copies of the last conga_sample_reads (on stream2)
+	hipEvent_t ev_pair[2] = {};        // the last compute that read buffer pair 0 / 1 (on stream)
+	bool used_recorded[2] = {false, false};
+	int pos_buf = 0;                   // which pair d_pos / d_mapq currently are
+	bool reads_on_stream2 = false;     // the next compute has to wait for ev_reads
+	bool reads_ahead = false;          // the HostSlots describe a newer sample than the one last computed
+	std::vector<std::pair<int64_t, int64_t>> computed_reads;
+	int64_t computed_total = 0;
 	hipGraphExec_t graph_exec = nullptr; // the captured step; dropped whenever the layout changes
 	bool graph_dense = false;
 	int computes_on_layout = 0;          // computes since the layout last changed
@@ -1425,6 +1437,9 @@ conga_ctx *conga_create(int device, const conga_opts *opts, int *status)
 			|| hipEventCreateWithFlags(&ctx->ev_head, hipEventDisableTiming) != hipSuccess)
 		return bail(CONGA_ERR_HIP);
 	if (hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_low) != hipSuccess
+			|| hipEventCreateWithFlags(&ctx->ev_reads, hipEventDisableTiming) != hipSuccess
+			|| hipEventCreateWithFlags(&ctx->ev_pair[0], hipEventDisableTiming) != hipSuccess
+			|| hipEventCreateWithFlags(&ctx->ev_pair[1], hipEventDisableTiming) != hipSuccess
 			|| hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess
 			|| hipEventCreateWithFlags(&ctx->ev_fork2, hipEventDisableTiming) != hipSuccess
 			|| hipEventCreateWithFlags(&ctx->ev_counted, hipEventDisableTiming) != hipSuccess
@@ -1456,6 +1471,9 @@ void conga_destroy(conga_ctx *ctx)
 		(void) hipStreamSynchronize(ctx->stream2);
 		(void) hipStreamDestroy(ctx->stream2);
 	}
+	for (hipEvent_t e : {ctx->ev_reads, ctx->ev_pair[0], ctx->ev_pair[1]})
+		if (e)
+			(void) hipEventDestroy(e);
 	if (ctx->ev_fork)
 		(void) hipEventDestroy(ctx->ev_fork);
 	if (ctx->ev_fork2)
@@ -1465,7 +1483,7 @@ void conga_destroy(conga_ctx *ctx)
 	if (ctx->ev_join)
 		(void) hipEventDestroy(ctx->ev_join);
 	// (d_slots and d_block_home are views into d_head)
-	DevBuf *bufs[] = {&ctx->d_pos, &ctx->d_mapq, &ctx->d_tile_start, &ctx->d_small_scratch, &ctx->d_item_slot,
+	DevBuf *bufs[] = {&ctx->d_pos, &ctx->d_mapq, &ctx->d_pos_alt, &ctx->d_mapq_alt, &ctx->d_tile_start, &ctx->d_small_scratch, &ctx->d_item_slot,
 			&ctx->d_head, &ctx->d_item_row0, &ctx->d_item_row1, &ctx->d_item_rt_off, &ctx->d_item_lo, &ctx->d_rd, &ctx->d_gc_hist, &ctx->d_gc_like,
 			&ctx->d_small, &ctx->d_map, &ctx->d_winner, &ctx->d_map_start, &ctx->d_map_end,
 			&ctx->d_map_val, &ctx->d_iv_start, &ctx->d_iv_end, &ctx->d_iv_type, &ctx->d_iv_slot, &ctx->d_iv_has_map,
@@ -1690,7 +1708,7 @@ void conga_host_free(conga_ctx *ctx, void *p)
 namespace {
 
 // Forget the reads of every chromosome; chromosomes, GC arrays, intervals, tracks and the device layout stay.
-int drop_reads(conga_ctx *ctx, const char *who)
+int drop_reads(conga_ctx *ctx, const char *who, bool keep_computed = false)
 {
 	if (ctx->slots.empty())
 		return fail(ctx, CONGA_ERR_INVALID, std::string(who) + ": no chromosome open");
@@ -1713,9 +1731,14 @@ int drop_reads(conga_ctx *ctx, const char *who)
 	ctx->sr_staged = false;
 	ctx->bz_keep_bytes = 0;
 	ctx->wrap_risk = false;
-	ctx->depth_resident = false;
 	ctx->sample_dirty = true;
-	ctx->computed = false;
+	if (keep_computed && ctx->computed)
+		ctx->reads_ahead = true; // (the records of the last compute stay fetchable: conga_sample_reads has left its inputs alone)
+	else {
+		ctx->depth_resident = false;
+		ctx->computed = false;
+		ctx->reads_ahead = false;
+	}
 	return CONGA_OK;
 }
 
@@ -1764,19 +1787,36 @@ int conga_sample_reads(conga_ctx *ctx, const int32_t *pos, const uint8_t *mapq, 
 	if (total >= 0xFFFFFFF0ull)
 		return fail(ctx, CONGA_ERR_RANGE, "conga_sample_reads: more than 2^32 reads in one context");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
-	TRY(drop_reads(ctx, "conga_sample_reads"));
+	if (ctx->reads_ahead) // (two samples handed over without a compute in between: the first one's copy must not be overtaken)
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
+	const bool ahead = ctx->computed && !ctx->reads_ahead && ctx->n_sr_total == 0 && ctx->bz_keep_bytes == 0;
+	TRY(drop_reads(ctx, "conga_sample_reads", ahead));
 	ctx->read_target = -1;
+	if (ahead) {
+		// The last compute (and the fetch that may still follow it) reads d_pos / d_mapq: this sample's tuples go into the
+		// other pair, on stream2, behind the last compute that read THAT pair.  A caller that hands over sample k + 1, fetches
+		// sample k and then computes sample k + 1 has the copy running beside the kernels and the fetch with one context.
+		std::swap(ctx->d_pos, ctx->d_pos_alt);
+		std::swap(ctx->d_mapq, ctx->d_mapq_alt);
+		ctx->pos_buf ^= 1;
+	}
 	if (total * 4 > ctx->d_pos.cap || total > ctx->d_mapq.cap) {
 		const size_t want = std::max((size_t) total + (size_t) total / 8, (size_t) 1 << 22); // (samples of a cohort differ a little)
 		TRY(ensure(ctx, ctx->d_pos, want * 4));
 		TRY(ensure(ctx, ctx->d_mapq, want));
 	}
 	if (total) {
-		// Straight from the caller's arrays: from pinned memory (conga_host_alloc) this is one DMA each at the link's
-		// rate, ordered on the context's stream behind whatever still reads the previous sample's tuples.
-		HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pos.p, pos, (size_t) total * 4, hipMemcpyHostToDevice, ctx->stream));
+		// Straight from the caller's arrays: from pinned memory (conga_host_alloc) this is one DMA each at the link's rate.
+		hipStream_t cs = ahead ? ctx->stream2 : ctx->stream;
+		if (ahead && ctx->used_recorded[ctx->pos_buf])
+			HIP_TRY(ctx, hipStreamWaitEvent(cs, ctx->ev_pair[ctx->pos_buf], 0));
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pos.p, pos, (size_t) total * 4, hipMemcpyHostToDevice, cs));
 		if (need_mapq)
-			HIP_TRY(ctx, hipMemcpyAsync(ctx->d_mapq.p, mapq, (size_t) total, hipMemcpyHostToDevice, ctx->stream));
+			HIP_TRY(ctx, hipMemcpyAsync(ctx->d_mapq.p, mapq, (size_t) total, hipMemcpyHostToDevice, cs));
+		if (ahead) {
+			HIP_TRY(ctx, hipEventRecord(ctx->ev_reads, cs));
+			ctx->reads_on_stream2 = true;
+		}
 	}
 	for (int c = 0; c < n_chrom; c++)
 		ctx->slots[(size_t) c].n_reads = (int64_t) (chrom_off[c + 1] - chrom_off[c]);
@@ -2319,6 +2359,10 @@ int conga_chrom_compute(conga_ctx *ctx)
 	// on.  Off by default: on ROCm 7.2 / MI355X the replay was measured no faster than the two-stream launch sequence
 	// (0.275 vs 0.268 ms per genome), and instantiation costs tens of milliseconds.
 	hipStream_t st = ctx->stream;
+	if (ctx->reads_on_stream2) { // the tuples came up on stream2 (conga_sample_reads beside the previous compute)
+		HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_reads, 0));
+		ctx->reads_on_stream2 = false;
+	}
 	ctx->computes_on_layout++;
 	const bool use_graph = (ctx->opts.flags & CONGA_FLAG_PROFILE) == 0 && getenv("CONGA_GRAPH")
 			&& (ctx->graph_exec || ctx->computes_on_layout >= 3);
@@ -2350,6 +2394,13 @@ int conga_chrom_compute(conga_ctx *ctx)
 	ctx->depth_resident = dense;
 	ctx->small_cur = ctx->small_cur_next; // the arena the chain launch has just cleared, if it did
 	HIP_TRY(ctx, hipEventRecord(ctx->ev_done, st));
+	HIP_TRY(ctx, hipEventRecord(ctx->ev_pair[ctx->pos_buf], st));
+	ctx->used_recorded[ctx->pos_buf] = true;
+	ctx->reads_ahead = false;
+	ctx->computed_reads.resize(ctx->slots.size());
+	for (size_t c = 0; c < ctx->slots.size(); c++)
+		ctx->computed_reads[c] = std::make_pair(ctx->slots[c].read_off, ctx->slots[c].n_reads);
+	ctx->computed_total = ctx->n_reads_total;
 	HIP_TRY(ctx, hipGetLastError());
 	ctx->computed = true;
 	return CONGA_OK;
@@ -2701,10 +2752,46 @@ int settle_wrap_risk(conga_ctx *ctx)
 		risk = risk || (ctx->h_small[s].status & kStatusWrapRisk) != 0;
 	if (!risk)
 		return CONGA_OK;
+	if (!ctx->reads_ahead) {
+		ctx->wrap_risk = true;
+		TRY(conga_chrom_compute(ctx));
+		HIP_TRY(ctx, hipEventSynchronize(ctx->ev_done));
+		return CONGA_OK;
+	}
+	// The next sample's tuples are already on their way (conga_sample_reads beside this compute): the sample that has to be
+	// computed again lies in the other pair of buffers, described by computed_reads.  Swap it in, compute, swap back; the
+	// copy under way writes the pair that is not touched here.
+	std::vector<std::pair<int64_t, int64_t>> next_reads(ctx->slots.size());
+	for (size_t c = 0; c < ctx->slots.size(); c++) {
+		next_reads[c] = std::make_pair(ctx->slots[c].read_off, ctx->slots[c].n_reads);
+		ctx->slots[c].read_off = ctx->computed_reads[c].first;
+		ctx->slots[c].n_reads = ctx->computed_reads[c].second;
+	}
+	const int64_t next_total = ctx->n_reads_total;
+	const bool pending_copy = ctx->reads_on_stream2;
+	ctx->n_reads_total = ctx->computed_total;
+	std::swap(ctx->d_pos, ctx->d_pos_alt);
+	std::swap(ctx->d_mapq, ctx->d_mapq_alt);
+	ctx->pos_buf ^= 1;
+	ctx->reads_on_stream2 = false; // (this compute reads the OLD pair: nothing to wait for)
 	ctx->wrap_risk = true;
-	TRY(conga_chrom_compute(ctx));
-	HIP_TRY(ctx, hipEventSynchronize(ctx->ev_done));
-	return CONGA_OK;
+	ctx->sample_dirty = true;
+	int rc = conga_chrom_compute(ctx);
+	if (rc == CONGA_OK && hipEventSynchronize(ctx->ev_done) != hipSuccess)
+		rc = fail(ctx, CONGA_ERR_HIP, "settle_wrap_risk: waiting for the second compute failed");
+	for (size_t c = 0; c < ctx->slots.size(); c++) {
+		ctx->slots[c].read_off = next_reads[c].first;
+		ctx->slots[c].n_reads = next_reads[c].second;
+	}
+	ctx->n_reads_total = next_total;
+	std::swap(ctx->d_pos, ctx->d_pos_alt);
+	std::swap(ctx->d_mapq, ctx->d_mapq_alt);
+	ctx->pos_buf ^= 1;
+	ctx->reads_on_stream2 = pending_copy;
+	ctx->wrap_risk = false; // (the next sample's own guard runs with its compute)
+	ctx->sample_dirty = true;
+	ctx->reads_ahead = true;
+	return rc;
 }
 
 } // namespace
@@ -2753,7 +2840,7 @@ int conga_chrom_fetch(conga_ctx *ctx, conga_result *dels, conga_result *dups, fl
 		memcpy(expected_rd, sb.E, kGcBins * sizeof(float));
 	if (stats) {
 		memset(stats, 0, sizeof *stats);
-		stats->reads_committed = h->n_reads;
+		stats->reads_committed = (size_t) ctx->cur < ctx->computed_reads.size() ? ctx->computed_reads[(size_t) ctx->cur].second : h->n_reads;
 		stats->reads_counted = (int64_t) sb.counters[CNT_COUNTED];
 		stats->reads_out_of_range = (int64_t) sb.counters[CNT_OUT_OF_RANGE];
 		long long total = 0;
@@ -2865,6 +2952,8 @@ int conga_sync(conga_ctx *ctx)
 		return CONGA_ERR_INVALID;
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	if (ctx->reads_on_stream2)
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2)); // (the copies of a conga_sample_reads that no compute has taken up yet)
 	TRY(settle_wrap_risk(ctx));
 	return CONGA_OK;
 }
@@ -2874,6 +2963,8 @@ int conga_copy_read_depth(conga_ctx *ctx, int16_t *out, int64_t n)
 	HostSlot *h = ctx ? current(ctx) : nullptr;
 	if (!ctx || !out || !ctx->computed || !h || n > h->L || n < 0)
 		return CONGA_ERR_INVALID;
+	if (ctx->reads_ahead)
+		return fail(ctx, CONGA_ERR_INVALID, "conga_copy_read_depth: the reads have been replaced since the compute");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	if (!ctx->depth_resident) {
 		// tuple-space compute: build read_depth[] now; its by-products go to a scratch block, not into the results

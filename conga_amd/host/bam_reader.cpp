@@ -570,6 +570,8 @@ public:
 		for (const device_target &t : targets) {
 			if (t.tid < 0 || t.tid >= (int) linear_.size() || t.chrom_len <= 0 || t.chrom_len > INT32_MAX)
 				return false;
+			if (ref_doubt_[(size_t) t.tid])
+				return false; // (the host decoders scan for this target; so must the run that would have decoded on the GPU)
 			if (ref_beg_[(size_t) t.tid] == 0)
 				continue; // no records: no start points, it gets no reads
 			any = true;
@@ -590,7 +592,7 @@ public:
 		uint64_t stop = (uint64_t) st.st_size;
 		if (c_end && c_end + 65536 + 18 < stop)
 			stop = c_end + 65536 + 18; // enough for the whole block that starts at c_end
-		uint64_t max_piece = 6ull << 30;
+		uint64_t max_piece = 32ull << 30; // (a 5x genome with sequences is 13 GB of file and 27 GB inflated, resident together: 288 GB of HBM)
 		if (const char *e = getenv("CONGA_GPU_BAM_MAX_MB"))
 			max_piece = (uint64_t) (atof(e) * 1048576.0); // (fractions allowed: tests)
 		if (stop - c_lo < min_piece_bytes || stop - c_lo > max_piece)
@@ -949,10 +951,12 @@ private:
 		int32_t n_ref;
 		std::vector<uint64_t> beg, fin; // per reference: smallest chunk begin, largest chunk end
 		std::vector<std::vector<uint64_t>> lin; // per reference: smallest virtual offset of a record overlapping each 16 kb window
+		std::vector<uint8_t> doubt;     // per reference: the index names records but its two views of where they begin differ
 		bool ok = fread(magic, 1, 4, f) == 4 && memcmp(magic, "BAI\1", 4) == 0 && fread(&n_ref, 4, 1, f) == 1 && n_ref >= 0;
 		for (int r = 0; ok && r < n_ref; r++) {
 			int32_t n_bin;
 			uint64_t first = 0, last = 0;
+			bool any_chunk = false;
 			ok = fread(&n_bin, 4, 1, f) == 1 && n_bin >= 0;
 			for (int b = 0; ok && b < n_bin; b++) {
 				uint32_t bin;
@@ -961,7 +965,9 @@ private:
 				for (int k = 0; ok && k < n_chunk; k++) {
 					uint64_t ce[2];
 					ok = fread(ce, 8, 2, f) == 2;
-					if (ok && bin != 37450 && (first == 0 || ce[0] < first))
+					if (ok && bin != 37450)
+						any_chunk = true;
+					if (ok && bin != 37450 && ce[0] != 0 && (first == 0 || ce[0] < first))
 						first = ce[0];
 					if (ok && bin != 37450 && ce[1] > last)
 						last = ce[1];
@@ -971,6 +977,18 @@ private:
 			ok = ok && fread(&n_intv, 4, 1, f) == 1 && n_intv >= 0 && n_intv <= (1 << 17);
 			std::vector<uint64_t> iv((size_t) (ok ? n_intv : 0));
 			ok = ok && (iv.empty() || fread(iv.data(), 8, iv.size(), f) == iv.size());
+			// Where a target's records begin is in the index twice: the smallest chunk begin of its bins and the first entry of its
+			// linear index (the first record overlaps its own window).  A whole index agrees with itself; one that does not
+			// (tools/bam_fuzz.py index: a zeroed chunk made the decode on the GPU take the target for empty while the sequential
+			// reader scanned forward and found its reads) is not used for this target: every decoder then scans for it.
+			uint64_t first_lin = 0;
+			for (size_t w = 0; w < iv.size() && first_lin == 0; w++)
+				first_lin = iv[w];
+			const bool names_records = any_chunk || first_lin != 0;
+			const bool in_doubt = ok && names_records && (first == 0 || first != first_lin);
+			if (in_doubt)
+				first = 0;
+			doubt.push_back(in_doubt ? 1 : 0);
 			beg.push_back(first);
 			fin.push_back(last);
 			lin.push_back(std::move(iv));
@@ -979,6 +997,7 @@ private:
 		if (ok && (int) beg.size() == n_targets()) {
 			ref_beg_ = beg;
 			ref_end_ = fin;
+			ref_doubt_ = doubt;
 			linear_ = lin;
 			bai_path_ = path;
 		}
@@ -990,6 +1009,7 @@ private:
 	std::vector<std::string> names_;
 	std::vector<uint64_t> ref_beg_, ref_end_;
 	std::vector<std::vector<uint64_t>> linear_;
+	std::vector<uint8_t> ref_doubt_; // targets whose index entries contradict each other: scanned for, never planned
 	std::vector<int32_t> pos_;
 	std::vector<uint8_t> mapq_;
 	int tid_ = -1, last_ref_ = -2;

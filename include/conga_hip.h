@@ -216,10 +216,13 @@ int conga_intervals(conga_ctx *ctx, char type, const int32_t *start, const int32
  * conga_sample_reads: pos / mapq hold the sample's (bam1_core_t.pos, bam1_core_t.qual) tuples, chromosome 0's first,
  * then chromosome 1's, ... each in BAM order; chromosome c owns [chrom_off[c], chrom_off[c + 1]) (n_chrom + 1 entries,
  * n_chrom == conga_chrom_count()).  With mq_threshold < 0 (the reference's default: every read counts) mapq is never read and
- * may be NULL -- 4 bytes per read cross the PCIe link instead of 5.  The copies into HBM are enqueued on the context's stream and the call returns: the
- * arrays must stay unchanged until the next conga_chrom_fetch / conga_sample_fetch / conga_sync of this context has
- * returned.  From pinned memory (conga_host_alloc) the copy runs at the PCIe link's rate with no staging copy; pageable
- * memory works, slower.  The tuple-space formulation's guard against a wrapping `short` depth counter runs on the
+ * may be NULL -- 4 bytes per read cross the PCIe link instead of 5.  The copies into HBM are enqueued and the call returns: the
+ * arrays must stay unchanged until a conga_chrom_fetch / conga_sample_fetch / conga_sync that FOLLOWS the next
+ * conga_chrom_compute of this context has returned (or a conga_sync right away).  From pinned memory (conga_host_alloc) the
+ * copy runs at the PCIe link's rate with no staging copy; pageable memory works, slower.
+ * The hand-over is double-buffered: called behind a conga_chrom_compute, it leaves that compute's inputs and results alone --
+ * the tuples go into a second pair of buffers on a stream of their own -- so that ONE context pipelines a cohort:
+ *     conga_sample_reads(k + 1);  conga_sample_fetch(k);  conga_chrom_compute();      (the copy beside kernels and fetch)  The tuple-space formulation's guard against a wrapping `short` depth counter runs on the
  * device for such reads (see CONGA_FLAG_MATERIALIZE_DEPTH): a sample that needs the dense kernels is recomputed with
  * them inside the fetch (or conga_sync) that follows -- a caller that reads the records on the device
  * (CONGA_FLAG_RESULTS_ON_DEVICE) calls conga_sync() first.

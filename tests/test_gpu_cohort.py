@@ -190,6 +190,39 @@ def test_sample_with_a_pile_up_wraps_like_a_short(capi, oracle, formulation):
         check_against_oracle(oracle, chroms, reads2, recs2, E2, False)
 
 
+def test_next_sample_handed_over_beside_the_compute_one_context(capi, oracle, formulation):
+    """conga_sample_reads is double-buffered: sample k + 1 is handed over while sample k is computed and before it is fetched --
+    its copy runs on a stream of its own into the other pair of buffers -- and every sample's records are still its own.
+    One of the samples wraps a `short` (40 000 reads on one base): its fetch computes it again in the dense formulation out of
+    the pair of buffers the NEXT sample's copy is not writing."""
+    chroms = layout(False)
+    samples = [sample_reads_of(chroms, 20 + k, [1.0, 2.0, 0.5, 1.5][k]) for k in range(4)]
+    hot = int(chroms[1][1][3]) + 17
+    p, m = samples[1][1]
+    p = np.sort(np.concatenate([p, np.full(40_000, hot, np.int32)])).astype(np.int32)
+    samples[1][1] = (p, np.full(len(p), 60, np.uint8))
+    with capi.Context(device=0, flags=capi.FLAG_BATCH) as ctx:
+        open_layout(ctx, chroms, False)
+        pinned = [pinned_sample(ctx, r) for r in samples]
+        ctx.sample_reads(*pinned[0])
+        ctx.compute()
+        for k in range(len(samples)):
+            if k + 1 < len(samples):
+                ctx.sample_reads(*pinned[k + 1])      # beside compute k; before fetch k
+            recs, E, st = ctx.sample_fetch(want_stats=True)
+            check_against_oracle(oracle, chroms, samples[k], recs, E, False)
+            assert [s.reads_committed for s in st] == [len(r[0]) for r in samples[k]]
+            assert st[1].depth_materialized == (1 if (k == 1 or formulation == "dense") else 0)
+            if k + 1 < len(samples):
+                ctx.compute()
+        # two samples handed over without a compute in between: the later one counts
+        ctx.sample_reads(*pinned[2])
+        ctx.sample_reads(*pinned[3])
+        ctx.compute()
+        recs, E, _ = ctx.sample_fetch()
+        check_against_oracle(oracle, chroms, samples[3], recs, E, False)
+
+
 # ---- conga_reads_bgzf called in process (the command-line tests run it in fresh subprocesses only) ---------------------
 def bgzf_table(raw):
     """[(data_off, data_len, inflated_len, crc32)] of the non-empty blocks of a BGZF file + their inflated bytes."""

@@ -674,6 +674,11 @@ def test_cli_damaged_bam_records_gpu_and_host_decoders_agree():
     # ... and the container of a deflated BAM: block headers, BSIZE, XLEN, deflate bytes and bits, CRC32, ISIZE, truncation
     r = subprocess.run([sys.executable, tool, "24", "20261005", "container"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "disagreements or crashes 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    # ... and the .bai: bytes, 32- and 64-bit fields overwritten, truncation.  An index whose two views of where a target begins
+    # contradict each other is used by neither decoder for that target (round 2: a zeroed chunk made the GPU plan take a target for
+    # empty while the sequential reader scanned forward and found its reads -- same input, different files, exit 0)
+    r = subprocess.run([sys.executable, tool, "60", "20261006", "index"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "disagreements or crashes 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 @pytest.mark.gpu
