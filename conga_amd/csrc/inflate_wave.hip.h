@@ -87,10 +87,10 @@ struct DistFormat {
 	__device__ static uint32_t pointer_bits(uint32_t ptr) { return ptr & 15u; }
 };
 
-struct WaveLds {
+struct alignas(16) WaveLds {
 	uint16_t lit[kLitCap];
 	uint16_t dist[kDistCap];
-	uint16_t sorted[288 + 32]; // builder: symbols in canonical order (by length, then value)
+	uint16_t sorted[288 + 32]; // builder: symbols in canonical order (by length, then value); symbol loop: the staged starts (64 dwords)
 	uint8_t lens[kMaxLens];    // code lengths of the block being set up (literal/length alphabet, then distances)
 	uint8_t pre[1 << kPreRoot]; // code-length code: [2:0] bits, [7:3] symbol -- 5 + 3 bits are enough for 19 symbols of <= 7 bits
 };
@@ -547,6 +547,202 @@ __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Lu
 	}
 }
 
+// ---- the same loop in two phases (round 3) -----------------------------------------------------------------------------
+// A trip of run_symbols() decodes sixty-four candidate symbols completely -- values, base tables, extra bits, the prefix sum
+// of what they produce, the stores -- for the ~8 that turn out to lie on the chain: the vector unit, which bounds the kernel,
+// spends seven eighths of that on lanes that are dropped.  Here a trip only finds out WHERE symbols start (the look-ups give
+// every candidate its length in bits, the scalar walk follows the chain) and notes the starts' bit positions; once
+// sixty-four are noted -- eight trips or so -- every lane takes ONE real symbol, reads its bits again (eight bytes from the
+// stream, in L1), decodes it for good and the whole wave produces output for sixty-four symbols at once.  Per trip ~60
+// vector instructions instead of 112, per batch ~100 more.
+// Matches: everything stored before a batch is in L2 when it starts (one s_waitcnt per batch, long satisfied); a short match
+// whose source lies in front of the batch's own output is copied by its lane as before; the others -- a match that reaches into
+// the batch's own bytes, a long one, one that repeats itself -- go one after the other behind a wait for the batch's stores.
+__device__ __forceinline__ int run_symbols_batched(Stream &s, const WaveLds &t, const Luts &luts, uint32_t *stage /* LDS, 64 dwords */)
+{
+	const uint32_t lane = lane_id();
+	uint32_t ibit = uni(s.ibit), opos = uni(s.opos), safe_pos = uni(s.safe_pos);
+	const uint32_t end_bit = uni(s.end_bit), out_len = uni(s.out_len);
+	const GWords in32 = s.in32;
+	const GConstBytes in8 = (GConstBytes) s.in32;
+	uint32_t staged = 0; // starts noted and not yet turned into output
+	auto leave = [&](int rc) {
+		s.ibit = ibit;
+		s.opos = opos;
+		s.safe_pos = safe_pos;
+		return rc;
+	};
+	auto load_window = [&](uint32_t dword) {
+		uint32_t w;
+		const GWords at = in32 + dword + lane;
+		asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(at) : "memory");
+		return w;
+	};
+	auto store_pieces = [&](uint64_t v8, uint32_t to, uint32_t n) {
+		const GBytes q = s.out + to;
+		if (n >= 4u) {
+			*(__attribute__((address_space(1))) uint32_t *) q = (uint32_t) v8;
+			*(__attribute__((address_space(1))) uint32_t *) (q + (n - 4u)) = (uint32_t) (v8 >> (8u * (n - 4u)));
+		} else {
+			*(__attribute__((address_space(1))) uint16_t *) q = (uint16_t) v8;
+			q[2] = (uint8_t) (v8 >> 16);
+		}
+	};
+	// phase 2: the staged starts become output.  false: the stream is invalid (more output than the block holds, a match
+	// that reaches in front of the output)
+	auto flush = [&]() -> bool {
+		const uint32_t n = staged;
+		staged = 0;
+		if (n == 0u)
+			return true;
+		wave_sync();
+		const bool have = lane < n;
+		const uint32_t bp = have ? stage[lane] : ibit; // (a bit position inside the stream for the idle lanes too)
+		uint64_t v;
+		{
+			const GConstBytes at = in8 + (bp >> 3);
+			asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(at) : "memory");
+			// (that wait is the batch's wait for everything stored before it as well)
+		}
+		safe_pos = opos;
+		v >>= (bp & 7u); // >= 57 bits of the symbol: 48 are needed
+		const uint32_t lo = (uint32_t) v;
+		const uint32_t e1 = t.lit[lo & ((1u << kLitRoot) - 1u)];
+		const bool sub1 = (e1 & 0xF0u) == LitFormat::kSub;
+		const uint32_t e2 = t.lit[(1u << kLitRoot) + ((e1 >> 8) << 1) + ((lo >> kLitRoot) & ((1u << (e1 & 15u)) - 1u))];
+		const uint32_t e = sub1 ? e2 : e1;
+		const uint32_t n1 = e & 15u, eb = (e >> 4) & 7u;
+		const bool is_len = have && (e & 0x80u) != 0u;
+		const uint32_t r2 = (uint32_t) (v >> (n1 + eb));
+		const uint32_t d1 = t.dist[r2 & ((1u << kDistRoot) - 1u)];
+		const bool subd = (d1 & 0xC000u) == 0x4000u;
+		const uint32_t d2 = t.dist[(1u << kDistRoot) + ((d1 >> 4) & 1023u) + ((r2 >> kDistRoot) & ((1u << (d1 & 15u)) - 1u))];
+		const uint32_t ed = subd ? d2 : d1;
+		const uint32_t lbase = luts.len[(e >> 8) & 31u];
+		const uint32_t dbase = luts.dist[(ed >> 9) & 31u];
+		const uint32_t deb = (ed >> 5) & 15u;
+		const uint32_t dist = dbase + ((r2 >> ((ed & 31u) - deb)) & ((1u << deb) - 1u));
+		const uint32_t produced = !have ? 0u : is_len ? lbase + ((lo >> n1) & ((1u << eb) - 1u)) : 1u;
+		const uint32_t incl = wave_incl_scan(produced);
+		const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
+		if (opos + total > out_len)
+			return false;
+		if (have && !is_len)
+			s.out[opos + incl - 1u] = (uint8_t) (e >> 8);
+		unsigned long long mm = __ballot(is_len);
+		{
+			const uint32_t to_l = opos + incl - produced, src_l = to_l - dist;
+			// (dist <= to_l on its own: see run_symbols)
+			const bool fast = is_len && produced <= 8u && dist >= produced && dist <= to_l && src_l + produced <= safe_pos;
+			const unsigned long long fast_m = __ballot(fast);
+			if (fast_m) {
+				if (fast)
+					store_pieces(load_written_u64_unaligned(s.out + src_l), to_l, produced);
+				mm &= ~fast_m;
+			}
+		}
+		while (mm) {
+			const uint32_t i = (uint32_t) __builtin_ctzll(mm);
+			mm &= mm - 1ull;
+			const uint32_t len = (uint32_t) __builtin_amdgcn_readlane((int) produced, (int) i);
+			const uint32_t d = (uint32_t) __builtin_amdgcn_readlane((int) dist, (int) i);
+			const uint32_t to = opos + (uint32_t) __builtin_amdgcn_readlane((int) incl, (int) i) - len;
+			if (d > to)
+				return false;
+			const uint32_t src = to - d;
+			if (src + (d < len ? d : len) > safe_pos) { // reaches into bytes stored since the last wait
+				asm volatile("" ::: "memory");
+				__builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the stores are acknowledged by L2
+				asm volatile("" ::: "memory");
+				safe_pos = to;
+			}
+			if (d >= len) {
+				for (uint32_t k = lane; k < len; k += 64u)
+					s.out[to + k] = (uint8_t) load_written_u8(s.out + src + k);
+			} else { // the match overlaps itself: it repeats its first d bytes
+				const float inv = 1.0f / (float) d;
+				for (uint32_t k = lane; k < len; k += 64u) {
+					uint32_t q = (uint32_t) ((float) k * inv);
+					int32_t r = (int32_t) (k - q * d);
+					if (r < 0)
+						r += (int32_t) d;
+					else if ((uint32_t) r >= d)
+						r -= (int32_t) d;
+					s.out[to + k] = (uint8_t) load_written_u8(s.out + src + (uint32_t) r);
+				}
+			}
+		}
+		opos += total;
+		return true;
+	};
+	uint32_t d0 = uni(ibit >> 5);
+	uint32_t wreg = load_window(d0);
+	for (;;) {
+		if (ibit > end_bit)
+			return leave(-1);
+		uint32_t dd = (ibit >> 5) - d0;
+		if (dd > 59u) {
+			d0 = ibit >> 5;
+			wreg = load_window(d0);
+			dd = 0;
+		}
+		// phase 1: how long is the symbol that would start at bit ibit + lane
+		const uint32_t b = (ibit & 31u) + lane;
+		const uint32_t at = (dd + (b >> 5)) << 2;
+		const uint32_t w0 = (uint32_t) __builtin_amdgcn_ds_bpermute((int) at, (int) wreg);
+		const uint32_t w1 = (uint32_t) __builtin_amdgcn_ds_bpermute((int) at + 4, (int) wreg);
+		const uint32_t w2 = (uint32_t) __builtin_amdgcn_ds_bpermute((int) at + 8, (int) wreg);
+		const uint32_t sh = b & 31u;
+		const uint32_t lo = alignbit(w1, w0, sh), hi = alignbit(w2, w1, sh);
+		const uint32_t e1 = t.lit[lo & ((1u << kLitRoot) - 1u)];
+		const bool sub1 = (e1 & 0xF0u) == LitFormat::kSub;
+		const uint32_t e2 = t.lit[(1u << kLitRoot) + ((e1 >> 8) << 1) + ((lo >> kLitRoot) & ((1u << (e1 & 15u)) - 1u))];
+		const uint32_t e = sub1 ? e2 : e1;
+		const uint32_t n1 = e & 15u, eb = (e >> 4) & 7u;
+		const bool is_match = (e & 0x80u) != 0u;
+		const uint32_t r2 = alignbit(hi, lo, n1 + eb);
+		const uint32_t d1 = t.dist[r2 & ((1u << kDistRoot) - 1u)];
+		const bool subd = (d1 & 0xC000u) == 0x4000u;
+		const uint32_t d2 = t.dist[(1u << kDistRoot) + ((d1 >> 4) & 1023u) + ((r2 >> kDistRoot) & ((1u << (d1 & 15u)) - 1u))];
+		const uint32_t ed = subd ? d2 : d1;
+		const unsigned long long is_match_m = __ballot(is_match);
+		const uint32_t bits = is_match ? n1 + eb + (ed & 31u) : n1;
+		const uint32_t nxt = lane + bits;
+		const uint32_t cls = e & 0xF0u;
+		const unsigned long long eob_m = __ballot(cls == LitFormat::kEob), hole_m = __ballot(cls == LitFormat::kHoleTag);
+		unsigned long long chain = 0;
+		{
+			uint32_t cur = 0;
+			do {
+				chain |= 1ull << cur;
+				cur = (uint32_t) __builtin_amdgcn_readlane((int) nxt, (int) cur);
+			} while (cur < 64u);
+		}
+		{
+			const unsigned long long stop = chain & (eob_m | hole_m);
+			if (stop)
+				chain &= (2ull << __builtin_ctzll(stop)) - 1ull;
+		}
+		if ((chain & hole_m) | (chain & is_match_m & __ballot((ed & 0x8000u) != 0u)))
+			return leave(-1);
+		const bool ends = (chain & eob_m) != 0ull;
+		const unsigned long long sym_m = chain & ~eob_m; // the starts that produce output
+		const uint32_t n_new = (uint32_t) __popcll(sym_m);
+		if (staged + n_new > 64u && !flush())
+			return leave(-1);
+		if (__builtin_amdgcn_inverse_ballot_w64(sym_m))
+			stage[staged + __builtin_amdgcn_mbcnt_hi((uint32_t) (sym_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) sym_m, 0u))] = ibit + lane;
+		staged += n_new;
+		const uint32_t last = 63u - (uint32_t) __builtin_clzll(chain);
+		ibit += (uint32_t) __builtin_amdgcn_readlane((int) nxt, (int) last);
+		if (ends) {
+			if (!flush())
+				return leave(-1);
+			return leave(ibit > end_bit ? -1 : 0);
+		}
+	}
+}
+
 #ifndef IW_PROF
 // The symbol loop as a function of its own: its registers are then allocated for the loop alone, not together with
 // everything a block's set-up keeps alive around it.  Arguments and results travel in registers; the tables are named by
@@ -575,6 +771,29 @@ __device__ __attribute__((noinline)) SymbolsOut run_symbols_call(GWords in32, GB
 	const Luts &luts = *(const Luts *) (LdsLuts) (uintptr_t) uni(luts_at);
 	SymbolsOut o;
 	o.rc = run_symbols(s, t, luts);
+	o.ibit = s.ibit;
+	o.opos = s.opos;
+	o.safe_pos = s.safe_pos;
+	return o;
+}
+
+__device__ __attribute__((noinline)) SymbolsOut run_symbols_batched_call(GWords in32, GBytes out, uint32_t ibit, uint32_t end_bit, uint32_t opos,
+		uint32_t out_len, uint32_t safe_pos, uint32_t tables_at, uint32_t luts_at)
+{
+	Stream s;
+	const uint64_t in_u = (uint64_t) uni((uint32_t) (uintptr_t) in32) | ((uint64_t) uni((uint32_t) ((uintptr_t) in32 >> 32)) << 32);
+	const uint64_t out_u = (uint64_t) uni((uint32_t) (uintptr_t) out) | ((uint64_t) uni((uint32_t) ((uintptr_t) out >> 32)) << 32);
+	s.in32 = (GWords) in_u;
+	s.out = (GBytes) out_u;
+	s.ibit = ibit;
+	s.end_bit = end_bit;
+	s.opos = opos;
+	s.out_len = out_len;
+	s.safe_pos = safe_pos;
+	WaveLds &t = *(WaveLds *) (__attribute__((address_space(3))) WaveLds *) (uintptr_t) uni(tables_at);
+	const Luts &luts = *(const Luts *) (LdsLuts) (uintptr_t) uni(luts_at);
+	SymbolsOut o;
+	o.rc = run_symbols_batched(s, t, luts, reinterpret_cast<uint32_t *>(t.sorted));
 	o.ibit = s.ibit;
 	o.opos = s.opos;
 	o.safe_pos = s.safe_pos;
@@ -636,8 +855,8 @@ __device__ __forceinline__ uint32_t wave_crc32(const uint8_t *out, uint32_t n, c
 
 enum { kStatusOk = 0, kStatusRefused = 1, kStatusCrc = 2 };
 
-// One whole BGZF block (a raw deflate stream of one or more deflate blocks) by one wave.
-__device__ __forceinline__ int inflate_block(WaveLds &t, const Luts &luts, const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len
+// One whole BGZF block (a raw deflate stream of one or more deflate blocks) by one wave.  BATCHED: run_symbols_batched.
+template <bool BATCHED> __device__ __forceinline__ int inflate_block(WaveLds &t, const Luts &luts, const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len
 #ifdef IW_PROF
 		, unsigned long long *prof
 #endif
@@ -802,7 +1021,9 @@ __device__ __forceinline__ int inflate_block(WaveLds &t, const Luts &luts, const
 				return kStatusRefused;
 #else
 			{
-				const SymbolsOut o = run_symbols_call(s.in32, s.out, s.ibit, s.end_bit, s.opos, s.out_len, s.safe_pos,
+				const SymbolsOut o = BATCHED ? run_symbols_batched_call(s.in32, s.out, s.ibit, s.end_bit, s.opos, s.out_len, s.safe_pos,
+						(uint32_t) (uintptr_t) (LdsTables) &t, (uint32_t) (uintptr_t) (LdsLuts) &luts)
+						: run_symbols_call(s.in32, s.out, s.ibit, s.end_bit, s.opos, s.out_len, s.safe_pos,
 						(uint32_t) (uintptr_t) (LdsTables) &t, (uint32_t) (uintptr_t) (LdsLuts) &luts);
 				s.ibit = o.ibit;
 				s.opos = o.opos;
@@ -823,7 +1044,7 @@ __device__ __forceinline__ int inflate_block(WaveLds &t, const Luts &luts, const
 constexpr int kWavesPerGroup = 4;
 
 // status[b]: kStatusOk / kStatusRefused / kStatusCrc.  Waves take blocks round robin.
-__global__ __launch_bounds__(64 * kWavesPerGroup, 8) void bgzf_inflate_wave_kernel(uint32_t n_blocks, const uint8_t *__restrict__ bytes,
+template <bool BATCHED> __global__ __launch_bounds__(64 * kWavesPerGroup, 8) void bgzf_inflate_wave_kernel(uint32_t n_blocks, const uint8_t *__restrict__ bytes,
 		const conga_bgzf_block *__restrict__ blocks, const uint64_t *__restrict__ out_off, uint8_t *out,
 		const uint32_t *__restrict__ crc_table, const uint32_t *__restrict__ x2n, uint8_t *__restrict__ status)
 {
@@ -845,10 +1066,10 @@ __global__ __launch_bounds__(64 * kWavesPerGroup, 8) void bgzf_inflate_wave_kern
 		uint8_t *dst = out + out_off[b];
 #ifdef IW_PROF
 		unsigned long long prof[P_N] = {};
-		int st = inflate_block(lds[wave], s_luts, bytes + bl.data_off, bl.data_len, dst, bl.inflated_len, prof);
+		int st = inflate_block<false>(lds[wave], s_luts, bytes + bl.data_off, bl.data_len, dst, bl.inflated_len, prof);
 		IW_T0();
 #else
-		int st = inflate_block(lds[wave], s_luts, bytes + bl.data_off, bl.data_len, dst, bl.inflated_len);
+		int st = inflate_block<BATCHED>(lds[wave], s_luts, bytes + bl.data_off, bl.data_len, dst, bl.inflated_len);
 #endif
 		if (st == kStatusOk) {
 			asm volatile("" ::: "memory");

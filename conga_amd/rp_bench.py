@@ -231,6 +231,8 @@ def leg(args, env):
     try:
         if not (os.path.exists(e2e_bench.CONGA) and os.path.exists(e2e_bench.BAMWRITE)):
             raise OSError("conga / tools/bamwrite are not built")
+        if not getattr(args, "rp_cli", True):
+            raise OSError("--no-cli")
         half = (READ_LEN + 1) // 2
         bam_in = []
         for ch in chroms:

@@ -92,7 +92,7 @@ int main(int argc, char **argv)
 #endif
 		const unsigned groups = (unsigned) std::min<size_t>((n + 3) / 4, 256 * 8);
 		CHECK(hipEventRecord(e0));
-		hipLaunchKernelGGL(conga::iw::bgzf_inflate_wave_kernel, dim3(groups), dim3(256), 0, 0, n, d_in, d_blocks, d_off, d_out, d_crc, d_x2n, d_status);
+		hipLaunchKernelGGL(conga::iw::bgzf_inflate_wave_kernel<false>, dim3(groups), dim3(256), 0, 0, n, d_in, d_blocks, d_off, d_out, d_crc, d_x2n, d_status);
 		CHECK(hipEventRecord(e1));
 		CHECK(hipEventSynchronize(e1));
 		float ms;

@@ -12,6 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rp-chroms", default="20,21,22")
 ap.add_argument("--chroms", default="")
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--no-cli", dest="rp_cli", action="store_false", help="the C-ABI part only (no BAM written, no `conga` runs): for profiler passes")
 a = ap.parse_args()
 out, _ = rp_bench.leg(a, dict(local_rank=0))
 print(json.dumps(out))
