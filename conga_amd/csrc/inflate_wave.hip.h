@@ -609,14 +609,14 @@ __device__ __forceinline__ int run_symbols_batched(Stream &s, const WaveLds &t, 
 		const uint32_t lo = (uint32_t) v;
 		const uint32_t e1 = t.lit[lo & ((1u << kLitRoot) - 1u)];
 		const bool sub1 = (e1 & 0xF0u) == LitFormat::kSub;
-		const uint32_t e2 = t.lit[(1u << kLitRoot) + ((e1 >> 8) << 1) + ((lo >> kLitRoot) & ((1u << (e1 & 15u)) - 1u))];
+		const uint32_t e2 = t.lit[(1u << kLitRoot) + ((e1 >> 8) << 1) + __builtin_amdgcn_ubfe(lo, (uint32_t) kLitRoot, e1 & 15u)];
 		const uint32_t e = sub1 ? e2 : e1;
 		const uint32_t n1 = e & 15u, eb = (e >> 4) & 7u;
 		const bool is_len = have && (e & 0x80u) != 0u;
 		const uint32_t r2 = (uint32_t) (v >> (n1 + eb));
 		const uint32_t d1 = t.dist[r2 & ((1u << kDistRoot) - 1u)];
 		const bool subd = (d1 & 0xC000u) == 0x4000u;
-		const uint32_t d2 = t.dist[(1u << kDistRoot) + ((d1 >> 4) & 1023u) + ((r2 >> kDistRoot) & ((1u << (d1 & 15u)) - 1u))];
+		const uint32_t d2 = t.dist[(1u << kDistRoot) + ((d1 >> 4) & 1023u) + __builtin_amdgcn_ubfe(r2, (uint32_t) kDistRoot, d1 & 15u)];
 		const uint32_t ed = subd ? d2 : d1;
 		const uint32_t lbase = luts.len[(e >> 8) & 31u];
 		const uint32_t dbase = luts.dist[(ed >> 9) & 31u];
@@ -625,7 +625,8 @@ __device__ __forceinline__ int run_symbols_batched(Stream &s, const WaveLds &t, 
 		const uint32_t produced = !have ? 0u : is_len ? lbase + ((lo >> n1) & ((1u << eb) - 1u)) : 1u;
 		const uint32_t incl = wave_incl_scan(produced);
 		const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
-		if (opos + total > out_len)
+		// more output than the block holds; a length whose distance code is a hole (asked here, of real symbols only)
+		if (opos + total > out_len || __ballot(is_len && (ed & 0x8000u) != 0u) != 0ull)
 			return false;
 		if (have && !is_len)
 			s.out[opos + incl - 1u] = (uint8_t) (e >> 8);
@@ -696,20 +697,20 @@ __device__ __forceinline__ int run_symbols_batched(Stream &s, const WaveLds &t, 
 		const uint32_t lo = alignbit(w1, w0, sh), hi = alignbit(w2, w1, sh);
 		const uint32_t e1 = t.lit[lo & ((1u << kLitRoot) - 1u)];
 		const bool sub1 = (e1 & 0xF0u) == LitFormat::kSub;
-		const uint32_t e2 = t.lit[(1u << kLitRoot) + ((e1 >> 8) << 1) + ((lo >> kLitRoot) & ((1u << (e1 & 15u)) - 1u))];
+		const uint32_t e2 = t.lit[(1u << kLitRoot) + ((e1 >> 8) << 1) + __builtin_amdgcn_ubfe(lo, (uint32_t) kLitRoot, e1 & 15u)];
 		const uint32_t e = sub1 ? e2 : e1;
 		const uint32_t n1 = e & 15u, eb = (e >> 4) & 7u;
 		const bool is_match = (e & 0x80u) != 0u;
 		const uint32_t r2 = alignbit(hi, lo, n1 + eb);
 		const uint32_t d1 = t.dist[r2 & ((1u << kDistRoot) - 1u)];
 		const bool subd = (d1 & 0xC000u) == 0x4000u;
-		const uint32_t d2 = t.dist[(1u << kDistRoot) + ((d1 >> 4) & 1023u) + ((r2 >> kDistRoot) & ((1u << (d1 & 15u)) - 1u))];
+		const uint32_t d2 = t.dist[(1u << kDistRoot) + ((d1 >> 4) & 1023u) + __builtin_amdgcn_ubfe(r2, (uint32_t) kDistRoot, d1 & 15u)];
 		const uint32_t ed = subd ? d2 : d1;
-		const unsigned long long is_match_m = __ballot(is_match);
 		const uint32_t bits = is_match ? n1 + eb + (ed & 31u) : n1;
-		const uint32_t nxt = lane + bits;
-		const uint32_t cls = e & 0xF0u;
-		const unsigned long long eob_m = __ballot(cls == LitFormat::kEob), hole_m = __ballot(cls == LitFormat::kHoleTag);
+		// An end-of-block symbol or a hole ends the chain where it stands: its "next start" lies outside the window, so the walk
+		// stops there by itself, and what it was is asked of that one lane afterwards -- no ballots, no cutting of masks.
+		// (entries that end a chain: [7] = 0 and [4] = 1 -- kEob 0x10, kHoleTag 0x30; a resolved entry is never a pointer)
+		const uint32_t nxt = (e & 0x90u) == 0x10u ? 64u : lane + bits;
 		unsigned long long chain = 0;
 		{
 			uint32_t cur = 0;
@@ -718,23 +719,19 @@ __device__ __forceinline__ int run_symbols_batched(Stream &s, const WaveLds &t, 
 				cur = (uint32_t) __builtin_amdgcn_readlane((int) nxt, (int) cur);
 			} while (cur < 64u);
 		}
-		{
-			const unsigned long long stop = chain & (eob_m | hole_m);
-			if (stop)
-				chain &= (2ull << __builtin_ctzll(stop)) - 1ull;
-		}
-		if ((chain & hole_m) | (chain & is_match_m & __ballot((ed & 0x8000u) != 0u)))
-			return leave(-1);
-		const bool ends = (chain & eob_m) != 0ull;
-		const unsigned long long sym_m = chain & ~eob_m; // the starts that produce output
+		const uint32_t last = 63u - (uint32_t) __builtin_clzll(chain);
+		const uint32_t e_last = (uint32_t) __builtin_amdgcn_readlane((int) e, (int) last);
+		if ((e_last & 0xF0u) == LitFormat::kHoleTag)
+			return leave(-1); // no codeword leads here (or one that must not occur)
+		const bool ends = (e_last & 0xF0u) == LitFormat::kEob;
+		const unsigned long long sym_m = ends ? chain & ~(1ull << last) : chain; // the starts that produce output
 		const uint32_t n_new = (uint32_t) __popcll(sym_m);
 		if (staged + n_new > 64u && !flush())
 			return leave(-1);
 		if (__builtin_amdgcn_inverse_ballot_w64(sym_m))
 			stage[staged + __builtin_amdgcn_mbcnt_hi((uint32_t) (sym_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) sym_m, 0u))] = ibit + lane;
 		staged += n_new;
-		const uint32_t last = 63u - (uint32_t) __builtin_clzll(chain);
-		ibit += (uint32_t) __builtin_amdgcn_readlane((int) nxt, (int) last);
+		ibit += last + (uint32_t) __builtin_amdgcn_readlane((int) bits, (int) last);
 		if (ends) {
 			if (!flush())
 				return leave(-1);
