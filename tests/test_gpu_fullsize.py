@@ -121,3 +121,16 @@ def test_configs4_chromosome_sized_split_reads(capi, oracle):
     assert np.array_equal(dels["border_rp"], od["border_rp"]) and np.all(dels["rp"] == 0)
     assert np.array_equal(dups["rp"], ou["rp"]) and np.all(dups["border_rp"] == 0)
     assert int((dels["border_rp"] > 0).sum()) + int((dups["rp"] > 0).sum()) > 5
+
+
+def test_configs4_chromosome_1_records_in_place_equal_the_staged_ones(capi):
+    """configs[4] at the size of the longest chromosome (249 Mb, 5x: 11.4 M records with sequences): the `conga --rp` run that
+    decodes on the GPU and maps the records where the inflate left them, the run on the host decoders (records through the
+    pinned staging) and the C-ABI's staged route give the same three files / the same support for every interval
+    (conga_amd/rp_bench.py checks all three against each other; bam_data.c:201-216, split_read.c:206-354, likelihood.c:41-94)."""
+    import argparse
+    from conga_amd import rp_bench
+    out, _sample = rp_bench.leg(argparse.Namespace(rp_chroms="1", chroms="", steps=3, rp_cli=True), dict(local_rank=0))
+    assert "checked" in out, out.get("regime")
+    assert out["records"] > 11_000_000 and out["split_rows"] > 1000 and out["supported_dels"] > 500
+    assert out["end_to_end"]["gpu_decode_calls_per_sample"] == 1
