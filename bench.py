@@ -73,8 +73,9 @@ def parse_args():
                     help="skip the configs[2] / configs[4] legs that follow the timed region at N=1")
     ap.add_argument("--no-e2e-leg", dest="e2e_leg", action="store_false",
                     help="skip the end-to-end leg (`conga --cohort` over whole-genome BAMs written into /tmp) that follows the timed region at N=1")
-    ap.add_argument("--rp-chroms", type=str, default="20,21,22",
-                    help="chromosomes of the configs[4] (--rp) leg; 'all' = the whole genome (21 GB of read records)")
+    ap.add_argument("--rp-chroms", type=str, default="auto",
+                    help="chromosomes of the configs[4] (--rp) leg; 'all' = the whole genome (131.5 M records: ~60 GB of host memory, "
+                         "~35 GB under /tmp for a minute, ~2 minutes); 'auto' = all when the host has that to spare, else 20,21,22")
     ap.add_argument("--dist-selftest", action="store_true",
                     help="run the multi-rank code path (RCCL process group, device-resident records, gather) with the "
                          "ranks there are, even one -- a one-GPU check of the path the driver runs at N > 1")
@@ -679,6 +680,16 @@ def config_legs(args, env):
     # ---- configs[4]: 5x with the split-read path (--rp with --dups)
     from conga_amd import rp_bench
     if rp_bench is not None:
+        if args.rp_chroms == "auto":
+            # the configuration names the whole genome: take it when the host can hold it (the driver's boxes can), else three chromosomes
+            import shutil
+            try:
+                import psutil
+                ram = psutil.virtual_memory().available
+            except Exception:
+                ram = 0
+            tmp_free = shutil.disk_usage(os.environ.get("CONGA_BENCH_TMP", "/tmp")).free
+            args.rp_chroms = "all" if (ram >= 150 << 30 and tmp_free >= 80 << 30 and not args.chroms) else "20,21,22"
         legs["configs[4]"], smp = rp_bench.leg(args, env)
         if args.cpu_seconds > 0:
             from oracle import oracle as O

@@ -8,8 +8,9 @@ path then runs as in the other configurations and copies the support into READ_P
 Inputs (synthetic): a random ACGT reference per chromosome with a leading N gap, ~1 % of bases in satellite
 blocks, reads of 100 bases at 5x copied from the reference with 0.3 % substitutions, reads across the junctions of the
 deletions / duplications the truth genotype carries, 42 000 x L/genome deletions and 6 000 x L/genome duplications.
-The whole genome is 144 M records = 21 GB of sequences and qualities; the default leg takes the chromosomes named by
-`--rp-chroms` (19-22: 11 M records) so that the default bench run stays within minutes, and says so in its workload.
+The whole genome is 131.5 M records = 20 GB of sequences and qualities and a 12.7 GB BAM; `bench.py` takes it when the host has
+the memory and the scratch space to spare (`--rp-chroms auto`), otherwise chromosomes 20-22 (6.56 M records), and the leg says
+which in its workload.
 """
 import ctypes as C
 import time
