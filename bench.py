@@ -689,8 +689,13 @@ def config_legs(args, env):
             except Exception:
                 ram = 0
             tmp_free = shutil.disk_usage(os.environ.get("CONGA_BENCH_TMP", "/tmp")).free
-            args.rp_chroms = "all" if (ram >= 150 << 30 and tmp_free >= 80 << 30 and not args.chroms) else "20,21,22"
+            auto = "host memory available %.0f GB (needs 120), scratch space %.0f GB (needs 45)" % (ram / 2**30, tmp_free / 2**30)
+            args.rp_chroms = "all" if (ram >= 120 << 30 and tmp_free >= 45 << 30 and not args.chroms) else "20,21,22"
+        else:
+            auto = None
         legs["configs[4]"], smp = rp_bench.leg(args, env)
+        if auto:
+            legs["configs[4]"]["chromosomes_chosen_by"] = "--rp-chroms auto: " + auto
         if args.cpu_seconds > 0:
             from oracle import oracle as O
             t0 = time.perf_counter()
@@ -746,10 +751,39 @@ def bgzf_leg(args, env):
                         "in the block table = %d blocks, %.1f MB compressed -> %.1f MB inflated per launch; one BGZF block per wave, "
                         "CRC32 checked on the device" % (len(blocks), times, len(table), len(raw) / 1e6, inflated / 1e6),
                blocks=len(table), kernel_ms=round(best, 3), value=round(inflated / best / 1e6, 2), unit="GB/s inflated",
-               note="instruction-bound byte work (profiles/r02c_inflate_pmc.txt: the vector unit is busy ~97 % of the launch); as HBM "
-                    "bytes this is under 1 % of the peak.  The rate depends on how the blocks fill the machine's 8 192 waves: three "
-                    "full rounds (24 465 blocks) measure 57.7 GB/s, the whole-genome BAM stage (79 086 blocks in 12 overlapping "
-                    "launches behind the upload) 62.4 GB/s end to end")
+               note="instruction-bound byte work (profiles/r03b_inflate_pmc_two_phase.txt: vector unit busy ~76 %, scalar ~65 % of the "
+                    "launch); as HBM bytes this is about 1 % of the peak.  The rate depends on how the blocks fill the machine's 8 192 "
+                    "waves and on the data: more bytes per symbol (matches) inflate faster")
+    # the same kernel on a BAM whose qualities come in runs of a few binned values (what a sequencer of the last decade writes),
+    # deflated at zlib's level 6 like samtools does: more and longer matches per symbol than random qualities give
+    try:
+        from conga_amd import e2e_bench
+        d2 = tempfile.mkdtemp(prefix="conga_bench_bgzf_")
+        p2, _t = e2e_bench.write_bam(d2, "q", [(c.name, c.length, c.pos, c.mapq)], level=6)
+        raw2 = np.fromfile(p2, np.uint8)
+        import shutil
+        shutil.rmtree(d2, ignore_errors=True)
+        buf2, blocks2, at = raw2.tobytes(), [], 0
+        while at + 18 <= len(buf2):
+            bsize = struct.unpack_from("<H", buf2, at + 16)[0] + 1
+            crc, isize = struct.unpack_from("<II", buf2, at + bsize - 8)
+            if isize:
+                blocks2.append((at + 18, bsize - 26, isize, crc))
+            at += bsize
+        times2 = max(1, round(2.5 * 8192 / max(len(blocks2), 1)))
+        table2 = blocks2 * times2
+        with capi.Context(device=env["local_rank"]) as ctx:
+            best2 = 1e30
+            for _ in range(4):
+                _o, status, ms = ctx.inflate_blocks(raw2, table2, want_out=False)
+                assert not status.any(), "a BGZF block of the bench's own BAM did not inflate"
+                best2 = min(best2, ms)
+        inflated2 = sum(b[2] for b in table2)
+        out["bam_like"] = dict(workload="the same chromosome written by tools/bamwrite: pseudo-random bases, run-structured binned qualities, zlib "
+                                        "level 6; %d blocks, %.1f MB -> %.1f MB per launch" % (len(table2), len(raw2) * times2 / 1e6, inflated2 / 1e6),
+                               kernel_ms=round(best2, 3), value=round(inflated2 / best2 / 1e6, 2), unit="GB/s inflated")
+    except (OSError, MemoryError) as e:
+        out["bam_like"] = dict(error="%s: %s" % (type(e).__name__, e))
     if args.cpu_seconds > 0:
         k = min(len(blocks), 400)
         t0 = time.perf_counter()

@@ -600,6 +600,7 @@ int read_bam_cohort(parameters *params, sonic *this_sonic)
 	// the next sample's file is opened, mapped and its block table read while this sample is on the GPU
 	std::unique_ptr<planned_input> ahead = plan_input(params, this_sonic, samples[0].first);
 	std::thread cleaner; // gives the sample before's mapping back (3 GB of touched pages: ~75 ms of munmap) beside this sample's work
+	const auto t_cohort = std::chrono::steady_clock::now();
 	for (size_t k = 0; k < samples.size(); k++) {
 		std::unique_ptr<planned_input> mine_now = std::move(ahead);
 		std::thread planner;
@@ -620,6 +621,9 @@ int read_bam_cohort(parameters *params, sonic *this_sonic)
 					std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_join).count());
 		if (cleaner.joinable())
 			cleaner.join();
+		if (getenv("CONGA_TIMING")) // (what a further sample costs, read off one process's own clock: bench.py's end-to-end legs)
+			fprintf(stderr, "[timing] cohort: sample %zu of %zu is done %.1f ms after the first one began\n", k + 1, samples.size(),
+					std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_cohort).count());
 		if (rc != 0)
 			return rc; // (nothing of ours is running: planner and cleaner are joined)
 		if (k + 1 < samples.size()) {
