@@ -2194,11 +2194,8 @@ int conga_reference(conga_ctx *ctx, const char *seq, int64_t len)
 	HostSlot &h = ctx->slots.back();
 	if (len != h.L)
 		return fail(ctx, CONGA_ERR_INVALID, "conga_reference: length differs from the chromosome length");
-	h.ref.resize((size_t) len);
-	for (int64_t i = 0; i < len; i++) { // readReferenceSeq upper-cases every base (common.c:449)
-		const unsigned char c = (unsigned char) seq[i];
-		h.ref[(size_t) i] = (c >= 'a' && c <= 'z') ? (uint8_t) (c - 32) : c;
-	}
+	// (readReferenceSeq upper-cases every base, common.c:449: ref_pack_kernel does that on the device while it packs the text)
+	h.ref.assign(reinterpret_cast<const uint8_t *>(seq), reinterpret_cast<const uint8_t *>(seq) + len);
 	h.ref_version = ++ctx->ref_stamp;
 	ctx->layout_dirty = true;
 	ctx->computed = false;

@@ -397,10 +397,34 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 	std::vector<uint64_t> gpu_counts; // reads per chromosome when all of this worker's chromosomes were decoded on the GPU at once
 	const char *gpu_bam = getenv("CONGA_GPU_BAM"); // 0: never, 1: always, unset: when it pays
 	// readReferenceSeq (common.c:423-463) and the satellite annotation (bam_data.c:96-97,207) for the chromosome begun last
+	// (all of this worker's chromosomes are read side by side the first time one is asked for: a genome's FASTA is 3 GB of text)
+	std::vector<std::string> ref_seqs;
 	auto hand_over_reference = [&](const chrom_job *job) {
-		std::string ref_seq, ferr;
-		if (!load_fasta_chrom(params->ref_genome, this_sonic->chromosome_names[job->chr_index], job->L, &ref_seq, &ferr))
-			print_error(ferr);
+		if (ref_seqs.empty()) {
+			ref_seqs.resize(mine.size());
+			std::vector<std::string> errs(mine.size());
+			std::atomic<size_t> next{0};
+			auto load_some = [&] {
+				for (size_t k; (k = next.fetch_add(1)) < mine.size();)
+					if (!load_fasta_chrom(params->ref_genome, this_sonic->chromosome_names[mine[k]->chr_index], mine[k]->L, &ref_seqs[k], &errs[k])
+							&& errs[k].empty())
+						errs[k] = "cannot read chromosome " + this_sonic->chromosome_names[mine[k]->chr_index] + " from " + params->ref_genome;
+			};
+			std::vector<std::thread> pool;
+			for (int t = 1; t < std::min<int>((int) mine.size(), std::max(1, usable_cpus() / reader_share())); t++)
+				pool.emplace_back(load_some);
+			load_some();
+			for (std::thread &t : pool)
+				t.join();
+			for (const std::string &e : errs)
+				if (!e.empty())
+					print_error(e);
+		}
+		size_t k = 0;
+		while (k < mine.size() && mine[k] != job)
+			k++;
+		std::string ref_seq;
+		ref_seq.swap(ref_seqs[k]);
 		engine_check(ctx, conga_reference(ctx, ref_seq.data(), (int64_t) ref_seq.size()), "conga_reference");
 		engine_check(ctx, conga_satellites(ctx, this_sonic->sat_start[job->chr_index].data(),
 				this_sonic->sat_end[job->chr_index].data(), this_sonic->sat_start[job->chr_index].size()), "conga_satellites");

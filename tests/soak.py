@@ -180,6 +180,9 @@ def main():
                     help="the command line on random BAM files (+ .bai): decode on the GPU (conga_reads_bgzf) against the host "
                          "decoders -- same three output files, same read counts")
     ap.add_argument("--split-reads", action="store_true", help="the --rp path: random references and whole BAM records")
+    ap.add_argument("--bam-rp", action="store_true",
+                    help="`conga --rp` on random BAMs with sequences: records mapped in place after the decode on the GPU (one call, and "
+                         "one per chromosome) against the host decoders handing them over -- same files, same split-read counts")
     ap.add_argument("--chroms-per-batch", type=int, default=0, help="with --batch: this many chromosomes in every batch (default: 1-12)")
     ap.add_argument("--batch", action="store_true",
                     help="CONGA_FLAG_BATCH: 1..12 random chromosomes per context (one launch per kernel over all of them), "
@@ -251,6 +254,64 @@ def main():
             if a.seconds and time.time() - t0 > a.seconds:
                 break
         print("soak: %d random BAMs: decode on the GPU == host decoders (seed %d, %.0f s)" % (done, a.seed, time.time() - t0))
+        return
+    if a.bam_rp:
+        import re
+        import shutil
+        import subprocess
+        import tempfile
+        from conga_amd import formats, synth
+        conga = os.path.join(ROOT, "conga_amd", "host", "conga")
+        for i in range(a.cases):
+            rng = np.random.default_rng([a.seed, 13_000_000 + i])
+            d = tempfile.mkdtemp(prefix="conga_soak_bamrp_")
+            n_chr = int(rng.integers(1, 4))
+            cases = [random_split_case(rng) for _ in range(n_chr)]
+            reads, recs, annot, fasta, dels, dups = [], {}, [], [], [], []
+            for k, c in enumerate(cases):
+                name = str(k + 1)
+                inside = c["pos"].astype(np.int64) < c["L"]     # (a record behind the annotation's chromosome end leaves the file to the host decoders)
+                keep = np.flatnonzero(inside)
+                lq = c["lq"][keep]
+                per_base = np.repeat(inside, c["lq"])
+                off = np.concatenate([[0], np.cumsum(lq)[:-1]]).astype(np.uint64) if len(lq) else np.zeros(0, np.uint64)
+                reads.append((name, c["L"], c["pos"][keep], c["mapq"][keep], c["flag"][keep]))
+                recs[name] = (lq, c["codes"][per_base], c["qual"][per_base], off)
+                annot.append((name, c["L"], np.full((c["L"] + 99) // 100, int(rng.integers(30, 60)), np.uint8), c["sat_s"], c["sat_e"]))
+                fasta.append((name, c["ref_lower"]))
+                dels += [(name, s_, e_) for s_, e_ in c["dels"]]
+                dups += [(name, s_, e_) for s_, e_ in c["dups"]]
+            formats.write_bam(os.path.join(d, "r.bam"), "S", reads, records=recs, index=True, unplaced=int(rng.integers(0, 6)),
+                              block_payload=int(rng.choice([1500, 9000, 40000, 65280])), level=int(rng.integers(0, 10)))
+            formats.write_annotation(os.path.join(d, "a.cga"), annot)
+            formats.write_fasta(os.path.join(d, "ref.fa"), fasta)
+            synth.write_bed(os.path.join(d, "dels.bed"), dels)
+            synth.write_bed(os.path.join(d, "dups.bed"), dups if dups else [("1", 10, 2000)])
+            args = ["-i", "r.bam", "--ref", "ref.fa", "--sonic", "a.cga", "--dels", "dels.bed", "--dups", "dups.bed", "--rp", str(int(rng.integers(1, 12)))]
+            if rng.random() < 0.4:
+                args += ["--min-mapq", str(int(rng.choice([0, 15, 25, 35])))]
+            if rng.random() < 0.3:
+                args += ["--min-read-length", str(int(rng.choice([10, 75, 100])))]
+            size = os.path.getsize(os.path.join(d, "r.bam"))
+            outs = {}
+            for tag, env in (("gpu", {"CONGA_GPU_BAM": "1"}), ("each", {"CONGA_GPU_BAM": "1", "CONGA_GPU_BAM_MAX_MB": "%.4f" % (size * 0.6 / 1048576)}),
+                             ("host", {"CONGA_GPU_BAM": "0"})):
+                r = subprocess.run([conga] + args + ["--out", tag], cwd=d, capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+                if r.returncode != 0 or (tag == "gpu" and "decoding on the host" in r.stderr):
+                    print("FAILED bam-rp case %d (seed %d, %s) in %s:\n%s" % (i, a.seed, tag, d, r.stderr[-1500:]), flush=True)
+                    raise SystemExit(1)
+                files = [open(os.path.join(d, "%s_%s.bed" % (tag, k)), "rb").read() for k in ("svs", "dels", "dups")]
+                outs[tag] = (files, re.findall(r"\((\d+) reads, (\d+) split-reads\)", r.stderr), re.findall(r"CONGA paired (\d+)", r.stderr))
+            if not (outs["gpu"] == outs["host"] == outs["each"]):
+                print("FAILED bam-rp case %d (seed %d): the routes differ, files in %s" % (i, a.seed, d), flush=True)
+                raise SystemExit(1)
+            shutil.rmtree(d)
+            done += 1
+            if i % 10 == 9:
+                print("%d bam-rp cases ok, %.0f s" % (done, time.time() - t0), flush=True)
+            if a.seconds and time.time() - t0 > a.seconds:
+                break
+        print("soak: %d random --rp BAMs: records in place (one call / per chromosome) == host decoders (seed %d, %.0f s)" % (done, a.seed, time.time() - t0))
         return
     if a.split_reads:
         import test_gpu_split_reads as S
