@@ -148,7 +148,11 @@ def pinned_samples(ctx, mine):
             mapq[at:at + len(p)] = m
             at += len(p)
             off[k + 1] = at
-        out.append((pos, mapq, off))
+        # the same positions as a producer that subtracts sends them (conga_sample_reads_d16): 16-bit differences + exceptions
+        delta, ei, ep = capi.encode_d16(pos[:at], off)
+        d_pin = ctx.host_alloc(max(at, 1), np.uint16)
+        d_pin[:at] = delta
+        out.append((pos, mapq, off, d_pin, ei, ep))
     return out
 
 
@@ -251,8 +255,10 @@ class Leg:
         self.E = [np.zeros((len(self.mine), 101), np.float32) for _ in range(N_ROTATE)]
         self.total_iv = self.n_iv_mine
         # handing the layout over is not a step: every context prepares its device layout here, once
+        self.packed = True
+        self.rotate_contexts = False   # N = 1: True = rounds 2-3's loop over three contexts (kept as a figure of its own)
         for j, c in enumerate(self.ctxs):
-            c.sample_reads(*self.samples[j])
+            self.reads(c, j)
             c.compute()
             c.sync()
         if env["dist_on"]:
@@ -282,10 +288,19 @@ class Leg:
         self.in_flight = [None] * N_ROTATE
         self.ext = [None if env["rehearsal"] else torch.cuda.ExternalStream(c.stream(), device=dev) for c in self.ctxs]
 
+    def reads(self, c, j):
+        """Sample j's tuples from pinned host memory into context c: the positions as 16-bit differences (what a producer that
+        subtracts sends: conga_sample_reads_d16) unless self.packed is off (32-bit positions: conga_sample_reads)."""
+        pos, mapq, off, d_pin, ei, ep = self.samples[j]
+        if self.packed:
+            c.sample_reads_d16(d_pin, ei, ep, mapq, off)
+        else:
+            c.sample_reads(pos, mapq, off)
+
     # -- one step, in two halves so that the copy of step k + 1 is in flight while step k finishes
     def enqueue(self, k):
         c = self.ctxs[k % N_ROTATE]
-        c.sample_reads(*self.samples[k % N_ROTATE])   # pinned host -> HBM, asynchronous
+        self.reads(c, k % N_ROTATE)                   # pinned host -> HBM, asynchronous
         c.compute()                                   # the whole hot path for this rank's chromosomes, asynchronous
 
     def finish(self, k):
@@ -323,6 +338,18 @@ class Leg:
                     self.in_flight[j] = None
 
     def run(self, n, pipelined=True):
+        if pipelined and not self.env["dist_on"] and not self.rotate_contexts:
+            # one context, the C-ABI's own pipelining: sample k + 1 is handed over (its copy runs on the context's second stream into
+            # the other pair of tuple buffers) while sample k is computed and fetched
+            c = self.ctxs[0]
+            self.reads(c, 0)
+            c.compute()
+            for k in range(1, n):
+                self.reads(c, k % N_ROTATE)
+                c.sample_fetch(self.out[0], self.E[0])
+                c.compute()
+            c.sample_fetch(self.out[0], self.E[0])
+            return
         if pipelined:
             self.enqueue(0)
             for k in range(1, n):
@@ -353,25 +380,6 @@ class Leg:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return elapsed
-
-    def single_context(self, steps):
-        """The pipelined step with ONE context (what a cohort driver behind the C-ABI has): sample k + 1 is handed over
-        (conga_sample_reads: its copy runs on the context's second stream into the other pair of tuple buffers), sample k is
-        fetched, sample k + 1 is computed.  -> seconds per step"""
-        c = self.ctxs[0]
-        c.sample_reads(*self.samples[0])
-        c.compute()
-        for k in range(2):   # warm-up
-            c.sample_reads(*self.samples[(k + 1) % N_ROTATE])
-            c.sample_fetch(self.out[0], self.E[0])
-            c.compute()
-        t0 = time.perf_counter()
-        for k in range(steps):
-            c.sample_reads(*self.samples[k % N_ROTATE])
-            c.sample_fetch(self.out[0], self.E[0])
-            c.compute()
-        c.sample_fetch(self.out[0], self.E[0])
-        return (time.perf_counter() - t0) / steps
 
     def kernel_only(self, steps, rotate=True):
         """The kernels alone on resident tuples (what round 1 reported as `value`): compute + sync per step."""
@@ -443,7 +451,7 @@ def workload_text(leg, args, config):
     if leg.env["world"] > 1 and leg.scaling == "strong":
         what = "BASELINE configs[3] (the configs[1] sample sharded by chromosome over %d GPUs)" % leg.env["world"]
     return ("%s: GRCh37 autosomes 1-22, %d deletion rows%s (%d intervals kept >= 1000 bp per sample)%s, %.1fx synthetic "
-            "samples, 100-bp GC windows; one step = one sample: tuples in pinned host memory -> records in host memory" % (
+            "samples, 100-bp GC windows; one step = one sample: tuples in pinned host memory (positions as 16-bit differences) -> records in host memory" % (
                 what, synth.N_DELS_GENOME, "" if config == "dels" else " + %d duplication rows" % synth.N_DUPS_GENOME,
                 per_sample, "" if config == "dels" else ", 100-mer-like mappability track", args.cov))
 
@@ -514,10 +522,11 @@ def main():
                 assert have == want, "gathered records differ from the fetched ones"
         mine = leg.mine
         reads_step = int(sum(len(u["reads"][0][0]) for u in mine))
-        h2d_bytes = 4 * reads_step  # int32 pos; the MAPQ bytes stay on the host with the default threshold (never read: every read counts)
+        # 16-bit differences + 8 bytes per exception; the MAPQ bytes stay on the host with the default threshold (never read: every read counts)
+        h2d_bytes = 2 * reads_step + 8 * len(leg.samples[0][4])
         cfg = dict(workload=workload_text(leg, args, args.config), samples_per_step=samples_per_step,
                    chromosomes_per_sample=len(leg.units) // samples_per_step, intervals_per_step=int(leg.total_iv),
-                   reads_per_step_rank0=reads_step, rotation="%d samples x %d contexts" % (N_ROTATE, N_ROTATE),
+                   reads_per_step_rank0=reads_step, rotation=("%d samples, one context" % N_ROTATE) if not dist_on else "%d samples x %d contexts" % (N_ROTATE, N_ROTATE),
                    parallelism="chromosome-sharded x%d, one RCCL gather per step" % world)
         out = dict(metric="CNV intervals genotyped/sec (1000G Phase-3 set); CN-call concordance vs ref",
                    value=round(leg.total_iv * args.steps / elapsed, 1), unit="intervals/s", n_gpus=world,
@@ -526,22 +535,34 @@ def main():
                    dtype="i32+f32/f64",  # counts, serial float32 chain, double scores
                    data="synthetic", config=cfg)
 
-    # ---- the same step unpipelined, and the kernels alone (all ranks take part: the step contains a gather)
+    # ---- the same step with the positions as 32-bit numbers (rounds 2-3's hand-over), unpipelined, and the kernels alone (all
+    # ranks take part: the step contains a gather)
+    leg.packed = False
+    e32 = leg.timed(args.steps, 2)
+    leg.packed = True
+    if rank == 0:
+        out["hand_over_int32"] = dict(ms_per_step=round(1e3 * e32 / args.steps, 4), value=round(leg.total_iv * args.steps / e32, 1),
+                                      bytes_per_step=4 * int(sum(len(u["reads"][0][0]) for u in leg.mine)),
+                                      note="the same pipelined step through conga_sample_reads (int32 positions: 4 bytes per read over PCIe)")
     single_s = leg.timed(max(3, min(args.steps, 10)), 1, pipelined=False) / max(3, min(args.steps, 10))
     if rank == 0:
         out["single_sample"] = dict(ms_per_step=round(1e3 * single_s, 4), value=round(leg.total_iv / single_s, 1),
                                     note="copy, kernels and fetch of one sample one after the other (latency of a step)")
         h2d = dict(bound="pcie-h2d", bytes_per_step=h2d_bytes, achieved=round(h2d_bytes / (ms_per_step * 1e-3) / 1e9, 2),
-                   peak=PCIE_PEAK_GBS, unit="GB/s", note="4 bytes per read (int32 pos; with --mq -1, the reference's default, the MAPQ "
-                   "bytes are never read and are not sent) over PCIe Gen5 x16 per step")
+                   peak=PCIE_PEAK_GBS, unit="GB/s", note="2 bytes per read (the positions as 16-bit differences, %d exceptions of 8 bytes; with "
+                   "--mq -1, the reference's default, the MAPQ bytes are never read and are not sent) over PCIe Gen5 x16 per step"
+                   % len(leg.samples[0][4]))
         h2d["frac"] = round(h2d["achieved"] / PCIE_PEAK_GBS, 4)
         out["step_bound"] = h2d
 
     if rank == 0 and not dist_on:
-        sc = leg.single_context(max(args.steps, 12))
-        out["single_context"] = dict(ms_per_step=round(1e3 * sc, 4), value=round(leg.total_iv / sc, 1),
-                                     note="one context, pipelined: conga_sample_reads(k + 1) -> conga_sample_fetch(k) -> "
-                                          "conga_chrom_compute(k + 1); the hand-over is double-buffered inside the context")
+        leg.rotate_contexts = True
+        e3 = leg.timed(args.steps, 2)
+        leg.rotate_contexts = False
+        out["three_contexts"] = dict(ms_per_step=round(1e3 * e3 / args.steps, 4), value=round(leg.total_iv * args.steps / e3, 1),
+                                     note="rounds 2-3's loop: the steps rotate over three contexts (the copy of sample k + 1 beside the "
+                                          "kernels and the fetch of sample k by way of separate contexts); `value` is ONE context: "
+                                          "conga_sample_reads_d16(k + 1) -> conga_sample_fetch(k) -> conga_chrom_compute(k + 1)")
     if rank == 0:
         ko_rot = leg.kernel_only(max(args.steps, 12), rotate=True)
         ko_one = leg.kernel_only(max(args.steps, 12), rotate=False)
@@ -592,7 +613,7 @@ def main():
             # the reference's dense formulation on the same inputs: a context with CONGA_FLAG_MATERIALIZE_DEPTH
             dctx = capi.Context(device=local_rank, flags=capi.FLAG_BATCH | capi.FLAG_MATERIALIZE_DEPTH)
             open_layout(dctx, mine)
-            dctx.sample_reads(*leg.samples[0])
+            dctx.sample_reads(*leg.samples[0][:3])
             for _ in range(3):
                 dctx.compute()
             dctx.sync()
@@ -615,7 +636,7 @@ def main():
             out["roofline_dense"]["value"] = round(leg.total_iv / (d_ms * 1e-3), 1)
             # both formulations must give the same records
             c0 = leg.ctxs[0]
-            c0.sample_reads(*leg.samples[0])
+            c0.sample_reads(*leg.samples[0][:3])
             c0.compute()
             g1 = c0.sample_fetch()[0]
             dctx.compute()
@@ -623,7 +644,7 @@ def main():
             assert g1.tobytes() == g2.tobytes(), "tuple-space and dense records differ"
             dctx.close()
         c0 = leg.ctxs[0]
-        c0.sample_reads(*leg.samples[0])
+        c0.sample_reads(*leg.samples[0][:3])
         c0.compute()
         recs, E, _ = c0.sample_fetch()
         if args.cpu_seconds > 0:
@@ -670,7 +691,7 @@ def config_legs(args, env):
                               kernel_only=dict(ms_per_step=round(1e3 * ko, 4), value=round(leg.total_iv / ko, 1)), roofline=r)
     if args.cpu_seconds > 0:
         c0 = leg.ctxs[0]
-        c0.sample_reads(*leg.samples[0])
+        c0.sample_reads(*leg.samples[0][:3])
         c0.compute()
         recs, E, _ = c0.sample_fetch()
         small = argparse.Namespace(**vars(args))

@@ -38,7 +38,7 @@ KERNEL_NAMES = ("ingest", "depth_tile", "expected_table", "paint", "interval_red
 EXPORTS = (
     "conga_create", "conga_destroy", "conga_strerror", "conga_last_error", "conga_abi_version",
     "conga_device_count", "conga_reset", "conga_chrom_count", "conga_chrom_select", "conga_chrom_begin", "conga_reads_staging", "conga_reads_commit",
-    "conga_reads_bgzf", "conga_reads_bgzf_fd", "conga_release_staging", "conga_inflate_blocks", "conga_host_alloc", "conga_host_free", "conga_sample_reads", "conga_sample_begin",
+    "conga_reads_bgzf", "conga_reads_bgzf_fd", "conga_release_staging", "conga_inflate_blocks", "conga_host_alloc", "conga_host_free", "conga_sample_reads", "conga_sample_reads_d16", "conga_sample_begin",
     "conga_sample_chrom", "conga_sample_fetch",
     "conga_mappability", "conga_intervals", "conga_reference", "conga_satellites", "conga_split_reads_staging",
     "conga_split_reads_commit", "conga_split_support", "conga_chrom_compute",
@@ -102,6 +102,25 @@ _lib = None
 EXTRA_FLAGS = 0
 
 
+def encode_d16(pos, chrom_off):
+    """What a producer that subtracts sends (conga_sample_reads_d16): pos int32[n] with chromosome c in [chrom_off[c], chrom_off[c + 1])
+    -> (delta uint16[n], esc_index uint32[k], esc_pos int32[k]).  A difference outside [0, 0xFFFE] and the first read of every
+    chromosome are exceptions (0xFFFF in the stream, index and position in the list)."""
+    pos = np.ascontiguousarray(pos, dtype=np.int32)
+    n = len(pos)
+    d = np.empty(n, np.int64)
+    if n:
+        d[0] = -1
+        d[1:] = pos[1:].astype(np.int64) - pos[:-1].astype(np.int64)
+        firsts = np.asarray(chrom_off[:-1], np.int64)
+        firsts = firsts[(firsts < n) & (np.asarray(chrom_off[1:], np.int64) > firsts)]
+        d[firsts] = -1
+    esc = (d < 0) | (d > 0xFFFE)
+    delta = np.where(esc, 0xFFFF, d).astype(np.uint16)
+    idx = np.flatnonzero(esc).astype(np.uint32)
+    return delta, idx, pos[idx].astype(np.int32)
+
+
 def load():
     """dlopen the HIP library.  Raises (never falls back) when it has not been built."""
     global _lib
@@ -148,6 +167,8 @@ def load():
     L.conga_host_free.argtypes = [vp, vp]
     L.conga_sample_reads.restype = C.c_int
     L.conga_sample_reads.argtypes = [vp, vp, vp, vp, C.c_int]
+    L.conga_sample_reads_d16.restype = C.c_int
+    L.conga_sample_reads_d16.argtypes = [vp, vp, vp, vp, sz, vp, vp, C.c_int]
     L.conga_sample_begin.restype = C.c_int
     L.conga_sample_begin.argtypes = [vp]
     L.conga_sample_chrom.restype = C.c_int
@@ -320,6 +341,14 @@ class Context:
             raise TypeError("sample_reads takes int32 pos, uint8 mapq (or None when mq_threshold < 0), uint64 chrom_off")
         self._check(self._lib.conga_sample_reads(self._h, pos.ctypes.data, None if mapq is None else mapq.ctypes.data,
                                                  chrom_off.ctypes.data, len(chrom_off) - 1))
+
+    def sample_reads_d16(self, delta, esc_index, esc_pos, mapq, chrom_off):
+        """conga_sample_reads_d16: the positions as 16-bit differences + exceptions (encode_d16); arrays passed as they are."""
+        if delta.dtype != np.uint16 or esc_index.dtype != np.uint32 or esc_pos.dtype != np.int32 or chrom_off.dtype != np.uint64 \
+                or (mapq is not None and mapq.dtype != np.uint8):
+            raise TypeError("sample_reads_d16 takes uint16 delta, uint32 esc_index, int32 esc_pos, uint8 mapq (or None), uint64 chrom_off")
+        self._check(self._lib.conga_sample_reads_d16(self._h, delta.ctypes.data, esc_index.ctypes.data, esc_pos.ctypes.data, len(esc_index),
+                                                     None if mapq is None else mapq.ctypes.data, chrom_off.ctypes.data, len(chrom_off) - 1))
 
     def sample_begin(self):
         self._check(self._lib.conga_sample_begin(self._h))

@@ -30,6 +30,7 @@
 
 #include "../../include/conga_hip.h"
 #include "kernels.hip.h"
+#include "delta16.hip.h"
 #include "kernels_bam.hip.h"
 #include "kmer_sort.h"
 #include "split_map.hip.h"
@@ -175,6 +176,12 @@ struct conga_ctx {
 	// last compute (which reads d_pos / d_mapq) and its fetch are still under way.  `computed_reads` is what that compute ran
 	// on (per chromosome: first tuple, count), for the fetch's statistics and for settle_wrap_risk's second compute.
 	DevBuf d_pos_alt, d_mapq_alt;
+	// conga_sample_reads_d16: the differences as they came up and the exceptions (one set per pair of tuple buffers: the copy stream
+	// carries nothing but copies, back to back), the scan's scratch; what the next compute has to expand first
+	DevBuf d_delta[2], d_delta_esc[2], d_delta_agg;
+	bool expand_pending = false;
+	uint64_t expand_total = 0;
+	size_t expand_n_esc = 0;
 	hipEvent_t ev_reads = nullptr;     // the copies of the last conga_sample_reads (on stream2)
 	hipEvent_t ev_pair[2] = {};        // the last compute that read buffer pair 0 / 1 (on stream)
 	bool used_recorded[2] = {false, false};
@@ -841,6 +848,7 @@ void reset_slots(conga_ctx *ctx)
 	ctx->sr_bytes_total = 0;
 	ctx->sr_staged = false;
 	ctx->bz_keep_bytes = 0;
+	ctx->expand_pending = false;
 	ctx->staging_cur = -1;
 	ctx->read_target = -1;
 	ctx->layout_dirty = true;
@@ -1491,7 +1499,8 @@ void conga_destroy(conga_ctx *ctx)
 	if (ctx->ev_join)
 		(void) hipEventDestroy(ctx->ev_join);
 	// (d_slots and d_block_home are views into d_head)
-	DevBuf *bufs[] = {&ctx->d_pos, &ctx->d_mapq, &ctx->d_pos_alt, &ctx->d_mapq_alt, &ctx->d_tile_start, &ctx->d_small_scratch, &ctx->d_item_slot,
+	DevBuf *bufs[] = {&ctx->d_pos, &ctx->d_mapq, &ctx->d_pos_alt, &ctx->d_mapq_alt, &ctx->d_delta[0], &ctx->d_delta[1], &ctx->d_delta_esc[0],
+			&ctx->d_delta_esc[1], &ctx->d_delta_agg, &ctx->d_tile_start, &ctx->d_small_scratch, &ctx->d_item_slot,
 			&ctx->d_head, &ctx->d_item_row0, &ctx->d_item_row1, &ctx->d_item_rt_off, &ctx->d_item_lo, &ctx->d_rd, &ctx->d_gc_hist, &ctx->d_gc_like,
 			&ctx->d_small, &ctx->d_map, &ctx->d_winner, &ctx->d_map_start, &ctx->d_map_end,
 			&ctx->d_map_val, &ctx->d_iv_start, &ctx->d_iv_end, &ctx->d_iv_type, &ctx->d_iv_slot, &ctx->d_iv_has_map,
@@ -1738,6 +1747,7 @@ int drop_reads(conga_ctx *ctx, const char *who, bool keep_computed = false)
 	ctx->sr_bytes_total = 0;
 	ctx->sr_staged = false;
 	ctx->bz_keep_bytes = 0;
+	ctx->expand_pending = false; // (differences that no compute has taken up go with the reads they stood for)
 	ctx->wrap_risk = false;
 	ctx->sample_dirty = true;
 	if (keep_computed && ctx->computed)
@@ -1777,28 +1787,48 @@ int conga_sample_chrom(conga_ctx *ctx, int index)
 	return CONGA_OK;
 }
 
-int conga_sample_reads(conga_ctx *ctx, const int32_t *pos, const uint8_t *mapq, const uint64_t *chrom_off, int n_chrom)
+} // extern "C"
+
+namespace {
+
+// conga_sample_reads / conga_sample_reads_d16: `pos` (32-bit positions) or `delta` + exceptions (16-bit differences)
+int sample_reads_impl(conga_ctx *ctx, const char *who, const int32_t *pos, const uint16_t *delta, const uint32_t *esc_index, const int32_t *esc_pos,
+		size_t n_esc, const uint8_t *mapq, const uint64_t *chrom_off, int n_chrom)
 {
 	if (!ctx || !chrom_off)
 		return CONGA_ERR_INVALID;
 	if (n_chrom != (int) ctx->slots.size())
-		return fail(ctx, CONGA_ERR_INVALID, "conga_sample_reads: n_chrom differs from the chromosomes the context holds");
+		return fail(ctx, CONGA_ERR_INVALID, std::string(who) + ": n_chrom differs from the chromosomes the context holds");
 	const uint64_t total = chrom_off[n_chrom];
 	// With the default threshold (-1: cmdline.c:188-194) every read passes `qual > mq_threshold` (bam_data.c:205) whatever its
 	// MAPQ: the bytes are never looked at, so they are not sent either (4 bytes per read over PCIe instead of 5) and may be NULL.
 	const bool need_mapq = ctx->opts.mq_threshold >= 0;
-	if (chrom_off[0] != 0 || (total && (!pos || (need_mapq && !mapq))))
-		return fail(ctx, CONGA_ERR_INVALID, "conga_sample_reads: chrom_off must start at 0 and the arrays must be given");
+	const bool packed = delta != nullptr;
+	if (chrom_off[0] != 0 || (total && ((!pos && !delta) || (need_mapq && !mapq))))
+		return fail(ctx, CONGA_ERR_INVALID, std::string(who) + ": chrom_off must start at 0 and the arrays must be given");
 	for (int c = 0; c < n_chrom; c++)
 		if (chrom_off[c + 1] < chrom_off[c])
-			return fail(ctx, CONGA_ERR_INVALID, "conga_sample_reads: chrom_off must not decrease");
+			return fail(ctx, CONGA_ERR_INVALID, std::string(who) + ": chrom_off must not decrease");
 	if (total >= 0xFFFFFFF0ull)
-		return fail(ctx, CONGA_ERR_RANGE, "conga_sample_reads: more than 2^32 reads in one context");
+		return fail(ctx, CONGA_ERR_RANGE, std::string(who) + ": more than 2^32 reads in one context");
+	if (packed) {
+		// the exceptions: sorted by index, one for the first read of every chromosome that has reads (nothing can be carried
+		// over a chromosome's border)
+		if (n_esc > 0xFFFFFFF0ull || (n_esc && (!esc_index || !esc_pos)))
+			return fail(ctx, CONGA_ERR_INVALID, std::string(who) + ": the exception list is missing");
+		for (size_t k = 0; k < n_esc; k++)
+			if (esc_index[k] >= total || (k && esc_index[k] <= esc_index[k - 1]))
+				return fail(ctx, CONGA_ERR_INVALID, std::string(who) + ": exceptions must be sorted by index and lie inside the reads");
+		for (int c = 0; c < n_chrom; c++)
+			if (chrom_off[c + 1] > chrom_off[c]
+					&& !std::binary_search(esc_index, esc_index + n_esc, (uint32_t) chrom_off[c]))
+				return fail(ctx, CONGA_ERR_INVALID, std::string(who) + ": the first read of every chromosome must be an exception (an absolute position)");
+	}
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	if (ctx->reads_ahead) // (two samples handed over without a compute in between: the first one's copy must not be overtaken)
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
 	const bool ahead = ctx->computed && !ctx->reads_ahead && ctx->n_sr_total == 0 && ctx->bz_keep_bytes == 0;
-	TRY(drop_reads(ctx, "conga_sample_reads", ahead));
+	TRY(drop_reads(ctx, who, ahead));
 	ctx->read_target = -1;
 	if (ahead) {
 		// The last compute (and the fetch that may still follow it) reads d_pos / d_mapq: this sample's tuples go into the
@@ -1815,13 +1845,33 @@ int conga_sample_reads(conga_ctx *ctx, const int32_t *pos, const uint8_t *mapq, 
 	}
 	if (total) {
 		// Straight from the caller's arrays: from pinned memory (conga_host_alloc) this is one DMA each at the link's rate.
-		hipStream_t cs = ahead ? ctx->stream2 : ctx->stream;
-		if (ahead && ctx->used_recorded[ctx->pos_buf])
+		// The packed form always travels on stream2 (one staging buffer for the differences: the stream keeps its users in order).
+		const bool on2 = ahead || packed;
+		hipStream_t cs = on2 ? ctx->stream2 : ctx->stream;
+		if (on2 && ctx->used_recorded[ctx->pos_buf])
 			HIP_TRY(ctx, hipStreamWaitEvent(cs, ctx->ev_pair[ctx->pos_buf], 0));
-		HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pos.p, pos, (size_t) total * 4, hipMemcpyHostToDevice, cs));
+		if (!packed)
+			HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pos.p, pos, (size_t) total * 4, hipMemcpyHostToDevice, cs));
+		else {
+			// only the copies here: the differences are turned into positions by the compute that takes them up, on ITS stream
+			// (expand_positions), so that the next sample's copy follows this one's without a kernel in between
+			DevBuf &dd = ctx->d_delta[ctx->pos_buf], &de = ctx->d_delta_esc[ctx->pos_buf];
+			TRY(ensure(ctx, dd, ((size_t) total + 16) * 2));
+			TRY(ensure(ctx, de, std::max<size_t>(n_esc, 1) * 8));
+			TRY(ensure(ctx, ctx->d_delta_agg, (size_t) ((total + kDeltaChunk - 1) / kDeltaChunk) * 12));
+			uint32_t *d_ei = ptr<uint32_t>(de);
+			HIP_TRY(ctx, hipMemcpyAsync(dd.p, delta, (size_t) total * 2, hipMemcpyHostToDevice, cs));
+			if (n_esc) {
+				HIP_TRY(ctx, hipMemcpyAsync(d_ei, esc_index, n_esc * 4, hipMemcpyHostToDevice, cs));
+				HIP_TRY(ctx, hipMemcpyAsync(d_ei + n_esc, esc_pos, n_esc * 4, hipMemcpyHostToDevice, cs));
+			}
+			ctx->expand_pending = true;
+			ctx->expand_total = total;
+			ctx->expand_n_esc = n_esc;
+		}
 		if (need_mapq)
 			HIP_TRY(ctx, hipMemcpyAsync(ctx->d_mapq.p, mapq, (size_t) total, hipMemcpyHostToDevice, cs));
-		if (ahead) {
+		if (on2) {
 			HIP_TRY(ctx, hipEventRecord(ctx->ev_reads, cs));
 			ctx->reads_on_stream2 = true;
 		}
@@ -1830,6 +1880,24 @@ int conga_sample_reads(conga_ctx *ctx, const int32_t *pos, const uint8_t *mapq, 
 		ctx->slots[(size_t) c].n_reads = (int64_t) (chrom_off[c + 1] - chrom_off[c]);
 	ctx->n_reads_total = (int64_t) total;
 	return CONGA_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int conga_sample_reads(conga_ctx *ctx, const int32_t *pos, const uint8_t *mapq, const uint64_t *chrom_off, int n_chrom)
+{
+	return sample_reads_impl(ctx, "conga_sample_reads", pos, nullptr, nullptr, nullptr, 0, mapq, chrom_off, n_chrom);
+}
+
+int conga_sample_reads_d16(conga_ctx *ctx, const uint16_t *delta, const uint32_t *esc_index, const int32_t *esc_pos, size_t n_esc,
+		const uint8_t *mapq, const uint64_t *chrom_off, int n_chrom)
+{
+	if (!delta && chrom_off && n_chrom >= 0 && chrom_off[n_chrom] != 0)
+		return CONGA_ERR_INVALID;
+	static const uint16_t none = 0;
+	return sample_reads_impl(ctx, "conga_sample_reads_d16", nullptr, delta ? delta : &none, esc_index, esc_pos, n_esc, mapq, chrom_off, n_chrom);
 }
 
 } // extern "C"
@@ -2368,6 +2436,20 @@ int conga_chrom_compute(conga_ctx *ctx)
 		HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_reads, 0));
 		ctx->reads_on_stream2 = false;
 	}
+	if (ctx->expand_pending) { // ... as 16-bit differences (conga_sample_reads_d16): positions first -- delta16.hip.h
+		const uint64_t total = ctx->expand_total;
+		const uint32_t n_chunks = (uint32_t) ((total + kDeltaChunk - 1) / kDeltaChunk), n_esc = (uint32_t) ctx->expand_n_esc;
+		const uint16_t *dd = ptr<uint16_t>(ctx->d_delta[ctx->pos_buf]);
+		const uint32_t *d_ei = ptr<uint32_t>(ctx->d_delta_esc[ctx->pos_buf]);
+		const int32_t *d_ep = reinterpret_cast<const int32_t *>(d_ei + n_esc);
+		int2 *d_agg = ptr<int2>(ctx->d_delta_agg);
+		int32_t *d_carry = reinterpret_cast<int32_t *>(d_agg + n_chunks);
+		hipLaunchKernelGGL(delta_aggregate_kernel, dim3(n_chunks), dim3(256), 0, st, dd, total, d_ei, d_ep, n_esc, d_agg);
+		hipLaunchKernelGGL(delta_carry_kernel, dim3(1), dim3(1024), 0, st, d_agg, n_chunks, d_carry);
+		hipLaunchKernelGGL(delta_expand_kernel, dim3(n_chunks), dim3(256), 0, st, dd, total, d_ei, d_ep, n_esc, d_carry, ptr<int32_t>(ctx->d_pos));
+		HIP_TRY(ctx, hipGetLastError());
+		ctx->expand_pending = false;
+	}
 	ctx->computes_on_layout++;
 	const bool use_graph = (ctx->opts.flags & CONGA_FLAG_PROFILE) == 0 && getenv("CONGA_GRAPH")
 			&& (ctx->graph_exec || ctx->computes_on_layout >= 3);
@@ -2773,7 +2855,8 @@ int settle_wrap_risk(conga_ctx *ctx)
 		ctx->slots[c].n_reads = ctx->computed_reads[c].second;
 	}
 	const int64_t next_total = ctx->n_reads_total;
-	const bool pending_copy = ctx->reads_on_stream2;
+	const bool pending_copy = ctx->reads_on_stream2, pending_expand = ctx->expand_pending;
+	ctx->expand_pending = false; // (the NEXT sample's differences: not this compute's to expand)
 	ctx->n_reads_total = ctx->computed_total;
 	std::swap(ctx->d_pos, ctx->d_pos_alt);
 	std::swap(ctx->d_mapq, ctx->d_mapq_alt);
@@ -2793,6 +2876,7 @@ int settle_wrap_risk(conga_ctx *ctx)
 	std::swap(ctx->d_mapq, ctx->d_mapq_alt);
 	ctx->pos_buf ^= 1;
 	ctx->reads_on_stream2 = pending_copy;
+	ctx->expand_pending = pending_expand;
 	ctx->wrap_risk = false; // (the next sample's own guard runs with its compute)
 	ctx->sample_dirty = true;
 	ctx->reads_ahead = true;

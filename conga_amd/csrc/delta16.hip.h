@@ -1,0 +1,169 @@
+// delta16.hip.h -- read positions handed over as 16-bit differences (conga_sample_reads_d16).
+//
+// The step of a cohort is the copy of the sample's tuples over PCIe (bench.py: step_bound), and a position-sorted sample's
+// positions (bam1_core_t.pos in the order sam_itr_next yields them, bam_data.c:201-213) are a 32-bit number each only because
+// nobody subtracted: at 1x two neighbours are ~100 bases apart.  The producer sends pos[i] - pos[i - 1] in 16 bits; whatever
+// does not fit -- the first read of a chromosome, a gap of 65 535 bases or more, a position in front of its predecessor -- is
+// sent as 0xFFFF plus an entry (index, position) of a short exception list.  Here the differences become positions again:
+// a segmented inclusive scan (an exception restarts the sum) in three launches -- per-chunk aggregates, one workgroup's scan
+// over them, the chunks' local scans with their carry -- writing the int32 array every kernel of the path reads.  25.6 M reads:
+// 51 MB over the link instead of 102, and ~40 us of HBM-bound work that hides under the next sample's copy.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace conga {
+
+constexpr int kDeltaChunk = 2048; // differences per workgroup: 256 threads x 8 (one 16-byte load each)
+constexpr uint32_t kDeltaEscape = 0xFFFFu;
+
+struct SegVal { // a run's sum and whether an exception (an absolute position) lies inside it
+	int32_t v;
+	uint32_t f;
+};
+
+__device__ __forceinline__ SegVal seg_combine(SegVal a, SegVal b) // a in front of b
+{
+	SegVal r;
+	r.v = b.f ? b.v : a.v + b.v;
+	r.f = a.f | b.f;
+	return r;
+}
+
+// position of exception `i` (the list is sorted by index; every 0xFFFF in the stream has its entry -- checked on the host)
+__device__ __forceinline__ int32_t escape_value(const uint32_t *esc_index, const int32_t *esc_pos, uint32_t n_esc, uint32_t i)
+{
+	uint32_t lo = 0, hi = n_esc;
+	while (lo < hi) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if (esc_index[mid] < i)
+			lo = mid + 1;
+		else
+			hi = mid;
+	}
+	return lo < n_esc ? esc_pos[lo] : 0;
+}
+
+// the thread's eight elements as segmented values, and their inclusive scan in place; -> the thread's aggregate
+__device__ __forceinline__ SegVal delta_thread_scan(const uint16_t *delta, uint64_t n, uint64_t first, const uint32_t *esc_index,
+		const int32_t *esc_pos, uint32_t n_esc, SegVal e[8])
+{
+	uint4 raw = make_uint4(0, 0, 0, 0);
+	if (first + 8 <= n)
+		raw = *reinterpret_cast<const uint4 *>(delta + first);
+	else {
+		uint16_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+		for (int k = 0; k < 8; k++)
+			if (first + k < n)
+				t[k] = delta[first + k];
+		raw = make_uint4(t[0] | (uint32_t) t[1] << 16, t[2] | (uint32_t) t[3] << 16, t[4] | (uint32_t) t[5] << 16, t[6] | (uint32_t) t[7] << 16);
+	}
+	const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+	SegVal run = {0, 0u};
+#pragma unroll
+	for (int k = 0; k < 8; k++) {
+		const uint32_t d = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+		SegVal x;
+		x.f = (d == kDeltaEscape && first + k < n) ? 1u : 0u;
+		x.v = x.f ? escape_value(esc_index, esc_pos, n_esc, (uint32_t) (first + k)) : (int32_t) d;
+		run = seg_combine(run, x);
+		e[k] = run;
+	}
+	return run;
+}
+
+// segmented scan of one value per thread over a workgroup of W waves; -> this thread's EXCLUSIVE prefix, the total in *all
+template <int W> __device__ __forceinline__ SegVal delta_block_exclusive(SegVal mine, SegVal *s_wave /* [W] */, SegVal *all)
+{
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	SegVal inc = mine;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		SegVal p;
+		p.v = __shfl_up(inc.v, o, 64);
+		p.f = (uint32_t) __shfl_up((int) inc.f, o, 64);
+		if (lane >= o)
+			inc = seg_combine(p, inc);
+	}
+	if (lane == 63)
+		s_wave[wv] = inc;
+	__syncthreads();
+	SegVal before = {0, 0u}; // of the waves in front of this one
+	for (int k = 0; k < wv; k++)
+		before = seg_combine(before, s_wave[k]);
+	if (all) {
+		SegVal t = before;
+		for (int k = wv; k < W; k++)
+			t = seg_combine(t, s_wave[k]);
+		*all = t;
+	}
+	SegVal ex;
+	ex.v = __shfl_up(inc.v, 1, 64);
+	ex.f = (uint32_t) __shfl_up((int) inc.f, 1, 64);
+	if (lane == 0)
+		ex = SegVal{0, 0u};
+	return seg_combine(before, ex);
+}
+
+// launch 1: every chunk's aggregate
+__global__ __launch_bounds__(256) void delta_aggregate_kernel(const uint16_t *__restrict__ delta, uint64_t n, const uint32_t *__restrict__ esc_index,
+		const int32_t *__restrict__ esc_pos, uint32_t n_esc, int2 *__restrict__ agg)
+{
+	__shared__ SegVal s_wave[4];
+	SegVal e[8], all;
+	const uint64_t first = (uint64_t) blockIdx.x * kDeltaChunk + (uint64_t) threadIdx.x * 8;
+	const SegVal mine = delta_thread_scan(delta, n, first, esc_index, esc_pos, n_esc, e);
+	(void) delta_block_exclusive<4>(mine, s_wave, &all);
+	if (threadIdx.x == 0)
+		agg[blockIdx.x] = make_int2(all.v, (int) all.f);
+}
+
+// launch 2 (one workgroup): exclusive scan over the chunks' aggregates -> what each chunk starts from
+__global__ __launch_bounds__(1024) void delta_carry_kernel(const int2 *__restrict__ agg, uint32_t n_chunks, int32_t *__restrict__ carry)
+{
+	__shared__ SegVal s_wave[16];
+	__shared__ SegVal s_all;
+	SegVal running = {0, 0u};
+	for (uint32_t base = 0; base < n_chunks; base += 1024) {
+		const uint32_t c = base + threadIdx.x;
+		SegVal mine = {0, 0u};
+		if (c < n_chunks) {
+			const int2 a = agg[c];
+			mine = SegVal{a.x, (uint32_t) a.y};
+		}
+		SegVal all;
+		const SegVal ex = delta_block_exclusive<16>(mine, s_wave, &all);
+		if (c < n_chunks)
+			carry[c] = seg_combine(running, ex).v;
+		if (threadIdx.x == 0)
+			s_all = all;
+		__syncthreads();
+		running = seg_combine(running, s_all);
+		__syncthreads();
+	}
+}
+
+// launch 3: the positions
+__global__ __launch_bounds__(256) void delta_expand_kernel(const uint16_t *__restrict__ delta, uint64_t n, const uint32_t *__restrict__ esc_index,
+		const int32_t *__restrict__ esc_pos, uint32_t n_esc, const int32_t *__restrict__ carry, int32_t *__restrict__ pos)
+{
+	__shared__ SegVal s_wave[4];
+	SegVal e[8];
+	const uint64_t first = (uint64_t) blockIdx.x * kDeltaChunk + (uint64_t) threadIdx.x * 8;
+	const SegVal mine = delta_thread_scan(delta, n, first, esc_index, esc_pos, n_esc, e);
+	SegVal before = delta_block_exclusive<4>(mine, s_wave, nullptr);
+	before = seg_combine(SegVal{carry[blockIdx.x], 0u}, before);
+	int32_t out[8];
+#pragma unroll
+	for (int k = 0; k < 8; k++)
+		out[k] = seg_combine(before, e[k]).v;
+	if (first + 8 <= n) {
+		*reinterpret_cast<int4 *>(pos + first) = make_int4(out[0], out[1], out[2], out[3]);
+		*reinterpret_cast<int4 *>(pos + first + 4) = make_int4(out[4], out[5], out[6], out[7]);
+	} else
+		for (int k = 0; k < 8; k++)
+			if (first + k < n)
+				pos[first + k] = out[k];
+}
+
+} // namespace conga

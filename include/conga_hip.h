@@ -233,6 +233,16 @@ int conga_intervals(conga_ctx *ctx, char type, const int32_t *start, const int32
 void *conga_host_alloc(conga_ctx *ctx, size_t bytes); /* pinned host memory (hipHostMalloc); NULL on failure */
 void conga_host_free(conga_ctx *ctx, void *p);
 int conga_sample_reads(conga_ctx *ctx, const int32_t *pos, const uint8_t *mapq, const uint64_t *chrom_off, int n_chrom);
+/* The same hand-over with the positions as 16-bit differences: the step of a cohort is the copy of the sample's tuples over PCIe,
+ * and the positions of a position-sorted sample (bam1_core_t.pos in the order sam_itr_next yields them, bam_data.c:201-213) are
+ * ~100 apart at 1x.  delta[i] = pos[i] - pos[i - 1] where that lies in [0, 0xFFFE]; otherwise 0xFFFF and an entry of the exception
+ * list -- (esc_index[k] = i, esc_pos[k] = pos[i]), sorted by index.  The first read of every chromosome that has reads IS an
+ * exception (nothing is carried over a chromosome's border), and so is a position in front of its predecessor (the engine's
+ * order check then sees it as it is).  The engine turns the differences back into the int32 array all its kernels read (a
+ * segmented scan, three small launches on the stream the copy runs on): 2 bytes per read over the link instead of 4.
+ * Everything said of conga_sample_reads above holds (mapq, lifetime of the arrays, double-buffering). */
+int conga_sample_reads_d16(conga_ctx *ctx, const uint16_t *delta, const uint32_t *esc_index, const int32_t *esc_pos, size_t n_esc,
+		const uint8_t *mapq, const uint64_t *chrom_off, int n_chrom);
 int conga_sample_begin(conga_ctx *ctx);
 int conga_sample_chrom(conga_ctx *ctx, int index);
 /* conga_chrom_fetch for every chromosome in one call: records[] receives conga_chrom_count() groups one behind the

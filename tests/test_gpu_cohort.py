@@ -223,6 +223,54 @@ def test_next_sample_handed_over_beside_the_compute_one_context(capi, oracle, fo
         check_against_oracle(oracle, chroms, samples[3], recs, E, False)
 
 
+def test_positions_as_16_bit_differences_give_the_same_records(capi, oracle, formulation):
+    """conga_sample_reads_d16: the same samples handed over as differences + exceptions (a gap of 65 535 bases and more, one of
+    exactly 65 534 and 65 535, equal neighbours, a chromosome without reads, a chromosome of one read, chunk borders of the scan
+    on chromosome borders) give byte for byte the records of the 32-bit hand-over; a position in front of its predecessor travels
+    as an exception and is refused as unsorted, as it is there."""
+    chroms = layout(False)
+    for sample, empty in ((30, None), (31, 1), (32, 0)):
+        reads = sample_reads_of(chroms, sample, [1.0, 3.0, 0.3][sample - 30], empty=empty)
+        p, m = reads[2]
+        keep = (p < 300_000) | (p > 300_000 + 65_534 + 70_000)          # a long gap ...
+        p = np.sort(np.concatenate([p[keep], [300_000, 300_000 + 65_534, 300_000 + 65_534 + 65_535, 300_000 + 65_534 + 65_535]])).astype(np.int32)
+        p = p[~((p > 300_000) & (p < 300_000 + 65_534))]                # ... with differences of exactly 65 534, 65 535 and 0 at its rim
+        reads[2] = (p, np.full(len(p), 60, np.uint8))
+        if sample == 32:
+            reads[1] = (reads[1][0][:1], reads[1][1][:1])                # one read
+        with capi.Context(device=0, flags=capi.FLAG_BATCH) as ctx:
+            open_layout(ctx, chroms, False)
+            pos, mapq, off = pinned_sample(ctx, reads)
+            ctx.sample_reads(pos, mapq, off)
+            ctx.compute()
+            want, wantE, _ = ctx.sample_fetch()
+            delta, ei, ep = capi.encode_d16(pos[:int(off[-1])], off)
+            assert len(ei) >= 3 and int((delta == 0xFFFF).sum()) == len(ei)
+            d_pin = ctx.host_alloc(max(len(delta), 1), np.uint16)
+            d_pin[:len(delta)] = delta
+            for _ in range(2):                                           # (the second time beside the first's compute: double-buffered)
+                ctx.sample_reads_d16(d_pin, ei, ep, mapq, off)
+                ctx.compute()
+                got, gotE, _ = ctx.sample_fetch()
+                assert got.tobytes() == want.tobytes() and gotE.tobytes() == wantE.tobytes()
+            check_against_oracle(oracle, chroms, reads, got, gotE, False)
+    # unsorted input: the exception carries the position as it is, the engine's order check sees it
+    if formulation == "tuple_space":
+        reads = sample_reads_of(chroms, 33, 1.0)
+        p = reads[0][0].copy()
+        p[100], p[101] = p[101] + 5, p[100]
+        reads[0] = (p, reads[0][1])
+        with capi.Context(device=0, flags=capi.FLAG_BATCH) as ctx:
+            open_layout(ctx, chroms, False)
+            pos, mapq, off = pinned_sample(ctx, reads)
+            delta, ei, ep = capi.encode_d16(pos[:int(off[-1])], off)
+            ctx.sample_reads_d16(delta, ei, ep, mapq, off)
+            ctx.compute()
+            with pytest.raises(capi.CongaError) as err:
+                ctx.sample_fetch()
+            assert err.value.status == capi.CONGA_ERR_UNSORTED
+
+
 # ---- conga_reads_bgzf called in process (the command-line tests run it in fresh subprocesses only) ---------------------
 def bgzf_table(raw):
     """[(data_off, data_len, inflated_len, crc32)] of the non-empty blocks of a BGZF file + their inflated bytes."""
