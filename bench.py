@@ -148,11 +148,13 @@ def pinned_samples(ctx, mine):
             mapq[at:at + len(p)] = m
             at += len(p)
             off[k + 1] = at
-        # the same positions as a producer that subtracts sends them (conga_sample_reads_d16): 16-bit differences + exceptions
-        delta, ei, ep = capi.encode_d16(pos[:at], off)
-        d_pin = ctx.host_alloc(max(at, 1), np.uint16)
-        d_pin[:at] = delta
-        out.append((pos, mapq, off, d_pin, ei, ep))
+        # the same positions as a producer that subtracts sends them (conga_sample_reads_packed): differences of the width that
+        # sends the fewest bytes at this coverage (10 bits at 1x) + exceptions
+        bits, width, ei, ep = capi.encode_packed(pos[:at], off)
+        d_pin = ctx.host_alloc(len(bits) + 64, np.uint8)
+        d_pin[:len(bits)] = bits
+        d_pin[len(bits):] = 0
+        out.append((pos, mapq, off, d_pin, ei, ep, width, len(bits)))
     return out
 
 
@@ -291,9 +293,9 @@ class Leg:
     def reads(self, c, j):
         """Sample j's tuples from pinned host memory into context c: the positions as 16-bit differences (what a producer that
         subtracts sends: conga_sample_reads_d16) unless self.packed is off (32-bit positions: conga_sample_reads)."""
-        pos, mapq, off, d_pin, ei, ep = self.samples[j]
+        pos, mapq, off, d_pin, ei, ep, width, _nb = self.samples[j]
         if self.packed:
-            c.sample_reads_d16(d_pin, ei, ep, mapq, off)
+            c.sample_reads_packed(d_pin, width, ei, ep, mapq, off)
         else:
             c.sample_reads(pos, mapq, off)
 
@@ -451,7 +453,7 @@ def workload_text(leg, args, config):
     if leg.env["world"] > 1 and leg.scaling == "strong":
         what = "BASELINE configs[3] (the configs[1] sample sharded by chromosome over %d GPUs)" % leg.env["world"]
     return ("%s: GRCh37 autosomes 1-22, %d deletion rows%s (%d intervals kept >= 1000 bp per sample)%s, %.1fx synthetic "
-            "samples, 100-bp GC windows; one step = one sample: tuples in pinned host memory (positions as 16-bit differences) -> records in host memory" % (
+            "samples, 100-bp GC windows; one step = one sample: tuples in pinned host memory (positions as packed differences) -> records in host memory" % (
                 what, synth.N_DELS_GENOME, "" if config == "dels" else " + %d duplication rows" % synth.N_DUPS_GENOME,
                 per_sample, "" if config == "dels" else ", 100-mer-like mappability track", args.cov))
 
@@ -522,8 +524,8 @@ def main():
                 assert have == want, "gathered records differ from the fetched ones"
         mine = leg.mine
         reads_step = int(sum(len(u["reads"][0][0]) for u in mine))
-        # 16-bit differences + 8 bytes per exception; the MAPQ bytes stay on the host with the default threshold (never read: every read counts)
-        h2d_bytes = 2 * reads_step + 8 * len(leg.samples[0][4])
+        # W-bit differences + 8 bytes per exception; the MAPQ bytes stay on the host with the default threshold (never read: every read counts)
+        h2d_bytes = leg.samples[0][7] + 8 * len(leg.samples[0][4])
         cfg = dict(workload=workload_text(leg, args, args.config), samples_per_step=samples_per_step,
                    chromosomes_per_sample=len(leg.units) // samples_per_step, intervals_per_step=int(leg.total_iv),
                    reads_per_step_rank0=reads_step, rotation=("%d samples, one context" % N_ROTATE) if not dist_on else "%d samples x %d contexts" % (N_ROTATE, N_ROTATE),
@@ -549,9 +551,9 @@ def main():
         out["single_sample"] = dict(ms_per_step=round(1e3 * single_s, 4), value=round(leg.total_iv / single_s, 1),
                                     note="copy, kernels and fetch of one sample one after the other (latency of a step)")
         h2d = dict(bound="pcie-h2d", bytes_per_step=h2d_bytes, achieved=round(h2d_bytes / (ms_per_step * 1e-3) / 1e9, 2),
-                   peak=PCIE_PEAK_GBS, unit="GB/s", note="2 bytes per read (the positions as 16-bit differences, %d exceptions of 8 bytes; with "
+                   peak=PCIE_PEAK_GBS, unit="GB/s", note="%.2f bytes per read (the positions as %d-bit differences, %d exceptions of 8 bytes; with "
                    "--mq -1, the reference's default, the MAPQ bytes are never read and are not sent) over PCIe Gen5 x16 per step"
-                   % len(leg.samples[0][4]))
+                   % (leg.samples[0][6] / 8, leg.samples[0][6], len(leg.samples[0][4])))
         h2d["frac"] = round(h2d["achieved"] / PCIE_PEAK_GBS, 4)
         out["step_bound"] = h2d
 

@@ -38,7 +38,7 @@ KERNEL_NAMES = ("ingest", "depth_tile", "expected_table", "paint", "interval_red
 EXPORTS = (
     "conga_create", "conga_destroy", "conga_strerror", "conga_last_error", "conga_abi_version",
     "conga_device_count", "conga_reset", "conga_chrom_count", "conga_chrom_select", "conga_chrom_begin", "conga_reads_staging", "conga_reads_commit",
-    "conga_reads_bgzf", "conga_reads_bgzf_fd", "conga_release_staging", "conga_inflate_blocks", "conga_host_alloc", "conga_host_free", "conga_sample_reads", "conga_sample_reads_d16", "conga_sample_begin",
+    "conga_reads_bgzf", "conga_reads_bgzf_fd", "conga_release_staging", "conga_inflate_blocks", "conga_host_alloc", "conga_host_free", "conga_sample_reads", "conga_sample_reads_d16", "conga_sample_reads_packed", "conga_sample_begin",
     "conga_sample_chrom", "conga_sample_fetch",
     "conga_mappability", "conga_intervals", "conga_reference", "conga_satellites", "conga_split_reads_staging",
     "conga_split_reads_commit", "conga_split_support", "conga_chrom_compute",
@@ -121,6 +121,34 @@ def encode_d16(pos, chrom_off):
     return delta, idx, pos[idx].astype(np.int32)
 
 
+def encode_packed(pos, chrom_off, width=None):
+    """conga_sample_reads_packed's input: pos int32[n] -> (bits uint8[], width, esc_index uint32[k], esc_pos int32[k]).  width: 8, 10, 12
+    or 16; None picks the one that sends the fewest bytes (differences + 8 bytes per exception)."""
+    pos = np.ascontiguousarray(pos, dtype=np.int32)
+    n = len(pos)
+    d = np.full(n, -1, np.int64)
+    if n:
+        d[1:] = pos[1:].astype(np.int64) - pos[:-1].astype(np.int64)
+        firsts = np.asarray(chrom_off[:-1], np.int64)
+        firsts = firsts[(firsts < n) & (np.asarray(chrom_off[1:], np.int64) > firsts)]
+        d[firsts] = -1
+    if width is None:
+        cost = {w: n * w / 8 + 8 * int(np.count_nonzero((d < 0) | (d >= (1 << w) - 1))) for w in (8, 10, 12, 16)}
+        width = min(cost, key=cost.get)
+    top = (1 << width) - 1
+    esc = (d < 0) | (d >= top)
+    v = np.where(esc, top, d).astype("<u2")
+    idx = np.flatnonzero(esc).astype(np.uint32)
+    if width == 16:
+        bits = v.view(np.uint8).copy()
+    else:
+        pad = (-n) % 8
+        v = np.concatenate([v, np.zeros(pad, "<u2")])
+        b = np.unpackbits(v.view(np.uint8).reshape(-1, 2), axis=1, bitorder="little")[:, :width]
+        bits = np.packbits(b.reshape(-1), bitorder="little")
+    return bits, width, idx, pos[idx].astype(np.int32)
+
+
 def load():
     """dlopen the HIP library.  Raises (never falls back) when it has not been built."""
     global _lib
@@ -169,6 +197,8 @@ def load():
     L.conga_sample_reads.argtypes = [vp, vp, vp, vp, C.c_int]
     L.conga_sample_reads_d16.restype = C.c_int
     L.conga_sample_reads_d16.argtypes = [vp, vp, vp, vp, sz, vp, vp, C.c_int]
+    L.conga_sample_reads_packed.restype = C.c_int
+    L.conga_sample_reads_packed.argtypes = [vp, vp, C.c_int, vp, vp, sz, vp, vp, C.c_int]
     L.conga_sample_begin.restype = C.c_int
     L.conga_sample_begin.argtypes = [vp]
     L.conga_sample_chrom.restype = C.c_int
@@ -349,6 +379,14 @@ class Context:
             raise TypeError("sample_reads_d16 takes uint16 delta, uint32 esc_index, int32 esc_pos, uint8 mapq (or None), uint64 chrom_off")
         self._check(self._lib.conga_sample_reads_d16(self._h, delta.ctypes.data, esc_index.ctypes.data, esc_pos.ctypes.data, len(esc_index),
                                                      None if mapq is None else mapq.ctypes.data, chrom_off.ctypes.data, len(chrom_off) - 1))
+
+    def sample_reads_packed(self, bits, width, esc_index, esc_pos, mapq, chrom_off):
+        """conga_sample_reads_packed: the positions as `width`-bit differences + exceptions (encode_packed); arrays passed as they are."""
+        if bits.dtype != np.uint8 or esc_index.dtype != np.uint32 or esc_pos.dtype != np.int32 or chrom_off.dtype != np.uint64 \
+                or (mapq is not None and mapq.dtype != np.uint8):
+            raise TypeError("sample_reads_packed takes uint8 bits, uint32 esc_index, int32 esc_pos, uint8 mapq (or None), uint64 chrom_off")
+        self._check(self._lib.conga_sample_reads_packed(self._h, bits.ctypes.data, width, esc_index.ctypes.data, esc_pos.ctypes.data, len(esc_index),
+                                                        None if mapq is None else mapq.ctypes.data, chrom_off.ctypes.data, len(chrom_off) - 1))
 
     def sample_begin(self):
         self._check(self._lib.conga_sample_begin(self._h))

@@ -24,6 +24,7 @@
 #include <cstring>
 #include <new>
 #include <numeric>
+#include <type_traits>
 #include <memory>
 #include <string>
 #include <vector>
@@ -180,6 +181,7 @@ struct conga_ctx {
 	// carries nothing but copies, back to back), the scan's scratch; what the next compute has to expand first
 	DevBuf d_delta[2], d_delta_esc[2], d_delta_agg;
 	bool expand_pending = false;
+	int expand_width = 16;
 	uint64_t expand_total = 0;
 	size_t expand_n_esc = 0;
 	hipEvent_t ev_reads = nullptr;     // the copies of the last conga_sample_reads (on stream2)
@@ -1792,8 +1794,8 @@ int conga_sample_chrom(conga_ctx *ctx, int index)
 namespace {
 
 // conga_sample_reads / conga_sample_reads_d16: `pos` (32-bit positions) or `delta` + exceptions (16-bit differences)
-int sample_reads_impl(conga_ctx *ctx, const char *who, const int32_t *pos, const uint16_t *delta, const uint32_t *esc_index, const int32_t *esc_pos,
-		size_t n_esc, const uint8_t *mapq, const uint64_t *chrom_off, int n_chrom)
+int sample_reads_impl(conga_ctx *ctx, const char *who, const int32_t *pos, const uint8_t *delta, int width, const uint32_t *esc_index,
+		const int32_t *esc_pos, size_t n_esc, const uint8_t *mapq, const uint64_t *chrom_off, int n_chrom)
 {
 	if (!ctx || !chrom_off)
 		return CONGA_ERR_INVALID;
@@ -1811,6 +1813,8 @@ int sample_reads_impl(conga_ctx *ctx, const char *who, const int32_t *pos, const
 			return fail(ctx, CONGA_ERR_INVALID, std::string(who) + ": chrom_off must not decrease");
 	if (total >= 0xFFFFFFF0ull)
 		return fail(ctx, CONGA_ERR_RANGE, std::string(who) + ": more than 2^32 reads in one context");
+	if (packed && width != 8 && width != 10 && width != 12 && width != 16)
+		return fail(ctx, CONGA_ERR_INVALID, std::string(who) + ": differences are 8, 10, 12 or 16 bits wide");
 	if (packed) {
 		// the exceptions: sorted by index, one for the first read of every chromosome that has reads (nothing can be carried
 		// over a chromosome's border)
@@ -1856,11 +1860,12 @@ int sample_reads_impl(conga_ctx *ctx, const char *who, const int32_t *pos, const
 			// only the copies here: the differences are turned into positions by the compute that takes them up, on ITS stream
 			// (expand_positions), so that the next sample's copy follows this one's without a kernel in between
 			DevBuf &dd = ctx->d_delta[ctx->pos_buf], &de = ctx->d_delta_esc[ctx->pos_buf];
-			TRY(ensure(ctx, dd, ((size_t) total + 16) * 2));
+			const size_t d_bytes = ((size_t) total + 7) / 8 * (size_t) width; // (eight differences are `width` whole bytes)
+			TRY(ensure(ctx, dd, d_bytes + 64));
 			TRY(ensure(ctx, de, std::max<size_t>(n_esc, 1) * 8));
 			TRY(ensure(ctx, ctx->d_delta_agg, (size_t) ((total + kDeltaChunk - 1) / kDeltaChunk) * 12));
 			uint32_t *d_ei = ptr<uint32_t>(de);
-			HIP_TRY(ctx, hipMemcpyAsync(dd.p, delta, (size_t) total * 2, hipMemcpyHostToDevice, cs));
+			HIP_TRY(ctx, hipMemcpyAsync(dd.p, delta, ((size_t) total * (size_t) width + 7) / 8, hipMemcpyHostToDevice, cs));
 			if (n_esc) {
 				HIP_TRY(ctx, hipMemcpyAsync(d_ei, esc_index, n_esc * 4, hipMemcpyHostToDevice, cs));
 				HIP_TRY(ctx, hipMemcpyAsync(d_ei + n_esc, esc_pos, n_esc * 4, hipMemcpyHostToDevice, cs));
@@ -1868,6 +1873,7 @@ int sample_reads_impl(conga_ctx *ctx, const char *who, const int32_t *pos, const
 			ctx->expand_pending = true;
 			ctx->expand_total = total;
 			ctx->expand_n_esc = n_esc;
+			ctx->expand_width = width;
 		}
 		if (need_mapq)
 			HIP_TRY(ctx, hipMemcpyAsync(ctx->d_mapq.p, mapq, (size_t) total, hipMemcpyHostToDevice, cs));
@@ -1888,16 +1894,22 @@ extern "C" {
 
 int conga_sample_reads(conga_ctx *ctx, const int32_t *pos, const uint8_t *mapq, const uint64_t *chrom_off, int n_chrom)
 {
-	return sample_reads_impl(ctx, "conga_sample_reads", pos, nullptr, nullptr, nullptr, 0, mapq, chrom_off, n_chrom);
+	return sample_reads_impl(ctx, "conga_sample_reads", pos, nullptr, 0, nullptr, nullptr, 0, mapq, chrom_off, n_chrom);
+}
+
+int conga_sample_reads_packed(conga_ctx *ctx, const uint8_t *bits, int width, const uint32_t *esc_index, const int32_t *esc_pos, size_t n_esc,
+		const uint8_t *mapq, const uint64_t *chrom_off, int n_chrom)
+{
+	if (!bits && chrom_off && n_chrom >= 0 && chrom_off[n_chrom] != 0)
+		return CONGA_ERR_INVALID;
+	static const uint8_t none[16] = {0};
+	return sample_reads_impl(ctx, "conga_sample_reads_packed", nullptr, bits ? bits : none, width, esc_index, esc_pos, n_esc, mapq, chrom_off, n_chrom);
 }
 
 int conga_sample_reads_d16(conga_ctx *ctx, const uint16_t *delta, const uint32_t *esc_index, const int32_t *esc_pos, size_t n_esc,
 		const uint8_t *mapq, const uint64_t *chrom_off, int n_chrom)
 {
-	if (!delta && chrom_off && n_chrom >= 0 && chrom_off[n_chrom] != 0)
-		return CONGA_ERR_INVALID;
-	static const uint16_t none = 0;
-	return sample_reads_impl(ctx, "conga_sample_reads_d16", nullptr, delta ? delta : &none, esc_index, esc_pos, n_esc, mapq, chrom_off, n_chrom);
+	return conga_sample_reads_packed(ctx, reinterpret_cast<const uint8_t *>(delta), 16, esc_index, esc_pos, n_esc, mapq, chrom_off, n_chrom);
 }
 
 } // extern "C"
@@ -2439,14 +2451,24 @@ int conga_chrom_compute(conga_ctx *ctx)
 	if (ctx->expand_pending) { // ... as 16-bit differences (conga_sample_reads_d16): positions first -- delta16.hip.h
 		const uint64_t total = ctx->expand_total;
 		const uint32_t n_chunks = (uint32_t) ((total + kDeltaChunk - 1) / kDeltaChunk), n_esc = (uint32_t) ctx->expand_n_esc;
-		const uint16_t *dd = ptr<uint16_t>(ctx->d_delta[ctx->pos_buf]);
+		const uint8_t *dd = ptr<uint8_t>(ctx->d_delta[ctx->pos_buf]);
 		const uint32_t *d_ei = ptr<uint32_t>(ctx->d_delta_esc[ctx->pos_buf]);
 		const int32_t *d_ep = reinterpret_cast<const int32_t *>(d_ei + n_esc);
 		int2 *d_agg = ptr<int2>(ctx->d_delta_agg);
 		int32_t *d_carry = reinterpret_cast<int32_t *>(d_agg + n_chunks);
-		hipLaunchKernelGGL(delta_aggregate_kernel, dim3(n_chunks), dim3(256), 0, st, dd, total, d_ei, d_ep, n_esc, d_agg);
-		hipLaunchKernelGGL(delta_carry_kernel, dim3(1), dim3(1024), 0, st, d_agg, n_chunks, d_carry);
-		hipLaunchKernelGGL(delta_expand_kernel, dim3(n_chunks), dim3(256), 0, st, dd, total, d_ei, d_ep, n_esc, d_carry, ptr<int32_t>(ctx->d_pos));
+		int32_t *d_pos = ptr<int32_t>(ctx->d_pos);
+		auto launch = [&](auto width_tag) {
+			constexpr int W = decltype(width_tag)::value;
+			hipLaunchKernelGGL(delta_aggregate_kernel<W>, dim3(n_chunks), dim3(256), 0, st, dd, total, d_ei, d_ep, n_esc, d_agg);
+			hipLaunchKernelGGL(delta_carry_kernel, dim3(1), dim3(1024), 0, st, d_agg, n_chunks, d_carry);
+			hipLaunchKernelGGL(delta_expand_kernel<W>, dim3(n_chunks), dim3(256), 0, st, dd, total, d_ei, d_ep, n_esc, d_carry, d_pos);
+		};
+		switch (ctx->expand_width) {
+		case 8: launch(std::integral_constant<int, 8>()); break;
+		case 10: launch(std::integral_constant<int, 10>()); break;
+		case 12: launch(std::integral_constant<int, 12>()); break;
+		default: launch(std::integral_constant<int, 16>()); break;
+		}
 		HIP_TRY(ctx, hipGetLastError());
 		ctx->expand_pending = false;
 	}

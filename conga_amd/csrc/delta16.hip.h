@@ -1,13 +1,13 @@
-// delta16.hip.h -- read positions handed over as 16-bit differences (conga_sample_reads_d16).
+// delta16.hip.h -- read positions handed over as 8- to 16-bit differences (conga_sample_reads_packed / _d16).
 //
 // The step of a cohort is the copy of the sample's tuples over PCIe (bench.py: step_bound), and a position-sorted sample's
 // positions (bam1_core_t.pos in the order sam_itr_next yields them, bam_data.c:201-213) are a 32-bit number each only because
-// nobody subtracted: at 1x two neighbours are ~100 bases apart.  The producer sends pos[i] - pos[i - 1] in 16 bits; whatever
-// does not fit -- the first read of a chromosome, a gap of 65 535 bases or more, a position in front of its predecessor -- is
-// sent as 0xFFFF plus an entry (index, position) of a short exception list.  Here the differences become positions again:
+// nobody subtracted: at 1x two neighbours are ~100 bases apart.  The producer sends pos[i] - pos[i - 1] in W bits; whatever
+// does not fit -- the first read of a chromosome, a gap of 2^W - 1 bases or more, a position in front of its predecessor -- is
+// sent as all ones plus an entry (index, position) of a short exception list.  Here the differences become positions again:
 // a segmented inclusive scan (an exception restarts the sum) in three launches -- per-chunk aggregates, one workgroup's scan
 // over them, the chunks' local scans with their carry -- writing the int32 array every kernel of the path reads.  25.6 M reads:
-// 51 MB over the link instead of 102, and ~40 us of HBM-bound work that hides under the next sample's copy.
+// 51 MB (16 bits) or 32 MB (10 bits) over the link instead of 102, and ~40 us of HBM-bound work that hides under the next sample's copy.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -15,7 +15,9 @@
 namespace conga {
 
 constexpr int kDeltaChunk = 2048; // differences per workgroup: 256 threads x 8 (one 16-byte load each)
-constexpr uint32_t kDeltaEscape = 0xFFFFu;
+// The differences are W bits wide (W = 8, 10, 12 or 16: the producer picks what its coverage needs -- at 1x two neighbours are
+// ~100 bases apart and 10 bits hold all but one difference in ten thousand), packed little-endian: difference i occupies bits
+// [i * W, (i + 1) * W) of the byte stream.  Eight of them are W whole bytes: a thread's share starts on a byte.  All ones = exception.
 
 struct SegVal { // a run's sum and whether an exception (an absolute position) lies inside it
 	int32_t v;
@@ -45,27 +47,24 @@ __device__ __forceinline__ int32_t escape_value(const uint32_t *esc_index, const
 }
 
 // the thread's eight elements as segmented values, and their inclusive scan in place; -> the thread's aggregate
-__device__ __forceinline__ SegVal delta_thread_scan(const uint16_t *delta, uint64_t n, uint64_t first, const uint32_t *esc_index,
+// (the stream has 16 bytes of slack behind its last difference: one 16-byte load whatever W is)
+template <int W> __device__ __forceinline__ SegVal delta_thread_scan(const uint8_t *delta, uint64_t n, uint64_t first, const uint32_t *esc_index,
 		const int32_t *esc_pos, uint32_t n_esc, SegVal e[8])
 {
-	uint4 raw = make_uint4(0, 0, 0, 0);
-	if (first + 8 <= n)
-		raw = *reinterpret_cast<const uint4 *>(delta + first);
-	else {
-		uint16_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-		for (int k = 0; k < 8; k++)
-			if (first + k < n)
-				t[k] = delta[first + k];
-		raw = make_uint4(t[0] | (uint32_t) t[1] << 16, t[2] | (uint32_t) t[3] << 16, t[4] | (uint32_t) t[5] << 16, t[6] | (uint32_t) t[7] << 16);
-	}
-	const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+	constexpr uint32_t kEscape = (1u << W) - 1u;
+	uint64_t raw[2] = {0, 0};
+	if (first < n)
+		__builtin_memcpy(raw, delta + (first >> 3) * W, 16);
 	SegVal run = {0, 0u};
 #pragma unroll
 	for (int k = 0; k < 8; k++) {
-		const uint32_t d = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+		const int bit = k * W; // (known at compile time once the loop is unrolled)
+		const uint64_t lo = raw[bit >> 6] >> (bit & 63);
+		const uint64_t hi = ((bit & 63) + W > 64) ? raw[1] << (64 - (bit & 63)) : 0ull;
+		const uint32_t d = (uint32_t) (lo | hi) & kEscape;
 		SegVal x;
-		x.f = (d == kDeltaEscape && first + k < n) ? 1u : 0u;
-		x.v = x.f ? escape_value(esc_index, esc_pos, n_esc, (uint32_t) (first + k)) : (int32_t) d;
+		x.f = (d == kEscape && first + k < n) ? 1u : 0u;
+		x.v = x.f ? escape_value(esc_index, esc_pos, n_esc, (uint32_t) (first + k)) : (first + k < n ? (int32_t) d : 0);
 		run = seg_combine(run, x);
 		e[k] = run;
 	}
@@ -106,13 +105,13 @@ template <int W> __device__ __forceinline__ SegVal delta_block_exclusive(SegVal 
 }
 
 // launch 1: every chunk's aggregate
-__global__ __launch_bounds__(256) void delta_aggregate_kernel(const uint16_t *__restrict__ delta, uint64_t n, const uint32_t *__restrict__ esc_index,
+template <int W> __global__ __launch_bounds__(256) void delta_aggregate_kernel(const uint8_t *__restrict__ delta, uint64_t n, const uint32_t *__restrict__ esc_index,
 		const int32_t *__restrict__ esc_pos, uint32_t n_esc, int2 *__restrict__ agg)
 {
 	__shared__ SegVal s_wave[4];
 	SegVal e[8], all;
 	const uint64_t first = (uint64_t) blockIdx.x * kDeltaChunk + (uint64_t) threadIdx.x * 8;
-	const SegVal mine = delta_thread_scan(delta, n, first, esc_index, esc_pos, n_esc, e);
+	const SegVal mine = delta_thread_scan<W>(delta, n, first, esc_index, esc_pos, n_esc, e);
 	(void) delta_block_exclusive<4>(mine, s_wave, &all);
 	if (threadIdx.x == 0)
 		agg[blockIdx.x] = make_int2(all.v, (int) all.f);
@@ -144,13 +143,13 @@ __global__ __launch_bounds__(1024) void delta_carry_kernel(const int2 *__restric
 }
 
 // launch 3: the positions
-__global__ __launch_bounds__(256) void delta_expand_kernel(const uint16_t *__restrict__ delta, uint64_t n, const uint32_t *__restrict__ esc_index,
+template <int W> __global__ __launch_bounds__(256) void delta_expand_kernel(const uint8_t *__restrict__ delta, uint64_t n, const uint32_t *__restrict__ esc_index,
 		const int32_t *__restrict__ esc_pos, uint32_t n_esc, const int32_t *__restrict__ carry, int32_t *__restrict__ pos)
 {
 	__shared__ SegVal s_wave[4];
 	SegVal e[8];
 	const uint64_t first = (uint64_t) blockIdx.x * kDeltaChunk + (uint64_t) threadIdx.x * 8;
-	const SegVal mine = delta_thread_scan(delta, n, first, esc_index, esc_pos, n_esc, e);
+	const SegVal mine = delta_thread_scan<W>(delta, n, first, esc_index, esc_pos, n_esc, e);
 	SegVal before = delta_block_exclusive<4>(mine, s_wave, nullptr);
 	before = seg_combine(SegVal{carry[blockIdx.x], 0u}, before);
 	int32_t out[8];

@@ -243,6 +243,12 @@ int conga_sample_reads(conga_ctx *ctx, const int32_t *pos, const uint8_t *mapq, 
  * Everything said of conga_sample_reads above holds (mapq, lifetime of the arrays, double-buffering). */
 int conga_sample_reads_d16(conga_ctx *ctx, const uint16_t *delta, const uint32_t *esc_index, const int32_t *esc_pos, size_t n_esc,
 		const uint8_t *mapq, const uint64_t *chrom_off, int n_chrom);
+/* ... and as differences of `width` = 8, 10, 12 or 16 bits, packed little-endian: difference i occupies bits [i * width,
+ * (i + 1) * width) of `bits` (bit b of the stream is bit b & 7 of bits[b >> 3]; width 16 is conga_sample_reads_d16's array).  All ones
+ * = see the exception list.  The producer picks the width its coverage needs: at 1x two neighbours are ~100 bases apart and 10 bits
+ * hold all but one difference in ten thousand -- 1.25 bytes per read over the link. */
+int conga_sample_reads_packed(conga_ctx *ctx, const uint8_t *bits, int width, const uint32_t *esc_index, const int32_t *esc_pos, size_t n_esc,
+		const uint8_t *mapq, const uint64_t *chrom_off, int n_chrom);
 int conga_sample_begin(conga_ctx *ctx);
 int conga_sample_chrom(conga_ctx *ctx, int index);
 /* conga_chrom_fetch for every chromosome in one call: records[] receives conga_chrom_count() groups one behind the

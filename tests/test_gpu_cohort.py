@@ -253,6 +253,19 @@ def test_positions_as_16_bit_differences_give_the_same_records(capi, oracle, for
                 ctx.compute()
                 got, gotE, _ = ctx.sample_fetch()
                 assert got.tobytes() == want.tobytes() and gotE.tobytes() == wantE.tobytes()
+            # ... and as differences of 8, 10 and 12 bits (conga_sample_reads_packed): other exceptions, the same positions
+            n_exc = []
+            for width in (8, 10, 12, 16, None):
+                bits, w, ei2, ep2 = capi.encode_packed(pos[:int(off[-1])], off, width)
+                assert w == (width or w) and len(bits) == ((int(off[-1]) + 7) // 8 * w if w != 16 else 2 * int(off[-1]))
+                n_exc.append(len(ei2))
+                ctx.sample_reads_packed(np.concatenate([bits, np.zeros(32, np.uint8)]), w, ei2, ep2, mapq, off)
+                ctx.compute()
+                got, gotE, _ = ctx.sample_fetch()
+                assert got.tobytes() == want.tobytes() and gotE.tobytes() == wantE.tobytes(), width
+            assert n_exc[0] > n_exc[1] >= n_exc[2] >= n_exc[3] == len(ei)
+            with pytest.raises(capi.CongaError):
+                ctx.sample_reads_packed(bits, 11, ei2, ep2, mapq, off)  # (no such width)
             check_against_oracle(oracle, chroms, reads, got, gotE, False)
     # unsorted input: the exception carries the position as it is, the engine's order check sees it
     if formulation == "tuple_space":
