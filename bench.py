@@ -151,9 +151,9 @@ def pinned_samples(ctx, mine):
         # the same positions as a producer that subtracts sends them (conga_sample_reads_packed): differences of the width that
         # sends the fewest bytes at this coverage (10 bits at 1x) + exceptions
         bits, width, ei, ep = capi.encode_packed(pos[:at], off)
-        d_pin = ctx.host_alloc(len(bits) + 64, np.uint8)
-        d_pin[:len(bits)] = bits
-        d_pin[len(bits):] = 0
+        one = capi.pack_inline(bits, ei, ep)          # the exceptions behind the differences: one copy per sample
+        d_pin = ctx.host_alloc(len(one), np.uint8)
+        d_pin[:] = one
         out.append((pos, mapq, off, d_pin, ei, ep, width, len(bits)))
     return out
 
@@ -295,7 +295,10 @@ class Leg:
         subtracts sends: conga_sample_reads_d16) unless self.packed is off (32-bit positions: conga_sample_reads)."""
         pos, mapq, off, d_pin, ei, ep, width, _nb = self.samples[j]
         if self.packed:
-            c.sample_reads_packed(d_pin, width, ei, ep, mapq, off)
+            if os.environ.get("CONGA_BENCH_SEPARATE_EXCEPTIONS"):   # (measurement switch: three copies per sample instead of one)
+                c.sample_reads_packed(d_pin, width, ei, ep, mapq, off)
+            else:
+                c.sample_reads_packed(d_pin, width, len(ei), None, mapq, off)
         else:
             c.sample_reads(pos, mapq, off)
 

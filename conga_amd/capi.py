@@ -149,6 +149,16 @@ def encode_packed(pos, chrom_off, width=None):
     return bits, width, idx, pos[idx].astype(np.int32)
 
 
+def pack_inline(bits, esc_index, esc_pos):
+    """[differences | pad to 16 bytes | esc_index | esc_pos] as one uint8 array (conga_sample_reads_packed with esc_index == NULL)."""
+    at = (len(bits) + 15) & ~15
+    out = np.zeros(at + 8 * len(esc_index) + 64, np.uint8)
+    out[:len(bits)] = bits
+    out[at:at + 4 * len(esc_index)] = esc_index.view(np.uint8)
+    out[at + 4 * len(esc_index):at + 8 * len(esc_index)] = esc_pos.view(np.uint8)
+    return out
+
+
 def load():
     """dlopen the HIP library.  Raises (never falls back) when it has not been built."""
     global _lib
@@ -382,6 +392,10 @@ class Context:
 
     def sample_reads_packed(self, bits, width, esc_index, esc_pos, mapq, chrom_off):
         """conga_sample_reads_packed: the positions as `width`-bit differences + exceptions (encode_packed); arrays passed as they are."""
+        if isinstance(esc_index, int):   # the exceptions lie behind the differences in `bits` (pack_inline): one copy per sample
+            self._check(self._lib.conga_sample_reads_packed(self._h, bits.ctypes.data, width, None, None, esc_index,
+                                                            None if mapq is None else mapq.ctypes.data, chrom_off.ctypes.data, len(chrom_off) - 1))
+            return
         if bits.dtype != np.uint8 or esc_index.dtype != np.uint32 or esc_pos.dtype != np.int32 or chrom_off.dtype != np.uint64 \
                 or (mapq is not None and mapq.dtype != np.uint8):
             raise TypeError("sample_reads_packed takes uint8 bits, uint32 esc_index, int32 esc_pos, uint8 mapq (or None), uint64 chrom_off")

@@ -182,6 +182,7 @@ struct conga_ctx {
 	DevBuf d_delta[2], d_delta_esc[2], d_delta_agg;
 	bool expand_pending = false;
 	int expand_width = 16;
+	size_t expand_esc_at = (size_t) -1; // the exceptions lie behind the differences at this offset of d_delta (-1: in d_delta_esc)
 	uint64_t expand_total = 0;
 	size_t expand_n_esc = 0;
 	hipEvent_t ev_reads = nullptr;     // the copies of the last conga_sample_reads (on stream2)
@@ -1815,6 +1816,15 @@ int sample_reads_impl(conga_ctx *ctx, const char *who, const int32_t *pos, const
 		return fail(ctx, CONGA_ERR_RANGE, std::string(who) + ": more than 2^32 reads in one context");
 	if (packed && width != 8 && width != 10 && width != 12 && width != 16)
 		return fail(ctx, CONGA_ERR_INVALID, std::string(who) + ": differences are 8, 10, 12 or 16 bits wide");
+	// exceptions behind the differences in ONE buffer (esc_index == NULL): [differences | up to the next multiple of 16 bytes |
+	// esc_index[n_esc] | esc_pos[n_esc]] -- one DMA per sample instead of three (each carries tens of microseconds of its own)
+	const size_t d_bytes_host = packed ? ((size_t) total + 7) / 8 * (size_t) width : 0;
+	const size_t esc_at = (d_bytes_host + 15) & ~(size_t) 15;
+	const bool inline_esc = packed && n_esc > 0 && !esc_index && !esc_pos;
+	if (inline_esc) {
+		esc_index = reinterpret_cast<const uint32_t *>(delta + esc_at);
+		esc_pos = reinterpret_cast<const int32_t *>(delta + esc_at) + n_esc;
+	}
 	if (packed) {
 		// the exceptions: sorted by index, one for the first read of every chromosome that has reads (nothing can be carried
 		// over a chromosome's border)
@@ -1861,15 +1871,20 @@ int sample_reads_impl(conga_ctx *ctx, const char *who, const int32_t *pos, const
 			// (expand_positions), so that the next sample's copy follows this one's without a kernel in between
 			DevBuf &dd = ctx->d_delta[ctx->pos_buf], &de = ctx->d_delta_esc[ctx->pos_buf];
 			const size_t d_bytes = ((size_t) total + 7) / 8 * (size_t) width; // (eight differences are `width` whole bytes)
-			TRY(ensure(ctx, dd, d_bytes + 64));
+			TRY(ensure(ctx, dd, esc_at + n_esc * 8 + 64));
 			TRY(ensure(ctx, de, std::max<size_t>(n_esc, 1) * 8));
 			TRY(ensure(ctx, ctx->d_delta_agg, (size_t) ((total + kDeltaChunk - 1) / kDeltaChunk) * 12));
 			uint32_t *d_ei = ptr<uint32_t>(de);
-			HIP_TRY(ctx, hipMemcpyAsync(dd.p, delta, ((size_t) total * (size_t) width + 7) / 8, hipMemcpyHostToDevice, cs));
-			if (n_esc) {
-				HIP_TRY(ctx, hipMemcpyAsync(d_ei, esc_index, n_esc * 4, hipMemcpyHostToDevice, cs));
-				HIP_TRY(ctx, hipMemcpyAsync(d_ei + n_esc, esc_pos, n_esc * 4, hipMemcpyHostToDevice, cs));
+			if (inline_esc) // differences and exceptions in one go; the expansion finds the exceptions behind the differences
+				HIP_TRY(ctx, hipMemcpyAsync(dd.p, delta, esc_at + n_esc * 8, hipMemcpyHostToDevice, cs));
+			else {
+				HIP_TRY(ctx, hipMemcpyAsync(dd.p, delta, std::min(d_bytes, ((size_t) total * (size_t) width + 7) / 8), hipMemcpyHostToDevice, cs));
+				if (n_esc) {
+					HIP_TRY(ctx, hipMemcpyAsync(d_ei, esc_index, n_esc * 4, hipMemcpyHostToDevice, cs));
+					HIP_TRY(ctx, hipMemcpyAsync(d_ei + n_esc, esc_pos, n_esc * 4, hipMemcpyHostToDevice, cs));
+				}
 			}
+			ctx->expand_esc_at = inline_esc ? esc_at : (size_t) -1;
 			ctx->expand_pending = true;
 			ctx->expand_total = total;
 			ctx->expand_n_esc = n_esc;
@@ -2452,7 +2467,8 @@ int conga_chrom_compute(conga_ctx *ctx)
 		const uint64_t total = ctx->expand_total;
 		const uint32_t n_chunks = (uint32_t) ((total + kDeltaChunk - 1) / kDeltaChunk), n_esc = (uint32_t) ctx->expand_n_esc;
 		const uint8_t *dd = ptr<uint8_t>(ctx->d_delta[ctx->pos_buf]);
-		const uint32_t *d_ei = ptr<uint32_t>(ctx->d_delta_esc[ctx->pos_buf]);
+		const uint32_t *d_ei = ctx->expand_esc_at == (size_t) -1 ? ptr<uint32_t>(ctx->d_delta_esc[ctx->pos_buf])
+				: reinterpret_cast<const uint32_t *>(dd + ctx->expand_esc_at);
 		const int32_t *d_ep = reinterpret_cast<const int32_t *>(d_ei + n_esc);
 		int2 *d_agg = ptr<int2>(ctx->d_delta_agg);
 		int32_t *d_carry = reinterpret_cast<int32_t *>(d_agg + n_chunks);

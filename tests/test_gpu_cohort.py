@@ -264,6 +264,11 @@ def test_positions_as_16_bit_differences_give_the_same_records(capi, oracle, for
                 got, gotE, _ = ctx.sample_fetch()
                 assert got.tobytes() == want.tobytes() and gotE.tobytes() == wantE.tobytes(), width
             assert n_exc[0] > n_exc[1] >= n_exc[2] >= n_exc[3] == len(ei)
+            # the exceptions behind the differences in one buffer (one copy per sample)
+            ctx.sample_reads_packed(capi.pack_inline(bits, ei2, ep2), w, len(ei2), None, mapq, off)
+            ctx.compute()
+            got, gotE, _ = ctx.sample_fetch()
+            assert got.tobytes() == want.tobytes() and gotE.tobytes() == wantE.tobytes()
             with pytest.raises(capi.CongaError):
                 ctx.sample_reads_packed(bits, 11, ei2, ep2, mapq, off)  # (no such width)
             check_against_oracle(oracle, chroms, reads, got, gotE, False)
