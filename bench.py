@@ -4,17 +4,20 @@
 A "step" is one SAMPLE through the whole hot path, on the path the metric is defined on ("the timed kernel
 path starts from decoded tuples in pinned memory"; the producer seam is count_reads_bam, bam_data.c:192-221):
 
-    the sample's decoded (pos, mapq) tuples in pinned host memory
-      -> HBM over PCIe (conga_sample_reads)
+    the sample's decoded (pos, mapq) tuples in pinned host memory -- the positions as a producer that subtracts leaves them:
+    differences of 10 bits at 1x, plus a short exception list (conga_sample_reads_packed; `hand_over_int32`: 32-bit positions)
+      -> HBM over PCIe, and back into the int32 array the kernels read (a segmented scan)
       -> GC-stratified depth sums -> expected_read_depth[101] -> per-interval observed depth, serial-float expected
          chain, 3-state log-likelihoods, c-score, CN (conga_chrom_compute: two launches)
       -> the result records in host memory (conga_sample_fetch)
 
 The annotation, the call set and the tracks are the same for every sample of a cohort, so they are handed over once
 (the library's cohort mode) and every step only brings new tuples; successive steps rotate over three different
-samples and three contexts, so that the copy of sample k + 1 runs beside the kernels and the fetch of sample k (the
-records of every step are fetched; nothing is cached between steps).  `value` is the steady-state rate of that loop.
+samples through ONE context whose hand-over is double-buffered, so that the copy of sample k + 1 runs beside the kernels
+and the fetch of sample k (the records of every step are fetched; nothing is cached between steps).  `value` is the
+steady-state rate of that loop.
 Also on the line:
+  hand_over_int32 the same loop with 32-bit positions (rounds 2-3's hand-over); three_contexts: rounds 2-3's rotation over contexts
   single_sample   the same step unpipelined (copy, kernels, fetch one after the other), its latency
   kernel_only     the kernels alone on tuples already in HBM (round 1's `value`), rotating over the three resident
                   samples so that every launch streams from HBM, not from the 256 MiB Infinity Cache
