@@ -260,7 +260,7 @@ class Leg:
         self.E = [np.zeros((len(self.mine), 101), np.float32) for _ in range(N_ROTATE)]
         self.total_iv = self.n_iv_mine
         # handing the layout over is not a step: every context prepares its device layout here, once
-        self.packed = True
+        self.packed_reads = True
         self.rotate_contexts = False   # N = 1: True = rounds 2-3's loop over three contexts (kept as a figure of its own)
         for j, c in enumerate(self.ctxs):
             self.reads(c, j)
@@ -295,9 +295,9 @@ class Leg:
 
     def reads(self, c, j):
         """Sample j's tuples from pinned host memory into context c: the positions as 16-bit differences (what a producer that
-        subtracts sends: conga_sample_reads_d16) unless self.packed is off (32-bit positions: conga_sample_reads)."""
+        subtracts sends: conga_sample_reads_d16) unless self.packed_reads is off (32-bit positions: conga_sample_reads)."""
         pos, mapq, off, d_pin, ei, ep, width, _nb = self.samples[j]
-        if self.packed:
+        if self.packed_reads:
             if os.environ.get("CONGA_BENCH_SEPARATE_EXCEPTIONS"):   # (measurement switch: three copies per sample instead of one)
                 c.sample_reads_packed(d_pin, width, ei, ep, mapq, off)
             else:
@@ -545,9 +545,9 @@ def main():
 
     # ---- the same step with the positions as 32-bit numbers (rounds 2-3's hand-over), unpipelined, and the kernels alone (all
     # ranks take part: the step contains a gather)
-    leg.packed = False
+    leg.packed_reads = False
     e32 = leg.timed(args.steps, 2)
-    leg.packed = True
+    leg.packed_reads = True
     if rank == 0:
         out["hand_over_int32"] = dict(ms_per_step=round(1e3 * e32 / args.steps, 4), value=round(leg.total_iv * args.steps / e32, 1),
                                       bytes_per_step=4 * int(sum(len(u["reads"][0][0]) for u in leg.mine)),
