@@ -10,6 +10,7 @@
 // There is deliberately no CPU fallback anywhere in this file: without a HIP device
 // conga_create() returns NULL / CONGA_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <atomic>
@@ -33,7 +34,7 @@
 #include "kernels.hip.h"
 #include "delta16.hip.h"
 #include "kernels_bam.hip.h"
-#include "kmer_sort.h"
+#include "kmer_sort.hip.h"
 #include "split_map.hip.h"
 
 using namespace conga;
@@ -640,9 +641,11 @@ int prepare_layout(conga_ctx *ctx)
 			// scratch of the build, sized for the longest chromosome: its text, a sort key per position, the keys in sorted
 			// order, and what the sort asks for
 			DevBuf text;
-			size_t tmp_bytes = 0;
-			if (kmer_sort_positions(nullptr, &tmp_bytes, nullptr, nullptr, nullptr, (uint32_t) max_L, 21, ctx->stream) != 0)
-				return fail(ctx, CONGA_ERR_HIP, "10-mer index: sizing the sort failed");
+			// the sort's scratch: two (key, value) buffers to go back and forth between (the third pass writes the keys into the
+			// first one's keys and the positions where they stay), the (digit, tile) counts, the digits' totals and bases
+			const size_t max_n = ((size_t) max_L + 63) & ~(size_t) 63;
+			const size_t max_tiles = (max_n + kRadixTile - 1) / kRadixTile;
+			const size_t tmp_bytes = 3 * max_n * 4 + (size_t) kRadixBins * max_tiles * 4 + 2 * kRadixBins * 4;
 			int rc = ensure(ctx, text, (size_t) max_L + 64);
 			if (rc == CONGA_OK)
 				rc = ensure(ctx, ctx->d_kmer_keys, (size_t) max_L * 4 + 256);
@@ -663,10 +666,25 @@ int prepare_layout(conga_ctx *ctx)
 					hipLaunchKernelGGL(ref_pack_kernel, dim3(gp), dim3(256), 0, st, ptr<uint8_t>(text), h.L, refn, n_words);
 					const int gk = (int) std::min<int64_t>(((h.L + 7) / 8 + 255) / 256, (int64_t) ctx->n_cu * 16);
 					hipLaunchKernelGGL(kmer_key_kernel, dim3(gk), dim3(256), 0, st, refn, h.L, ptr<uint32_t>(ctx->d_kmer_keys));
-					size_t tb = tmp_bytes;
-					if (kmer_sort_positions(ctx->d_kmer_tmp.p, &tb, ptr<uint32_t>(ctx->d_kmer_keys), ptr<uint32_t>(ctx->d_kmer_sorted),
-							ptr<int32_t>(ctx->d_kmer_pos) + h.kpos_off, (uint32_t) h.L, 21, st) != 0)
-						rc = fail(ctx, CONGA_ERR_HIP, "10-mer index: the sort failed");
+					{
+						// three stable passes of 7 bits over the 21-bit keys (kmer_sort.hip.h)
+						const uint32_t n = (uint32_t) h.L, n_tiles = (uint32_t) ((h.L + kRadixTile - 1) / kRadixTile);
+						uint32_t *k0 = ptr<uint32_t>(ctx->d_kmer_keys), *kA = ptr<uint32_t>(ctx->d_kmer_sorted);
+						int32_t *vA = ptr<int32_t>(ctx->d_kmer_tmp);
+						uint32_t *kB = reinterpret_cast<uint32_t *>(vA + max_n);
+						int32_t *vB = reinterpret_cast<int32_t *>(kB + max_n);
+						uint32_t *counts = reinterpret_cast<uint32_t *>(vB + max_n), *totals = counts + (size_t) kRadixBins * max_tiles, *base = totals + kRadixBins;
+						const unsigned g = (n_tiles + kRadixWaves - 1) / kRadixWaves;
+						auto pass = [&](const uint32_t *ki, const int32_t *vi, int shift, uint32_t *ko, int32_t *vo) {
+							hipLaunchKernelGGL(radix_hist_kernel, dim3(g), dim3(64 * kRadixWaves), 0, st, ki, n, shift, n_tiles, counts);
+							hipLaunchKernelGGL(radix_scan_kernel, dim3(kRadixBins), dim3(1024), 0, st, counts, n_tiles, totals);
+							hipLaunchKernelGGL(radix_base_kernel, dim3(1), dim3(kRadixBins), 0, st, totals, base);
+							hipLaunchKernelGGL(radix_scatter_kernel, dim3(g), dim3(64 * kRadixWaves), 0, st, ki, vi, n, shift, n_tiles, counts, base, ko, vo);
+						};
+						pass(k0, nullptr, 0, kA, vA);
+						pass(kA, vA, kRadixBits, kB, vB);
+						pass(kB, vB, 2 * kRadixBits, kA, ptr<int32_t>(ctx->d_kmer_pos) + h.kpos_off);
+					}
 					const int gb = (int) std::min<int64_t>((h.L + 256) / 256, (int64_t) ctx->n_cu * 16);
 					hipLaunchKernelGGL(kmer_bounds_kernel, dim3(gb), dim3(256), 0, st, ptr<uint32_t>(ctx->d_kmer_sorted), h.L,
 							ptr<uint32_t>(ctx->d_kmer_offset) + (size_t) h.kidx * ((size_t) kKmerBuckets + 2));
@@ -1080,6 +1098,26 @@ void make_bz_ring(conga_ctx *ctx)
 	}
 }
 
+// cores this process may use: the affinity mask and the cgroup's CPU quota (a container's 16 of the machine's 256)
+unsigned cpus_allowed()
+{
+	static const unsigned n = [] {
+		unsigned c = std::max(1u, std::thread::hardware_concurrency());
+		cpu_set_t set;
+		if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0)
+			c = std::min(c, (unsigned) CPU_COUNT(&set));
+		if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+			char q[32] = "";
+			long long period = 0;
+			if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0)
+				c = std::min(c, (unsigned) std::max(1LL, (atoll(q) + period - 1) / period));
+			fclose(f);
+		}
+		return c;
+	}();
+	return n;
+}
+
 // where the compressed bytes are: in the caller's memory, or in a file (read with pread: no mapping, no page faults)
 struct ByteSource {
 	const uint8_t *bytes = nullptr;
@@ -1189,7 +1227,12 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const ByteSource &src, size_t 
 				return;
 		}
 	};
-	int n_threads = (int) std::min<size_t>(n_pieces, std::min<unsigned>(std::max(2u, std::thread::hardware_concurrency() * 3 / 4), (unsigned) kBzSlots));
+	// (half of the cores this process MAY use -- the cgroup's quota, not the machine's 256 --: 6-10 GB/s of page cache -> pinned
+	// memory per thread against a link of 45-55 GB/s.  With a quota of 16: 8 threads have a 1.4 GB file enqueued after 29-35 ms, 6
+	// after 28-34, 12 after 37-39 (profiles/r03d_upload_modes.log); the other half is the caller's -- a cohort reads the next sample's
+	// block table meanwhile on four threads -- and a quota overdrawn stalls them all: 12 + 16 threads made a 5x genome's upload take
+	// 450-1 200 ms instead of 290-370)
+	int n_threads = (int) std::min<size_t>(n_pieces, std::min<unsigned>(std::max(2u, cpus_allowed() / 2), (unsigned) kBzSlots));
 	if (const char *e = getenv("CONGA_BGZF_COPY_THREADS"))
 		n_threads = std::max(1, std::min(atoi(e), kBzSlots));
 	std::vector<std::thread> threads;

@@ -98,6 +98,9 @@ def cohort_times(d, bams, k_many, common, env_extra, tag, repeats=2):
         per = min(per, (done[-1] - done[0]) / (k_many - 1))
         if t < best:
             best, err = t, e
+    if os.environ.get("CONGA_BENCH_STDERR_DIR"):   # (the [timing] lines of the long run, for whoever wants the stages)
+        with open(os.path.join(os.environ["CONGA_BENCH_STDERR_DIR"], "conga_cohort_%s.err" % tag), "w") as f:
+            f.write(err)
     return t1, per, best, err
 
 

@@ -629,7 +629,11 @@ int read_bam_cohort(parameters *params, sonic *this_sonic)
 		std::unique_ptr<planned_input> mine_now = std::move(ahead);
 		std::thread planner;
 		if (k + 1 < samples.size())
-			planner = std::thread([&, k] { ahead = plan_input(params, this_sonic, samples[k + 1].first); });
+			planner = std::thread([&, k] {
+				plan_beside_upload = true;
+				ahead = plan_input(params, this_sonic, samples[k + 1].first);
+				plan_beside_upload = false;
+			});
 		params->bam_file = samples[k].first;
 		params->outdir.clear(); // (a prefix from the list is taken as it is; the default one already carries --out's directory)
 		params->outprefix = samples[k].second;

@@ -615,11 +615,9 @@ public:
 			conga_bgzf_block b;
 			uint64_t file_off;
 		};
-		// 1: *b filled (inflated_len may be 0: an empty block), *next set; 0: the piece ends inside this block; -1: not a block
-		auto block_at = [&](size_t at, conga_bgzf_block *b, size_t *next) -> int {
-			uint8_t h[18];
-			if (at + 18 > bytes->size || !bytes->read_at(at, h, 18))
-				return 0;
+		// 1: *b filled but for its trailer, *next set; 0: the piece ends inside this block; -1: not a block.  h = the header's
+		// first eighteen bytes (everything a BGZF writer's header has; a longer extra field is read behind them)
+		auto block_header = [&](size_t at, const uint8_t *h, conga_bgzf_block *b, size_t *next) -> int {
 			if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4))
 				return -1;
 			const unsigned xlen = h[10] | (h[11] << 8);
@@ -643,28 +641,40 @@ public:
 				return -1;
 			if (at + (size_t) bsize + 1 > bytes->size)
 				return 0; // the piece ends inside this block (only behind c_end)
-			uint8_t tail[8];
-			if (!bytes->read_at(at + (size_t) bsize + 1 - 8, tail, 8))
-				return 0;
 			memset(b, 0, sizeof *b);
 			b->data_off = at + 12 + xlen;
 			b->data_len = (uint32_t) ((size_t) bsize + 1 - 12 - xlen - 8);
-			memcpy(&b->crc32, tail, 4);
-			memcpy(&b->inflated_len, tail + 4, 4);
 			*next = at + (size_t) bsize + 1;
 			return 1;
 		};
-		// walks [from, until) of the piece; *arrived = where it stopped; false: something that is not a block
+		// walks [from, until) of the piece; *arrived = where it stopped; false: something that is not a block.  A block's
+		// trailer (CRC32, ISIZE) and the next block's header lie side by side: ONE read of 26 bytes per block (with the bytes
+		// behind a descriptor, a cohort's way, every read is a system call -- 0.8 M of them for a 5x genome's 407 000 blocks).
 		auto walk = [&](size_t from, size_t until, std::vector<found> *out, size_t *arrived) -> bool {
 			size_t at = from;
+			uint8_t h[18];
+			bool have_header = false;
 			while (at < until) {
+				if (!have_header && (at + 18 > bytes->size || !bytes->read_at(at, h, 18)))
+					break;
+				have_header = false;
 				conga_bgzf_block b;
 				size_t next = 0;
-				const int rc = block_at(at, &b, &next);
+				const int rc = block_header(at, h, &b, &next);
 				if (rc < 0)
 					return false;
 				if (rc == 0)
 					break;
+				uint8_t tn[26];
+				const size_t want = std::min<size_t>(26, bytes->size - (next - 8));
+				if (!bytes->read_at(next - 8, tn, want))
+					break;
+				memcpy(&b.crc32, tn, 4);
+				memcpy(&b.inflated_len, tn + 4, 4);
+				if (want == 26) {
+					memcpy(h, tn + 8, 18);
+					have_header = true;
+				}
 				if (b.inflated_len)
 					out->push_back(found{b, c_lo + at});
 				const uint64_t this_off = c_lo + at;
@@ -687,7 +697,9 @@ public:
 							starts.push_back(v >> 16);
 			std::sort(starts.begin(), starts.end());
 			starts.erase(std::unique(starts.begin(), starts.end()), starts.end());
-			const int n_threads = std::min(16, std::max(1, usable_cpus() / reader_share()));
+			// (beside another sample's upload -- a cohort plans sample k + 1 while sample k goes up -- a quarter of the cores: the
+			// upload's threads and these share one CPU quota, and a throttled upload is what the GPU then waits for)
+			const int n_threads = std::min(plan_beside_upload.load() ? 4 : 16, std::max(1, usable_cpus() / reader_share()));
 			// (CONGA_BAM_PARALLEL_MIN_KB: the tests walk small files in parts too)
 			const char *min_kb = getenv("CONGA_BAM_PARALLEL_MIN_KB");
 			const size_t min_bytes = min_kb ? (size_t) atoll(min_kb) << 10 : (size_t) 64 << 20;

@@ -262,6 +262,8 @@ int reader_share() { return g_reader_share; }
 
 // CPUs this process may actually use: the affinity mask, cut down to a cgroup v2 / v1 CPU quota when one is set
 // (a container on a 256-thread host is often allowed 16).
+std::atomic<bool> plan_beside_upload{false};
+
 int usable_cpus()
 {
 	int n = (int) std::thread::hardware_concurrency();

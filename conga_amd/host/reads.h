@@ -3,6 +3,7 @@
 // and coordinate-sorted BAM (bam_reader.cpp; needs the .bai only for random access, not used here).
 #pragma once
 #include <cstdint>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -98,6 +99,7 @@ bool load_fasta_chrom(const std::string &fasta_path, const std::string &name, in
 
 read_source *open_reads(const std::string &path, std::string *err);
 // Readers opened from now on size their inflate pool for 1/n of the host's threads (n readers run side by side).
+extern std::atomic<bool> plan_beside_upload; // device_plan() runs while another sample's bytes go up (read_bam_cohort)
 void set_reader_share(int n);
 int reader_share();
 int usable_cpus(); // affinity mask and cgroup CPU quota taken into account

@@ -248,13 +248,16 @@ def leg(args, env):
         common = ["--ref", "ref.fa", "--sonic", "a.cga", "--dels", "dels.bed", "--dups", "dups.bed", "--rp", "10"]
         e2e = {}
         for decode, envx, k in (("gpu", dict(CONGA_GPU_BAM="1"), 4), ("host", dict(CONGA_GPU_BAM="0"), 2)):
-            t1, per, t_k, err = e2e_bench.cohort_times(d, [bam], k, common, dict(envx, CONGA_TIMING="1"), decode, repeats=1)
+            t1, per, t_k, err = e2e_bench.cohort_times(d, [bam], k, common, dict(envx, CONGA_TIMING="1"), decode, repeats=2 if decode == "gpu" else 1)
             # (one call per sample; one per chromosome when a sample's stretch of the file is beyond the engine's piece limit)
             n_calls = err.count("conga_reads_bgzf:")
             assert "decoding on the host" not in err and (n_calls >= k if decode == "gpu" else n_calls == 0), err[-1500:]
             e2e[decode] = dict(decode=decode, first_sample_s=round(t1, 3), per_further_sample_ms=round(per, 1), samples=k, wall_s=round(t_k, 3),
                                intervals_per_s=round(n_iv / (per * 1e-3), 1), records_per_s=round(n_reads / (per * 1e-3), 1),
                                gpu_decode_calls_per_sample=n_calls // k)
+            if decode == "gpu":   # what the engine says about the last sample's BAM stage (CONGA_TIMING)
+                e2e[decode]["bam_stage_of_the_last_sample"] = [ln.split("] ", 1)[-1] for ln in err.splitlines()
+                                                               if "conga_reads_bgzf:" in ln or "overlapped upload:" in ln][-2:]
         for kind in ("svs", "dels", "dups"):
             a = open(os.path.join(d, "gpu_s1_%s.bed" % kind), "rb").read()
             assert a == open(os.path.join(d, "host_s1_%s.bed" % kind), "rb").read() and len(a) > 100, kind

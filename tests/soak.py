@@ -180,6 +180,9 @@ def main():
                     help="the command line on random BAM files (+ .bai): decode on the GPU (conga_reads_bgzf) against the host "
                          "decoders -- same three output files, same read counts")
     ap.add_argument("--split-reads", action="store_true", help="the --rp path: random references and whole BAM records")
+    ap.add_argument("--packed", action="store_true",
+                    help="cohort hand-overs: random samples behind random layouts through conga_sample_reads and through "
+                         "conga_sample_reads_packed at every width (exceptions separate and inline, beside the previous compute): same records")
     ap.add_argument("--bam-rp", action="store_true",
                     help="`conga --rp` on random BAMs with sequences: records mapped in place after the decode on the GPU (one call, and "
                          "one per chromosome) against the host decoders handing them over -- same files, same split-read counts")
@@ -254,6 +257,60 @@ def main():
             if a.seconds and time.time() - t0 > a.seconds:
                 break
         print("soak: %d random BAMs: decode on the GPU == host decoders (seed %d, %.0f s)" % (done, a.seed, time.time() - t0))
+        return
+    if a.packed:
+        from conga_amd import synth
+        for i in range(a.cases):
+            rng = np.random.default_rng([a.seed, 15_000_000 + i])
+            n_chr = int(rng.integers(1, 6))
+            chroms = []
+            for k in range(n_chr):
+                L = int(rng.choice([rng.integers(5_000, 100_000), rng.integers(100_000, 3_000_000)]))
+                c = synth.make_chrom(str(k + 1), L, cov=0.0, n_dels=int(rng.integers(1, 40)), n_dups=int(rng.integers(0, 10)), gaps=bool(rng.integers(0, 2)),
+                                     seed=int(rng.integers(1, 1 << 30)))
+                chroms.append((c, *synth.kept_sorted(c.del_start, c.del_end), *synth.kept_sorted(c.dup_start, c.dup_end)))
+            mq = int(rng.choice([-1, -1, 0, 30]))
+            with capi.Context(device=0, mq_threshold=mq, flags=capi.FLAG_BATCH) as ctx:
+                for c, ds, de, us, ue in chroms:
+                    ctx.chrom_begin(c.length, c.gc)
+                    ctx.intervals("D", ds, de)
+                    ctx.intervals("E", us, ue)
+                for smp in range(int(rng.integers(1, 4))):
+                    reads = []
+                    for c, *_r in chroms:
+                        cov = float(rng.choice([0.0, 0.02, 0.5, 1.0, 8.0]))
+                        p, m = synth.make_reads(c.length, c.gc, c.step, cov, 100, rng) if cov else (np.zeros(0, np.int32), np.zeros(0, np.uint8))
+                        if len(p) and rng.random() < 0.3:       # pile-ups and long gaps
+                            p = np.sort(np.concatenate([p, np.full(int(rng.integers(1, 300)), int(rng.integers(0, c.length)))])).astype(np.int32)
+                            lo = int(rng.integers(0, c.length))
+                            p = p[(p < lo) | (p > lo + int(rng.integers(1, 300_000)))]
+                            m = rng.integers(0, 61, len(p)).astype(np.uint8)
+                        reads.append((p, m))
+                    n = sum(len(p) for p, _ in reads)
+                    pos = np.concatenate([p for p, _ in reads]).astype(np.int32) if n else np.zeros(0, np.int32)
+                    mapq = np.concatenate([m for _, m in reads]).astype(np.uint8) if n else np.zeros(0, np.uint8)
+                    off = np.concatenate([[0], np.cumsum([len(p) for p, _ in reads])]).astype(np.uint64)
+                    pos_a, mapq_a = np.concatenate([pos, np.zeros(1, np.int32)]), np.concatenate([mapq, np.zeros(1, np.uint8)])
+                    ctx.sample_reads(pos_a, mapq_a, off)
+                    ctx.compute()
+                    want, wantE, _ = ctx.sample_fetch()
+                    for width in (8, 10, 12, 16, None):
+                        bits, w, ei, ep = capi.encode_packed(pos, off, width)
+                        if rng.random() < 0.5:
+                            ctx.sample_reads_packed(capi.pack_inline(bits, ei, ep), w, len(ei), None, mapq_a, off)
+                        else:
+                            ctx.sample_reads_packed(np.concatenate([bits, np.zeros(32, np.uint8)]), w, ei, ep, mapq_a, off)
+                        ctx.compute()
+                        got, gotE, _ = ctx.sample_fetch()
+                        if got.tobytes() != want.tobytes() or gotE.tobytes() != wantE.tobytes():
+                            print("FAILED packed case %d (seed %d): sample %d width %s, %d chromosomes, %d reads" % (i, a.seed, smp, width, n_chr, n), flush=True)
+                            raise SystemExit(1)
+            done += 1
+            if i % 10 == 9:
+                print("%d packed cases ok, %.0f s" % (done, time.time() - t0), flush=True)
+            if a.seconds and time.time() - t0 > a.seconds:
+                break
+        print("soak: %d layouts: conga_sample_reads_packed at every width == conga_sample_reads (seed %d, %.0f s)" % (done, a.seed, time.time() - t0))
         return
     if a.bam_rp:
         import re
