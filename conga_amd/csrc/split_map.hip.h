@@ -263,20 +263,115 @@ __device__ __forceinline__ int half_distance(const uint32_t *refn, int c, const 
 	return d;
 }
 
+// ---- the same comparison with WIDE loads.  A lane's loads are what this kernel is made of (the machine takes ~250 G divergent
+// 4-byte probes a second from L2 and ~55 G from beyond it, tools/gathercal.hip; a half read compared dword by dword is fifteen of
+// them per candidate): 56 bases of either side are 28 bytes -- two 16-byte loads give eight dwords, a funnel shift the seven
+// words of eight bases each.
+__device__ __forceinline__ void load_dwords8(const void *p, uint32_t r[8])
+{
+	uint4 a, b;
+	__builtin_memcpy(&a, p, 16);
+	__builtin_memcpy(&b, static_cast<const uint8_t *>(p) + 16, 16);
+	r[0] = a.x, r[1] = a.y, r[2] = a.z, r[3] = a.w, r[4] = b.x, r[5] = b.y, r[6] = b.z, r[7] = b.w;
+}
+
+// bases [s, s + 56) of the read as seven words of codes (read_codes' rules; up to 32 bytes from sq + s / 2 on are read: the
+// callers' buffers end with that much slack)
+__device__ __forceinline__ void read_words7(const uint8_t *sq, int s, uint32_t h[7])
+{
+	uint32_t u[8];
+	load_dwords8(sq + (s >> 1), u);
+#pragma unroll
+	for (int j = 0; j < 8; j++)
+		u[j] = __builtin_bswap32(u[j]);
+	const bool odd = (s & 1) != 0;
+#pragma unroll
+	for (int j = 0; j < 7; j++)
+		h[j] = norm_codes(odd ? (u[j] << 4) | (u[j + 1] >> 28) : u[j]);
+}
+
+// Hamming distance of the half read [from, from + n) -- h0 = its first 56 bases, read_words7(sq, from) -- and the reference at c
+__device__ __forceinline__ int half_distance_fwd(const uint32_t *refn, int c, const uint8_t *sq, int from, int n, const uint32_t h0[7])
+{
+	int d = 0;
+	for (int k0 = 0; k0 < n; k0 += 56) {
+		uint32_t r[8], hk[7];
+		load_dwords8(refn + ((c + k0) >> 3), r);
+		const uint32_t sh = ((uint32_t) (c + k0) & 7u) * 4u;
+		if (k0)
+			read_words7(sq, from + k0, hk);
+		const int m = n - k0;
+#pragma unroll
+		for (int j = 0; j < 7; j++)
+			if (8 * j < m)
+				d += codes_differ(funnel_codes(r[j], r[j + 1], sh) ^ (k0 ? hk[j] : h0[j]), min(8, m - 8 * j));
+	}
+	return d;
+}
+
+// ... and of its reverse complement and the reference at c: base k of the reverse complement is the complement of the half's
+// base n - 1 - k, so the half's base i meets the complement of reference base c + n - 1 - i -- the half's words as they are
+// against the reference's words from the window's END backwards, bits reversed.  (A window that starts within 56 bases of
+// the chromosome's first: the caller's dword-by-dword form.)
+__device__ __forceinline__ int half_distance_rev(const uint32_t *refn, int c, const uint8_t *sq, int from, int n, const uint32_t h0[7])
+{
+	int d = 0;
+	for (int k0 = 0; k0 < n; k0 += 56) {
+		const int t = c + n - k0 - 56; // word i of the load below: the eight bases from t + 8 i on; the half's word j meets word 6 - j
+		uint32_t r[8], hk[7];
+		load_dwords8(refn + (t >> 3), r);
+		const uint32_t sh = ((uint32_t) t & 7u) * 4u;
+		if (k0)
+			read_words7(sq, from + k0, hk);
+		const int m = n - k0;
+#pragma unroll
+		for (int j = 0; j < 7; j++)
+			if (8 * j < m)
+				d += codes_differ(__brev(funnel_codes(r[6 - j], r[7 - j], sh)) ^ (k0 ? hk[j] : h0[j]), min(8, m - 8 * j));
+	}
+	return d;
+}
+
 // The seed's bucket, or nothing (a seed with a letter outside ACGT; a bucket that init_hash_table dropped), from its first
 // position p > anchor - SR_LOOKAHEAD on: [k0, b1) of `positions`.  The caller walks it while p < anchor + SR_LOOKAHEAD
 // (abs(p - anchor) < SR_LOOKAHEAD, split_read.c:118,166): a read's window holds a position or two.
-__device__ __forceinline__ void bucket_from(const uint32_t *offset, const int32_t *positions, int hash, int64_t anchor, uint32_t &k0, uint32_t &b1)
+// A bucket's positions are spread over the chromosome, so where the window begins in it can be guessed (inv_len = 1 / L):
+// eight positions around the guess -- two 16-byte loads, one cache line as a rule -- usually hold the answer; when they do not,
+// a binary search of the side they point to does.  The answer never depends on the guess.
+__device__ __forceinline__ void bucket_from(const uint32_t *offset, const int32_t *positions, int hash, int64_t anchor, float inv_len, uint32_t &k0,
+		uint32_t &b1)
 {
 	k0 = b1 = 0;
 	if (hash < 0)
 		return;
 	uint2 b;
 	__builtin_memcpy(&b, offset + hash, 8);
-	if (b.y - b.x >= (uint32_t) kMaxSrHit)
+	const uint32_t size = b.y - b.x;
+	if (size >= (uint32_t) kMaxSrHit)
 		return;
 	const int64_t lo_pos = anchor - (kSrLookahead - 1);
 	uint32_t lo = b.x, hi = b.y;
+	if (size > 0 && lo_pos > 0) { // (lo_pos <= 0: the bucket's first position is the answer)
+		uint32_t w0 = b.x;
+		if (size > 8u) {
+			const uint32_t guess = (uint32_t) fminf((float) lo_pos * inv_len * (float) size, (float) (size - 1u));
+			w0 = b.x + min(max(guess, 4u) - 4u, size - 8u);
+		}
+		uint32_t w[8]; // (behind a chromosome's last bucket: the next chromosome's positions, or the buffer's slack)
+		load_dwords8(positions + w0, w);
+		const uint32_t in_bucket = min(size, 8u);
+		uint32_t below = 0;
+#pragma unroll
+		for (int i = 0; i < 8; i++)
+			below += ((uint32_t) i < in_bucket && (int64_t) (int32_t) w[i] < lo_pos) ? 1u : 0u;
+		if (below == 0u)
+			hi = w0; // (w0 itself qualifies, or is the bucket's end)
+		else if (below == in_bucket && w0 + in_bucket < b.y)
+			lo = w0 + in_bucket;
+		else
+			lo = hi = w0 + below;
+	} else
+		hi = lo;
 	while (lo < hi) { // first position >= lo_pos
 		const uint32_t mid = (lo + hi) >> 1;
 		if ((int64_t) positions[mid] < lo_pos)
@@ -339,6 +434,7 @@ __global__ __launch_bounds__(256) void split_map_kernel(SplitMapArgs g)
 		const int32_t *sat_s = g.sat_start + sl.sat_off, *sat_e = g.sat_end + sl.sat_off;
 		const uint32_t *offset = g.offset + (int64_t) sl.kidx * (kKmerBuckets + 2);
 		const int32_t *positions = g.positions + sl.kpos_off;
+		const float inv_len = 1.0f / (float) max(L, (int64_t) 1);
 
 		// ---- the record, and the gate of count_reads_bam (bam_data.c:205-207) and of find_split_reads (split_read.c:216)
 		bool alive = r < sl.n_sr;
@@ -408,14 +504,16 @@ __global__ __launch_bounds__(256) void split_map_kernel(SplitMapArgs g)
 		const int64_t hi_pos = anchor + kSrLookahead;
 		int size = 0, row_candidates = 0;
 		const int dist_max = (int) (0.05 * (double) n);
+		uint32_t h0[7] = {0, 0, 0, 0, 0, 0, 0}; // the half's first 56 bases
 		if (alive && n >= kKmerLen) {
-			bucket_from(offset, positions, seed_hash(read_codes(sq, from), read_codes(sq, from + 8)), anchor, f0, f1);
+			read_words7(sq, from, h0);
+			bucket_from(offset, positions, seed_hash(h0[0], h0[1]), anchor, inv_len, f0, f1);
 			int cf = 0;
 			for (uint32_t k = f0; k < f1 && cf < kMaxMapping; k++) { // (a hundred hits or more: the element is dropped whatever follows)
 				const int c = positions[k];
 				if ((int64_t) c >= hi_pos)
 					break;
-				if (half_distance(refn, c, sq, from, n, false) <= dist_max) {
+				if (half_distance_fwd(refn, c, sq, from, n, h0) <= dist_max) {
 					cf++;
 					int64_t a1, a2;
 					if (c > 0 && pair_geometry(anchor, c, l, a1, a2))
@@ -425,12 +523,13 @@ __global__ __launch_bounds__(256) void split_map_kernel(SplitMapArgs g)
 			size = cf;
 			if (cf < kMaxMapping) {
 				uint32_t r0, r1;
-				bucket_from(offset, positions, seed_hash(revcomp_codes(sq, from, n, 0), revcomp_codes(sq, from, n, 8)), anchor, r0, r1);
+				bucket_from(offset, positions, seed_hash(revcomp_codes(sq, from, n, 0), revcomp_codes(sq, from, n, 8)), anchor, inv_len, r0, r1);
 				for (uint32_t k = r0; k < r1 && size <= kMaxMapping; k++) {
 					const int c = positions[k];
 					if ((int64_t) c >= hi_pos)
 						break;
-					if (half_distance(refn, c, sq, from, n, true) <= dist_max)
+					const int d = c + n >= 56 + 8 ? half_distance_rev(refn, c, sq, from, n, h0) : half_distance(refn, c, sq, from, n, true);
+					if (d <= dist_max)
 						size++;
 				}
 			}
@@ -460,7 +559,7 @@ __global__ __launch_bounds__(256) void split_map_kernel(SplitMapArgs g)
 					break;
 				}
 				int64_t a1, a2;
-				if (c > 0 && pair_geometry(anchor, c, l, a1, a2) && half_distance(refn, c, sq, from, n, false) <= dist_max
+				if (c > 0 && pair_geometry(anchor, c, l, a1, a2) && half_distance_fwd(refn, c, sq, from, n, h0) <= dist_max
 						&& !is_satellite_lane(sat_s, sat_e, sl.n_sat, c, (int64_t) c + 1)) {
 					row = true;
 					is_del = (anchor < c && e == 0) || (anchor > c && e == 1);
