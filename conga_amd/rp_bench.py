@@ -146,6 +146,7 @@ def leg(args, env):
     `conga --cohort --rp` run, the decode on the GPU and the split-read stage reading the records where the inflate left them
     (bam_data.c:201-216 with find_split_reads inside the BAM loop).  Beside it: the same with the host decoders, and the
     kernels alone on records resident in HBM (handed over through the C-ABI's pinned staging)."""
+    import json
     import os
     import shutil
     import tempfile
@@ -224,8 +225,26 @@ def leg(args, env):
                              frac=round(alg / max(sr_ms, 1e-6) / 1e6 / 8000.0, 4), traffic=None,
                              records_per_s=round(n_reads / (sr_ms * 1e-3), 1),
                              note="HIP events around the launch on the context's stream (CONGA_FLAG_PROFILE); a lane per half-read "
-                                  "element: dependent 4-byte probes into 10-mer buckets spread over the whole index -- latency- and "
-                                  "request-bound, not a streaming kernel (counters: profiles/)"))
+                                  "element: 4-byte probes into 10-mer buckets spread over the whole index, each a 128-byte line "
+                                  "from beyond L2 -- bound by the rate of such fetches (random_fetch), not by streamed bytes"))
+    # HBM traffic and the bound that holds for this kernel, from the PMC campaign in profiles/ (per element, scaled to this run)
+    try:
+        with open(os.path.join(e2e_bench.ROOT, "profiles", "split_map_traffic.json")) as f:
+            tr = json.load(f)
+        n_el = out["split_elements"]
+        raw = tr["fetch_bytes_raw_per_element"] * n_el
+        cal = tr["random_probe_calibration"]
+        out["roofline"].update(
+            traffic=round(tr["hbm_bytes_per_launch"] / tr["elements"] * n_el),
+            traffic_source="profiles/split_map_traffic.json (rocprofv3 --pmc campaign %s, per half-read element; not measured in this run)" % tr["campaign"],
+            random_fetch=dict(unit="TB/s of FETCH_SIZE (raw: a 128-byte line counts 63 bytes)", achieved=round(raw / (sr_ms * 1e-3) / 1e12, 3),
+                              peak=round(cal["fetch_rate_raw_bytes_per_s"] / 1e12, 3),
+                              frac=round(raw / (sr_ms * 1e-3) / cal["fetch_rate_raw_bytes_per_s"], 3),
+                              line_fetches_per_element=round(tr["fetch_bytes_raw_per_element"] / cal["FETCH_SIZE_bytes_raw_per_probe_beyond_L2"], 2),
+                              peak_source="tools/gathercal.hip: %.1f G independent 4-byte probes a second into a 2 GiB table"
+                                          % (cal["probes_per_s_2GiB_table"] / 1e9)))
+    except (OSError, KeyError, ValueError):
+        pass
 
     # ---- the configuration's path: BAM files in, three files out
     d = tempfile.mkdtemp(prefix="conga_bench_rp_", dir=os.environ.get("CONGA_BENCH_TMP", "/tmp"))

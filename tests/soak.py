@@ -111,6 +111,13 @@ def random_split_case(rng):
         n = int(rng.integers(50, 3000))
         a, b = int(rng.integers(0, L - n)), int(rng.integers(0, L - n))
         ref[b:b + n] = ref[a:a + n]
+    comp = np.arange(256, dtype=np.uint8)
+    comp[[65, 67, 71, 84]] = [84, 71, 67, 65]
+    for _ in range(int(rng.integers(0, 5))):                        # inverted repeats: mappings of the reverse complement
+        n = int(rng.integers(50, 2000))
+        a = int(rng.integers(0, L - n))
+        b = int(np.clip(a + rng.integers(-150_000, 150_000), 0, L - n)) if rng.random() < 0.8 else int(rng.integers(0, min(L - n, 300)))
+        ref[b:b + n] = comp[ref[a:a + n][::-1]]
     for _ in range(int(rng.integers(0, 3))):
         a = int(rng.integers(0, L - 500))
         ref[a:a + int(rng.integers(1, 400))] = ord("N")
@@ -138,7 +145,7 @@ def random_split_case(rng):
         for k in range(int(rng.integers(25, 45)), 75, int(rng.integers(2, 9))):
             add(e0 - k, np.concatenate([ref[e0 - k:e0], ref[s0:s0 + 100 - k]]))
     for _ in range(int(rng.integers(0, 6000))):
-        l = int(rng.choice([100, 100, 101, 76, 70, 59, 60, 61, 151, 36, 250]))
+        l = int(rng.choice([100, 100, 101, 76, 70, 59, 60, 61, 151, 36, 250, 111, 113, 225, 400, 1021, 1022]))
         p = int(rng.integers(0, max(1, L - l - 1)))
         b = ref[p:p + l].copy()
         if rng.random() < 0.3:

@@ -100,6 +100,40 @@ def test_split_read_support_matches_the_oracle(capi, oracle, mq, min_len):
         assert counts[0] > 5_000 and counts[1] > 3_000
 
 
+def test_reverse_complement_mappings_and_long_reads(capi, oracle):
+    """Inverted repeats -- a half read's reverse complement maps -- at the chromosome's very start, within and beyond the
+    look-ahead, and reads of every length up to the 1 022 bases a half-read buffer holds (the comparison goes by 56 bases)."""
+    rng = np.random.default_rng(77)
+    L = 300_000
+    ref = rng.choice(np.frombuffer(b"ACGT", np.uint8), L)
+    comp = np.arange(256, dtype=np.uint8)
+    comp[[65, 67, 71, 84]] = [84, 71, 67, 65]
+    for a, b, n in ((40_000, 0, 1500), (90_000, 120_000, 3000), (10_000, 200_000, 2000), (150_000, 150_700, 600), (260_000, 3, 90)):
+        ref[b:b + n] = comp[ref[a:a + n][::-1]]
+    reads = []
+    for a, n in ((40_000, 1500), (90_000, 3000), (10_000, 2000), (150_000, 600), (260_000, 90), (0, 1500), (120_000, 3000)):
+        for l in (60, 61, 100, 111, 112, 113, 151, 224, 225, 250, 400, 1021, 1022):
+            for p in (a, a + 7, a + max(0, n - l), a + max(0, n - l) // 2):
+                b = ref[p:p + l].copy()
+                if len(b) == l and p > 0:
+                    if rng.random() < 0.5:
+                        b[rng.integers(0, l, 2)] = rng.choice(np.frombuffer(b"ACGTN", np.uint8), 2)
+                    reads.append((p, b))
+    reads.sort(key=lambda r: r[0])
+    lut = np.full(256, 15, np.uint8)
+    for k, v in CODE.items():
+        lut[k] = v
+    lq = np.array([len(r[1]) for r in reads], np.int32)
+    c = dict(L=L, ref=bytes(ref), ref_lower=bytes(ref), dels=[(50_000, 53_000)], dups=[(100_000, 104_000)],
+             pos=np.array([r[0] for r in reads], np.int32), mapq=np.full(len(reads), 60, np.uint8), flag=np.zeros(len(reads), np.uint16), lq=lq,
+             off=np.concatenate([[0], np.cumsum(lq)[:-1]]).astype(np.uint64), codes=lut[np.concatenate([r[1] for r in reads])],
+             qual=np.full(int(lq.sum()), 30, np.uint8), sat_s=np.zeros(0, np.int32), sat_e=np.zeros(0, np.int32))
+    (dels, dups, st), (od, ou, rows, counts) = run_both(capi, oracle, c, -1, 50)
+    assert (st.split_elements, st.split_mappings, st.split_del_rows, st.split_dup_rows) == tuple(int(x) for x in counts)
+    assert np.array_equal(dels["border_rp"], od["border_rp"]) and np.array_equal(dups["rp"], ou["rp"])
+    assert counts[1] > 1.5 * counts[0] > 0   # (forward at the read's own place and reverse in the inverted copy: about two mappings per element)
+
+
 def test_without_reference_or_reads_nothing_is_counted(capi):
     c = make_case(n_normal=200)
     ds, de = np.array([100_000], np.int32), np.array([103_000], np.int32)
