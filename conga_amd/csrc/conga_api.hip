@@ -1230,7 +1230,7 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const ByteSource &src, size_t 
 	// (half of the cores this process MAY use -- the cgroup's quota, not the machine's 256 --: 6-10 GB/s of page cache -> pinned
 	// memory per thread against a link of 45-55 GB/s.  With a quota of 16: 8 threads have a 1.4 GB file enqueued after 29-35 ms, 6
 	// after 28-34, 12 after 37-39 (profiles/r03d_upload_modes.log); the other half is the caller's -- a cohort reads the next sample's
-	// block table meanwhile on four threads -- and a quota overdrawn stalls them all: 12 + 16 threads made a 5x genome's upload take
+	// block table meanwhile on six threads -- and a quota overdrawn stalls them all: 12 + 16 threads made a 5x genome's upload take
 	// 450-1 200 ms instead of 290-370)
 	int n_threads = (int) std::min<size_t>(n_pieces, std::min<unsigned>(std::max(2u, cpus_allowed() / 2), (unsigned) kBzSlots));
 	if (const char *e = getenv("CONGA_BGZF_COPY_THREADS"))

@@ -697,9 +697,9 @@ public:
 							starts.push_back(v >> 16);
 			std::sort(starts.begin(), starts.end());
 			starts.erase(std::unique(starts.begin(), starts.end()), starts.end());
-			// (beside another sample's upload -- a cohort plans sample k + 1 while sample k goes up -- a quarter of the cores: the
+			// (beside another sample's upload -- a cohort plans sample k + 1 while sample k goes up -- six threads: the
 			// upload's threads and these share one CPU quota, and a throttled upload is what the GPU then waits for)
-			const int n_threads = std::min(plan_beside_upload.load() ? 4 : 16, std::max(1, usable_cpus() / reader_share()));
+			const int n_threads = std::min(plan_beside_upload.load() ? 6 : 16, std::max(1, usable_cpus() / reader_share()));
 			// (CONGA_BAM_PARALLEL_MIN_KB: the tests walk small files in parts too)
 			const char *min_kb = getenv("CONGA_BAM_PARALLEL_MIN_KB");
 			const size_t min_bytes = min_kb ? (size_t) atoll(min_kb) << 10 : (size_t) 64 << 20;
