@@ -16,6 +16,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <thread>
 
@@ -147,7 +148,10 @@ struct conga_ctx {
 			d_sr_mapq, d_sr_flag, d_sr_lq, d_sr_off, d_sr_data, d_sr_recoff, d_refn, d_kmer_keys, d_kmer_sorted, d_kmer_tmp, d_kmer_offset, d_kmer_pos, d_sr_slots,
 			// conga_reads_bgzf: compressed blocks, their table, the inflated stream, the decoders' scratch, the walk's per-segment results
 			d_bz_in, d_bz_blocks, d_bz_off, d_bz_out, d_bz_status, d_bz_scratch, d_bz_crc, d_bz_seg, d_bz_cnt, d_bz_first, d_bz_stop,
-			d_bz_bad, d_bz_at, d_bz_flag, d_bz_x2n;
+			d_bz_bad, d_bz_at, d_bz_flag, d_bz_x2n,
+			// the spare output set: bytes named ahead WITH their block table (conga_reads_bgzf_next_blocks) are inflated into it
+			// while the sample in front is still walked and computed; the call that takes them up swaps the sets
+			d_bz_out2, d_bz_blocks2, d_bz_off2, d_bz_status2;
 
 	// conga_reads_bgzf: the file's bytes go up through a ring of pinned pieces filled by host threads, inflate launches follow
 	uint8_t *h_bz_ring = nullptr;
@@ -163,6 +167,27 @@ struct conga_ctx {
 	std::atomic<bool> bz_third_ready{false};
 	hipStream_t bz_third = nullptr;
 	hipEvent_t ev_bz_third = nullptr;
+	// The upload is a JOB run by a thread of the context's own (BzJob below): conga_reads_bgzf* starts one and launches the
+	// inflates behind its batches; conga_reads_bgzf_next_fd queues the NEXT sample's behind it, into the other of two device
+	// buffers, so that sample k + 1 is on its way up while sample k is walked, computed and written out.
+	std::thread bz_up_thread;
+	std::mutex bz_up_mu;
+	std::condition_variable bz_up_cv;
+	std::deque<std::shared_ptr<struct BzJob>> bz_up_queue;
+	bool bz_up_quit = false, bz_up_busy = false;
+	// named ahead, not yet taken up by a conga_reads_bgzf_fd call: at most two (a cohort's planning thread may name sample k + 1
+	// before the call for sample k has taken ITS bytes up), in the order of their calls
+	std::vector<std::shared_ptr<struct BzJob>> bz_named;
+	bool bz_in_call = false; // a conga_reads_bgzf* call is between queueing its bytes and its return
+	uint8_t *bz_up_buf[2] = {nullptr, nullptr};
+	size_t bz_up_cap[2] = {0, 0};
+	std::shared_ptr<struct BzJob> bz_buf_owner[2]; // a buffer is its job's until the call that took the bytes up is through with them
+	uint64_t bz_up_tickets = 0;
+	bool bz_slot_used[12] = {};
+	const uint8_t *bz_in_now = nullptr; // the compressed bytes the last overlapped upload brought
+	hipStream_t bz_ahead[2] = {nullptr, nullptr}; // launch streams of the inflate ahead (lowest priority), made by its thread
+	hipEvent_t ev_bz_ahead[2] = {nullptr, nullptr};
+	std::shared_ptr<struct BzJob> bz_job_kept;
 
 	// pinned read-back
 	Small *h_small = nullptr;
@@ -1009,13 +1034,15 @@ int ensure_x2n(conga_ctx *ctx)
 	return CONGA_OK;
 }
 
-int launch_inflate(conga_ctx *ctx, size_t n_blocks, uint32_t lanes, hipStream_t st = nullptr, size_t b0 = 0)
+int launch_inflate(conga_ctx *ctx, size_t n_blocks, uint32_t lanes, hipStream_t st = nullptr, size_t b0 = 0, const uint8_t *in = nullptr)
 {
 	if (!st)
 		st = ctx->stream;
+	if (!in)
+		in = ptr<uint8_t>(ctx->d_bz_in);
 	if (lane_kernel_asked()) {
 		TRY(ensure(ctx, ctx->d_bz_scratch, (size_t) lanes * sizeof(InflateScratch)));
-		hipLaunchKernelGGL(bgzf_inflate_kernel, dim3(lanes / 64), dim3(64), 0, st, (uint32_t) n_blocks, ptr<uint8_t>(ctx->d_bz_in),
+		hipLaunchKernelGGL(bgzf_inflate_kernel, dim3(lanes / 64), dim3(64), 0, st, (uint32_t) n_blocks, in,
 				ptr<conga_bgzf_block>(ctx->d_bz_blocks) + b0, ptr<uint64_t>(ctx->d_bz_off) + b0, ptr<uint8_t>(ctx->d_bz_out),
 				ptr<InflateScratch>(ctx->d_bz_scratch), ptr<uint32_t>(ctx->d_bz_crc), ptr<uint8_t>(ctx->d_bz_status) + b0);
 		return CONGA_OK;
@@ -1028,11 +1055,11 @@ int launch_inflate(conga_ctx *ctx, size_t n_blocks, uint32_t lanes, hipStream_t 
 	const bool one_phase = which && strcmp(which, "wave1") == 0;
 	if (one_phase)
 		hipLaunchKernelGGL(iw::bgzf_inflate_wave_kernel<false>, dim3((unsigned) groups), dim3(64 * iw::kWavesPerGroup), 0, st, (uint32_t) n_blocks,
-				ptr<uint8_t>(ctx->d_bz_in), ptr<conga_bgzf_block>(ctx->d_bz_blocks) + b0, ptr<uint64_t>(ctx->d_bz_off) + b0,
+				in, ptr<conga_bgzf_block>(ctx->d_bz_blocks) + b0, ptr<uint64_t>(ctx->d_bz_off) + b0,
 				ptr<uint8_t>(ctx->d_bz_out), ptr<uint32_t>(ctx->d_bz_crc), ptr<uint32_t>(ctx->d_bz_x2n), ptr<uint8_t>(ctx->d_bz_status) + b0);
 	else
 		hipLaunchKernelGGL(iw::bgzf_inflate_wave_kernel<true>, dim3((unsigned) groups), dim3(64 * iw::kWavesPerGroup), 0, st, (uint32_t) n_blocks,
-				ptr<uint8_t>(ctx->d_bz_in), ptr<conga_bgzf_block>(ctx->d_bz_blocks) + b0, ptr<uint64_t>(ctx->d_bz_off) + b0,
+				in, ptr<conga_bgzf_block>(ctx->d_bz_blocks) + b0, ptr<uint64_t>(ctx->d_bz_off) + b0,
 				ptr<uint8_t>(ctx->d_bz_out), ptr<uint32_t>(ctx->d_bz_crc), ptr<uint32_t>(ctx->d_bz_x2n), ptr<uint8_t>(ctx->d_bz_status) + b0);
 	return CONGA_OK;
 }
@@ -1142,15 +1169,436 @@ struct ByteSource {
 	}
 };
 
-int upload_and_inflate_overlapped(conga_ctx *ctx, const ByteSource &src, size_t n_bytes, const conga_bgzf_block *blocks, size_t n_blocks)
+} // namespace
+
+// One sample's compressed bytes on their way to HBM (the context's upload thread runs it): host threads copy pieces of the
+// file into the ring of pinned buffers, each piece goes up on the copy stream as soon as it is full, and behind every batch of
+// pieces an event is recorded that the inflate launches of that batch wait for.
+struct BzJob {
+	ByteSource src;
+	size_t n_bytes = 0, piece = 0, n_pieces = 0, pieces_per_batch = 0, n_batches = 0;
+	int buf = -1;        // which of the context's two device buffers (taken when the job starts)
+	std::atomic<bool> released{false}; // nothing reads the buffer any more
+	uint64_t ticket = 0; // conga_reads_bgzf_next_fd's
+	std::mutex mu;
+	std::condition_variable cv;
+	std::vector<uint8_t> filled;
+	size_t issued = 0;        // pieces whose copy up has been enqueued
+	size_t batches_ready = 0; // batches whose event has been recorded
+	bool failed = false, short_read = false, done = false, started = false;
+	bool queued = false; // handed to the upload thread (bytes named ahead wait for the call in front of theirs to queue its own)
+	std::atomic<bool> cancel{false};
+	std::vector<hipEvent_t> ev_batch;
+	const uint8_t *d_bytes = nullptr; // where the bytes go (set when the job starts)
+	std::string error;
+	std::chrono::steady_clock::time_point t_queued, t_started;
+	double ms_enqueued = 0, ms_copy = 0, ms_wait = 0; // (CONGA_TIMING)
+	int n_threads = 0;
+	// inflate ahead (conga_reads_bgzf_next_blocks): a thread launches the batches' inflates into the context's spare output set
+	std::vector<conga_bgzf_block> blocks;
+	std::vector<uint64_t> out_off;
+	uint64_t total_out = 0;
+	std::thread inflater;
+	bool inflate_asked = false, inflate_done = false, inflate_ok = false; // (mu)
+	int launches_ahead = 0;
+	double ms_inflate_ahead = 0;
+	~BzJob()
+	{
+		if (inflater.joinable())
+			inflater.join();
+		for (hipEvent_t e : ev_batch)
+			if (e)
+				(void) hipEventDestroy(e);
+	}
+};
+
+namespace {
+
+void bz_run_job(conga_ctx *ctx, const std::shared_ptr<BzJob> &self)
+{
+	BzJob &job = *self;
+	auto ms_since = [](std::chrono::steady_clock::time_point t) {
+		return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+	};
+	auto give_up = [&](const std::string &why, bool short_read) {
+		std::lock_guard<std::mutex> g(job.mu);
+		job.failed = true;
+		job.short_read = job.short_read || short_read;
+		if (job.error.empty())
+			job.error = why;
+		job.done = true;
+		job.cv.notify_all();
+	};
+	job.t_started = std::chrono::steady_clock::now();
+	if (hipSetDevice(ctx->device) != hipSuccess)
+		return give_up("hipSetDevice", false);
+	{ // one of the two device buffers: the one no job owns, or whose job's bytes nobody reads any more
+		std::unique_lock<std::mutex> lk(ctx->bz_up_mu);
+		auto free_buf = [&]() {
+			for (int b = 0; b < 2; b++)
+				if (!ctx->bz_buf_owner[b] || ctx->bz_buf_owner[b]->released.load())
+					return b;
+			return -1;
+		};
+		ctx->bz_up_cv.wait(lk, [&] { return free_buf() >= 0 || job.cancel.load(); });
+		if (job.cancel.load()) {
+			lk.unlock();
+			return give_up("given up", false);
+		}
+		job.buf = free_buf();
+		ctx->bz_buf_owner[job.buf] = self;
+	}
+	// the device buffer (grown only: a cohort's samples are of a size) and the batches' events
+	if (ctx->bz_up_cap[job.buf] < job.n_bytes + 512) {
+		if (ctx->bz_up_buf[job.buf])
+			(void) hipFree(ctx->bz_up_buf[job.buf]);
+		ctx->bz_up_buf[job.buf] = nullptr;
+		ctx->bz_up_cap[job.buf] = 0;
+		const size_t want = job.n_bytes + job.n_bytes / 16 + 512;
+		if (hipMalloc((void **) &ctx->bz_up_buf[job.buf], want) != hipSuccess) {
+			(void) hipGetLastError();
+			return give_up("no device memory for the file's bytes", false);
+		}
+		ctx->bz_up_cap[job.buf] = want;
+	}
+	uint8_t *const d_dst = ctx->bz_up_buf[job.buf];
+	job.ev_batch.assign(job.n_batches, nullptr);
+	for (size_t k = 0; k < job.n_batches; k++)
+		if (hipEventCreateWithFlags(&job.ev_batch[k], hipEventDisableTiming) != hipSuccess)
+			return give_up("hipEventCreate", false);
+	{
+		std::lock_guard<std::mutex> g(job.mu);
+		job.d_bytes = d_dst;
+		job.started = true;
+	}
+	job.cv.notify_all();
+
+	const int n_slots = bz_slots();
+	const size_t piece = job.piece, n_pieces = job.n_pieces, n_bytes = job.n_bytes;
+	std::atomic<size_t> next_piece{0};
+	std::atomic<long long> us_copy{0}, us_wait{0};
+	const int device = ctx->device;
+	auto worker = [&]() {
+		(void) hipSetDevice(device);
+		for (;;) {
+			const size_t c = next_piece.fetch_add(1);
+			if (c >= n_pieces || job.cancel.load())
+				return;
+			const auto tw = std::chrono::steady_clock::now();
+			const int slot = (int) (c % (size_t) n_slots);
+			if (c >= (size_t) n_slots) { // the slot still holds piece c - n_slots until that one's copy up is done
+				std::unique_lock<std::mutex> lk(job.mu);
+				job.cv.wait(lk, [&] { return job.failed || job.issued > c - (size_t) n_slots; });
+				if (job.failed)
+					return;
+			}
+			// (a slot's first use in this job: the job before may have left its last pieces in the ring)
+			if ((c >= (size_t) n_slots || ctx->bz_slot_used[slot]) && hipEventSynchronize(ctx->ev_bz_slot[slot]) != hipSuccess) {
+				std::lock_guard<std::mutex> g(job.mu);
+				job.failed = true;
+				job.cv.notify_all();
+				return;
+			}
+			const size_t at = c * piece, len = std::min(piece, n_bytes - at);
+			const auto tc = std::chrono::steady_clock::now();
+			const bool got = job.src.fetch(at, ctx->h_bz_ring + (size_t) slot * kBzPiece, len);
+			us_wait += (long long) std::chrono::duration<double, std::micro>(tc - tw).count();
+			us_copy += (long long) std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tc).count();
+			{
+				std::lock_guard<std::mutex> g(job.mu);
+				job.filled[c] = 1;
+				if (!got)
+					job.failed = job.short_read = true; // (a file that ends early)
+			}
+			job.cv.notify_all();
+			if (!got)
+				return;
+		}
+	};
+	// (half of the cores this process MAY use -- the cgroup's quota, not the machine's 256 --: 6-10 GB/s of page cache -> pinned
+	// memory per thread against a link of 45-55 GB/s.  With a quota of 16: 8 threads have a 1.4 GB file enqueued after 29-35 ms, 6
+	// after 28-34, 12 after 37-39 (profiles/r03d_upload_modes.log); the other half is the caller's -- a cohort reads the next sample's
+	// block table meanwhile on six threads -- and a quota overdrawn stalls them all: 12 + 16 threads made a 5x genome's upload take
+	// 450-1 200 ms instead of 290-370)
+	int n_threads = (int) std::min<size_t>(n_pieces, std::min<unsigned>(std::max(2u, cpus_allowed() / 2), (unsigned) n_slots));
+	if (const char *e = getenv("CONGA_BGZF_COPY_THREADS"))
+		n_threads = std::max(1, std::min(atoi(e), n_slots));
+	job.n_threads = n_threads;
+	std::vector<std::thread> threads;
+	for (int t = 0; t < n_threads; t++)
+		threads.emplace_back(worker);
+
+	std::string why;
+	for (size_t c = 0; c < n_pieces && why.empty(); c++) {
+		{
+			std::unique_lock<std::mutex> lk(job.mu);
+			job.cv.wait(lk, [&] { return job.failed || job.filled[c] || job.cancel.load(); });
+			if (job.failed || job.cancel.load()) {
+				why = job.cancel.load() ? "given up" : job.short_read ? "the file ends inside the piece that was named" : "waiting for a pinned piece failed";
+				break;
+			}
+		}
+		const size_t at = c * piece, len = std::min(piece, n_bytes - at);
+		const int slot = (int) (c % (size_t) n_slots);
+		hipError_t e = hipMemcpyAsync(d_dst + at, ctx->h_bz_ring + (size_t) slot * kBzPiece, len, hipMemcpyHostToDevice, ctx->bz_copy);
+		if (e == hipSuccess)
+			e = hipEventRecord(ctx->ev_bz_slot[slot], ctx->bz_copy);
+		ctx->bz_slot_used[slot] = true;
+		const bool batch_end = (c + 1) % job.pieces_per_batch == 0 || c + 1 == n_pieces;
+		const size_t batch = c / job.pieces_per_batch;
+		if (e == hipSuccess && batch_end)
+			e = hipEventRecord(job.ev_batch[batch], ctx->bz_copy);
+		if (e != hipSuccess) {
+			why = std::string("copy up: ") + hipGetErrorString(e);
+			break;
+		}
+		{
+			std::lock_guard<std::mutex> g(job.mu);
+			job.issued = c + 1;
+			if (batch_end)
+				job.batches_ready = batch + 1;
+		}
+		job.cv.notify_all();
+	}
+	if (!why.empty()) {
+		std::lock_guard<std::mutex> g(job.mu);
+		job.failed = true;
+		if (job.error.empty())
+			job.error = why;
+	}
+	job.cv.notify_all();
+	for (std::thread &t : threads)
+		t.join();
+	job.ms_enqueued = ms_since(job.t_started);
+	job.ms_copy = us_copy / 1e3 / n_threads;
+	job.ms_wait = us_wait / 1e3 / n_threads;
+	{
+		std::lock_guard<std::mutex> g(job.mu);
+		job.done = true;
+	}
+	job.cv.notify_all();
+}
+
+void bz_upload_loop(conga_ctx *ctx)
+{
+	for (;;) {
+		std::shared_ptr<BzJob> job;
+		{
+			std::unique_lock<std::mutex> lk(ctx->bz_up_mu);
+			ctx->bz_up_busy = false;
+			ctx->bz_up_cv.notify_all();
+			ctx->bz_up_cv.wait(lk, [&] { return ctx->bz_up_quit || !ctx->bz_up_queue.empty(); });
+			if (ctx->bz_up_queue.empty())
+				return; // (quit, nothing left)
+			job = ctx->bz_up_queue.front();
+			ctx->bz_up_queue.pop_front();
+			ctx->bz_up_busy = true;
+		}
+		if (job->cancel.load()) {
+			std::lock_guard<std::mutex> g(job->mu);
+			job->failed = job->done = true;
+			job->error = "given up";
+			job->cv.notify_all();
+			continue;
+		}
+		bz_run_job(ctx, job);
+	}
+}
+
+void bz_enqueue(conga_ctx *ctx, const std::shared_ptr<BzJob> &job) // (bz_up_mu held by the caller)
+{
+	if (job->queued)
+		return;
+	job->queued = true;
+	job->t_queued = std::chrono::steady_clock::now();
+	if (!ctx->bz_up_thread.joinable())
+		ctx->bz_up_thread = std::thread(bz_upload_loop, ctx);
+	ctx->bz_up_queue.push_back(job);
+	ctx->bz_up_cv.notify_all();
+}
+
+// a job for n_bytes of `src`, queued behind whatever the upload thread is doing if `now` (bz_up_mu held by the caller)
+std::shared_ptr<BzJob> bz_queue_job(conga_ctx *ctx, const ByteSource &src, size_t n_bytes, bool now = true)
+{
+	std::shared_ptr<BzJob> job = std::make_shared<BzJob>();
+	job->src = src;
+	job->n_bytes = n_bytes;
+	size_t piece = kBzPiece; // (tests: small pieces, so that a small file goes through every part of this)
+	if (const char *e = getenv("CONGA_BGZF_PIECE_KB"))
+		piece = std::min(kBzPiece, std::max<size_t>(4096, (size_t) atol(e) << 10));
+	job->piece = piece;
+	job->n_pieces = (n_bytes + piece - 1) / piece;
+	// a batch = what one inflate launch takes with three launch streams: 128 MB (small test pieces: sixteen of them)
+	job->pieces_per_batch = piece < kBzPiece ? (size_t) kBzPiecesPerLaunch : std::max<size_t>(1, ((size_t) 128 << 20) / piece);
+	job->n_batches = (job->n_pieces + job->pieces_per_batch - 1) / job->pieces_per_batch;
+	job->filled.assign(job->n_pieces, 0);
+	job->t_queued = std::chrono::steady_clock::now();
+	if (now)
+		bz_enqueue(ctx, job);
+	return job;
+}
+
+// the job's device buffer may be written again
+void bz_release(conga_ctx *ctx, const std::shared_ptr<BzJob> &job)
+{
+	if (!job)
+		return;
+	std::lock_guard<std::mutex> g(ctx->bz_up_mu);
+	job->released.store(true);
+	ctx->bz_up_cv.notify_all();
+}
+
+// gives a job up and waits until the upload thread is through with it
+void bz_abandon(conga_ctx *ctx, const std::shared_ptr<BzJob> &job)
+{
+	if (!job)
+		return;
+	job->cancel.store(true);
+	job->cv.notify_all();
+	{
+		std::lock_guard<std::mutex> g(ctx->bz_up_mu);
+		ctx->bz_up_cv.notify_all(); // (it may be waiting for a buffer)
+		if (!job->queued) { // (never handed to the upload thread: nobody else will say it is done)
+			std::lock_guard<std::mutex> g2(job->mu);
+			job->failed = job->done = true;
+		}
+	}
+	{
+		std::unique_lock<std::mutex> lk(job->mu);
+		job->cv.wait(lk, [&] { return job->done && (!job->inflate_asked || job->inflate_done); });
+	}
+	if (job->inflater.joinable())
+		job->inflater.join();
+	if (job->inflate_asked && ctx->bz_ahead[0])
+		for (int k = 0; k < 2; k++)
+			(void) hipStreamSynchronize(ctx->bz_ahead[k]); // (what it launched reads the job's bytes)
+	bz_release(ctx, job);
+}
+
+// everything the upload thread has been given is through (conga_release_staging, conga_destroy)
+void bz_upload_quiesce(conga_ctx *ctx, bool quit)
+{
+	std::vector<std::shared_ptr<BzJob>> pre;
+	{
+		std::lock_guard<std::mutex> g(ctx->bz_up_mu);
+		pre.swap(ctx->bz_named);
+	}
+	for (const std::shared_ptr<BzJob> &j : pre)
+		bz_abandon(ctx, j);
+	bz_release(ctx, ctx->bz_job_kept); // (the call that took those bytes up has returned: nothing reads them)
+	{
+		std::unique_lock<std::mutex> lk(ctx->bz_up_mu);
+		ctx->bz_up_cv.wait(lk, [&] { return ctx->bz_up_queue.empty() && !ctx->bz_up_busy; });
+		if (quit)
+			ctx->bz_up_quit = true;
+		ctx->bz_up_cv.notify_all();
+	}
+	if (quit && ctx->bz_up_thread.joinable())
+		ctx->bz_up_thread.join();
+}
+
+// a device buffer of the spare set, grown without a word to the context (this runs beside the caller's thread)
+bool quiet_ensure(DevBuf &b, size_t bytes)
+{
+	if (bytes <= b.cap)
+		return true;
+	size_t want = std::max(bytes, b.cap + b.cap / 16);
+	want = (want + 255) & ~(size_t) 255;
+	void *np = nullptr;
+	if (hipMalloc(&np, want) != hipSuccess) {
+		(void) hipGetLastError();
+		return false;
+	}
+	if (b.p)
+		(void) hipFree(b.p); // (nothing uses the spare set: the call that swapped it out has returned behind its walks)
+	b.p = np;
+	b.cap = want;
+	return true;
+}
+
+void bz_inflate_ahead(conga_ctx *ctx, const std::shared_ptr<BzJob> &self)
+{
+	BzJob &job = *self;
+	const auto t0 = std::chrono::steady_clock::now();
+	bool ok = hipSetDevice(ctx->device) == hipSuccess;
+	const size_t n_blocks = job.blocks.size();
+	ok = ok && quiet_ensure(ctx->d_bz_blocks2, n_blocks * sizeof(conga_bgzf_block)) && quiet_ensure(ctx->d_bz_off2, n_blocks * 8)
+			&& quiet_ensure(ctx->d_bz_out2, (size_t) job.total_out + 64) && quiet_ensure(ctx->d_bz_status2, n_blocks);
+	if (ok && !ctx->bz_ahead[0]) {
+		int lo = 0, hi = 0;
+		ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
+		for (int k = 0; ok && k < 2; k++)
+			ok = hipStreamCreateWithPriority(&ctx->bz_ahead[k], hipStreamNonBlocking, lo) == hipSuccess
+					&& hipEventCreateWithFlags(&ctx->ev_bz_ahead[k], hipEventDisableTiming) == hipSuccess;
+	}
+	if (ok) {
+		ok = hipMemcpyAsync(ctx->d_bz_blocks2.p, job.blocks.data(), n_blocks * sizeof(conga_bgzf_block), hipMemcpyHostToDevice, ctx->bz_ahead[0]) == hipSuccess
+				&& hipMemcpyAsync(ctx->d_bz_off2.p, job.out_off.data(), n_blocks * 8, hipMemcpyHostToDevice, ctx->bz_ahead[0]) == hipSuccess
+				&& hipMemsetAsync(ctx->d_bz_status2.p, 0xFF, n_blocks, ctx->bz_ahead[0]) == hipSuccess
+				&& hipEventRecord(ctx->ev_bz_ahead[0], ctx->bz_ahead[0]) == hipSuccess
+				&& hipStreamWaitEvent(ctx->bz_ahead[1], ctx->ev_bz_ahead[0], 0) == hipSuccess;
+	}
+	size_t b_done = 0;
+	int launches = 0;
+	for (size_t batch = 0; ok && batch < job.n_batches; batch++) {
+		{
+			std::unique_lock<std::mutex> lk(job.mu);
+			job.cv.wait(lk, [&] { return job.failed || job.cancel.load() || job.batches_ready > batch; });
+			if (job.failed || job.cancel.load()) {
+				ok = false;
+				break;
+			}
+		}
+		const bool last = batch + 1 == job.n_batches;
+		const size_t have = std::min(job.n_bytes, (batch + 1) * job.pieces_per_batch * job.piece);
+		size_t b1 = b_done;
+		while (b1 < n_blocks && job.blocks[b1].data_off + job.blocks[b1].data_len <= have)
+			b1++;
+		if (last)
+			b1 = n_blocks;
+		if (b1 > b_done) {
+			hipStream_t ks = ctx->bz_ahead[launches % 2];
+			ok = hipStreamWaitEvent(ks, job.ev_batch[batch], 0) == hipSuccess;
+			if (ok) {
+				const size_t n = b1 - b_done;
+				const size_t groups = std::min<size_t>((n + iw::kWavesPerGroup - 1) / iw::kWavesPerGroup, (size_t) ctx->n_cu * 8);
+				hipLaunchKernelGGL(iw::bgzf_inflate_wave_kernel<true>, dim3((unsigned) groups), dim3(64 * iw::kWavesPerGroup), 0, ks, (uint32_t) n,
+						job.d_bytes, ptr<conga_bgzf_block>(ctx->d_bz_blocks2) + b_done, ptr<uint64_t>(ctx->d_bz_off2) + b_done,
+						ptr<uint8_t>(ctx->d_bz_out2), ptr<uint32_t>(ctx->d_bz_crc), ptr<uint32_t>(ctx->d_bz_x2n), ptr<uint8_t>(ctx->d_bz_status2) + b_done);
+				ok = hipGetLastError() == hipSuccess;
+			}
+			launches++;
+			b_done = b1;
+		}
+	}
+	for (int k = 0; ok && k < 2; k++)
+		ok = hipEventRecord(ctx->ev_bz_ahead[k], ctx->bz_ahead[k]) == hipSuccess;
+	if (!ok)
+		(void) hipGetLastError();
+	job.launches_ahead = launches;
+	job.ms_inflate_ahead = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	{
+		std::lock_guard<std::mutex> g(job.mu);
+		job.inflate_ok = ok;
+		job.inflate_done = true;
+	}
+	job.cv.notify_all();
+}
+
+// *inflated: the bytes named ahead came with their block table and are inflated (the launches are enqueued) in what is now the
+// context's output set -- the caller goes straight to its walks
+int upload_and_inflate_overlapped(conga_ctx *ctx, const ByteSource &src, size_t n_bytes, const conga_bgzf_block *blocks, size_t n_blocks,
+		uint64_t base)
 {
 	const bool timing = getenv("CONGA_TIMING") != nullptr;
 	const auto t0 = std::chrono::steady_clock::now();
 	auto ms_since = [](std::chrono::steady_clock::time_point t) {
 		return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
 	};
-	if (!ctx->h_bz_ring && !ctx->bz_ring_failed)
+	if (!ctx->h_bz_ring && !ctx->bz_ring_failed) {
+		bz_upload_quiesce(ctx, false); // (nothing of ours is in the ring: it is not there)
 		make_bz_ring(ctx);
+	}
 	if (ctx->bz_ring_failed || !ctx->h_bz_ring)
 		return fail(ctx, CONGA_ERR_NOMEM, "conga_reads_bgzf: no pinned staging ring");
 	TRY(ensure_x2n(ctx));
@@ -1163,150 +1611,159 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const ByteSource &src, size_t 
 		ctx->n_bz_streams = 3;
 	}
 	const double ms_ring = ms_since(t0);
-	size_t piece = kBzPiece; // (tests: small pieces, so that a small file goes through every part of this)
-	if (const char *e = getenv("CONGA_BGZF_PIECE_KB"))
-		piece = std::min(kBzPiece, std::max<size_t>(4096, (size_t) atol(e) << 10));
-	const size_t n_pieces = (n_bytes + piece - 1) / piece;
+	// (the call before has returned behind its walks: nothing reads its compressed bytes any more)
+	bz_release(ctx, ctx->bz_job_kept);
+	ctx->bz_job_kept.reset();
+	// The bytes: already on their way when conga_reads_bgzf_next_fd named exactly these, otherwise a job of this call's own.
+	std::shared_ptr<BzJob> job;
+	bool ahead = false;
+	{
+		std::lock_guard<std::mutex> g(ctx->bz_up_mu);
+		ctx->bz_in_call = true; // (until reads_bgzf_from returns)
+		for (size_t k = 0; k < ctx->bz_named.size() && !job; k++) {
+			BzJob &p = *ctx->bz_named[k];
+			if (src.fd >= 0 && p.src.fd == src.fd && p.src.file_off == src.file_off && p.n_bytes == n_bytes) {
+				job = ctx->bz_named[k];
+				ahead = job->queued;
+				bz_enqueue(ctx, job); // (named between two calls: it starts now)
+				ctx->bz_named.erase(ctx->bz_named.begin() + (long) k);
+			}
+		}
+		if (job)
+			for (const std::shared_ptr<BzJob> &later : ctx->bz_named)
+				bz_enqueue(ctx, later); // (the bytes of the call after this one: behind this call's)
+	}
+	if (job) { // (one that failed before it was asked for is no reason to fail now: start over)
+		std::unique_lock<std::mutex> lk(job->mu);
+		if (job->failed) {
+			lk.unlock();
+			bz_abandon(ctx, job);
+			job.reset();
+			ahead = false;
+		}
+	}
+	if (!job) {
+		// Bytes named ahead that are NOT these belong to a later call (a cohort's planning thread may name sample k + 1 before
+		// sample k's call gets here): they stay named; when their upload has not begun, this call's goes in front of it.
+		std::lock_guard<std::mutex> g(ctx->bz_up_mu);
+		job = bz_queue_job(ctx, src, n_bytes);
+		// (in front of named bytes whose upload has not begun)
+		for (size_t at = ctx->bz_up_queue.size() - 1; at > 0 && ctx->bz_up_queue[at - 1]->ticket != 0; at--)
+			std::swap(ctx->bz_up_queue[at - 1], ctx->bz_up_queue[at]);
+		for (const std::shared_ptr<BzJob> &later : ctx->bz_named)
+			bz_enqueue(ctx, later); // (behind this call's: the bytes of the calls after this one)
+	}
+	const double ms_head_start = ahead ? ms_since(job->t_queued) : 0.0;
+	// Named ahead WITH the block table: the inflates are launched (or being launched) into the spare output set by the job's own
+	// thread.  When that went well and the table is this call's, the sets change places and nothing is left to launch.
+	bool inflated_ahead = false;
+	{
+		bool asked;
+		{
+			std::lock_guard<std::mutex> g(job->mu);
+			asked = job->inflate_asked;
+		}
+		if (asked) {
+			{
+				std::unique_lock<std::mutex> lk(job->mu);
+				job->cv.wait(lk, [&] { return job->inflate_done; });
+			}
+			if (job->inflater.joinable())
+				job->inflater.join();
+			if (job->inflate_ok && base == 0 && job->blocks.size() == n_blocks
+					&& memcmp(job->blocks.data(), blocks, n_blocks * sizeof(conga_bgzf_block)) == 0) {
+				std::swap(ctx->d_bz_out, ctx->d_bz_out2);
+				std::swap(ctx->d_bz_blocks, ctx->d_bz_blocks2);
+				std::swap(ctx->d_bz_off, ctx->d_bz_off2);
+				std::swap(ctx->d_bz_status, ctx->d_bz_status2);
+				for (int k = 0; k < 2; k++)
+					HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_bz_ahead[k], 0));
+				inflated_ahead = true;
+			} else if (ctx->bz_ahead[0]) { // (whatever it launched writes the spare set: let it finish before that set is used again)
+				for (int k = 0; k < 2; k++)
+					(void) hipStreamSynchronize(ctx->bz_ahead[k]);
+			}
+		}
+	}
+	if (inflated_ahead) {
+		{
+			std::unique_lock<std::mutex> lk(job->mu);
+			job->cv.wait(lk, [&] { return job->done; });
+		}
+		if (timing)
+			fprintf(stderr, "\n[timing] overlapped upload: named ahead with its block table %d ms before this call: %zu pieces by %d threads enqueued after "
+					"%.1f ms (threads: %.1f ms copying, %.1f ms waiting for a free slot, each), %d inflate launches made ahead (their thread: %.1f ms)\n",
+					(int) ms_head_start, job->n_pieces, job->n_threads, job->ms_enqueued, job->ms_copy, job->ms_wait, job->launches_ahead,
+					job->ms_inflate_ahead);
+		ctx->bz_in_now = job->d_bytes;
+		ctx->bz_job_kept = job;
+		return CONGA_OK;
+	}
 	// Launch size: a launch lasts at least one block's 4.4 ms and the launches of a stream follow one another, so with two
 	// launch streams (the first call of a context, make_bz_ring) 128 MB per launch -- 3 440 blocks, 42 % of the waves the
 	// machine holds -- left it half empty: 97 ms for the stage against 86-93 with 256 MB (32 MB: 248 ms, 64: 143, 384: 96);
-	// with three streams 128 MB fill it.  (Small test pieces: sixteen per launch.  CONGA_BGZF_LAUNCH_MB: measurement switch.)
-	size_t pieces_per_launch = piece < kBzPiece ? (size_t) kBzPiecesPerLaunch
-			: std::max<size_t>(1, ((size_t) (ctx->n_bz_streams >= 3 ? 128 : 256) << 20) / piece);
+	// with three streams 128 MB fill it.  (CONGA_BGZF_LAUNCH_MB: measurement switch, in batches of 128 MB.)
+	size_t batches_per_launch = job->piece < kBzPiece ? 1 : (ctx->n_bz_streams >= 3 ? 1 : 2);
 	if (const char *e = getenv("CONGA_BGZF_LAUNCH_MB"))
-		pieces_per_launch = std::max<size_t>(1, ((size_t) std::max(1, atoi(e)) << 20) / piece);
-	// everything enqueued on ctx->stream so far (tables, buffers grown) comes first
+		batches_per_launch = std::max<size_t>(1, (size_t) std::max(1, atoi(e)) / 128);
+	// everything enqueued on ctx->stream so far (the block table, buffers grown) comes before the launches
 	HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-	HIP_TRY(ctx, hipStreamWaitEvent(ctx->bz_copy, ctx->ev_fork, 0));
 	for (int k = 0; k < ctx->n_bz_streams; k++)
 		HIP_TRY(ctx, hipStreamWaitEvent(ctx->bz_kernel[k], ctx->ev_fork, 0));
-
-	const int kBzSlots = bz_slots();
-	std::mutex mu;
-	std::condition_variable cv;
-	std::vector<uint8_t> filled(n_pieces, 0);
-	size_t issued = 0;       // pieces whose copy up has been enqueued (their slot's event is recorded)
-	bool failed = false, short_read = false; // (short_read: the file ends inside the piece -- the input's fault, not HIP's)
-	std::atomic<size_t> next_piece{0};
-	std::atomic<long long> us_copy{0}, us_wait{0}; // (CONGA_TIMING: what the host threads spent copying and waiting for a free slot)
-	const int device = ctx->device;
-	auto worker = [&]() {
-		(void) hipSetDevice(device);
-		for (;;) {
-			const size_t c = next_piece.fetch_add(1);
-			if (c >= n_pieces)
-				return;
-			const auto tw = std::chrono::steady_clock::now();
-			if (c >= (size_t) kBzSlots) { // the slot still holds piece c - kBzSlots until that one's copy up is done
-				{
-					std::unique_lock<std::mutex> lk(mu);
-					cv.wait(lk, [&] { return failed || issued > c - kBzSlots; });
-					if (failed)
-						return;
-				}
-				if (hipEventSynchronize(ctx->ev_bz_slot[c % kBzSlots]) != hipSuccess) {
-					std::lock_guard<std::mutex> g(mu);
-					failed = true;
-					cv.notify_all();
-					return;
-				}
-			}
-			const size_t at = c * piece, len = std::min(piece, n_bytes - at);
-			const auto tc = std::chrono::steady_clock::now();
-			const bool got = src.fetch(at, ctx->h_bz_ring + (c % kBzSlots) * kBzPiece, len);
-			us_wait += (long long) std::chrono::duration<double, std::micro>(tc - tw).count();
-			us_copy += (long long) std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tc).count();
-			{
-				std::lock_guard<std::mutex> g(mu);
-				filled[c] = 1;
-				if (!got)
-					failed = short_read = true; // (a file that ends early)
-			}
-			cv.notify_all();
-			if (!got)
-				return;
-		}
-	};
-	// (half of the cores this process MAY use -- the cgroup's quota, not the machine's 256 --: 6-10 GB/s of page cache -> pinned
-	// memory per thread against a link of 45-55 GB/s.  With a quota of 16: 8 threads have a 1.4 GB file enqueued after 29-35 ms, 6
-	// after 28-34, 12 after 37-39 (profiles/r03d_upload_modes.log); the other half is the caller's -- a cohort reads the next sample's
-	// block table meanwhile on six threads -- and a quota overdrawn stalls them all: 12 + 16 threads made a 5x genome's upload take
-	// 450-1 200 ms instead of 290-370)
-	int n_threads = (int) std::min<size_t>(n_pieces, std::min<unsigned>(std::max(2u, cpus_allowed() / 2), (unsigned) kBzSlots));
-	if (const char *e = getenv("CONGA_BGZF_COPY_THREADS"))
-		n_threads = std::max(1, std::min(atoi(e), kBzSlots));
-	std::vector<std::thread> threads;
-	for (int t = 0; t < n_threads; t++)
-		threads.emplace_back(worker);
 
 	int rc = CONGA_OK;
 	size_t b_done = 0; // blocks launched so far
 	int launches = 0;
-	for (size_t c = 0; c < n_pieces && rc == CONGA_OK; c++) {
+	for (size_t batch = 0; batch < job->n_batches && rc == CONGA_OK;) {
+		const size_t last_batch = std::min(job->n_batches, batch + batches_per_launch) - 1;
 		{
-			std::unique_lock<std::mutex> lk(mu);
-			cv.wait(lk, [&] { return failed || filled[c]; });
-			if (failed)
-				rc = short_read ? fail(ctx, CONGA_ERR_DATA, "conga_reads_bgzf: the file ends inside the piece that was named")
-						: fail(ctx, CONGA_ERR_HIP, "conga_reads_bgzf: waiting for a pinned piece failed");
+			std::unique_lock<std::mutex> lk(job->mu);
+			job->cv.wait(lk, [&] { return job->failed || job->batches_ready > last_batch; });
+			if (job->failed)
+				rc = job->short_read ? fail(ctx, CONGA_ERR_DATA, "conga_reads_bgzf: the file ends inside the piece that was named")
+						: fail(ctx, CONGA_ERR_HIP, "conga_reads_bgzf: the upload failed: " + job->error);
 		}
 		if (rc != CONGA_OK)
 			break;
-		const size_t at = c * piece, len = std::min(piece, n_bytes - at);
-		hipError_t e = hipMemcpyAsync(ptr<uint8_t>(ctx->d_bz_in) + at, ctx->h_bz_ring + (c % kBzSlots) * kBzPiece, len, hipMemcpyHostToDevice,
-				ctx->bz_copy);
-		if (e == hipSuccess)
-			e = hipEventRecord(ctx->ev_bz_slot[c % kBzSlots], ctx->bz_copy);
-		if (e != hipSuccess)
-			rc = fail(ctx, CONGA_ERR_HIP, std::string("conga_reads_bgzf: copy up: ") + hipGetErrorString(e));
-		{
-			std::lock_guard<std::mutex> g(mu);
-			issued = c + 1;
-			if (rc != CONGA_OK)
-				failed = true;
+		const bool last = last_batch + 1 == job->n_batches;
+		const size_t have = std::min(n_bytes, (last_batch + 1) * job->pieces_per_batch * job->piece);
+		size_t b1 = b_done; // the blocks that are complete with the bytes up to here
+		while (b1 < n_blocks && blocks[b1].data_off + blocks[b1].data_len <= have)
+			b1++;
+		if (last)
+			b1 = n_blocks;
+		if (b1 > b_done) {
+			hipStream_t ks = ctx->bz_kernel[launches % ctx->n_bz_streams];
+			const hipError_t e = hipStreamWaitEvent(ks, job->ev_batch[last_batch], 0);
+			if (e != hipSuccess)
+				rc = fail(ctx, CONGA_ERR_HIP, std::string("conga_reads_bgzf: ") + hipGetErrorString(e));
+			else if (!getenv("CONGA_BGZF_UPLOAD_ONLY")) // (measurement switch: the copy up alone; the call then fails its checks)
+				rc = launch_inflate(ctx, b1 - b_done, 0, ks, b_done, job->d_bytes);
+			launches++;
+			b_done = b1;
 		}
-		cv.notify_all();
-		if (rc != CONGA_OK)
-			break;
-		const bool last = c + 1 == n_pieces;
-		if ((c + 1) % pieces_per_launch == 0 || last) {
-			// the blocks that are complete with the bytes up to here
-			const size_t have = at + len;
-			size_t b1 = b_done;
-			while (b1 < n_blocks && blocks[b1].data_off + blocks[b1].data_len <= have)
-				b1++;
-			if (last)
-				b1 = n_blocks;
-			if (b1 > b_done) {
-				hipStream_t ks = ctx->bz_kernel[launches % ctx->n_bz_streams];
-				e = hipStreamWaitEvent(ks, ctx->ev_bz_slot[c % kBzSlots], 0);
-				if (e != hipSuccess)
-					rc = fail(ctx, CONGA_ERR_HIP, std::string("conga_reads_bgzf: ") + hipGetErrorString(e));
-				else if (!getenv("CONGA_BGZF_UPLOAD_ONLY")) // (measurement switch: the copy up alone; the call then fails its checks)
-					rc = launch_inflate(ctx, b1 - b_done, 0, ks, b_done);
-				launches++;
-				b_done = b1;
-			}
-		}
+		batch = last_batch + 1;
 	}
-	if (rc != CONGA_OK) {
-		std::lock_guard<std::mutex> g(mu);
-		failed = true;
+	if (rc != CONGA_OK)
+		bz_abandon(ctx, job);
+	else { // (every batch is ready: the job is through but for its bookkeeping)
+		std::unique_lock<std::mutex> lk(job->mu);
+		job->cv.wait(lk, [&] { return job->done; });
 	}
-	cv.notify_all();
-	for (std::thread &t : threads)
-		t.join();
 	if (timing)
 		fprintf(stderr, "\n[timing] overlapped upload: pinned ring + streams %.1f ms, %zu pieces by %d threads enqueued after %.1f ms (threads: %.1f ms "
-				"copying, %.1f ms waiting for a free slot, each), %d inflate launches\n", ms_ring, n_pieces, n_threads, ms_since(t0),
-				us_copy / 1e3 / n_threads, us_wait / 1e3 / n_threads, launches);
-	// ctx->stream goes on behind every launch (and the copy stream, for the case of no launch at all)
+				"copying, %.1f ms waiting for a free slot, each), %d inflate launches%s\n", ms_ring, job->n_pieces, job->n_threads, job->ms_enqueued,
+				job->ms_copy, job->ms_wait, launches,
+				ahead ? (", named ahead: on its way " + std::to_string((int) ms_head_start) + " ms before this call").c_str() : "");
+	// ctx->stream goes on behind every launch (and behind the last piece's copy, for the case of no launch at all)
 	for (int k = 0; k < ctx->n_bz_streams; k++) {
 		(void) hipEventRecord(ctx->ev_bz_kernel[k], ctx->bz_kernel[k]);
 		(void) hipStreamWaitEvent(ctx->stream, ctx->ev_bz_kernel[k], 0);
 	}
-	(void) hipEventRecord(ctx->ev_fork2, ctx->bz_copy);
-	(void) hipStreamWaitEvent(ctx->stream, ctx->ev_fork2, 0);
+	if (rc == CONGA_OK && job->n_batches)
+		(void) hipStreamWaitEvent(ctx->stream, job->ev_batch[job->n_batches - 1], 0);
+	ctx->bz_in_now = job->d_bytes;
+	ctx->bz_job_kept = job; // (its events are waited for by work still in flight)
 	if (ctx->bz_shared && ctx->n_bz_streams == 2 && !ctx->bz_third_maker.joinable() && !ctx->bz_third_ready.load(std::memory_order_acquire)
 			&& bz_streams_wanted() > 2) {
 		const int device = ctx->device;
@@ -1341,6 +1798,7 @@ int conga_release_staging(conga_ctx *ctx)
 	// leave the process while it is inside the runtime)
 	if (ctx->bz_third_maker.joinable())
 		ctx->bz_third_maker.join();
+	bz_upload_quiesce(ctx, false); // (an upload named ahead and never asked for is given up: its pieces go through the ring)
 	if (!ctx->h_bz_ring)
 		return CONGA_OK;
 	if (hipSetDevice(ctx->device) != hipSuccess)
@@ -1550,7 +2008,7 @@ void conga_destroy(conga_ctx *ctx)
 			&ctx->d_head, &ctx->d_item_row0, &ctx->d_item_row1, &ctx->d_item_rt_off, &ctx->d_item_lo, &ctx->d_rd, &ctx->d_gc_hist, &ctx->d_gc_like,
 			&ctx->d_small, &ctx->d_map, &ctx->d_winner, &ctx->d_map_start, &ctx->d_map_end,
 			&ctx->d_map_val, &ctx->d_iv_start, &ctx->d_iv_end, &ctx->d_iv_type, &ctx->d_iv_slot, &ctx->d_iv_has_map,
-			&ctx->d_order, &ctx->d_bz_in, &ctx->d_bz_blocks, &ctx->d_bz_off, &ctx->d_bz_out, &ctx->d_bz_status, &ctx->d_bz_scratch,
+			&ctx->d_order, &ctx->d_bz_in, &ctx->d_bz_blocks, &ctx->d_bz_off, &ctx->d_bz_out, &ctx->d_bz_status, &ctx->d_bz_out2, &ctx->d_bz_blocks2, &ctx->d_bz_off2, &ctx->d_bz_status2, &ctx->d_bz_scratch,
 			&ctx->d_bz_crc, &ctx->d_bz_x2n, &ctx->d_bz_seg, &ctx->d_bz_cnt, &ctx->d_bz_first, &ctx->d_bz_stop, &ctx->d_bz_bad, &ctx->d_bz_at, &ctx->d_bz_flag, &ctx->d_expected, &ctx->d_item_off, &ctx->d_item_len, &ctx->d_item_iv,
 			&ctx->d_item_has_map, &ctx->d_item_first, &ctx->d_map_part, &ctx->d_support, &ctx->d_results,
 			&ctx->d_bases, &ctx->d_row_tile, &ctx->d_depth_blocks, &ctx->d_support_base, &ctx->d_ref, &ctx->d_sat_start, &ctx->d_sat_end,
@@ -1577,6 +2035,17 @@ void conga_destroy(conga_ctx *ctx)
 		(void) hipHostFree(ctx->h_small);
 	if (ctx->h_head)
 		(void) hipHostFree(ctx->h_head);
+	bz_upload_quiesce(ctx, true);
+	ctx->bz_job_kept.reset();
+	for (int k = 0; k < 2; k++) {
+		if (ctx->bz_ahead[k])
+			(void) hipStreamDestroy(ctx->bz_ahead[k]);
+		if (ctx->ev_bz_ahead[k])
+			(void) hipEventDestroy(ctx->ev_bz_ahead[k]);
+	}
+	for (uint8_t *q : ctx->bz_up_buf)
+		if (q)
+			(void) hipFree(q);
 	if (ctx->h_bz_ring)
 		(void) hipHostFree(ctx->h_bz_ring);
 	for (hipEvent_t e : ctx->ev_bz_slot)
@@ -2000,6 +2469,91 @@ int conga_reads_bgzf_fd(conga_ctx *ctx, int fd, uint64_t file_off, size_t n_byte
 	return reads_bgzf_from(ctx, src, n_bytes, blocks, n_blocks, segments, n_segments, reads_per_chrom);
 }
 
+int conga_reads_bgzf_next_fd(conga_ctx *ctx, int fd, uint64_t file_off, size_t n_bytes, uint64_t *ticket)
+{
+	if (ticket)
+		*ticket = 0;
+	if (!ctx || fd < 0 || !ticket)
+		return CONGA_ERR_INVALID;
+	// (only what the overlapped route would take, and only with the ring in place: this call allocates nothing and touches
+	// nothing but the upload thread's queue -- it may come from another thread than the one inside conga_reads_bgzf_fd)
+	const char *ov = getenv("CONGA_BGZF_OVERLAP");
+	if (lane_kernel_asked() || !(ov ? atoi(ov) != 0 : n_bytes >= ((size_t) 96 << 20)) || n_bytes == 0 || getenv("CONGA_BGZF_NO_AHEAD"))
+		return CONGA_OK;
+	std::lock_guard<std::mutex> g(ctx->bz_up_mu);
+	if (!ctx->h_bz_ring || ctx->bz_ring_failed || !ctx->bz_copy || ctx->bz_named.size() >= 2 || ctx->bz_up_quit)
+		return CONGA_OK;
+	ByteSource src;
+	src.fd = fd;
+	src.file_off = file_off;
+	// (inside a call: behind that call's bytes, at once.  Between calls -- or before the call in front of these bytes' own has
+	// begun, which a cohort's planning thread cannot know --: when the next call begins, behind its bytes or as its bytes)
+	// (only behind a job that is itself on its way: what was named first goes up first)
+	const bool now = ctx->bz_in_call && (ctx->bz_named.empty() || ctx->bz_named.back()->queued);
+	ctx->bz_named.push_back(bz_queue_job(ctx, src, n_bytes, now));
+	ctx->bz_named.back()->ticket = *ticket = ++ctx->bz_up_tickets;
+	return CONGA_OK;
+}
+
+int conga_reads_bgzf_next_blocks(conga_ctx *ctx, uint64_t ticket, const conga_bgzf_block *blocks, size_t n_blocks)
+{
+	if (!ctx || !blocks || n_blocks == 0 || n_blocks > (size_t) 1 << 28)
+		return CONGA_ERR_INVALID;
+	if (ticket == 0 || getenv("CONGA_BGZF_NO_INFLATE_AHEAD") || (getenv("CONGA_BGZF_KERNEL") && strcmp(getenv("CONGA_BGZF_KERNEL"), "wave") != 0))
+		return CONGA_OK;
+	// (one spare output set: one named job at a time is inflated ahead -- the set is free again when the call that takes those
+	// bytes up has swapped it in)
+	std::lock_guard<std::mutex> g(ctx->bz_up_mu);
+	std::shared_ptr<BzJob> job;
+	for (const std::shared_ptr<BzJob> &j : ctx->bz_named) {
+		std::lock_guard<std::mutex> gj(j->mu);
+		if (j->ticket == ticket)
+			job = j;
+		else if (j->inflate_asked)
+			return CONGA_OK;
+	}
+	if (!job || !ctx->d_bz_x2n.p || !ctx->d_bz_crc.p) // (taken up already, or no call of this context has inflated anything yet)
+		return CONGA_OK;
+	// the table as conga_reads_bgzf* checks it: in file order, inside the bytes, 1..64 KiB each
+	std::vector<uint64_t> out_off(n_blocks);
+	uint64_t total = 0;
+	for (size_t b = 0; b < n_blocks; b++) {
+		const conga_bgzf_block &bl = blocks[b];
+		if (bl.data_off > job->n_bytes || (uint64_t) bl.data_len > job->n_bytes - bl.data_off || bl.inflated_len == 0 || bl.inflated_len > 65536u
+				|| (b && bl.data_off < blocks[b - 1].data_off + blocks[b - 1].data_len))
+			return CONGA_OK; // (the call itself will say what is wrong with it)
+		out_off[b] = total;
+		total += bl.inflated_len;
+	}
+	std::lock_guard<std::mutex> gj(job->mu);
+	if (job->inflate_asked || job->cancel.load())
+		return CONGA_OK;
+	job->blocks.assign(blocks, blocks + n_blocks);
+	job->out_off.swap(out_off);
+	job->total_out = total;
+	job->inflate_asked = true;
+	job->inflater = std::thread(bz_inflate_ahead, ctx, job);
+	return CONGA_OK;
+}
+
+int conga_reads_bgzf_forget(conga_ctx *ctx, uint64_t ticket)
+{
+	if (!ctx)
+		return CONGA_ERR_INVALID;
+	std::shared_ptr<BzJob> job;
+	{
+		std::lock_guard<std::mutex> g(ctx->bz_up_mu);
+		for (size_t k = 0; ticket != 0 && k < ctx->bz_named.size(); k++)
+			if (ctx->bz_named[k]->ticket == ticket) {
+				job = ctx->bz_named[k];
+				ctx->bz_named.erase(ctx->bz_named.begin() + (long) k);
+				break;
+			}
+	}
+	bz_abandon(ctx, job); // (returns when the upload thread no longer reads from the descriptor)
+	return CONGA_OK;
+}
+
 } // extern "C"
 
 namespace {
@@ -2085,8 +2639,16 @@ int reads_bgzf_from(conga_ctx *ctx, const ByteSource &src, size_t n_bytes, const
 	double ms_alloc_upload = 0, ms_inflate = 0;
 	auto t_inflate = std::chrono::steady_clock::now();
 	std::vector<uint8_t> whole; // (a small piece of a file: read in one go)
+	struct InCall { // (bytes named ahead while this call runs go up right behind this call's)
+		conga_ctx *c;
+		~InCall()
+		{
+			std::lock_guard<std::mutex> g(c->bz_up_mu);
+			c->bz_in_call = false;
+		}
+	} in_call{ctx};
 	if (overlapped) {
-		TRY(upload_and_inflate_overlapped(ctx, src, n_bytes, blocks, n_blocks));
+		TRY(upload_and_inflate_overlapped(ctx, src, n_bytes, blocks, n_blocks, base));
 	} else {
 		const uint8_t *bytes = src.bytes;
 		if (!bytes) {

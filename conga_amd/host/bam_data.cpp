@@ -265,6 +265,7 @@ struct planned_input {
 	std::vector<conga_bam_segment> segments;
 	bool planned = false;
 	double ms_plan = 0;
+	uint64_t ahead_ticket = 0; // conga_reads_bgzf_next_fd's: the engine was told about the bytes before their sample began
 };
 
 bool gpu_decode_wanted(const parameters *params)
@@ -292,7 +293,8 @@ std::vector<std::pair<int, int>> select_chromosomes(const parameters *params, co
 	return sel;
 }
 
-std::unique_ptr<planned_input> plan_input(const parameters *params, const sonic *this_sonic, const std::string &path)
+// engine: a context that will be given this input next (a cohort's kept one), or nullptr
+std::unique_ptr<planned_input> plan_input(const parameters *params, const sonic *this_sonic, const std::string &path, conga_ctx *engine = nullptr)
 {
 	std::unique_ptr<planned_input> p(new planned_input);
 	std::string err;
@@ -306,8 +308,15 @@ std::unique_ptr<planned_input> plan_input(const parameters *params, const sonic 
 		return p;
 	const auto t0 = std::chrono::steady_clock::now();
 	const char *gpu_bam = getenv("CONGA_GPU_BAM");
-	p->planned = p->src->device_plan(p->targets, gpu_bam != nullptr ? 0 : gpu_bam_min_piece(), &p->bytes, &p->blocks, &p->segments, &err);
+	planned_input *raw = p.get();
+	const std::function<void(const file_piece &)> opened = [raw, engine](const file_piece &bytes) {
+		if (engine && bytes.data == nullptr && bytes.fd >= 0)
+			(void) conga_reads_bgzf_next_fd(engine, bytes.fd, bytes.file_off, bytes.size, &raw->ahead_ticket);
+	};
+	p->planned = p->src->device_plan(p->targets, gpu_bam != nullptr ? 0 : gpu_bam_min_piece(), &p->bytes, &p->blocks, &p->segments, &err, &opened);
 	p->ms_plan = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	if (p->planned && engine && p->ahead_ticket) // (the table is read: the bytes named above can be inflated ahead as well)
+		(void) conga_reads_bgzf_next_blocks(engine, p->ahead_ticket, p->blocks.data(), p->blocks.size());
 	return p;
 }
 
@@ -629,9 +638,9 @@ int read_bam_cohort(parameters *params, sonic *this_sonic)
 		std::unique_ptr<planned_input> mine_now = std::move(ahead);
 		std::thread planner;
 		if (k + 1 < samples.size())
-			planner = std::thread([&, k] {
+			planner = std::thread([&, k, engine = keep.ctx] { // (keep.ctx: made by the first sample's run, the same from then on)
 				plan_beside_upload = true;
-				ahead = plan_input(params, this_sonic, samples[k + 1].first);
+				ahead = plan_input(params, this_sonic, samples[k + 1].first, engine);
 				plan_beside_upload = false;
 			});
 		params->bam_file = samples[k].first;
@@ -652,8 +661,15 @@ int read_bam_cohort(parameters *params, sonic *this_sonic)
 		if (getenv("CONGA_TIMING")) // (what a further sample costs, read off one process's own clock: bench.py's end-to-end legs)
 			fprintf(stderr, "[timing] cohort: sample %zu of %zu is done %.1f ms after the first one began\n", k + 1, samples.size(),
 					std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_cohort).count());
-		if (rc != 0)
+		// (bytes the engine was told about and never asked for -- this sample was decoded on the host after all, or failed --
+		// are given up before their descriptor goes; for bytes taken up this does nothing)
+		if (keep.ctx && mine_now && mine_now->ahead_ticket)
+			(void) conga_reads_bgzf_forget(keep.ctx, mine_now->ahead_ticket);
+		if (rc != 0) {
+			if (keep.ctx && ahead && ahead->ahead_ticket)
+				(void) conga_reads_bgzf_forget(keep.ctx, ahead->ahead_ticket);
 			return rc; // (nothing of ours is running: planner and cleaner are joined)
+		}
 		if (k + 1 < samples.size()) {
 			planned_input *done = mine_now.release();
 			cleaner = std::thread([done] { delete done; });

@@ -560,7 +560,8 @@ public:
 	// sees a record that ends it; to the end of the file when there is none), the table of those blocks, and for every
 	// target one start point per distinct linear-index offset.
 	bool device_plan(const std::vector<device_target> &targets, uint64_t min_piece_bytes, file_piece *bytes,
-			std::vector<conga_bgzf_block> *blocks, std::vector<conga_bam_segment> *segments, std::string *err) override
+			std::vector<conga_bgzf_block> *blocks, std::vector<conga_bam_segment> *segments, std::string *err,
+			const std::function<void(const file_piece &)> *opened = nullptr) override
 	{
 		if (targets.empty() || linear_.empty())
 			return false;
@@ -607,6 +608,10 @@ public:
 		const char *mm = getenv("CONGA_BAM_MMAP");
 		if ((mm != nullptr ? atoi(mm) != 0 : map_bam_pieces) ? !bytes->open(path_, c_lo, stop) : !bytes->open_fd(path_, c_lo, stop))
 			return false;
+		// (which bytes the GPU will be given is known from the index alone: a cohort lets the engine start on them now, while
+		// the block table below is still being read -- conga_reads_bgzf_next_fd)
+		if (opened && *opened)
+			(*opened)(*bytes);
 		// ---- block table.  A BGZF file is a chain (every header says where the next block starts), but the index knows
 		// thousands of block starts along it: the stretch is cut at some of them and every part is walked by its own thread;
 		// a part must arrive exactly at the next part's start, otherwise the index is not trusted and the chain is walked

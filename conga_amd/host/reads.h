@@ -4,6 +4,7 @@
 #pragma once
 #include <cstdint>
 #include <atomic>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -80,7 +81,8 @@ public:
 	// points from the index's linear offsets.  false with an empty *err: not
 	// available (no index, not a BAM, a piece of the file smaller than min_piece_bytes or too large) -- decode on the host.
 	virtual bool device_plan(const std::vector<device_target> &targets, uint64_t min_piece_bytes, file_piece *bytes,
-			std::vector<conga_bgzf_block> *blocks, std::vector<conga_bam_segment> *segments, std::string *err)
+			std::vector<conga_bgzf_block> *blocks, std::vector<conga_bam_segment> *segments, std::string *err,
+			const std::function<void(const file_piece &)> *opened = nullptr)
 	{
 		return false;
 	}

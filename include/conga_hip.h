@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define CONGA_ABI_VERSION 5
+#define CONGA_ABI_VERSION 6
 
 typedef struct conga_ctx conga_ctx;
 
@@ -302,6 +302,26 @@ int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const
  * are relative to file_off, as they are to `bytes` above. */
 int conga_reads_bgzf_fd(conga_ctx *ctx, int fd, uint64_t file_off, size_t n_bytes, const conga_bgzf_block *blocks, size_t n_blocks,
 		const conga_bam_segment *segments, size_t n_segments, uint64_t *reads_per_chrom /* [conga_chrom_count()] or NULL */);
+
+/* A cohort's pipeline (conga --cohort: read_bam_cohort).  Names the bytes that the NEXT conga_reads_bgzf_fd call of this
+ * context will bring -- same descriptor, offset and length --: the context's upload thread starts on them as soon as the
+ * bytes of the call in progress (if any) are up, into the other of two device buffers, so that sample k + 1 crosses the link
+ * while sample k is inflated, walked, computed and written out.  The reference reads its samples one process at a time
+ * (bam_data.c:253-339); nothing of its results depends on when a sample's bytes were copied.
+ * May be called from another thread than the one that is inside a call of this context (it touches the upload queue only).
+ * *ticket: 0 when nothing was started (a piece too small for the overlapped route, no pinned ring yet, one named already).
+ * The descriptor must stay open until the conga_reads_bgzf_fd call that takes the bytes up has returned, or until
+ * conga_reads_bgzf_forget(ticket) has: that one gives an upload up that no call will ask for (the caller decided to decode
+ * on the host), and is a no-op for a ticket already taken up.  A conga_reads_bgzf_fd call that names other bytes gives a
+ * pending upload up by itself. */
+int conga_reads_bgzf_next_fd(conga_ctx *ctx, int fd, uint64_t file_off, size_t n_bytes, uint64_t *ticket);
+/* ... and their block table, once the caller has read it (the bytes are named from the index alone, before): the engine then
+ * also INFLATES them ahead, batch by batch as they come up, into a spare output buffer; the conga_reads_bgzf_fd call that
+ * brings the same table finds the stream inflated and goes straight to its record walks.  A table that differs from the
+ * call's, or anything that goes wrong ahead, costs nothing but the head start: the call inflates as usual.  May be called
+ * from another thread, like conga_reads_bgzf_next_fd; the table is copied. */
+int conga_reads_bgzf_next_blocks(conga_ctx *ctx, uint64_t ticket, const conga_bgzf_block *blocks, size_t n_blocks);
+int conga_reads_bgzf_forget(conga_ctx *ctx, uint64_t ticket);
 
 /* Gives the pinned staging of conga_reads_bgzf* (96 MB) back to the system; the next call makes it again.  A caller that is
  * done reading -- the conga executable after its last BAM -- calls this, from a thread of its own if it likes, while the
