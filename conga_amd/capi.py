@@ -38,7 +38,7 @@ KERNEL_NAMES = ("ingest", "depth_tile", "expected_table", "paint", "interval_red
 EXPORTS = (
     "conga_create", "conga_destroy", "conga_strerror", "conga_last_error", "conga_abi_version",
     "conga_device_count", "conga_reset", "conga_chrom_count", "conga_chrom_select", "conga_chrom_begin", "conga_reads_staging", "conga_reads_commit",
-    "conga_reads_bgzf", "conga_reads_bgzf_fd", "conga_reads_bgzf_next_fd", "conga_reads_bgzf_next_blocks", "conga_reads_bgzf_forget", "conga_release_staging", "conga_inflate_blocks", "conga_host_alloc", "conga_host_free", "conga_sample_reads", "conga_sample_reads_d16", "conga_sample_reads_packed", "conga_sample_begin",
+    "conga_reads_bgzf", "conga_reads_bgzf_fd", "conga_reads_bgzf_next_fd", "conga_reads_bgzf_next_table", "conga_reads_bgzf_next_blocks", "conga_reads_bgzf_forget", "conga_release_staging", "conga_inflate_blocks", "conga_host_alloc", "conga_host_free", "conga_sample_reads", "conga_sample_reads_d16", "conga_sample_reads_packed", "conga_sample_begin",
     "conga_sample_chrom", "conga_sample_fetch",
     "conga_mappability", "conga_intervals", "conga_reference", "conga_satellites", "conga_split_reads_staging",
     "conga_split_reads_commit", "conga_split_support", "conga_chrom_compute",
@@ -196,7 +196,9 @@ def load():
     L.conga_reads_bgzf_fd.restype = C.c_int
     L.conga_reads_bgzf_fd.argtypes = [vp, C.c_int, C.c_uint64, sz, C.POINTER(BgzfBlock), sz, C.POINTER(BamSegment), sz, C.POINTER(C.c_uint64)]
     L.conga_reads_bgzf_next_fd.restype = C.c_int
-    L.conga_reads_bgzf_next_fd.argtypes = [vp, C.c_int, C.c_uint64, sz, C.POINTER(C.c_uint64)]
+    L.conga_reads_bgzf_next_fd.argtypes = [vp, C.c_int, C.c_uint64, sz, C.POINTER(C.c_uint64), sz, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.conga_reads_bgzf_next_table.restype = C.c_int
+    L.conga_reads_bgzf_next_table.argtypes = [vp, C.c_uint64, C.POINTER(C.POINTER(BgzfBlock)), C.POINTER(sz)]
     L.conga_reads_bgzf_next_blocks.restype = C.c_int
     L.conga_reads_bgzf_next_blocks.argtypes = [vp, C.c_uint64, C.POINTER(BgzfBlock), sz]
     L.conga_reads_bgzf_forget.restype = C.c_int

@@ -175,10 +175,12 @@ struct conga_ctx {
 	std::condition_variable bz_up_cv;
 	std::deque<std::shared_ptr<struct BzJob>> bz_up_queue;
 	bool bz_up_quit = false, bz_up_busy = false;
-	// named ahead, not yet taken up by a conga_reads_bgzf_fd call: at most two (a cohort's planning thread may name sample k + 1
-	// before the call for sample k has taken ITS bytes up), in the order of their calls
+	// named ahead, not yet taken up by a conga_reads_bgzf_fd call, in the order of their calls: at most three (a cohort names two
+	// samples ahead, and its planning thread may do so before the call for the sample in front has taken ITS bytes up)
 	std::vector<std::shared_ptr<struct BzJob>> bz_named;
 	bool bz_in_call = false; // a conga_reads_bgzf* call is between queueing its bytes and its return
+	double bz_ratio = 0;     // inflated bytes per compressed byte of the largest call so far: sizes the spare output buffer
+	std::shared_ptr<struct BzJob> bz_spare_owner; // the named job whose inflates fill the spare output set (until the call that takes it up swaps the sets)
 	uint8_t *bz_up_buf[2] = {nullptr, nullptr};
 	size_t bz_up_cap[2] = {0, 0};
 	std::shared_ptr<struct BzJob> bz_buf_owner[2]; // a buffer is its job's until the call that took the bytes up is through with them
@@ -1187,6 +1189,7 @@ struct BzJob {
 	size_t batches_ready = 0; // batches whose event has been recorded
 	bool failed = false, short_read = false, done = false, started = false;
 	bool queued = false; // handed to the upload thread (bytes named ahead wait for the call in front of theirs to queue its own)
+	bool adopted = false; // a conga_reads_bgzf_fd call has taken the job up (mu): no inflating ahead begins behind its back
 	std::atomic<bool> cancel{false};
 	std::vector<hipEvent_t> ev_batch;
 	const uint8_t *d_bytes = nullptr; // where the bytes go (set when the job starts)
@@ -1202,6 +1205,29 @@ struct BzJob {
 	bool inflate_asked = false, inflate_done = false, inflate_ok = false; // (mu)
 	int launches_ahead = 0;
 	double ms_inflate_ahead = 0;
+	// The block table read off the bytes as they pass through the pinned ring (conga_reads_bgzf_next_fd with the block starts the
+	// caller knows from the index): every copying thread walks the chain of headers inside its piece from the first known start
+	// on, the upload thread joins the pieces' findings in file order (what straddles two pieces it reads from the file: a
+	// trailer, now and then a header) and publishes the table batch by batch -- the inflate-ahead thread needs no more.
+	struct PieceTable {
+		std::vector<conga_bgzf_block> blocks; // complete inside the piece
+		uint64_t seed = ~0ull;                 // where the walk began (~0: no known start inside the piece)
+		uint64_t arrived = 0;                  // where it stopped: the offset of the next header
+		bool open = false;                     // the last block's header is in, its trailer lies behind the piece
+		conga_bgzf_block open_block = {};
+		uint64_t open_end = 0;
+		bool bad = false;                      // something that is not a BGZF block of the usual form
+	};
+	bool build_table = false;
+	std::vector<uint64_t> known; // piece-relative offsets of block headers, ascending
+	uint64_t stop_at = 0;        // 0, or: the table ends with the first block that starts at or behind this offset
+	std::vector<PieceTable> piece_tables;
+	uint64_t expect = 0;         // where the chain goes on (upload thread)
+	bool table_failed = false, table_stopped = false; // (upload thread; published with the counters below)
+	size_t cap_blocks = 0;
+	uint64_t cap_out = 0;        // 0: no inflate ahead (only the table)
+	size_t table_n = 0;          // blocks published (mu)
+	bool table_final = false, table_ok = false; // (mu)
 	~BzJob()
 	{
 		if (inflater.joinable())
@@ -1213,6 +1239,146 @@ struct BzJob {
 };
 
 namespace {
+
+void bz_inflate_ahead(conga_ctx *ctx, const std::shared_ptr<BzJob> &self);
+
+// BGZF header of the usual form at h[0..18) -> BSIZE + 1 (the block's length), or 0
+inline uint32_t bgzf_block_len(const uint8_t *h)
+{
+	if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4) || h[10] != 6 || h[11] != 0 || h[12] != 'B' || h[13] != 'C' || h[14] != 2 || h[15] != 0)
+		return 0;
+	const uint32_t len = (uint32_t) (h[16] | (h[17] << 8)) + 1u;
+	return len >= 26u ? len : 0u;
+}
+
+// one piece's share of the table: buf = the piece's bytes [begin, begin + len) of the job's stretch
+void bz_walk_piece(BzJob &job, size_t c, const uint8_t *buf, uint64_t begin, size_t len)
+{
+	BzJob::PieceTable &pt = job.piece_tables[c];
+	const uint64_t end = begin + len;
+	const auto it = std::lower_bound(job.known.begin(), job.known.end(), begin);
+	if (it == job.known.end() || *it >= end)
+		return;
+	pt.seed = *it;
+	uint64_t at = pt.seed;
+	while (at < end) {
+		if (at + 18 > end)
+			break; // (the header straddles the piece's end: the upload thread reads it from the file)
+		const uint8_t *h = buf + (at - begin);
+		const uint32_t blen = bgzf_block_len(h);
+		if (!blen) {
+			pt.bad = true;
+			break;
+		}
+		const uint64_t bend = at + blen;
+		if (bend > job.n_bytes)
+			break; // the stretch ends inside this block (behind the last one that counts)
+		conga_bgzf_block b = {};
+		b.data_off = at + 18;
+		b.data_len = blen - 26u;
+		if (bend <= end) {
+			memcpy(&b.crc32, buf + (bend - 8 - begin), 4);
+			memcpy(&b.inflated_len, buf + (bend - 4 - begin), 4);
+			if (b.inflated_len)
+				pt.blocks.push_back(b);
+			at = bend;
+		} else {
+			pt.open = true;
+			pt.open_block = b;
+			pt.open_end = bend;
+			at = bend;
+			break;
+		}
+	}
+	pt.arrived = at;
+}
+
+// piece c is in its slot (buf): its findings join the table.  Upload thread, pieces in file order.
+void bz_join_piece(BzJob &job, size_t c, const uint8_t *buf, uint64_t begin, size_t len)
+{
+	if (job.table_failed || job.table_stopped)
+		return;
+	const uint64_t end = begin + len;
+	BzJob::PieceTable &pt = job.piece_tables[c];
+	auto read_at = [&](uint64_t off, void *dst, size_t n) { // from the slot when it is all there, from the file otherwise
+		if (off >= begin && off + n <= end) {
+			memcpy(dst, buf + (off - begin), n);
+			return true;
+		}
+		return off + n <= job.n_bytes && job.src.fetch((size_t) off, dst, n);
+	};
+	auto append = [&](const conga_bgzf_block &b) {
+		if (b.inflated_len == 0)
+			return;
+		if (b.inflated_len > 65536u || job.blocks.size() >= job.cap_blocks) {
+			job.table_failed = true;
+			return;
+		}
+		job.out_off.push_back(job.total_out);
+		job.blocks.push_back(b);
+		job.total_out += b.inflated_len;
+		if (job.stop_at && b.data_off - 18 >= job.stop_at)
+			job.table_stopped = true; // (the block in which the next target begins is in: enough)
+	};
+	if (pt.bad) {
+		job.table_failed = true;
+		return;
+	}
+	// the chain from where it stood up to the piece's first known start (or through the whole piece when it has none): blocks the
+	// index does not know, a header cut by the piece before
+	const uint64_t upto = pt.seed != ~0ull ? pt.seed : end;
+	while (job.expect < upto && !job.table_failed && !job.table_stopped) {
+		uint8_t h[18];
+		if (job.expect + 18 > job.n_bytes || !read_at(job.expect, h, 18)) {
+			job.table_stopped = true; // (the stretch ends here)
+			return;
+		}
+		const uint32_t blen = bgzf_block_len(h);
+		if (!blen) {
+			job.table_failed = true;
+			return;
+		}
+		const uint64_t bend = job.expect + blen;
+		if (bend > job.n_bytes) {
+			job.table_stopped = true;
+			return;
+		}
+		uint8_t t[8];
+		if (!read_at(bend - 8, t, 8)) {
+			job.table_failed = true;
+			return;
+		}
+		conga_bgzf_block b = {};
+		b.data_off = job.expect + 18;
+		b.data_len = blen - 26u;
+		memcpy(&b.crc32, t, 4);
+		memcpy(&b.inflated_len, t + 4, 4);
+		append(b);
+		job.expect = bend;
+	}
+	if (job.table_failed || job.table_stopped || pt.seed == ~0ull)
+		return;
+	if (job.expect != pt.seed) { // (the chain does not arrive at what the index calls a block's start: the index is not believed)
+		job.table_failed = true;
+		return;
+	}
+	for (const conga_bgzf_block &b : pt.blocks) {
+		append(b);
+		if (job.table_failed || job.table_stopped)
+			return;
+	}
+	if (pt.open) {
+		uint8_t t[8];
+		if (!read_at(pt.open_end - 8, t, 8)) {
+			job.table_failed = true;
+			return;
+		}
+		memcpy(&pt.open_block.crc32, t, 4);
+		memcpy(&pt.open_block.inflated_len, t + 4, 4);
+		append(pt.open_block);
+	}
+	job.expect = pt.arrived;
+}
 
 void bz_run_job(conga_ctx *ctx, const std::shared_ptr<BzJob> &self)
 {
@@ -1227,6 +1393,7 @@ void bz_run_job(conga_ctx *ctx, const std::shared_ptr<BzJob> &self)
 		if (job.error.empty())
 			job.error = why;
 		job.done = true;
+		job.table_final = true;
 		job.cv.notify_all();
 	};
 	job.t_started = std::chrono::steady_clock::now();
@@ -1266,10 +1433,26 @@ void bz_run_job(conga_ctx *ctx, const std::shared_ptr<BzJob> &self)
 	for (size_t k = 0; k < job.n_batches; k++)
 		if (hipEventCreateWithFlags(&job.ev_batch[k], hipEventDisableTiming) != hipSuccess)
 			return give_up("hipEventCreate", false);
+	// The table is made here, batch by batch: the inflates can follow it into the spare output set (its thread waits until the set
+	// is free: the named job in front of this one owns it until the call that takes THAT one up has swapped it in) -- when a
+	// call of this context has shown how much such a file inflates to, and the job is a named one.
+	bool ahead = false;
+	if (job.build_table && job.ticket != 0 && !getenv("CONGA_BGZF_NO_INFLATE_AHEAD")
+			&& !(getenv("CONGA_BGZF_KERNEL") && strcmp(getenv("CONGA_BGZF_KERNEL"), "wave") != 0)) {
+		std::lock_guard<std::mutex> g(ctx->bz_up_mu);
+		if (ctx->bz_ratio > 0 && ctx->d_bz_x2n.p && ctx->d_bz_crc.p) {
+			job.cap_out = (uint64_t) ((double) job.n_bytes * ctx->bz_ratio * 1.25) + ((uint64_t) 64 << 20);
+			ahead = true;
+		}
+	}
 	{
 		std::lock_guard<std::mutex> g(job.mu);
 		job.d_bytes = d_dst;
 		job.started = true;
+		if (ahead && !job.inflate_asked && !job.adopted && !job.cancel.load()) {
+			job.inflate_asked = true;
+			job.inflater = std::thread(bz_inflate_ahead, ctx, self);
+		}
 	}
 	job.cv.notify_all();
 
@@ -1302,6 +1485,8 @@ void bz_run_job(conga_ctx *ctx, const std::shared_ptr<BzJob> &self)
 			const size_t at = c * piece, len = std::min(piece, n_bytes - at);
 			const auto tc = std::chrono::steady_clock::now();
 			const bool got = job.src.fetch(at, ctx->h_bz_ring + (size_t) slot * kBzPiece, len);
+			if (got && job.build_table)
+				bz_walk_piece(job, c, ctx->h_bz_ring + (size_t) slot * kBzPiece, at, len);
 			us_wait += (long long) std::chrono::duration<double, std::micro>(tc - tw).count();
 			us_copy += (long long) std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tc).count();
 			{
@@ -1340,6 +1525,8 @@ void bz_run_job(conga_ctx *ctx, const std::shared_ptr<BzJob> &self)
 		}
 		const size_t at = c * piece, len = std::min(piece, n_bytes - at);
 		const int slot = (int) (c % (size_t) n_slots);
+		if (job.build_table)
+			bz_join_piece(job, c, ctx->h_bz_ring + (size_t) slot * kBzPiece, at, len);
 		hipError_t e = hipMemcpyAsync(d_dst + at, ctx->h_bz_ring + (size_t) slot * kBzPiece, len, hipMemcpyHostToDevice, ctx->bz_copy);
 		if (e == hipSuccess)
 			e = hipEventRecord(ctx->ev_bz_slot[slot], ctx->bz_copy);
@@ -1355,8 +1542,14 @@ void bz_run_job(conga_ctx *ctx, const std::shared_ptr<BzJob> &self)
 		{
 			std::lock_guard<std::mutex> g(job.mu);
 			job.issued = c + 1;
-			if (batch_end)
+			if (batch_end) {
 				job.batches_ready = batch + 1;
+				job.table_n = job.blocks.size();
+				if (job.build_table && (job.table_failed || c + 1 == n_pieces)) {
+					job.table_final = true;
+					job.table_ok = !job.table_failed && !job.blocks.empty();
+				}
+			}
 		}
 		job.cv.notify_all();
 	}
@@ -1375,6 +1568,10 @@ void bz_run_job(conga_ctx *ctx, const std::shared_ptr<BzJob> &self)
 	{
 		std::lock_guard<std::mutex> g(job.mu);
 		job.done = true;
+		if (job.build_table && !job.table_final) { // (given up on the way)
+			job.table_final = true;
+			job.table_ok = false;
+		}
 	}
 	job.cv.notify_all();
 }
@@ -1448,6 +1645,16 @@ void bz_release(conga_ctx *ctx, const std::shared_ptr<BzJob> &job)
 	ctx->bz_up_cv.notify_all();
 }
 
+// the spare output set is nobody's again (when it was this job's)
+void bz_spare_free(conga_ctx *ctx, const std::shared_ptr<BzJob> &job)
+{
+	std::lock_guard<std::mutex> g(ctx->bz_up_mu);
+	if (ctx->bz_spare_owner == job) {
+		ctx->bz_spare_owner.reset();
+		ctx->bz_up_cv.notify_all();
+	}
+}
+
 // gives a job up and waits until the upload thread is through with it
 void bz_abandon(conga_ctx *ctx, const std::shared_ptr<BzJob> &job)
 {
@@ -1472,6 +1679,7 @@ void bz_abandon(conga_ctx *ctx, const std::shared_ptr<BzJob> &job)
 	if (job->inflate_asked && ctx->bz_ahead[0])
 		for (int k = 0; k < 2; k++)
 			(void) hipStreamSynchronize(ctx->bz_ahead[k]); // (what it launched reads the job's bytes)
+	bz_spare_free(ctx, job);
 	bz_release(ctx, job);
 }
 
@@ -1519,11 +1727,21 @@ bool quiet_ensure(DevBuf &b, size_t bytes)
 void bz_inflate_ahead(conga_ctx *ctx, const std::shared_ptr<BzJob> &self)
 {
 	BzJob &job = *self;
-	const auto t0 = std::chrono::steady_clock::now();
 	bool ok = hipSetDevice(ctx->device) == hipSuccess;
-	const size_t n_blocks = job.blocks.size();
-	ok = ok && quiet_ensure(ctx->d_bz_blocks2, n_blocks * sizeof(conga_bgzf_block)) && quiet_ensure(ctx->d_bz_off2, n_blocks * 8)
-			&& quiet_ensure(ctx->d_bz_out2, (size_t) job.total_out + 64) && quiet_ensure(ctx->d_bz_status2, n_blocks);
+	{ // the spare output set: one job at a time, in the order the jobs were named
+		std::unique_lock<std::mutex> lk(ctx->bz_up_mu);
+		ctx->bz_up_cv.wait(lk, [&] { return !ctx->bz_spare_owner || job.cancel.load(); });
+		if (job.cancel.load())
+			ok = false;
+		else
+			ctx->bz_spare_owner = self;
+	}
+	const auto t0 = std::chrono::steady_clock::now();
+	// room for the table and the stream: the table's own size when the caller brought it, a bound when it grows with the upload
+	const size_t room_blocks = std::max(job.cap_blocks, job.blocks.size());
+	const uint64_t room_out = std::max<uint64_t>(job.cap_out, job.total_out);
+	ok = ok && quiet_ensure(ctx->d_bz_blocks2, room_blocks * sizeof(conga_bgzf_block)) && quiet_ensure(ctx->d_bz_off2, room_blocks * 8)
+			&& quiet_ensure(ctx->d_bz_out2, (size_t) room_out + 64) && quiet_ensure(ctx->d_bz_status2, room_blocks);
 	if (ok && !ctx->bz_ahead[0]) {
 		int lo = 0, hi = 0;
 		ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
@@ -1531,36 +1749,40 @@ void bz_inflate_ahead(conga_ctx *ctx, const std::shared_ptr<BzJob> &self)
 			ok = hipStreamCreateWithPriority(&ctx->bz_ahead[k], hipStreamNonBlocking, lo) == hipSuccess
 					&& hipEventCreateWithFlags(&ctx->ev_bz_ahead[k], hipEventDisableTiming) == hipSuccess;
 	}
-	if (ok) {
-		ok = hipMemcpyAsync(ctx->d_bz_blocks2.p, job.blocks.data(), n_blocks * sizeof(conga_bgzf_block), hipMemcpyHostToDevice, ctx->bz_ahead[0]) == hipSuccess
-				&& hipMemcpyAsync(ctx->d_bz_off2.p, job.out_off.data(), n_blocks * 8, hipMemcpyHostToDevice, ctx->bz_ahead[0]) == hipSuccess
-				&& hipMemsetAsync(ctx->d_bz_status2.p, 0xFF, n_blocks, ctx->bz_ahead[0]) == hipSuccess
-				&& hipEventRecord(ctx->ev_bz_ahead[0], ctx->bz_ahead[0]) == hipSuccess
-				&& hipStreamWaitEvent(ctx->bz_ahead[1], ctx->ev_bz_ahead[0], 0) == hipSuccess;
-	}
 	size_t b_done = 0;
 	int launches = 0;
 	for (size_t batch = 0; ok && batch < job.n_batches; batch++) {
+		size_t n_avail = 0;
+		bool final = false;
 		{
 			std::unique_lock<std::mutex> lk(job.mu);
 			job.cv.wait(lk, [&] { return job.failed || job.cancel.load() || job.batches_ready > batch; });
-			if (job.failed || job.cancel.load()) {
+			if (job.failed || job.cancel.load() || (job.table_final && !job.table_ok)) {
 				ok = false;
 				break;
 			}
+			n_avail = job.table_n;
+			final = job.table_final;
 		}
 		const bool last = batch + 1 == job.n_batches;
 		const size_t have = std::min(job.n_bytes, (batch + 1) * job.pieces_per_batch * job.piece);
 		size_t b1 = b_done;
-		while (b1 < n_blocks && job.blocks[b1].data_off + job.blocks[b1].data_len <= have)
+		while (b1 < n_avail && job.blocks[b1].data_off + job.blocks[b1].data_len + 8 <= have)
 			b1++;
-		if (last)
-			b1 = n_blocks;
-		if (b1 > b_done) {
+		if (last) {
+			ok = final;
+			b1 = n_avail;
+		}
+		if (ok && b1 > b_done) {
+			const size_t n = b1 - b_done;
+			ok = job.out_off[b1 - 1] + job.blocks[b1 - 1].inflated_len <= room_out && b1 <= room_blocks;
 			hipStream_t ks = ctx->bz_ahead[launches % 2];
-			ok = hipStreamWaitEvent(ks, job.ev_batch[batch], 0) == hipSuccess;
+			ok = ok && hipMemcpyAsync(ptr<conga_bgzf_block>(ctx->d_bz_blocks2) + b_done, job.blocks.data() + b_done, n * sizeof(conga_bgzf_block),
+							hipMemcpyHostToDevice, ks) == hipSuccess
+					&& hipMemcpyAsync(ptr<uint64_t>(ctx->d_bz_off2) + b_done, job.out_off.data() + b_done, n * 8, hipMemcpyHostToDevice, ks) == hipSuccess
+					&& hipMemsetAsync(ptr<uint8_t>(ctx->d_bz_status2) + b_done, 0xFF, n, ks) == hipSuccess
+					&& hipStreamWaitEvent(ks, job.ev_batch[batch], 0) == hipSuccess;
 			if (ok) {
-				const size_t n = b1 - b_done;
 				const size_t groups = std::min<size_t>((n + iw::kWavesPerGroup - 1) / iw::kWavesPerGroup, (size_t) ctx->n_cu * 8);
 				hipLaunchKernelGGL(iw::bgzf_inflate_wave_kernel<true>, dim3((unsigned) groups), dim3(64 * iw::kWavesPerGroup), 0, ks, (uint32_t) n,
 						job.d_bytes, ptr<conga_bgzf_block>(ctx->d_bz_blocks2) + b_done, ptr<uint64_t>(ctx->d_bz_off2) + b_done,
@@ -1583,6 +1805,21 @@ void bz_inflate_ahead(conga_ctx *ctx, const std::shared_ptr<BzJob> &self)
 		job.inflate_done = true;
 	}
 	job.cv.notify_all();
+	// The compressed bytes have done their duty once the last launch is through: their buffer goes back now -- the job named
+	// behind this one can start on its way up before the call for this one has even begun (two buffers carry any depth).
+	if (ok) {
+		bool through = true;
+		for (int k = 0; k < 2; k++)
+			through = hipEventSynchronize(ctx->ev_bz_ahead[k]) == hipSuccess && through;
+		bool uploaded;
+		{
+			std::unique_lock<std::mutex> lk(job.mu);
+			job.cv.wait(lk, [&] { return job.done; });
+			uploaded = !job.failed;
+		}
+		if (through && uploaded)
+			bz_release(ctx, self);
+	}
 }
 
 // *inflated: the bytes named ahead came with their block table and are inflated (the launches are enqueued) in what is now the
@@ -1629,10 +1866,12 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const ByteSource &src, size_t 
 				ctx->bz_named.erase(ctx->bz_named.begin() + (long) k);
 			}
 		}
-		if (job)
-			for (const std::shared_ptr<BzJob> &later : ctx->bz_named)
-				bz_enqueue(ctx, later); // (the bytes of the call after this one: behind this call's)
 	}
+	auto enqueue_later = [&]() { // the bytes of the calls after this one: behind this call's (and behind the swap of the output sets below)
+		std::lock_guard<std::mutex> g(ctx->bz_up_mu);
+		for (const std::shared_ptr<BzJob> &later : ctx->bz_named)
+			bz_enqueue(ctx, later);
+	};
 	if (job) { // (one that failed before it was asked for is no reason to fail now: start over)
 		std::unique_lock<std::mutex> lk(job->mu);
 		if (job->failed) {
@@ -1645,13 +1884,26 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const ByteSource &src, size_t 
 	if (!job) {
 		// Bytes named ahead that are NOT these belong to a later call (a cohort's planning thread may name sample k + 1 before
 		// sample k's call gets here): they stay named; when their upload has not begun, this call's goes in front of it.
+		// With two or more of them, though, both device buffers may be theirs: the ones behind the first are given up (their
+		// calls bring them again) -- a caller that names in the order of its calls, as it must, gets here only at a run's start.
+		for (;;) {
+			std::shared_ptr<BzJob> last;
+			{
+				std::lock_guard<std::mutex> g(ctx->bz_up_mu);
+				if (ctx->bz_named.size() >= 2) {
+					last = ctx->bz_named.back();
+					ctx->bz_named.pop_back();
+				}
+			}
+			if (!last)
+				break;
+			bz_abandon(ctx, last);
+		}
 		std::lock_guard<std::mutex> g(ctx->bz_up_mu);
 		job = bz_queue_job(ctx, src, n_bytes);
 		// (in front of named bytes whose upload has not begun)
 		for (size_t at = ctx->bz_up_queue.size() - 1; at > 0 && ctx->bz_up_queue[at - 1]->ticket != 0; at--)
 			std::swap(ctx->bz_up_queue[at - 1], ctx->bz_up_queue[at]);
-		for (const std::shared_ptr<BzJob> &later : ctx->bz_named)
-			bz_enqueue(ctx, later); // (behind this call's: the bytes of the calls after this one)
 	}
 	const double ms_head_start = ahead ? ms_since(job->t_queued) : 0.0;
 	// Named ahead WITH the block table: the inflates are launched (or being launched) into the spare output set by the job's own
@@ -1661,6 +1913,7 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const ByteSource &src, size_t 
 		bool asked;
 		{
 			std::lock_guard<std::mutex> g(job->mu);
+			job->adopted = true; // (a job that has not started yet will not start inflating ahead now: this call launches its inflates)
 			asked = job->inflate_asked;
 		}
 		if (asked) {
@@ -1683,8 +1936,10 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const ByteSource &src, size_t 
 				for (int k = 0; k < 2; k++)
 					(void) hipStreamSynchronize(ctx->bz_ahead[k]);
 			}
+			bz_spare_free(ctx, job);
 		}
 	}
+	enqueue_later();
 	if (inflated_ahead) {
 		{
 			std::unique_lock<std::mutex> lk(job->mu);
@@ -2469,19 +2724,23 @@ int conga_reads_bgzf_fd(conga_ctx *ctx, int fd, uint64_t file_off, size_t n_byte
 	return reads_bgzf_from(ctx, src, n_bytes, blocks, n_blocks, segments, n_segments, reads_per_chrom);
 }
 
-int conga_reads_bgzf_next_fd(conga_ctx *ctx, int fd, uint64_t file_off, size_t n_bytes, uint64_t *ticket)
+int conga_reads_bgzf_next_fd(conga_ctx *ctx, int fd, uint64_t file_off, size_t n_bytes, const uint64_t *known_starts, size_t n_known,
+		uint64_t stop_at, uint64_t *ticket)
 {
 	if (ticket)
 		*ticket = 0;
-	if (!ctx || fd < 0 || !ticket)
+	if (!ctx || fd < 0 || !ticket || (n_known && !known_starts))
 		return CONGA_ERR_INVALID;
+	for (size_t k = 0; k < n_known; k++)
+		if (known_starts[k] >= n_bytes || (k && known_starts[k] <= known_starts[k - 1]))
+			return CONGA_ERR_INVALID;
 	// (only what the overlapped route would take, and only with the ring in place: this call allocates nothing and touches
 	// nothing but the upload thread's queue -- it may come from another thread than the one inside conga_reads_bgzf_fd)
 	const char *ov = getenv("CONGA_BGZF_OVERLAP");
 	if (lane_kernel_asked() || !(ov ? atoi(ov) != 0 : n_bytes >= ((size_t) 96 << 20)) || n_bytes == 0 || getenv("CONGA_BGZF_NO_AHEAD"))
 		return CONGA_OK;
 	std::lock_guard<std::mutex> g(ctx->bz_up_mu);
-	if (!ctx->h_bz_ring || ctx->bz_ring_failed || !ctx->bz_copy || ctx->bz_named.size() >= 2 || ctx->bz_up_quit)
+	if (!ctx->h_bz_ring || ctx->bz_ring_failed || !ctx->bz_copy || ctx->bz_named.size() >= 3 || ctx->bz_up_quit)
 		return CONGA_OK;
 	ByteSource src;
 	src.fd = fd;
@@ -2490,8 +2749,20 @@ int conga_reads_bgzf_next_fd(conga_ctx *ctx, int fd, uint64_t file_off, size_t n
 	// begun, which a cohort's planning thread cannot know --: when the next call begins, behind its bytes or as its bytes)
 	// (only behind a job that is itself on its way: what was named first goes up first)
 	const bool now = ctx->bz_in_call && (ctx->bz_named.empty() || ctx->bz_named.back()->queued);
-	ctx->bz_named.push_back(bz_queue_job(ctx, src, n_bytes, now));
-	ctx->bz_named.back()->ticket = *ticket = ++ctx->bz_up_tickets;
+	std::shared_ptr<BzJob> job = bz_queue_job(ctx, src, n_bytes, false);
+	if (n_known && known_starts[0] == 0 && !getenv("CONGA_BGZF_NO_TABLE")) {
+		job->build_table = true;
+		job->known.assign(known_starts, known_starts + n_known);
+		job->stop_at = stop_at;
+		job->piece_tables.resize(job->n_pieces);
+		job->cap_blocks = n_bytes / 4096 + 65536; // (BAM writers fill a block with ~64 KB of records: 10-30 KB deflated)
+		job->blocks.reserve(job->cap_blocks);     // (the inflate-ahead thread reads what is published while the upload thread appends)
+		job->out_off.reserve(job->cap_blocks);
+	}
+	if (now)
+		bz_enqueue(ctx, job);
+	ctx->bz_named.push_back(job);
+	job->ticket = *ticket = ++ctx->bz_up_tickets;
 	return CONGA_OK;
 }
 
@@ -2528,11 +2799,45 @@ int conga_reads_bgzf_next_blocks(conga_ctx *ctx, uint64_t ticket, const conga_bg
 	std::lock_guard<std::mutex> gj(job->mu);
 	if (job->inflate_asked || job->cancel.load())
 		return CONGA_OK;
+	if (job->build_table)
+		return CONGA_OK; // (the engine reads the table off the bytes itself)
 	job->blocks.assign(blocks, blocks + n_blocks);
 	job->out_off.swap(out_off);
 	job->total_out = total;
+	job->table_n = n_blocks;
+	job->table_final = job->table_ok = true;
 	job->inflate_asked = true;
 	job->inflater = std::thread(bz_inflate_ahead, ctx, job);
+	return CONGA_OK;
+}
+
+int conga_reads_bgzf_next_table(conga_ctx *ctx, uint64_t ticket, const conga_bgzf_block **blocks, size_t *n_blocks)
+{
+	if (!ctx || !blocks || !n_blocks)
+		return CONGA_ERR_INVALID;
+	*blocks = nullptr;
+	*n_blocks = 0;
+	std::shared_ptr<BzJob> job;
+	{
+		std::unique_lock<std::mutex> lk(ctx->bz_up_mu);
+		for (const std::shared_ptr<BzJob> &j : ctx->bz_named)
+			if (ticket != 0 && j->ticket == ticket)
+				job = j;
+		if (!job || !job->build_table)
+			return CONGA_OK;
+		// Bytes named before the call in front of theirs has begun go up when it does -- a cohort's planning thread names sample
+		// k + 1 a few milliseconds before the call for sample k begins.  Not for ever: with no such call to come (the caller
+		// decodes sample k on the host after all) there will be no table, and the caller must not wait for one.
+		ctx->bz_up_cv.wait_for(lk, std::chrono::milliseconds(400), [&] { return job->queued; });
+		if (!job->queued)
+			return CONGA_OK;
+	}
+	std::unique_lock<std::mutex> lk(job->mu);
+	job->cv.wait(lk, [&] { return job->table_final || job->done; });
+	if (job->table_final && job->table_ok) {
+		*blocks = job->blocks.data();
+		*n_blocks = job->blocks.size();
+	}
 	return CONGA_OK;
 }
 
@@ -2603,6 +2908,10 @@ int reads_bgzf_from(conga_ctx *ctx, const ByteSource &src, size_t n_bytes, const
 	}
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	hipStream_t st = ctx->stream;
+	{
+		std::lock_guard<std::mutex> g(ctx->bz_up_mu);
+		ctx->bz_ratio = std::max(ctx->bz_ratio, (double) total / (double) std::max<size_t>(n_bytes, 1));
+	}
 	const bool timing = getenv("CONGA_TIMING") != nullptr;
 	const auto t_begin = std::chrono::steady_clock::now();
 	auto ms_since = [](std::chrono::steady_clock::time_point t) {

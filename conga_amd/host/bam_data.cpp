@@ -294,7 +294,8 @@ std::vector<std::pair<int, int>> select_chromosomes(const parameters *params, co
 }
 
 // engine: a context that will be given this input next (a cohort's kept one), or nullptr
-std::unique_ptr<planned_input> plan_input(const parameters *params, const sonic *this_sonic, const std::string &path, conga_ctx *engine = nullptr)
+std::unique_ptr<planned_input> plan_input(const parameters *params, const sonic *this_sonic, const std::string &path, conga_ctx *engine = nullptr,
+		std::atomic<bool> *named = nullptr, std::atomic<uint64_t> *ticket_out = nullptr)
 {
 	std::unique_ptr<planned_input> p(new planned_input);
 	std::string err;
@@ -309,13 +310,32 @@ std::unique_ptr<planned_input> plan_input(const parameters *params, const sonic 
 	const auto t0 = std::chrono::steady_clock::now();
 	const char *gpu_bam = getenv("CONGA_GPU_BAM");
 	planned_input *raw = p.get();
-	const std::function<void(const file_piece &)> opened = [raw, engine](const file_piece &bytes) {
-		if (engine && bytes.data == nullptr && bytes.fd >= 0)
-			(void) conga_reads_bgzf_next_fd(engine, bytes.fd, bytes.file_off, bytes.size, &raw->ahead_ticket);
-	};
-	p->planned = p->src->device_plan(p->targets, gpu_bam != nullptr ? 0 : gpu_bam_min_piece(), &p->bytes, &p->blocks, &p->segments, &err, &opened);
+	plan_hooks hooks;
+	bool engine_table = false;
+	if (engine) {
+		hooks.named = [raw, engine, named, ticket_out](const file_piece &bytes, const std::vector<uint64_t> &known_starts, uint64_t stop_at) {
+			if (bytes.data == nullptr && bytes.fd >= 0)
+				(void) conga_reads_bgzf_next_fd(engine, bytes.fd, bytes.file_off, bytes.size, known_starts.data(), known_starts.size(), stop_at,
+						&raw->ahead_ticket);
+			if (ticket_out)
+				ticket_out->store(raw->ahead_ticket);
+			if (named)
+				named->store(true); // (the sample behind this one may name its bytes now)
+		};
+		hooks.table = [raw, engine, &engine_table](std::vector<conga_bgzf_block> *blocks) {
+			const conga_bgzf_block *b = nullptr;
+			size_t n = 0;
+			if (!raw->ahead_ticket || conga_reads_bgzf_next_table(engine, raw->ahead_ticket, &b, &n) != CONGA_OK || n == 0)
+				return false;
+			blocks->assign(b, b + n); // (waits until the bytes are up: the sample in front is on the GPU meanwhile)
+			engine_table = true;
+			return true;
+		};
+	}
+	p->planned = p->src->device_plan(p->targets, gpu_bam != nullptr ? 0 : gpu_bam_min_piece(), &p->bytes, &p->blocks, &p->segments, &err,
+			engine ? &hooks : nullptr);
 	p->ms_plan = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-	if (p->planned && engine && p->ahead_ticket) // (the table is read: the bytes named above can be inflated ahead as well)
+	if (p->planned && engine && p->ahead_ticket && !engine_table) // (the table was read here: the bytes named above can be inflated ahead with it)
 		(void) conga_reads_bgzf_next_blocks(engine, p->ahead_ticket, p->blocks.data(), p->blocks.size());
 	return p;
 }
@@ -630,47 +650,82 @@ int read_bam_cohort(parameters *params, sonic *this_sonic)
 	kept_engine keep;
 	map_bam_pieces = samples.size() < 2; // (a mapping per sample would have to be given back between samples: reads.h)
 	const std::string outdir = params->outdir, outprefix = params->outprefix;
-	// the next sample's file is opened, mapped and its block table read while this sample is on the GPU
-	std::unique_ptr<planned_input> ahead = plan_input(params, this_sonic, samples[0].first);
+	// The samples behind the one on the GPU are got ready meanwhile, two deep: their files are opened and -- once the engine
+	// exists -- their bytes named to it from the index alone (conga_reads_bgzf_next_fd), so that the engine's upload thread
+	// brings sample k + 1 and then k + 2 up back to back, reads their block tables off the bytes and inflates them ahead; a
+	// sample's planning thread sleeps in conga_reads_bgzf_next_table until its bytes are up, then places the start points.
+	const size_t n_samples = samples.size();
+	std::vector<std::unique_ptr<planned_input>> plans(n_samples);
+	std::vector<std::thread> planners(n_samples);
+	std::unique_ptr<std::atomic<bool>[]> named(new std::atomic<bool>[n_samples]); // sample j's bytes are named (or will not be)
+	for (size_t j = 0; j < n_samples; j++)
+		named[j] = false;
+	std::unique_ptr<std::atomic<uint64_t>[]> tickets(new std::atomic<uint64_t>[n_samples]); // conga_reads_bgzf_next_fd's, 0: not named
+	for (size_t j = 0; j < n_samples; j++)
+		tickets[j] = 0;
+	auto launch = [&](size_t j, conga_ctx *engine, size_t ahead_of) { // ahead_of: the sample right behind the one on the GPU
+		if (j >= n_samples || planners[j].joinable() || plans[j])
+			return;
+		planners[j] = std::thread([&, j, engine, ahead_of] {
+			// (bytes go up in the order they were named: sample j's not before sample j - 1's)
+			while (engine && j > 0 && !named[j - 1].load())
+				std::this_thread::sleep_for(std::chrono::microseconds(200));
+			// (... and only behind NAMED bytes, or behind the sample on the GPU: a sample whose bytes the engine was not told about
+			// brings them with its call, and a call must not find two named stretches in front of its own)
+			conga_ctx *tell = engine && (j <= ahead_of || tickets[j - 1].load() != 0) ? engine : nullptr;
+			plans[j] = plan_input(params, this_sonic, samples[j].first, tell, &named[j], &tickets[j]);
+			named[j] = true;
+		});
+	};
+	plans[0] = plan_input(params, this_sonic, samples[0].first);
+	named[0] = true;
+	plan_beside_upload = n_samples > 1; // (from here on a plan runs beside a sample's upload: reads.h)
 	std::thread cleaner; // gives the sample before's mapping back (3 GB of touched pages: ~75 ms of munmap) beside this sample's work
 	const auto t_cohort = std::chrono::steady_clock::now();
-	for (size_t k = 0; k < samples.size(); k++) {
-		std::unique_ptr<planned_input> mine_now = std::move(ahead);
-		std::thread planner;
-		if (k + 1 < samples.size())
-			planner = std::thread([&, k, engine = keep.ctx] { // (keep.ctx: made by the first sample's run, the same from then on)
-				plan_beside_upload = true;
-				ahead = plan_input(params, this_sonic, samples[k + 1].first, engine);
-				plan_beside_upload = false;
-			});
+	auto give_up_plans = [&](size_t from) { // (an error ends the run: nothing of ours may still be running, no named bytes left behind)
+		for (size_t j = from; j < n_samples; j++) {
+			if (planners[j].joinable())
+				planners[j].join();
+			if (keep.ctx && plans[j] && plans[j]->ahead_ticket)
+				(void) conga_reads_bgzf_forget(keep.ctx, plans[j]->ahead_ticket);
+		}
+	};
+	for (size_t k = 0; k < n_samples; k++) {
+		if (planners[k].joinable())
+			planners[k].join();
+		std::unique_ptr<planned_input> mine_now = std::move(plans[k]);
+		launch(k + 1, keep.ctx, k + 1); // (keep.ctx: made by the first sample's run, the same from then on)
+		if (keep.ctx)
+			launch(k + 2, keep.ctx, k + 1);
 		params->bam_file = samples[k].first;
 		params->outdir.clear(); // (a prefix from the list is taken as it is; the default one already carries --out's directory)
 		params->outprefix = samples[k].second;
-		keep.last_sample = k + 1 == samples.size();
-		fprintf(stderr, "\n[CONGA] sample %zu of %zu: %s\n", k + 1, samples.size(), params->bam_file.c_str());
+		keep.last_sample = k + 1 == n_samples;
+		fprintf(stderr, "\n[CONGA] sample %zu of %zu: %s\n", k + 1, n_samples, params->bam_file.c_str());
 		// several contexts (--gpus N) are made per sample; one context is kept from sample to sample
 		const int rc = read_bam_with(params, this_sonic, params->n_gpus == 1 ? &keep : nullptr, mine_now.get());
 		const auto t_join = std::chrono::steady_clock::now();
-		if (planner.joinable())
-			planner.join();
-		if (getenv("CONGA_TIMING") && k + 1 < samples.size())
-			fprintf(stderr, "[timing] waited %.1f ms more for the next sample's plan (file opened, mapped, block table)\n",
+		if (k + 1 < n_samples && planners[k + 1].joinable())
+			planners[k + 1].join();
+		if (getenv("CONGA_TIMING") && k + 1 < n_samples)
+			fprintf(stderr, "[timing] waited %.1f ms more for the next sample's plan (file opened, bytes up, block table, start points)\n",
 					std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_join).count());
 		if (cleaner.joinable())
 			cleaner.join();
 		if (getenv("CONGA_TIMING")) // (what a further sample costs, read off one process's own clock: bench.py's end-to-end legs)
-			fprintf(stderr, "[timing] cohort: sample %zu of %zu is done %.1f ms after the first one began\n", k + 1, samples.size(),
+			fprintf(stderr, "[timing] cohort: sample %zu of %zu is done %.1f ms after the first one began\n", k + 1, n_samples,
 					std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_cohort).count());
 		// (bytes the engine was told about and never asked for -- this sample was decoded on the host after all, or failed --
 		// are given up before their descriptor goes; for bytes taken up this does nothing)
 		if (keep.ctx && mine_now && mine_now->ahead_ticket)
 			(void) conga_reads_bgzf_forget(keep.ctx, mine_now->ahead_ticket);
 		if (rc != 0) {
-			if (keep.ctx && ahead && ahead->ahead_ticket)
-				(void) conga_reads_bgzf_forget(keep.ctx, ahead->ahead_ticket);
-			return rc; // (nothing of ours is running: planner and cleaner are joined)
+			give_up_plans(k + 1);
+			if (cleaner.joinable())
+				cleaner.join();
+			return rc;
 		}
-		if (k + 1 < samples.size()) {
+		if (k + 1 < n_samples) {
 			planned_input *done = mine_now.release();
 			cleaner = std::thread([done] { delete done; });
 		} else if (getenv("CONGA_CLEAN_EXIT") == nullptr)

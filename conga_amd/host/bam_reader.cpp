@@ -561,7 +561,7 @@ public:
 	// target one start point per distinct linear-index offset.
 	bool device_plan(const std::vector<device_target> &targets, uint64_t min_piece_bytes, file_piece *bytes,
 			std::vector<conga_bgzf_block> *blocks, std::vector<conga_bam_segment> *segments, std::string *err,
-			const std::function<void(const file_piece &)> *opened = nullptr) override
+			const plan_hooks *hooks = nullptr) override
 	{
 		if (targets.empty() || linear_.empty())
 			return false;
@@ -608,10 +608,23 @@ public:
 		const char *mm = getenv("CONGA_BAM_MMAP");
 		if ((mm != nullptr ? atoi(mm) != 0 : map_bam_pieces) ? !bytes->open(path_, c_lo, stop) : !bytes->open_fd(path_, c_lo, stop))
 			return false;
-		// (which bytes the GPU will be given is known from the index alone: a cohort lets the engine start on them now, while
-		// the block table below is still being read -- conga_reads_bgzf_next_fd)
-		if (opened && *opened)
-			(*opened)(*bytes);
+		// known block starts inside the stretch, from the linear indexes of the targets
+		std::vector<uint64_t> starts;
+		for (const device_target &t : targets)
+			if (ref_beg_[(size_t) t.tid] != 0)
+				for (uint64_t v : linear_[(size_t) t.tid])
+					if (v != 0 && (v >> 16) > c_lo && (v >> 16) < (c_end ? c_end : stop))
+						starts.push_back(v >> 16);
+		std::sort(starts.begin(), starts.end());
+		starts.erase(std::unique(starts.begin(), starts.end()), starts.end());
+		// (which bytes the GPU will be given is known from the index alone: a cohort lets the engine start on them now -- and
+		// read the block table off them on their way, conga_reads_bgzf_next_fd)
+		if (hooks && hooks->named) {
+			std::vector<uint64_t> rel{0};
+			for (uint64_t v : starts)
+				rel.push_back(v - c_lo);
+			hooks->named(*bytes, rel, c_end ? c_end - c_lo : 0);
+		}
 		// ---- block table.  A BGZF file is a chain (every header says where the next block starts), but the index knows
 		// thousands of block starts along it: the stretch is cut at some of them and every part is walked by its own thread;
 		// a part must arrive exactly at the next part's start, otherwise the index is not trusted and the chain is walked
@@ -692,16 +705,16 @@ public:
 		};
 		std::vector<found> all;
 		bool walked = false;
-		{
-			// known block starts inside the stretch, from the linear indexes of the targets
-			std::vector<uint64_t> starts;
-			for (const device_target &t : targets)
-				if (ref_beg_[(size_t) t.tid] != 0)
-					for (uint64_t v : linear_[(size_t) t.tid])
-						if (v != 0 && (v >> 16) > c_lo && (v >> 16) < (c_end ? c_end : stop))
-							starts.push_back(v >> 16);
-			std::sort(starts.begin(), starts.end());
-			starts.erase(std::unique(starts.begin(), starts.end()), starts.end());
+		// the table the engine read off the bytes, if it did (a cohort's sample whose bytes were named ahead)
+		std::vector<conga_bgzf_block> given;
+		const bool have_given = hooks && hooks->table && hooks->table(&given) && !given.empty();
+		const bool check_given = have_given && getenv("CONGA_BGZF_CHECK_TABLE") != nullptr; // (tests: both, and they must agree)
+		if (have_given && !check_given) {
+			for (const conga_bgzf_block &b : given)
+				all.push_back(found{b, c_lo + b.data_off - 18});
+			walked = true;
+		}
+		if (!walked) {
 			// (beside another sample's upload -- a cohort plans sample k + 1 while sample k goes up -- six threads: the
 			// upload's threads and these share one CPU quota, and a throttled upload is what the GPU then waits for)
 			const int n_threads = std::min(plan_beside_upload.load() ? 6 : 16, std::max(1, usable_cpus() / reader_share()));
@@ -741,6 +754,17 @@ public:
 				*err = "not a BGZF block";
 				return false;
 			}
+		}
+		if (check_given) {
+			bool same = given.size() == all.size();
+			for (size_t k = 0; same && k < all.size(); k++)
+				same = memcmp(&given[k], &all[k].b, sizeof(conga_bgzf_block)) == 0;
+			if (!same) {
+				fprintf(stderr, "\n[CONGA] the block table the engine read off the bytes (%zu blocks) is not the one read from the file (%zu)\n",
+						given.size(), all.size());
+				abort();
+			}
+			fprintf(stderr, "\n[CONGA] block table: the engine's and the file's agree (%zu blocks)\n", all.size());
 		}
 		blocks->clear();
 		std::vector<uint64_t> file_off, inflated_off; // per kept block

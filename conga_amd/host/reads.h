@@ -50,6 +50,16 @@ struct file_piece {
 	bool open(const std::string &path, uint64_t from, uint64_t to);
 };
 
+// What a caller that keeps an engine context across inputs (a cohort) wants to know while an input is being planned:
+//   named   the stretch of the file is fixed (bytes: the open descriptor), with the offsets inside it at which the index knows
+//           a BGZF block to begin (ascending, the first one 0) and where the table will end (0: at the stretch's end)
+//   table   called before the block table is read from the file: true = *blocks holds it already (the engine read it off the
+//           bytes on their way to the GPU, conga_reads_bgzf_next_table), data_off relative to the stretch
+struct plan_hooks {
+	std::function<void(const file_piece &bytes, const std::vector<uint64_t> &known_starts, uint64_t stop_at)> named;
+	std::function<bool(std::vector<conga_bgzf_block> *blocks)> table;
+};
+
 struct device_target {
 	int tid;           // in the BAM header
 	int64_t chrom_len; // from the annotation
@@ -82,7 +92,7 @@ public:
 	// available (no index, not a BAM, a piece of the file smaller than min_piece_bytes or too large) -- decode on the host.
 	virtual bool device_plan(const std::vector<device_target> &targets, uint64_t min_piece_bytes, file_piece *bytes,
 			std::vector<conga_bgzf_block> *blocks, std::vector<conga_bam_segment> *segments, std::string *err,
-			const std::function<void(const file_piece &)> *opened = nullptr)
+			const plan_hooks *hooks = nullptr)
 	{
 		return false;
 	}

@@ -303,23 +303,33 @@ int conga_reads_bgzf(conga_ctx *ctx, const uint8_t *bytes, size_t n_bytes, const
 int conga_reads_bgzf_fd(conga_ctx *ctx, int fd, uint64_t file_off, size_t n_bytes, const conga_bgzf_block *blocks, size_t n_blocks,
 		const conga_bam_segment *segments, size_t n_segments, uint64_t *reads_per_chrom /* [conga_chrom_count()] or NULL */);
 
-/* A cohort's pipeline (conga --cohort: read_bam_cohort).  Names the bytes that the NEXT conga_reads_bgzf_fd call of this
- * context will bring -- same descriptor, offset and length --: the context's upload thread starts on them as soon as the
- * bytes of the call in progress (if any) are up, into the other of two device buffers, so that sample k + 1 crosses the link
- * while sample k is inflated, walked, computed and written out.  The reference reads its samples one process at a time
- * (bam_data.c:253-339); nothing of its results depends on when a sample's bytes were copied.
- * May be called from another thread than the one that is inside a call of this context (it touches the upload queue only).
- * *ticket: 0 when nothing was started (a piece too small for the overlapped route, no pinned ring yet, one named already).
- * The descriptor must stay open until the conga_reads_bgzf_fd call that takes the bytes up has returned, or until
- * conga_reads_bgzf_forget(ticket) has: that one gives an upload up that no call will ask for (the caller decided to decode
- * on the host), and is a no-op for a ticket already taken up.  A conga_reads_bgzf_fd call that names other bytes gives a
- * pending upload up by itself. */
-int conga_reads_bgzf_next_fd(conga_ctx *ctx, int fd, uint64_t file_off, size_t n_bytes, uint64_t *ticket);
-/* ... and their block table, once the caller has read it (the bytes are named from the index alone, before): the engine then
- * also INFLATES them ahead, batch by batch as they come up, into a spare output buffer; the conga_reads_bgzf_fd call that
- * brings the same table finds the stream inflated and goes straight to its record walks.  A table that differs from the
- * call's, or anything that goes wrong ahead, costs nothing but the head start: the call inflates as usual.  May be called
- * from another thread, like conga_reads_bgzf_next_fd; the table is copied. */
+/* A cohort's pipeline (conga --cohort: read_bam_cohort).  Names the bytes that a LATER conga_reads_bgzf_fd call of this context
+ * will bring -- same descriptor, offset and length --: the context's upload thread starts on them as soon as the bytes of the
+ * call in progress are up (bytes named between two calls go up when the next call begins, behind its own), into the other of
+ * two device buffers, so that sample k + 1 crosses the link while sample k is inflated, walked, computed and written out.
+ * The reference reads its samples one process at a time (bam_data.c:253-339); nothing of its results depends on when a
+ * sample's bytes were copied.  At most three stretches are held named; *ticket is 0 when nothing was started (a fourth one, a
+ * stretch too small for the overlapped route, no pinned ring yet).
+ *
+ * known_starts (n_known > 0): offsets inside the stretch at which the caller KNOWS a BGZF block to begin -- the index's linear
+ * offsets, ascending, the first one 0.  The engine then reads the block table off the bytes while they pass through its pinned
+ * ring (every copying thread follows the chain of headers inside its piece from the first known start on; what straddles two
+ * pieces is read from the file), publishes it batch by batch, and -- once a call of this context has shown how much such a
+ * file inflates to -- inflates the batches ahead as well, into a spare output buffer.  stop_at (0: none): the table ends with
+ * the first block that begins at or behind this offset.  conga_reads_bgzf_next_table() waits for the table (n_blocks 0: none
+ * -- a header of an unusual form, a chain that does not arrive at a known start: the caller walks the file itself); the
+ * conga_reads_bgzf_fd call that brings the SAME table finds the stream inflated and goes straight to its record walks, any
+ * other table makes it inflate as usual.  The pointer stays valid until that call has returned or the ticket is forgotten.
+ *
+ * A caller that has read the table by itself hands it over with conga_reads_bgzf_next_blocks() (copied) to the same effect.
+ *
+ * All of these may be called from another thread than the one inside a call of this context: they touch the upload thread's
+ * queue only.  The descriptor must stay open until the conga_reads_bgzf_fd call that takes the bytes up has returned, or until
+ * conga_reads_bgzf_forget(ticket) has: that one gives an upload up that no call will ask for (the caller decided to decode on
+ * the host) and is a no-op for a ticket already taken up. */
+int conga_reads_bgzf_next_fd(conga_ctx *ctx, int fd, uint64_t file_off, size_t n_bytes, const uint64_t *known_starts, size_t n_known,
+		uint64_t stop_at, uint64_t *ticket);
+int conga_reads_bgzf_next_table(conga_ctx *ctx, uint64_t ticket, const conga_bgzf_block **blocks, size_t *n_blocks);
 int conga_reads_bgzf_next_blocks(conga_ctx *ctx, uint64_t ticket, const conga_bgzf_block *blocks, size_t n_blocks);
 int conga_reads_bgzf_forget(conga_ctx *ctx, uint64_t ticket);
 

@@ -206,6 +206,7 @@ def main():
     t0 = time.time()
     done = 0
     if a.bam:
+        ahead_total = [0, 0]
         import re
         import subprocess
         import tempfile
@@ -256,6 +257,31 @@ def main():
             if outs["gpu"] != outs["host"]:
                 print("FAILED bam case %d (seed %d): GPU and host decode differ, files in %s" % (i, a.seed, d), flush=True)
                 raise SystemExit(1)
+            if "--gpus" not in args:
+                # ... and as a cohort of four: the engine kept, every further sample's bytes named ahead, its block table read off
+                # them by the engine (checked against the file's: CONGA_BGZF_CHECK_TABLE) and inflated ahead; pieces of any size,
+                # also far smaller than a BGZF block
+                with open(os.path.join(d, "list.txt"), "w") as f:
+                    f.write("".join("r.bam\tc%d\n" % k for k in range(4)))
+                env = dict(os.environ, CONGA_GPU_BAM="1", CONGA_BGZF_OVERLAP="1", CONGA_BGZF_CHECK_TABLE="1", CONGA_TIMING="1",
+                           CONGA_BGZF_PIECE_KB=str(int(rng.choice([4, 6, 16, 64, 512, 8192]))))
+                print("bam case %d: cohort of four, pieces of %s KB" % (i, env["CONGA_BGZF_PIECE_KB"]), flush=True)
+                try:
+                    r = subprocess.run([conga, "--cohort", "list.txt", "--out", "co"] + args[2:], cwd=d, capture_output=True, text=True, timeout=90, env=env)
+                except subprocess.TimeoutExpired as e:
+                    print("FAILED bam case %d (seed %d, cohort): no end after 90 s, files in %s\n%s" % (
+                        i, a.seed, d, (e.stderr or b"")[-3000:].decode("utf-8", "replace") if isinstance(e.stderr, bytes) else str(e.stderr)[-3000:]), flush=True)
+                    raise SystemExit(1)
+                if r.returncode != 0 or "decoding on the host" in r.stderr:
+                    print("FAILED bam case %d (seed %d, cohort) in %s:\n%s" % (i, a.seed, d, r.stderr[-2500:]), flush=True)
+                    raise SystemExit(1)
+                for k in range(4):
+                    files = [open(os.path.join(d, "c%d_%s.bed" % (k, kind)), "rb").read() for kind in ("svs", "dels", "dups")]
+                    if files != outs["gpu"][0]:
+                        print("FAILED bam case %d (seed %d): sample %d of the cohort differs from the single run, files in %s" % (i, a.seed, k, d), flush=True)
+                        raise SystemExit(1)
+                ahead_total[0] += r.stderr.count("named ahead with its block table")
+                ahead_total[1] += r.stderr.count("the engine's and the file's agree")
             import shutil
             shutil.rmtree(d)
             done += 1
@@ -263,7 +289,8 @@ def main():
                 print("%d bam cases ok, %.0f s" % (done, time.time() - t0), flush=True)
             if a.seconds and time.time() - t0 > a.seconds:
                 break
-        print("soak: %d random BAMs: decode on the GPU == host decoders (seed %d, %.0f s)" % (done, a.seed, time.time() - t0))
+        print("soak: %d random BAMs: decode on the GPU == host decoders == every sample of a cohort of four (%d samples inflated ahead, %d block "
+              "tables read by the engine and checked) (seed %d, %.0f s)" % (done, ahead_total[0], ahead_total[1], a.seed, time.time() - t0))
         return
     if a.packed:
         from conga_amd import synth

@@ -614,7 +614,7 @@ def test_fast_bed_parser_equals_the_literal_fgets_strtok_reader(tmp_path, oracle
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("decode", ["gpu", "host", "gpu_each"])
+@pytest.mark.parametrize("decode", ["gpu", "host", "gpu_each", "gpu_ahead", "gpu_ahead_small_pieces"])
 def test_cli_cohort_keeps_the_engine_and_every_byte(tmp_path, decode):
     """`--cohort list` (an extension: the reference is started once per sample, svdepth.c:16-74): several BAMs in one process,
     the engine context kept from sample to sample -- the layout too when the samples select the same chromosomes
@@ -646,10 +646,19 @@ def test_cli_cohort_keeps_the_engine_and_every_byte(tmp_path, decode):
         # a piece limit below the second (deepest) sample's stretch: that sample goes up chromosome by chromosome into the KEPT
         # layout (conga_sample_chrom names the chromosome of the context each call feeds), the others in one call each
         env["CONGA_GPU_BAM_MAX_MB"] = "%.4f" % (os.path.getsize(os.path.join(d, samples[1])) * 0.92 / 1048576)
+    if decode.startswith("gpu_ahead"):
+        # the pipeline of a cohort on files of test size: the overlapped upload forced (pieces of 64 KB -- or of 6 KB, smaller than a
+        # BGZF block: headers and trailers straddle pieces, pieces hold no known start), every further sample's bytes named ahead
+        # (conga_reads_bgzf_next_fd), the block table read off them by the engine -- checked against the one read from the file
+        # (CONGA_BGZF_CHECK_TABLE) -- and inflated ahead into the spare output set
+        env.update(CONGA_BGZF_OVERLAP="1", CONGA_BGZF_PIECE_KB="64" if decode == "gpu_ahead" else "6", CONGA_BGZF_CHECK_TABLE="1")
     r = subprocess.run([CONGA, "--cohort", "list.txt", "--out", "co"] + common, cwd=d, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     if decode != "host":
-        assert r.stderr.count("conga_reads_bgzf:") == (4 if decode == "gpu" else 6) and "decoding on the host" not in r.stderr
+        assert r.stderr.count("conga_reads_bgzf:") == (6 if decode == "gpu_each" else 4) and "decoding on the host" not in r.stderr
+    if decode.startswith("gpu_ahead"):
+        assert r.stderr.count("block table: the engine's and the file's agree") >= 2, r.stderr[-3000:]
+        assert r.stderr.count("named ahead with its block table") >= 1, r.stderr[-3000:]   # (how far ahead depends on the threads' timing)
     prefixes = ["co.s0", "named/two", "co.s2", "co.s3"]
     for k, bam in enumerate(samples):
         one = subprocess.run([CONGA, "-i", bam, "--out", "one%d" % k] + common, cwd=d, capture_output=True, text=True, timeout=600, env=env)
