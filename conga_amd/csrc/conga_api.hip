@@ -180,6 +180,8 @@ struct conga_ctx {
 	std::vector<std::shared_ptr<struct BzJob>> bz_named;
 	bool bz_in_call = false; // a conga_reads_bgzf* call is between queueing its bytes and its return
 	double bz_ratio = 0;     // inflated bytes per compressed byte of the largest call so far: sizes the spare output buffer
+	std::thread bz_prewarm; // CONGA_FLAG_EXPECT_COHORT: gets the second buffer of compressed bytes and the spare output set while the first sample is on
+	bool bz_prewarmed = false;
 	std::shared_ptr<struct BzJob> bz_spare_owner; // the named job whose inflates fill the spare output set (until the call that takes it up swaps the sets)
 	uint8_t *bz_up_buf[2] = {nullptr, nullptr};
 	size_t bz_up_cap[2] = {0, 0};
@@ -1241,6 +1243,7 @@ struct BzJob {
 namespace {
 
 void bz_inflate_ahead(conga_ctx *ctx, const std::shared_ptr<BzJob> &self);
+void bz_prewarm_join(conga_ctx *ctx);
 
 // BGZF header of the usual form at h[0..18) -> BSIZE + 1 (the block's length), or 0
 inline uint32_t bgzf_block_len(const uint8_t *h)
@@ -1399,6 +1402,7 @@ void bz_run_job(conga_ctx *ctx, const std::shared_ptr<BzJob> &self)
 	job.t_started = std::chrono::steady_clock::now();
 	if (hipSetDevice(ctx->device) != hipSuccess)
 		return give_up("hipSetDevice", false);
+	bz_prewarm_join(ctx); // (the buffers it allocates are about to be looked at)
 	{ // one of the two device buffers: the one no job owns, or whose job's bytes nobody reads any more
 		std::unique_lock<std::mutex> lk(ctx->bz_up_mu);
 		auto free_buf = [&]() {
@@ -1693,6 +1697,7 @@ void bz_upload_quiesce(conga_ctx *ctx, bool quit)
 	}
 	for (const std::shared_ptr<BzJob> &j : pre)
 		bz_abandon(ctx, j);
+	bz_prewarm_join(ctx);
 	bz_release(ctx, ctx->bz_job_kept); // (the call that took those bytes up has returned: nothing reads them)
 	{
 		std::unique_lock<std::mutex> lk(ctx->bz_up_mu);
@@ -1703,6 +1708,56 @@ void bz_upload_quiesce(conga_ctx *ctx, bool quit)
 	}
 	if (quit && ctx->bz_up_thread.joinable())
 		ctx->bz_up_thread.join();
+}
+
+bool quiet_ensure(DevBuf &b, size_t bytes);
+
+// CONGA_FLAG_EXPECT_COHORT: what the pipeline of a cohort needs besides the first sample's own buffers -- the second device buffer
+// for compressed bytes and the spare output set, ~3.6 bytes of HBM per byte of file -- is allocated by a thread of its own
+// while the first sample is inflated, indexed and computed: 45 GB take the runtime 1.3 s, which the second and third sample
+// would otherwise wait for (profiles/r03e_cohort_depth.log).
+void bz_prewarm_start(conga_ctx *ctx, size_t n_bytes)
+{
+	if (ctx->bz_prewarmed || !(ctx->opts.flags & CONGA_FLAG_EXPECT_COHORT) || getenv("CONGA_BGZF_NO_INFLATE_AHEAD"))
+		return;
+	ctx->bz_prewarmed = true;
+	double ratio;
+	{
+		std::lock_guard<std::mutex> g(ctx->bz_up_mu);
+		ratio = ctx->bz_ratio;
+	}
+	const int device = ctx->device;
+	ctx->bz_prewarm = std::thread([ctx, device, n_bytes, ratio] {
+		if (hipSetDevice(device) != hipSuccess)
+			return;
+		const size_t want = n_bytes + n_bytes / 16 + 512;
+		if (ctx->bz_up_cap[1] < want) {
+			uint8_t *p = nullptr;
+			if (hipMalloc((void **) &p, want) == hipSuccess) {
+				if (ctx->bz_up_buf[1])
+					(void) hipFree(ctx->bz_up_buf[1]);
+				ctx->bz_up_buf[1] = p;
+				ctx->bz_up_cap[1] = want;
+			} else
+				(void) hipGetLastError();
+		}
+		const size_t cap_blocks = n_bytes / 4096 + 65536;
+		const uint64_t cap_out = (uint64_t) ((double) n_bytes * ratio * 1.25) + ((uint64_t) 64 << 20);
+		(void) (quiet_ensure(ctx->d_bz_blocks2, cap_blocks * sizeof(conga_bgzf_block)) && quiet_ensure(ctx->d_bz_off2, cap_blocks * 8)
+				&& quiet_ensure(ctx->d_bz_out2, (size_t) cap_out + 64) && quiet_ensure(ctx->d_bz_status2, cap_blocks));
+	});
+}
+
+// (before anything else touches what it allocates: a named job's start, the inflate ahead, the context's end)
+void bz_prewarm_join(conga_ctx *ctx)
+{
+	std::thread t;
+	{
+		std::lock_guard<std::mutex> g(ctx->bz_up_mu);
+		t.swap(ctx->bz_prewarm);
+	}
+	if (t.joinable())
+		t.join();
 }
 
 // a device buffer of the spare set, grown without a word to the context (this runs beside the caller's thread)
@@ -1728,6 +1783,7 @@ void bz_inflate_ahead(conga_ctx *ctx, const std::shared_ptr<BzJob> &self)
 {
 	BzJob &job = *self;
 	bool ok = hipSetDevice(ctx->device) == hipSuccess;
+	bz_prewarm_join(ctx);
 	{ // the spare output set: one job at a time, in the order the jobs were named
 		std::unique_lock<std::mutex> lk(ctx->bz_up_mu);
 		ctx->bz_up_cv.wait(lk, [&] { return !ctx->bz_spare_owner || job.cancel.load(); });
@@ -1906,6 +1962,13 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const ByteSource &src, size_t 
 			std::swap(ctx->bz_up_queue[at - 1], ctx->bz_up_queue[at]);
 	}
 	const double ms_head_start = ahead ? ms_since(job->t_queued) : 0.0;
+	if ((ctx->opts.flags & CONGA_FLAG_EXPECT_COHORT) && !ctx->bz_prewarmed) {
+		{ // (once this call's job has taken its buffer: the thread below allocates the other one)
+			std::unique_lock<std::mutex> lk(job->mu);
+			job->cv.wait(lk, [&] { return job->started || job->failed || job->done; });
+		}
+		bz_prewarm_start(ctx, n_bytes);
+	}
 	// Named ahead WITH the block table: the inflates are launched (or being launched) into the spare output set by the job's own
 	// thread.  When that went well and the table is this call's, the sets change places and nothing is left to launch.
 	bool inflated_ahead = false;
@@ -2921,7 +2984,15 @@ int reads_bgzf_from(conga_ctx *ctx, const ByteSource &src, size_t n_bytes, const
 	uint32_t lanes = (uint32_t) std::min<size_t>((n_blocks + 63) & ~(size_t) 63, 131072);
 	if (const char *e = getenv("CONGA_BGZF_LANES")) // (tests: few lanes, several blocks each)
 		lanes = std::min(lanes, (uint32_t) std::max(64, atoi(e) & ~63));
-	TRY(ensure(ctx, ctx->d_bz_in, n_bytes + 512)); // (the decoders read ahead of their position: up to 64 dwords)
+	// the bytes and their inflate: overlapped (pinned pieces, several launches) for a piece of the file worth it and blocks in
+	// file order; otherwise one copy, one launch
+	bool in_order = true;
+	for (size_t b = 1; b < n_blocks && in_order; b++)
+		in_order = blocks[b].data_off >= blocks[b - 1].data_off + blocks[b - 1].data_len;
+	const char *ov = getenv("CONGA_BGZF_OVERLAP"); // (0 / 1 forces; tests run both forms on small files)
+	const bool overlapped = !lane_kernel_asked() && in_order && (ov ? atoi(ov) != 0 : n_bytes >= ((size_t) 96 << 20));
+	if (!overlapped) // (the overlapped form has device buffers of its own for the compressed bytes: the upload jobs')
+		TRY(ensure(ctx, ctx->d_bz_in, n_bytes + 512)); // (the decoders read ahead of their position: up to 64 dwords)
 	TRY(ensure(ctx, ctx->d_bz_blocks, n_blocks * sizeof(conga_bgzf_block)));
 	TRY(ensure(ctx, ctx->d_bz_off, n_blocks * 8));
 	TRY(ensure(ctx, ctx->d_bz_out, (size_t) (base + total) + 64, base > 0));
@@ -2938,13 +3009,6 @@ int reads_bgzf_from(conga_ctx *ctx, const ByteSource &src, size_t n_bytes, const
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bz_blocks.p, blocks, n_blocks * sizeof(conga_bgzf_block), hipMemcpyHostToDevice, st));
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bz_off.p, out_off.data(), n_blocks * 8, hipMemcpyHostToDevice, st));
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bz_seg.p, segments, n_segments * sizeof(conga_bam_segment), hipMemcpyHostToDevice, st));
-	// the bytes and their inflate: overlapped (pinned pieces, several launches) for a piece of the file worth it and blocks in
-	// file order; otherwise one copy, one launch
-	bool in_order = true;
-	for (size_t b = 1; b < n_blocks && in_order; b++)
-		in_order = blocks[b].data_off >= blocks[b - 1].data_off + blocks[b - 1].data_len;
-	const char *ov = getenv("CONGA_BGZF_OVERLAP"); // (0 / 1 forces; tests run both forms on small files)
-	const bool overlapped = !lane_kernel_asked() && in_order && (ov ? atoi(ov) != 0 : n_bytes >= ((size_t) 96 << 20));
 	double ms_alloc_upload = 0, ms_inflate = 0;
 	auto t_inflate = std::chrono::steady_clock::now();
 	std::vector<uint8_t> whole; // (a small piece of a file: read in one go)

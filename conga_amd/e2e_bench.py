@@ -95,7 +95,7 @@ def cohort_times(d, bams, k_many, common, env_extra, tag, repeats=2):
         import re
         done = [float(x) for x in re.findall(r"cohort: sample \d+ of \d+ is done ([0-9.]+) ms", e)]
         assert len(done) == k_many, e[-1500:]
-        per = min(per, (done[-1] - done[0]) / (k_many - 1))
+        per = min(per, (done[-1] - done[0]) / (k_many - 1))   # (ramp and drain of the two-deep pipeline included: what a cohort of K costs)
         if t < best:
             best, err = t, e
     if os.environ.get("CONGA_BENCH_STDERR_DIR"):   # (the [timing] lines of the long run, for whoever wants the stages)
@@ -129,7 +129,7 @@ def zlib_one_core(path, budget_s=1.5):
     return done / max(t_used, 1e-9) / 1e9, inflated_total, n
 
 
-def leg(args, env, mine, recs0, cpu_intervals_per_s, k_many=5):
+def leg(args, env, mine, recs0, cpu_intervals_per_s, k_many=10):
     """mine: the main leg's units (layout + three samples' tuples); recs0: the records the tuple route computed for sample 0."""
     if not (os.path.exists(CONGA) and os.path.exists(BAMWRITE)):
         return dict(error="conga / tools/bamwrite are not built")

@@ -346,6 +346,7 @@ struct kept_engine {
 	conga_ctx *ctx = nullptr;
 	std::string layout_key;
 	bool last_sample = false; // no BAM behind this one: the pinned staging can go while the context computes
+	bool expect_cohort = false; // three samples or more: their bytes will be named ahead (read_bam_cohort)
 };
 
 std::string layout_key_of(const std::vector<chrom_job *> &mine)
@@ -392,6 +393,8 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 		const char *gb = getenv("CONGA_GPU_BAM"); // (the decode may go to the GPU: let the engine get its staging ring meanwhile)
 		if (gb == nullptr || atoi(gb) != 0)
 			opts.flags |= CONGA_FLAG_EXPECT_BGZF;
+		if (keep && keep->expect_cohort)
+			opts.flags |= CONGA_FLAG_EXPECT_COHORT; // (a list of several BAMs: the pipeline's buffers while the first one is on)
 	}
 	opts.min_read_length = params->min_read_length;
 	// the reference's split-read gate: `!no_sr && dup_file` (svdepth.c:57, bam_data.c:207,306,331, likelihood.c:344)
@@ -677,6 +680,15 @@ int read_bam_cohort(parameters *params, sonic *this_sonic)
 			named[j] = true;
 		});
 	};
+	// How many samples behind the one on the GPU have their bytes named to the engine (CONGA_COHORT_AHEAD: measurement switch).
+	// Two where the GPU has slack beside the link -- a 1x genome: 35-40 ms of upload against ~40 ms of inflate, walks and compute
+	// that wait for it; 49 ms per sample against 56 with none named.  None with split reads: a 5x genome with sequences keeps the
+	// GPU as long as the link (inflate 265 ms + walks + the split-read stage against 310-370 ms of upload), uploads that share
+	// the machine with the sample in front's kernels take 440-470 ms instead, and the pipeline's second set of buffers (45 GB)
+	// costs the first samples a second: 430-690 ms per sample of a cohort of six against 380-405 (profiles/r03e_cohort_depth.log).
+	const bool with_split_reads = !params->no_sr && params->have_dups;
+	const int ahead_depth = getenv("CONGA_COHORT_AHEAD") ? atoi(getenv("CONGA_COHORT_AHEAD")) : with_split_reads ? 0 : 2;
+	keep.expect_cohort = n_samples >= 3 && ahead_depth >= 1;
 	plans[0] = plan_input(params, this_sonic, samples[0].first);
 	named[0] = true;
 	plan_beside_upload = n_samples > 1; // (from here on a plan runs beside a sample's upload: reads.h)
@@ -694,8 +706,8 @@ int read_bam_cohort(parameters *params, sonic *this_sonic)
 		if (planners[k].joinable())
 			planners[k].join();
 		std::unique_ptr<planned_input> mine_now = std::move(plans[k]);
-		launch(k + 1, keep.ctx, k + 1); // (keep.ctx: made by the first sample's run, the same from then on)
-		if (keep.ctx)
+		launch(k + 1, ahead_depth >= 1 ? keep.ctx : nullptr, k + 1); // (keep.ctx: made by the first sample's run, the same from then on)
+		if (keep.ctx && ahead_depth >= 2)
 			launch(k + 2, keep.ctx, k + 1);
 		params->bam_file = samples[k].first;
 		params->outdir.clear(); // (a prefix from the list is taken as it is; the default one already carries --out's directory)
