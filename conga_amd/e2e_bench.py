@@ -87,7 +87,7 @@ def cohort_times(d, bams, k_many, common, env_extra, tag, repeats=2):
         for k in range(k_many):
             f.write("%s\t%s_s%d\n" % (bams[k % len(bams)], tag, k))
     t1 = min(run_conga(["--cohort", one, "--out", tag] + common, d, env_extra)[0] for _ in range(repeats))
-    best, err, per = 1e30, "", 1e30
+    best, err, per, steady = 1e30, "", 1e30, 1e30
     for _ in range(repeats):
         t, e = run_conga(["--cohort", many, "--out", tag] + common, d, env_extra)
         # the process's own clock at every sample's end (CONGA_TIMING): a further sample = (last - first) / (K - 1), free of how
@@ -96,8 +96,12 @@ def cohort_times(d, bams, k_many, common, env_extra, tag, repeats=2):
         done = [float(x) for x in re.findall(r"cohort: sample \d+ of \d+ is done ([0-9.]+) ms", e)]
         assert len(done) == k_many, e[-1500:]
         per = min(per, (done[-1] - done[0]) / (k_many - 1))   # (ramp and drain of the two-deep pipeline included: what a cohort of K costs)
+        deltas = sorted(b - a for a, b in zip(done[3:-1], done[4:]))   # (samples 5 .. K: the pipeline is full)
+        if deltas:
+            steady = min(steady, deltas[len(deltas) // 2])
         if t < best:
             best, err = t, e
+    cohort_times.steady_state_ms = None if steady > 1e29 else steady
     if os.environ.get("CONGA_BENCH_STDERR_DIR"):   # (the [timing] lines of the long run, for whoever wants the stages)
         with open(os.path.join(os.environ["CONGA_BENCH_STDERR_DIR"], "conga_cohort_%s.err" % tag), "w") as f:
             f.write(err)
@@ -143,6 +147,10 @@ def leg(args, env, mine, recs0, cpu_intervals_per_s, k_many=10):
             p, dt = write_bam(d, "s%d" % j, [(u["name"], u["length"], u["reads"][j][0], u["reads"][j][1]) for u in mine])
             bams.append(p)
             t_write += dt
+        for p in bams * 3:   # (a file's pages are promoted in the kernel's lists on their second and third reading, at a price that is
+            with open(p, "rb") as f:   # not this path's: the timed runs below read settled pages, as they would read a file once)
+                while f.read(64 << 20):
+                    pass
         size = os.path.getsize(bams[0])
         n_reads = int(sum(len(u["reads"][0][0]) for u in mine))
         common = ["--ref", "r.fa", "--sonic", "a.cga", "--dels", "dels.bed"]
@@ -159,6 +167,10 @@ def leg(args, env, mine, recs0, cpu_intervals_per_s, k_many=10):
             assert ("decoding on the host" not in err) and (err.count("conga_reads_bgzf:") == (k if decode == "gpu" else 0)), err[-1500:]
             res[decode] = dict(decode=decode, first_sample_s=round(t1, 3), per_further_sample_ms=round(per, 1), samples=k, wall_s=round(t_k, 3),
                                intervals_per_s=round(n_iv / (per * 1e-3), 1))
+            if decode == "gpu" and cohort_times.steady_state_ms:
+                res[decode]["steady_state_ms"] = round(cohort_times.steady_state_ms, 1)
+                res[decode]["note"] = ("per_further_sample_ms: (end of sample K - end of sample 1) / (K - 1), the pipeline's first samples -- its second "
+                                       "set of buffers is allocated while they run -- and its drain included; steady_state_ms: the median over samples 5 .. K")
         # the two decoders wrote the same files; sample 0's observed depths are the tuple route's
         for k in range(3):
             for kind in ("svs", "dels"):
