@@ -133,7 +133,7 @@ def zlib_one_core(path, budget_s=1.5):
     return done / max(t_used, 1e-9) / 1e9, inflated_total, n
 
 
-def leg(args, env, mine, recs0, cpu_intervals_per_s, k_many=10):
+def leg(args, env, mine, recs0, cpu_intervals_per_s, k_many=30):
     """mine: the main leg's units (layout + three samples' tuples); recs0: the records the tuple route computed for sample 0."""
     if not (os.path.exists(CONGA) and os.path.exists(BAMWRITE)):
         return dict(error="conga / tools/bamwrite are not built")

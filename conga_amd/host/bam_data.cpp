@@ -347,6 +347,7 @@ struct kept_engine {
 	std::string layout_key;
 	bool last_sample = false; // no BAM behind this one: the pinned staging can go while the context computes
 	bool expect_cohort = false; // three samples or more: their bytes will be named ahead (read_bam_cohort)
+	std::atomic<conga_ctx *> early_ctx{nullptr}; // the context as soon as it exists (the first sample's run makes it on a thread of its own)
 };
 
 std::string layout_key_of(const std::vector<chrom_job *> &mine)
@@ -422,6 +423,8 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 			exit(CONGA_EXIT_COMMON);
 		}
 		wt->ms_create = ms_since(t_create);
+		if (keep)
+			keep->early_ctx.store(ctx); // (the second sample's planning thread is waiting for it: read_bam_cohort)
 	};
 	const auto t_loop = now();
 
@@ -666,11 +669,19 @@ int read_bam_cohort(parameters *params, sonic *this_sonic)
 	std::unique_ptr<std::atomic<uint64_t>[]> tickets(new std::atomic<uint64_t>[n_samples]); // conga_reads_bgzf_next_fd's, 0: not named
 	for (size_t j = 0; j < n_samples; j++)
 		tickets[j] = 0;
-	auto launch = [&](size_t j, conga_ctx *engine, size_t ahead_of) { // ahead_of: the sample right behind the one on the GPU
+	std::atomic<bool> first_sample_done{false};
+	auto launch = [&](size_t j, conga_ctx *engine_now, size_t ahead_of, bool wait_for_engine = false) { // ahead_of: the sample right behind the one on the GPU
 		if (j >= n_samples || planners[j].joinable() || plans[j])
 			return;
-		planners[j] = std::thread([&, j, engine, ahead_of] {
+		planners[j] = std::thread([&, j, engine_now, ahead_of, wait_for_engine] {
 			// (bytes go up in the order they were named: sample j's not before sample j - 1's)
+			conga_ctx *engine = engine_now;
+			if (!engine && wait_for_engine) { // the first sample is on: its context appears a few hundred milliseconds into it
+				for (int spin = 0; spin < 20000 && !(engine = keep.early_ctx.load()) && !first_sample_done.load(); spin++)
+					std::this_thread::sleep_for(std::chrono::microseconds(200));
+				if (!engine)
+					engine = keep.early_ctx.load();
+			}
 			while (engine && j > 0 && !named[j - 1].load())
 				std::this_thread::sleep_for(std::chrono::microseconds(200));
 			// (... and only behind NAMED bytes, or behind the sample on the GPU: a sample whose bytes the engine was not told about
@@ -698,15 +709,17 @@ int read_bam_cohort(parameters *params, sonic *this_sonic)
 		for (size_t j = from; j < n_samples; j++) {
 			if (planners[j].joinable())
 				planners[j].join();
-			if (keep.ctx && plans[j] && plans[j]->ahead_ticket)
-				(void) conga_reads_bgzf_forget(keep.ctx, plans[j]->ahead_ticket);
+			conga_ctx *engine = keep.ctx ? keep.ctx : keep.early_ctx.load();
+			if (engine && plans[j] && plans[j]->ahead_ticket)
+				(void) conga_reads_bgzf_forget(engine, plans[j]->ahead_ticket);
 		}
 	};
 	for (size_t k = 0; k < n_samples; k++) {
 		if (planners[k].joinable())
 			planners[k].join();
 		std::unique_ptr<planned_input> mine_now = std::move(plans[k]);
-		launch(k + 1, ahead_depth >= 1 ? keep.ctx : nullptr, k + 1); // (keep.ctx: made by the first sample's run, the same from then on)
+		// (keep.ctx: made by the first sample's run, the same from then on; the second sample's planning thread waits for it to appear)
+		launch(k + 1, ahead_depth >= 1 ? keep.ctx : nullptr, k + 1, ahead_depth >= 1 && k == 0 && params->n_gpus == 1);
 		if (keep.ctx && ahead_depth >= 2)
 			launch(k + 2, keep.ctx, k + 1);
 		params->bam_file = samples[k].first;
@@ -716,6 +729,7 @@ int read_bam_cohort(parameters *params, sonic *this_sonic)
 		fprintf(stderr, "\n[CONGA] sample %zu of %zu: %s\n", k + 1, n_samples, params->bam_file.c_str());
 		// several contexts (--gpus N) are made per sample; one context is kept from sample to sample
 		const int rc = read_bam_with(params, this_sonic, params->n_gpus == 1 ? &keep : nullptr, mine_now.get());
+		first_sample_done = true;
 		const auto t_join = std::chrono::steady_clock::now();
 		if (k + 1 < n_samples && planners[k + 1].joinable())
 			planners[k + 1].join();
