@@ -48,10 +48,14 @@ constexpr int kMaxLens = 320;
 // follow it; the base values of lengths and distances (needed only for the lanes that turn out to be symbols) come from
 // two small tables afterwards.
 struct LitFormat {
-	// [3:0] codeword length n1; [6:4] extra bits of a length symbol (0 for a literal); [7] length symbol;
-	// [15:8] literal byte / index of the length symbol (0..28).  [7] = 0 and [6:4] != 0: something that ends a chain --
-	enum : uint32_t { kEob = 0x10, kSub = 0x20, kHoleTag = 0x30 };
-	// kEob | n1: end of block; kSub | bits indexing the second-level table | (its offset behind the root / 2) << 8;
+	// [4:0] codeword length n1 -- of a length symbol: PLUS its count of extra bits (<= 15 + 5), which is what a lane needs to find
+	// the distance code behind it; the count itself comes with the base value (Luts::len); [6:5] class: 0 literal / length symbol,
+	// 1 pointer to a second-level table, 2 end of block, 3 hole; [7] length symbol; [15:8] literal byte / index of the length
+	// symbol (0..28) / a pointer's (offset behind the root) / 2.  So `entry & 0x5F` is the distance from a symbol's first bit to
+	// whatever follows its literal / length part, and 64 or more exactly for the two kinds of entry that end a chain.
+	enum : uint32_t { kSub = 0x20, kEob = 0x40, kHoleTag = 0x60 };
+	// kEob | n1: end of block; kSub | bits indexing the second-level table ([4:0]: the field width v_bfe_u32 takes from a
+	// register as it is) | (its offset behind the root / 2) << 8;
 	// kHoleTag: no codeword leads here (or one of the two that must not occur)
 	static constexpr uint32_t hole = kHoleTag | 1u; // (n1 = 1: whatever stands at a position, the symbol behind it starts further on)
 	__device__ static uint32_t entry(uint32_t sym, uint32_t len)
@@ -64,7 +68,7 @@ struct LitFormat {
 		if (i > 28u)
 			return hole; // 286, 287: in the fixed code, never in valid data
 		const uint32_t eb = (i < 8u || i == 28u) ? 0u : (i >> 2) - 1u;
-		return len | (eb << 4) | 0x80u | (i << 8);
+		return (len + eb) | 0x80u | (i << 8);
 	}
 	// (second-level tables have 2^sb >= 2 entries each and follow one another behind the root: every offset is even)
 	__device__ static uint32_t pointer(uint32_t sb, uint32_t rel) { return sb | kSub | ((rel >> 1) << 8); }
@@ -73,7 +77,8 @@ struct LitFormat {
 };
 struct DistFormat {
 	// [15:14] = 0: [4:0] codeword length + extra bits, [8:5] extra bits, [13:9] distance symbol (0..29)
-	// [15:14] = 1: [3:0] bits indexing the second-level table, [13:4] its offset behind the root;  [15:14] = 2: no codeword
+	// [15:14] = 1: [4:0] bits indexing the second-level table, [13:5] (its offset behind the root) / 2;  [15:14] = 2: no codeword
+	// (a pointer's low five bits are the field width v_bfe_u32 takes from a register: no masking on the way to the second level)
 	static constexpr uint32_t hole = 0x8000u;
 	__device__ static uint32_t entry(uint32_t sym, uint32_t len)
 	{
@@ -82,9 +87,10 @@ struct DistFormat {
 		const uint32_t deb = sym < 4u ? 0u : (sym >> 1) - 1u;
 		return (len + deb) | (deb << 5) | (sym << 9);
 	}
-	__device__ static uint32_t pointer(uint32_t sb, uint32_t rel) { return sb | (rel << 4) | 0x4000u; }
-	__device__ static uint32_t pointer_start(uint32_t ptr) { return (ptr >> 4) & 1023u; }
-	__device__ static uint32_t pointer_bits(uint32_t ptr) { return ptr & 15u; }
+	// (second-level tables have 2^sb >= 2 entries each and follow one another behind the root: every offset is even)
+	__device__ static uint32_t pointer(uint32_t sb, uint32_t rel) { return sb | ((rel >> 1) << 5) | 0x4000u; }
+	__device__ static uint32_t pointer_start(uint32_t ptr) { return ((ptr >> 5) & 511u) << 1; }
+	__device__ static uint32_t pointer_bits(uint32_t ptr) { return ptr & 31u; }
 };
 
 struct alignas(16) WaveLds {
@@ -316,7 +322,7 @@ struct Stream {
 // Base value and number of extra bits of the length symbols 257..285 (index 0..28; 29, 30: the fixed code's 286, 287,
 // refused) and of the distance symbols 0..29 (30, 31: refused) -- RFC 1951 3.2.5 -- computed, not tabulated by hand.
 struct Luts {
-	uint16_t len[32];  // base value of length symbol 257 + i
+	uint16_t len[32];  // [8:0] base value of length symbol 257 + i, [14:12] its count of extra bits
 	uint16_t dist[32]; // base value of distance symbol i
 };
 
@@ -324,7 +330,7 @@ __device__ __forceinline__ void fill_luts(Luts &l, uint32_t i /* 0..31 */)
 {
 	const uint32_t eb = (i < 8u || i >= 28u) ? 0u : (i >> 2) - 1u;
 	const uint32_t lbase = i < 8u ? 3u + i : i == 28u ? 258u : 3u + ((4u + (i & 3u)) << eb);
-	l.len[i] = (uint16_t) lbase;
+	l.len[i] = (uint16_t) (lbase | (eb << 12));
 	const uint32_t deb = i < 4u ? 0u : (i >> 1) - 1u;
 	const uint32_t dbase = i < 4u ? 1u + i : 1u + ((2u + (i & 1u)) << deb);
 	l.dist[i] = (uint16_t) dbase; // (<= 24 577; the entries of symbols that do not exist are never asked for: their codewords are holes)
@@ -415,22 +421,22 @@ __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Lu
 		// returns 0 -- and drops it.  Deliberate: a clamp would be two more vector instructions per trip for nothing.)
 		const uint32_t e1 = t.lit[lo & ((1u << kLitRoot) - 1u)];
 		const bool sub1 = (e1 & 0xF0u) == LitFormat::kSub;
-		const uint32_t e2 = t.lit[(1u << kLitRoot) + ((e1 >> 8) << 1) + ((lo >> kLitRoot) & ((1u << (e1 & 15u)) - 1u))];
+		const uint32_t e2 = t.lit[(1u << kLitRoot) + ((e1 >> 8) << 1) + __builtin_amdgcn_ubfe(lo, (uint32_t) kLitRoot, e1)];
 		const uint32_t e = sub1 ? e2 : e1;
-		const uint32_t n1 = e & 15u, eb = (e >> 4) & 7u; // (eb: of a literal 0; of an entry that ends the chain, not used)
+		const uint32_t n1eb = e & 31u; // the codeword's length, of a length symbol with its extra bits
 		const bool is_match = (e & 0x80u) != 0u;
 		// ... as a length: its extra bits, the distance code behind them and that one's extra bits (<= 15 + 13 bits from bit n1 + eb <= 20)
-		const uint32_t r2 = alignbit(hi, lo, n1 + eb);
+		const uint32_t r2 = alignbit(hi, lo, n1eb);
 		const uint32_t d1 = t.dist[r2 & ((1u << kDistRoot) - 1u)];
 		const bool subd = (d1 & 0xC000u) == 0x4000u;
-		const uint32_t d2 = t.dist[(1u << kDistRoot) + ((d1 >> 4) & 1023u) + ((r2 >> kDistRoot) & ((1u << (d1 & 15u)) - 1u))];
+		const uint32_t d2 = t.dist[(1u << kDistRoot) + (((d1 >> 5) & 511u) << 1) + __builtin_amdgcn_ubfe(r2, (uint32_t) kDistRoot, d1)];
 		const uint32_t ed = subd ? d2 : d1;
 		// base values: asked for now, needed behind the walk
-		const uint32_t lbase = luts.len[(e >> 8) & 31u];
+		const uint32_t lb = luts.len[(e >> 8) & 31u];
 		const uint32_t dbase = luts.dist[(ed >> 9) & 31u];
 		// (never 0: a codeword has a length, and a hole is given one -- LitFormat::hole; the walk below must move)
 		const unsigned long long is_match_m = __ballot(is_match);
-		const uint32_t bits = is_match ? n1 + eb + (ed & 31u) : n1;
+		const uint32_t bits = is_match ? n1eb + (ed & 31u) : n1eb;
 		const uint32_t nxt = lane + bits; // where the symbol behind this one starts
 		IW_LAP(P_VIEW);
 
@@ -467,7 +473,8 @@ __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Lu
 		const uint32_t deb = (ed >> 5) & 15u;
 		const uint32_t dist = dbase + ((r2 >> ((ed & 31u) - deb)) & ((1u << deb) - 1u));
 		const bool is_len = __builtin_amdgcn_inverse_ballot_w64(is_match_m); // (the predicate behind the walk: straight from the mask)
-		const uint32_t produced = is_len ? lbase + ((lo >> n1) & ((1u << eb) - 1u)) : is_lit ? 1u : 0u;
+		const uint32_t eb = lb >> 12, lbase = lb & 511u;
+		const uint32_t produced = is_len ? lbase + ((lo >> (n1eb - eb)) & ((1u << eb) - 1u)) : is_lit ? 1u : 0u;
 		IW_LAP(P_WALK);
 		// where every start's bytes go
 		const uint32_t mine = on_chain ? produced : 0u;
@@ -609,20 +616,21 @@ __device__ __forceinline__ int run_symbols_batched(Stream &s, const WaveLds &t, 
 		const uint32_t lo = (uint32_t) v;
 		const uint32_t e1 = t.lit[lo & ((1u << kLitRoot) - 1u)];
 		const bool sub1 = (e1 & 0xF0u) == LitFormat::kSub;
-		const uint32_t e2 = t.lit[(1u << kLitRoot) + ((e1 >> 8) << 1) + __builtin_amdgcn_ubfe(lo, (uint32_t) kLitRoot, e1 & 15u)];
+		const uint32_t e2 = t.lit[(1u << kLitRoot) + ((e1 >> 8) << 1) + __builtin_amdgcn_ubfe(lo, (uint32_t) kLitRoot, e1)];
 		const uint32_t e = sub1 ? e2 : e1;
-		const uint32_t n1 = e & 15u, eb = (e >> 4) & 7u;
+		const uint32_t n1eb = e & 31u;
 		const bool is_len = have && (e & 0x80u) != 0u;
-		const uint32_t r2 = (uint32_t) (v >> (n1 + eb));
+		const uint32_t r2 = (uint32_t) (v >> n1eb);
 		const uint32_t d1 = t.dist[r2 & ((1u << kDistRoot) - 1u)];
 		const bool subd = (d1 & 0xC000u) == 0x4000u;
-		const uint32_t d2 = t.dist[(1u << kDistRoot) + ((d1 >> 4) & 1023u) + __builtin_amdgcn_ubfe(r2, (uint32_t) kDistRoot, d1 & 15u)];
+		const uint32_t d2 = t.dist[(1u << kDistRoot) + (((d1 >> 5) & 511u) << 1) + __builtin_amdgcn_ubfe(r2, (uint32_t) kDistRoot, d1)];
 		const uint32_t ed = subd ? d2 : d1;
-		const uint32_t lbase = luts.len[(e >> 8) & 31u];
+		const uint32_t lb = luts.len[(e >> 8) & 31u];
 		const uint32_t dbase = luts.dist[(ed >> 9) & 31u];
 		const uint32_t deb = (ed >> 5) & 15u;
 		const uint32_t dist = dbase + ((r2 >> ((ed & 31u) - deb)) & ((1u << deb) - 1u));
-		const uint32_t produced = !have ? 0u : is_len ? lbase + ((lo >> n1) & ((1u << eb) - 1u)) : 1u;
+		const uint32_t eb = lb >> 12, lbase = lb & 511u;
+		const uint32_t produced = !have ? 0u : is_len ? lbase + ((lo >> (n1eb - eb)) & ((1u << eb) - 1u)) : 1u;
 		const uint32_t incl = wave_incl_scan(produced);
 		const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
 		// more output than the block holds; a length whose distance code is a hole (asked here, of real symbols only)
@@ -697,41 +705,54 @@ __device__ __forceinline__ int run_symbols_batched(Stream &s, const WaveLds &t, 
 		const uint32_t lo = alignbit(w1, w0, sh), hi = alignbit(w2, w1, sh);
 		const uint32_t e1 = t.lit[lo & ((1u << kLitRoot) - 1u)];
 		const bool sub1 = (e1 & 0xF0u) == LitFormat::kSub;
-		const uint32_t e2 = t.lit[(1u << kLitRoot) + ((e1 >> 8) << 1) + __builtin_amdgcn_ubfe(lo, (uint32_t) kLitRoot, e1 & 15u)];
+		const uint32_t e2 = t.lit[(1u << kLitRoot) + ((e1 >> 8) << 1) + __builtin_amdgcn_ubfe(lo, (uint32_t) kLitRoot, e1)];
 		const uint32_t e = sub1 ? e2 : e1;
-		const uint32_t n1 = e & 15u, eb = (e >> 4) & 7u;
-		const bool is_match = (e & 0x80u) != 0u;
-		const uint32_t r2 = alignbit(hi, lo, n1 + eb);
+		const unsigned long long match_m = __builtin_amdgcn_ballot_w64((e & 0x80u) != 0u); // the candidates that are length symbols
+		// from the symbol's first bit to what follows its literal / length part; 64 or more for an end-of-block symbol and for a
+		// hole (LitFormat): their "next start" lies outside the window, so the walk stops there by itself, and what stood there
+		// is asked of that one lane afterwards -- no ballots, no cutting of masks.
+		uint32_t bits = e & 0x5Fu;
+		const uint32_t r2 = alignbit(hi, lo, bits);
 		const uint32_t d1 = t.dist[r2 & ((1u << kDistRoot) - 1u)];
-		const bool subd = (d1 & 0xC000u) == 0x4000u;
-		const uint32_t d2 = t.dist[(1u << kDistRoot) + ((d1 >> 4) & 1023u) + __builtin_amdgcn_ubfe(r2, (uint32_t) kDistRoot, d1 & 15u)];
-		const uint32_t ed = subd ? d2 : d1;
-		const uint32_t bits = is_match ? n1 + eb + (ed & 31u) : n1;
-		// An end-of-block symbol or a hole ends the chain where it stands: its "next start" lies outside the window, so the walk
-		// stops there by itself, and what it was is asked of that one lane afterwards -- no ballots, no cutting of masks.
-		// (entries that end a chain: [7] = 0 and [4] = 1 -- kEob 0x10, kHoleTag 0x30; a resolved entry is never a pointer)
-		const uint32_t nxt = (e & 0x90u) == 0x10u ? 64u : lane + bits;
-		unsigned long long chain = 0;
+		uint32_t dbits = d1 & 31u; // the distance code with its extra bits
+		// (the second level of the distance code only in trips where a candidate length symbol leads to one: distance codes of
+		// more than seven bits are the rare small distances)
+		const unsigned long long subd_m = match_m & __builtin_amdgcn_ballot_w64((d1 & 0xC000u) == 0x4000u);
+		if (subd_m != 0ull) {
+			const uint32_t d2 = t.dist[(1u << kDistRoot) + (((d1 >> 5) & 511u) << 1) + __builtin_amdgcn_ubfe(r2, (uint32_t) kDistRoot, d1)];
+			dbits = __builtin_amdgcn_inverse_ballot_w64(subd_m) ? d2 & 31u : dbits;
+		}
+		bits += __builtin_amdgcn_inverse_ballot_w64(match_m) ? dbits : 0u;
+		const uint32_t nxt = min(lane + bits, 64u);
+		// The chain of symbol starts by a scalar walk, two symbols a step: every lane also knows where the symbol after next starts
+		// (one ds_bpermute), so a step is two v_readlane with the same lane select -- the four wait states between a select's
+		// write and its use are paid once per two symbols -- and two s_bitset1.  A start "at 64" sets bit 0, which is set anyway.
+		unsigned long long chain = 1ull;
 		{
+			const uint32_t nxt2 = max((uint32_t) __builtin_amdgcn_ds_bpermute((int) (nxt << 2), (int) nxt), nxt); // (nxt = 64 reads lane 0: dropped by the max)
 			uint32_t cur = 0;
 			do {
-				chain |= 1ull << cur;
-				cur = (uint32_t) __builtin_amdgcn_readlane((int) nxt, (int) cur);
+				const uint32_t n_a = (uint32_t) __builtin_amdgcn_readlane((int) nxt, (int) cur);
+				const uint32_t n_b = (uint32_t) __builtin_amdgcn_readlane((int) nxt2, (int) cur);
+				asm("s_bitset1_b64 %0, %1" : "+s"(chain) : "s"(n_a));
+				asm("s_bitset1_b64 %0, %1" : "+s"(chain) : "s"(n_b));
+				cur = n_b;
 			} while (cur < 64u);
 		}
 		const uint32_t last = 63u - (uint32_t) __builtin_clzll(chain);
-		const uint32_t e_last = (uint32_t) __builtin_amdgcn_readlane((int) e, (int) last);
-		if ((e_last & 0xF0u) == LitFormat::kHoleTag)
+		const uint32_t bits_last = (uint32_t) __builtin_amdgcn_readlane((int) bits, (int) last);
+		const uint32_t ends = bits_last >> 6; // 1: an end-of-block symbol or a hole stands there (a symbol has fewer than 64 bits)
+		if (ends && ((uint32_t) __builtin_amdgcn_readlane((int) e, (int) last) & 0xF0u) == LitFormat::kHoleTag)
 			return leave(-1); // no codeword leads here (or one that must not occur)
-		const bool ends = (e_last & 0xF0u) == LitFormat::kEob;
-		const unsigned long long sym_m = ends ? chain & ~(1ull << last) : chain; // the starts that produce output
-		const uint32_t n_new = (uint32_t) __popcll(sym_m);
+		// every start notes its bit position; the end-of-block symbol, last on its chain, lands in the slot behind the others
+		// and is not counted (the stage has room for sixty-five)
+		const uint32_t n_new = (uint32_t) __popcll(chain) - ends;
 		if (staged + n_new > 64u && !flush())
 			return leave(-1);
-		if (__builtin_amdgcn_inverse_ballot_w64(sym_m))
-			stage[staged + __builtin_amdgcn_mbcnt_hi((uint32_t) (sym_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) sym_m, 0u))] = ibit + lane;
+		if (__builtin_amdgcn_inverse_ballot_w64(chain))
+			stage[staged + __builtin_amdgcn_mbcnt_hi((uint32_t) (chain >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) chain, 0u))] = ibit + lane;
 		staged += n_new;
-		ibit += last + (uint32_t) __builtin_amdgcn_readlane((int) bits, (int) last);
+		ibit += last + (bits_last & 63u);
 		if (ends) {
 			if (!flush())
 				return leave(-1);
