@@ -103,7 +103,7 @@ struct alignas(16) WaveLds {
 
 #ifdef IW_PROF
 // tools/inflate_prof.hip: where a wave's time goes (s_memtime ticks per phase, summed per wave; lane 0 adds them up)
-enum { P_VIEW = 0, P_WALK, P_LITS, P_MATCH_WAIT, P_MATCH_COPY, P_TABLES, P_CRC, P_TRIPS, P_MATCHES, P_WAITS, P_SYMS, P_SLOW, P_SLOW_BYTES, P_SLOW_LONG, P_SLOW_OVERLAP, P_N };
+enum { P_VIEW = 0, P_WALK, P_LITS, P_MATCH_WAIT, P_MATCH_COPY, P_TABLES, P_CRC, P_TRIPS, P_MATCHES, P_WAITS, P_SYMS, P_SLOW, P_SLOW_BYTES, P_SLOW_LONG, P_SLOW_OVERLAP, P_SLOW_LE16, P_SLOW_LE32, P_SLOW_LE64, P_SLOW_SAFE32, P_N };
 __device__ unsigned long long g_prof[P_N];
 #define IW_T0() unsigned long long t_prof_ = __builtin_readcyclecounter()
 #define IW_LAP(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); prof[k] += n_ - t_prof_; t_prof_ = n_; } while (0)
@@ -160,6 +160,39 @@ template <typename P> __device__ __forceinline__ uint64_t load_written_u64_unali
 	return v;
 }
 
+// A match of n bytes that does not overlap itself, by ONE lane: its first and its last 8 (9 <= n <= 16), 16 (17 <= n <= 32) or 32
+// (33 <= n <= 64) bytes -- the two pieces overlap in the middle, nothing is read or written outside the match.  Loads at any
+// address, past the L1, all in flight before the one wait; the stores are the compiler's (unaligned dword stores, as everywhere here).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) uint64_t *GU64;
+typedef __attribute__((address_space(1))) u32x4 *GU128;
+template <typename P, typename Q> __device__ __forceinline__ void copy_9_to_16(P src, Q to, uint32_t n)
+{
+	uint64_t a, b;
+	asm volatile("global_load_dwordx2 %0, %2, off sc0 sc1\n\tglobal_load_dwordx2 %1, %3, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+			: "=&v"(a), "=&v"(b) : "v"(src), "v"(src + (n - 8u)) : "memory");
+	*(GU64) to = a;
+	*(GU64) (to + (n - 8u)) = b;
+}
+template <typename P, typename Q> __device__ __forceinline__ void copy_17_to_32(P src, Q to, uint32_t n)
+{
+	u32x4 a, b;
+	asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %3, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+			: "=&v"(a), "=&v"(b) : "v"(src), "v"(src + (n - 16u)) : "memory");
+	*(GU128) to = a;
+	*(GU128) (to + (n - 16u)) = b;
+}
+template <typename P, typename Q> __device__ __forceinline__ void copy_33_to_64(P src, Q to, uint32_t n)
+{
+	u32x4 a, b, c, d;
+	asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc0 sc1\n\t"
+			"global_load_dwordx4 %2, %5, off sc0 sc1\n\tglobal_load_dwordx4 %3, %5, off offset:16 sc0 sc1\n\ts_waitcnt vmcnt(0)"
+			: "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(src), "v"(src + (n - 32u)) : "memory");
+	*(GU128) to = a;
+	*(GU128) (to + 16u) = b;
+	*(GU128) (to + (n - 32u)) = c;
+	*(GU128) (to + (n - 16u)) = d;
+}
 
 // ---- the stream, read uniformly (block headers, code lengths) ---------------------------------------------------------
 // 64 consecutive dwords of the input live in one register across the wave; a field is two v_readlane and a funnel shift.
@@ -530,6 +563,10 @@ __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Lu
 			IW_ADD(P_SLOW_BYTES, len);
 			IW_ADD(P_SLOW_LONG, len > 8u ? 1 : 0);
 			IW_ADD(P_SLOW_OVERLAP, d < len ? 1 : 0);
+			IW_ADD(P_SLOW_LE16, len > 8u && len <= 16u ? 1 : 0);
+			IW_ADD(P_SLOW_LE32, len > 16u && len <= 32u ? 1 : 0);
+			IW_ADD(P_SLOW_LE64, len > 32u && len <= 64u ? 1 : 0);
+			IW_ADD(P_SLOW_SAFE32, len > 8u && len <= 32u && d >= len && src + len <= opos ? 1 : 0);
 			if (d >= len) {
 				for (uint32_t k = lane; k < len; k += 64u)
 					s.out[to + k] = (uint8_t) load_written_u8(s.out + src + k);
@@ -642,12 +679,27 @@ __device__ __forceinline__ int run_symbols_batched(Stream &s, const WaveLds &t, 
 		{
 			const uint32_t to_l = opos + incl - produced, src_l = to_l - dist;
 			// (dist <= to_l on its own: see run_symbols)
-			const bool fast = is_len && produced <= 8u && dist >= produced && dist <= to_l && src_l + produced <= safe_pos;
+			// a match that does not repeat itself and whose source lies in front of the batch's output is copied by its own lane
+			const bool own = is_len && dist >= produced && dist <= to_l && src_l + produced <= safe_pos;
+			const bool fast = own && produced <= 8u;
 			const unsigned long long fast_m = __ballot(fast);
 			if (fast_m) {
 				if (fast)
 					store_pieces(load_written_u64_unaligned(s.out + src_l), to_l, produced);
 				mm &= ~fast_m;
+			}
+			// ... also the longer ones, up to 64 bytes (with run-structured qualities seven in ten of the bytes come from matches of
+			// more than eight): three sizes, each only when the batch has one
+			const unsigned long long own_m = __builtin_amdgcn_ballot_w64(own && produced > 8u && produced <= 64u);
+			if (own_m) {
+				const bool c16 = own && produced - 9u < 8u, c32 = own && produced - 17u < 16u, c64 = own && produced - 33u < 32u;
+				if (__builtin_amdgcn_ballot_w64(c16) && c16)
+					copy_9_to_16(s.out + src_l, s.out + to_l, produced);
+				if (__builtin_amdgcn_ballot_w64(c32) && c32)
+					copy_17_to_32(s.out + src_l, s.out + to_l, produced);
+				if (__builtin_amdgcn_ballot_w64(c64) && c64)
+					copy_33_to_64(s.out + src_l, s.out + to_l, produced);
+				mm &= ~own_m;
 			}
 		}
 		while (mm) {
@@ -700,29 +752,31 @@ __device__ __forceinline__ int run_symbols_batched(Stream &s, const WaveLds &t, 
 		const uint32_t at = (dd + (b >> 5)) << 2;
 		const uint32_t w0 = (uint32_t) __builtin_amdgcn_ds_bpermute((int) at, (int) wreg);
 		const uint32_t w1 = (uint32_t) __builtin_amdgcn_ds_bpermute((int) at + 4, (int) wreg);
-		const uint32_t w2 = (uint32_t) __builtin_amdgcn_ds_bpermute((int) at + 8, (int) wreg);
 		const uint32_t sh = b & 31u;
-		const uint32_t lo = alignbit(w1, w0, sh), hi = alignbit(w2, w1, sh);
+		const uint32_t lo = alignbit(w1, w0, sh); // (thirty-two bits of view are enough up to the distance code's first level)
 		const uint32_t e1 = t.lit[lo & ((1u << kLitRoot) - 1u)];
 		const bool sub1 = (e1 & 0xF0u) == LitFormat::kSub;
 		const uint32_t e2 = t.lit[(1u << kLitRoot) + ((e1 >> 8) << 1) + __builtin_amdgcn_ubfe(lo, (uint32_t) kLitRoot, e1)];
 		const uint32_t e = sub1 ? e2 : e1;
-		const unsigned long long match_m = __builtin_amdgcn_ballot_w64((e & 0x80u) != 0u); // the candidates that are length symbols
+		const uint32_t is_len = (e >> 7) & 1u;
+		const unsigned long long match_m = __builtin_amdgcn_ballot_w64(is_len != 0u); // the candidates that are length symbols
 		// from the symbol's first bit to what follows its literal / length part; 64 or more for an end-of-block symbol and for a
 		// hole (LitFormat): their "next start" lies outside the window, so the walk stops there by itself, and what stood there
 		// is asked of that one lane afterwards -- no ballots, no cutting of masks.
 		uint32_t bits = e & 0x5Fu;
-		const uint32_t r2 = alignbit(hi, lo, bits);
-		const uint32_t d1 = t.dist[r2 & ((1u << kDistRoot) - 1u)];
+		// (v_bfe_u32 takes its offset from the entry's low five bits as they are; <= 20 where it matters: seven bits from there lie in `lo`)
+		const uint32_t d1 = t.dist[__builtin_amdgcn_ubfe(lo, e, (uint32_t) kDistRoot)];
 		uint32_t dbits = d1 & 31u; // the distance code with its extra bits
 		// (the second level of the distance code only in trips where a candidate length symbol leads to one: distance codes of
-		// more than seven bits are the rare small distances)
+		// more than seven bits are the rare small distances; the view's upper half is fetched for those trips alone)
 		const unsigned long long subd_m = match_m & __builtin_amdgcn_ballot_w64((d1 & 0xC000u) == 0x4000u);
 		if (subd_m != 0ull) {
+			const uint32_t w2 = (uint32_t) __builtin_amdgcn_ds_bpermute((int) at + 8, (int) wreg);
+			const uint32_t r2 = alignbit(alignbit(w2, w1, sh), lo, bits);
 			const uint32_t d2 = t.dist[(1u << kDistRoot) + (((d1 >> 5) & 511u) << 1) + __builtin_amdgcn_ubfe(r2, (uint32_t) kDistRoot, d1)];
 			dbits = __builtin_amdgcn_inverse_ballot_w64(subd_m) ? d2 & 31u : dbits;
 		}
-		bits += __builtin_amdgcn_inverse_ballot_w64(match_m) ? dbits : 0u;
+		bits += __umul24(dbits, is_len); // (one v_mad_u32_u24)
 		const uint32_t nxt = min(lane + bits, 64u);
 		// The chain of symbol starts by a scalar walk, two symbols a step: every lane also knows where the symbol after next starts
 		// (one ds_bpermute), so a step is two v_readlane with the same lane select -- the four wait states between a select's

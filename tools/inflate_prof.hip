@@ -115,6 +115,8 @@ int main(int argc, char **argv)
 		printf("  per block: %.0f matches one after the other (%.0f longer than 8 bytes, %.0f overlapping themselves), %.0f bytes\n",
 				(double) p[conga::iw::P_SLOW] / n, (double) p[conga::iw::P_SLOW_LONG] / n, (double) p[conga::iw::P_SLOW_OVERLAP] / n,
 				(double) p[conga::iw::P_SLOW_BYTES] / n);
+		printf("  per block: of those %.0f of 9..16 bytes, %.0f of 17..32, %.0f of 33..64; %.0f of 9..32 bytes that do not overlap themselves and whose source lies in front of the trip's output\n",
+				(double) p[conga::iw::P_SLOW_LE16] / n, (double) p[conga::iw::P_SLOW_LE32] / n, (double) p[conga::iw::P_SLOW_LE64] / n, (double) p[conga::iw::P_SLOW_SAFE32] / n);
 		unsigned long long sum = 0;
 		for (int k = 0; k < 7; k++)
 			sum += p[k];
