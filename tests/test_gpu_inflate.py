@@ -78,6 +78,36 @@ def test_every_kind_of_stream_matches_zlib(capi):
         at += len(plain)
 
 
+def test_matches_of_every_length_near_and_far(capi):
+    """Matches of 3..70 bytes (the sizes a lane copies on its own: up to 8, 9-16, 17-32, 33-64; beyond: all lanes) at distances
+    equal to the length, one more, a few hundred (inside the batch of sixty-four symbols that is turned into output at once) and
+    thousands (in front of it), and matches that repeat themselves (distance below the length), between literals -- every
+    stream compared with the plain text zlib made it from."""
+    rng = np.random.default_rng(11)
+    streams = []
+    for variant in range(6):
+        plain = bytearray(rng.integers(0, 256, 6000, dtype=np.uint8).tobytes())
+        for n in range(3, 71):
+            for dist in (n, n + 1, int(rng.integers(n + 2, 400)), int(rng.integers(1000, 5000)), max(1, n - int(rng.integers(1, n)))):
+                plain += bytes(rng.integers(0, 256, int(rng.integers(0, 4)), dtype=np.uint8))   # 0..3 literals between two matches
+                a = len(plain) - dist
+                for k in range(n):                                                              # (byte by byte: a match may repeat itself)
+                    plain.append(plain[a + k])
+            if len(plain) > 60000:
+                break
+        plain = bytes(plain[:65280])
+        for level, strategy in ((1, 0), (6, 0), (9, 0), (6, zlib.Z_FIXED)):
+            streams.append((deflate(plain, level, strategy), plain))
+    data, blocks = pack(streams)
+    with capi.Context(device=0) as ctx:
+        out, status, _ms = ctx.inflate_blocks(data, blocks)
+    assert status.tolist() == [0] * len(blocks), [i for i, s in enumerate(status) if s]
+    at = 0
+    for k, (_comp, plain) in enumerate(streams):
+        assert out[at:at + len(plain)].tobytes() == plain, "stream %d" % k
+        at += len(plain)
+
+
 def test_damaged_streams_are_refused_not_believed(capi):
     rng = np.random.default_rng(8)
     plain = payloads(rng)[6]
