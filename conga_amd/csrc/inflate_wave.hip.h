@@ -16,9 +16,14 @@
 // * Tables: 16-bit entries, two levels (9-bit root for literals / lengths, 7-bit for distances), built by the wave for
 //   every deflate block: code lengths -> per-length ballots give every symbol its canonical code without a serial
 //   pass; the width of each second-level table follows from the canonical ranges, so there is no atomic anywhere.
-//   An entry holds the whole codeword length and the count of extra bits behind it (LitFormat / DistFormat below):
+//   An entry's low bits ARE the distance from a symbol's first bit to whatever follows its literal / length part -- the whole
+//   codeword length, of a length symbol with its extra bits, 64 or more for what ends a chain (LitFormat / DistFormat below):
 //   the vector unit is what bounds this kernel, and that is what sixty-four lanes compute for the eight that count.
-// * The symbol loop is a function of its own (run_symbols_call): 32 VGPRs and no spill, whatever the set-up around it keeps.
+// * The product's symbol loop (run_symbols_batched) works in two phases: a trip only finds where symbols start -- 26 vector
+//   instructions for its look-ups, the chain walked two symbols a step --, and sixty-four starts at a time become output with
+//   every lane on a real symbol; matches of up to 64 bytes are copied by their own lanes.  (run_symbols is round 2's loop, kept
+//   for comparison: every trip decodes its sixty-four candidates completely.)
+// * The symbol loop is a function of its own (run_symbols_batched_call): no spill, whatever the set-up around it keeps.
 // * The output goes to HBM (L2) as it is produced.  A match reads what the wave wrote before: stores are waited for
 //   (s_waitcnt vmcnt(0)) only when the match reaches into bytes stored since the last wait, and the read-back loads
 //   bypass the L1 (it is write-through and may hold a line from before the store).
@@ -44,9 +49,9 @@ constexpr int kMaxLens = 320;
 
 // Table entries are 16 bits and made so that a lane gets from the stream's bits to "where does the symbol behind mine start"
 // in as few instructions as possible -- sixty-four lanes do that every trip, for the eight that turn out to be symbols.
-// An entry holds the WHOLE length of its codeword, also behind a second-level table, and the number of extra bits that
-// follow it; the base values of lengths and distances (needed only for the lanes that turn out to be symbols) come from
-// two small tables afterwards.
+// An entry holds the WHOLE length of its codeword, also behind a second-level table -- of a length symbol with the extra bits
+// that follow it added in; the base values of lengths and distances and a length's count of extra bits (needed only for the
+// lanes that turn out to be symbols) come from two small tables afterwards.
 struct LitFormat {
 	// [4:0] codeword length n1 -- of a length symbol: PLUS its count of extra bits (<= 15 + 5), which is what a lane needs to find
 	// the distance code behind it; the count itself comes with the base value (Luts::len); [6:5] class: 0 literal / length symbol,
