@@ -17,6 +17,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--chroms", default="")
 ap.add_argument("--samples", type=int, default=4)
 ap.add_argument("--decode", default="1")
+ap.add_argument("--variants", default="", help="semicolon-separated sets of K=V,K=V environment settings: the cohort is run once per set "
+                                               "and only the BAM stage's [timing] lines are printed (measurement switches of the engine)")
 a = ap.parse_args()
 chroms = synth.GRCH37_AUTOSOMES
 if a.chroms:
@@ -32,11 +34,24 @@ try:
     with open(os.path.join(d, "list.txt"), "w") as f:
         for k in range(a.samples):
             f.write("%s\ts%d\n" % (bam, k))
-    for rep in range(2):
+    for var in [v for v in a.variants.split(";") if v]:
+        envx = dict(kv.split("=", 1) for kv in var.split(","))
+        for rep in range(2):
+            try:
+                dt, err = e2e_bench.run_conga(["--cohort", "list.txt", "--out", "x", "--ref", "r.fa", "--sonic", "a.cga", "--dels", "dels.bed"], d,
+                                              dict(envx, CONGA_GPU_BAM=a.decode, CONGA_TIMING="1"))
+            except RuntimeError as e:
+                print("[%s] failed: %s" % (var, str(e)[-200:]))
+                continue
+            print("[%s] run %d: wall %.3f s" % (var, rep, dt))
+            for line in err.splitlines():
+                if "overlapped upload" in line or "conga_reads_bgzf:" in line:
+                    print("   " + line[:300])
+    for rep in range(0 if a.variants else 2):
         dt, err = e2e_bench.run_conga(["--cohort", "list.txt", "--out", "x", "--ref", "r.fa", "--sonic", "a.cga", "--dels", "dels.bed"], d,
                                       dict(CONGA_GPU_BAM=a.decode, CONGA_TIMING="1"))
         print("run %d: wall %.3f s for %d samples" % (rep, dt, a.samples))
-    for line in err.splitlines():
+    for line in ([] if a.variants else err.splitlines()):
         if "[timing]" in line or "[CONGA] sample" in line:
             print(line[:260])
 finally:
