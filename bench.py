@@ -685,9 +685,9 @@ def config_legs(args, env):
     """Short driver-run legs for the other single-GPU configurations of BASELINE.json."""
     legs = {}
     # ---- configs[2]: dels + dups together with the 100-mer mappability track
-    steps = max(5, min(args.steps, 10))
+    steps = max(10, min(2 * args.steps, 40))   # (a step is about a millisecond: ten of them behind two warm-up steps spread 0.78-1.16 ms from run to run)
     leg = Leg(args, env, "weak", "dels+dups+map")
-    e = leg.timed(steps, 2)
+    e = leg.timed(steps, 5)
     ko = leg.kernel_only(steps)
     kms, _ = leg.profile_kernels(reps=2)
     rows = int(sum(len(u["chrom"].map_start) for u in leg.mine))
