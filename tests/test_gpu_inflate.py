@@ -57,7 +57,11 @@ def payloads(rng):
     return out
 
 
-def test_every_kind_of_stream_matches_zlib(capi):
+@pytest.mark.parametrize("loop", ["two_phase", "wave1"])
+def test_every_kind_of_stream_matches_zlib(capi, loop, monkeypatch):
+    """(wave1: round 2's symbol loop, kept behind CONGA_BGZF_KERNEL for comparison -- it reads the same table entries)"""
+    if loop == "wave1":
+        monkeypatch.setenv("CONGA_BGZF_KERNEL", "wave1")
     rng = np.random.default_rng(5)
     streams = []
     for plain in payloads(rng):
