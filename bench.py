@@ -440,16 +440,22 @@ def traffic_of(name):
     if not os.path.exists(tpath):
         return None, None
     t = json.load(open(tpath))
-    return t.get("hbm_bytes_per_launch"), t.get("campaign")
+    return t.get("hbm_bytes_per_launch"), t.get("campaign"), t.get("algorithmic_bytes_per_launch")
 
 
 def roofline_of(kernel, ms, nbytes, kms, traffic_file, regime):
     achieved = nbytes / (max(ms, 1e-9) * 1e-3) / 1e9
-    traffic, campaign = traffic_of(traffic_file)
+    traffic, campaign, alg_then = traffic_of(traffic_file)
+    scaled = ""
+    if traffic and alg_then and abs(nbytes / alg_then - 1.0) > 0.005:
+        # the counters were taken on the N=1 workload of configs[1]: a launch over another share of it (a rank's chromosomes at
+        # N > 1, another configuration or coverage) moves the same bytes per algorithmic byte
+        traffic = round(traffic * nbytes / alg_then)
+        scaled = "; scaled to this launch's algorithmic bytes: the campaign's launch had %d" % alg_then
     return dict(bound="hbm", kernel=kernel, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=round(achieved / HBM_PEAK_GBS, 4), algorithmic_bytes_per_launch=int(nbytes),
                 avg_launch_ms=round(float(ms), 5), traffic=traffic,
-                traffic_source="profiles/%s (rocprofv3 --pmc campaign %s; not measured in this run)" % (traffic_file, campaign),
+                traffic_source="profiles/%s (rocprofv3 --pmc campaign %s; not measured in this run%s)" % (traffic_file, campaign, scaled),
                 regime=regime, kernel_ms_per_step={k: round(float(v), 4) for k, v in zip(capi.KERNEL_NAMES, kms)})
 
 
