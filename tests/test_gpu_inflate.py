@@ -102,6 +102,14 @@ def test_matches_of_every_length_near_and_far(capi):
         plain = bytes(plain[:65280])
         for level, strategy in ((1, 0), (6, 0), (9, 0), (6, zlib.Z_FIXED)):
             streams.append((deflate(plain, level, strategy), plain))
+    # a stream whose LAST symbol is such a match, its source the stream's very first bytes: nothing may be read in front of the
+    # output or written behind its end (the blocks' outputs lie side by side: the next stream's bytes would be the ones hit)
+    for n in range(3, 71):
+        head = bytes(rng.integers(0, 256, n + int(rng.integers(0, 40)), dtype=np.uint8))
+        plain = head + head[:n]
+        streams.append((deflate(plain, 9, 0), plain))
+        plain = head + bytes(rng.integers(0, 256, 300, dtype=np.uint8)) + head[:n]
+        streams.append((deflate(plain, 6, zlib.Z_FIXED), plain))
     data, blocks = pack(streams)
     with capi.Context(device=0) as ctx:
         out, status, _ms = ctx.inflate_blocks(data, blocks)
