@@ -567,6 +567,25 @@ def main():
                    "--mq -1, the reference's default, the MAPQ bytes are never read and are not sent) over PCIe Gen5 x16 per step"
                    % (leg.samples[0][6] / 8, leg.samples[0][6], len(leg.samples[0][4])))
         h2d["frac"] = round(h2d["achieved"] / PCIE_PEAK_GBS, 4)
+        # what THIS box's link gives a copy of that size by itself (the boxes differ: 39-57 GB/s): pinned host -> HBM, nothing beside it
+        try:
+            import torch
+            src = torch.empty(h2d_bytes, dtype=torch.uint8).pin_memory()
+            dst = torch.empty(h2d_bytes, dtype=torch.uint8, device=env["dev"])
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            best = 1e30
+            for _ in range(12):
+                ev0.record()
+                dst.copy_(src, non_blocking=True)
+                ev1.record()
+                ev1.synchronize()
+                best = min(best, ev0.elapsed_time(ev1))
+            h2d["link_probe"] = dict(gbs=round(h2d_bytes / (best * 1e-3) / 1e9, 2), ms=round(best, 4),
+                                     note="one pinned copy of bytes_per_step by itself in this run (best of 12): what the step's copy can reach on this box")
+            h2d["frac_of_link_probe"] = round(h2d["achieved"] / h2d["link_probe"]["gbs"], 4)
+            del src, dst
+        except Exception as e:   # (the probe is a figure beside the line, not part of it)
+            h2d["link_probe"] = dict(error="%s: %s" % (type(e).__name__, e))
         out["step_bound"] = h2d
 
     if rank == 0 and not dist_on:
