@@ -122,8 +122,10 @@ def encode_d16(pos, chrom_off):
 
 
 def encode_packed(pos, chrom_off, width=None):
-    """conga_sample_reads_packed's input: pos int32[n] -> (bits uint8[], width, esc_index uint32[k], esc_pos int32[k]).  width: 8, 10, 12
-    or 16; None picks the one that sends the fewest bytes (differences + 8 bytes per exception)."""
+    """conga_sample_reads_packed's input: pos int32[n] -> (bits uint8[], width, esc_index uint32[k], esc_pos int32[k]).  width: 4 .. 16;
+    None picks the one that sends the fewest bytes (differences + 8 bytes per exception) among those with at most one exception in
+    a thousand reads: an exception costs the expansion a search of the list (at 1x, 9 bits are 5 % fewer bytes than 10 and a
+    slower step -- 0.6 % of the reads are exceptions and the expansion no longer hides under the copy; profiles/README.md, r03h)."""
     pos = np.ascontiguousarray(pos, dtype=np.int32)
     n = len(pos)
     d = np.full(n, -1, np.int64)
@@ -133,7 +135,8 @@ def encode_packed(pos, chrom_off, width=None):
         firsts = firsts[(firsts < n) & (np.asarray(chrom_off[1:], np.int64) > firsts)]
         d[firsts] = -1
     if width is None:
-        cost = {w: n * w / 8 + 8 * int(np.count_nonzero((d < 0) | (d >= (1 << w) - 1))) for w in (8, 10, 12, 16)}
+        n_exc = {w: int(np.count_nonzero((d < 0) | (d >= (1 << w) - 1))) for w in range(4, 17)}
+        cost = {w: n * w / 8 + 8 * n_exc[w] for w in range(4, 17) if n_exc[w] <= max(n // 1000, 64) or w == 16}
         width = min(cost, key=cost.get)
     top = (1 << width) - 1
     esc = (d < 0) | (d >= top)

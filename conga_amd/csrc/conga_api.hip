@@ -2644,8 +2644,8 @@ int sample_reads_impl(conga_ctx *ctx, const char *who, const int32_t *pos, const
 			return fail(ctx, CONGA_ERR_INVALID, std::string(who) + ": chrom_off must not decrease");
 	if (total >= 0xFFFFFFF0ull)
 		return fail(ctx, CONGA_ERR_RANGE, std::string(who) + ": more than 2^32 reads in one context");
-	if (packed && width != 8 && width != 10 && width != 12 && width != 16)
-		return fail(ctx, CONGA_ERR_INVALID, std::string(who) + ": differences are 8, 10, 12 or 16 bits wide");
+	if (packed && (width < 4 || width > 16))
+		return fail(ctx, CONGA_ERR_INVALID, std::string(who) + ": differences are 4 to 16 bits wide");
 	// exceptions behind the differences in ONE buffer (esc_index == NULL): [differences | up to the next multiple of 16 bytes |
 	// esc_index[n_esc] | esc_pos[n_esc]] -- one DMA per sample instead of three (each carries tens of microseconds of its own)
 	const size_t d_bytes_host = packed ? ((size_t) total + 7) / 8 * (size_t) width : 0;
@@ -2660,9 +2660,13 @@ int sample_reads_impl(conga_ctx *ctx, const char *who, const int32_t *pos, const
 		// over a chromosome's border)
 		if (n_esc > 0xFFFFFFF0ull || (n_esc && (!esc_index || !esc_pos)))
 			return fail(ctx, CONGA_ERR_INVALID, std::string(who) + ": the exception list is missing");
-		for (size_t k = 0; k < n_esc; k++)
-			if (esc_index[k] >= total || (k && esc_index[k] <= esc_index[k - 1]))
-				return fail(ctx, CONGA_ERR_INVALID, std::string(who) + ": exceptions must be sorted by index and lie inside the reads");
+		// (no early way out of the loop: it is on the hand-over's critical path -- the copy is enqueued behind it -- and a narrow
+		// width has hundreds of thousands of exceptions; without a branch the compiler makes it a vector loop)
+		uint32_t bad = n_esc && esc_index[0] >= total ? 1u : 0u;
+		for (size_t k = 1; k < n_esc; k++)
+			bad |= (uint32_t) (esc_index[k] >= total) | (uint32_t) (esc_index[k] <= esc_index[k - 1]);
+		if (bad)
+			return fail(ctx, CONGA_ERR_INVALID, std::string(who) + ": exceptions must be sorted by index and lie inside the reads");
 		for (int c = 0; c < n_chrom; c++)
 			if (chrom_off[c + 1] > chrom_off[c]
 					&& !std::binary_search(esc_index, esc_index + n_esc, (uint32_t) chrom_off[c]))
@@ -3457,10 +3461,19 @@ int conga_chrom_compute(conga_ctx *ctx)
 			hipLaunchKernelGGL(delta_carry_kernel, dim3(1), dim3(1024), 0, st, d_agg, n_chunks, d_carry);
 			hipLaunchKernelGGL(delta_expand_kernel<W>, dim3(n_chunks), dim3(256), 0, st, dd, total, d_ei, d_ep, n_esc, d_carry, d_pos);
 		};
-		switch (ctx->expand_width) {
+		switch (ctx->expand_width) { // (any width from 4 to 16: eight differences are `width` whole bytes)
+		case 4: launch(std::integral_constant<int, 4>()); break;
+		case 5: launch(std::integral_constant<int, 5>()); break;
+		case 6: launch(std::integral_constant<int, 6>()); break;
+		case 7: launch(std::integral_constant<int, 7>()); break;
 		case 8: launch(std::integral_constant<int, 8>()); break;
+		case 9: launch(std::integral_constant<int, 9>()); break;
 		case 10: launch(std::integral_constant<int, 10>()); break;
+		case 11: launch(std::integral_constant<int, 11>()); break;
 		case 12: launch(std::integral_constant<int, 12>()); break;
+		case 13: launch(std::integral_constant<int, 13>()); break;
+		case 14: launch(std::integral_constant<int, 14>()); break;
+		case 15: launch(std::integral_constant<int, 15>()); break;
 		default: launch(std::integral_constant<int, 16>()); break;
 		}
 		HIP_TRY(ctx, hipGetLastError());

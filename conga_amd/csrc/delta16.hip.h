@@ -1,4 +1,4 @@
-// delta16.hip.h -- read positions handed over as 8- to 16-bit differences (conga_sample_reads_packed / _d16).
+// delta16.hip.h -- read positions handed over as 4- to 16-bit differences (conga_sample_reads_packed / _d16).
 //
 // The step of a cohort is the copy of the sample's tuples over PCIe (bench.py: step_bound), and a position-sorted sample's
 // positions (bam1_core_t.pos in the order sam_itr_next yields them, bam_data.c:201-213) are a 32-bit number each only because
@@ -15,8 +15,10 @@
 namespace conga {
 
 constexpr int kDeltaChunk = 2048; // differences per workgroup: 256 threads x 8 (one 16-byte load each)
-// The differences are W bits wide (W = 8, 10, 12 or 16: the producer picks what its coverage needs -- at 1x two neighbours are
-// ~100 bases apart and 10 bits hold all but one difference in ten thousand), packed little-endian: difference i occupies bits
+// The differences are W bits wide (W = 4 .. 16: the producer picks what its coverage needs -- at 1x two neighbours are ~100 bases
+// apart: 10 bits hold all but one difference in ten thousand; 9 bits would be fewer bytes, but six exceptions in a thousand reads
+// are a search of the list each, and the expansion then takes longer than the copy it hides under; at 30x six bits do), packed
+// little-endian: difference i occupies bits
 // [i * W, (i + 1) * W) of the byte stream.  Eight of them are W whole bytes: a thread's share starts on a byte.  All ones = exception.
 
 struct SegVal { // a run's sum and whether an exception (an absolute position) lies inside it

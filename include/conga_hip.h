@@ -248,10 +248,11 @@ int conga_sample_reads(conga_ctx *ctx, const int32_t *pos, const uint8_t *mapq, 
  * Everything said of conga_sample_reads above holds (mapq, lifetime of the arrays, double-buffering). */
 int conga_sample_reads_d16(conga_ctx *ctx, const uint16_t *delta, const uint32_t *esc_index, const int32_t *esc_pos, size_t n_esc,
 		const uint8_t *mapq, const uint64_t *chrom_off, int n_chrom);
-/* ... and as differences of `width` = 8, 10, 12 or 16 bits, packed little-endian: difference i occupies bits [i * width,
+/* ... and as differences of `width` = 4 .. 16 bits, packed little-endian: difference i occupies bits [i * width,
  * (i + 1) * width) of `bits` (bit b of the stream is bit b & 7 of bits[b >> 3]; width 16 is conga_sample_reads_d16's array).  All ones
- * = see the exception list.  The producer picks the width its coverage needs: at 1x two neighbours are ~100 bases apart and 10 bits
- * hold all but one difference in ten thousand -- 1.25 bytes per read over the link.
+ * = see the exception list.  The producer picks the narrowest width that keeps exceptions rare (one in a thousand reads or fewer: an
+ * exception costs the expansion a search of the list): at 1x two neighbours are ~100 bases apart and 10 bits hold all but one
+ * difference in ten thousand -- 1.25 bytes per read over the link --, at 5x eight bits do, at 30x six.
  * esc_index == esc_pos == NULL with n_esc > 0: the exceptions lie in `bits` behind the differences -- at the next multiple of 16
  * bytes behind ceil(n / 8) * width, esc_index[n_esc] then esc_pos[n_esc] -- and the sample goes up as ONE copy. */
 int conga_sample_reads_packed(conga_ctx *ctx, const uint8_t *bits, int width, const uint32_t *esc_index, const int32_t *esc_pos, size_t n_esc,

@@ -328,7 +328,7 @@ def main():
                     ctx.sample_reads(pos_a, mapq_a, off)
                     ctx.compute()
                     want, wantE, _ = ctx.sample_fetch()
-                    for width in (8, 10, 12, 16, None):
+                    for width in (5, 7, 8, 9, 10, 11, 12, 14, 16, None):
                         bits, w, ei, ep = capi.encode_packed(pos, off, width)
                         if rng.random() < 0.5:
                             ctx.sample_reads_packed(capi.pack_inline(bits, ei, ep), w, len(ei), None, mapq_a, off)
