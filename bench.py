@@ -153,7 +153,7 @@ def pinned_samples(ctx, mine):
             off[k + 1] = at
         # the same positions as a producer that subtracts sends them (conga_sample_reads_packed): differences of the width that
         # sends the fewest bytes at this coverage (10 bits at 1x) + exceptions
-        bits, width, ei, ep = capi.encode_packed(pos[:at], off)
+        bits, width, ei, ep = capi.encode_packed(pos[:at], off, int(os.environ["CONGA_BENCH_WIDTH"]) if os.environ.get("CONGA_BENCH_WIDTH") else None)   # (measurement switch)
         one = capi.pack_inline(bits, ei, ep)          # the exceptions behind the differences: one copy per sample
         d_pin = ctx.host_alloc(len(one), np.uint8)
         d_pin[:] = one

@@ -2707,7 +2707,7 @@ int sample_reads_impl(conga_ctx *ctx, const char *who, const int32_t *pos, const
 			const size_t d_bytes = ((size_t) total + 7) / 8 * (size_t) width; // (eight differences are `width` whole bytes)
 			TRY(ensure(ctx, dd, esc_at + n_esc * 8 + 64));
 			TRY(ensure(ctx, de, std::max<size_t>(n_esc, 1) * 8));
-			TRY(ensure(ctx, ctx->d_delta_agg, (size_t) ((total + kDeltaChunk - 1) / kDeltaChunk) * 12));
+			TRY(ensure(ctx, ctx->d_delta_agg, (size_t) ((total + kDeltaChunk - 1) / kDeltaChunk) * 16 + 16)); // (aggregates, carries, exception ranks)
 			uint32_t *d_ei = ptr<uint32_t>(de);
 			if (inline_esc) // differences and exceptions in one go; the expansion finds the exceptions behind the differences
 				HIP_TRY(ctx, hipMemcpyAsync(dd.p, delta, esc_at + n_esc * 8, hipMemcpyHostToDevice, cs));
@@ -3454,12 +3454,14 @@ int conga_chrom_compute(conga_ctx *ctx)
 		const int32_t *d_ep = reinterpret_cast<const int32_t *>(d_ei + n_esc);
 		int2 *d_agg = ptr<int2>(ctx->d_delta_agg);
 		int32_t *d_carry = reinterpret_cast<int32_t *>(d_agg + n_chunks);
+		uint32_t *d_rank = reinterpret_cast<uint32_t *>(d_carry + n_chunks);
 		int32_t *d_pos = ptr<int32_t>(ctx->d_pos);
 		auto launch = [&](auto width_tag) {
 			constexpr int W = decltype(width_tag)::value;
-			hipLaunchKernelGGL(delta_aggregate_kernel<W>, dim3(n_chunks), dim3(256), 0, st, dd, total, d_ei, d_ep, n_esc, d_agg);
+			hipLaunchKernelGGL(delta_esc_rank_kernel, dim3((n_chunks + 256) / 256), dim3(256), 0, st, d_ei, n_esc, n_chunks, d_rank);
+			hipLaunchKernelGGL(delta_aggregate_kernel<W>, dim3(n_chunks), dim3(256), 0, st, dd, total, d_ei, d_ep, n_esc, d_rank, d_agg);
 			hipLaunchKernelGGL(delta_carry_kernel, dim3(1), dim3(1024), 0, st, d_agg, n_chunks, d_carry);
-			hipLaunchKernelGGL(delta_expand_kernel<W>, dim3(n_chunks), dim3(256), 0, st, dd, total, d_ei, d_ep, n_esc, d_carry, d_pos);
+			hipLaunchKernelGGL(delta_expand_kernel<W>, dim3(n_chunks), dim3(256), 0, st, dd, total, d_ei, d_ep, n_esc, d_rank, d_carry, d_pos);
 		};
 		switch (ctx->expand_width) { // (any width from 4 to 16: eight differences are `width` whole bytes)
 		case 4: launch(std::integral_constant<int, 4>()); break;

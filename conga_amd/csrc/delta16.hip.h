@@ -5,8 +5,8 @@
 // nobody subtracted: at 1x two neighbours are ~100 bases apart.  The producer sends pos[i] - pos[i - 1] in W bits; whatever
 // does not fit -- the first read of a chromosome, a gap of 2^W - 1 bases or more, a position in front of its predecessor -- is
 // sent as all ones plus an entry (index, position) of a short exception list.  Here the differences become positions again:
-// a segmented inclusive scan (an exception restarts the sum) in three launches -- per-chunk aggregates, one workgroup's scan
-// over them, the chunks' local scans with their carry -- writing the int32 array every kernel of the path reads.  25.6 M reads:
+// a segmented inclusive scan (an exception restarts the sum) in four launches -- where every chunk's exceptions begin in the list,
+// per-chunk aggregates, one workgroup's scan over them, the chunks' local scans with their carry -- writing the int32 array every kernel of the path reads.  25.6 M reads:
 // 51 MB (16 bits) or 32 MB (10 bits) over the link instead of 102, and ~40 us of HBM-bound work that hides under the next sample's copy.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -34,10 +34,11 @@ __device__ __forceinline__ SegVal seg_combine(SegVal a, SegVal b) // a in front 
 	return r;
 }
 
-// position of exception `i` (the list is sorted by index; every 0xFFFF in the stream has its entry -- checked on the host)
-__device__ __forceinline__ int32_t escape_value(const uint32_t *esc_index, const int32_t *esc_pos, uint32_t n_esc, uint32_t i)
+// position of exception `i` (the list is sorted by index; every all-ones value in the stream has its entry -- checked on the host):
+// looked for among the exceptions of the read's own chunk, [lo, hi) of the list (delta_esc_rank_kernel) -- a dozen entries where
+// the whole list has hundreds of thousands, and a narrow width makes one read in a hundred an exception
+__device__ __forceinline__ int32_t escape_value(const uint32_t *esc_index, const int32_t *esc_pos, uint32_t n_esc, uint32_t lo, uint32_t hi, uint32_t i)
 {
-	uint32_t lo = 0, hi = n_esc;
 	while (lo < hi) {
 		const uint32_t mid = (lo + hi) >> 1;
 		if (esc_index[mid] < i)
@@ -51,7 +52,7 @@ __device__ __forceinline__ int32_t escape_value(const uint32_t *esc_index, const
 // the thread's eight elements as segmented values, and their inclusive scan in place; -> the thread's aggregate
 // (the stream has 16 bytes of slack behind its last difference: one 16-byte load whatever W is)
 template <int W> __device__ __forceinline__ SegVal delta_thread_scan(const uint8_t *delta, uint64_t n, uint64_t first, const uint32_t *esc_index,
-		const int32_t *esc_pos, uint32_t n_esc, SegVal e[8])
+		const int32_t *esc_pos, uint32_t n_esc, uint32_t esc_lo, uint32_t esc_hi, SegVal e[8])
 {
 	constexpr uint32_t kEscape = (1u << W) - 1u;
 	uint64_t raw[2] = {0, 0};
@@ -66,7 +67,7 @@ template <int W> __device__ __forceinline__ SegVal delta_thread_scan(const uint8
 		const uint32_t d = (uint32_t) (lo | hi) & kEscape;
 		SegVal x;
 		x.f = (d == kEscape && first + k < n) ? 1u : 0u;
-		x.v = x.f ? escape_value(esc_index, esc_pos, n_esc, (uint32_t) (first + k)) : (first + k < n ? (int32_t) d : 0);
+		x.v = x.f ? escape_value(esc_index, esc_pos, n_esc, esc_lo, esc_hi, (uint32_t) (first + k)) : (first + k < n ? (int32_t) d : 0);
 		run = seg_combine(run, x);
 		e[k] = run;
 	}
@@ -106,14 +107,32 @@ template <int W> __device__ __forceinline__ SegVal delta_block_exclusive(SegVal 
 	return seg_combine(before, ex);
 }
 
+// launch 0: rank[c] = how many exceptions lie in front of chunk c (c = 0 .. n_chunks: the last entry is n_esc)
+__global__ __launch_bounds__(256) void delta_esc_rank_kernel(const uint32_t *__restrict__ esc_index, uint32_t n_esc, uint32_t n_chunks, uint32_t *__restrict__ rank)
+{
+	const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c > n_chunks)
+		return;
+	const uint64_t first = (uint64_t) c * kDeltaChunk;
+	uint32_t lo = 0, hi = n_esc;
+	while (lo < hi) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if ((uint64_t) esc_index[mid] < first)
+			lo = mid + 1;
+		else
+			hi = mid;
+	}
+	rank[c] = lo;
+}
+
 // launch 1: every chunk's aggregate
 template <int W> __global__ __launch_bounds__(256) void delta_aggregate_kernel(const uint8_t *__restrict__ delta, uint64_t n, const uint32_t *__restrict__ esc_index,
-		const int32_t *__restrict__ esc_pos, uint32_t n_esc, int2 *__restrict__ agg)
+		const int32_t *__restrict__ esc_pos, uint32_t n_esc, const uint32_t *__restrict__ rank, int2 *__restrict__ agg)
 {
 	__shared__ SegVal s_wave[4];
 	SegVal e[8], all;
 	const uint64_t first = (uint64_t) blockIdx.x * kDeltaChunk + (uint64_t) threadIdx.x * 8;
-	const SegVal mine = delta_thread_scan<W>(delta, n, first, esc_index, esc_pos, n_esc, e);
+	const SegVal mine = delta_thread_scan<W>(delta, n, first, esc_index, esc_pos, n_esc, rank[blockIdx.x], rank[blockIdx.x + 1], e);
 	(void) delta_block_exclusive<4>(mine, s_wave, &all);
 	if (threadIdx.x == 0)
 		agg[blockIdx.x] = make_int2(all.v, (int) all.f);
@@ -146,12 +165,12 @@ __global__ __launch_bounds__(1024) void delta_carry_kernel(const int2 *__restric
 
 // launch 3: the positions
 template <int W> __global__ __launch_bounds__(256) void delta_expand_kernel(const uint8_t *__restrict__ delta, uint64_t n, const uint32_t *__restrict__ esc_index,
-		const int32_t *__restrict__ esc_pos, uint32_t n_esc, const int32_t *__restrict__ carry, int32_t *__restrict__ pos)
+		const int32_t *__restrict__ esc_pos, uint32_t n_esc, const uint32_t *__restrict__ rank, const int32_t *__restrict__ carry, int32_t *__restrict__ pos)
 {
 	__shared__ SegVal s_wave[4];
 	SegVal e[8];
 	const uint64_t first = (uint64_t) blockIdx.x * kDeltaChunk + (uint64_t) threadIdx.x * 8;
-	const SegVal mine = delta_thread_scan<W>(delta, n, first, esc_index, esc_pos, n_esc, e);
+	const SegVal mine = delta_thread_scan<W>(delta, n, first, esc_index, esc_pos, n_esc, rank[blockIdx.x], rank[blockIdx.x + 1], e);
 	SegVal before = delta_block_exclusive<4>(mine, s_wave, nullptr);
 	before = seg_combine(SegVal{carry[blockIdx.x], 0u}, before);
 	int32_t out[8];
