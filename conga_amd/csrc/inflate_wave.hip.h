@@ -165,39 +165,11 @@ template <typename P> __device__ __forceinline__ uint64_t load_written_u64_unali
 	return v;
 }
 
-// A match of n bytes that does not overlap itself, by ONE lane: its first and its last 8 (9 <= n <= 16), 16 (17 <= n <= 32) or 32
-// (33 <= n <= 64) bytes -- the two pieces overlap in the middle, nothing is read or written outside the match.  Loads at any
-// address, past the L1, all in flight before the one wait; the stores are the compiler's (unaligned dword stores, as everywhere here).
+// the types a lane copies a match of up to 64 bytes with (run_symbols_batched: loads at any address, past the L1; the stores are the
+// compiler's -- unaligned dword stores, as everywhere here)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) uint64_t *GU64;
 typedef __attribute__((address_space(1))) u32x4 *GU128;
-template <typename P, typename Q> __device__ __forceinline__ void copy_9_to_16(P src, Q to, uint32_t n)
-{
-	uint64_t a, b;
-	asm volatile("global_load_dwordx2 %0, %2, off sc0 sc1\n\tglobal_load_dwordx2 %1, %3, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
-			: "=&v"(a), "=&v"(b) : "v"(src), "v"(src + (n - 8u)) : "memory");
-	*(GU64) to = a;
-	*(GU64) (to + (n - 8u)) = b;
-}
-template <typename P, typename Q> __device__ __forceinline__ void copy_17_to_32(P src, Q to, uint32_t n)
-{
-	u32x4 a, b;
-	asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %3, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
-			: "=&v"(a), "=&v"(b) : "v"(src), "v"(src + (n - 16u)) : "memory");
-	*(GU128) to = a;
-	*(GU128) (to + (n - 16u)) = b;
-}
-template <typename P, typename Q> __device__ __forceinline__ void copy_33_to_64(P src, Q to, uint32_t n)
-{
-	u32x4 a, b, c, d;
-	asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc0 sc1\n\t"
-			"global_load_dwordx4 %2, %5, off sc0 sc1\n\tglobal_load_dwordx4 %3, %5, off offset:16 sc0 sc1\n\ts_waitcnt vmcnt(0)"
-			: "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(src), "v"(src + (n - 32u)) : "memory");
-	*(GU128) to = a;
-	*(GU128) (to + 16u) = b;
-	*(GU128) (to + (n - 32u)) = c;
-	*(GU128) (to + (n - 16u)) = d;
-}
 
 // ---- the stream, read uniformly (block headers, code lengths) ---------------------------------------------------------
 // 64 consecutive dwords of the input live in one register across the wave; a field is two v_readlane and a funnel shift.
@@ -686,24 +658,46 @@ __device__ __forceinline__ int run_symbols_batched(Stream &s, const WaveLds &t, 
 			// (dist <= to_l on its own: see run_symbols)
 			// a match that does not repeat itself and whose source lies in front of the batch's output is copied by its own lane
 			const bool own = is_len && dist >= produced && dist <= to_l && src_l + produced <= safe_pos;
-			const bool fast = own && produced <= 8u;
-			const unsigned long long fast_m = __ballot(fast);
-			if (fast_m) {
-				if (fast)
-					store_pieces(load_written_u64_unaligned(s.out + src_l), to_l, produced);
-				mm &= ~fast_m;
-			}
-			// ... also the longer ones, up to 64 bytes (with run-structured qualities seven in ten of the bytes come from matches of
-			// more than eight): three sizes, each only when the batch has one
-			const unsigned long long own_m = __builtin_amdgcn_ballot_w64(own && produced > 8u && produced <= 64u);
+			// ... up to 64 bytes long (with run-structured qualities seven in ten of the output bytes come from matches of more than
+			// eight): four sizes, each with loads of its own -- the first and the last 8, 16 or 32 bytes of the match, the pieces
+			// overlap in the middle, nothing outside the match is touched -- and ALL of them in flight before the one wait: a
+			// batch pays one trip to L2 for its matches, not one per size.
+			const unsigned long long own_m = __builtin_amdgcn_ballot_w64(own && produced <= 64u);
 			if (own_m) {
-				const bool c16 = own && produced - 9u < 8u, c32 = own && produced - 17u < 16u, c64 = own && produced - 33u < 32u;
-				if (__builtin_amdgcn_ballot_w64(c16) && c16)
-					copy_9_to_16(s.out + src_l, s.out + to_l, produced);
-				if (__builtin_amdgcn_ballot_w64(c32) && c32)
-					copy_17_to_32(s.out + src_l, s.out + to_l, produced);
-				if (__builtin_amdgcn_ballot_w64(c64) && c64)
-					copy_33_to_64(s.out + src_l, s.out + to_l, produced);
+				const bool c8 = own && produced <= 8u, c16 = own && produced - 9u < 8u, c32 = own && produced - 17u < 16u, c64 = own && produced - 33u < 32u;
+				const GBytes from = s.out + src_l, to = s.out + to_l;
+				uint64_t q0, q1;
+				u32x4 x0, x1, x2, x3;
+				if (c8)
+					asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1" : "=&v"(q0) : "v"(from) : "memory");
+				if (c16)
+					asm volatile("global_load_dwordx2 %0, %2, off sc0 sc1\n\tglobal_load_dwordx2 %1, %3, off sc0 sc1"
+							: "=&v"(q0), "=&v"(q1) : "v"(from), "v"(from + (produced - 8u)) : "memory");
+				if (c32)
+					asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %3, off sc0 sc1"
+							: "=&v"(x0), "=&v"(x1) : "v"(from), "v"(from + (produced - 16u)) : "memory");
+				if (c64)
+					asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc0 sc1\n\t"
+							"global_load_dwordx4 %2, %5, off sc0 sc1\n\tglobal_load_dwordx4 %3, %5, off offset:16 sc0 sc1"
+							: "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3) : "v"(from), "v"(from + (produced - 32u)) : "memory");
+				// (the registers go through the wait: nothing that reads them can be moved in front of it)
+				asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0), "+v"(q1), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : : "memory");
+				if (c8)
+					store_pieces(q0, to_l, produced);
+				if (c16) {
+					*(GU64) to = q0;
+					*(GU64) (to + (produced - 8u)) = q1;
+				}
+				if (c32) {
+					*(GU128) to = x0;
+					*(GU128) (to + (produced - 16u)) = x1;
+				}
+				if (c64) {
+					*(GU128) to = x0;
+					*(GU128) (to + 16u) = x1;
+					*(GU128) (to + (produced - 32u)) = x2;
+					*(GU128) (to + (produced - 16u)) = x3;
+				}
 				mm &= ~own_m;
 			}
 		}
