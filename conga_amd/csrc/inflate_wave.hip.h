@@ -101,7 +101,7 @@ struct DistFormat {
 struct alignas(16) WaveLds {
 	uint16_t lit[kLitCap];
 	uint16_t dist[kDistCap];
-	uint16_t sorted[288 + 32]; // builder: symbols in canonical order (by length, then value); symbol loop: the staged starts (64 dwords)
+	uint16_t sorted[288 + 32]; // builder: symbols in canonical order (by length, then value); symbol loop: the staged symbols' bits (65 x 8 bytes; offset 3040: 8-byte aligned)
 	uint8_t lens[kMaxLens];    // code lengths of the block being set up (literal/length alphabet, then distances)
 	uint8_t pre[1 << kPreRoot]; // code-length code: [2:0] bits, [7:3] symbol -- 5 + 3 bits are enough for 19 symbols of <= 7 bits
 };
@@ -579,13 +579,12 @@ __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Lu
 // Matches: everything stored before a batch is in L2 when it starts (one s_waitcnt per batch, long satisfied); a short match
 // whose source lies in front of the batch's own output is copied by its lane as before; the others -- a match that reaches into
 // the batch's own bytes, a long one, one that repeats itself -- go one after the other behind a wait for the batch's stores.
-__device__ __forceinline__ int run_symbols_batched(Stream &s, const WaveLds &t, const Luts &luts, uint32_t *stage /* LDS, 64 dwords */)
+__device__ __forceinline__ int run_symbols_batched(Stream &s, const WaveLds &t, const Luts &luts, uint32_t *stage /* LDS: sixty-five times eight bytes, 8-byte aligned */)
 {
 	const uint32_t lane = lane_id();
 	uint32_t ibit = uni(s.ibit), opos = uni(s.opos), safe_pos = uni(s.safe_pos);
 	const uint32_t end_bit = uni(s.end_bit), out_len = uni(s.out_len);
 	const GWords in32 = s.in32;
-	const GConstBytes in8 = (GConstBytes) s.in32;
 	uint32_t staged = 0; // starts noted and not yet turned into output
 	auto leave = [&](int rc) {
 		s.ibit = ibit;
@@ -618,15 +617,12 @@ __device__ __forceinline__ int run_symbols_batched(Stream &s, const WaveLds &t, 
 			return true;
 		wave_sync();
 		const bool have = lane < n;
-		const uint32_t bp = have ? stage[lane] : ibit; // (a bit position inside the stream for the idle lanes too)
-		uint64_t v;
-		{
-			const GConstBytes at = in8 + (bp >> 3);
-			asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(at) : "memory");
-			// (that wait is the batch's wait for everything stored before it as well)
-		}
+		// the symbol's sixty-four bits as the trip that found it saw them (48 are needed): staged in LDS, no trip to memory for them
+		const uint64_t v = have ? reinterpret_cast<const uint64_t *>(stage)[lane] : 0ull;
+		asm volatile("" ::: "memory");
+		__builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): everything stored before the batch has arrived (long since, as a rule)
+		asm volatile("" ::: "memory");
 		safe_pos = opos;
-		v >>= (bp & 7u); // >= 57 bits of the symbol: 48 are needed
 		const uint32_t lo = (uint32_t) v;
 		const uint32_t e1 = t.lit[lo & ((1u << kLitRoot) - 1u)];
 		const bool sub1 = (e1 & 0xF0u) == LitFormat::kSub;
@@ -751,8 +747,9 @@ __device__ __forceinline__ int run_symbols_batched(Stream &s, const WaveLds &t, 
 		const uint32_t at = (dd + (b >> 5)) << 2;
 		const uint32_t w0 = (uint32_t) __builtin_amdgcn_ds_bpermute((int) at, (int) wreg);
 		const uint32_t w1 = (uint32_t) __builtin_amdgcn_ds_bpermute((int) at + 4, (int) wreg);
+		const uint32_t w2 = (uint32_t) __builtin_amdgcn_ds_bpermute((int) at + 8, (int) wreg);
 		const uint32_t sh = b & 31u;
-		const uint32_t lo = alignbit(w1, w0, sh); // (thirty-two bits of view are enough up to the distance code's first level)
+		const uint32_t lo = alignbit(w1, w0, sh), hi = alignbit(w2, w1, sh); // (the upper half: for the rare second level below, and staged with the lower one)
 		const uint32_t e1 = t.lit[lo & ((1u << kLitRoot) - 1u)];
 		const bool sub1 = (e1 & 0xF0u) == LitFormat::kSub;
 		const uint32_t e2 = t.lit[(1u << kLitRoot) + ((e1 >> 8) << 1) + __builtin_amdgcn_ubfe(lo, (uint32_t) kLitRoot, e1)];
@@ -770,8 +767,7 @@ __device__ __forceinline__ int run_symbols_batched(Stream &s, const WaveLds &t, 
 		// more than seven bits are the rare small distances; the view's upper half is fetched for those trips alone)
 		const unsigned long long subd_m = match_m & __builtin_amdgcn_ballot_w64((d1 & 0xC000u) == 0x4000u);
 		if (subd_m != 0ull) {
-			const uint32_t w2 = (uint32_t) __builtin_amdgcn_ds_bpermute((int) at + 8, (int) wreg);
-			const uint32_t r2 = alignbit(alignbit(w2, w1, sh), lo, bits);
+			const uint32_t r2 = alignbit(hi, lo, bits);
 			const uint32_t d2 = t.dist[(1u << kDistRoot) + (((d1 >> 5) & 511u) << 1) + __builtin_amdgcn_ubfe(r2, (uint32_t) kDistRoot, d1)];
 			dbits = __builtin_amdgcn_inverse_ballot_w64(subd_m) ? d2 & 31u : dbits;
 		}
@@ -803,7 +799,8 @@ __device__ __forceinline__ int run_symbols_batched(Stream &s, const WaveLds &t, 
 		if (staged + n_new > 64u && !flush())
 			return leave(-1);
 		if (__builtin_amdgcn_inverse_ballot_w64(chain))
-			stage[staged + __builtin_amdgcn_mbcnt_hi((uint32_t) (chain >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) chain, 0u))] = ibit + lane;
+			reinterpret_cast<uint64_t *>(stage)[staged + __builtin_amdgcn_mbcnt_hi((uint32_t) (chain >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) chain, 0u))]
+					= (uint64_t) lo | ((uint64_t) hi << 32);
 		staged += n_new;
 		ibit += last + (bits_last & 63u);
 		if (ends) {
