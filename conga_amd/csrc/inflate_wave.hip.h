@@ -572,13 +572,13 @@ __device__ __forceinline__ int run_symbols(Stream &s, const WaveLds &t, const Lu
 // A trip of run_symbols() decodes sixty-four candidate symbols completely -- values, base tables, extra bits, the prefix sum
 // of what they produce, the stores -- for the ~8 that turn out to lie on the chain: the vector unit, which bounds the kernel,
 // spends seven eighths of that on lanes that are dropped.  Here a trip only finds out WHERE symbols start (the look-ups give
-// every candidate its length in bits, the scalar walk follows the chain) and notes the starts' bit positions; once
-// sixty-four are noted -- eight trips or so -- every lane takes ONE real symbol, reads its bits again (eight bytes from the
-// stream, in L1), decodes it for good and the whole wave produces output for sixty-four symbols at once.  Per trip ~60
-// vector instructions instead of 112, per batch ~100 more.
-// Matches: everything stored before a batch is in L2 when it starts (one s_waitcnt per batch, long satisfied); a short match
-// whose source lies in front of the batch's own output is copied by its lane as before; the others -- a match that reaches into
-// the batch's own bytes, a long one, one that repeats itself -- go one after the other behind a wait for the batch's stores.
+// every candidate its length in bits, the scalar walk follows the chain) and stages the sixty-four bits every start saw (LDS);
+// once sixty-four are staged -- eight trips or so -- every lane takes ONE real symbol's bits back, decodes it for good and the
+// whole wave produces output for sixty-four symbols at once.  Per trip ~50 vector instructions instead of 112, per batch ~100 more.
+// Matches: everything stored before a batch is in L2 when it starts (one s_waitcnt per batch, long satisfied); a match of up to
+// 64 bytes that does not repeat itself and whose source lies in front of the batch's own output is copied by its lane -- the
+// loads of all of them in flight before one wait --; the others -- a match that reaches into the batch's own bytes, a longer
+// one, one that repeats itself -- go one after the other behind a wait for the batch's stores.
 __device__ __forceinline__ int run_symbols_batched(Stream &s, const WaveLds &t, const Luts &luts, uint32_t *stage /* LDS: sixty-five times eight bytes, 8-byte aligned */)
 {
 	const uint32_t lane = lane_id();
