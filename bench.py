@@ -805,7 +805,7 @@ def bgzf_leg(args, env):
                         "in the block table = %d blocks, %.1f MB compressed -> %.1f MB inflated per launch; one BGZF block per wave, "
                         "CRC32 checked on the device" % (len(blocks), times, len(table), len(raw) / 1e6, inflated / 1e6),
                blocks=len(table), kernel_ms=round(best, 3), value=round(inflated / best / 1e6, 2), unit="GB/s inflated",
-               note="instruction-bound byte work (profiles/r03g_inflate_pmc.txt: vector unit busy ~83 %, scalar ~69 % of the "
+               note="instruction-bound byte work (profiles/r03j_inflate_pmc.txt: vector unit busy ~83 %, scalar ~68 % of the "
                     "launch); as HBM bytes this is about 1 % of the peak.  The rate depends on how the blocks fill the machine's 8 192 "
                     "waves and on the data: more bytes per symbol (matches) inflate faster")
     # the same kernel on a BAM whose qualities come in runs of a few binned values (what a sequencer of the last decade writes),
