@@ -182,6 +182,9 @@ struct conga_ctx {
 	double bz_ratio = 0;     // inflated bytes per compressed byte of the largest call so far: sizes the spare output buffer
 	std::thread bz_prewarm; // CONGA_FLAG_EXPECT_COHORT: gets the second buffer of compressed bytes and the spare output set while the first sample is on
 	bool bz_prewarmed = false;
+	std::atomic<bool> sr_layout{false}; // a chromosome has its reference text (conga_reference): split reads will be mapped on the records
+	                                    // where the inflate leaves them -- the inflated stream of a sample is in use until its compute is
+	                                    // through, so bytes named ahead are only brought up, not inflated ahead (no spare output set)
 	std::shared_ptr<struct BzJob> bz_spare_owner; // the named job whose inflates fill the spare output set (until the call that takes it up swaps the sets)
 	uint8_t *bz_up_buf[2] = {nullptr, nullptr};
 	size_t bz_up_cap[2] = {0, 0};
@@ -890,6 +893,7 @@ struct KernelTimer {
 void reset_slots(conga_ctx *ctx)
 {
 	ctx->slots.clear();
+	ctx->sr_layout.store(false);
 	ctx->cur = -1;
 	ctx->n_reads_total = 0;
 	ctx->wrap_risk = false;
@@ -1441,7 +1445,7 @@ void bz_run_job(conga_ctx *ctx, const std::shared_ptr<BzJob> &self)
 	// is free: the named job in front of this one owns it until the call that takes THAT one up has swapped it in) -- when a
 	// call of this context has shown how much such a file inflates to, and the job is a named one.
 	bool ahead = false;
-	if (job.build_table && job.ticket != 0 && !getenv("CONGA_BGZF_NO_INFLATE_AHEAD")
+	if (job.build_table && job.ticket != 0 && !getenv("CONGA_BGZF_NO_INFLATE_AHEAD") && !ctx->sr_layout.load()
 			&& !(getenv("CONGA_BGZF_KERNEL") && strcmp(getenv("CONGA_BGZF_KERNEL"), "wave") != 0)) {
 		std::lock_guard<std::mutex> g(ctx->bz_up_mu);
 		if (ctx->bz_ratio > 0 && ctx->d_bz_x2n.p && ctx->d_bz_crc.p) {
@@ -1741,6 +1745,8 @@ void bz_prewarm_start(conga_ctx *ctx, size_t n_bytes)
 			} else
 				(void) hipGetLastError();
 		}
+		if (ctx->sr_layout.load()) // (split reads: named bytes are brought up ahead, not inflated ahead -- no spare output set)
+			return;
 		const size_t cap_blocks = n_bytes / 4096 + 65536;
 		const uint64_t cap_out = (uint64_t) ((double) n_bytes * ratio * 1.25) + ((uint64_t) 64 << 20);
 		(void) (quiet_ensure(ctx->d_bz_blocks2, cap_blocks * sizeof(conga_bgzf_block)) && quiet_ensure(ctx->d_bz_off2, cap_blocks * 8)
@@ -3273,6 +3279,7 @@ int conga_reference(conga_ctx *ctx, const char *seq, int64_t len)
 		return fail(ctx, CONGA_ERR_INVALID, "conga_reference: length differs from the chromosome length");
 	// (readReferenceSeq upper-cases every base, common.c:449: ref_pack_kernel does that on the device while it packs the text)
 	h.ref.assign(reinterpret_cast<const uint8_t *>(seq), reinterpret_cast<const uint8_t *>(seq) + len);
+	ctx->sr_layout.store(true);
 	h.ref_version = ++ctx->ref_stamp;
 	ctx->layout_dirty = true;
 	ctx->computed = false;

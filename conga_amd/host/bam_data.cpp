@@ -693,12 +693,13 @@ int read_bam_cohort(parameters *params, sonic *this_sonic)
 	};
 	// How many samples behind the one on the GPU have their bytes named to the engine (CONGA_COHORT_AHEAD: measurement switch).
 	// Two where the GPU has slack beside the link -- a 1x genome: 35-40 ms of upload against ~40 ms of inflate, walks and compute
-	// that wait for it; 49 ms per sample against 56 with none named.  None with split reads: a 5x genome with sequences keeps the
-	// GPU as long as the link (inflate 265 ms + walks + the split-read stage against 310-370 ms of upload), uploads that share
-	// the machine with the sample in front's kernels take 440-470 ms instead, and the pipeline's second set of buffers (45 GB)
-	// costs the first samples a second: 430-690 ms per sample of a cohort of six against 380-405 (profiles/r03e_cohort_depth.log).
+	// that wait for it; 49 ms per sample against 56 with none named.  One with split reads, and the engine only brings its bytes
+	// up (a context that holds reference text does not inflate ahead: the sample in front maps its split reads on the inflated
+	// stream where it lies, a second one would be another 45 GB and share the machine with that stage): the link, which is what
+	// a 5x genome with sequences waits for, never stands still -- 319 ms per sample of a cohort of twelve against 417 with none
+	// named and 370-400 with the next sample inflated ahead as well (profiles/r03j_rp_cohort_ahead.log).
 	const bool with_split_reads = !params->no_sr && params->have_dups;
-	const int ahead_depth = getenv("CONGA_COHORT_AHEAD") ? atoi(getenv("CONGA_COHORT_AHEAD")) : with_split_reads ? 0 : 2;
+	const int ahead_depth = getenv("CONGA_COHORT_AHEAD") ? atoi(getenv("CONGA_COHORT_AHEAD")) : with_split_reads ? 1 : 2;
 	keep.expect_cohort = n_samples >= 3 && ahead_depth >= 1;
 	plans[0] = plan_input(params, this_sonic, samples[0].first);
 	named[0] = true;

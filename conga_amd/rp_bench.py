@@ -266,7 +266,7 @@ def leg(args, env):
         synth.write_bed(os.path.join(d, "dups.bed"), [(ch["name"], s, e) for ch in chroms for s, e in zip(ch["us"], ch["ue"])])
         common = ["--ref", "ref.fa", "--sonic", "a.cga", "--dels", "dels.bed", "--dups", "dups.bed", "--rp", "10"]
         e2e = {}
-        k_gpu = int(os.environ.get("CONGA_BENCH_RP_K", "6"))   # (measurement switch: a longer cohort)
+        k_gpu = int(os.environ.get("CONGA_BENCH_RP_K", "8"))   # (the switch: a longer or shorter cohort)
         for decode, envx, k in (("gpu", dict(CONGA_GPU_BAM="1"), k_gpu), ("host", dict(CONGA_GPU_BAM="0"), 2)):
             t1, per, t_k, err = e2e_bench.cohort_times(d, [bam], k, common, dict(envx, CONGA_TIMING="1"), decode, repeats=2 if decode == "gpu" else 1)
             # (one call per sample; one per chromosome when a sample's stretch of the file is beyond the engine's piece limit)

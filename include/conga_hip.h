@@ -91,7 +91,9 @@ typedef enum conga_status {
 #define CONGA_FLAG_EXPECT_COHORT 0x40u /* conga_reads_bgzf_next_fd() will be called for further inputs of the size of the first: the
                                           second device buffer for compressed bytes and the spare output set (~3.6 bytes of HBM per byte
                                           of file) are allocated by a thread of the engine's while the first input is on, not when
-                                          the second one is named (45 GB take the runtime 1.3 s) */
+                                          the second one is named (45 GB take the runtime 1.3 s).  A context that holds reference
+                                          text (conga_reference: split reads are mapped on the inflated stream in place) brings named
+                                          bytes up ahead without inflating them ahead: only the second buffer for compressed bytes */
 
 /* SV types, as the reference's DELETION / DUPLICATION (common.h:12-13) */
 #define CONGA_DELETION 'D'
