@@ -471,11 +471,22 @@ def test_cli_split_reads_rp(tmp_path, oracle):
                       index=True, block_payload=30_000)
     with open(os.path.join(d, "list.txt"), "w") as f:
         f.write("r.bam\nb.bam\nr.bam\n")
-    for decode in ("1", "0"):
-        env = dict(os.environ, CONGA_GPU_BAM=decode, CONGA_TIMING="1")
+    for decode in ("1", "0", "1ahead"):
+        env = dict(os.environ, CONGA_GPU_BAM=decode[0], CONGA_TIMING="1")
+        if decode == "1ahead":
+            # the cohort's pipeline with split reads on files of test size: the overlapped upload forced (pieces of 64 KB), the next
+            # sample's bytes named ahead and brought up beside the sample in front -- but NOT inflated ahead: the context holds
+            # reference text, the sample in front maps its split reads on the inflated stream in place
+            env.update(CONGA_BGZF_OVERLAP="1", CONGA_BGZF_PIECE_KB="64", CONGA_BGZF_CHECK_TABLE="1")
         rc = subprocess.run([CONGA, "--cohort", "list.txt", "--out", "co" + decode] + common, cwd=d, capture_output=True, text=True, timeout=600, env=env)
         assert rc.returncode == 0, rc.stderr[-3000:]
         assert rc.stderr.count("10-mer indexes of") == 1, "the indexes are built once for the cohort"
+        if decode == "1ahead":
+            assert "decoding on the host" not in rc.stderr and rc.stderr.count("conga_reads_bgzf:") == 3, rc.stderr[-3000:]
+            assert "inflate launches made ahead" not in rc.stderr, rc.stderr[-3000:]
+            assert rc.stderr.count("named ahead") >= 1, rc.stderr[-3000:]   # (how far ahead depends on the threads' timing)
+            assert files("co1ahead.r") == files("got") and files("co1ahead.b") == files("oneb1")
+            continue
         one = run(["-i", "b.bam", "--out", "oneb" + decode] + common, d, env=env)
         assert one.returncode == 0, one.stderr[-3000:]
         assert files("co%s.r" % decode) == files("got") and files("co%s.b" % decode) == files("oneb" + decode)
