@@ -4,6 +4,9 @@
 //   cold    nobody writes: the slots go up again and again (what the copy engine does with 8 MB pieces of memory that lies in DRAM)
 //   cached  the threads fill the slots with memcpy (ordinary stores: the lines are dirty in the cores' caches when the engine reads)
 //   stream  the threads fill the slots with non-temporal stores (the lines go past the caches to DRAM)
+//   kernels as `cached`, with every wave slot of the machine taken by a long launch on a low-priority stream (the inflate's stand-in)
+//   workers as `cached`, but every filling thread waits for its slot's event itself (hipEventSynchronize in eight threads beside the
+//           thread that sends: the product's structure)
 //   bounce  the threads copy 256 KB at a time into a buffer of their own with memcpy (stand-in for pread: the kernel's copy ends in
 //           the core's cache) and from there into the slot with non-temporal stores
 //   hipcc --offload-arch=gfx950 -O3 -mavx2 -o tools/h2d_fresh tools/h2d_fresh.hip -lpthread && tools/h2d_fresh [threads] [total MB]
@@ -21,6 +24,19 @@
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+// a launch that keeps every wave slot of the machine busy for `ticks` of the 100 MHz clock (stands in for the inflate launches the
+// upload shares the machine with)
+__global__ __launch_bounds__(256) void busy_kernel(unsigned long long ticks, unsigned *sink)
+{
+	const unsigned long long t0 = wall_clock64();
+	unsigned x = threadIdx.x;
+	while (wall_clock64() - t0 < ticks)
+		for (int k = 0; k < 256; k++)
+			x = x * 1664525u + 1013904223u;
+	if (x == 12345u)
+		sink[0] = x;
+}
 
 static void copy_stream(uint8_t *dst, const uint8_t *src, size_t n) // n a multiple of 64, dst 32-byte aligned
 {
@@ -51,14 +67,22 @@ int main(int argc, char **argv)
 	std::vector<hipEvent_t> ev(n_slots);
 	for (auto &e : ev)
 		CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-	const char *names[] = {"cold", "cached", "stream", "bounce"};
+	const char *names[] = {"cold", "cached", "stream", "bounce", "kernels", "workers"};
+	hipStream_t kst;
+	int lo_prio = 0, hi_prio = 0;
+	CK(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
+	CK(hipStreamCreateWithPriority(&kst, hipStreamNonBlocking, lo_prio));
+	unsigned *sink;
+	CK(hipMalloc((void **) &sink, 64));
 	for (int rep = 0; rep < 2; rep++)
-		for (int mode = 0; mode < 4; mode++) {
+		for (int mode = 0; mode < 6; mode++) {
+			if (mode == 4) // the "cached" fill with every wave slot of the machine taken by a long launch on a low-priority stream
+				hipLaunchKernelGGL(busy_kernel, dim3(2048), dim3(256), 0, kst, 6000000ull /* 60 ms */, sink);
 			std::mutex mu;
 			std::condition_variable cv;
 			std::vector<int> filled(n_pieces, 0);
 			std::vector<char> busy(n_slots, 0);
-			std::atomic<size_t> next{0};
+			std::atomic<size_t> next{0}, issued{0};
 			std::atomic<long long> ns_copy{0}, ns_wait{0};
 			const auto t0 = std::chrono::steady_clock::now();
 			auto worker = [&]() {
@@ -71,12 +95,17 @@ int main(int argc, char **argv)
 					const auto w0 = std::chrono::steady_clock::now();
 					if (c >= (size_t) n_slots) { // the slot's previous piece must have gone up
 						std::unique_lock<std::mutex> l(mu);
-						cv.wait(l, [&] { return filled[c - n_slots] == 2; });
+						if (mode == 5) { // the product's way: wait until that piece's copy is ISSUED, then for its event -- in this thread
+							cv.wait(l, [&] { return issued.load() > c - n_slots; });
+							l.unlock();
+							CK(hipEventSynchronize(ev[slot]));
+						} else
+							cv.wait(l, [&] { return filled[c - n_slots] == 2; });
 					}
 					const auto w1 = std::chrono::steady_clock::now();
 					uint8_t *dst = ring + (size_t) slot * piece;
 					const uint8_t *from = src.data() + c * piece;
-					if (mode == 1)
+					if (mode == 1 || mode == 4 || mode == 5)
 						memcpy(dst, from, piece);
 					else if (mode == 2)
 						copy_stream(dst, from, piece);
@@ -113,8 +142,20 @@ int main(int argc, char **argv)
 						CK(hipMemcpyAsync(dev + sent * piece, ring + (sent % n_slots) * piece, piece, hipMemcpyHostToDevice, st));
 						CK(hipEventRecord(ev[sent % n_slots], st));
 						sent++;
+						if (mode == 5) {
+							{
+								std::lock_guard<std::mutex> l(mu);
+								issued = sent;
+							}
+							cv.notify_all();
+						}
 						continue;
 					}
+				}
+				if (mode == 5 && sent < n_pieces) { // (the workers free the slots: this thread only sends)
+					std::unique_lock<std::mutex> l(mu);
+					cv.wait(l, [&] { return filled[sent] == 1; });
+					continue;
 				}
 				CK(hipEventSynchronize(ev[freed % n_slots]));
 				{
@@ -126,10 +167,12 @@ int main(int argc, char **argv)
 			}
 			for (auto &t : th)
 				t.join();
+			CK(hipStreamSynchronize(st));
 			const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 			printf("%-7s %5.1f ms = %5.1f GB/s  (%d threads: %.1f ms filling, %.1f ms waiting for a slot, each)\n", names[mode], ms, total / ms / 1e6,
 					n_threads, ns_copy / 1e6 / n_threads, ns_wait / 1e6 / n_threads);
 			(void) busy;
+			CK(hipStreamSynchronize(kst));
 		}
 	return 0;
 }
