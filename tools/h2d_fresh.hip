@@ -7,11 +7,14 @@
 //   kernels as `cached`, with every wave slot of the machine taken by a long launch on a low-priority stream (the inflate's stand-in)
 //   workers as `cached`, but every filling thread waits for its slot's event itself (hipEventSynchronize in eight threads beside the
 //           thread that sends: the product's structure)
+//   pread   the threads fill the slots with pread() from a file in the page cache (the product's source)
+//   pread+b / pread+c   pread() 256 KB at a time into a buffer of the thread's own, from there into the slot with non-temporal / ordinary stores
 //   bounce  the threads copy 256 KB at a time into a buffer of their own with memcpy (stand-in for pread: the kernel's copy ends in
 //           the core's cache) and from there into the slot with non-temporal stores
 //   hipcc --offload-arch=gfx950 -O3 -mavx2 -o tools/h2d_fresh tools/h2d_fresh.hip -lpthread && tools/h2d_fresh [threads] [total MB]
 #include <hip/hip_runtime.h>
 #include <immintrin.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <chrono>
@@ -62,12 +65,22 @@ int main(int argc, char **argv)
 	for (size_t i = 0; i < total; i += 4096)
 		src[i] = (uint8_t) (i >> 12);
 	memset(ring, 1, piece * n_slots);
+	// the same bytes as a file in the page cache (written, then read twice so that its pages are settled)
+	char path[] = "/tmp/h2d_fresh_XXXXXX";
+	const int fd = mkstemp(path);
+	if (fd < 0 || write(fd, src.data(), total) != (ssize_t) total)
+		return 2;
+	unlink(path);
+	for (int k = 0; k < 2; k++)
+		for (size_t o = 0; o < total; o += piece)
+			if (pread(fd, ring, piece, (off_t) o) != (ssize_t) piece)
+				return 2;
 	hipStream_t st;
 	CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
 	std::vector<hipEvent_t> ev(n_slots);
 	for (auto &e : ev)
 		CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-	const char *names[] = {"cold", "cached", "stream", "bounce", "kernels", "workers"};
+	const char *names[] = {"cold", "cached", "stream", "bounce", "kernels", "workers", "pread", "pread+b", "pread+c"};
 	hipStream_t kst;
 	int lo_prio = 0, hi_prio = 0;
 	CK(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
@@ -75,7 +88,7 @@ int main(int argc, char **argv)
 	unsigned *sink;
 	CK(hipMalloc((void **) &sink, 64));
 	for (int rep = 0; rep < 2; rep++)
-		for (int mode = 0; mode < 6; mode++) {
+		for (int mode = 0; mode < 9; mode++) {
 			if (mode == 4) // the "cached" fill with every wave slot of the machine taken by a long launch on a low-priority stream
 				hipLaunchKernelGGL(busy_kernel, dim3(2048), dim3(256), 0, kst, 6000000ull /* 60 ms */, sink);
 			std::mutex mu;
@@ -107,7 +120,19 @@ int main(int argc, char **argv)
 					const uint8_t *from = src.data() + c * piece;
 					if (mode == 1 || mode == 4 || mode == 5)
 						memcpy(dst, from, piece);
-					else if (mode == 2)
+					else if (mode == 7 || mode == 8) { // pread into a buffer of the thread's own, from there into the slot (non-temporal / ordinary stores)
+						for (size_t o = 0; o < piece; o += bounce.size()) {
+							if (pread(fd, bounce.data(), bounce.size(), (off_t) (c * piece + o)) != (ssize_t) bounce.size())
+								exit(3);
+							if (mode == 7)
+								copy_stream(dst + o, bounce.data(), bounce.size());
+							else
+								memcpy(dst + o, bounce.data(), bounce.size());
+						}
+					} else if (mode == 6) { // the product's source: the page cache, by way of the kernel's copy
+						if (pread(fd, dst, piece, (off_t) (c * piece)) != (ssize_t) piece)
+							exit(3);
+					} else if (mode == 2)
 						copy_stream(dst, from, piece);
 					else if (mode == 3)
 						for (size_t o = 0; o < piece; o += bounce.size()) {
