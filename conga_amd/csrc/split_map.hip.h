@@ -311,8 +311,9 @@ __device__ __forceinline__ int half_distance_fwd(const uint32_t *refn, int c, co
 
 // ... and of its reverse complement and the reference at c: base k of the reverse complement is the complement of the half's
 // base n - 1 - k, so the half's base i meets the complement of reference base c + n - 1 - i -- the half's words as they are
-// against the reference's words from the window's END backwards, bits reversed.  (A window that starts within 56 bases of
-// the chromosome's first: the caller's dword-by-dword form.)
+// against the reference's words from the window's END backwards, bits reversed.  (The last step's load begins 56 bases in
+// front of the end of the (n - 1) % 56 + 1 bases it looks at: a window whose c is not that far from the text's first base goes
+// to the caller's dword-by-dword form.)
 __device__ __forceinline__ int half_distance_rev(const uint32_t *refn, int c, const uint8_t *sq, int from, int n, const uint32_t h0[7])
 {
 	int d = 0;
@@ -528,7 +529,11 @@ __global__ __launch_bounds__(256) void split_map_kernel(SplitMapArgs g)
 					const int c = positions[k];
 					if ((int64_t) c >= hi_pos)
 						break;
-					const int d = c + n >= 56 + 8 ? half_distance_rev(refn, c, sq, from, n, h0) : half_distance(refn, c, sq, from, n, true);
+					// (half_distance_rev's LAST step looks at the window's first (n - 1) % 56 + 1 bases and loads the 56 that end
+					// with them: those begin in front of base 0 of the reference text unless c is that far in.  `c + n >= 64` was the
+					// test until tests/soak.py --bam-rp (seed 82, case 11) met a half of more than 56 bases within 56 of chromosome
+					// 1's first base -- two dwords in front of the buffer, on a page that was not there)
+					const int d = c + (n - 1) % 56 + 1 >= 56 + 8 ? half_distance_rev(refn, c, sq, from, n, h0) : half_distance(refn, c, sq, from, n, true);
 					if (d <= dist_max)
 						size++;
 				}

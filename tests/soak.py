@@ -182,6 +182,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--first-case", type=int, default=0, help="--bam-rp: begin with this case of the seed's sequence (a failure names its case)")
     ap.add_argument("--seconds", type=float, default=0, help="stop after this long (0: run all cases)")
     ap.add_argument("--bam", action="store_true",
                     help="the command line on random BAM files (+ .bai): decode on the GPU (conga_reads_bgzf) against the host "
@@ -353,7 +354,7 @@ def main():
         import tempfile
         from conga_amd import formats, synth
         conga = os.path.join(ROOT, "conga_amd", "host", "conga")
-        for i in range(a.cases):
+        for i in range(a.first_case, a.first_case + a.cases):
             rng = np.random.default_rng([a.seed, 13_000_000 + i])
             d = tempfile.mkdtemp(prefix="conga_soak_bamrp_")
             n_chr = int(rng.integers(1, 4))
@@ -389,7 +390,7 @@ def main():
                              ("host", {"CONGA_GPU_BAM": "0"})):
                 r = subprocess.run([conga] + args + ["--out", tag], cwd=d, capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
                 if r.returncode != 0 or (tag == "gpu" and "decoding on the host" in r.stderr):
-                    print("FAILED bam-rp case %d (seed %d, %s) in %s:\n%s" % (i, a.seed, tag, d, r.stderr[-1500:]), flush=True)
+                    print("FAILED bam-rp case %d (seed %d, %s) in %s: %s\n%s" % (i, a.seed, tag, d, " ".join(args), r.stderr[-3000:]), flush=True)
                     raise SystemExit(1)
                 files = [open(os.path.join(d, "%s_%s.bed" % (tag, k)), "rb").read() for k in ("svs", "dels", "dups")]
                 outs[tag] = (files, re.findall(r"\((\d+) reads, (\d+) split-reads\)", r.stderr), re.findall(r"CONGA paired (\d+)", r.stderr))
