@@ -30,6 +30,7 @@
 #include <numeric>
 #include <type_traits>
 #include <memory>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -188,6 +189,10 @@ struct conga_ctx {
 	                                    // where the inflate leaves them -- the inflated stream of a sample is in use until its compute is
 	                                    // through, so bytes named ahead are only brought up, not inflated ahead (no spare output set)
 	std::shared_ptr<struct BzJob> bz_spare_owner; // the named job whose inflates fill the spare output set (until the call that takes it up swaps the sets)
+	std::set<uint64_t> bz_spare_waiting;          // tickets of the named jobs that will inflate ahead and have not got the set yet: it goes to the
+	                                              // OLDEST of them (bz_up_mu).  Whoever wakes first took it until tests/soak.py --bam (seed 81, case 38):
+	                                              // the job named second behind the call got the set, the call in front waited for the job named first
+	                                              // to be inflated, that one for the set, the set for the call behind -- a standstill
 	uint8_t *bz_up_buf[2] = {nullptr, nullptr};
 	size_t bz_up_cap[2] = {0, 0};
 	std::shared_ptr<struct BzJob> bz_buf_owner[2]; // a buffer is its job's until the call that took the bytes up is through with them
@@ -1495,14 +1500,24 @@ void bz_run_job(conga_ctx *ctx, const std::shared_ptr<BzJob> &self)
 			ahead = true;
 		}
 	}
+	if (ahead) { // (in the order the jobs begin, which is the order they were named in: the spare set goes to the oldest ticket)
+		std::lock_guard<std::mutex> g(ctx->bz_up_mu);
+		ctx->bz_spare_waiting.insert(job.ticket);
+	}
+	bool inflating = false;
 	{
 		std::lock_guard<std::mutex> g(job.mu);
 		job.d_bytes = d_dst;
 		job.started = true;
 		if (ahead && !job.inflate_asked && !job.adopted && !job.cancel.load()) {
-			job.inflate_asked = true;
+			job.inflate_asked = inflating = true;
 			job.inflater = std::thread(bz_inflate_ahead, ctx, self);
 		}
+	}
+	if (ahead && !inflating) { // (taken up by its call, or given up, in the meantime: it will not ask for the set)
+		std::lock_guard<std::mutex> g(ctx->bz_up_mu);
+		ctx->bz_spare_waiting.erase(job.ticket);
+		ctx->bz_up_cv.notify_all();
 	}
 	job.cv.notify_all();
 
@@ -1835,11 +1850,15 @@ void bz_inflate_ahead(conga_ctx *ctx, const std::shared_ptr<BzJob> &self)
 	bz_prewarm_join(ctx);
 	{ // the spare output set: one job at a time, in the order the jobs were named
 		std::unique_lock<std::mutex> lk(ctx->bz_up_mu);
-		ctx->bz_up_cv.wait(lk, [&] { return !ctx->bz_spare_owner || job.cancel.load(); });
+		ctx->bz_up_cv.wait(lk, [&] {
+			return job.cancel.load() || (!ctx->bz_spare_owner && !ctx->bz_spare_waiting.empty() && *ctx->bz_spare_waiting.begin() == job.ticket);
+		});
+		ctx->bz_spare_waiting.erase(job.ticket);
 		if (job.cancel.load())
 			ok = false;
 		else
 			ctx->bz_spare_owner = self;
+		ctx->bz_up_cv.notify_all(); // (the next ticket may be waiting for this one to be out of the way)
 	}
 	const auto t0 = std::chrono::steady_clock::now();
 	// room for the table and the stream: the table's own size when the caller brought it, a bound when it grows with the upload

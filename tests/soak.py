@@ -182,7 +182,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--first-case", type=int, default=0, help="--bam-rp: begin with this case of the seed's sequence (a failure names its case)")
+    ap.add_argument("--first-case", type=int, default=0, help="--bam / --bam-rp: begin with this case of the seed's sequence (a failure names its case)")
     ap.add_argument("--seconds", type=float, default=0, help="stop after this long (0: run all cases)")
     ap.add_argument("--bam", action="store_true",
                     help="the command line on random BAM files (+ .bai): decode on the GPU (conga_reads_bgzf) against the host "
@@ -214,7 +214,7 @@ def main():
         import zlib
         from conga_amd import formats, synth
         conga = os.path.join(ROOT, "conga_amd", "host", "conga")
-        for i in range(a.cases):
+        for i in range(a.first_case, a.first_case + a.cases):
             rng = np.random.default_rng([a.seed, 11_000_000 + i])
             d = tempfile.mkdtemp(prefix="conga_soak_bam_")
             n_chr = int(rng.integers(1, 6))
