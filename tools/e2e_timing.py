@@ -47,6 +47,11 @@ try:
             for line in err.splitlines():
                 if "overlapped upload" in line or "conga_reads_bgzf:" in line:
                     print("   " + line[:300])
+            import re
+            done = [float(x) for x in re.findall(r"cohort: sample \d+ of \d+ is done ([0-9.]+) ms", err)]
+            if len(done) > 2:
+                print("   sample ends (ms): " + " ".join("%.0f" % x for x in done) + "   per further sample: %.1f, median of the later ones: %.1f"
+                      % ((done[-1] - done[0]) / (len(done) - 1), sorted(b - a for a, b in zip(done[2:-1], done[3:]))[max(0, (len(done) - 4) // 2)] if len(done) > 4 else float("nan")))
     for rep in range(0 if a.variants else 2):
         dt, err = e2e_bench.run_conga(["--cohort", "list.txt", "--out", "x", "--ref", "r.fa", "--sonic", "a.cga", "--dels", "dels.bed"], d,
                                       dict(CONGA_GPU_BAM=a.decode, CONGA_TIMING="1"))
