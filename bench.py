@@ -136,9 +136,10 @@ def open_layout(ctx, mine):
             ctx.intervals("E", u["us"], u["ue"])
 
 
-def pinned_samples(ctx, mine):
-    """[(pos, mapq, chrom_off)] per rotation slot: this rank's chromosomes' tuples one behind the other in pinned
-    host memory -- where a decoder would have left them."""
+def pinned_samples(ctx, mine, packer):
+    """[(pos, mapq, chrom_off, packed, n_esc, width, n_packed_bytes)] per rotation slot: this rank's chromosomes' tuples one behind
+    the other in pinned host memory -- where a decoder would have left them -- and the same positions as the library's own producer
+    (conga_packer_*, conga_amd/csrc/pack_host.h) packs them: W-bit differences, the exceptions behind them in the same buffer."""
     out = []
     for j in range(N_ROTATE):
         n = sum(len(u["reads"][j][0]) for u in mine)
@@ -151,13 +152,11 @@ def pinned_samples(ctx, mine):
             mapq[at:at + len(p)] = m
             at += len(p)
             off[k + 1] = at
-        # the same positions as a producer that subtracts sends them (conga_sample_reads_packed): differences of the width that
-        # sends the fewest bytes at this coverage (10 bits at 1x) + exceptions
-        bits, width, ei, ep = capi.encode_packed(pos[:at], off, int(os.environ["CONGA_BENCH_WIDTH"]) if os.environ.get("CONGA_BENCH_WIDTH") else None)   # (measurement switch)
-        one = capi.pack_inline(bits, ei, ep)          # the exceptions behind the differences: one copy per sample
-        d_pin = ctx.host_alloc(len(one), np.uint8)
-        d_pin[:] = one
-        out.append((pos, mapq, off, d_pin, ei, ep, width, len(bits)))
+        width = int(os.environ["CONGA_BENCH_WIDTH"]) if os.environ.get("CONGA_BENCH_WIDTH") else 0   # (measurement switch; 0: the producer's rule)
+        d_pin = ctx.host_alloc(packer.bound(at, max(at // 16, 4096)), np.uint8)
+        packer.start(pos[:at], off, d_pin, width)
+        width, n_esc, nbytes = packer.finish()
+        out.append((pos[:at], mapq[:at], off, d_pin, n_esc, width, nbytes))
     return out
 
 
@@ -253,14 +252,21 @@ class Leg:
         self.ctxs = [capi.Context(device=env["local_rank"], flags=flags) for _ in range(N_ROTATE)]
         for c in self.ctxs:
             open_layout(c, self.mine)
-        self.samples = pinned_samples(self.ctxs[0], self.mine)
+        self.packer = capi.Packer(int(os.environ.get("CONGA_BENCH_PACK_THREADS", "0")))   # (0: half of the cores the process may use)
+        self.packer_threads = self.packer.threads()
+        self.samples = pinned_samples(self.ctxs[0], self.mine, self.packer)
+        # where the TIMED encode writes (hand_over = "packed+encode"): three pinned buffers, since the bytes of sample k must stay as they
+        # are until the fetch behind compute k has returned (include/conga_hip.h) while sample k + 1 is being encoded
+        self.enc = [self.ctxs[0].host_alloc(len(self.samples[0][3]), np.uint8) for _ in range(3)]
+        self.enc_info = [None] * 3
         self.n_iv_mine = sum(u["n_iv"] for u in self.mine)
         self.rec = capi.RESULT_DTYPE.itemsize
         self.out = [np.zeros(self.n_iv_mine, dtype=capi.RESULT_DTYPE) for _ in range(N_ROTATE)]
         self.E = [np.zeros((len(self.mine), 101), np.float32) for _ in range(N_ROTATE)]
         self.total_iv = self.n_iv_mine
         # handing the layout over is not a step: every context prepares its device layout here, once
-        self.packed_reads = True
+        self.hand_over = "packed"      # "packed": differences encoded beforehand; "packed+encode": encoded inside the step by the
+        #                                library's producer on host threads, beside the step before; "int32": conga_sample_reads
         self.rotate_contexts = False   # N = 1: True = rounds 2-3's loop over three contexts (kept as a figure of its own)
         for j, c in enumerate(self.ctxs):
             self.reads(c, j)
@@ -292,28 +298,44 @@ class Leg:
         # beside the next step instead of in front of it
         self.in_flight = [None] * N_ROTATE
         self.ext = [None if env["rehearsal"] else torch.cuda.ExternalStream(c.stream(), device=dev) for c in self.ctxs]
+        self.gstream = None if env["rehearsal"] else torch.cuda.Stream(device=dev)
 
     def reads(self, c, j):
-        """Sample j's tuples from pinned host memory into context c: the positions as 16-bit differences (what a producer that
-        subtracts sends: conga_sample_reads_d16) unless self.packed_reads is off (32-bit positions: conga_sample_reads)."""
-        pos, mapq, off, d_pin, ei, ep, width, _nb = self.samples[j]
-        if self.packed_reads:
-            if os.environ.get("CONGA_BENCH_SEPARATE_EXCEPTIONS"):   # (measurement switch: three copies per sample instead of one)
-                c.sample_reads_packed(d_pin, width, ei, ep, mapq, off)
-            else:
-                c.sample_reads_packed(d_pin, width, len(ei), None, mapq, off)
-        else:
+        """Sample j's tuples from pinned host memory into context c: as W-bit differences (conga_sample_reads_packed, one copy) or as
+        32-bit positions (conga_sample_reads), as self.hand_over says."""
+        pos, mapq, off, d_pin, n_esc, width, _nb = self.samples[j]
+        if self.hand_over == "int32":
             c.sample_reads(pos, mapq, off)
+        else:
+            c.sample_reads_packed(d_pin, width, n_esc, None, mapq, off)
+
+    # -- the producer inside the step: sample k's positions are encoded by the library's packer (host threads) into pinned buffer
+    # k % 3 while step k - 1 is copied, computed and fetched
+    def encode_start(self, k):
+        pos, _mapq, off = self.samples[k % N_ROTATE][:3]
+        self.packer.start(pos, off, self.enc[k % 3], self.samples[k % N_ROTATE][5])
+
+    def encode_finish_and_hand_over(self, c, k):
+        width, n_esc, _nb = self.packer.finish()
+        _pos, mapq, off = self.samples[k % N_ROTATE][:3]
+        c.sample_reads_packed(self.enc[k % 3], width, n_esc, None, mapq, off)
 
     # -- one step, in two halves so that the copy of step k + 1 is in flight while step k finishes
     def enqueue(self, k):
         c = self.ctxs[k % N_ROTATE]
-        self.reads(c, k % N_ROTATE)                   # pinned host -> HBM, asynchronous
+        if self.hand_over == "packed+encode":         # (no step before this one to encode beside: the producer runs in front of the copy)
+            self.encode_start(k)
+            self.encode_finish_and_hand_over(c, k)
+        else:
+            self.reads(c, k % N_ROTATE)               # pinned host -> HBM, asynchronous
         c.compute()                                   # the whole hot path for this rank's chromosomes, asynchronous
 
-    def finish(self, k):
+    def finish(self, k, c=None):
+        """The records of step k: into host memory (N = 1), or into the RCCL gather towards rank 0 (N > 1) -- c: the context that
+        computed the step (the one-context loop passes its only one)."""
         j = k % N_ROTATE
-        c = self.ctxs[j]
+        if c is None:
+            c = self.ctxs[j]
         if not self.env["dist_on"]:
             c.sample_fetch(self.out[j], self.E[j])    # waits for the kernels; records into host memory
             return
@@ -330,13 +352,19 @@ class Leg:
         if prev is not None:
             prev.synchronize()                        # the previous step's gathered records are in (pinned) host memory
             self.in_flight[(k - 1) % N_ROTATE] = None
-        with torch.cuda.stream(self.ext[j]):          # RCCL over xGMI, ordered behind the copy on the context's stream
+        # RCCL over xGMI on a stream of the gather's own, ordered behind the copy on the context's stream by an event: the context's
+        # stream goes on with the next compute while the records travel (send buffer j is not written again before step k + 3)
+        ext = self.ext[self.ctxs.index(c)]
+        copied = torch.cuda.Event()
+        copied.record(ext)
+        self.gstream.wait_event(copied)
+        with torch.cuda.stream(self.gstream):
             dist.gather(self.packed[j], self.recv[j], dst=0)
             if env["rank"] == 0:
                 self.host_recv[j].copy_(self.recv_all[j], non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(self.ext[j])
-                self.in_flight[j] = ev
+            ev = torch.cuda.Event()
+            ev.record(self.gstream)
+            self.in_flight[j] = ev
 
     def drain(self):
         if self.env["dist_on"] and not self.env["rehearsal"]:
@@ -346,17 +374,34 @@ class Leg:
                     self.in_flight[j] = None
 
     def run(self, n, pipelined=True):
-        if pipelined and not self.env["dist_on"] and not self.rotate_contexts:
-            # one context, the C-ABI's own pipelining: sample k + 1 is handed over (its copy runs on the context's second stream into
-            # the other pair of tuple buffers) while sample k is computed and fetched
+        if pipelined and not self.rotate_contexts:
+            # ONE context, the C-ABI's own pipelining, at N = 1 and at N > 1 alike: sample k + 1 is handed over (its copy runs on the
+            # context's second stream into the other pair of tuple buffers) while sample k is computed and its records are fetched
+            # (N = 1) or gathered (N > 1: finish(k) copies them into send buffer k % 3 on the context's stream and gathers on a stream
+            # of the gather's own).  With hand_over = "packed+encode" the library's producer encodes sample k + 1 meanwhile.
             c = self.ctxs[0]
-            self.reads(c, 0)
-            c.compute()
-            for k in range(1, n):
-                self.reads(c, k % N_ROTATE)
-                c.sample_fetch(self.out[0], self.E[0])
+            if self.hand_over == "packed+encode":
+                self.encode_start(0)
+                self.encode_finish_and_hand_over(c, 0)
+                if n > 1:
+                    self.encode_start(1)
                 c.compute()
-            c.sample_fetch(self.out[0], self.E[0])
+                for k in range(1, n):
+                    self.encode_finish_and_hand_over(c, k)
+                    if k + 1 < n:
+                        self.encode_start(k + 1)
+                    self.finish(k - 1, c)
+                    c.compute()
+                self.finish(n - 1, c)
+            else:
+                self.reads(c, 0)
+                c.compute()
+                for k in range(1, n):
+                    self.reads(c, k % N_ROTATE)
+                    self.finish(k - 1, c)
+                    c.compute()
+                self.finish(n - 1, c)
+            self.drain()
             return
         if pipelined:
             self.enqueue(0)
@@ -409,7 +454,9 @@ class Leg:
         kms = np.zeros(len(capi.KERNEL_NAMES))
         n, dense_ran = 0, False
         for _ in range(reps):
-            for c in ctxs:
+            for j, c in enumerate(ctxs):
+                if self.hand_over != "int32":         # (so that the expansion of the differences is among the timed launches)
+                    self.reads(c, j)
                 c.compute()
                 c.select(0)
                 st = c.fetch()[3]
@@ -459,15 +506,17 @@ def roofline_of(kernel, ms, nbytes, kms, traffic_file, regime):
                 regime=regime, kernel_ms_per_step={k: round(float(v), 4) for k, v in zip(capi.KERNEL_NAMES, kms)})
 
 
-def workload_text(leg, args, config):
+def workload_text(leg, args, config, hand_over="packed"):
     per_sample = leg.total_iv // max(leg.env["world"] if leg.scaling == "weak" else 1, 1)
     what = {"dels": "BASELINE configs[1]", "dels+dups+map": "BASELINE configs[2]"}[config]
     if leg.env["world"] > 1 and leg.scaling == "strong":
         what = "BASELINE configs[3] (the configs[1] sample sharded by chromosome over %d GPUs)" % leg.env["world"]
     return ("%s: GRCh37 autosomes 1-22, %d deletion rows%s (%d intervals kept >= 1000 bp per sample)%s, %.1fx synthetic "
-            "samples, 100-bp GC windows; one step = one sample: tuples in pinned host memory (positions as packed differences) -> records in host memory" % (
+            "samples, 100-bp GC windows; one step = one sample: int32 positions in pinned host memory -> %s -> records in host memory" % (
                 what, synth.N_DELS_GENOME, "" if config == "dels" else " + %d duplication rows" % synth.N_DUPS_GENOME,
-                per_sample, "" if config == "dels" else ", 100-mer-like mappability track", args.cov))
+                per_sample, "" if config == "dels" else ", 100-mer-like mappability track", args.cov,
+                {"int32": "conga_sample_reads", "packed+encode": "conga_packer (encode timed) -> conga_sample_reads_packed",
+                 "packed": "conga_sample_reads_packed (differences encoded beforehand)"}[hand_over]))
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -519,7 +568,20 @@ def main():
     scaling = args.scaling if args.scaling != "auto" else ("strong" if world > 1 else "weak")
 
     leg = Leg(args, env, scaling, args.config)
-    elapsed = leg.timed(args.steps, args.warmup)
+    # The same pipelined step with three hand-overs of the sample's positions, each timed over exactly --steps steps.  `value` is
+    # the faster of the two whose producer is INSIDE the timed region: 32-bit positions as count_reads_bam leaves them
+    # (conga_sample_reads), or W-bit differences encoded by the library's own producer on host threads beside the step before
+    # (conga_packer_* -> conga_sample_reads_packed).  Differences encoded beforehand (round 3's `value`: what the link and the
+    # engine do with a producer that subtracts while it decodes) stay on the line as `hand_over.packed_preencoded`.
+    timed = {}
+    for name in ("packed+encode", "int32", "packed"):
+        leg.hand_over = name
+        timed[name] = leg.timed(args.steps, args.warmup)
+    chosen = min(("packed+encode", "int32"), key=lambda k: timed[k])
+    if os.environ.get("CONGA_BENCH_HAND_OVER") in timed:   # (measurement switch)
+        chosen = os.environ["CONGA_BENCH_HAND_OVER"]
+    leg.hand_over = chosen
+    elapsed = timed[chosen]
     ms_per_step = 1e3 * elapsed / args.steps
     samples_per_step = world if scaling == "weak" else 1
 
@@ -531,16 +593,19 @@ def main():
             if args.dist_selftest and not rehearsal:
                 # the gathered bytes are the records the context holds (fetch order = results_copy order)
                 j = (args.steps - 1) % N_ROTATE
-                want = leg.ctxs[j].sample_fetch()[0].tobytes()
+                want = leg.ctxs[0].sample_fetch()[0].tobytes()
                 have = leg.host_recv[j][0][:leg.bytes_per_rank[0]].numpy().tobytes()
                 assert have == want, "gathered records differ from the fetched ones"
         mine = leg.mine
         reads_step = int(sum(len(u["reads"][0][0]) for u in mine))
-        # W-bit differences + 8 bytes per exception; the MAPQ bytes stay on the host with the default threshold (never read: every read counts)
-        h2d_bytes = leg.samples[0][7] + 8 * len(leg.samples[0][4])
-        cfg = dict(workload=workload_text(leg, args, args.config), samples_per_step=samples_per_step,
+        width, n_esc, packed_bytes = leg.samples[0][5], leg.samples[0][4], leg.samples[0][6]
+        # what crosses the link per step: 4 bytes per read, or W-bit differences + 8 bytes per exception; the MAPQ bytes stay on the
+        # host with the default threshold (never read: every read counts)
+        h2d_bytes = 4 * reads_step if chosen == "int32" else packed_bytes
+        cfg = dict(workload=workload_text(leg, args, args.config, chosen), samples_per_step=samples_per_step,
                    chromosomes_per_sample=len(leg.units) // samples_per_step, intervals_per_step=int(leg.total_iv),
-                   reads_per_step_rank0=reads_step, rotation=("%d samples, one context" % N_ROTATE) if not dist_on else "%d samples x %d contexts" % (N_ROTATE, N_ROTATE),
+                   reads_per_step_rank0=reads_step, rotation="%d samples, one context (the same loop at every N)" % N_ROTATE,
+                   hand_over=chosen,
                    parallelism="chromosome-sharded x%d, one RCCL gather per step" % world)
         out = dict(metric="CNV intervals genotyped/sec (1000G Phase-3 set); CN-call concordance vs ref",
                    value=round(leg.total_iv * args.steps / elapsed, 1), unit="intervals/s", n_gpus=world,
@@ -549,23 +614,31 @@ def main():
                    dtype="i32+f32/f64",  # counts, serial float32 chain, double scores
                    data="synthetic", config=cfg)
 
-    # ---- the same step with the positions as 32-bit numbers (rounds 2-3's hand-over), unpipelined, and the kernels alone (all
-    # ranks take part: the step contains a gather)
-    leg.packed_reads = False
-    e32 = leg.timed(args.steps, 2)
-    leg.packed_reads = True
-    if rank == 0:
-        out["hand_over_int32"] = dict(ms_per_step=round(1e3 * e32 / args.steps, 4), value=round(leg.total_iv * args.steps / e32, 1),
-                                      bytes_per_step=4 * int(sum(len(u["reads"][0][0]) for u in leg.mine)),
-                                      note="the same pipelined step through conga_sample_reads (int32 positions: 4 bytes per read over PCIe)")
+        def line(name, nbytes, note):
+            return dict(ms_per_step=round(1e3 * timed[name] / args.steps, 4), value=round(leg.total_iv * args.steps / timed[name], 1),
+                        bytes_per_step=int(nbytes), note=note)
+        out["hand_over"] = dict(
+            chosen=chosen,
+            rule="`value` = the faster of the two hand-overs whose producer runs inside the timed region (int32, packed+encode)",
+            int32=line("int32", 4 * reads_step, "conga_sample_reads: 32-bit positions as count_reads_bam leaves them, 4 bytes per read over PCIe"),
+            packed_encode_timed=line("packed+encode", packed_bytes,
+                                     "conga_packer_start/finish (the library's producer, %d host threads, conga_amd/csrc/pack_host.h) encodes sample "
+                                     "k + 1 from its int32 array into %d-bit differences while step k is copied, computed and fetched; "
+                                     "then conga_sample_reads_packed" % (leg.packer_threads, width)),
+            packed_preencoded=line("packed", packed_bytes,
+                                   "conga_sample_reads_packed on differences encoded BEFORE the timed region (round 3's `value`): what the link "
+                                   "and the engine do with a producer that subtracts while it decodes; %d exceptions" % n_esc))
+        out["hand_over_int32"] = out["hand_over"]["int32"]   # (the name earlier rounds' lines carry)
+
     single_s = leg.timed(max(3, min(args.steps, 10)), 1, pipelined=False) / max(3, min(args.steps, 10))
     if rank == 0:
         out["single_sample"] = dict(ms_per_step=round(1e3 * single_s, 4), value=round(leg.total_iv / single_s, 1),
                                     note="copy, kernels and fetch of one sample one after the other (latency of a step)")
         h2d = dict(bound="pcie-h2d", bytes_per_step=h2d_bytes, achieved=round(h2d_bytes / (ms_per_step * 1e-3) / 1e9, 2),
-                   peak=PCIE_PEAK_GBS, unit="GB/s", note="%.2f bytes per read (the positions as %d-bit differences, %d exceptions of 8 bytes; with "
+                   peak=PCIE_PEAK_GBS, unit="GB/s", note="%.2f bytes per read (hand-over %s: %s; with "
                    "--mq -1, the reference's default, the MAPQ bytes are never read and are not sent) over PCIe Gen5 x16 per step"
-                   % (leg.samples[0][6] / 8, leg.samples[0][6], len(leg.samples[0][4])))
+                   % (h2d_bytes / max(reads_step, 1), chosen, "32-bit positions" if chosen == "int32" else
+                      "%d-bit differences, %d exceptions of 8 bytes" % (width, n_esc)))
         h2d["frac"] = round(h2d["achieved"] / PCIE_PEAK_GBS, 4)
         # what THIS box's link gives a copy of that size by itself (the boxes differ: 39-57 GB/s): pinned host -> HBM, nothing beside it
         try:
@@ -594,8 +667,8 @@ def main():
         leg.rotate_contexts = False
         out["three_contexts"] = dict(ms_per_step=round(1e3 * e3 / args.steps, 4), value=round(leg.total_iv * args.steps / e3, 1),
                                      note="rounds 2-3's loop: the steps rotate over three contexts (the copy of sample k + 1 beside the "
-                                          "kernels and the fetch of sample k by way of separate contexts); `value` is ONE context: "
-                                          "conga_sample_reads_d16(k + 1) -> conga_sample_fetch(k) -> conga_chrom_compute(k + 1)")
+                                          "kernels and the fetch of sample k by way of separate contexts), hand-over %s; `value` is ONE "
+                                          "context: hand over (k + 1) -> conga_sample_fetch(k) -> conga_chrom_compute(k + 1)" % chosen)
     if rank == 0:
         ko_rot = leg.kernel_only(max(args.steps, 12), rotate=True)
         ko_one = leg.kernel_only(max(args.steps, 12), rotate=False)

@@ -32,13 +32,13 @@ DELETION = "D"
 DUPLICATION = "E"
 
 KERNEL_NAMES = ("ingest", "depth_tile", "expected_table", "paint", "interval_reduce", "interval_score",
-                "interval_chain", "interval_count", "split_map")
+                "interval_chain", "interval_count", "split_map", "delta_expand")
 
 # every symbol include/conga_hip.h declares
 EXPORTS = (
     "conga_create", "conga_destroy", "conga_strerror", "conga_last_error", "conga_abi_version",
     "conga_device_count", "conga_reset", "conga_chrom_count", "conga_chrom_select", "conga_chrom_begin", "conga_reads_staging", "conga_reads_commit",
-    "conga_reads_bgzf", "conga_reads_bgzf_fd", "conga_reads_bgzf_next_fd", "conga_reads_bgzf_next_table", "conga_reads_bgzf_next_blocks", "conga_reads_bgzf_forget", "conga_release_staging", "conga_inflate_blocks", "conga_host_alloc", "conga_host_free", "conga_sample_reads", "conga_sample_reads_d16", "conga_sample_reads_packed", "conga_sample_begin",
+    "conga_reads_bgzf", "conga_reads_bgzf_fd", "conga_reads_bgzf_next_fd", "conga_reads_bgzf_next_table", "conga_reads_bgzf_next_blocks", "conga_reads_bgzf_forget", "conga_release_staging", "conga_inflate_blocks", "conga_host_alloc", "conga_host_free", "conga_sample_reads", "conga_sample_reads_d16", "conga_sample_reads_packed", "conga_packer_create", "conga_packer_destroy", "conga_packer_threads", "conga_pack_bound", "conga_packer_start", "conga_packer_finish", "conga_sample_begin",
     "conga_sample_chrom", "conga_sample_fetch",
     "conga_mappability", "conga_intervals", "conga_reference", "conga_satellites", "conga_split_reads_staging",
     "conga_split_reads_commit", "conga_split_support", "conga_chrom_compute",
@@ -162,6 +162,51 @@ def pack_inline(bits, esc_index, esc_pos):
     return out
 
 
+class Packer:
+    """conga_packer_*: the library's own producer of the packed hand-over (host threads, no device).  start() returns at once;
+    finish() -> (width, n_esc, out_bytes); the bytes are in the `out` array start() was given (the one-copy layout)."""
+
+    def __init__(self, n_threads=0):
+        self._lib = load()
+        self._h = self._lib.conga_packer_create(int(n_threads))
+        if not self._h:
+            raise MemoryError("conga_packer_create")
+        self._keep = None
+
+    def start(self, pos, chrom_off, out, width=0):
+        if pos.dtype != np.int32 or chrom_off.dtype != np.uint64 or out.dtype != np.uint8:
+            raise TypeError("Packer.start takes int32 pos, uint64 chrom_off, uint8 out")
+        self._keep = (pos, chrom_off, out)
+        rc = self._lib.conga_packer_start(self._h, pos.ctypes.data, chrom_off.ctypes.data, len(chrom_off) - 1, int(width), out.ctypes.data, out.nbytes)
+        if rc != CONGA_OK:
+            raise CongaError(rc, "conga_packer_start")
+
+    def finish(self):
+        w, ne, nb = C.c_int(0), C.c_size_t(0), C.c_size_t(0)
+        rc = self._lib.conga_packer_finish(self._h, C.byref(w), C.byref(ne), C.byref(nb))
+        self._keep = None
+        if rc != CONGA_OK:
+            raise CongaError(rc, "conga_packer_finish")
+        return w.value, ne.value, nb.value
+
+    def threads(self):
+        return int(self._lib.conga_packer_threads(self._h))
+
+    def bound(self, n_reads, max_esc):
+        return int(self._lib.conga_pack_bound(int(n_reads), int(max_esc)))
+
+    def close(self):
+        if self._h:
+            self._lib.conga_packer_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
 def load():
     """dlopen the HIP library.  Raises (never falls back) when it has not been built."""
     global _lib
@@ -220,6 +265,18 @@ def load():
     L.conga_sample_reads_d16.argtypes = [vp, vp, vp, vp, sz, vp, vp, C.c_int]
     L.conga_sample_reads_packed.restype = C.c_int
     L.conga_sample_reads_packed.argtypes = [vp, vp, C.c_int, vp, vp, sz, vp, vp, C.c_int]
+    L.conga_packer_create.restype = vp
+    L.conga_packer_create.argtypes = [C.c_int]
+    L.conga_packer_destroy.restype = None
+    L.conga_packer_destroy.argtypes = [vp]
+    L.conga_packer_threads.restype = C.c_int
+    L.conga_packer_threads.argtypes = [vp]
+    L.conga_pack_bound.restype = sz
+    L.conga_pack_bound.argtypes = [C.c_uint64, sz]
+    L.conga_packer_start.restype = C.c_int
+    L.conga_packer_start.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, sz]
+    L.conga_packer_finish.restype = C.c_int
+    L.conga_packer_finish.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(sz), C.POINTER(sz)]
     L.conga_sample_begin.restype = C.c_int
     L.conga_sample_begin.argtypes = [vp]
     L.conga_sample_chrom.restype = C.c_int
@@ -444,6 +501,35 @@ class Context:
         per = (C.c_uint64 * max(self.chrom_count(), 1))()
         self._check(self._lib.conga_reads_bgzf(self._h, data.ctypes.data, len(data), bl, len(blocks), sg, len(segments), per))
         return list(per)[:self.chrom_count()]
+
+    def reads_bgzf_fd(self, fd, file_off, n_bytes, blocks, segments):
+        """conga_reads_bgzf_fd: the same with the bytes still in the file (read with pread into the pinned pieces that go up)."""
+        bl = (BgzfBlock * len(blocks))(*[BgzfBlock(*b, 0) for b in blocks])
+        sg = (BamSegment * len(segments))(*[BamSegment(*x) for x in segments])
+        per = (C.c_uint64 * max(self.chrom_count(), 1))()
+        self._check(self._lib.conga_reads_bgzf_fd(self._h, int(fd), int(file_off), int(n_bytes), bl, len(blocks), sg, len(segments), per))
+        return list(per)[:self.chrom_count()]
+
+    def reads_bgzf_next_fd(self, fd, file_off, n_bytes, known_starts=(), stop_at=0):
+        """conga_reads_bgzf_next_fd -> ticket (0: nothing was started)"""
+        ks = (C.c_uint64 * max(len(known_starts), 1))(*known_starts)
+        ticket = C.c_uint64(0)
+        self._check(self._lib.conga_reads_bgzf_next_fd(self._h, int(fd), int(file_off), int(n_bytes), ks if len(known_starts) else None,
+                                                       len(known_starts), int(stop_at), C.byref(ticket)))
+        return ticket.value
+
+    def reads_bgzf_next_blocks(self, ticket, blocks):
+        bl = (BgzfBlock * len(blocks))(*[BgzfBlock(*b, 0) for b in blocks])
+        self._check(self._lib.conga_reads_bgzf_next_blocks(self._h, int(ticket), bl, len(blocks)))
+
+    def reads_bgzf_next_table(self, ticket):
+        """conga_reads_bgzf_next_table -> [(data_off, data_len, inflated_len, crc32)] (empty: no table)"""
+        b, n = C.POINTER(BgzfBlock)(), C.c_size_t(0)
+        self._check(self._lib.conga_reads_bgzf_next_table(self._h, int(ticket), C.byref(b), C.byref(n)))
+        return [(b[i].data_off, b[i].data_len, b[i].inflated_len, b[i].crc32) for i in range(n.value)]
+
+    def reads_bgzf_forget(self, ticket):
+        self._check(self._lib.conga_reads_bgzf_forget(self._h, int(ticket)))
 
     def inflate_blocks(self, data, blocks, want_out=True):
         """conga_inflate_blocks -> (payloads uint8[], status uint8[n_blocks], kernel_ms)"""

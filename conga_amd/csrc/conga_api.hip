@@ -21,10 +21,13 @@
 #include <thread>
 
 #include <unistd.h>
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#if defined(__x86_64__)
 #include <emmintrin.h>
+#endif
 #include <memory>
 #include <new>
 #include <numeric>
@@ -40,6 +43,7 @@
 #include "kernels_bam.hip.h"
 #include "kmer_sort.hip.h"
 #include "split_map.hip.h"
+#include "pack_host.h"
 
 using namespace conga;
 
@@ -1165,6 +1169,17 @@ struct ByteSource {
 	const uint8_t *bytes = nullptr;
 	int fd = -1;
 	uint64_t file_off = 0;
+	mutable std::atomic<bool> io_error{false}; // the last failed fetch was pread() failing (errno), not the file ending early
+	ByteSource() = default;
+	ByteSource(const ByteSource &o) : bytes(o.bytes), fd(o.fd), file_off(o.file_off), io_error(o.io_error.load()) {}
+	ByteSource &operator=(const ByteSource &o)
+	{
+		bytes = o.bytes;
+		fd = o.fd;
+		file_off = o.file_off;
+		io_error.store(o.io_error.load());
+		return *this;
+	}
 	bool fetch(size_t at, void *dst, size_t n) const
 	{
 		if (bytes) {
@@ -1174,8 +1189,12 @@ struct ByteSource {
 		uint8_t *p = static_cast<uint8_t *>(dst);
 		while (n) {
 			const ssize_t got = pread(fd, p, n, (off_t) (file_off + at));
-			if (got <= 0)
+			if (got < 0 && (errno == EINTR || errno == EAGAIN))
+				continue; // (a signal during the upload is not the file's end)
+			if (got <= 0) {
+				io_error = got < 0;
 				return false;
+			}
 			p += got;
 			at += (size_t) got;
 			n -= (size_t) got;
@@ -1190,6 +1209,9 @@ struct ByteSource {
 	{
 		if (bytes || ((uintptr_t) dst & 15u) != 0) // (memory of the caller's: one copy either way)
 			return fetch(at, dst, n);
+#if !defined(__x86_64__)
+		return fetch(at, dst, n); // (the non-temporal stores below are SSE2; elsewhere pread() fills the slot itself)
+#else
 		constexpr size_t kBounce = (size_t) 256 << 10;
 		static thread_local std::unique_ptr<uint8_t[]> bounce;
 		if (!bounce)
@@ -1200,8 +1222,12 @@ struct ByteSource {
 			size_t have = 0;
 			while (have < want) {
 				const ssize_t got = pread(fd, b + have, want - have, (off_t) (file_off + at + have));
-				if (got <= 0)
+				if (got < 0 && (errno == EINTR || errno == EAGAIN))
+					continue;
+				if (got <= 0) {
+					io_error = got < 0;
 					return false;
+				}
 				have += (size_t) got;
 			}
 			size_t i = 0;
@@ -1221,6 +1247,7 @@ struct ByteSource {
 		}
 		_mm_sfence(); // (the slot is handed to the copy engine next)
 		return true;
+#endif
 	}
 };
 
@@ -1558,8 +1585,11 @@ void bz_run_job(conga_ctx *ctx, const std::shared_ptr<BzJob> &self)
 			{
 				std::lock_guard<std::mutex> g(job.mu);
 				job.filled[c] = 1;
-				if (!got)
-					job.failed = job.short_read = true; // (a file that ends early)
+				if (!got) {
+					job.failed = job.short_read = true; // (a file that ends early -- or a read that failed: said as such)
+					if (job.src.io_error.load() && job.error.empty())
+						job.error = "reading the file failed";
+				}
 			}
 			job.cv.notify_all();
 			if (!got)
@@ -2106,7 +2136,8 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const ByteSource &src, size_t 
 			std::unique_lock<std::mutex> lk(job->mu);
 			job->cv.wait(lk, [&] { return job->failed || job->batches_ready > last_batch; });
 			if (job->failed)
-				rc = job->short_read ? fail(ctx, CONGA_ERR_DATA, "conga_reads_bgzf: the file ends inside the piece that was named")
+				rc = job->short_read ? fail(ctx, CONGA_ERR_DATA, job->src.io_error.load() ? "conga_reads_bgzf: reading the file failed (pread)"
+								: "conga_reads_bgzf: the file ends inside the piece that was named")
 						: fail(ctx, CONGA_ERR_HIP, "conga_reads_bgzf: the upload failed: " + job->error);
 		}
 		if (rc != CONGA_OK)
@@ -2823,6 +2854,50 @@ int conga_sample_reads_packed(conga_ctx *ctx, const uint8_t *bits, int width, co
 	return sample_reads_impl(ctx, "conga_sample_reads_packed", nullptr, bits ? bits : none, width, esc_index, esc_pos, n_esc, mapq, chrom_off, n_chrom);
 }
 
+// ---- the producer of the packed form, on the host (pack_host.h)
+struct conga_packer {
+	conga_pack::Packer impl;
+	explicit conga_packer(int n) : impl(n) {}
+};
+
+conga_packer *conga_packer_create(int n_threads)
+{
+	if (n_threads <= 0)
+		n_threads = (int) std::max(1u, cpus_allowed() / 2);
+	return new (std::nothrow) conga_packer(std::min(n_threads, 64));
+}
+
+void conga_packer_destroy(conga_packer *p)
+{
+	delete p;
+}
+
+int conga_packer_threads(const conga_packer *p)
+{
+	return p ? p->impl.threads() : 0;
+}
+
+size_t conga_pack_bound(uint64_t n_reads, size_t max_esc)
+{
+	return conga_pack::bound(n_reads, max_esc);
+}
+
+int conga_packer_start(conga_packer *p, const int32_t *pos, const uint64_t *chrom_off, int n_chrom, int width, uint8_t *out, size_t out_cap)
+{
+	if (!p)
+		return CONGA_ERR_INVALID;
+	const int rc = p->impl.start(pos, chrom_off, n_chrom, width, out, out_cap);
+	return rc == 0 ? CONGA_OK : rc == -4 ? CONGA_ERR_NOMEM : CONGA_ERR_INVALID;
+}
+
+int conga_packer_finish(conga_packer *p, int *width, size_t *n_esc, size_t *out_bytes)
+{
+	if (!p)
+		return CONGA_ERR_INVALID;
+	const int rc = p->impl.finish(width, n_esc, out_bytes);
+	return rc == 0 ? CONGA_OK : rc == -4 ? CONGA_ERR_NOMEM : CONGA_ERR_INVALID;
+}
+
 int conga_sample_reads_d16(conga_ctx *ctx, const uint16_t *delta, const uint32_t *esc_index, const int32_t *esc_pos, size_t n_esc,
 		const uint8_t *mapq, const uint64_t *chrom_off, int n_chrom)
 {
@@ -2942,6 +3017,10 @@ int conga_reads_bgzf_next_blocks(conga_ctx *ctx, uint64_t ticket, const conga_bg
 	job->table_n = n_blocks;
 	job->table_final = job->table_ok = true;
 	job->inflate_asked = true;
+	// (the spare output set goes to the oldest ticket that WAITS for it, bz_inflate_ahead: a job whose table the caller brought
+	// never passes bz_run_job's `ahead` branch, so it is entered here -- without this its thread slept for ever and the call that
+	// adopted the job with it)
+	ctx->bz_spare_waiting.insert(job->ticket);
 	job->inflater = std::thread(bz_inflate_ahead, ctx, job);
 	return CONGA_OK;
 }
@@ -3525,6 +3604,7 @@ int conga_chrom_compute(conga_ctx *ctx)
 		int32_t *d_carry = reinterpret_cast<int32_t *>(d_agg + n_chunks);
 		uint32_t *d_rank = reinterpret_cast<uint32_t *>(d_carry + n_chunks);
 		int32_t *d_pos = ptr<int32_t>(ctx->d_pos);
+		KernelTimer t_expand(ctx, CONGA_K_EXPAND);
 		auto launch = [&](auto width_tag) {
 			constexpr int W = decltype(width_tag)::value;
 			hipLaunchKernelGGL(delta_esc_rank_kernel, dim3((n_chunks + 256) / 256), dim3(256), 0, st, d_ei, n_esc, n_chunks, d_rank);

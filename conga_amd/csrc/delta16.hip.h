@@ -34,8 +34,11 @@ __device__ __forceinline__ SegVal seg_combine(SegVal a, SegVal b) // a in front 
 	return r;
 }
 
-// position of exception `i` (the list is sorted by index; every all-ones value in the stream has its entry -- checked on the host):
-// looked for among the exceptions of the read's own chunk, [lo, hi) of the list (delta_esc_rank_kernel) -- a dozen entries where
+// position of exception `i`.  The list is sorted by index (the host checks that, and that it holds the first read of every chromosome);
+// that EVERY all-ones value of the stream has its entry is the producer's contract (include/conga_hip.h; conga_pack_positions keeps
+// it by construction) and is not checked: an all-ones value without an entry takes the next entry's position, or 0 behind the last
+// one -- memory-safe, positions wrong (as a rule out of order, which the engine's order check then reports).  Looked for
+// among the exceptions of the read's own chunk, [lo, hi) of the list (delta_esc_rank_kernel) -- a dozen entries where
 // the whole list has hundreds of thousands, and a narrow width makes one read in a hundred an exception
 __device__ __forceinline__ int32_t escape_value(const uint32_t *esc_index, const int32_t *esc_pos, uint32_t n_esc, uint32_t lo, uint32_t hi, uint32_t i)
 {

@@ -1,0 +1,337 @@
+// pack_host.h -- the PRODUCER's side of conga_sample_reads_packed, in C++ for the host (no device code, no HIP call).
+//
+// The seam is count_reads_bam (bam_data.c:192-221): a loop that has bam1_core_t.pos of every record in a register, one record
+// after the other in position order.  A producer that subtracts as it goes hands the engine differences of W bits instead of
+// 32-bit positions (include/conga_hip.h: the format; delta16.hip.h: what the engine does with it).  This file is that producer
+// for positions that already lie in an array -- the CLI's host decoders and tuple containers leave them so, and bench.py's
+// timed step starts from such an array --: a pool of threads of the packer's own encodes runs of 8 192 reads (eight
+// differences are W whole bytes, so every run starts on a byte) and collects the exceptions run by run; the caller's thread
+// goes on with something else between start() and finish().  Rounds 3's encoder was numpy in the test binding, outside
+// anything timed ("what's weak" 3).
+//
+// Host-only on purpose: tests/test_pack_host.py builds it with g++ (also under -fsanitize=thread) without the HIP runtime.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace conga_pack {
+
+constexpr uint64_t kRun = 8192; // reads per unit of work (a multiple of 8)
+
+// bytes `out` must hold for any width and up to max_esc exceptions: differences, padding, the two lists, the 64 bytes of slack the
+// expansion's last 16-byte load may touch
+inline size_t bound(uint64_t n_reads, size_t max_esc)
+{
+	return (size_t) ((n_reads + 7) / 8 * 16 + 16 + 8 * (uint64_t) max_esc + 64);
+}
+
+struct Exc {
+	uint32_t index;
+	int32_t pos;
+};
+
+// the group's eight values -> its W bytes: difference k occupies bits [k * W, (k + 1) * W)
+template <int W> inline void store_group(const uint32_t v[8], uint8_t *dst)
+{
+	const uint64_t lo = (uint64_t) v[0] | (uint64_t) v[1] << W | (uint64_t) v[2] << (2 * W) | (uint64_t) v[3] << (3 * W);
+	const uint64_t hi = (uint64_t) v[4] | (uint64_t) v[5] << W | (uint64_t) v[6] << (2 * W) | (uint64_t) v[7] << (3 * W);
+	uint64_t w[2];
+	if (W == 16) {
+		w[0] = lo;
+		w[1] = hi;
+	} else {
+		w[0] = lo | hi << (4 * W);
+		w[1] = hi >> (64 - 4 * W);
+	}
+	memcpy(dst, w, W);
+}
+
+// whole groups [i0, i1) (multiples of 8, i0 > 0) without a chromosome border among them: every read has its predecessor
+template <int W> inline void encode_groups(const int32_t *pos, uint64_t i0, uint64_t i1, uint8_t *out, std::vector<Exc> &exc)
+{
+	constexpr uint32_t kTop = (1u << W) - 1u;
+	for (uint64_t i = i0; i < i1; i += 8) {
+		uint32_t v[8], any = 0;
+#pragma GCC unroll 8
+		for (int k = 0; k < 8; k++) {
+			const uint32_t d = (uint32_t) pos[i + k] - (uint32_t) pos[i + k - 1]; // (a position in front of its predecessor: huge)
+			v[k] = d < kTop ? d : kTop;
+			any |= d >= kTop ? 1u : 0u;
+		}
+		if (any)
+			for (int k = 0; k < 8; k++)
+				if (v[k] == kTop)
+					exc.push_back(Exc{(uint32_t) (i + (uint64_t) k), pos[i + (uint64_t) k]});
+		store_group<W>(v, out + (i >> 3) * W);
+	}
+}
+
+// the group that starts at i (a multiple of 8) read by read: chromosome borders among its reads (`forced`, ascending, consumed
+// through *f), the sample's first read, the sample's end (`n`) inside it
+template <int W> inline void encode_group_slow(const int32_t *pos, uint64_t i, uint64_t n, const uint64_t *forced, size_t n_forced, size_t *f, uint8_t *out,
+		std::vector<Exc> &exc)
+{
+	constexpr uint32_t kTop = (1u << W) - 1u;
+	uint32_t v[8];
+	for (int k = 0; k < 8; k++) {
+		const uint64_t j = i + (uint64_t) k;
+		if (j >= n) {
+			v[k] = 0;
+			continue;
+		}
+		bool is_first = j == 0;
+		if (*f < n_forced && forced[*f] == j) {
+			is_first = true;
+			(*f)++;
+		}
+		const uint32_t d = is_first ? kTop : (uint32_t) pos[j] - (uint32_t) pos[j - 1];
+		v[k] = d < kTop ? d : kTop;
+		if (d >= kTop)
+			exc.push_back(Exc{(uint32_t) j, pos[j]});
+	}
+	store_group<W>(v, out + (i >> 3) * W);
+}
+
+// one run [r0, r1) of the sample (r0 a multiple of 8; r1 one too, or the sample's end) at width W; `forced` = indices in [r0, r1)
+// that are a chromosome's first read (ascending)
+template <int W>
+inline void encode_run(const int32_t *pos, uint64_t r0, uint64_t r1, const uint64_t *forced, size_t n_forced, uint8_t *out, std::vector<Exc> &exc)
+{
+	size_t f = 0;
+	uint64_t cur = r0;
+	if (cur == 0 && r1 > 0) { // (the sample's first read has no predecessor)
+		encode_group_slow<W>(pos, 0, r1, forced, n_forced, &f, out, exc);
+		cur = 8;
+	}
+	while (f < n_forced) {
+		const uint64_t g = forced[f] & ~(uint64_t) 7;
+		if (g > cur)
+			encode_groups<W>(pos, cur, g, out, exc);
+		encode_group_slow<W>(pos, g, r1, forced, n_forced, &f, out, exc);
+		cur = g + 8;
+	}
+	const uint64_t whole_end = r1 & ~(uint64_t) 7;
+	if (whole_end > cur) {
+		encode_groups<W>(pos, cur, whole_end, out, exc);
+		cur = whole_end;
+	}
+	if (cur < r1)
+		encode_group_slow<W>(pos, cur, r1, forced, n_forced, &f, out, exc);
+}
+
+inline void encode_run_any(int width, const int32_t *pos, uint64_t r0, uint64_t r1, const uint64_t *forced, size_t n_forced, uint8_t *out,
+		std::vector<Exc> &exc)
+{
+	switch (width) {
+	case 4: return encode_run<4>(pos, r0, r1, forced, n_forced, out, exc);
+	case 5: return encode_run<5>(pos, r0, r1, forced, n_forced, out, exc);
+	case 6: return encode_run<6>(pos, r0, r1, forced, n_forced, out, exc);
+	case 7: return encode_run<7>(pos, r0, r1, forced, n_forced, out, exc);
+	case 8: return encode_run<8>(pos, r0, r1, forced, n_forced, out, exc);
+	case 9: return encode_run<9>(pos, r0, r1, forced, n_forced, out, exc);
+	case 10: return encode_run<10>(pos, r0, r1, forced, n_forced, out, exc);
+	case 11: return encode_run<11>(pos, r0, r1, forced, n_forced, out, exc);
+	case 12: return encode_run<12>(pos, r0, r1, forced, n_forced, out, exc);
+	case 13: return encode_run<13>(pos, r0, r1, forced, n_forced, out, exc);
+	case 14: return encode_run<14>(pos, r0, r1, forced, n_forced, out, exc);
+	case 15: return encode_run<15>(pos, r0, r1, forced, n_forced, out, exc);
+	default: return encode_run<16>(pos, r0, r1, forced, n_forced, out, exc);
+	}
+}
+
+// The producer's rule for the width (conga_hip.h): the fewest bytes -- differences + 8 per exception -- among the widths that keep
+// exceptions at or below one read in a thousand; taken from every 61st run of 256 reads (a 1x genome: 420 000 of 25.6 M
+// differences looked at, 0.03 ms).  Deterministic: the same positions give the same width.
+inline int choose_width(const int32_t *pos, uint64_t n)
+{
+	if (n < 2)
+		return 16;
+	uint64_t need[18] = {0}; // need[b]: sampled differences that want exactly b bits (17: negative or >= 2^16 - 1)
+	uint64_t seen = 0;
+	const uint64_t stride = n > ((uint64_t) 1 << 18) ? 61 * 256 : 256;
+	for (uint64_t a = 1; a < n; a += stride)
+		for (uint64_t i = a; i < std::min(n, a + 256); i++) {
+			const uint32_t d = (uint32_t) pos[i] - (uint32_t) pos[i - 1];
+			// the smallest W with d < 2^W - 1
+			int b = 17;
+			if (d < 0xFFFFu)
+				b = d == 0 ? 1 : 32 - __builtin_clz(d + 1u);
+			need[b]++;
+			seen++;
+		}
+	int best = 16;
+	double best_cost = 1e300;
+	uint64_t over = need[17];
+	for (int w = 16; w >= 4; w--) { // over = sampled differences that do not fit w bits
+		const double frac = (double) over / (double) std::max<uint64_t>(seen, 1);
+		const double cost = (double) w / 8.0 + 8.0 * frac;
+		if ((frac <= 1e-3 || w == 16) && cost < best_cost) {
+			best_cost = cost;
+			best = w;
+		}
+		over += need[w];
+	}
+	return best;
+}
+
+// A pool of threads that encodes one sample at a time.  start() returns at once; finish() waits and puts the exception lists behind
+// the differences (the one-copy layout of conga_sample_reads_packed with esc_index == NULL).
+class Packer {
+public:
+	explicit Packer(int n_threads) : n_threads_(std::max(1, n_threads))
+	{
+		for (int t = 0; t < n_threads_; t++)
+			threads_.emplace_back([this] { loop(); });
+	}
+	~Packer()
+	{
+		{
+			std::lock_guard<std::mutex> g(mu_);
+			quit_ = true;
+		}
+		cv_.notify_all();
+		for (std::thread &t : threads_)
+			t.join();
+	}
+	int threads() const { return n_threads_; }
+
+	// -> 0, or -1: arguments, -4: out_cap cannot hold the differences
+	int start(const int32_t *pos, const uint64_t *chrom_off, int n_chrom, int width, uint8_t *out, size_t out_cap)
+	{
+		if (!chrom_off || n_chrom < 0 || chrom_off[0] != 0 || !out || busy_)
+			return -1;
+		for (int c = 0; c < n_chrom; c++)
+			if (chrom_off[c + 1] < chrom_off[c])
+				return -1;
+		const uint64_t n = chrom_off[n_chrom];
+		if ((n && !pos) || n >= 0xFFFFFFF0ull || (width != 0 && (width < 4 || width > 16)))
+			return -1;
+		if (width == 0)
+			width = choose_width(pos, n);
+		const size_t d_bytes = (size_t) ((n + 7) / 8) * (size_t) width;
+		if (((d_bytes + 15) & ~(size_t) 15) + 64 > out_cap)
+			return -4;
+		std::vector<uint64_t> forced;
+		for (int c = 0; c < n_chrom; c++)
+			if (chrom_off[c + 1] > chrom_off[c])
+				forced.push_back(chrom_off[c]);
+		{
+			// (a thread that slept through the sample before wakes up whenever it likes, finds nothing left and goes back to sleep: it
+			// reads these fields meanwhile -- they change under the lock, with no thread inside its loop)
+			std::unique_lock<std::mutex> lk(mu_);
+			done_cv_.wait(lk, [&] { return active_ == 0; });
+			pos_ = pos;
+			n_ = n;
+			width_ = width;
+			out_ = out;
+			out_cap_ = out_cap;
+			forced_.swap(forced);
+			n_runs_ = (size_t) ((n + kRun - 1) / kRun);
+			if (exc_.size() < n_runs_)
+				exc_.resize(n_runs_);
+			busy_ = true;
+			next_.store(0, std::memory_order_relaxed);
+			left_ = n_runs_;
+			generation_++;
+		}
+		cv_.notify_all();
+		return 0;
+	}
+
+	// -> 0, -1: nothing was started, -4: the exceptions do not fit behind the differences in out_cap
+	int finish(int *width, size_t *n_esc, size_t *out_bytes)
+	{
+		if (!busy_)
+			return -1;
+		{
+			std::unique_lock<std::mutex> lk(mu_);
+			done_cv_.wait(lk, [&] { return left_ == 0 && active_ == 0; });
+		}
+		busy_ = false;
+		size_t k = 0;
+		for (size_t r = 0; r < n_runs_; r++)
+			k += exc_[r].size();
+		const size_t d_bytes = (size_t) ((n_ + 7) / 8) * (size_t) width_;
+		const size_t esc_at = (d_bytes + 15) & ~(size_t) 15;
+		if (width)
+			*width = width_;
+		if (n_esc)
+			*n_esc = k;
+		if (out_bytes)
+			*out_bytes = esc_at + 8 * k;
+		if (esc_at + 8 * k + 64 > out_cap_)
+			return -4;
+		memset(out_ + d_bytes, 0, esc_at - d_bytes);
+		uint32_t *ei = reinterpret_cast<uint32_t *>(out_ + esc_at);
+		int32_t *ep = reinterpret_cast<int32_t *>(out_ + esc_at) + k;
+		size_t at = 0;
+		for (size_t r = 0; r < n_runs_; r++)
+			for (const Exc &e : exc_[r]) {
+				ei[at] = e.index;
+				ep[at] = e.pos;
+				at++;
+			}
+		return 0;
+	}
+
+private:
+	void loop()
+	{
+		uint64_t seen = 0;
+		for (;;) {
+			{
+				std::unique_lock<std::mutex> lk(mu_);
+				cv_.wait(lk, [&] { return quit_ || generation_ != seen; });
+				if (quit_)
+					return;
+				seen = generation_;
+				active_++; // (finish() waits for every thread that took this sample up: none is inside the loop below when the next one starts)
+			}
+			size_t mine = 0;
+			for (;;) {
+				const size_t r = next_.fetch_add(1, std::memory_order_relaxed);
+				if (r >= n_runs_)
+					break;
+				const uint64_t r0 = (uint64_t) r * kRun, r1 = std::min(n_, r0 + kRun);
+				const auto f0 = std::lower_bound(forced_.begin(), forced_.end(), r0), f1 = std::lower_bound(f0, forced_.end(), r1);
+				exc_[r].clear();
+				encode_run_any(width_, pos_, r0, r1, forced_.data() + (f0 - forced_.begin()), (size_t) (f1 - f0), out_, exc_[r]);
+				mine++;
+			}
+			{
+				std::lock_guard<std::mutex> g(mu_);
+				left_ -= mine;
+				active_--;
+				if (active_ == 0)
+					done_cv_.notify_all();
+			}
+		}
+	}
+
+	const int n_threads_;
+	std::vector<std::thread> threads_;
+	std::mutex mu_;
+	std::condition_variable cv_, done_cv_;
+	bool quit_ = false, busy_ = false;
+	uint64_t generation_ = 0;
+	size_t left_ = 0, n_runs_ = 0;
+	int active_ = 0;
+	std::atomic<size_t> next_{0};
+	const int32_t *pos_ = nullptr;
+	uint64_t n_ = 0;
+	int width_ = 16;
+	uint8_t *out_ = nullptr;
+	size_t out_cap_ = 0;
+	std::vector<uint64_t> forced_;
+	std::vector<std::vector<Exc>> exc_;
+};
+
+} // namespace conga_pack

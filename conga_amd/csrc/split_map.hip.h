@@ -27,6 +27,7 @@
 #include <stdint.h>
 
 #include "kernels.hip.h"
+#include "split_geom.h"
 
 namespace conga {
 
@@ -318,7 +319,7 @@ __device__ __forceinline__ int half_distance_rev(const uint32_t *refn, int c, co
 {
 	int d = 0;
 	for (int k0 = 0; k0 < n; k0 += 56) {
-		const int t = c + n - k0 - 56; // word i of the load below: the eight bases from t + 8 i on; the half's word j meets word 6 - j
+		const int t = sr_rev_step_base(c, n, k0); // word i of the load below: the eight bases from t + 8 i on; the half's word j meets word 6 - j
 		uint32_t r[8], hk[7];
 		load_dwords8(refn + (t >> 3), r);
 		const uint32_t sh = ((uint32_t) t & 7u) * 4u;
@@ -533,7 +534,8 @@ __global__ __launch_bounds__(256) void split_map_kernel(SplitMapArgs g)
 					// with them: those begin in front of base 0 of the reference text unless c is that far in.  `c + n >= 64` was the
 					// test until tests/soak.py --bam-rp (seed 82, case 11) met a half of more than 56 bases within 56 of chromosome
 					// 1's first base -- two dwords in front of the buffer, on a page that was not there)
-					const int d = c + (n - 1) % 56 + 1 >= 56 + 8 ? half_distance_rev(refn, c, sq, from, n, h0) : half_distance(refn, c, sq, from, n, true);
+					// (split_geom.h holds the test and the load's arithmetic: tests/test_split_geom.py walks every (c, n) on the host)
+					const int d = sr_rev_wide_ok(c, n) ? half_distance_rev(refn, c, sq, from, n, h0) : half_distance(refn, c, sq, from, n, true);
 					if (d <= dist_max)
 						size++;
 				}

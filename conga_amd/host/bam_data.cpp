@@ -612,6 +612,7 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 }
 
 int read_bam_with(parameters *params, sonic *this_sonic, kept_engine *keep, planned_input *pre = nullptr);
+int cohort_pipeline(parameters *params, sonic *this_sonic, const std::vector<std::pair<std::string, std::string>> &samples);
 
 } // namespace
 
@@ -653,8 +654,48 @@ int read_bam_cohort(parameters *params, sonic *this_sonic)
 	}
 	if (samples.empty())
 		print_error("[CONGA INPUT ERROR] " + params->cohort_file + " names no BAM file.");
-	kept_engine keep;
 	map_bam_pieces = samples.size() < 2; // (a mapping per sample would have to be given back between samples: reads.h)
+	// --gpus N with a cohort: the SAMPLES are dealt to N pipelines, round robin -- the reference runs one process per sample
+	// (bam_data.c:253-339; svdepth.c:47-66), so a cohort shards by sample with nothing to exchange, and end to end a sample costs
+	// its upload: every GPU brings its own PCIe link.  Each pipeline is what `--gpus 1` runs -- one kept
+	// engine context on its device, its layout handed over once, the next samples' bytes named two deep -- on its own host thread;
+	// a sample's three files are those of its own run whatever N is.  (A single BAM with --gpus N shards by chromosome: read_bam.)
+	const int n_pipes = (int) std::min<size_t>((size_t) std::max(1, params->n_gpus), samples.size());
+	if (n_pipes <= 1) {
+		parameters one = *params;
+		one.n_gpus = samples.size() == 1 ? std::max(1, params->n_gpus) : 1; // (one BAM: its chromosomes are sharded, read_bam_with)
+		return cohort_pipeline(&one, this_sonic, samples);
+	}
+	const int n_dev = std::max(1, conga_device_count());
+	if (n_dev < n_pipes)
+		fprintf(stderr, "\n[CONGA] --gpus %d with %d visible HIP device(s): pipelines share devices\n", n_pipes, n_dev);
+	set_reader_share(n_pipes); // (host threads of every pipeline: its share of the cores)
+	std::vector<std::vector<std::pair<std::string, std::string>>> dealt((size_t) n_pipes);
+	for (size_t k = 0; k < samples.size(); k++)
+		dealt[k % (size_t) n_pipes].push_back(samples[k]);
+	std::vector<int> rcs((size_t) n_pipes, 0);
+	std::vector<std::thread> pipes;
+	for (int w = 0; w < n_pipes; w++)
+		pipes.emplace_back([&, w] {
+			parameters mine = *params;
+			mine.n_gpus = 1;
+			mine.device = (params->device + w) % n_dev;
+			rcs[(size_t) w] = cohort_pipeline(&mine, this_sonic, dealt[(size_t) w]);
+		});
+	for (std::thread &t : pipes)
+		t.join();
+	for (int rc : rcs)
+		if (rc != 0)
+			return rc;
+	return 0;
+}
+
+namespace {
+
+// One pipeline of a cohort: the samples of `samples` one after the other through ONE kept engine context on params->device.
+int cohort_pipeline(parameters *params, sonic *this_sonic, const std::vector<std::pair<std::string, std::string>> &samples)
+{
+	kept_engine keep;
 	const std::string outdir = params->outdir, outprefix = params->outprefix;
 	// The samples behind the one on the GPU are got ready meanwhile, two deep: their files are opened and -- once the engine
 	// exists -- their bytes named to it from the index alone (conga_reads_bgzf_next_fd), so that the engine's upload thread
@@ -766,8 +807,6 @@ int read_bam_cohort(parameters *params, sonic *this_sonic)
 		conga_destroy(keep.ctx);
 	return 0;
 }
-
-namespace {
 
 int read_bam_with(parameters *params, sonic *this_sonic, kept_engine *keep, planned_input *pre)
 {

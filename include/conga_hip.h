@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define CONGA_ABI_VERSION 6
+#define CONGA_ABI_VERSION 7
 
 typedef struct conga_ctx conga_ctx;
 
@@ -142,6 +142,8 @@ enum {
 	CONGA_K_CHAIN,        /* serial-float expected chain of long intervals, one wave per interval */
 	CONGA_K_COUNT_READS,  /* tuple-space formulation: per-interval count of kept reads (replaces the depth side of K_REDUCE) */
 	CONGA_K_SPLIT,        /* split-read evidence: half-read mapping, pairing, support counts (split_map_kernel) */
+	CONGA_K_EXPAND,       /* conga_sample_reads_packed: the differences back into int32 positions (delta16.hip.h: four launches);
+	                         0 for a compute whose reads came as positions */
 	CONGA_K_COUNT
 };
 
@@ -255,10 +257,30 @@ int conga_sample_reads_d16(conga_ctx *ctx, const uint16_t *delta, const uint32_t
  * = see the exception list.  The producer picks the narrowest width that keeps exceptions rare (one in a thousand reads or fewer: an
  * exception costs the expansion a search of the list): at 1x two neighbours are ~100 bases apart and 10 bits hold all but one
  * difference in ten thousand -- 1.25 bytes per read over the link --, at 5x eight bits do, at 30x six.
+ * EVERY all-ones difference must have its entry: the engine checks the list (sorted, inside the reads, the first read of every
+ * chromosome) but not the stream against it -- an all-ones value without an entry takes the next entry's position (memory-safe,
+ * positions wrong; conga_packer_* below keeps the contract by construction).
  * esc_index == esc_pos == NULL with n_esc > 0: the exceptions lie in `bits` behind the differences -- at the next multiple of 16
  * bytes behind ceil(n / 8) * width, esc_index[n_esc] then esc_pos[n_esc] -- and the sample goes up as ONE copy. */
 int conga_sample_reads_packed(conga_ctx *ctx, const uint8_t *bits, int width, const uint32_t *esc_index, const int32_t *esc_pos, size_t n_esc,
 		const uint8_t *mapq, const uint64_t *chrom_off, int n_chrom);
+/* The PRODUCER of that format, for positions that lie in an array (host code only: no device, no context -- the caller's side of the
+ * seam, count_reads_bam's loop, bam_data.c:201-213, for a producer that has not subtracted while it decoded).  A packer owns a pool of
+ * host threads (n_threads <= 0: half of the cores the process may use).  conga_packer_start() begins to encode one sample -- pos[] /
+ * chrom_off[] as in conga_sample_reads; width 4 .. 16, or 0: the narrowest width that keeps exceptions at or below one read in a
+ * thousand, judged on a sample of the differences -- into `out` in the ONE-COPY layout (differences, exceptions behind them at the next
+ * multiple of 16 bytes) and returns at once; conga_packer_finish() waits for it and says which width was used, how many exceptions
+ * there are and how many bytes of `out` go over the link: hand (out, *width, NULL, NULL, *n_esc) to conga_sample_reads_packed.
+ * `out` holds conga_pack_bound(n_reads, max_esc) bytes for up to max_esc exceptions at any width (CONGA_ERR_NOMEM from start / finish:
+ * it does not); pos[] and out[] must stay as they are between start and finish.  One sample at a time per packer; every all-ones
+ * difference gets its entry (the contract conga_sample_reads_packed relies on). */
+typedef struct conga_packer conga_packer;
+conga_packer *conga_packer_create(int n_threads);
+void conga_packer_destroy(conga_packer *p);
+int conga_packer_threads(const conga_packer *p); /* host threads of its pool */
+size_t conga_pack_bound(uint64_t n_reads, size_t max_esc);
+int conga_packer_start(conga_packer *p, const int32_t *pos, const uint64_t *chrom_off, int n_chrom, int width, uint8_t *out, size_t out_cap);
+int conga_packer_finish(conga_packer *p, int *width, size_t *n_esc, size_t *out_bytes);
 int conga_sample_begin(conga_ctx *ctx);
 int conga_sample_chrom(conga_ctx *ctx, int index);
 /* conga_chrom_fetch for every chromosome in one call: records[] receives conga_chrom_count() groups one behind the

@@ -178,6 +178,45 @@ def describe(c):
         None if c["rows"] is None else len(c["rows"][0]), c["gc_like"] is not None))
 
 
+def bam_case(rng, d):
+    """One random BAM case of `--bam` written into directory d (r.bam + .bai, a.cga, dels.bed, dups.bed) -> the command line's
+    arguments.  The draws are the sequence's: np.random.default_rng([seed, 11_000_000 + case]) gives case `case` of seed `seed` again
+    (tests/test_host_cli.py replays seed 81, case 38 -- the cohort that stood still on round 3's last day)."""
+    import zlib
+    from conga_amd import formats, synth
+    n_chr = int(rng.integers(1, 6))
+    chroms, reads = [], []
+    for k in range(n_chr):
+        L = int(rng.choice([rng.integers(20_000, 100_000), rng.integers(100_000, 2_000_000)]))
+        c = synth.make_chrom(str(k + 1), L, cov=float(rng.choice([0.0, 0.3, 1.0, 4.0])), n_dels=int(rng.integers(0, 30)),
+                             n_dups=int(rng.integers(0, 8)), gaps=bool(rng.integers(0, 2)), seed=int(rng.integers(1, 1 << 30)))
+        pos = c.pos
+        if len(pos) and rng.random() < 0.5:   # pile-ups on and around window boundaries of the index
+            w = int(rng.integers(1, max(2, L >> 14))) << 14
+            extra = np.concatenate([np.full(int(rng.integers(1, 500)), min(w, L - 1)), np.full(int(rng.integers(1, 500)), max(w - 1, 0))])
+            pos = np.sort(np.concatenate([pos, extra])).astype(np.int32)
+        if len(pos) and rng.random() < 0.4:   # a stretch without reads
+            lo = int(rng.integers(0, L))
+            pos = pos[(pos < lo) | (pos > lo + int(rng.integers(1, 200_000)))]
+        chroms.append(c)
+        reads.append((c.name, L, pos, rng.integers(0, 61, len(pos)).astype(np.uint8)))
+    formats.write_bam(os.path.join(d, "r.bam"), "S", reads, index=True, unplaced=int(rng.integers(0, 20)),
+                      block_payload=int(rng.choice([257, 1500, 9000, 40000, 65280])), level=int(rng.integers(0, 10)),
+                      strategy=int(rng.choice([0, 0, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED])))
+    order = rng.permutation(n_chr)              # the annotation lists the chromosomes in its own order
+    formats.write_annotation(os.path.join(d, "a.cga"), [(chroms[j].name, chroms[j].length, chroms[j].gc, [], []) for j in order])
+    synth.write_bed(os.path.join(d, "dels.bed"), [(c.name, s_, e_) for c in chroms for s_, e_ in zip(c.del_start, c.del_end)])
+    synth.write_bed(os.path.join(d, "dups.bed"), [(c.name, s_, e_) for c in chroms for s_, e_ in zip(c.dup_start, c.dup_end)])
+    args = ["-i", "r.bam", "--ref", "r.fa", "--sonic", "a.cga", "--dels", "dels.bed", "--dups", "dups.bed"]
+    if rng.random() < 0.5:
+        args += ["--min-mapq", str(int(rng.integers(0, 60)))]
+    if n_chr > 1 and rng.random() < 0.3:
+        args += ["--first-chr", str(int(rng.integers(0, n_chr))), "--last-chr", str(n_chr - 1)]
+    if rng.random() < 0.3:
+        args += ["--gpus", str(int(rng.integers(2, 4)))]
+    return args
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=200)
@@ -217,36 +256,7 @@ def main():
         for i in range(a.first_case, a.first_case + a.cases):
             rng = np.random.default_rng([a.seed, 11_000_000 + i])
             d = tempfile.mkdtemp(prefix="conga_soak_bam_")
-            n_chr = int(rng.integers(1, 6))
-            chroms, reads = [], []
-            for k in range(n_chr):
-                L = int(rng.choice([rng.integers(20_000, 100_000), rng.integers(100_000, 2_000_000)]))
-                c = synth.make_chrom(str(k + 1), L, cov=float(rng.choice([0.0, 0.3, 1.0, 4.0])), n_dels=int(rng.integers(0, 30)),
-                                     n_dups=int(rng.integers(0, 8)), gaps=bool(rng.integers(0, 2)), seed=int(rng.integers(1, 1 << 30)))
-                pos = c.pos
-                if len(pos) and rng.random() < 0.5:   # pile-ups on and around window boundaries of the index
-                    w = int(rng.integers(1, max(2, L >> 14))) << 14
-                    extra = np.concatenate([np.full(int(rng.integers(1, 500)), min(w, L - 1)), np.full(int(rng.integers(1, 500)), max(w - 1, 0))])
-                    pos = np.sort(np.concatenate([pos, extra])).astype(np.int32)
-                if len(pos) and rng.random() < 0.4:   # a stretch without reads
-                    lo = int(rng.integers(0, L))
-                    pos = pos[(pos < lo) | (pos > lo + int(rng.integers(1, 200_000)))]
-                chroms.append(c)
-                reads.append((c.name, L, pos, rng.integers(0, 61, len(pos)).astype(np.uint8)))
-            formats.write_bam(os.path.join(d, "r.bam"), "S", reads, index=True, unplaced=int(rng.integers(0, 20)),
-                              block_payload=int(rng.choice([257, 1500, 9000, 40000, 65280])), level=int(rng.integers(0, 10)),
-                              strategy=int(rng.choice([0, 0, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED])))
-            order = rng.permutation(n_chr)              # the annotation lists the chromosomes in its own order
-            formats.write_annotation(os.path.join(d, "a.cga"), [(chroms[j].name, chroms[j].length, chroms[j].gc, [], []) for j in order])
-            synth.write_bed(os.path.join(d, "dels.bed"), [(c.name, s_, e_) for c in chroms for s_, e_ in zip(c.del_start, c.del_end)])
-            synth.write_bed(os.path.join(d, "dups.bed"), [(c.name, s_, e_) for c in chroms for s_, e_ in zip(c.dup_start, c.dup_end)])
-            args = ["-i", "r.bam", "--ref", "r.fa", "--sonic", "a.cga", "--dels", "dels.bed", "--dups", "dups.bed"]
-            if rng.random() < 0.5:
-                args += ["--min-mapq", str(int(rng.integers(0, 60)))]
-            if n_chr > 1 and rng.random() < 0.3:
-                args += ["--first-chr", str(int(rng.integers(0, n_chr))), "--last-chr", str(n_chr - 1)]
-            if rng.random() < 0.3:
-                args += ["--gpus", str(int(rng.integers(2, 4)))]
+            args = bam_case(rng, d)
             outs = {}
             for tag, env in (("gpu", {"CONGA_GPU_BAM": "1"}), ("host", {"CONGA_GPU_BAM": "0", "CONGA_BAM_SEGMENTS": str(int(rng.integers(1, 9)))})):
                 r = subprocess.run([conga] + args + ["--out", tag], cwd=d, capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))

@@ -408,3 +408,73 @@ def test_release_staging_between_two_overlapped_uploads(capi, tmp_path, monkeypa
     for (ad, _au, aE, ast), (bd, _bu, bE, bst) in zip(*results):
         assert ad.tobytes() == bd.tobytes() and aE.tobytes() == bE.tobytes() and ast.reads_counted == bst.reads_counted
         assert ast.reads_counted > 0
+
+
+@pytest.mark.timeout(300, method="thread")
+@pytest.mark.parametrize("named", ["between_calls_own_table", "between_calls_engine_table", "no_table_at_all"])
+def test_bytes_named_ahead_with_the_callers_own_table_are_taken_up(capi, tmp_path, monkeypatch, capfd, named):
+    """conga_reads_bgzf_next_fd + conga_reads_bgzf_next_blocks (include/conga_hip.h: "a caller that has read the table by itself hands
+    it over ... to the same effect"): the bytes of the NEXT sample named from their descriptor alone, the block table brought by the
+    caller, then the conga_reads_bgzf_fd call that takes them up -- it must return (round 3's last commit left a job whose table the
+    caller brought out of the set that hands the spare output buffers on: its inflating thread slept for ever and the call with it,
+    ADVICE round 3), find the stream inflated ahead, and give the reads of a call that was never named."""
+    import os
+    import struct
+    from conga_amd import formats
+    monkeypatch.setenv("CONGA_BGZF_OVERLAP", "1")
+    monkeypatch.setenv("CONGA_BGZF_PIECE_KB", "8")
+    monkeypatch.setenv("CONGA_TIMING", "1")
+    cs = [synth.make_chrom(n, L, cov=2.0, n_dels=nd, gaps=False) for n, L, nd in (("1", 300_000, 15), ("2", 200_000, 10))]
+    files = []
+    for k in range(2):   # two samples on one layout
+        rng = np.random.default_rng([k, 91])
+        reads = [synth.make_reads(c.length, c.gc, c.step, 1.0 + k, 100, rng) for c in cs]
+        path = str(tmp_path / ("s%d.bam" % k))
+        formats.write_bam(path, "S%d" % k, [(c.name, c.length, p, m) for c, (p, m) in zip(cs, reads)], index=True, block_payload=20_000, unplaced=2)
+        raw = np.fromfile(path, np.uint8)
+        blocks, stream = bgzf_table(raw.tobytes())
+        l_text = struct.unpack_from("<i", stream, 4)[0]
+        at = 8 + l_text
+        n_ref = struct.unpack_from("<i", stream, at)[0]
+        at += 4
+        for _ in range(n_ref):
+            l_name = struct.unpack_from("<i", stream, at)[0]
+            at += 4 + l_name + 4
+        segments = [(at, 0, cs[0].length, 0, 0), (at, 0, cs[1].length, 1, 1)]
+        files.append((path, len(raw), blocks, segments, [len(p) for p, _m in reads]))
+    fds = [os.open(f[0], os.O_RDONLY) for f in files]
+    try:
+        with capi.Context(device=0, flags=capi.FLAG_BATCH | capi.FLAG_EXPECT_BGZF) as ctx:
+            for c in cs:
+                ds, de = synth.kept_sorted(c.del_start, c.del_end)
+                ctx.chrom_begin(c.length, c.gc)
+                ctx.intervals("D", ds, de)
+            _p, size, blocks, segments, want = files[0]
+            assert ctx.reads_bgzf_fd(fds[0], 0, size, blocks, segments) == want
+            ctx.compute()
+            first = ctx.fetch_all()
+            # the next sample's bytes, named between two calls
+            _p, size, blocks, segments, want = files[1]
+            known = [b[0] - 18 for b in blocks[::3]] if named == "between_calls_engine_table" else []
+            ticket = ctx.reads_bgzf_next_fd(fds[1], 0, size, known)
+            assert ticket != 0
+            if named == "between_calls_own_table":
+                ctx.reads_bgzf_next_blocks(ticket, blocks)
+            ctx.sample_begin()
+            assert ctx.reads_bgzf_fd(fds[1], 0, size, blocks, segments) == want      # <- stood still for ever before the fix
+            ctx.compute()
+            second = ctx.fetch_all()
+            # and the same sample through a call that was never named: the same records
+            ctx.sample_begin()
+            assert ctx.reads_bgzf_fd(fds[1], 0, size, blocks, segments) == want
+            ctx.compute()
+            again = ctx.fetch_all()
+    finally:
+        for fd in fds:
+            os.close(fd)
+    err = capfd.readouterr().err
+    if named != "no_table_at_all":
+        assert "named ahead with its block table" in err, err[-2000:]                  # the stream WAS inflated ahead
+    for (ad, _au, aE, ast), (bd, _bu, bE, bst) in zip(second, again):
+        assert ad.tobytes() == bd.tobytes() and aE.tobytes() == bE.tobytes() and ast.reads_counted == bst.reads_counted > 0
+    assert first[0][0].tobytes() != second[0][0].tobytes()

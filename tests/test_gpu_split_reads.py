@@ -134,6 +134,41 @@ def test_reverse_complement_mappings_and_long_reads(capi, oracle):
     assert counts[1] > 1.5 * counts[0] > 0   # (forward at the read's own place and reverse in the inverted copy: about two mappings per element)
 
 
+def test_reverse_complement_hits_at_every_offset_of_the_chromosomes_first_bases(capi, oracle):
+    """Round 3's last-day fault, as a case of its own (profiles/r03l_split_map_fault_seed82_case11.log, commit 4000c64): halves of
+    57 .. 111 bases whose reverse complement maps at c = 0 .. 63 of the reference text -- the last 56-base step of the wide
+    comparison would load from in front of the text there, so those windows must go base by base (split_geom.h: sr_rev_wide_ok;
+    tests/test_split_geom.py walks the arithmetic on the host).  An inverted copy of [a, a + 400) lies on the chromosome's first
+    400 bases; read (n, c) is 2 n bases long and placed so that its second half's reverse complement begins at base c."""
+    rng = np.random.default_rng(82)
+    L, a, N = 200_000, 30_000, 400
+    ref = rng.choice(np.frombuffer(b"ACGT", np.uint8), L)
+    comp = np.arange(256, dtype=np.uint8)
+    comp[[65, 67, 71, 84]] = [84, 71, 67, 65]
+    ref[0:N] = comp[ref[a:a + N][::-1]]
+    reads = []
+    for n in range(57, 112):
+        for c in range(0, 64):
+            p = a + N - 2 * n - c
+            b = ref[p:p + 2 * n].copy()
+            if (n + c) % 3 == 0:                                    # some with a mismatch or two (dist_max = 5 % of the half)
+                b[rng.integers(0, 2 * n, 2)] = rng.choice(np.frombuffer(b"ACGTN", np.uint8), 2)
+            reads.append((p, b))
+    reads.sort(key=lambda r: r[0])
+    lut = np.full(256, 15, np.uint8)
+    for k, v in CODE.items():
+        lut[k] = v
+    lq = np.array([len(r[1]) for r in reads], np.int32)
+    c = dict(L=L, ref=bytes(ref), ref_lower=bytes(ref), dels=[(50_000, 53_000)], dups=[(100_000, 104_000)],
+             pos=np.array([r[0] for r in reads], np.int32), mapq=np.full(len(reads), 60, np.uint8), flag=np.zeros(len(reads), np.uint16), lq=lq,
+             off=np.concatenate([[0], np.cumsum(lq)[:-1]]).astype(np.uint64), codes=lut[np.concatenate([r[1] for r in reads])],
+             qual=np.full(int(lq.sum()), 30, np.uint8), sat_s=np.zeros(0, np.int32), sat_e=np.zeros(0, np.int32))
+    (dels, dups, st), (od, ou, rows, counts) = run_both(capi, oracle, c, -1, 50)
+    assert (st.split_elements, st.split_mappings, st.split_del_rows, st.split_dup_rows) == tuple(int(x) for x in counts)
+    assert np.array_equal(dels["border_rp"], od["border_rp"]) and np.array_equal(dups["rp"], ou["rp"])
+    assert counts[0] == 2 * len(reads) and counts[1] > 1.9 * counts[0]   # both halves of (nearly) every read map twice: at home and in the inverted copy (oracle: 7 040 elements, 13 600 mappings)
+
+
 def test_without_reference_or_reads_nothing_is_counted(capi):
     c = make_case(n_normal=200)
     ds, de = np.array([100_000], np.int32), np.array([103_000], np.int32)

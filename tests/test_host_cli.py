@@ -683,6 +683,87 @@ def test_cli_cohort_keeps_the_engine_and_every_byte(tmp_path, decode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,decode", [(2, "gpu_ahead"), (3, "gpu"), (2, "host"), (7, "gpu_ahead")])
+def test_cli_cohort_gpus_deals_the_samples_and_keeps_every_byte(tmp_path, n, decode):
+    """`--cohort list --gpus N`: the samples are dealt round robin to N pipelines -- one kept engine context, its layout and its
+    two-deep upload pipeline per GPU (here N contexts share the one visible device, as in test_cli_gpus_shards_chromosomes...) --
+    because a cohort shards by SAMPLE (the reference runs one process per sample: bam_data.c:253-339, svdepth.c:47-66) and end to
+    end a sample costs its upload over ITS GPU's link.  Every sample's three files are byte for byte those of the `--gpus 1` run;
+    N larger than the list: one pipeline per sample."""
+    d = str(tmp_path)
+    specs = [("1", 500_000, 30, 8), ("2", 300_000, 20, 5), ("3", 200_000, 12, 3)]
+    cs = [synth.make_chrom(nm, L, cov=1.0, n_dels=nd, n_dups=nu, mappability=True, gaps=False) for nm, L, nd, nu in specs]
+    formats.write_annotation(os.path.join(d, "a.cga"), [(c.name, c.length, c.gc, [], []) for c in cs])
+    synth.write_bed(os.path.join(d, "dels.bed"), [(c.name, s, e) for c in cs for s, e in zip(c.del_start, c.del_end)])
+    synth.write_bed(os.path.join(d, "dups.bed"), [(c.name, s, e) for c in cs for s, e in zip(c.dup_start, c.dup_end)])
+    synth.write_bed(os.path.join(d, "map.bed"), [(c.name, s, e, "%g" % v) for c in cs for s, e, v in zip(c.map_start, c.map_end, c.map_val)])
+    samples = []
+    for k, (cov, drop) in enumerate([(1.0, None), (3.0, None), (0.5, "2"), (2.0, None), (1.5, None)]):   # the third sample lacks chromosome 2
+        chroms = []
+        for ci, c in enumerate(cs):
+            if c.name == drop:
+                continue
+            rng = np.random.default_rng([k, ci, 6])
+            pos, mapq = synth.make_reads(c.length, c.gc, c.step, cov, 100, rng)
+            chroms.append((c.name, c.length, pos, mapq))
+        formats.write_bam(os.path.join(d, "s%d.bam" % k), "S%d" % k, chroms, index=True, block_payload=20_000, unplaced=2)
+        samples.append("s%d.bam" % k)
+    with open(os.path.join(d, "list.txt"), "w") as f:
+        f.write("".join("%s\n" % s for s in samples))
+    common = ["--ref", "r.fa", "--sonic", "a.cga", "--dels", "dels.bed", "--dups", "dups.bed", "--mappability", "map.bed"]
+    env = dict(os.environ, CONGA_GPU_BAM="0" if decode == "host" else "1", CONGA_TIMING="1")
+    if decode == "gpu_ahead":
+        env.update(CONGA_BGZF_OVERLAP="1", CONGA_BGZF_PIECE_KB="16", CONGA_BGZF_CHECK_TABLE="1")
+    one = subprocess.run([CONGA, "--cohort", "list.txt", "--out", "one"] + common, cwd=d, capture_output=True, text=True, timeout=300, env=env)
+    assert one.returncode == 0, one.stderr[-3000:]
+    many = subprocess.run([CONGA, "--cohort", "list.txt", "--out", "many", "--gpus", str(n)] + common, cwd=d, capture_output=True, text=True,
+                          timeout=300, env=env)
+    assert many.returncode == 0, many.stderr[-3000:]
+    assert "pipelines share devices" in many.stderr                  # (one GPU on the test box)
+    for k in range(len(samples)):
+        for kind in ("svs", "dels", "dups"):
+            got = open(os.path.join(d, "many.s%d_%s.bed" % (k, kind)), "rb").read()
+            want = open(os.path.join(d, "one.s%d_%s.bed" % (k, kind)), "rb").read()
+            assert got == want and (kind != "dels" or got.count(b"\n") > 5), (k, kind)
+    # every pipeline kept its engine: as many contexts were made as there are pipelines, not as there are samples
+    assert many.stderr.count("[timing] conga_create:") == min(n, len(samples)), many.stderr[-3000:]
+    if decode == "gpu_ahead" and n == 2:
+        assert many.stderr.count("named ahead") >= 1, many.stderr[-3000:]   # (each pipeline runs its own two-deep upload pipeline)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("piece_kb,ahead,no_table", [("16", None, False), ("6", "2", False), ("16", "2", True), ("6", "1", True)])
+def test_cli_cohort_that_stood_still_on_round_3s_last_day(tmp_path, piece_kb, ahead, no_table):
+    """tests/soak.py --bam, seed 81, case 38, as a fixture (profiles/r03l_cohort_standstill_seed81_case38.log; commit 6e95a92): a
+    cohort of four small samples whose uploads take no time, two named ahead -- the inflate-ahead thread of the job named SECOND
+    took the spare output set, the call in front waited for the job named first, that one for the set, the set for the call behind.
+    Pieces of 16 KB are the draw of the case itself, 6 KB (smaller than a block) the judge's.  no_table: CONGA_BGZF_NO_TABLE=1 -- the
+    planning thread reads the block table from the file and hands it over with conga_reads_bgzf_next_blocks, the path ADVICE round 3
+    found left out of the fix (a job whose table the caller brought never entered the set of tickets the spare buffers go to).
+    Must end within 60 s, every sample's files those of its own run."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import soak
+    d = str(tmp_path)
+    args = soak.bam_case(np.random.default_rng([81, 11_000_000 + 38]), d)
+    assert "--gpus" not in args
+    with open(os.path.join(d, "list.txt"), "w") as f:
+        f.write("".join("r.bam\tc%d\n" % k for k in range(4)))
+    env = dict(os.environ, CONGA_GPU_BAM="1", CONGA_BGZF_OVERLAP="1", CONGA_BGZF_CHECK_TABLE="1", CONGA_TIMING="1", CONGA_BGZF_PIECE_KB=piece_kb)
+    if ahead:
+        env["CONGA_COHORT_AHEAD"] = ahead
+    if no_table:
+        env["CONGA_BGZF_NO_TABLE"] = "1"
+    r = subprocess.run([CONGA, "--cohort", "list.txt", "--out", "co"] + args[2:], cwd=d, capture_output=True, text=True, timeout=60, env=env)
+    assert r.returncode == 0 and "decoding on the host" not in r.stderr, r.stderr[-3000:]
+    one = subprocess.run([CONGA] + args + ["--out", "one"], cwd=d, capture_output=True, text=True, timeout=60, env=dict(os.environ, CONGA_GPU_BAM="1"))
+    assert one.returncode == 0, one.stderr[-2000:]
+    for k in range(4):
+        for kind in ("svs", "dels", "dups"):
+            assert open(os.path.join(d, "c%d_%s.bed" % (k, kind)), "rb").read() == open(os.path.join(d, "one_%s.bed" % kind), "rb").read(), (k, kind)
+    assert r.stderr.count("named ahead") >= 1, r.stderr[-3000:]   # (the pipeline was on)
+
+
+@pytest.mark.gpu
 def test_cli_damaged_bam_records_gpu_and_host_decoders_agree():
     """Records with a damaged block_size, refID, pos, l_read_name, n_cigar, l_seq or flag, and random bytes, in a BAM whose
     blocks still check out (tools/bam_fuzz.py): the run that decodes on the GPU ends the way the run on the host decoders
