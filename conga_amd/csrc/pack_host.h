@@ -13,7 +13,11 @@
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include <algorithm>
 #include <atomic>
@@ -74,6 +78,55 @@ template <int W> inline void encode_groups(const int32_t *pos, uint64_t i0, uint
 	}
 }
 
+#if defined(__x86_64__)
+// The same with AVX2 + BMI2 (every x86 host an MI355X sits in has both; taken when the CPU says so): eight differences in one
+// subtract, the clamp to all-ones a `min`, the exceptions a compare + movemask that is zero for all but one group in a few
+// hundred, and the bits squeezed together by two `pext` -- a dozen instructions per eight reads where the scalar loop has sixty.
+// What is left is the read of the positions themselves: 4 bytes per read from host memory.
+template <int W> __attribute__((target("avx2,bmi2"))) inline void encode_groups_avx2(const int32_t *pos, uint64_t i0, uint64_t i1, uint8_t *out, std::vector<Exc> &exc)
+{
+	constexpr uint32_t kTop = (1u << W) - 1u;
+	constexpr uint64_t kMask = (uint64_t) kTop * 0x0001000100010001ull;
+	const __m256i top = _mm256_set1_epi32((int) kTop);
+	for (uint64_t i = i0; i < i1; i += 8) {
+		const __m256i cur = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(pos + i));
+		const __m256i prev = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(pos + i - 1));
+		const __m256i v = _mm256_min_epu32(_mm256_sub_epi32(cur, prev), top); // (a position in front of its predecessor: huge, clamped)
+		const int esc = _mm256_movemask_ps(_mm256_castsi256_ps(_mm256_cmpeq_epi32(v, top)));
+		if (esc)
+			for (int k = 0; k < 8; k++)
+				if (esc >> k & 1)
+					exc.push_back(Exc{(uint32_t) (i + (uint64_t) k), pos[i + (uint64_t) k]});
+		const __m256i p16 = _mm256_packus_epi32(v, v); // 16 bits each: v0..v3 in the low lane's first quadword, v4..v7 in the high lane's
+		const uint64_t lo = _pext_u64((uint64_t) _mm256_extract_epi64(p16, 0), kMask), hi = _pext_u64((uint64_t) _mm256_extract_epi64(p16, 2), kMask);
+		uint64_t w[2];
+		if (W == 16) {
+			w[0] = lo;
+			w[1] = hi;
+		} else {
+			w[0] = lo | hi << (4 * W);
+			w[1] = hi >> (64 - 4 * W);
+		}
+		memcpy(out + (i >> 3) * W, w, W);
+	}
+}
+
+inline bool have_avx2_bmi2()
+{
+	static const bool yes = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && getenv("CONGA_PACK_SCALAR") == nullptr; // (measurement switch)
+	return yes;
+}
+#endif
+
+template <int W> inline void encode_whole_groups(const int32_t *pos, uint64_t i0, uint64_t i1, uint8_t *out, std::vector<Exc> &exc)
+{
+#if defined(__x86_64__)
+	if (have_avx2_bmi2())
+		return encode_groups_avx2<W>(pos, i0, i1, out, exc);
+#endif
+	encode_groups<W>(pos, i0, i1, out, exc);
+}
+
 // the group that starts at i (a multiple of 8) read by read: chromosome borders among its reads (`forced`, ascending, consumed
 // through *f), the sample's first read, the sample's end (`n`) inside it
 template <int W> inline void encode_group_slow(const int32_t *pos, uint64_t i, uint64_t n, const uint64_t *forced, size_t n_forced, size_t *f, uint8_t *out,
@@ -114,13 +167,13 @@ inline void encode_run(const int32_t *pos, uint64_t r0, uint64_t r1, const uint6
 	while (f < n_forced) {
 		const uint64_t g = forced[f] & ~(uint64_t) 7;
 		if (g > cur)
-			encode_groups<W>(pos, cur, g, out, exc);
+			encode_whole_groups<W>(pos, cur, g, out, exc);
 		encode_group_slow<W>(pos, g, r1, forced, n_forced, &f, out, exc);
 		cur = g + 8;
 	}
 	const uint64_t whole_end = r1 & ~(uint64_t) 7;
 	if (whole_end > cur) {
-		encode_groups<W>(pos, cur, whole_end, out, exc);
+		encode_whole_groups<W>(pos, cur, whole_end, out, exc);
 		cur = whole_end;
 	}
 	if (cur < r1)
@@ -184,6 +237,15 @@ inline int choose_width(const int32_t *pos, uint64_t n)
 
 // A pool of threads that encodes one sample at a time.  start() returns at once; finish() waits and puts the exception lists behind
 // the differences (the one-copy layout of conga_sample_reads_packed with esc_index == NULL).
+inline void cpu_relax()
+{
+#if defined(__x86_64__)
+	_mm_pause();
+#else
+	std::this_thread::yield();
+#endif
+}
+
 class Packer {
 public:
 	explicit Packer(int n_threads) : n_threads_(std::max(1, n_threads))
@@ -196,6 +258,7 @@ public:
 		{
 			std::lock_guard<std::mutex> g(mu_);
 			quit_ = true;
+			quit_hint_.store(true, std::memory_order_relaxed);
 		}
 		cv_.notify_all();
 		for (std::thread &t : threads_)
@@ -241,6 +304,7 @@ public:
 			next_.store(0, std::memory_order_relaxed);
 			left_ = n_runs_;
 			generation_++;
+			generation_hint_.store(generation_, std::memory_order_release);
 		}
 		cv_.notify_all();
 		return 0;
@@ -287,6 +351,11 @@ private:
 	{
 		uint64_t seen = 0;
 		for (;;) {
+			// (a caller that packs sample after sample -- a cohort, bench.py's step -- starts the next one within a millisecond: a
+			// thread that goes to sleep at once pays a wake-up, and a core that idled its clock ramp, on every sample.  Look for the
+			// next sample for that long before sleeping.)
+			for (int spin = 0; spin < 20000 && generation_hint_.load(std::memory_order_acquire) == seen && !quit_hint_.load(std::memory_order_relaxed); spin++)
+				cpu_relax();
 			{
 				std::unique_lock<std::mutex> lk(mu_);
 				cv_.wait(lk, [&] { return quit_ || generation_ != seen; });
@@ -322,6 +391,8 @@ private:
 	std::condition_variable cv_, done_cv_;
 	bool quit_ = false, busy_ = false;
 	uint64_t generation_ = 0;
+	std::atomic<uint64_t> generation_hint_{0}; // generation_, readable without the lock (the workers' spin)
+	std::atomic<bool> quit_hint_{false};
 	size_t left_ = 0, n_runs_ = 0;
 	int active_ = 0;
 	std::atomic<size_t> next_{0};
