@@ -113,7 +113,7 @@ template <int W> __attribute__((target("avx2,bmi2"))) inline void encode_groups_
 
 inline bool have_avx2_bmi2()
 {
-	static const bool yes = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && getenv("CONGA_PACK_SCALAR") == nullptr; // (measurement switch)
+	static const bool yes = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && !(getenv("CONGA_DEBUG") && getenv("CONGA_PACK_SCALAR")); // (measurement switch, read once: CONGA_DEBUG=1 CONGA_PACK_SCALAR=1)
 	return yes;
 }
 #endif

@@ -6,6 +6,7 @@
 // `--gpus N` runs N such contexts, one host thread and one HIP device each, over a longest-first partition of the
 // chromosomes; the files are still written by the calling thread in annotation order.
 #include "bam_data.h"
+#include "knobs.h"
 
 #include <algorithm>
 #include <atomic>
@@ -74,8 +75,8 @@ int64_t count_reads_bam(conga_ctx *ctx, read_source *src, int chr_index_bam, int
 		exit(1);
 	}
 	int64_t cnt = 0;
-	const char *gpu_bam = getenv("CONGA_GPU_BAM"); // 0: never, 1: always, unset: when it pays
-	if (gpu_bam == nullptr || atoi(gpu_bam) != 0) {
+	const int gpu_bam = knobs().gpu_bam; // CONGA_GPU_BAM: 0 never, 1 always, -1 (unset): when it pays
+	if (gpu_bam != 0) {
 		// a BAM with an index: its compressed blocks go to the GPU as they are and are inflated and walked there
 		// (conga_reads_bgzf); with split reads the engine then reads the records where they lie in HBM.  Anything that does
 		// not check out falls through to the host decoders below.  A launch lasts at least one block's few milliseconds, so it
@@ -84,7 +85,7 @@ int64_t count_reads_bam(conga_ctx *ctx, read_source *src, int chr_index_bam, int
 		file_piece bytes;
 		std::vector<conga_bgzf_block> blocks;
 		std::vector<conga_bam_segment> segments;
-		const uint64_t min_piece = gpu_bam != nullptr ? 0 : gpu_bam_min_piece();
+		const uint64_t min_piece = gpu_bam >= 0 ? 0 : gpu_bam_min_piece();
 		if (src->device_plan({device_target{chr_index_bam, chrom_len, chrom}}, min_piece, &bytes, &blocks, &segments, &err)) {
 			std::vector<uint64_t> per_chrom((size_t) conga_chrom_count(ctx), 0);
 			const int rc = bytes.data ? conga_reads_bgzf(ctx, bytes.data, bytes.size, blocks.data(), blocks.size(), segments.data(), segments.size(),
@@ -270,8 +271,7 @@ struct planned_input {
 
 bool gpu_decode_wanted(const parameters *params)
 {
-	const char *gpu_bam = getenv("CONGA_GPU_BAM"); // 0: never, 1: always, unset: when it pays
-	return gpu_bam == nullptr || atoi(gpu_bam) != 0;
+	return knobs().gpu_bam != 0; // CONGA_GPU_BAM: 0 never, 1 always, unset: when it pays
 }
 
 // the chromosomes read_bam will work on, in its order (bam_data.c:269-291): (annotation index, BAM target)
@@ -308,7 +308,7 @@ std::unique_ptr<planned_input> plan_input(const parameters *params, const sonic 
 	if (p->targets.empty())
 		return p;
 	const auto t0 = std::chrono::steady_clock::now();
-	const char *gpu_bam = getenv("CONGA_GPU_BAM");
+	const int gpu_bam = knobs().gpu_bam;
 	planned_input *raw = p.get();
 	plan_hooks hooks;
 	bool engine_table = false;
@@ -332,7 +332,7 @@ std::unique_ptr<planned_input> plan_input(const parameters *params, const sonic 
 			return true;
 		};
 	}
-	p->planned = p->src->device_plan(p->targets, gpu_bam != nullptr ? 0 : gpu_bam_min_piece(), &p->bytes, &p->blocks, &p->segments, &err,
+	p->planned = p->src->device_plan(p->targets, gpu_bam >= 0 ? 0 : gpu_bam_min_piece(), &p->bytes, &p->blocks, &p->segments, &err,
 			engine ? &hooks : nullptr);
 	p->ms_plan = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 	if (p->planned && engine && p->ahead_ticket && !engine_table) // (the table was read here: the bytes named above can be inflated ahead with it)
@@ -391,8 +391,7 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 	opts.gc_step = this_sonic->gc_step;
 	opts.flags = CONGA_FLAG_BATCH;
 	{
-		const char *gb = getenv("CONGA_GPU_BAM"); // (the decode may go to the GPU: let the engine get its staging ring meanwhile)
-		if (gb == nullptr || atoi(gb) != 0)
+		if (knobs().gpu_bam != 0) // (the decode may go to the GPU: let the engine get its staging ring meanwhile)
 			opts.flags |= CONGA_FLAG_EXPECT_BGZF;
 		if (keep && keep->expect_cohort)
 			opts.flags |= CONGA_FLAG_EXPECT_COHORT; // (a list of several BAMs: the pipeline's buffers while the first one is on)
@@ -430,7 +429,7 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 
 	std::string err;
 	std::vector<uint64_t> gpu_counts; // reads per chromosome when all of this worker's chromosomes were decoded on the GPU at once
-	const char *gpu_bam = getenv("CONGA_GPU_BAM"); // 0: never, 1: always, unset: when it pays
+	const int gpu_bam = knobs().gpu_bam; // CONGA_GPU_BAM: 0 never, 1 always, -1 (unset): when it pays
 	// readReferenceSeq (common.c:423-463) and the satellite annotation (bam_data.c:96-97,207) for the chromosome begun last
 	// (all of this worker's chromosomes are read side by side the first time one is asked for: a genome's FASTA is 3 GB of text)
 	std::vector<std::string> ref_seqs;
@@ -464,7 +463,7 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 		engine_check(ctx, conga_satellites(ctx, this_sonic->sat_start[job->chr_index].data(),
 				this_sonic->sat_end[job->chr_index].data(), this_sonic->sat_start[job->chr_index].size()), "conga_satellites");
 	};
-	if (!mine.empty() && (gpu_bam == nullptr || atoi(gpu_bam) != 0)) {
+	if (!mine.empty() && gpu_bam != 0) {
 		// All chromosomes of this context in ONE decode on the GPU (conga_reads_bgzf): a low-coverage genome is tens of
 		// thousands of BGZF blocks as a whole, not per chromosome.  The chromosomes are opened (with their intervals and
 		// tracks) first, then the file's stretch goes up as it is.
@@ -480,7 +479,7 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 		for (size_t i = 0; use_pre && i < targets.size(); i++)
 			use_pre = pre->targets[i].tid == targets[i].tid && pre->targets[i].chrom_len == targets[i].chrom_len && pre->targets[i].chrom == targets[i].chrom;
 		const bool planned = use_pre ? pre->planned
-				: src->device_plan(targets, gpu_bam != nullptr ? 0 : gpu_bam_min_piece(), &own_bytes, &own_blocks, &own_segments, &err);
+				: src->device_plan(targets, gpu_bam >= 0 ? 0 : gpu_bam_min_piece(), &own_bytes, &own_blocks, &own_segments, &err);
 		file_piece &bytes = use_pre ? pre->bytes : own_bytes;
 		std::vector<conga_bgzf_block> &blocks = use_pre ? pre->blocks : own_blocks;
 		std::vector<conga_bam_segment> &segments = use_pre ? pre->segments : own_segments;
@@ -501,7 +500,7 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 					attach_intervals(ctx, params, map_bed, job->cs);
 				}
 			gpu_counts.assign(mine.size(), 0);
-			if (getenv("CONGA_TIMING"))
+			if (knobs().timing)
 				fprintf(stderr, "\n[timing] block table + start points %.1f ms, chromosomes opened (GC tracks, intervals, tracks) %.1f ms\n",
 						ms_plan, ms_since(t_open));
 			const int rc = bytes.data ? conga_reads_bgzf(ctx, bytes.data, bytes.size, blocks.data(), blocks.size(), segments.data(), segments.size(),
@@ -607,7 +606,7 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 	if (keep) {
 		keep->ctx = ctx; // (the next sample's)
 		keep->layout_key = layout_key_of(mine);
-	} else if (getenv("CONGA_CLEAN_EXIT") != nullptr)
+	} else if (knobs().clean_exit)
 		conga_destroy(ctx);
 }
 
@@ -740,7 +739,7 @@ int cohort_pipeline(parameters *params, sonic *this_sonic, const std::vector<std
 	// a 5x genome with sequences waits for, never stands still -- 319 ms per sample of a cohort of twelve against 417 with none
 	// named and 370-400 with the next sample inflated ahead as well (profiles/r03j_rp_cohort_ahead.log).
 	const bool with_split_reads = !params->no_sr && params->have_dups;
-	const int ahead_depth = getenv("CONGA_COHORT_AHEAD") ? atoi(getenv("CONGA_COHORT_AHEAD")) : with_split_reads ? 1 : 2;
+	const int ahead_depth = knobs().cohort_ahead >= 0 ? knobs().cohort_ahead : with_split_reads ? 1 : 2;
 	keep.expect_cohort = n_samples >= 3 && ahead_depth >= 1;
 	plans[0] = plan_input(params, this_sonic, samples[0].first);
 	named[0] = true;
@@ -775,12 +774,12 @@ int cohort_pipeline(parameters *params, sonic *this_sonic, const std::vector<std
 		const auto t_join = std::chrono::steady_clock::now();
 		if (k + 1 < n_samples && planners[k + 1].joinable())
 			planners[k + 1].join();
-		if (getenv("CONGA_TIMING") && k + 1 < n_samples)
+		if (knobs().timing && k + 1 < n_samples)
 			fprintf(stderr, "[timing] waited %.1f ms more for the next sample's plan (file opened, bytes up, block table, start points)\n",
 					std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_join).count());
 		if (cleaner.joinable())
 			cleaner.join();
-		if (getenv("CONGA_TIMING")) // (what a further sample costs, read off one process's own clock: bench.py's end-to-end legs)
+		if (knobs().timing) // (what a further sample costs, read off one process's own clock: bench.py's end-to-end legs)
 			fprintf(stderr, "[timing] cohort: sample %zu of %zu is done %.1f ms after the first one began\n", k + 1, n_samples,
 					std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_cohort).count());
 		// (bytes the engine was told about and never asked for -- this sample was decoded on the host after all, or failed --
@@ -796,14 +795,14 @@ int cohort_pipeline(parameters *params, sonic *this_sonic, const std::vector<std
 		if (k + 1 < n_samples) {
 			planned_input *done = mine_now.release();
 			cleaner = std::thread([done] { delete done; });
-		} else if (getenv("CONGA_CLEAN_EXIT") == nullptr)
+		} else if (!knobs().clean_exit)
 			(void) mine_now.release(); // the last one's mapping goes with the process
 	}
 	if (cleaner.joinable())
 		cleaner.join();
 	params->outdir = outdir;
 	params->outprefix = outprefix;
-	if (keep.ctx && getenv("CONGA_CLEAN_EXIT") != nullptr)
+	if (keep.ctx && knobs().clean_exit)
 		conga_destroy(keep.ctx);
 	return 0;
 }
@@ -831,7 +830,7 @@ int read_bam_with(parameters *params, sonic *this_sonic, kept_engine *keep, plan
 	}
 
 	// CONGA_TIMING=1: wall time of the host phases on stderr (where an end-to-end run spends its time)
-	const bool timing = getenv("CONGA_TIMING") != nullptr;
+	const bool timing = knobs().timing;
 	auto now = [] { return std::chrono::steady_clock::now(); };
 	auto ms_since = [&](std::chrono::steady_clock::time_point t) {
 		return std::chrono::duration<double, std::milli>(now() - t).count();

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "inflate_fast.h"
+#include "knobs.h"
 #include "reads.h"
 
 namespace conga_host {
@@ -38,8 +39,8 @@ public:
 	explicit bgzf_reader(int workers = -1)
 	{
 		int n = std::max(2, usable_cpus() / reader_share());
-		if (const char *e = getenv("CONGA_BAM_THREADS"))
-			n = atoi(e) + 1;
+		if (knobs().bam_threads >= 0)
+			n = knobs().bam_threads + 1;
 		n_workers_ = std::max(0, std::min(n - 1, 24)); // one record-walking thread keeps up with ~24 inflating ones
 		if (workers >= 0)
 			n_workers_ = workers;
@@ -167,7 +168,7 @@ private:
 		t.out.resize(t.isize);
 		// the block decoder of inflate_fast.cpp first (CONGA_ZLIB_INFLATE=1: zlib only); whatever it produces has to pass
 		// the block's CRC32, and a block it refuses or gets wrong goes through zlib before anything is reported
-		static const bool zlib_only = getenv("CONGA_ZLIB_INFLATE") != nullptr;
+		const bool zlib_only = knobs().zlib_inflate;
 		if (!zlib_only && inflate_raw(t.cdata.data(), t.cdata.size(), t.out.data(), t.out.size())
 				&& (uint32_t) crc32(crc32(0L, Z_NULL, 0), t.out.data(), (uInt) t.out.size()) == t.crc)
 			return true;
@@ -432,8 +433,8 @@ public:
 			return false;
 		const uint64_t c_lo = lin[w_first] >> 16, c_hi = lin[n_win - 1] >> 16;
 		int want = threads;
-		if (const char *e = getenv("CONGA_BAM_SEGMENTS"))
-			want = atoi(e); // (tests: any number of segments on a small file; 0 / 1: off)
+		if (knobs().bam_segments >= 0)
+			want = knobs().bam_segments; // (tests: any number of segments on a small file; 0 / 1: off)
 		else
 			want = (int) std::min<uint64_t>((uint64_t) std::min(threads, 128), (c_hi - c_lo) / (4u << 20)); // >= 4 MiB of file per segment
 		if (want < 2)
@@ -594,8 +595,8 @@ public:
 		if (c_end && c_end + 65536 + 18 < stop)
 			stop = c_end + 65536 + 18; // enough for the whole block that starts at c_end
 		uint64_t max_piece = 32ull << 30; // (a 5x genome with sequences is 13 GB of file and 27 GB inflated, resident together: 288 GB of HBM)
-		if (const char *e = getenv("CONGA_GPU_BAM_MAX_MB"))
-			max_piece = (uint64_t) (atof(e) * 1048576.0); // (fractions allowed: tests)
+		if (knobs().gpu_bam_max_mb > 0)
+			max_piece = (uint64_t) (knobs().gpu_bam_max_mb * 1048576.0); // (fractions allowed: tests)
 		if (stop - c_lo < min_piece_bytes || stop - c_lo > max_piece)
 			return false; // (nothing has been read yet)
 		// The stretch is mapped and its pages touched on all cores (this runs beside the HIP runtime's start, or beside the
@@ -605,8 +606,8 @@ public:
 		// A process that goes on to other samples (`conga --cohort`) has to give the mapping back -- 75 ms of munmap for 3 GB of
 		// touched pages, on its critical path or as TLB shootdowns under the next sample's threads -- and is better off with
 		// pread: ten genomes in 1.76 s against 1.90-1.99 s (map_bam_pieces, bam_data.cpp).  CONGA_BAM_MMAP=0 / 1 decides for both.
-		const char *mm = getenv("CONGA_BAM_MMAP");
-		if ((mm != nullptr ? atoi(mm) != 0 : map_bam_pieces) ? !bytes->open(path_, c_lo, stop) : !bytes->open_fd(path_, c_lo, stop))
+		const int mm = knobs().bam_mmap;
+		if ((mm >= 0 ? mm != 0 : map_bam_pieces) ? !bytes->open(path_, c_lo, stop) : !bytes->open_fd(path_, c_lo, stop))
 			return false;
 		// known block starts inside the stretch, from the linear indexes of the targets
 		std::vector<uint64_t> starts;
@@ -708,7 +709,7 @@ public:
 		// the table the engine read off the bytes, if it did (a cohort's sample whose bytes were named ahead)
 		std::vector<conga_bgzf_block> given;
 		const bool have_given = hooks && hooks->table && hooks->table(&given) && !given.empty();
-		const bool check_given = have_given && getenv("CONGA_BGZF_CHECK_TABLE") != nullptr; // (tests: both, and they must agree)
+		const bool check_given = have_given && knobs().check_table; // (tests: both, and they must agree)
 		if (have_given && !check_given) {
 			for (const conga_bgzf_block &b : given)
 				all.push_back(found{b, c_lo + b.data_off - 18});
@@ -719,8 +720,8 @@ public:
 			// upload's threads and these share one CPU quota, and a throttled upload is what the GPU then waits for)
 			const int n_threads = std::min(plan_beside_upload.load() ? 6 : 16, std::max(1, usable_cpus() / reader_share()));
 			// (CONGA_BAM_PARALLEL_MIN_KB: the tests walk small files in parts too)
-			const char *min_kb = getenv("CONGA_BAM_PARALLEL_MIN_KB");
-			const size_t min_bytes = min_kb ? (size_t) atoll(min_kb) << 10 : (size_t) 64 << 20;
+			const long min_kb = knobs().parallel_min_kb;
+			const size_t min_bytes = min_kb >= 0 ? (size_t) min_kb << 10 : (size_t) 64 << 20;
 			if (n_threads > 1 && starts.size() >= (size_t) n_threads * 4 && bytes->size > min_bytes) {
 				std::vector<size_t> cut{0}; // piece offsets of the parts' starts
 				for (int k = 1; k < n_threads; k++)
@@ -743,7 +744,7 @@ public:
 				if (walked)
 					for (size_t k = 0; k < parts; k++)
 						all.insert(all.end(), got[k].begin(), got[k].end());
-				if (getenv("CONGA_TIMING"))
+				if (knobs().timing)
 					fprintf(stderr, "[timing] block table: %zu parts walked side by side%s\n", parts, walked ? "" : " (a part did not arrive at the next one's start: walked from the front instead)");
 			}
 		}

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/conga_hip.h"
+#include "knobs.h"
 #include "annotation.h"
 #include "bam_data.h"
 #include "cmdline.h"
@@ -24,13 +25,12 @@ int main(int argc, char **argv)
 	// CONGA_T0_NS (tools/e2e_quick.sh): the caller's clock just before the process was started -- what of a run's wall time lies
 	// in front of main and behind _exit is then visible
 	auto since_t0 = [](const char *what) {
-		const char *t0 = getenv("CONGA_T0_NS");
-		if (!t0 || !getenv("CONGA_TIMING"))
+		if (!knobs().t0_ns || !knobs().timing)
 			return;
 		struct timespec ts;
 		clock_gettime(CLOCK_REALTIME, &ts);
 		const long long now = (long long) ts.tv_sec * 1000000000ll + ts.tv_nsec;
-		fprintf(stderr, "[timing] %s: %.1f ms after the caller's clock\n", what, (double) (now - atoll(t0)) * 1e-6);
+		fprintf(stderr, "[timing] %s: %.1f ms after the caller's clock\n", what, (double) (now - knobs().t0_ns) * 1e-6);
 	};
 	since_t0("main entered");
 	time_t rawtime;
@@ -186,7 +186,7 @@ int main(int argc, char **argv)
 		username[0] = '\0';
 	fprintf(stderr, "\nThank you %s. I found %d DELs and %d DUPs. Hope to see you again...\n", username, total_dels, total_dups);
 	fclose(logFile);
-	if (getenv("CONGA_CLEAN_EXIT") == nullptr) {
+	if (!knobs().clean_exit) {
 		// outputs are written and closed: leave without the HIP runtime's and the contexts' teardown (bam_data.cpp)
 		since_t0("leaving");
 		fflush(nullptr);

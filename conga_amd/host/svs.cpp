@@ -1,4 +1,5 @@
 #include "svs.h"
+#include "knobs.h"
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -180,7 +181,7 @@ void parse_range(const char *b, const char *e, bool with_value, parsed_chunk *ou
 // ranges are merged in file order, so every chromosome's rows keep their order.  Same rows as load_bed_fgets.
 bool load_bed(const std::string &path, bool with_value, bed_index *out)
 {
-	if (getenv("CONGA_BED_LITERAL")) // test hook: force the reference-literal reader
+	if (knobs().bed_literal) // test hook: force the reference-literal reader
 		return load_bed_fgets(path, with_value, out);
 	const int fd = open(path.c_str(), O_RDONLY);
 	if (fd < 0)

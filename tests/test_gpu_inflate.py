@@ -61,6 +61,7 @@ def payloads(rng):
 def test_every_kind_of_stream_matches_zlib(capi, loop, monkeypatch):
     """(wave1: round 2's symbol loop, kept behind CONGA_BGZF_KERNEL for comparison -- it reads the same table entries)"""
     if loop == "wave1":
+        monkeypatch.setenv("CONGA_DEBUG", "1")   # (measurement switches are read only with it: conga_amd/csrc/engine_knobs.h)
         monkeypatch.setenv("CONGA_BGZF_KERNEL", "wave1")
     rng = np.random.default_rng(5)
     streams = []

@@ -308,8 +308,8 @@ def test_cli_bam_decoded_on_the_gpu_matches_the_host_decoders(tmp_path, oracle):
     assert gpu == host and gpu[1].count(b"\n") > 50
     # the overlapped form of the upload (pinned pieces filled by host threads, one inflate launch per 8 pieces), forced onto
     # this small file with 8 KB pieces, and the plain form; the round-1 kernel (one block per lane) once more
-    for tag, env in (("ovl", dict(CONGA_BGZF_OVERLAP="1", CONGA_BGZF_PIECE_KB="8")), ("ovl1", dict(CONGA_BGZF_OVERLAP="1", CONGA_BGZF_PIECE_KB="8", CONGA_BGZF_COPY_THREADS="1")),
-                     ("plain", dict(CONGA_BGZF_OVERLAP="0")), ("lane", dict(CONGA_BGZF_KERNEL="lane")),
+    for tag, env in (("ovl", dict(CONGA_BGZF_OVERLAP="1", CONGA_BGZF_PIECE_KB="8")), ("ovl1", dict(CONGA_BGZF_OVERLAP="1", CONGA_BGZF_PIECE_KB="8", CONGA_BGZF_COPY_THREADS="1", CONGA_DEBUG="1")),
+                     ("plain", dict(CONGA_BGZF_OVERLAP="0")), ("lane", dict(CONGA_BGZF_KERNEL="lane", CONGA_DEBUG="1")),
                      # (the file read with pread instead of mapped)
                      ("unmapped", dict(CONGA_BAM_MMAP="0")), ("ovlfd", dict(CONGA_BAM_MMAP="0", CONGA_BGZF_OVERLAP="1", CONGA_BGZF_PIECE_KB="8")),
                      # the block table walked in parts from block starts the index knows (as for files above 64 MB), read with pread and mapped

@@ -52,6 +52,7 @@ def main():
             hi = sel[-1][0] + sel[-1][1] + 8
             inflated = sum(b[2] for b in sel)
             for kernel in a.kernels.split(","):
+                os.environ["CONGA_DEBUG"] = "1"
                 os.environ["CONGA_BGZF_KERNEL"] = kernel
                 best = 1e30
                 for _ in range(a.reps):
