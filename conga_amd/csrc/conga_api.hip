@@ -79,6 +79,7 @@ int conga_release_staging(conga_ctx *ctx)
 	// leave the process while it is inside the runtime)
 	if (ctx->bz_third_maker.joinable())
 		ctx->bz_third_maker.join();
+	hand_spare_on(ctx);
 	ctx->sched.quiesce(false); // (an upload named ahead and never asked for is given up: its pieces go through the ring)
 	if (!ctx->h_bz_ring)
 		return CONGA_OK;
@@ -331,6 +332,7 @@ void conga_destroy(conga_ctx *ctx)
 		(void) hipHostFree(ctx->h_small);
 	if (ctx->h_head)
 		(void) hipHostFree(ctx->h_head);
+	hand_spare_on(ctx);
 	ctx->sched.quiesce(true);
 	ctx->sched.job_kept.reset();
 	for (auto &o : ctx->sched.buf_owner)

@@ -218,6 +218,15 @@ struct HipMachine final : bz::Machine {
 			int launch) override
 	{
 		hipStream_t ks = ctx->bz_ahead[launch % 2];
+		// A launch ahead is up to a whole sample's blocks on every wave slot of the machine, resident until its last block is through
+		// (27-30 ms of a 1x genome), and the compute of the sample in front is a CHAIN of small launches: once these waves are in, the
+		// chain's next link finds no slot and that compute -- 0.3 ms of work -- ends when the inflate does (a run at 41 ms per sample
+		// instead of 32, profiles/r04b_cohort_one_launch.log).  The set was handed on when that compute was enqueued: its launches go
+		// behind the compute's END, in stream order, without the host in between.
+		if (launch < 2 && ctx->computed_once.load(std::memory_order_acquire) && hipStreamWaitEvent(ks, ctx->ev_done, 0) != hipSuccess) {
+			(void) hipGetLastError();
+			return false;
+		}
 		bool ok = hipMemcpyAsync(ptr<conga_bgzf_block>(ctx->d_bz_blocks2) + first, blocks + first, n * sizeof(conga_bgzf_block), hipMemcpyHostToDevice, ks)
 						== hipSuccess
 				&& hipMemcpyAsync(ptr<uint64_t>(ctx->d_bz_off2) + first, out_off + first, n * 8, hipMemcpyHostToDevice, ks) == hipSuccess
@@ -329,6 +338,15 @@ bool quiet_ensure(DevBuf &b, size_t bytes)
 	return true;
 }
 
+// the spare output set, held back by the call that swapped it in (see there), goes to the next named job that waits for it
+void hand_spare_on(conga_ctx *ctx)
+{
+	if (ctx->spare_held) {
+		ctx->sched.spare_free(ctx->spare_held);
+		ctx->spare_held.reset();
+	}
+}
+
 // *inflated: the bytes named ahead came with their block table and are inflated (the launches are enqueued) in what is now the
 // context's output set -- the caller goes straight to its walks
 int upload_and_inflate_overlapped(conga_ctx *ctx, const ByteSource &src, size_t n_bytes, const conga_bgzf_block *blocks, size_t n_blocks,
@@ -340,6 +358,7 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const ByteSource &src, size_t 
 		return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
 	};
 	bz::Scheduler &sched = ctx->sched;
+	hand_spare_on(ctx); // (a call without a compute behind it -- a sample that goes up chromosome by chromosome)
 	if (!ctx->h_bz_ring && !ctx->bz_ring_failed) {
 		sched.quiesce(false); // (nothing of ours is in the ring: it is not there)
 		make_bz_ring(ctx);
@@ -383,7 +402,16 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const ByteSource &src, size_t 
 			inflated_ahead = true;
 		} else if (took < 0) // (whatever it launched writes the spare set: let it finish before that set is used again)
 			ctx->machine->ahead_drain();
-		if (took != 0)
+		// The set that was swapped out is the next named job's to fill -- and its inflates are a sample's worth of launches (30 ms of
+		// a 1x genome) that go to the GPU the moment the set is free.  This sample's record walks and its compute are a tenth of
+		// that and not enqueued yet: handed the set now, the next sample's launches would be in front of them in the GPU's queues
+		// and this call (or the compute behind it) would wait a whole inflate for 3 ms of work -- round 3's "walks + checks 30 ms"
+		// mode (profiles/r03m_cohort_1x_hw_queues.log).  The set is handed on when this sample's compute is enqueued
+		// (conga_chrom_compute), or when the next call of this kind begins: order in the queues, not priorities, keeps the walks in
+		// front.
+		if (took > 0)
+			ctx->spare_held = job;
+		else if (took < 0)
 			sched.spare_free(job);
 	}
 	sched.enqueue_later();
@@ -394,9 +422,10 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const ByteSource &src, size_t 
 		}
 		if (timing)
 			fprintf(stderr, "\n[timing] overlapped upload: named ahead with its block table %d ms before this call: %zu pieces by %d threads enqueued after "
-					"%.1f ms (threads: %.1f ms copying, %.1f ms waiting for a free slot, each), %d inflate launches made ahead (their thread: %.1f ms)\n",
+					"%.1f ms (threads: %.1f ms copying, %.1f ms waiting for a free slot, each), %d inflate launches made ahead (the first one: %zu blocks; their "
+					"thread: %.1f ms)\n",
 					(int) ms_head_start, job->n_pieces, job->n_threads, job->ms_enqueued, job->ms_copy, job->ms_wait, job->launches_ahead,
-					job->ms_inflate_ahead);
+					job->first_launch_blocks, job->ms_inflate_ahead);
 		ctx->bz_in_now = job->d_bytes;
 		sched.job_kept = job;
 		return CONGA_OK;

@@ -115,6 +115,7 @@ int conga_chrom_compute(conga_ctx *ctx)
 	ctx->depth_resident = dense;
 	ctx->small_cur = ctx->small_cur_next; // the arena the chain launch has just cleared, if it did
 	HIP_TRY(ctx, hipEventRecord(ctx->ev_done, st));
+	ctx->computed_once.store(true, std::memory_order_release);
 	HIP_TRY(ctx, hipEventRecord(ctx->ev_pair[ctx->pos_buf], st));
 	ctx->used_recorded[ctx->pos_buf] = true;
 	ctx->reads_ahead = false;
@@ -124,6 +125,7 @@ int conga_chrom_compute(conga_ctx *ctx)
 	ctx->computed_total = ctx->n_reads_total;
 	HIP_TRY(ctx, hipGetLastError());
 	ctx->computed = true;
+	hand_spare_on(ctx); // (this sample's launches are in the queues: the next sample's inflates may follow them -- engine_bgzf.hip.h)
 	return CONGA_OK;
 }
 

@@ -136,6 +136,8 @@ struct conga_ctx {
 	conga::Knobs knobs;
 	std::unique_ptr<bz::Machine> machine; // (in front of the scheduler: its jobs give their events back through it when they go)
 	bz::Scheduler sched;
+	std::atomic<bool> computed_once{false}; // ev_done has been recorded at least once (the inflate-ahead thread waits for it on ITS streams)
+	std::shared_ptr<bz::Job> spare_held; // the job whose inflated-ahead set the last call swapped in: the set that went out is handed on behind this sample's compute
 	std::mutex prewarm_mu;
 	std::thread bz_prewarm; // CONGA_FLAG_EXPECT_COHORT: gets the second buffer of compressed bytes and the spare output set while the first sample is on
 	bool bz_prewarmed = false;
