@@ -609,6 +609,18 @@ def main():
     # (conga_sample_reads), or W-bit differences encoded by the library's own producer on host threads beside the step before
     # (conga_packer_* -> conga_sample_reads_packed).  Differences encoded beforehand (round 3's `value`: what the link and the
     # engine do with a producer that subtracts while it decodes) stay on the line as `hand_over.packed_preencoded`.
+    if os.environ.get("CONGA_BENCH_TRACE_THREE"):
+        # (measurement switch, for a rocprofv3 timeline: only the pre-encoded packed step through ONE context and through THREE, a
+        # second of sleep between the two so that the trace shows which is which)
+        leg.hand_over = "packed"
+        one = leg.timed(args.steps, args.warmup)
+        time.sleep(1.0)
+        leg.rotate_contexts = True
+        three = leg.timed(args.steps, args.warmup)
+        if rank == 0:
+            os.write(json_fd, (json.dumps(dict(one_context_ms=round(1e3 * one / args.steps, 4), three_contexts_ms=round(1e3 * three / args.steps, 4))) + "\n").encode())
+        leg.close()
+        return
     timed = {}
     for name in ("packed+encode", "int32", "packed"):
         leg.hand_over = name

@@ -310,7 +310,7 @@ void conga_destroy(conga_ctx *ctx)
 			&ctx->d_item_has_map, &ctx->d_item_first, &ctx->d_map_part, &ctx->d_support, &ctx->d_results,
 			&ctx->d_bases, &ctx->d_row_tile, &ctx->d_depth_blocks, &ctx->d_support_base, &ctx->d_ref, &ctx->d_sat_start, &ctx->d_sat_end,
 			&ctx->d_sr_pos, &ctx->d_sr_mapq, &ctx->d_sr_flag, &ctx->d_sr_lq, &ctx->d_sr_off, &ctx->d_sr_data,
-			&ctx->d_sr_recoff, &ctx->d_refn, &ctx->d_kmer_keys, &ctx->d_kmer_sorted, &ctx->d_kmer_tmp, &ctx->d_kmer_offset, &ctx->d_kmer_pos};
+			&ctx->d_sr_recoff, &ctx->d_refn, &ctx->d_kmer_keys, &ctx->d_kmer_sorted, &ctx->d_kmer_tmp, &ctx->d_kmer_offset, &ctx->d_kmer_pos, &ctx->d_kmer_pres};
 	for (DevBuf *b : bufs)
 		free_buf(*b);
 	for (auto &s : ctx->staging) {

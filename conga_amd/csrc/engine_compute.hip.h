@@ -347,6 +347,8 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 		g.sat_end = ptr<int32_t>(ctx->d_sat_end);
 		g.offset = ptr<uint32_t>(ctx->d_kmer_offset);
 		g.positions = ptr<int32_t>(ctx->d_kmer_pos);
+		g.pres = ptr<uint2>(ctx->d_kmer_pres);
+		g.flags = (uint32_t) ctx->knobs.split_flags;
 		g.iv_start = ptr<int32_t>(ctx->d_iv_start);
 		g.iv_end = ptr<int32_t>(ctx->d_iv_end);
 		g.support = ptr<int32_t>(ctx->d_support);
@@ -356,7 +358,8 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 		g.small = small;
 		g.mq_threshold = ctx->opts.mq_threshold;
 		g.min_read_length = ctx->opts.min_read_length;
-		const int sgrid = (int) std::min<int64_t>((int64_t) ctx->sr_units, (int64_t) ctx->n_cu * ctx->split_blocks_per_cu);
+		// (a multiple of eight workgroups: workgroup w runs on XCD w % 8, and the kernel gives every XCD a run of consecutive units)
+		const int sgrid = (int) std::max<int64_t>(8, std::min<int64_t>(((int64_t) ctx->sr_units + 7) & ~(int64_t) 7, (int64_t) ctx->n_cu * ctx->split_blocks_per_cu) & ~(int64_t) 7);
 		hipLaunchKernelGGL(split_map_kernel, dim3(sgrid), dim3(256), 0, st, g);
 	}
 

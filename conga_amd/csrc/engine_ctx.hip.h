@@ -37,6 +37,7 @@ struct HostSlot {
 	int64_t sr_off = 0, n_sr = 0;           // this chromosome's records in the split-read arrays (in place: in d_sr_recoff = its tuples' indices)
 	bool sr_inplace = false;                // its records lie in the inflated BAM stream of conga_reads_bgzf
 	int64_t refn_off = 0, kpos_off = 0, sat_off = 0; // where its packed reference / 10-mer index / satellites lie (prepare_layout)
+	int64_t pres_off = 0;                           // ... and its {solo, echo} bits (in uint2: 32 positions each)
 	int kidx = -1;                          // its offset table; -1: no reference, no part in the split-read launch
 	uint64_t ref_version = 0;               // stamps every conga_reference(): the 10-mer index is rebuilt only for new text
 	// filled by prepare()
@@ -88,6 +89,7 @@ struct conga_ctx {
 	int n_sr_slots = 0;                       // chromosomes with split-read records and a reference (one SplitSlot each)
 	uint32_t sr_units = 0;                    // work units of the split-read launch
 	int64_t refn_words = 0, kpos_total = 0, sat_total = 0; // layout totals of the split-read inputs
+	int64_t pres_words = 0;
 	uint64_t bz_keep_bytes = 0;               // bytes of d_bz_out that hold records in place: the next conga_reads_bgzf goes behind them
 	uint64_t ref_stamp = 0;                   // source of HostSlot::ref_version
 	std::vector<uint64_t> index_sig;          // what the resident 10-mer indexes were built from (slot, length, version)
@@ -107,7 +109,7 @@ struct conga_ctx {
 			d_map_start, d_map_end, d_map_val, d_iv_start, d_iv_end, d_iv_type, d_iv_slot, d_iv_has_map, d_order,
 			d_expected, d_item_off, d_item_len, d_item_iv, d_item_has_map, d_item_first, d_map_part,
 			d_support, d_results, d_bases, d_row_tile, d_depth_blocks, d_support_base, d_ref, d_sat_start, d_sat_end, d_sr_pos,
-			d_sr_mapq, d_sr_flag, d_sr_lq, d_sr_off, d_sr_data, d_sr_recoff, d_refn, d_kmer_keys, d_kmer_sorted, d_kmer_tmp, d_kmer_offset, d_kmer_pos, d_sr_slots,
+			d_sr_mapq, d_sr_flag, d_sr_lq, d_sr_off, d_sr_data, d_sr_recoff, d_refn, d_kmer_keys, d_kmer_sorted, d_kmer_tmp, d_kmer_offset, d_kmer_pos, d_kmer_pres, d_sr_slots,
 			// conga_reads_bgzf: compressed blocks, their table, the inflated stream, the decoders' scratch, the walk's per-segment results
 			d_bz_in, d_bz_blocks, d_bz_off, d_bz_out, d_bz_status, d_bz_scratch, d_bz_crc, d_bz_seg, d_bz_cnt, d_bz_first, d_bz_stop,
 			d_bz_bad, d_bz_at, d_bz_flag, d_bz_x2n,

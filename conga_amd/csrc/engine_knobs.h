@@ -44,6 +44,7 @@ struct Knobs {
 	bool streams_normal = false;      // CONGA_STREAMS_NORMAL: the context's streams at the default priority, launch streams of their own
 	int tuple_blocks_per_cu = 0;      // CONGA_TUPLE_BLOCKS_PER_CU
 	int depth_tiles_per_block = 0;    // CONGA_DEPTH_TILES_PER_BLOCK
+	int split_flags = 0;              // CONGA_SPLIT_FLAGS: 1 = split_map_kernel does not ask the presence bitmaps, 2 = plain unit order
 };
 
 inline Knobs read_knobs()
@@ -84,6 +85,7 @@ inline Knobs read_knobs()
 	k.streams_normal = getenv("CONGA_STREAMS_NORMAL") != nullptr;
 	k.tuple_blocks_per_cu = num("CONGA_TUPLE_BLOCKS_PER_CU", 0);
 	k.depth_tiles_per_block = num("CONGA_DEPTH_TILES_PER_BLOCK", 0);
+	k.split_flags = num("CONGA_SPLIT_FLAGS", 0);
 	return k;
 }
 

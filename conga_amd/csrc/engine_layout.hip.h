@@ -98,6 +98,7 @@ int prepare_sample(conga_ctx *ctx)
 			sl.refn_off = h.refn_off;
 			sl.L = h.L;
 			sl.kpos_off = h.kpos_off;
+			sl.pres_off = h.pres_off;
 			sl.kidx = h.kidx;
 			sl.sat_off = (int32_t) h.sat_off;
 			sl.n_sat = (int32_t) h.sat_start.size();
@@ -139,7 +140,7 @@ int prepare_layout(conga_ctx *ctx)
 	ctx->support_given = false;
 	// split-read inputs: every chromosome with a reference sequence gets its packed reference (8 bases per dword, kRefPadBases
 	// of code 0 behind it), its 10-mer index (one position per base) and its satellites, whatever records this sample has
-	int64_t refn_words = 0, kpos_total = 0, sat_total = 0;
+	int64_t refn_words = 0, kpos_total = 0, sat_total = 0, pres_words = 0;
 	int n_ref = 0;
 	for (int s = 0; s < n_slots; s++) {
 		HostSlot &h = ctx->slots[s];
@@ -148,6 +149,8 @@ int prepare_layout(conga_ctx *ctx)
 			h.kidx = n_ref++;
 			h.refn_off = refn_words;
 			h.kpos_off = kpos_total;
+			h.pres_off = pres_words;
+			pres_words += ((h.L + 31) / 32 + 63) & ~(int64_t) 63;
 			h.sat_off = sat_total;
 			refn_words += ((h.L + kRefPadBases + 7) / 8 + 63) & ~(int64_t) 63;
 			kpos_total += (h.L + 63) & ~(int64_t) 63;
@@ -157,6 +160,7 @@ int prepare_layout(conga_ctx *ctx)
 	ctx->any_ref = n_ref > 0;
 	ctx->refn_words = refn_words;
 	ctx->kpos_total = kpos_total;
+	ctx->pres_words = pres_words;
 	ctx->sat_total = sat_total;
 	for (int s = 0; s < n_slots; s++) {
 		HostSlot &h = ctx->slots[s];
@@ -325,6 +329,9 @@ int prepare_layout(conga_ctx *ctx)
 			TRY(ensure(ctx, ctx->d_refn, (size_t) ctx->refn_words * 4 + 256));
 			TRY(ensure(ctx, ctx->d_kmer_pos, (size_t) ctx->kpos_total * 4 + 256));
 			TRY(ensure(ctx, ctx->d_kmer_offset, n_idx * ((size_t) kKmerBuckets + 2) * 4));
+			// two bits per position: what its own 10-mer's bucket would answer (split_map.hip.h: solo / echo)
+			TRY(ensure(ctx, ctx->d_kmer_pres, (size_t) std::max<int64_t>(ctx->pres_words, 1) * sizeof(uint2) + 256));
+			HIP_TRY(ctx, hipMemsetAsync(ctx->d_kmer_pres.p, 0, (size_t) std::max<int64_t>(ctx->pres_words, 1) * sizeof(uint2), ctx->stream));
 			// scratch of the build, sized for the longest chromosome: its text, a sort key per position, the keys in sorted
 			// order, and what the sort asks for
 			DevBuf text;
@@ -375,6 +382,14 @@ int prepare_layout(conga_ctx *ctx)
 					const int gb = (int) std::min<int64_t>((h.L + 256) / 256, (int64_t) ctx->n_cu * 16);
 					hipLaunchKernelGGL(kmer_bounds_kernel, dim3(gb), dim3(256), 0, st, ptr<uint32_t>(ctx->d_kmer_sorted), h.L,
 							ptr<uint32_t>(ctx->d_kmer_offset) + (size_t) h.kidx * ((size_t) kKmerBuckets + 2));
+					{
+						const uint32_t *off_c = ptr<uint32_t>(ctx->d_kmer_offset) + (size_t) h.kidx * ((size_t) kKmerBuckets + 2);
+						const int32_t *pos_c = ptr<int32_t>(ctx->d_kmer_pos) + h.kpos_off;
+						uint2 *bits_c = ptr<uint2>(ctx->d_kmer_pres) + h.pres_off;
+						const int gs = (int) std::min<int64_t>((h.L + 255) / 256, (int64_t) ctx->n_cu * 16);
+						hipLaunchKernelGGL(kmer_solo_kernel, dim3(gs), dim3(256), 0, st, ptr<uint32_t>(ctx->d_kmer_sorted), pos_c, h.L, off_c, bits_c);
+						hipLaunchKernelGGL(kmer_echo_kernel, dim3(gs), dim3(256), 0, st, refn, h.L, off_c, pos_c, bits_c);
+					}
 					e = hipGetLastError();
 				}
 				if (e != hipSuccess && rc == CONGA_OK)

@@ -57,6 +57,7 @@ struct SplitSlot {
 	uint32_t unit0;       // first work unit
 	int32_t inplace;      // records lie in the inflated BAM stream (conga_reads_bgzf), found through rec_off
 	int32_t pad;
+	int64_t pres_off;     // its {solo, echo} bits, in uint2 (32 positions each)
 };
 
 // ---- the packed reference ------------------------------------------------------------------------------------------
@@ -202,6 +203,92 @@ __global__ __launch_bounds__(256) void kmer_bounds_kernel(const uint32_t *__rest
 	}
 }
 
+// ---- what a position knows about its own 10-mer -------------------------------------------------------------------
+// A half read asks its seed's bucket for the positions within SR_LOOKAHEAD of its anchor (split_read.c:118,166).  The forward
+// seed finds the read's own place there and, five times in six, nothing else; the reverse seed finds nothing five times in six.
+// Each of those answers used to cost the bucket's bounds (a line of a 4 MB table) and a line of the bucket: two fetches from
+// beyond L2 that say "nothing here" -- 4.4 of the kernel's 7 line fetches per element (profiles/split_map_traffic.json).
+// But a half read that matches the reference where it lies asks about 10-mers OF the reference, and what the bucket would
+// answer is a property of that place, known when the index is built.  The half lies at `own` (the read's second half at
+// pos + l / 2, its first half at pos) and is looked for around the OTHER half's place, the anchor: |own - anchor| = l / 2.
+// Two bits per position:
+//   solo[p]  the 10-mer at p is in a bucket that init_hash_table keeps (fewer than MAX_SR_HIT positions, split_read.c:450-457)
+//            and has no namesake q != p with |q - p| < SR_LOOKAHEAD + 1024: a forward seed that IS the reference's ten bases
+//            at own and finds solo[own] set has own for its only candidate (|c - anchor| < SR_LOOKAHEAD implies
+//            |c - own| < SR_LOOKAHEAD + l / 2) -- no bucket is looked at;
+//   echo[q]  the reverse complement of the 10-mer at q occurs, in a kept bucket, at some p with |p - q| < SR_LOOKAHEAD + 1024:
+//            a reverse seed that is the reverse complement of the reference's ten bases at q = own + n - 10 (the half's last
+//            ten) and finds echo[q] clear has no candidate (|c - anchor| < SR_LOOKAHEAD implies |c - q| < SR_LOOKAHEAD + l / 2
+//            + n, and a read is at most 1 022 bases).
+// Both are read next to the read's own place -- the same lines for neighbouring reads, L2 hits -- and both are exact in the
+// direction they are used: whatever they do not settle (a seed with a mismatch, a 10-mer with a namesake nearby: one element in
+// five) goes to the bucket as before.  One uint2 {solo, echo} per 32 positions: a quarter of a byte per base.
+constexpr int kOwnSlack = 1024; // (2 * kSrMaxHalf: a read's length bounds how far own and its last ten bases lie from the anchor)
+
+// solo: over the positions in (10-mer, position) order
+__global__ __launch_bounds__(256) void kmer_solo_kernel(const uint32_t *__restrict__ sorted_keys, const int32_t *__restrict__ positions, int64_t n,
+		const uint32_t *__restrict__ offset, uint2 *__restrict__ bits)
+{
+	const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+	for (int64_t k = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+		const uint32_t key = sorted_keys[k];
+		if (key >= (uint32_t) kKmerBuckets)
+			continue;
+		const uint32_t b0 = offset[key], b1 = offset[key + 1];
+		if (b1 - b0 >= (uint32_t) kMaxSrHit)
+			continue;
+		const int32_t p = positions[k];
+		if ((uint64_t) k > b0 && p - positions[k - 1] < kSrLookahead + kOwnSlack)
+			continue;
+		if ((uint64_t) k + 1 < b1 && positions[k + 1] - p < kSrLookahead + kOwnSlack)
+			continue;
+		atomicOr(&bits[p >> 5].x, 1u << (p & 31));
+	}
+}
+
+// echo: over the positions of the reference
+__global__ __launch_bounds__(256) void kmer_echo_kernel(const uint32_t *__restrict__ refn, int64_t L, const uint32_t *__restrict__ offset,
+		const int32_t *__restrict__ positions, uint2 *__restrict__ bits)
+{
+	const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+	for (int64_t q = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; q + kKmerLen <= L; q += stride) {
+		const uint32_t *rw = refn + (q >> 3);
+		const uint32_t sh = ((uint32_t) q & 7u) * 4u;
+		const uint32_t a = rw[0], b = rw[1], c = rw[2];
+		const uint32_t w0 = funnel_codes(a, b, sh), w1 = funnel_codes(b, c, sh) & 0xFF000000u; // bases q .. q + 7, q + 8 .. q + 9
+		// the reverse complement of the ten: base j of it is the complement of base 9 - j -- the twelve nibbles' bits in reverse
+		// order, the two of w1 first
+		const uint32_t r0 = __brev(w0), r1 = __brev(w1);      // r1: bases 9, 8 complemented in its low byte; r0: bases 7 .. 0
+		const uint32_t v0 = (r1 << 24) | (r0 >> 8), v1 = r0 << 24;
+		const int h = seed_hash(v0, v1);
+		if (h < 0)
+			continue;
+		const uint32_t b0 = offset[h], b1 = offset[h + 1];
+		if (b1 == b0 || b1 - b0 >= (uint32_t) kMaxSrHit)
+			continue;
+		const int64_t lo_pos = q - (kSrLookahead + kOwnSlack - 1), hi_pos = q + (kSrLookahead + kOwnSlack - 1);
+		uint32_t lo = b0, hi = b1;
+		while (lo < hi) { // first position >= lo_pos
+			const uint32_t mid = (lo + hi) >> 1;
+			if ((int64_t) positions[mid] < lo_pos)
+				lo = mid + 1;
+			else
+				hi = mid;
+		}
+		if (lo < b1 && (int64_t) positions[lo] <= hi_pos)
+			atomicOr(&bits[q >> 5].y, 1u << (q & 31));
+	}
+}
+
+// the reference's ten bases at c are the ten at the top of w0 : w1 (codes of an ACGT-only seed: seed_hash(w0, w1) >= 0)
+__device__ __forceinline__ bool ref_ten_equal(const uint32_t *refn, int64_t c, uint32_t w0, uint32_t w1)
+{
+	const uint32_t *rw = refn + (c >> 3);
+	const uint32_t sh = ((uint32_t) c & 7u) * 4u;
+	const uint32_t a = rw[0], b = rw[1], d = rw[2];
+	return funnel_codes(a, b, sh) == w0 && ((funnel_codes(b, d, sh) ^ w1) >> 24) == 0u;
+}
+
 // ---- mapping, pairing, counting ------------------------------------------------------------------------------------
 
 struct SplitMapArgs {
@@ -221,6 +308,8 @@ struct SplitMapArgs {
 	const int32_t *sat_end;
 	const uint32_t *offset;
 	const int32_t *positions;
+	const uint2 *pres;
+	uint32_t flags; // measurement switches (engine_knobs.h): 1 = do not ask the solo / echo bits, 2 = units in plain grid-stride order
 	const int32_t *iv_start;
 	const int32_t *iv_end;
 	int32_t *support; // [n_iv] rp (dups) / border_rp (dels)
@@ -422,7 +511,16 @@ __global__ __launch_bounds__(256) void split_map_kernel(SplitMapArgs g)
 		}
 		n_elem = n_map = n_del = n_dup = 0;
 	};
-	for (uint32_t u = blockIdx.x; u < g.n_units; u += gridDim.x) {
+	// Workgroup w runs on XCD w % 8 (the dispatcher deals them round robin), and every XCD has an L2 of its own: XCD x takes the
+	// runs of `per` consecutive units numbered x, x + 8, x + 16 ..., its workgroups side by side inside a run -- neighbouring reads,
+	// the same lines of the reference and of its solo / echo bits, in ONE L2 instead of a copy in each of eight.
+	const uint32_t per = gridDim.x >> 3, xcd = blockIdx.x & 7u, seat = blockIdx.x >> 3;
+	const bool plain_order = (g.flags & 2u) != 0, ask_presence = (g.flags & 1u) == 0;
+	for (uint32_t round = 0; plain_order || seat < per; round++) {
+		const uint64_t u64 = plain_order ? (uint64_t) round * gridDim.x + blockIdx.x : ((uint64_t) round * 8u + xcd) * per + seat;
+		if (u64 >= g.n_units)
+			break;
+		const uint32_t u = (uint32_t) u64;
 		if (cur + 1 < g.n_slots && u >= g.slots[cur + 1].unit0) { // (the same for the whole workgroup)
 			flush(cur);
 			do
@@ -436,6 +534,7 @@ __global__ __launch_bounds__(256) void split_map_kernel(SplitMapArgs g)
 		const int32_t *sat_s = g.sat_start + sl.sat_off, *sat_e = g.sat_end + sl.sat_off;
 		const uint32_t *offset = g.offset + (int64_t) sl.kidx * (kKmerBuckets + 2);
 		const int32_t *positions = g.positions + sl.kpos_off;
+		const uint2 *pres = g.pres + sl.pres_off;
 		const float inv_len = 1.0f / (float) max(L, (int64_t) 1);
 
 		// ---- the record, and the gate of count_reads_bam (bam_data.c:205-207) and of find_split_reads (split_read.c:216)
@@ -509,8 +608,16 @@ __global__ __launch_bounds__(256) void split_map_kernel(SplitMapArgs g)
 		uint32_t h0[7] = {0, 0, 0, 0, 0, 0, 0}; // the half's first 56 bases
 		if (alive && n >= kKmerLen) {
 			read_words7(sq, from, h0);
-			bucket_from(offset, positions, seed_hash(h0[0], h0[1]), anchor, inv_len, f0, f1);
+			const int hf = seed_hash(h0[0], h0[1]);
 			int cf = 0;
+			const int64_t own = e == 0 ? (int64_t) p + half : (int64_t) p; // where this half lies if the read is the reference's
+			if (hf >= 0 && ask_presence && own + kKmerLen <= L && (pres[own >> 5].x >> (own & 31) & 1u) != 0u
+					&& ref_ten_equal(refn, own, h0[0], h0[1])) {
+				// the half's own place is its bucket's only position in the window (and cannot make a row: the pieces abut, pair_geometry)
+				if (half_distance_fwd(refn, (int) own, sq, from, n, h0) <= dist_max)
+					cf = 1;
+			} else
+				bucket_from(offset, positions, hf, anchor, inv_len, f0, f1);
 			for (uint32_t k = f0; k < f1 && cf < kMaxMapping; k++) { // (a hundred hits or more: the element is dropped whatever follows)
 				const int c = positions[k];
 				if ((int64_t) c >= hi_pos)
@@ -524,8 +631,15 @@ __global__ __launch_bounds__(256) void split_map_kernel(SplitMapArgs g)
 			}
 			size = cf;
 			if (cf < kMaxMapping) {
-				uint32_t r0, r1;
-				bucket_from(offset, positions, seed_hash(revcomp_codes(sq, from, n, 0), revcomp_codes(sq, from, n, 8)), anchor, inv_len, r0, r1);
+				uint32_t r0 = 0, r1 = 0;
+				const int hr = seed_hash(revcomp_codes(sq, from, n, 0), revcomp_codes(sq, from, n, 8));
+				// the reverse seed is the reverse complement of the half's last ten bases: when those are the reference's at
+				// q = own + n - 10 and echo[q] is clear, its bucket holds nothing within the window
+				const int64_t q = own + n - kKmerLen;
+				const bool nothing = hr >= 0 && ask_presence && q + kKmerLen <= L && (pres[q >> 5].y >> (q & 31) & 1u) == 0u
+						&& ref_ten_equal(refn, q, read_codes(sq, from + n - kKmerLen), read_codes(sq, from + n - kKmerLen + 8));
+				if (!nothing)
+					bucket_from(offset, positions, hr, anchor, inv_len, r0, r1);
 				for (uint32_t k = r0; k < r1 && size <= kMaxMapping; k++) {
 					const int c = positions[k];
 					if ((int64_t) c >= hi_pos)

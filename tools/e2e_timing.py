@@ -38,12 +38,16 @@ try:
         envx = dict(kv.split("=", 1) for kv in var.split(","))
         for rep in range(2):
             try:
+                import time
                 dt, err = e2e_bench.run_conga(["--cohort", "list.txt", "--out", "x", "--ref", "r.fa", "--sonic", "a.cga", "--dels", "dels.bed"], d,
-                                              dict(envx, CONGA_GPU_BAM=a.decode, CONGA_TIMING="1"))
+                                              dict(envx, CONGA_GPU_BAM=a.decode, CONGA_TIMING="1", CONGA_T0_NS=str(time.time_ns())))
             except RuntimeError as e:
                 print("[%s] failed: %s" % (var, str(e)[-200:]))
                 continue
             print("[%s] run %d: wall %.3f s" % (var, rep, dt))
+            for line in err.splitlines():   # (with CONGA_T0_NS in the variant: where the process's own clock stands against the caller's)
+                if "after the caller's clock" in line or "conga_create:" in line:
+                    print("   " + line[:300])
             for line in err.splitlines():
                 if "overlapped upload" in line or "conga_reads_bgzf:" in line:
                     print("   " + line[:300])
