@@ -225,8 +225,9 @@ def leg(args, env):
                              frac=round(alg / max(sr_ms, 1e-6) / 1e6 / 8000.0, 4), traffic=None,
                              records_per_s=round(n_reads / (sr_ms * 1e-3), 1),
                              note="HIP events around the launch on the context's stream (CONGA_FLAG_PROFILE); a lane per half-read "
-                                  "element: 4-byte probes into 10-mer buckets spread over the whole index, each a 128-byte line "
-                                  "from beyond L2 -- bound by the rate of such fetches (random_fetch), not by streamed bytes"))
+                                  "element.  Four seeds in five are settled by two bits read next to the read's own place (split_map.hip.h: "
+                                  "solo / echo); the fifth probes its 10-mer's bucket, each probe a 128-byte line from beyond L2 -- "
+                                  "`random_fetch` prices the launch against the machine's rate for such fetches, `frac` against streamed bytes"))
     # HBM traffic and the bound that holds for this kernel, from the PMC campaign in profiles/ (per element, scaled to this run)
     try:
         with open(os.path.join(e2e_bench.ROOT, "profiles", "split_map_traffic.json")) as f:
@@ -236,7 +237,8 @@ def leg(args, env):
         cal = tr["random_probe_calibration"]
         out["roofline"].update(
             traffic=round(tr["hbm_bytes_per_launch"] / tr["elements"] * n_el),
-            traffic_source="profiles/split_map_traffic.json (rocprofv3 --pmc campaign %s, per half-read element; not measured in this run)" % tr["campaign"],
+            traffic_source="profiles/split_map_traffic.json (rocprofv3 --pmc campaign %s on the whole genome, per half-read element; not measured "
+                           "in this run)" % tr["campaign"],
             random_fetch=dict(unit="TB/s of FETCH_SIZE (raw: a 128-byte line counts 63 bytes)", achieved=round(raw / (sr_ms * 1e-3) / 1e12, 3),
                               peak=round(cal["fetch_rate_raw_bytes_per_s"] / 1e12, 3),
                               frac=round(raw / (sr_ms * 1e-3) / cal["fetch_rate_raw_bytes_per_s"], 3),
