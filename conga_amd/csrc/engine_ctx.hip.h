@@ -90,6 +90,8 @@ struct conga_ctx {
 	uint32_t sr_units = 0;                    // work units of the split-read launch
 	int64_t refn_words = 0, kpos_total = 0, sat_total = 0; // layout totals of the split-read inputs
 	int64_t pres_words = 0;
+	bool pres_built = false;      // the solo / echo bits of the resident indexes are made (enqueue_compute: before the second split-read launch)
+	int sr_launches_on_index = 0; // split-read launches since the indexes were built
 	uint64_t bz_keep_bytes = 0;               // bytes of d_bz_out that hold records in place: the next conga_reads_bgzf goes behind them
 	uint64_t ref_stamp = 0;                   // source of HostSlot::ref_version
 	std::vector<uint64_t> index_sig;          // what the resident 10-mer indexes were built from (slot, length, version)

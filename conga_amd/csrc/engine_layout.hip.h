@@ -382,14 +382,6 @@ int prepare_layout(conga_ctx *ctx)
 					const int gb = (int) std::min<int64_t>((h.L + 256) / 256, (int64_t) ctx->n_cu * 16);
 					hipLaunchKernelGGL(kmer_bounds_kernel, dim3(gb), dim3(256), 0, st, ptr<uint32_t>(ctx->d_kmer_sorted), h.L,
 							ptr<uint32_t>(ctx->d_kmer_offset) + (size_t) h.kidx * ((size_t) kKmerBuckets + 2));
-					{
-						const uint32_t *off_c = ptr<uint32_t>(ctx->d_kmer_offset) + (size_t) h.kidx * ((size_t) kKmerBuckets + 2);
-						const int32_t *pos_c = ptr<int32_t>(ctx->d_kmer_pos) + h.kpos_off;
-						uint2 *bits_c = ptr<uint2>(ctx->d_kmer_pres) + h.pres_off;
-						const int gs = (int) std::min<int64_t>((h.L + 255) / 256, (int64_t) ctx->n_cu * 16);
-						hipLaunchKernelGGL(kmer_solo_kernel, dim3(gs), dim3(256), 0, st, ptr<uint32_t>(ctx->d_kmer_sorted), pos_c, h.L, off_c, bits_c);
-						hipLaunchKernelGGL(kmer_echo_kernel, dim3(gs), dim3(256), 0, st, refn, h.L, off_c, pos_c, bits_c);
-					}
 					e = hipGetLastError();
 				}
 				if (e != hipSuccess && rc == CONGA_OK)
@@ -403,6 +395,8 @@ int prepare_layout(conga_ctx *ctx)
 			free_buf(ctx->d_kmer_tmp);
 			TRY(rc);
 			ctx->index_sig = sig;
+			ctx->pres_built = false; // (the solo / echo bits of the new text: made before the second split-read launch on it)
+			ctx->sr_launches_on_index = 0;
 			if (ctx->knobs.timing)
 				fprintf(stderr, "[timing] 10-mer indexes of %zu chromosomes (%.0f Mb) built in %.1f ms (once per reference)\n", n_idx,
 						ctx->kpos_total / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_index).count());

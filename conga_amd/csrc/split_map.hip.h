@@ -225,61 +225,6 @@ __global__ __launch_bounds__(256) void kmer_bounds_kernel(const uint32_t *__rest
 // five) goes to the bucket as before.  One uint2 {solo, echo} per 32 positions: a quarter of a byte per base.
 constexpr int kOwnSlack = 1024; // (2 * kSrMaxHalf: a read's length bounds how far own and its last ten bases lie from the anchor)
 
-// solo: over the positions in (10-mer, position) order
-__global__ __launch_bounds__(256) void kmer_solo_kernel(const uint32_t *__restrict__ sorted_keys, const int32_t *__restrict__ positions, int64_t n,
-		const uint32_t *__restrict__ offset, uint2 *__restrict__ bits)
-{
-	const int64_t stride = (int64_t) gridDim.x * blockDim.x;
-	for (int64_t k = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
-		const uint32_t key = sorted_keys[k];
-		if (key >= (uint32_t) kKmerBuckets)
-			continue;
-		const uint32_t b0 = offset[key], b1 = offset[key + 1];
-		if (b1 - b0 >= (uint32_t) kMaxSrHit)
-			continue;
-		const int32_t p = positions[k];
-		if ((uint64_t) k > b0 && p - positions[k - 1] < kSrLookahead + kOwnSlack)
-			continue;
-		if ((uint64_t) k + 1 < b1 && positions[k + 1] - p < kSrLookahead + kOwnSlack)
-			continue;
-		atomicOr(&bits[p >> 5].x, 1u << (p & 31));
-	}
-}
-
-// echo: over the positions of the reference
-__global__ __launch_bounds__(256) void kmer_echo_kernel(const uint32_t *__restrict__ refn, int64_t L, const uint32_t *__restrict__ offset,
-		const int32_t *__restrict__ positions, uint2 *__restrict__ bits)
-{
-	const int64_t stride = (int64_t) gridDim.x * blockDim.x;
-	for (int64_t q = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; q + kKmerLen <= L; q += stride) {
-		const uint32_t *rw = refn + (q >> 3);
-		const uint32_t sh = ((uint32_t) q & 7u) * 4u;
-		const uint32_t a = rw[0], b = rw[1], c = rw[2];
-		const uint32_t w0 = funnel_codes(a, b, sh), w1 = funnel_codes(b, c, sh) & 0xFF000000u; // bases q .. q + 7, q + 8 .. q + 9
-		// the reverse complement of the ten: base j of it is the complement of base 9 - j -- the twelve nibbles' bits in reverse
-		// order, the two of w1 first
-		const uint32_t r0 = __brev(w0), r1 = __brev(w1);      // r1: bases 9, 8 complemented in its low byte; r0: bases 7 .. 0
-		const uint32_t v0 = (r1 << 24) | (r0 >> 8), v1 = r0 << 24;
-		const int h = seed_hash(v0, v1);
-		if (h < 0)
-			continue;
-		const uint32_t b0 = offset[h], b1 = offset[h + 1];
-		if (b1 == b0 || b1 - b0 >= (uint32_t) kMaxSrHit)
-			continue;
-		const int64_t lo_pos = q - (kSrLookahead + kOwnSlack - 1), hi_pos = q + (kSrLookahead + kOwnSlack - 1);
-		uint32_t lo = b0, hi = b1;
-		while (lo < hi) { // first position >= lo_pos
-			const uint32_t mid = (lo + hi) >> 1;
-			if ((int64_t) positions[mid] < lo_pos)
-				lo = mid + 1;
-			else
-				hi = mid;
-		}
-		if (lo < b1 && (int64_t) positions[lo] <= hi_pos)
-			atomicOr(&bits[q >> 5].y, 1u << (q & 31));
-	}
-}
-
 // the reference's ten bases at c are the ten at the top of w0 : w1 (codes of an ACGT-only seed: seed_hash(w0, w1) >= 0)
 __device__ __forceinline__ bool ref_ten_equal(const uint32_t *refn, int64_t c, uint32_t w0, uint32_t w1)
 {
@@ -472,6 +417,56 @@ __device__ __forceinline__ void bucket_from(const uint32_t *offset, const int32_
 	}
 	k0 = lo;
 	b1 = b.y;
+}
+
+// solo: a thread per bucket walks its positions (they are one behind the other, in increasing position); the bits can be made at
+// any time from what stays resident (offset, positions) -- the engine makes them before the SECOND split-read launch on an index, so
+// that a single sample never pays for them (engine_compute.hip.h)
+__global__ __launch_bounds__(256) void kmer_solo_kernel(const int32_t *__restrict__ positions, const uint32_t *__restrict__ offset, uint2 *__restrict__ bits)
+{
+	const uint32_t stride = gridDim.x * blockDim.x;
+	for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < (uint32_t) kKmerBuckets; h += stride) {
+		const uint32_t b0 = offset[h], b1 = offset[h + 1];
+		if (b1 == b0 || b1 - b0 >= (uint32_t) kMaxSrHit)
+			continue;
+		int32_t prev = positions[b0];
+		bool prev_far = true;
+		for (uint32_t k = b0; k < b1; k++) {
+			const int32_t p = prev;
+			const bool last = k + 1 == b1;
+			const int32_t next = last ? 0 : positions[k + 1];
+			const bool next_far = last || next - p >= kSrLookahead + kOwnSlack;
+			if (prev_far && next_far)
+				atomicOr(&bits[p >> 5].x, 1u << (p & 31));
+			prev_far = next_far;
+			prev = next;
+		}
+	}
+}
+
+// echo: over the positions of the reference.  Where the window begins in the bucket is guessed like a read's (bucket_from): a line of
+// bounds, a line of the bucket
+__global__ __launch_bounds__(256) void kmer_echo_kernel(const uint32_t *__restrict__ refn, int64_t L, const uint32_t *__restrict__ offset,
+		const int32_t *__restrict__ positions, uint2 *__restrict__ bits)
+{
+	const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+	const float inv_len = 1.0f / (float) max(L, (int64_t) 1);
+	for (int64_t q = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; q + kKmerLen <= L; q += stride) {
+		const uint32_t *rw = refn + (q >> 3);
+		const uint32_t sh = ((uint32_t) q & 7u) * 4u;
+		const uint32_t a = rw[0], b = rw[1], c = rw[2];
+		const uint32_t w0 = funnel_codes(a, b, sh), w1 = funnel_codes(b, c, sh) & 0xFF000000u; // bases q .. q + 7, q + 8 .. q + 9
+		// the reverse complement of the ten: base j of it is the complement of base 9 - j -- the twelve nibbles' bits in reverse
+		// order, the two of w1 first
+		const uint32_t r0 = __brev(w0), r1 = __brev(w1);      // r1: bases 9, 8 complemented in its low byte; r0: bases 7 .. 0
+		const uint32_t v0 = (r1 << 24) | (r0 >> 8), v1 = r0 << 24;
+		const int h = seed_hash(v0, v1);
+		uint32_t k0 = 0, b1 = 0;
+		// (bucket_from's window begins at anchor - (SR_LOOKAHEAD - 1): an anchor kOwnSlack in front of q makes it q - (LA + slack - 1))
+		bucket_from(offset, positions, h, q - kOwnSlack, inv_len, k0, b1);
+		if (k0 < b1 && (int64_t) positions[k0] <= q + (kSrLookahead + kOwnSlack - 1))
+			atomicOr(&bits[q >> 5].y, 1u << (q & 31));
+	}
 }
 
 // determine_SvType's geometry for a forward mapping `pm` of the element anchored at `anchor` (bam_data.c:40-61): the two
