@@ -352,7 +352,8 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 		// The solo / echo bits (split_map.hip.h) cost a genome's index ~0.15 s more and save a sample's launch a quarter of its time:
 		// a single sample is better off without them, a cohort's second sample pays for them and every later one gains.  Made
 		// here, once per index, in front of the second launch that uses it (everything they are made from is resident).
-		if (!ctx->pres_built && ctx->sr_launches_on_index >= 1 && (g.flags & 1u) == 0) {
+		// (a context that was told a cohort is coming -- CONGA_FLAG_EXPECT_COHORT -- makes them with the first launch)
+		if (!ctx->pres_built && (ctx->sr_launches_on_index >= 1 || (ctx->opts.flags & CONGA_FLAG_EXPECT_COHORT) != 0) && (g.flags & 1u) == 0) {
 			for (int s = 0; s < n_slots; s++) {
 				const HostSlot &h = ctx->slots[(size_t) s];
 				if (h.kidx < 0)
