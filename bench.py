@@ -266,7 +266,9 @@ class Leg:
             open_layout(c, self.mine)
         # the producer's threads: in this loop nothing else works on the host, so all of the cores the process may use but two (the
         # thread that drives the step and the runtime's own) -- 14 on a box that grants 16: 1.5 ms per 1x genome against 1.8 with 8
-        self.packer = capi.Packer(int(os.environ.get("CONGA_BENCH_PACK_THREADS", str(max(1, cpus_granted() - 2)))))
+        # (N ranks on one host share its cores: each rank's share, and never more than 14 -- beyond 8 the host's memory is the limit)
+        share = max(1, min(14, cpus_granted() // max(env["world"], 1) - 2))
+        self.packer = capi.Packer(int(os.environ.get("CONGA_BENCH_PACK_THREADS", str(share))))
         self.packer_threads = self.packer.threads()
         self.samples = pinned_samples(self.ctxs[0], self.mine, self.packer)
         # where the TIMED encode writes (hand_over = "packed+encode"): three pinned buffers, since the bytes of sample k must stay as they
@@ -516,6 +518,7 @@ class Leg:
             torch.cuda.empty_cache()
         for c in self.ctxs:
             c.close()
+        self.packer.close()
 
 
 def traffic_of(name):
@@ -713,7 +716,7 @@ def main():
 
     if rank == 0 and not dist_on:
         leg.rotate_contexts = True
-        e3 = leg.timed(args.steps, 2)
+        e3 = leg.timed(args.steps, 2 * N_ROTATE)   # (every context's second pair of buffers is touched once before the clock starts)
         leg.rotate_contexts = False
         out["three_contexts"] = dict(ms_per_step=round(1e3 * e3 / args.steps, 4), value=round(leg.total_iv * args.steps / e3, 1),
                                      note="rounds 2-3's loop: the steps rotate over three contexts (the copy of sample k + 1 beside the "

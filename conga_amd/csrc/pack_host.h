@@ -15,6 +15,11 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#if defined(__linux__)
+#include <pthread.h>
+#include <sched.h>
+#include <unistd.h>
+#endif
 #if defined(__x86_64__)
 #include <immintrin.h>
 #endif
@@ -248,10 +253,23 @@ inline void cpu_relax()
 
 class Packer {
 public:
-	explicit Packer(int n_threads) : n_threads_(std::max(1, n_threads))
+	// spread > 0: worker t pins itself to CPU (t * spread) mod the CPUs of the machine -- one worker per L3 domain reads through
+	// that domain's own link to memory instead of eight sharing one (tools/packbench --spread)
+	explicit Packer(int n_threads, int spread = 0) : n_threads_(std::max(1, n_threads))
 	{
 		for (int t = 0; t < n_threads_; t++)
-			threads_.emplace_back([this] { loop(); });
+			threads_.emplace_back([this, t, spread] {
+#if defined(__linux__)
+				if (spread > 0) {
+					const long n_cpu = sysconf(_SC_NPROCESSORS_CONF);
+					cpu_set_t set;
+					CPU_ZERO(&set);
+					CPU_SET((int) (((long) t * spread) % std::max(1L, n_cpu)), &set);
+					(void) pthread_setaffinity_np(pthread_self(), sizeof set, &set); // (refused: the worker runs where the scheduler puts it)
+				}
+#endif
+				loop();
+			});
 	}
 	~Packer()
 	{

@@ -22,9 +22,14 @@ int main(int argc, char **argv)
 	}
 	const uint64_t off[3] = {0, n / 2, n};
 	std::vector<uint8_t> out(conga_pack::bound(n, n / 16));
+	int spread = 0;
 	for (int a = 1; a < (argc > 1 ? argc : 2); a++) {
+		if (argc > 1 && strcmp(argv[a], "--spread") == 0 && a + 1 < argc) {
+			spread = atoi(argv[++a]);
+			continue;
+		}
 		const int nt = argc > 1 ? atoi(argv[a]) : 8;
-		conga_pack::Packer pk(nt);
+		conga_pack::Packer pk(nt, spread);
 		double best = 1e30;
 		int w = 0;
 		size_t ne = 0, nb = 0;
@@ -34,7 +39,7 @@ int main(int argc, char **argv)
 				return 1;
 			best = std::min(best, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
 		}
-		printf("%2d threads: %.3f ms best of 12 (width %d, %zu exceptions, %zu bytes) = %.1f GB/s of positions read, %s\n", nt, best, w, ne, nb,
+		printf("%2d threads (spread %d): %.3f ms best of 12 (width %d, %zu exceptions, %zu bytes) = %.1f GB/s of positions read, %s\n", nt, spread, best, w, ne, nb,
 				4.0 * n / best / 1e6, conga_pack::have_avx2_bmi2() ? "avx2+bmi2" : "scalar");
 	}
 	return 0;
