@@ -31,6 +31,21 @@ bool lane_kernel_asked(const conga_ctx *ctx)
 	return ctx->knobs.bgzf_lane_kernel;
 }
 
+constexpr size_t kBzTickets = 1024; // a counter per launch, taken in turn: a launch is long through when its counter comes round again
+
+// a zeroed counter for one launch on stream `st` (any thread)
+uint32_t *bz_ticket(conga_ctx *ctx, hipStream_t st)
+{
+	if (!ctx->d_bz_ticket.p)
+		return nullptr;
+	uint32_t *t = ptr<uint32_t>(ctx->d_bz_ticket) + (ctx->bz_ticket_next.fetch_add(1) % kBzTickets);
+	if (hipMemsetAsync(t, 0, 4, st) != hipSuccess) {
+		(void) hipGetLastError();
+		return nullptr; // (round robin then)
+	}
+	return t;
+}
+
 int ensure_x2n(conga_ctx *ctx)
 {
 	if (ctx->d_bz_x2n.p)
@@ -50,6 +65,7 @@ int ensure_x2n(conga_ctx *ctx)
 	for (int k = 1; k < 32; k++)
 		x2n[k] = mul(x2n[k - 1], x2n[k - 1]);
 	TRY(upload(ctx, ctx->d_bz_x2n, x2n, sizeof x2n));
+	TRY(ensure(ctx, ctx->d_bz_ticket, kBzTickets * 4)); // the launches' block counters (inflate_wave.hip.h: `ticket`)
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // (`x2n` is on the stack)
 	return CONGA_OK;
 }
@@ -72,14 +88,15 @@ int launch_inflate(conga_ctx *ctx, size_t n_blocks, uint32_t lanes, hipStream_t 
 	const size_t groups = std::min<size_t>((n_blocks + iw::kWavesPerGroup - 1) / iw::kWavesPerGroup, (size_t) ctx->n_cu * 8);
 	// CONGA_BGZF_KERNEL=wave1: round 2's symbol loop (every trip decodes its sixty-four candidates completely), for comparison
 	const bool one_phase = ctx->knobs.bgzf_one_phase;
+	uint32_t *ticket = ctx->knobs.bgzf_round_robin ? nullptr : bz_ticket(ctx, st);
 	if (one_phase)
 		hipLaunchKernelGGL(iw::bgzf_inflate_wave_kernel<false>, dim3((unsigned) groups), dim3(64 * iw::kWavesPerGroup), 0, st, (uint32_t) n_blocks,
 				in, ptr<conga_bgzf_block>(ctx->d_bz_blocks) + b0, ptr<uint64_t>(ctx->d_bz_off) + b0,
-				ptr<uint8_t>(ctx->d_bz_out), ptr<uint32_t>(ctx->d_bz_crc), ptr<uint32_t>(ctx->d_bz_x2n), ptr<uint8_t>(ctx->d_bz_status) + b0);
+				ptr<uint8_t>(ctx->d_bz_out), ptr<uint32_t>(ctx->d_bz_crc), ptr<uint32_t>(ctx->d_bz_x2n), ptr<uint8_t>(ctx->d_bz_status) + b0, ticket);
 	else
 		hipLaunchKernelGGL(iw::bgzf_inflate_wave_kernel<true>, dim3((unsigned) groups), dim3(64 * iw::kWavesPerGroup), 0, st, (uint32_t) n_blocks,
 				in, ptr<conga_bgzf_block>(ctx->d_bz_blocks) + b0, ptr<uint64_t>(ctx->d_bz_off) + b0,
-				ptr<uint8_t>(ctx->d_bz_out), ptr<uint32_t>(ctx->d_bz_crc), ptr<uint32_t>(ctx->d_bz_x2n), ptr<uint8_t>(ctx->d_bz_status) + b0);
+				ptr<uint8_t>(ctx->d_bz_out), ptr<uint32_t>(ctx->d_bz_crc), ptr<uint32_t>(ctx->d_bz_x2n), ptr<uint8_t>(ctx->d_bz_status) + b0, ticket);
 	return CONGA_OK;
 }
 
@@ -236,7 +253,8 @@ struct HipMachine final : bz::Machine {
 			const size_t groups = std::min<size_t>((n + iw::kWavesPerGroup - 1) / iw::kWavesPerGroup, (size_t) ctx->n_cu * 8);
 			hipLaunchKernelGGL(iw::bgzf_inflate_wave_kernel<true>, dim3((unsigned) groups), dim3(64 * iw::kWavesPerGroup), 0, ks, (uint32_t) n, d_bytes,
 					ptr<conga_bgzf_block>(ctx->d_bz_blocks2) + first, ptr<uint64_t>(ctx->d_bz_off2) + first, ptr<uint8_t>(ctx->d_bz_out2),
-					ptr<uint32_t>(ctx->d_bz_crc), ptr<uint32_t>(ctx->d_bz_x2n), ptr<uint8_t>(ctx->d_bz_status2) + first);
+					ptr<uint32_t>(ctx->d_bz_crc), ptr<uint32_t>(ctx->d_bz_x2n), ptr<uint8_t>(ctx->d_bz_status2) + first,
+					ctx->knobs.bgzf_round_robin ? nullptr : bz_ticket(ctx, ks));
 			ok = hipGetLastError() == hipSuccess;
 		}
 		if (!ok)

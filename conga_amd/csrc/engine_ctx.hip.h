@@ -114,7 +114,7 @@ struct conga_ctx {
 			d_sr_mapq, d_sr_flag, d_sr_lq, d_sr_off, d_sr_data, d_sr_recoff, d_refn, d_kmer_keys, d_kmer_sorted, d_kmer_tmp, d_kmer_offset, d_kmer_pos, d_kmer_pres, d_sr_slots,
 			// conga_reads_bgzf: compressed blocks, their table, the inflated stream, the decoders' scratch, the walk's per-segment results
 			d_bz_in, d_bz_blocks, d_bz_off, d_bz_out, d_bz_status, d_bz_scratch, d_bz_crc, d_bz_seg, d_bz_cnt, d_bz_first, d_bz_stop,
-			d_bz_bad, d_bz_at, d_bz_flag, d_bz_x2n,
+			d_bz_bad, d_bz_at, d_bz_flag, d_bz_x2n, d_bz_ticket,
 			// the spare output set: bytes named ahead WITH their block table (conga_reads_bgzf_next_blocks) are inflated into it
 			// while the sample in front is still walked and computed; the call that takes them up swaps the sets
 			d_bz_out2, d_bz_blocks2, d_bz_off2, d_bz_status2;
@@ -140,6 +140,7 @@ struct conga_ctx {
 	conga::Knobs knobs;
 	std::unique_ptr<bz::Machine> machine; // (in front of the scheduler: its jobs give their events back through it when they go)
 	bz::Scheduler sched;
+	std::atomic<uint32_t> bz_ticket_next{0}; // which of d_bz_ticket's counters the next inflate launch takes
 	std::atomic<bool> computed_once{false}; // ev_done has been recorded at least once (the inflate-ahead thread waits for it on ITS streams)
 	std::shared_ptr<bz::Job> spare_held; // the job whose inflated-ahead set the last call swapped in: the set that went out is handed on behind this sample's compute
 	std::mutex prewarm_mu;

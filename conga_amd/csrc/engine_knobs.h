@@ -40,6 +40,7 @@ struct Knobs {
 	bool bgzf_plain_pread = false;    // CONGA_BGZF_PLAIN_PREAD: pread() straight into the pinned slot
 	int bgzf_copy_threads = 0;        // CONGA_BGZF_COPY_THREADS
 	int bgzf_launch_mb = 0;           // CONGA_BGZF_LAUNCH_MB: bytes of file per inflate launch
+	bool bgzf_round_robin = false;    // CONGA_BGZF_ROUND_ROBIN: inflate launches deal their blocks round robin (no ticket counter)
 	bool bgzf_upload_only = false;    // CONGA_BGZF_UPLOAD_ONLY: no inflate launches (the call then fails its checks)
 	bool streams_normal = false;      // CONGA_STREAMS_NORMAL: the context's streams at the default priority, launch streams of their own
 	int tuple_blocks_per_cu = 0;      // CONGA_TUPLE_BLOCKS_PER_CU
@@ -82,6 +83,7 @@ inline Knobs read_knobs()
 	k.bgzf_copy_threads = num("CONGA_BGZF_COPY_THREADS", 0);
 	k.bgzf_launch_mb = num("CONGA_BGZF_LAUNCH_MB", 0);
 	k.bgzf_upload_only = getenv("CONGA_BGZF_UPLOAD_ONLY") != nullptr;
+	k.bgzf_round_robin = getenv("CONGA_BGZF_ROUND_ROBIN") != nullptr;
 	k.streams_normal = getenv("CONGA_STREAMS_NORMAL") != nullptr;
 	k.tuple_blocks_per_cu = num("CONGA_TUPLE_BLOCKS_PER_CU", 0);
 	k.depth_tiles_per_block = num("CONGA_DEPTH_TILES_PER_BLOCK", 0);

@@ -1111,10 +1111,13 @@ template <bool BATCHED> __device__ __forceinline__ int inflate_block(WaveLds &t,
 
 constexpr int kWavesPerGroup = 4;
 
-// status[b]: kStatusOk / kStatusRefused / kStatusCrc.  Waves take blocks round robin.
+// status[b]: kStatusOk / kStatusRefused / kStatusCrc.  `ticket` (a zeroed counter, or NULL): waves take the next block off it -- a
+// wave that is through early takes more, and the launch ends a block's time after its mean instead of with the wave that drew the
+// ten dearest of 79 086 (a 1x genome is 9.65 rounds of the machine's 8 192 waves: dealt round robin, the last round is two thirds
+// full); NULL: blocks round robin over the waves (round 2-3's order).
 template <bool BATCHED> __global__ __launch_bounds__(64 * kWavesPerGroup, 8) void bgzf_inflate_wave_kernel(uint32_t n_blocks, const uint8_t *__restrict__ bytes,
 		const conga_bgzf_block *__restrict__ blocks, const uint64_t *__restrict__ out_off, uint8_t *out,
-		const uint32_t *__restrict__ crc_table, const uint32_t *__restrict__ x2n, uint8_t *__restrict__ status)
+		const uint32_t *__restrict__ crc_table, const uint32_t *__restrict__ x2n, uint8_t *__restrict__ status, uint32_t *ticket = nullptr)
 {
 	__shared__ WaveLds lds[kWavesPerGroup];
 	__shared__ uint32_t s_crc[256];
@@ -1129,7 +1132,15 @@ template <bool BATCHED> __global__ __launch_bounds__(64 * kWavesPerGroup, 8) voi
 	__syncthreads();
 	const uint32_t wave = uni(threadIdx.x >> 6); // (uniform by construction; said so, everything per block stays in scalar registers)
 	const uint32_t n_waves = gridDim.x * kWavesPerGroup;
-	for (uint32_t b = blockIdx.x * kWavesPerGroup + wave; b < n_blocks; b += n_waves) {
+	auto next_block = [&](uint32_t b) -> uint32_t { // (every wave reaches b >= n_blocks: the counter only grows)
+		if (!ticket)
+			return b + n_waves;
+		uint32_t t = 0;
+		if (lane_id() == 0u)
+			t = atomicAdd(ticket, 1u);
+		return uni(t);
+	};
+	for (uint32_t b = ticket ? next_block(0) : blockIdx.x * kWavesPerGroup + wave; b < n_blocks; b = next_block(b)) {
 		const conga_bgzf_block bl = blocks[b];
 		uint8_t *dst = out + out_off[b];
 #ifdef IW_PROF
