@@ -359,10 +359,15 @@ bool quiet_ensure(DevBuf &b, size_t bytes)
 // the spare output set, held back by the call that swapped it in (see there), goes to the next named job that waits for it
 void hand_spare_on(conga_ctx *ctx)
 {
-	if (ctx->spare_held) {
-		ctx->sched.spare_free(ctx->spare_held);
-		ctx->spare_held.reset();
+	// (conga_release_staging may run on a thread of the caller's beside conga_chrom_compute -- the executable does that behind its
+	// last BAM --, and both hand the set on: the pointer changes hands under a lock)
+	std::shared_ptr<bz::Job> held;
+	{
+		std::lock_guard<std::mutex> g(ctx->spare_mu);
+		held.swap(ctx->spare_held);
 	}
+	if (held)
+		ctx->sched.spare_free(held);
 }
 
 // *inflated: the bytes named ahead came with their block table and are inflated (the launches are enqueued) in what is now the
@@ -427,8 +432,10 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const ByteSource &src, size_t 
 		// mode (profiles/r03m_cohort_1x_hw_queues.log).  The set is handed on when this sample's compute is enqueued
 		// (conga_chrom_compute), or when the next call of this kind begins: order in the queues, not priorities, keeps the walks in
 		// front.
-		if (took > 0)
+		if (took > 0) {
+			std::lock_guard<std::mutex> g(ctx->spare_mu);
 			ctx->spare_held = job;
+		}
 		else if (took < 0)
 			sched.spare_free(job);
 	}

@@ -142,6 +142,7 @@ struct conga_ctx {
 	bz::Scheduler sched;
 	std::atomic<uint32_t> bz_ticket_next{0}; // which of d_bz_ticket's counters the next inflate launch takes
 	std::atomic<bool> computed_once{false}; // ev_done has been recorded at least once (the inflate-ahead thread waits for it on ITS streams)
+	std::mutex spare_mu; // (spare_held: the caller's thread and a thread that releases the staging may both hand it on)
 	std::shared_ptr<bz::Job> spare_held; // the job whose inflated-ahead set the last call swapped in: the set that went out is handed on behind this sample's compute
 	std::mutex prewarm_mu;
 	std::thread bz_prewarm; // CONGA_FLAG_EXPECT_COHORT: gets the second buffer of compressed bytes and the spare output set while the first sample is on
