@@ -189,9 +189,16 @@ def leg(args, env):
         ctx.compute()
         ctx.sync()
         out["first_compute_ms"] = round(1e3 * (time.perf_counter() - t0), 1)  # layout + the 10-mer indexes, once per layout
+        first = ctx.fetch_all()   # (the first launch on an index runs without the solo / echo bits: every seed asks its bucket)
         t_with = timed(ctx)
         res = ctx.fetch_all()
         st = [r[3] for r in res]
+        # the launches behind the first one use the bits: the same rows, the same support, at this leg's full size
+        for (d1, u1, _e1, s1), (d0, u0, _e0, s0) in zip(res, first):
+            assert np.array_equal(d1["border_rp"], d0["border_rp"]) and np.array_equal(u1["rp"], u0["rp"]), "support differs with the solo / echo bits"
+            assert (s1.split_elements, s1.split_mappings, s1.split_del_rows, s1.split_dup_rows) == \
+                (s0.split_elements, s0.split_mappings, s0.split_del_rows, s0.split_dup_rows), "split-read counters differ with the solo / echo bits"
+        out["bits_checked"] = "support columns and element / mapping / row counters of every chromosome equal between the first launch (no solo / echo bits) and the later ones"
         # the split-read launch by itself: HIP events around it on the context's stream (CONGA_FLAG_PROFILE)
         ctx.set_profile(True)
         k_ms = []
