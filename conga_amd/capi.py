@@ -38,7 +38,7 @@ KERNEL_NAMES = ("ingest", "depth_tile", "expected_table", "paint", "interval_red
 EXPORTS = (
     "conga_create", "conga_destroy", "conga_strerror", "conga_last_error", "conga_abi_version",
     "conga_device_count", "conga_reset", "conga_chrom_count", "conga_chrom_select", "conga_chrom_begin", "conga_reads_staging", "conga_reads_commit",
-    "conga_reads_bgzf", "conga_reads_bgzf_fd", "conga_reads_bgzf_next_fd", "conga_reads_bgzf_next_table", "conga_reads_bgzf_next_blocks", "conga_reads_bgzf_forget", "conga_release_staging", "conga_inflate_blocks", "conga_host_alloc", "conga_host_free", "conga_sample_reads", "conga_sample_reads_d16", "conga_sample_reads_packed", "conga_packer_create", "conga_packer_destroy", "conga_packer_threads", "conga_pack_bound", "conga_packer_start", "conga_packer_finish", "conga_sample_begin",
+    "conga_reads_bgzf", "conga_reads_bgzf_fd", "conga_reads_bgzf_next_fd", "conga_reads_bgzf_next_table", "conga_reads_bgzf_next_blocks", "conga_reads_bgzf_forget", "conga_release_staging", "conga_inflate_blocks", "conga_host_alloc", "conga_host_free", "conga_sample_reads", "conga_sample_reads_d16", "conga_sample_reads_packed", "conga_packer_create", "conga_packer_destroy", "conga_packer_threads", "conga_pack_bound", "conga_packer_start", "conga_packer_start_v", "conga_packer_finish", "conga_sample_begin",
     "conga_sample_chrom", "conga_sample_fetch",
     "conga_mappability", "conga_intervals", "conga_reference", "conga_satellites", "conga_split_reads_staging",
     "conga_split_reads_commit", "conga_split_support", "conga_chrom_compute",
@@ -181,6 +181,19 @@ class Packer:
         if rc != CONGA_OK:
             raise CongaError(rc, "conga_packer_start")
 
+    def start_v(self, chrom_pos, out, width=0):
+        """conga_packer_start_v: one int32 array per chromosome (what a decoder that works chromosome by chromosome leaves)."""
+        if any(a.dtype != np.int32 or not a.flags.c_contiguous for a in chrom_pos) or out.dtype != np.uint8:
+            raise TypeError("Packer.start_v takes contiguous int32 arrays and a uint8 out")
+        off = np.zeros(len(chrom_pos) + 1, np.uint64)
+        off[1:] = np.cumsum([len(a) for a in chrom_pos], dtype=np.uint64)
+        ptrs = (C.c_void_p * max(len(chrom_pos), 1))(*[a.ctypes.data if len(a) else None for a in chrom_pos])
+        self._keep = (chrom_pos, off, ptrs, out)
+        rc = self._lib.conga_packer_start_v(self._h, C.cast(ptrs, C.c_void_p), off.ctypes.data, len(chrom_pos), int(width), out.ctypes.data, out.nbytes)
+        if rc != CONGA_OK:
+            raise CongaError(rc, "conga_packer_start_v")
+        return off
+
     def finish(self):
         w, ne, nb = C.c_int(0), C.c_size_t(0), C.c_size_t(0)
         rc = self._lib.conga_packer_finish(self._h, C.byref(w), C.byref(ne), C.byref(nb))
@@ -275,6 +288,8 @@ def load():
     L.conga_pack_bound.argtypes = [C.c_uint64, sz]
     L.conga_packer_start.restype = C.c_int
     L.conga_packer_start.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, sz]
+    L.conga_packer_start_v.restype = C.c_int
+    L.conga_packer_start_v.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, sz]
     L.conga_packer_finish.restype = C.c_int
     L.conga_packer_finish.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(sz), C.POINTER(sz)]
     L.conga_sample_begin.restype = C.c_int

@@ -774,6 +774,15 @@ int conga_packer_start(conga_packer *p, const int32_t *pos, const uint64_t *chro
 	return rc == 0 ? CONGA_OK : rc == -4 ? CONGA_ERR_NOMEM : CONGA_ERR_INVALID;
 }
 
+int conga_packer_start_v(conga_packer *p, const int32_t *const *chrom_pos, const uint64_t *chrom_off, int n_chrom, int width, uint8_t *out,
+		size_t out_cap)
+{
+	if (!p)
+		return CONGA_ERR_INVALID;
+	const int rc = p->impl.start_v(chrom_pos, chrom_off, n_chrom, width, out, out_cap);
+	return rc == 0 ? CONGA_OK : rc == -4 ? CONGA_ERR_NOMEM : CONGA_ERR_INVALID;
+}
+
 int conga_packer_finish(conga_packer *p, int *width, size_t *n_esc, size_t *out_bytes)
 {
 	if (!p)

@@ -133,9 +133,11 @@ template <int W> inline void encode_whole_groups(const int32_t *pos, uint64_t i0
 }
 
 // the group that starts at i (a multiple of 8) read by read: chromosome borders among its reads (`forced`, ascending, consumed
-// through *f), the sample's first read, the sample's end (`n`) inside it
-template <int W> inline void encode_group_slow(const int32_t *pos, uint64_t i, uint64_t n, const uint64_t *forced, size_t n_forced, size_t *f, uint8_t *out,
-		std::vector<Exc> &exc)
+// through *f), the sample's first read, the sample's end (`n`) inside it.  `pos` is the array read j is read from as pos[j]; with one
+// array per chromosome (`fbase` != nullptr: fbase[k] is that array for the chromosome whose first read is forced[k], shifted so that the
+// sample's index applies) it moves on as the borders are consumed -- a read is only ever compared with a predecessor of its own chromosome
+template <int W> inline void encode_group_slow(const int32_t *&pos, uint64_t i, uint64_t n, const uint64_t *forced, const int32_t *const *fbase, size_t n_forced,
+		size_t *f, uint8_t *out, std::vector<Exc> &exc)
 {
 	constexpr uint32_t kTop = (1u << W) - 1u;
 	uint32_t v[8];
@@ -148,6 +150,8 @@ template <int W> inline void encode_group_slow(const int32_t *pos, uint64_t i, u
 		bool is_first = j == 0;
 		if (*f < n_forced && forced[*f] == j) {
 			is_first = true;
+			if (fbase)
+				pos = fbase[*f];
 			(*f)++;
 		}
 		const uint32_t d = is_first ? kTop : (uint32_t) pos[j] - (uint32_t) pos[j - 1];
@@ -159,21 +163,22 @@ template <int W> inline void encode_group_slow(const int32_t *pos, uint64_t i, u
 }
 
 // one run [r0, r1) of the sample (r0 a multiple of 8; r1 one too, or the sample's end) at width W; `forced` = indices in [r0, r1)
-// that are a chromosome's first read (ascending)
+// that are a chromosome's first read (ascending); `pos`: the array of read r0 (see encode_group_slow)
 template <int W>
-inline void encode_run(const int32_t *pos, uint64_t r0, uint64_t r1, const uint64_t *forced, size_t n_forced, uint8_t *out, std::vector<Exc> &exc)
+inline void encode_run(const int32_t *pos, uint64_t r0, uint64_t r1, const uint64_t *forced, const int32_t *const *fbase, size_t n_forced, uint8_t *out,
+		std::vector<Exc> &exc)
 {
 	size_t f = 0;
 	uint64_t cur = r0;
 	if (cur == 0 && r1 > 0) { // (the sample's first read has no predecessor)
-		encode_group_slow<W>(pos, 0, r1, forced, n_forced, &f, out, exc);
+		encode_group_slow<W>(pos, 0, r1, forced, fbase, n_forced, &f, out, exc);
 		cur = 8;
 	}
 	while (f < n_forced) {
 		const uint64_t g = forced[f] & ~(uint64_t) 7;
 		if (g > cur)
 			encode_whole_groups<W>(pos, cur, g, out, exc);
-		encode_group_slow<W>(pos, g, r1, forced, n_forced, &f, out, exc);
+		encode_group_slow<W>(pos, g, r1, forced, fbase, n_forced, &f, out, exc);
 		cur = g + 8;
 	}
 	const uint64_t whole_end = r1 & ~(uint64_t) 7;
@@ -182,42 +187,46 @@ inline void encode_run(const int32_t *pos, uint64_t r0, uint64_t r1, const uint6
 		cur = whole_end;
 	}
 	if (cur < r1)
-		encode_group_slow<W>(pos, cur, r1, forced, n_forced, &f, out, exc);
+		encode_group_slow<W>(pos, cur, r1, forced, fbase, n_forced, &f, out, exc);
 }
 
-inline void encode_run_any(int width, const int32_t *pos, uint64_t r0, uint64_t r1, const uint64_t *forced, size_t n_forced, uint8_t *out,
-		std::vector<Exc> &exc)
+inline void encode_run_any(int width, const int32_t *pos, uint64_t r0, uint64_t r1, const uint64_t *forced, const int32_t *const *fbase, size_t n_forced,
+		uint8_t *out, std::vector<Exc> &exc)
 {
 	switch (width) {
-	case 4: return encode_run<4>(pos, r0, r1, forced, n_forced, out, exc);
-	case 5: return encode_run<5>(pos, r0, r1, forced, n_forced, out, exc);
-	case 6: return encode_run<6>(pos, r0, r1, forced, n_forced, out, exc);
-	case 7: return encode_run<7>(pos, r0, r1, forced, n_forced, out, exc);
-	case 8: return encode_run<8>(pos, r0, r1, forced, n_forced, out, exc);
-	case 9: return encode_run<9>(pos, r0, r1, forced, n_forced, out, exc);
-	case 10: return encode_run<10>(pos, r0, r1, forced, n_forced, out, exc);
-	case 11: return encode_run<11>(pos, r0, r1, forced, n_forced, out, exc);
-	case 12: return encode_run<12>(pos, r0, r1, forced, n_forced, out, exc);
-	case 13: return encode_run<13>(pos, r0, r1, forced, n_forced, out, exc);
-	case 14: return encode_run<14>(pos, r0, r1, forced, n_forced, out, exc);
-	case 15: return encode_run<15>(pos, r0, r1, forced, n_forced, out, exc);
-	default: return encode_run<16>(pos, r0, r1, forced, n_forced, out, exc);
+	case 4: return encode_run<4>(pos, r0, r1, forced, fbase, n_forced, out, exc);
+	case 5: return encode_run<5>(pos, r0, r1, forced, fbase, n_forced, out, exc);
+	case 6: return encode_run<6>(pos, r0, r1, forced, fbase, n_forced, out, exc);
+	case 7: return encode_run<7>(pos, r0, r1, forced, fbase, n_forced, out, exc);
+	case 8: return encode_run<8>(pos, r0, r1, forced, fbase, n_forced, out, exc);
+	case 9: return encode_run<9>(pos, r0, r1, forced, fbase, n_forced, out, exc);
+	case 10: return encode_run<10>(pos, r0, r1, forced, fbase, n_forced, out, exc);
+	case 11: return encode_run<11>(pos, r0, r1, forced, fbase, n_forced, out, exc);
+	case 12: return encode_run<12>(pos, r0, r1, forced, fbase, n_forced, out, exc);
+	case 13: return encode_run<13>(pos, r0, r1, forced, fbase, n_forced, out, exc);
+	case 14: return encode_run<14>(pos, r0, r1, forced, fbase, n_forced, out, exc);
+	case 15: return encode_run<15>(pos, r0, r1, forced, fbase, n_forced, out, exc);
+	default: return encode_run<16>(pos, r0, r1, forced, fbase, n_forced, out, exc);
 	}
 }
 
 // The producer's rule for the width (conga_hip.h): the fewest bytes -- differences + 8 per exception -- among the widths that keep
 // exceptions at or below one read in a thousand; taken from every 61st run of 256 reads (a 1x genome: 420 000 of 25.6 M
 // differences looked at, 0.03 ms).  Deterministic: the same positions give the same width.
-inline int choose_width(const int32_t *pos, uint64_t n)
+// (at(i): the position of the sample's read i; asked for in ascending order of i)
+template <class At> inline int choose_width_at(At at, uint64_t n)
 {
 	if (n < 2)
 		return 16;
 	uint64_t need[18] = {0}; // need[b]: sampled differences that want exactly b bits (17: negative or >= 2^16 - 1)
 	uint64_t seen = 0;
 	const uint64_t stride = n > ((uint64_t) 1 << 18) ? 61 * 256 : 256;
-	for (uint64_t a = 1; a < n; a += stride)
+	for (uint64_t a = 1; a < n; a += stride) {
+		uint32_t before = (uint32_t) at(a - 1);
 		for (uint64_t i = a; i < std::min(n, a + 256); i++) {
-			const uint32_t d = (uint32_t) pos[i] - (uint32_t) pos[i - 1];
+			const uint32_t here = (uint32_t) at(i);
+			const uint32_t d = here - before;
+			before = here;
 			// the smallest W with d < 2^W - 1
 			int b = 17;
 			if (d < 0xFFFFu)
@@ -225,6 +234,7 @@ inline int choose_width(const int32_t *pos, uint64_t n)
 			need[b]++;
 			seen++;
 		}
+	}
 	int best = 16;
 	double best_cost = 1e300;
 	uint64_t over = need[17];
@@ -238,6 +248,22 @@ inline int choose_width(const int32_t *pos, uint64_t n)
 		over += need[w];
 	}
 	return best;
+}
+
+inline int choose_width(const int32_t *pos, uint64_t n)
+{
+	return choose_width_at([pos](uint64_t i) { return pos[i]; }, n);
+}
+
+// ... of a sample whose positions lie in one array per chromosome (the same reads give the same width as in one array)
+inline int choose_width(const int32_t *const *chrom_pos, const uint64_t *chrom_off, int n_chrom)
+{
+	int c = 0;
+	return choose_width_at([&](uint64_t i) {
+		while (c + 1 < n_chrom && i >= chrom_off[c + 1])
+			c++;
+		return chrom_pos[c][i - chrom_off[c]];
+	}, chrom_off[n_chrom]);
 }
 
 // A pool of threads that encodes one sample at a time.  start() returns at once; finish() waits and puts the exception lists behind
@@ -287,34 +313,54 @@ public:
 	// -> 0, or -1: arguments, -4: out_cap cannot hold the differences
 	int start(const int32_t *pos, const uint64_t *chrom_off, int n_chrom, int width, uint8_t *out, size_t out_cap)
 	{
+		return start_any(pos, nullptr, chrom_off, n_chrom, width, out, out_cap);
+	}
+	// the same for positions that lie in one array per chromosome: chrom_pos[c][0 .. chrom_off[c + 1] - chrom_off[c]) (what a decoder
+	// that works chromosome by chromosome leaves; chrom_pos[c] of a chromosome without reads is not looked at)
+	int start_v(const int32_t *const *chrom_pos, const uint64_t *chrom_off, int n_chrom, int width, uint8_t *out, size_t out_cap)
+	{
+		if (!chrom_pos && n_chrom > 0)
+			return -1;
+		return start_any(nullptr, chrom_pos, chrom_off, n_chrom, width, out, out_cap);
+	}
+
+private:
+	int start_any(const int32_t *pos, const int32_t *const *chrom_pos, const uint64_t *chrom_off, int n_chrom, int width, uint8_t *out, size_t out_cap)
+	{
 		if (!chrom_off || n_chrom < 0 || chrom_off[0] != 0 || !out || busy_)
 			return -1;
 		for (int c = 0; c < n_chrom; c++)
-			if (chrom_off[c + 1] < chrom_off[c])
+			if (chrom_off[c + 1] < chrom_off[c] || (chrom_pos && chrom_off[c + 1] > chrom_off[c] && !chrom_pos[c]))
 				return -1;
 		const uint64_t n = chrom_off[n_chrom];
-		if ((n && !pos) || n >= 0xFFFFFFF0ull || (width != 0 && (width < 4 || width > 16)))
+		if ((n && !pos && !chrom_pos) || n >= 0xFFFFFFF0ull || (width != 0 && (width < 4 || width > 16)))
 			return -1;
 		if (width == 0)
-			width = choose_width(pos, n);
+			width = chrom_pos ? choose_width(chrom_pos, chrom_off, n_chrom) : choose_width(pos, n);
 		const size_t d_bytes = (size_t) ((n + 7) / 8) * (size_t) width;
 		if (((d_bytes + 15) & ~(size_t) 15) + 64 > out_cap)
 			return -4;
 		std::vector<uint64_t> forced;
+		std::vector<const int32_t *> fbase;
 		for (int c = 0; c < n_chrom; c++)
-			if (chrom_off[c + 1] > chrom_off[c])
+			if (chrom_off[c + 1] > chrom_off[c]) {
 				forced.push_back(chrom_off[c]);
+				// the chromosome's array as the sample's index sees it: element chrom_off[c] is its first read (an address computed as an
+				// integer; only elements of the chromosome's own index range are ever read through it)
+				fbase.push_back(chrom_pos ? reinterpret_cast<const int32_t *>(reinterpret_cast<uintptr_t>(chrom_pos[c]) - (uintptr_t) (4 * chrom_off[c])) : pos);
+			}
 		{
 			// (a thread that slept through the sample before wakes up whenever it likes, finds nothing left and goes back to sleep: it
 			// reads these fields meanwhile -- they change under the lock, with no thread inside its loop)
 			std::unique_lock<std::mutex> lk(mu_);
 			done_cv_.wait(lk, [&] { return active_ == 0; });
-			pos_ = pos;
+			gather_ = chrom_pos != nullptr;
 			n_ = n;
 			width_ = width;
 			out_ = out;
 			out_cap_ = out_cap;
 			forced_.swap(forced);
+			fbase_.swap(fbase);
 			n_runs_ = (size_t) ((n + kRun - 1) / kRun);
 			if (exc_.size() < n_runs_)
 				exc_.resize(n_runs_);
@@ -328,6 +374,7 @@ public:
 		return 0;
 	}
 
+public:
 	// -> 0, -1: nothing was started, -4: the exceptions do not fit behind the differences in out_cap
 	int finish(int *width, size_t *n_esc, size_t *out_bytes)
 	{
@@ -389,8 +436,11 @@ private:
 					break;
 				const uint64_t r0 = (uint64_t) r * kRun, r1 = std::min(n_, r0 + kRun);
 				const auto f0 = std::lower_bound(forced_.begin(), forced_.end(), r0), f1 = std::lower_bound(f0, forced_.end(), r1);
+				const size_t k0 = (size_t) (f0 - forced_.begin());
+				// the array read r0 lies in: that of the last chromosome that begins at or before it (forced_[0] == 0 whenever there are reads)
+				const int32_t *at_r0 = fbase_[(f0 != forced_.end() && *f0 == r0) ? k0 : k0 - 1];
 				exc_[r].clear();
-				encode_run_any(width_, pos_, r0, r1, forced_.data() + (f0 - forced_.begin()), (size_t) (f1 - f0), out_, exc_[r]);
+				encode_run_any(width_, at_r0, r0, r1, forced_.data() + k0, gather_ ? fbase_.data() + k0 : nullptr, (size_t) (f1 - f0), out_, exc_[r]);
 				mine++;
 			}
 			{
@@ -414,12 +464,13 @@ private:
 	size_t left_ = 0, n_runs_ = 0;
 	int active_ = 0;
 	std::atomic<size_t> next_{0};
-	const int32_t *pos_ = nullptr;
+	bool gather_ = false;
 	uint64_t n_ = 0;
 	int width_ = 16;
 	uint8_t *out_ = nullptr;
 	size_t out_cap_ = 0;
-	std::vector<uint64_t> forced_;
+	std::vector<uint64_t> forced_;        // first read of every chromosome that has reads
+	std::vector<const int32_t *> fbase_;  // ... and the array its reads are read from, indexed by the sample's read index
 	std::vector<std::vector<Exc>> exc_;
 };
 

@@ -348,7 +348,119 @@ struct kept_engine {
 	bool last_sample = false; // no BAM behind this one: the pinned staging can go while the context computes
 	bool expect_cohort = false; // three samples or more: their bytes will be named ahead (read_bam_cohort)
 	std::atomic<conga_ctx *> early_ctx{nullptr}; // the context as soon as it exists (the first sample's run makes it on a thread of its own)
+	bed_index dels_bed, dups_bed, map_bed; // --dels / --dups / --mappability as parsed for the first sample
+	bool beds_loaded = false;
+	// the producer of the packed hand-over and its pinned buffers (hand_over_packed: further samples from the host decoders)
+	conga_packer *packer = nullptr;
+	uint8_t *packed_pin = nullptr, *mapq_pin = nullptr;
+	size_t packed_cap = 0, mapq_cap = 0;
 };
+
+// count_reads_bam's tuples of a whole sample, one array per chromosome of the context: where the source holds them (a tuple
+// container's mapping) or in vectors of its own (a BAM through the host decoders)
+struct whole_sample {
+	std::vector<const int32_t *> pos;
+	std::vector<const uint8_t *> mapq;
+	std::vector<uint64_t> off;
+	std::vector<std::vector<int32_t>> own_pos;
+	std::vector<std::vector<uint8_t>> own_mapq;
+};
+
+// count_reads_bam (bam_data.c:192-221) for every chromosome of a FURTHER sample of a cohort at once, host decoders: the positions go
+// through the library's producer (conga_packer_start_v: host threads turn them into differences of a few bits in pinned memory, 1.25
+// bytes per read at 1x instead of 4) and over the link in one copy (conga_sample_reads_packed) -- no staging ring, no pass over the
+// tuples on this thread.  false: not this way (a sample whose positions are not differences of
+// sorted ones, no pinned memory to be had) -- the ring, chromosome by chromosome, as for the first sample.  `ws` must live until the
+// compute's sync.
+bool hand_over_packed(conga_ctx *ctx, kept_engine *keep, read_source *src, const parameters *params, const std::vector<chrom_job *> &mine,
+		whole_sample *ws)
+{
+	const auto t0 = std::chrono::steady_clock::now();
+	auto ms_since = [](std::chrono::steady_clock::time_point t) {
+		return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+	};
+	const size_t nc = mine.size();
+	ws->pos.assign(nc, nullptr);
+	ws->mapq.assign(nc, nullptr);
+	ws->off.assign(nc + 1, 0);
+	ws->own_pos.resize(nc);
+	ws->own_mapq.resize(nc);
+	const int threads = std::max(1, usable_cpus() / reader_share());
+	std::string err;
+	for (size_t i = 0; i < nc; i++) {
+		size_t n = 0;
+		if (!src->whole(mine[i]->chr_index_bam, mine[i]->L, &ws->pos[i], &ws->mapq[i], &n, &err)) {
+			if (err.empty() && src->read_all(mine[i]->chr_index_bam, mine[i]->L, threads, &ws->own_pos[i], &ws->own_mapq[i], &err)) {
+				ws->pos[i] = ws->own_pos[i].data();
+				ws->mapq[i] = ws->own_mapq[i].data();
+				n = ws->own_pos[i].size();
+			} else if (!err.empty())
+				print_error("[CONGA INPUT ERROR] " + err);
+			else { // a source that is read front to back (a BAM without an index, a small one): the records as they come
+				if (!src->begin(mine[i]->chr_index_bam, mine[i]->L, &err)) {
+					fprintf(stderr, "Error: Iterator cannot be loaded (bam_itr_queryi)\n");
+					exit(1);
+				}
+				constexpr size_t kAtOnce = (size_t) 1 << 20;
+				for (;;) {
+					read_batch b;
+					if (!src->next(kAtOnce, &b, &err))
+						print_error("[CONGA INPUT ERROR] " + err);
+					ws->own_pos[i].insert(ws->own_pos[i].end(), b.pos, b.pos + b.n);
+					ws->own_mapq[i].insert(ws->own_mapq[i].end(), b.mapq, b.mapq + b.n);
+					if (b.n < kAtOnce)
+						break;
+				}
+				ws->pos[i] = ws->own_pos[i].data();
+				ws->mapq[i] = ws->own_mapq[i].data();
+				n = ws->own_pos[i].size();
+			}
+		}
+		ws->off[i + 1] = ws->off[i] + n;
+	}
+	const double ms_arrays = ms_since(t0);
+	const uint64_t total = ws->off[nc];
+	if (!keep->packer && !(keep->packer = conga_packer_create(std::min(16, threads))))
+		return false;
+	// (room for one exception in sixteen reads: a position-sorted sample has one in thousands at the width the producer picks)
+	const size_t need = conga_pack_bound(total, (size_t) (total / 16) + 1024);
+	if (need > keep->packed_cap) {
+		conga_host_free(ctx, keep->packed_pin);
+		keep->packed_cap = need + need / 8; // (samples of a cohort differ a little)
+		if (!(keep->packed_pin = (uint8_t *) conga_host_alloc(ctx, keep->packed_cap))) {
+			keep->packed_cap = 0;
+			return false;
+		}
+	}
+	const bool need_mapq = params->mq_threshold >= 0; // (otherwise the bytes are never looked at: include/conga_hip.h)
+	if (need_mapq && total > keep->mapq_cap) {
+		conga_host_free(ctx, keep->mapq_pin);
+		keep->mapq_cap = (size_t) total + (size_t) total / 8;
+		if (!(keep->mapq_pin = (uint8_t *) conga_host_alloc(ctx, keep->mapq_cap))) {
+			keep->mapq_cap = 0;
+			return false;
+		}
+	}
+	const auto t1 = std::chrono::steady_clock::now();
+	if (conga_packer_start_v(keep->packer, ws->pos.data(), ws->off.data(), (int) nc, 0, keep->packed_pin, keep->packed_cap) != CONGA_OK)
+		return false;
+	if (need_mapq) // beside the encode
+		for (size_t i = 0; i < nc; i++)
+			if (ws->off[i + 1] > ws->off[i])
+				memcpy(keep->mapq_pin + ws->off[i], ws->mapq[i], (size_t) (ws->off[i + 1] - ws->off[i]));
+	int width = 0;
+	size_t n_esc = 0, bytes = 0;
+	if (conga_packer_finish(keep->packer, &width, &n_esc, &bytes) != CONGA_OK)
+		return false; // (more exceptions than fit: not a sorted sample -- through the ring the engine says what is wrong with it)
+	const double ms_encode = ms_since(t1);
+	engine_check(ctx, conga_sample_reads_packed(ctx, keep->packed_pin, width, nullptr, nullptr, n_esc, need_mapq ? keep->mapq_pin : nullptr,
+			ws->off.data(), (int) nc), "conga_sample_reads_packed");
+	if (knobs().timing)
+		fprintf(stderr, "\n[timing] packed hand-over: %llu reads of %zu chromosomes, arrays %.1f ms, conga_packer (%d threads) %.1f ms -> %d-bit differences, "
+				"%zu exceptions, %.1f MB over the link (%.1f MB as int32)\n", (unsigned long long) total, nc, ms_arrays, conga_packer_threads(keep->packer),
+				ms_encode, width, n_esc, (double) (bytes + (need_mapq ? total : 0)) / 1e6, (double) total * (need_mapq ? 5 : 4) / 1e6);
+	return true;
+}
 
 std::string layout_key_of(const std::vector<chrom_job *> &mine)
 {
@@ -524,11 +636,17 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 		err.clear();
 	}
 	need_ctx();
-	if (same_layout && gpu_counts.empty())
+	whole_sample ws; // (handed over as it lies: stays until the compute below is through)
+	// (only where the chromosome loop below would decode on the host: an indexed BAM whose whole stretch was refused above -- too large
+	// for one call -- still goes up chromosome by chromosome, count_reads_bam)
+	const bool host_decoders = gpu_bam == 0 || src->index_path().empty();
+	const bool packed_done = same_layout && gpu_counts.empty() && keep && !split_reads && knobs().host_packed && host_decoders && !mine.empty()
+			&& hand_over_packed(ctx, keep, src, params, mine, &ws);
+	if (same_layout && gpu_counts.empty() && !packed_done)
 		engine_check(ctx, conga_sample_begin(ctx), "conga_sample_begin"); // (host decoders: the staging ring, chromosome by chromosome)
 	for (size_t job_index = 0; job_index < mine.size(); job_index++) {
 		chrom_job *job = mine[job_index];
-		const bool on_gpu = !gpu_counts.empty(); // opened, equipped and filled above: only the progress text is left
+		const bool on_gpu = !gpu_counts.empty() || packed_done; // opened, equipped and filled above: only the progress text is left
 		progress out = {buffered ? &job->messages : nullptr};
 		job->counts_pending = !counts_known_now;
 		if (!buffered && !job->messages.empty()) {
@@ -554,7 +672,8 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 				hand_over_reference(job);
 		}
 		out.say("\n-->counting reads");
-		const int64_t cnt_reads = on_gpu ? (int64_t) gpu_counts[job_index]
+		const int64_t cnt_reads = packed_done ? (int64_t) (ws.off[job_index + 1] - ws.off[job_index])
+				: on_gpu ? (int64_t) gpu_counts[job_index]
 				: count_reads_bam(ctx, src, job->chr_index_bam, L, split_reads, (int) job_index);
 		if (counts_known_now)
 			out.say(" (%lld reads, %ld split-reads)\n", (long long) cnt_reads, 0L); // every record counts, no split reads
@@ -802,8 +921,13 @@ int cohort_pipeline(parameters *params, sonic *this_sonic, const std::vector<std
 		cleaner.join();
 	params->outdir = outdir;
 	params->outprefix = outprefix;
-	if (keep.ctx && knobs().clean_exit)
+	if (keep.packer)
+		conga_packer_destroy(keep.packer); // (its threads)
+	if (keep.ctx && knobs().clean_exit) {
+		conga_host_free(keep.ctx, keep.packed_pin);
+		conga_host_free(keep.ctx, keep.mapq_pin);
 		conga_destroy(keep.ctx);
+	}
 	return 0;
 }
 
@@ -842,13 +966,19 @@ int read_bam_with(parameters *params, sonic *this_sonic, kept_engine *keep, plan
 	std::unique_ptr<read_source> src(pre && pre->src ? pre->src.release() : open_reads(params->bam_file, &err));
 	if (!src)
 		print_error(err);
-	bed_index dels_bed, dups_bed, map_bed;
-	if (params->have_dels && !load_bed(params->del_file, false, &dels_bed))
-		print_error("[CONGA INPUT ERROR] Unable to open file " + params->del_file + " in read mode.");
-	if (params->have_dups && !load_bed(params->dup_file, false, &dups_bed))
-		print_error("[CONGA INPUT ERROR] Unable to open file " + params->dup_file + " in read mode.");
-	if (params->have_map && !load_bed(params->mappability_file, true, &map_bed))
-		print_error("[CONGA INPUT ERROR] Unable to open file " + params->mappability_file + " in read mode.");
+	// (a cohort's samples share the three files: parsed for the first one, kept with the engine -- a mappability track is millions of rows)
+	bed_index own_dels, own_dups, own_map;
+	bed_index &dels_bed = keep ? keep->dels_bed : own_dels, &dups_bed = keep ? keep->dups_bed : own_dups, &map_bed = keep ? keep->map_bed : own_map;
+	if (!keep || !keep->beds_loaded) {
+		if (params->have_dels && !load_bed(params->del_file, false, &dels_bed))
+			print_error("[CONGA INPUT ERROR] Unable to open file " + params->del_file + " in read mode.");
+		if (params->have_dups && !load_bed(params->dup_file, false, &dups_bed))
+			print_error("[CONGA INPUT ERROR] Unable to open file " + params->dup_file + " in read mode.");
+		if (params->have_map && !load_bed(params->mappability_file, true, &map_bed))
+			print_error("[CONGA INPUT ERROR] Unable to open file " + params->mappability_file + " in read mode.");
+		if (keep)
+			keep->beds_loaded = true;
+	}
 	const double ms_inputs = ms_since(t_start);
 
 	// ---- chromosome selection (bam_data.c:269-291) and the known SVs of each (likelihood.c:319-331)

@@ -20,6 +20,8 @@ struct host_knobs {
 	bool check_table = false;    // CONGA_BGZF_CHECK_TABLE: read the block table from the file as well and compare with the engine's
 	long parallel_min_kb = -1;   // CONGA_BAM_PARALLEL_MIN_KB: from this size on the block table is walked in parts (-1: default)
 	bool bed_literal = false;    // CONGA_BED_LITERAL: the reference-literal fgets / strtok BED reader
+	bool host_packed = true;     // CONGA_HOST_PACKED=0: a cohort's further samples from the host decoders go through the staging ring,
+	                             // chromosome by chromosome, instead of conga_packer_* + conga_sample_reads_packed (tests compare the two)
 };
 
 inline const host_knobs &knobs()
@@ -47,6 +49,8 @@ inline const host_knobs &knobs()
 		if (const char *e = getenv("CONGA_BAM_PARALLEL_MIN_KB"))
 			h.parallel_min_kb = atol(e);
 		h.bed_literal = getenv("CONGA_BED_LITERAL") != nullptr;
+		if (const char *e = getenv("CONGA_HOST_PACKED"))
+			h.host_packed = atoi(e) != 0;
 		return h;
 	}();
 	return k;

@@ -86,6 +86,13 @@ public:
 	{
 		return false;
 	}
+	// The same records where they already lie as arrays (a container that holds them so): valid until the source goes.  false with an
+	// empty *err: this source has no such arrays -- read_all() or iterate.  (Position order is taken for granted when the ends are cut
+	// to [0, chrom_len): the engine refuses reads that are out of order.)
+	virtual bool whole(int tid, int64_t chrom_len, const int32_t **pos, const uint8_t **mapq, size_t *n, std::string *err)
+	{
+		return false;
+	}
 	// What conga_reads_bgzf (include/conga_hip.h) needs to decode the same records on the GPU: the stretch of the file that
 	// holds the targets (in the order of their chromosomes in the context), as it is, the table of its BGZF blocks, and start
 	// points from the index's linear offsets.  false with an empty *err: not

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define CONGA_ABI_VERSION 7
+#define CONGA_ABI_VERSION 8
 
 typedef struct conga_ctx conga_ctx;
 
@@ -231,7 +231,8 @@ int conga_intervals(conga_ctx *ctx, char type, const int32_t *start, const int32
  * copy runs at the PCIe link's rate with no staging copy; pageable memory works, slower.
  * The hand-over is double-buffered: called behind a conga_chrom_compute, it leaves that compute's inputs and results alone --
  * the tuples go into a second pair of buffers on a stream of their own -- so that ONE context pipelines a cohort:
- *     conga_sample_reads(k + 1);  conga_sample_fetch(k);  conga_chrom_compute();      (the copy beside kernels and fetch)  The tuple-space formulation's guard against a wrapping `short` depth counter runs on the
+ *     conga_sample_reads(k + 1);  conga_sample_fetch(k);  conga_chrom_compute();      (the copy beside kernels and fetch)
+ * The tuple-space formulation's guard against a wrapping `short` depth counter runs on the
  * device for such reads (see CONGA_FLAG_MATERIALIZE_DEPTH): a sample that needs the dense kernels is recomputed with
  * them inside the fetch (or conga_sync) that follows -- a caller that reads the records on the device
  * (CONGA_FLAG_RESULTS_ON_DEVICE) calls conga_sync() first.
@@ -280,6 +281,11 @@ void conga_packer_destroy(conga_packer *p);
 int conga_packer_threads(const conga_packer *p); /* host threads of its pool */
 size_t conga_pack_bound(uint64_t n_reads, size_t max_esc);
 int conga_packer_start(conga_packer *p, const int32_t *pos, const uint64_t *chrom_off, int n_chrom, int width, uint8_t *out, size_t out_cap);
+/* ... for a decoder that leaves one array per chromosome (the loop of read_bam, bam_data.c:269-339, calls count_reads_bam once per
+ * chromosome): chrom_pos[c] holds chromosome c's chrom_off[c + 1] - chrom_off[c] positions (not looked at where that is 0).  The bytes
+ * written are those conga_packer_start writes for the same reads in one array. */
+int conga_packer_start_v(conga_packer *p, const int32_t *const *chrom_pos, const uint64_t *chrom_off, int n_chrom, int width, uint8_t *out,
+		size_t out_cap);
 int conga_packer_finish(conga_packer *p, int *width, size_t *n_esc, size_t *out_bytes);
 int conga_sample_begin(conga_ctx *ctx);
 int conga_sample_chrom(conga_ctx *ctx, int index);

@@ -683,6 +683,76 @@ def test_cli_cohort_keeps_the_engine_and_every_byte(tmp_path, decode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mq", [None, 20])
+def test_cli_cohort_further_samples_from_the_host_go_packed_and_keep_every_byte(tmp_path, mq):
+    """The seam is count_reads_bam (bam_data.c:192-221).  A cohort's further samples that are decoded on the host -- tuple containers,
+    BAMs with CONGA_GPU_BAM=0 -- are handed over whole: conga_packer_start_v (one position array per chromosome, as the container /
+    the decoders leave them) -> conga_sample_reads_packed, instead of the staging ring chromosome by chromosome.  Every file is byte
+    for byte that of the ring route (CONGA_HOST_PACKED=0); samples with reads outside [0, L), with an empty chromosome, and one whose
+    positions are out of order (refused alike by both routes)."""
+    d = str(tmp_path)
+    specs = [("1", 500_000, 30, 8), ("2", 300_000, 20, 5), ("3", 200_000, 12, 3)]
+    cs = [synth.make_chrom(n, L, cov=1.0, n_dels=nd, n_dups=nu, mappability=True, gaps=False) for n, L, nd, nu in specs]
+    formats.write_annotation(os.path.join(d, "a.cga"), [(c.name, c.length, c.gc, [], []) for c in cs])
+    synth.write_bed(os.path.join(d, "dels.bed"), [(c.name, s, e) for c in cs for s, e in zip(c.del_start, c.del_end)])
+    synth.write_bed(os.path.join(d, "dups.bed"), [(c.name, s, e) for c in cs for s, e in zip(c.dup_start, c.dup_end)])
+    samples = []
+    for k, cov in enumerate([1.0, 3.0, 0.5, 2.0, 1.5]):
+        chroms = []
+        for ci, c in enumerate(cs):
+            rng = np.random.default_rng([k, ci, 9])
+            pos, mapq = synth.make_reads(c.length, c.gc, c.step, cov, 100, rng)
+            if k == 2 and ci == 1:
+                pos, mapq = pos[:0], mapq[:0]                                   # a chromosome without a read
+            past = k in (2, 3) and ci == 0                                      # reads at / behind the annotated length (the file says L + 100)
+            if past:
+                pos = np.concatenate([pos, np.array([c.length, c.length + 5], np.int32)])
+                mapq = np.concatenate([mapq, np.array([60, 60], np.uint8)])
+            if k == 2 and ci == 2:                                              # a container may hold anything: reads in front of base 0
+                pos = np.concatenate([np.array([-7, -1], np.int32), pos])
+                mapq = np.concatenate([np.array([60, 60], np.uint8), mapq])
+            chroms.append((c.name, c.length + (100 if past else 0), pos, mapq))
+        if k % 2 == 0:
+            formats.write_tuples(os.path.join(d, "s%d.ctp" % k), "S%d" % k, chroms, aligned=k != 4)   # (the last one: CONGATP1, unaligned arrays)
+            samples.append("s%d.ctp" % k)
+        else:
+            formats.write_bam(os.path.join(d, "s%d.bam" % k), "S%d" % k, chroms, index=True, block_payload=20_000, unplaced=2)
+            samples.append("s%d.bam" % k)
+    with open(os.path.join(d, "list.txt"), "w") as f:
+        f.write("".join("%s\n" % s_ for s_ in samples))
+    common = ["--ref", "r.fa", "--sonic", "a.cga", "--dels", "dels.bed", "--dups", "dups.bed"] + (["--mq", str(mq)] if mq is not None else [])
+    outs = {}
+    for packed in ("1", "0"):
+        env = dict(os.environ, CONGA_GPU_BAM="0", CONGA_TIMING="1", CONGA_HOST_PACKED=packed)
+        r = subprocess.run([CONGA, "--cohort", "list.txt", "--out", "p" + packed] + common, cwd=d, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert r.stderr.count("[timing] packed hand-over:") == (4 if packed == "1" else 0), r.stderr[-3000:]   # every sample but the first
+        outs[packed] = r.stderr
+    for k in range(len(samples)):
+        stem = samples[k][:-4] if samples[k].endswith(".bam") else samples[k]   # (<--out>.<file name without .bam>)
+        for kind in ("svs", "dels", "dups"):
+            got = open(os.path.join(d, "p1.%s_%s.bed" % (stem, kind)), "rb").read()
+            want = open(os.path.join(d, "p0.%s_%s.bed" % (stem, kind)), "rb").read()
+            assert got == want and (kind != "dels" or got.count(b"\n") > 5), (k, kind)
+    # the progress lines too: the reads counted per chromosome are the ring route's
+    counted = lambda text: [ln for ln in text.splitlines() if "-->counting reads" in ln]   # noqa: E731
+    assert counted(outs["1"]) == counted(outs["0"]) and len(counted(outs["1"])) == 15
+    assert open(os.path.join(d, "p1.s0.ctp_dels.bed"), "rb").read() != open(os.path.join(d, "p1.s4.ctp_dels.bed"), "rb").read()
+    # positions out of order: both routes end with the engine's refusal
+    bad = cs[0]
+    rng = np.random.default_rng(77)
+    pos, mapq = synth.make_reads(bad.length, bad.gc, bad.step, 1.0, 100, rng)
+    pos[1000], pos[1001] = pos[1001] + 300, pos[1000]
+    formats.write_tuples(os.path.join(d, "bad.ctp"), "BAD", [(bad.name, bad.length, pos, mapq)] + [(c.name, c.length, c.pos, c.mapq) for c in cs[1:]])
+    with open(os.path.join(d, "list2.txt"), "w") as f:
+        f.write("s0.ctp\nbad.ctp\n")
+    for packed in ("1", "0"):
+        r = subprocess.run([CONGA, "--cohort", "list2.txt", "--out", "q" + packed] + common, cwd=d, capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, CONGA_HOST_PACKED=packed))
+        assert r.returncode != 0 and "out of position order" in r.stderr, (packed, r.stderr[-2000:])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,decode", [(2, "gpu_ahead"), (3, "gpu"), (2, "host"), (7, "gpu_ahead")])
 def test_cli_cohort_gpus_deals_the_samples_and_keeps_every_byte(tmp_path, n, decode):
     """`--cohort list --gpus N`: the samples are dealt round robin to N pipelines -- one kept engine context, its layout and its

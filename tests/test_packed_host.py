@@ -92,6 +92,11 @@ def test_c_producer_writes_what_the_numpy_encoder_writes(threads):
                 assert (w, n_esc) == (w2, len(ei)) and nbytes == ((len(bits) + 15) & ~15) + 8 * len(ei), (trial, width)
                 assert np.array_equal(out[:nbytes], want[:nbytes]), (trial, width)
                 assert (out[pk.bound(n, n):] == 0xAB).all()               # nothing behind what the bound promises
+                # conga_packer_start_v -- one array per chromosome, each an allocation of its own -- writes the same bytes
+                parts = [pos[int(off[c]):int(off[c + 1])].copy() for c in range(len(off) - 1)]
+                out_v = np.full(len(out), 0xAB, np.uint8)
+                assert np.array_equal(pk.start_v(parts, out_v, width), off)
+                assert pk.finish() == (w, n_esc, nbytes) and np.array_equal(out_v[:nbytes], out[:nbytes]), (trial, width)
             # width 0: the producer's rule on a sample of the differences -- exceptions stay rare, and the positions come back
             pk.start(pos, off, out, 0)
             w, n_esc, nbytes = pk.finish()
@@ -99,6 +104,9 @@ def test_c_producer_writes_what_the_numpy_encoder_writes(threads):
             at = ((n + 7) // 8 * w + 15) & ~15
             ei, ep = out[at:at + 4 * n_esc].view("<u4"), out[at + 4 * n_esc:at + 8 * n_esc].view("<i4")
             assert np.array_equal(decode(out[:(n + 7) // 8 * w].copy(), w, ei, ep, n), pos)
+            out_v = np.full(len(out), 0xAB, np.uint8)
+            pk.start_v([pos[int(off[c]):int(off[c + 1])].copy() for c in range(len(off) - 1)], out_v, 0)
+            assert pk.finish() == (w, n_esc, nbytes) and np.array_equal(out_v[:nbytes], out[:nbytes])   # (the same width from the same reads)
 
 
 def test_c_producer_picks_the_bench_widths_and_refuses_what_does_not_fit():
@@ -139,7 +147,10 @@ int main()
 		for (uint64_t i = 0; i < n; i++) { p += (int32_t) (i * 2654435761u %% 211u); if (i %% 9001 == 9000) p += 400000; pos[i] = p; }
 		uint64_t off[4] = {0, n / 3, n / 3, n};
 		std::vector<uint8_t> out(conga_pack::bound(n, n));
-		if (pk.start(pos.data(), off, 3, rep %% 2 ? 0 : 9, out.data(), out.size()) != 0) return 2;
+		std::vector<int32_t> a(pos.begin(), pos.begin() + n / 3), b(pos.begin() + n / 3, pos.end());   // (every third sample: one array per chromosome)
+		const int32_t *parts[3] = {a.data(), nullptr, b.data()};
+		if ((rep %% 3 == 2 ? pk.start_v(parts, off, 3, rep %% 2 ? 0 : 9, out.data(), out.size())
+				: pk.start(pos.data(), off, 3, rep %% 2 ? 0 : 9, out.data(), out.size())) != 0) return 2;
 		int w = 0; size_t ne = 0, nb = 0;
 		if (pk.finish(&w, &ne, &nb) != 0 || ne < 2) return 3;
 		// decode: the positions come back

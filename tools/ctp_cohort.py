@@ -33,9 +33,11 @@ try:
         dt, err = e2e_bench.run_conga(["--cohort", "list.txt", "--out", "x", "--ref", "r.fa", "--sonic", "a.cga", "--dels", "dels.bed"], d, dict(CONGA_TIMING="1"))
         done = [float(x) for x in re.findall(r"cohort: sample \d+ of \d+ is done ([0-9.]+) ms", err)]
         print("run %d: wall %.3f s; sample ends (ms): %s; per further sample %.1f ms" % (rep, dt, " ".join("%.0f" % x for x in done), (done[-1] - done[0]) / max(len(done) - 1, 1)))
-        for line in err.splitlines():
-            if "[timing] open + BED" in line:
-                print("   " + line[:260])
-                break
+        lines = [ln for ln in err.splitlines() if "[timing] packed hand-over" in ln]
+        for ln in lines[2:3]:
+            print("   " + ln[:300])
+        lines = [ln for ln in err.splitlines() if "[timing] open + BED" in ln]
+        for ln in lines[:1] + lines[3:4]:   # the first sample's and a later one's
+            print("   " + ln[:300])
 finally:
     shutil.rmtree(d, ignore_errors=True)
