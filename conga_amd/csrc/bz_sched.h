@@ -17,7 +17,9 @@
 // VERDICT found that the scheduler (a context-wide and a per-job mutex taken nested, five kinds of helper thread) had no test
 // that runs without a GPU and no sanitizer coverage.
 #pragma once
+#include <stdarg.h>
 #include <stddef.h>
+#include <stdio.h>
 #include <stdint.h>
 #include <string.h>
 #include <errno.h>
@@ -42,6 +44,30 @@
 #include "../../include/conga_hip.h"
 
 namespace bz {
+
+// Measurement switch (CONGA_DEBUG=1 CONGA_BGZF_TRACE=1): what happened when, on stderr -- milliseconds of the steady clock (the last
+// five digits), so that lines of several threads and of the caller's own clock can be laid side by side.
+inline std::atomic<bool> &trace_on()
+{
+	static std::atomic<bool> on{false};
+	return on;
+}
+inline void trace(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+inline void trace(const char *fmt, ...)
+{
+	if (!trace_on().load(std::memory_order_relaxed))
+		return;
+	char line[320];
+	const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+	int n = snprintf(line, sizeof line, "[bz %9.2f] ", ms - 100000.0 * (double) (long long) (ms / 100000.0));
+	va_list ap;
+	va_start(ap, fmt);
+	n += vsnprintf(line + n, sizeof line - (size_t) n - 2, fmt, ap);
+	va_end(ap);
+	n = std::min<int>(n, (int) sizeof line - 2);
+	line[n] = '\n';
+	(void) !fwrite(line, 1, (size_t) n + 1, stderr);
+}
 
 // ---- what the pipeline asks of the machine.  Calls may come from the upload thread, its copying threads, a job's inflating
 // thread or the caller's thread, as noted; an implementation keeps whatever per-thread binding its runtime wants in bind().
@@ -554,6 +580,7 @@ public:
 			job.cv.notify_all();
 		};
 		job.t_started = std::chrono::steady_clock::now();
+		trace("job %llu: the upload thread takes it up (%zu bytes)", (unsigned long long) job.ticket, job.n_bytes);
 		if (!m->bind())
 			return give_up("the device cannot be selected", false);
 		m->prewarm_join(); // (the buffers it allocates are about to be looked at)
@@ -573,6 +600,7 @@ public:
 			job.buf = free_buf();
 			buf_owner[job.buf] = self;
 		}
+		trace("job %llu: has device buffer %d", (unsigned long long) job.ticket, job.buf);
 		// the device buffer (grown only: a cohort's samples are of a size) and the batches' events
 		uint8_t *const d_dst = m->up_buffer(job.buf, job.n_bytes + 512);
 		if (!d_dst)
@@ -726,6 +754,7 @@ public:
 		for (std::thread &t : threads)
 			t.join();
 		job.ms_enqueued = ms_since(job.t_started);
+		trace("job %llu: every piece is enqueued%s", (unsigned long long) job.ticket, why.empty() ? "" : " (given up)");
 		job.ms_copy = us_copy / 1e3 / n_threads;
 		job.ms_wait = us_wait / 1e3 / n_threads;
 		{
@@ -763,6 +792,7 @@ public:
 				spare_owner = self;
 			cv.notify_all(); // (the next ticket may be waiting for this one to be out of the way)
 		}
+		trace("job %llu: its inflating thread has the spare output set", (unsigned long long) job.ticket);
 		const auto t0 = std::chrono::steady_clock::now();
 		// room for the table and the stream: the table's own size when the caller brought it, a bound when it grows with the upload
 		size_t room_blocks;
@@ -808,6 +838,7 @@ public:
 						&& m->ahead_launch(job.ev_batch[batch], job.d_bytes, job.blocks.data(), job.out_off.data(), b_done, n, launches);
 				if (launches == 0)
 					job.first_launch_blocks = n;
+				trace("job %llu: inflate launch %d made ahead, %zu blocks (batch %zu of %zu)", (unsigned long long) job.ticket, launches, n, batch + 1, job.n_batches);
 				launches++;
 				b_done = b1;
 			}
@@ -825,6 +856,7 @@ public:
 		// behind this one can start on its way up before the call for this one has even begun (two buffers carry any depth).
 		if (ok) {
 			const bool through = m->ahead_wait();
+			trace("job %llu: its launches are through", (unsigned long long) job.ticket);
 			bool uploaded;
 			{
 				std::unique_lock<std::mutex> lk(job.mu);
@@ -862,6 +894,7 @@ public:
 			job->out_off.reserve(job->cap_blocks);
 		}
 		job->ticket = ++tickets;
+		trace("job %llu: named (%zu bytes)%s", (unsigned long long) job->ticket, n_bytes, now ? ", queued for the upload thread" : ", to be queued later");
 		if (now)
 			enqueue(job);
 		named.push_back(job);

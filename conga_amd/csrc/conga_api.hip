@@ -170,6 +170,8 @@ conga_ctx *conga_create(int device, const conga_opts *opts, int *status)
 	ctx->sched.cfg.no_inflate_ahead = knobs.bgzf_no_inflate_ahead || knobs.bgzf_other_kernel;
 	ctx->sched.cfg.no_table = knobs.bgzf_no_table;
 	ctx->sched.cfg.no_ahead = knobs.bgzf_no_ahead;
+	if (knobs.bgzf_trace)
+		bz::trace_on().store(true);
 	ctx->sched.cfg.timing = knobs.timing;
 	ctx->opts.struct_size = sizeof(conga_opts);
 	ctx->opts.mq_threshold = -1;

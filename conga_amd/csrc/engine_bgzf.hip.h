@@ -85,7 +85,7 @@ int launch_inflate(conga_ctx *ctx, size_t n_blocks, uint32_t lanes, hipStream_t 
 	}
 	TRY(ensure_x2n(ctx));
 	// one resident round of workgroups (8 per CU), blocks round robin over their waves
-	const size_t groups = std::min<size_t>((n_blocks + iw::kWavesPerGroup - 1) / iw::kWavesPerGroup, (size_t) ctx->n_cu * 8);
+	const size_t groups = std::min<size_t>((n_blocks + iw::kWavesPerGroup - 1) / iw::kWavesPerGroup, (size_t) ctx->n_cu * (size_t) ctx->knobs.bgzf_groups_per_cu);
 	// CONGA_BGZF_KERNEL=wave1: round 2's symbol loop (every trip decodes its sixty-four candidates completely), for comparison
 	const bool one_phase = ctx->knobs.bgzf_one_phase;
 	uint32_t *ticket = ctx->knobs.bgzf_round_robin ? nullptr : bz_ticket(ctx, st);
@@ -250,7 +250,7 @@ struct HipMachine final : bz::Machine {
 				&& hipMemsetAsync(ptr<uint8_t>(ctx->d_bz_status2) + first, 0xFF, n, ks) == hipSuccess
 				&& hipStreamWaitEvent(ks, (hipEvent_t) batch_event, 0) == hipSuccess;
 		if (ok) {
-			const size_t groups = std::min<size_t>((n + iw::kWavesPerGroup - 1) / iw::kWavesPerGroup, (size_t) ctx->n_cu * 8);
+			const size_t groups = std::min<size_t>((n + iw::kWavesPerGroup - 1) / iw::kWavesPerGroup, (size_t) ctx->n_cu * (size_t) ctx->knobs.bgzf_groups_per_cu);
 			hipLaunchKernelGGL(iw::bgzf_inflate_wave_kernel<true>, dim3((unsigned) groups), dim3(64 * iw::kWavesPerGroup), 0, ks, (uint32_t) n, d_bytes,
 					ptr<conga_bgzf_block>(ctx->d_bz_blocks2) + first, ptr<uint64_t>(ctx->d_bz_off2) + first, ptr<uint8_t>(ctx->d_bz_out2),
 					ptr<uint32_t>(ctx->d_bz_crc), ptr<uint32_t>(ctx->d_bz_x2n), ptr<uint8_t>(ctx->d_bz_status2) + first,
@@ -366,8 +366,10 @@ void hand_spare_on(conga_ctx *ctx)
 		std::lock_guard<std::mutex> g(ctx->spare_mu);
 		held.swap(ctx->spare_held);
 	}
-	if (held)
+	if (held) {
+		bz::trace("the spare output set is handed on (behind job %llu)", (unsigned long long) held->ticket);
 		ctx->sched.spare_free(held);
+	}
 }
 
 // *inflated: the bytes named ahead came with their block table and are inflated (the launches are enqueued) in what is now the
@@ -401,6 +403,7 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const ByteSource &src, size_t 
 	// The bytes: already on their way when conga_reads_bgzf_next_fd named exactly these, otherwise a job of this call's own
 	// (bz_sched.h: adopt -- the scheduler is `in a call` from here until reads_bgzf_from returns)
 	bool ahead = false;
+	bz::trace("call: begins (%zu bytes)", n_bytes);
 	std::shared_ptr<bz::Job> job = sched.adopt(src, n_bytes, &ahead);
 	const double ms_head_start = ahead ? ms_since(job->t_queued) : 0.0;
 	if ((ctx->opts.flags & CONGA_FLAG_EXPECT_COHORT) && !ctx->bz_prewarmed) {
@@ -415,6 +418,7 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const ByteSource &src, size_t 
 	bool inflated_ahead = false;
 	{
 		const int took = sched.take_inflated(job, blocks, n_blocks, base == 0);
+		bz::trace("call: job %llu taken up (%s)", (unsigned long long) job->ticket, took > 0 ? "inflated ahead: the output sets change places" : took < 0 ? "its launches ahead failed" : "to be launched here");
 		if (took > 0) {
 			std::swap(ctx->d_bz_out, ctx->d_bz_out2);
 			std::swap(ctx->d_bz_blocks, ctx->d_bz_blocks2);
@@ -810,6 +814,7 @@ int reads_bgzf_from(conga_ctx *ctx, const ByteSource &src, size_t n_bytes, const
 		if (flag)
 			ctx->wrap_risk = true;
 	}
+	bz::trace("call: the walks are through");
 	if (timing)
 		fprintf(stderr, "\n[timing] conga_reads_bgzf: %zu blocks, %.1f MB -> %.1f MB, %zu start points, %llu reads: %s %.1f ms, "
 				"%s %.1f ms, walks + checks %.1f ms\n", n_blocks, n_bytes / 1e6, total / 1e6, n_segments, (unsigned long long) n_new,

@@ -125,6 +125,7 @@ int conga_chrom_compute(conga_ctx *ctx)
 	ctx->computed_total = ctx->n_reads_total;
 	HIP_TRY(ctx, hipGetLastError());
 	ctx->computed = true;
+	bz::trace("compute: enqueued");
 	hand_spare_on(ctx); // (this sample's launches are in the queues: the next sample's inflates may follow them -- engine_bgzf.hip.h)
 	return CONGA_OK;
 }

@@ -45,6 +45,8 @@ struct Knobs {
 	bool streams_normal = false;      // CONGA_STREAMS_NORMAL: the context's streams at the default priority, launch streams of their own
 	int tuple_blocks_per_cu = 0;      // CONGA_TUPLE_BLOCKS_PER_CU
 	int depth_tiles_per_block = 0;    // CONGA_DEPTH_TILES_PER_BLOCK
+	int bgzf_groups_per_cu = 8;       // CONGA_BGZF_GROUPS_PER_CU: workgroups (of four waves) an inflate launch puts on a CU, 1 .. 8
+	bool bgzf_trace = false;          // CONGA_BGZF_TRACE: the upload pipeline's events with a clock, on stderr (bz::trace)
 	int split_flags = 0;              // CONGA_SPLIT_FLAGS: 1 = split_map_kernel does not ask the presence bitmaps, 2 = plain unit order
 };
 
@@ -87,6 +89,8 @@ inline Knobs read_knobs()
 	k.streams_normal = getenv("CONGA_STREAMS_NORMAL") != nullptr;
 	k.tuple_blocks_per_cu = num("CONGA_TUPLE_BLOCKS_PER_CU", 0);
 	k.depth_tiles_per_block = num("CONGA_DEPTH_TILES_PER_BLOCK", 0);
+	k.bgzf_trace = getenv("CONGA_BGZF_TRACE") != nullptr;
+	k.bgzf_groups_per_cu = std::max(1, std::min(num("CONGA_BGZF_GROUPS_PER_CU", 8), 8));
 	k.split_flags = num("CONGA_SPLIT_FLAGS", 0);
 	return k;
 }

@@ -63,6 +63,15 @@ uint64_t gpu_bam_min_piece()
 	return (uint64_t) 27000000 * (uint64_t) std::max(1, usable_cpus() / reader_share());
 }
 
+// (measurement switch: the sample loop's events on the clock of the engine's own trace lines, conga_amd/csrc/bz_sched.h)
+void host_trace(const char *what, size_t k = 0)
+{
+	if (!knobs().trace)
+		return;
+	const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+	fprintf(stderr, "[bz %9.2f] cli: %s (sample %zu)\n", ms - 100000.0 * (double) (long long) (ms / 100000.0), what, k);
+}
+
 // count_reads_bam (bam_data.c:192-221), producer side: records go straight into the pinned staging ring.
 // With split reads enabled (--rp and --dups) every record is also handed over whole (split_read.c:206-354).
 // `chrom`: the chromosome of the engine context the records go to (the one begun last in a fresh context; any of them when
@@ -700,6 +709,7 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 		const auto t_compute = now();
 		engine_check(ctx, conga_chrom_compute(ctx), "conga_chrom_compute");
 		engine_check(ctx, conga_sync(ctx), "conga_sync");
+		host_trace("compute + sync returned");
 		wt->ms_compute = ms_since(t_compute);
 		const auto t_fetch = now();
 		for (size_t i = 0; i < mine.size(); i++) {
@@ -887,9 +897,11 @@ int cohort_pipeline(parameters *params, sonic *this_sonic, const std::vector<std
 		params->outprefix = samples[k].second;
 		keep.last_sample = k + 1 == n_samples;
 		fprintf(stderr, "\n[CONGA] sample %zu of %zu: %s\n", k + 1, n_samples, params->bam_file.c_str());
+		host_trace("begins", k + 1);
 		// several contexts (--gpus N) are made per sample; one context is kept from sample to sample
 		const int rc = read_bam_with(params, this_sonic, params->n_gpus == 1 ? &keep : nullptr, mine_now.get());
 		first_sample_done = true;
+		host_trace("files written", k + 1);
 		const auto t_join = std::chrono::steady_clock::now();
 		if (k + 1 < n_samples && planners[k + 1].joinable())
 			planners[k + 1].join();

@@ -20,6 +20,7 @@ struct host_knobs {
 	bool check_table = false;    // CONGA_BGZF_CHECK_TABLE: read the block table from the file as well and compare with the engine's
 	long parallel_min_kb = -1;   // CONGA_BAM_PARALLEL_MIN_KB: from this size on the block table is walked in parts (-1: default)
 	bool bed_literal = false;    // CONGA_BED_LITERAL: the reference-literal fgets / strtok BED reader
+	bool trace = false;          // CONGA_DEBUG=1 CONGA_BGZF_TRACE=1: the sample loop's events with the engine's trace clock (bz_sched.h: trace)
 	bool host_packed = true;     // CONGA_HOST_PACKED=0: a cohort's further samples from the host decoders go through the staging ring,
 	                             // chromosome by chromosome, instead of conga_packer_* + conga_sample_reads_packed (tests compare the two)
 };
@@ -49,6 +50,7 @@ inline const host_knobs &knobs()
 		if (const char *e = getenv("CONGA_BAM_PARALLEL_MIN_KB"))
 			h.parallel_min_kb = atol(e);
 		h.bed_literal = getenv("CONGA_BED_LITERAL") != nullptr;
+		h.trace = getenv("CONGA_BGZF_TRACE") != nullptr && getenv("CONGA_DEBUG") != nullptr && atoi(getenv("CONGA_DEBUG")) != 0;
 		if (const char *e = getenv("CONGA_HOST_PACKED"))
 			h.host_packed = atoi(e) != 0;
 		return h;
