@@ -1,0 +1,5 @@
+set -e
+mkdir -p gpurun_out
+python -m pytest tests -x -q -m gpu > gpurun_out/r04i_gpu_tests.log 2>&1 || { tail -30 gpurun_out/r04i_gpu_tests.log; exit 1; }
+tail -2 gpurun_out/r04i_gpu_tests.log
+bash tools/evidence4.sh r04i
