@@ -38,7 +38,7 @@ KERNEL_NAMES = ("ingest", "depth_tile", "expected_table", "paint", "interval_red
 EXPORTS = (
     "conga_create", "conga_destroy", "conga_strerror", "conga_last_error", "conga_abi_version",
     "conga_device_count", "conga_reset", "conga_chrom_count", "conga_chrom_select", "conga_chrom_begin", "conga_reads_staging", "conga_reads_commit",
-    "conga_reads_bgzf", "conga_reads_bgzf_fd", "conga_reads_bgzf_next_fd", "conga_reads_bgzf_next_table", "conga_reads_bgzf_next_blocks", "conga_reads_bgzf_forget", "conga_release_staging", "conga_inflate_blocks", "conga_host_alloc", "conga_host_free", "conga_sample_reads", "conga_sample_reads_d16", "conga_sample_reads_packed", "conga_packer_create", "conga_packer_destroy", "conga_packer_threads", "conga_pack_bound", "conga_packer_start", "conga_packer_start_v", "conga_packer_finish", "conga_sample_begin",
+    "conga_reads_bgzf", "conga_reads_bgzf_fd", "conga_reads_bgzf_next_fd", "conga_reads_bgzf_next_table", "conga_reads_bgzf_next_blocks", "conga_reads_bgzf_next_go", "conga_reads_bgzf_forget", "conga_release_staging", "conga_inflate_blocks", "conga_host_alloc", "conga_host_free", "conga_sample_reads", "conga_sample_reads_d16", "conga_sample_reads_packed", "conga_packer_create", "conga_packer_destroy", "conga_packer_threads", "conga_pack_bound", "conga_packer_start", "conga_packer_start_v", "conga_packer_finish", "conga_sample_begin",
     "conga_sample_chrom", "conga_sample_fetch",
     "conga_mappability", "conga_intervals", "conga_reference", "conga_satellites", "conga_split_reads_staging",
     "conga_split_reads_commit", "conga_split_support", "conga_chrom_compute",
@@ -262,6 +262,8 @@ def load():
     L.conga_reads_bgzf_next_table.argtypes = [vp, C.c_uint64, C.POINTER(C.POINTER(BgzfBlock)), C.POINTER(sz)]
     L.conga_reads_bgzf_next_blocks.restype = C.c_int
     L.conga_reads_bgzf_next_blocks.argtypes = [vp, C.c_uint64, C.POINTER(BgzfBlock), sz]
+    L.conga_reads_bgzf_next_go.restype = C.c_int
+    L.conga_reads_bgzf_next_go.argtypes = [vp, C.c_uint64]
     L.conga_reads_bgzf_forget.restype = C.c_int
     L.conga_reads_bgzf_forget.argtypes = [vp, C.c_uint64]
     L.conga_release_staging.restype = C.c_int
@@ -542,6 +544,9 @@ class Context:
         b, n = C.POINTER(BgzfBlock)(), C.c_size_t(0)
         self._check(self._lib.conga_reads_bgzf_next_table(self._h, int(ticket), C.byref(b), C.byref(n)))
         return [(b[i].data_off, b[i].data_len, b[i].inflated_len, b[i].crc32) for i in range(n.value)]
+
+    def reads_bgzf_next_go(self, ticket):
+        self._check(self._lib.conga_reads_bgzf_next_go(self._h, int(ticket)))
 
     def reads_bgzf_forget(self, ticket):
         self._check(self._lib.conga_reads_bgzf_forget(self._h, int(ticket)))

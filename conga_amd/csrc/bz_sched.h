@@ -190,6 +190,16 @@ struct Config {
 	bool plain_pread = false;             // measurement switch: pread() straight into the slot
 	bool no_inflate_ahead = false, no_table = false, no_ahead = false;
 	bool timing = false;
+	// A job that gets the output set while its bytes are still on their way: launches that follow the batches as they arrive hide
+	// the inflate behind a SLOW source (a file that is not in the page cache) -- but beside launches of its own job a fast upload
+	// runs at half its rate (28 GB/s against 50, the copy threads waiting for ring slots: profiles/r04j_cohort_two_modes.log), the
+	// next job then finds its bytes a fifth up when ITS turn comes, and the cohort stays at 50 ms per sample instead of 32.  So:
+	// when the rest of the bytes will be up within `ahead_wait_factor` times what the whole job takes to inflate (at the rate they
+	// have come at so far -- a throttled upload included, hence the factor), the job waits for them and is ONE launch; the upload
+	// behind it then runs beside that one launch at full rate and is complete when its own turn comes: one cycle, and the steady
+	// state is the fast one.  0: follow the batches whatever the rate (round 4's rule until its last day).
+	double ahead_wait_factor = 2.0;
+	double inflate_ms_per_gb = 20.0; // of file: 184 GB/s inflated at a ratio of 3.7 (a 1x genome: 1.4 GB, 28 ms)
 };
 
 // One sample's compressed bytes on their way to HBM (the upload thread runs it): host threads copy pieces of the file into the ring
@@ -215,6 +225,7 @@ struct Job {
 	const uint8_t *d_bytes = nullptr; // where the bytes go (set when the job starts)
 	std::string error;
 	std::chrono::steady_clock::time_point t_queued, t_started;
+	std::chrono::steady_clock::time_point t_upload_begin; // the job has its device buffer: its first piece is about to be read (written before `started`)
 	double ms_enqueued = 0, ms_copy = 0, ms_wait = 0; // (timing)
 	int n_threads = 0;
 	// inflate ahead: a thread launches the batches' inflates into the spare output set
@@ -628,6 +639,7 @@ public:
 		{
 			std::lock_guard<std::mutex> g(job.mu);
 			job.d_bytes = d_dst;
+			job.t_upload_begin = std::chrono::steady_clock::now();
 			job.started = true;
 			if (ahead && !job.inflate_asked && !job.adopted && !job.cancel.load()) {
 				job.inflate_asked = inflating = true;
@@ -644,7 +656,8 @@ public:
 		const int n_slots = cfg.n_slots;
 		const size_t piece = job.piece, n_pieces = job.n_pieces, n_bytes = job.n_bytes;
 		std::atomic<size_t> next_piece{0};
-		std::atomic<long long> us_copy{0}, us_wait{0};
+		std::atomic<long long> us_copy{0}, us_wait{0}, us_wait_order{0};
+		std::atomic<int> slow_slot_waits{0};
 		auto worker = [&]() {
 			(void) m->bind();
 			for (;;) {
@@ -664,8 +677,13 @@ public:
 					std::lock_guard<std::mutex> g(job.mu); // (slot_used is written by the upload thread under this lock)
 					first_use = !slot_used[slot];
 				}
+				const auto to_ = std::chrono::steady_clock::now();
+				us_wait_order += (long long) std::chrono::duration<double, std::micro>(to_ - tw).count();
 				// (a slot's first use in this job: the job before may have left its last pieces in the ring)
-				if (!first_use && !m->slot_wait(slot)) {
+				const bool slot_ok = first_use || m->slot_wait(slot);
+				if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - to_).count() > 300.0)
+					slow_slot_waits++;
+				if (!slot_ok) {
 					std::lock_guard<std::mutex> g(job.mu);
 					job.failed = true;
 					job.cv.notify_all();
@@ -707,6 +725,14 @@ public:
 			threads.emplace_back(worker);
 
 		std::string why;
+		double us_pieces = 0, us_join = 0, us_issue = 0; // (the upload thread's own time: waiting for a filled piece, the table, the copy calls)
+		auto lap = [](std::chrono::steady_clock::time_point &t) {
+			const auto n = std::chrono::steady_clock::now();
+			const double us = std::chrono::duration<double, std::micro>(n - t).count();
+			t = n;
+			return us;
+		};
+		auto t_lap = std::chrono::steady_clock::now();
 		for (size_t c = 0; c < n_pieces && why.empty(); c++) {
 			{
 				std::unique_lock<std::mutex> lk(job.mu);
@@ -718,13 +744,16 @@ public:
 			}
 			const size_t at = c * piece, len = std::min(piece, n_bytes - at);
 			const int slot = (int) (c % (size_t) n_slots);
+			us_pieces += lap(t_lap);
 			if (job.build_table)
 				join_piece(job, c, m->ring_slot(slot), at, len);
+			us_join += lap(t_lap);
 			bool ok = m->copy_up(d_dst + at, slot, len);
 			const bool batch_end = (c + 1) % job.pieces_per_batch == 0 || c + 1 == n_pieces;
 			const size_t batch = c / job.pieces_per_batch;
 			if (ok && batch_end)
 				ok = m->event_record(job.ev_batch[batch]);
+			us_issue += lap(t_lap);
 			if (!ok) {
 				why = "copy up failed";
 				break;
@@ -754,7 +783,10 @@ public:
 		for (std::thread &t : threads)
 			t.join();
 		job.ms_enqueued = ms_since(job.t_started);
-		trace("job %llu: every piece is enqueued%s", (unsigned long long) job.ticket, why.empty() ? "" : " (given up)");
+		trace("job %llu: every piece is enqueued%s (the upload thread: %.1f ms waiting for filled pieces, %.1f ms joining the table, %.1f ms in the copy calls; "
+				"a copying thread: %.1f ms copying, %.1f ms waiting for its turn in the ring, %.1f ms for the slot's copy up to end -- %d of those waits over 0.3 ms)",
+				(unsigned long long) job.ticket, why.empty() ? "" : " (given up)", us_pieces / 1e3, us_join / 1e3, us_issue / 1e3, us_copy / 1e3 / n_threads,
+				us_wait_order / 1e3 / n_threads, (us_wait - us_wait_order) / 1e3 / n_threads, slow_slot_waits.load());
 		job.ms_copy = us_copy / 1e3 / n_threads;
 		job.ms_wait = us_wait / 1e3 / n_threads;
 		{
@@ -815,6 +847,17 @@ public:
 			{
 				std::unique_lock<std::mutex> lk(job.mu);
 				job.cv.wait(lk, [&] { return job.failed || job.cancel.load() || job.batches_ready > batch; });
+				if (!job.failed && !job.cancel.load() && job.batches_ready < job.n_batches && cfg.ahead_wait_factor > 0) {
+					// (see Config::ahead_wait_factor) the rest of the bytes at the rate they have come at so far
+					const double so_far = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - job.t_upload_begin).count();
+					const double rest = so_far / (double) job.batches_ready * (double) (job.n_batches - job.batches_ready);
+					if (rest <= cfg.ahead_wait_factor * cfg.inflate_ms_per_gb * (double) job.n_bytes / 1e9) {
+						trace("job %llu: %zu of %zu batches are up, the rest within %.0f ms: one launch when they are", (unsigned long long) job.ticket,
+								job.batches_ready, job.n_batches, rest);
+						batch = job.n_batches - 1;
+						job.cv.wait(lk, [&] { return job.failed || job.cancel.load() || job.batches_ready > batch; });
+					}
+				}
 				if (job.failed || job.cancel.load() || (job.table_final && !job.table_ok)) {
 					ok = false;
 					break;
@@ -977,6 +1020,22 @@ public:
 		if (job->table_final && job->table_ok) {
 			*blocks = job->blocks.data();
 			*n_blocks = job->blocks.size();
+		}
+	}
+
+	// conga_reads_bgzf_next_go: the caller will bring nothing in front of these bytes -- they (and whatever was named before them)
+	// start on their way now instead of when the next call begins.  A no-op for bytes already on their way or taken up.
+	void go(uint64_t ticket)
+	{
+		std::lock_guard<std::mutex> g(mu);
+		size_t upto = named.size();
+		for (size_t k = 0; ticket != 0 && k < named.size(); k++)
+			if (named[k]->ticket == ticket)
+				upto = k;
+		for (size_t k = 0; upto < named.size() && k <= upto; k++) {
+			if (!named[k]->queued)
+				trace("job %llu: told to go", (unsigned long long) named[k]->ticket);
+			enqueue(named[k]); // (in the order they were named)
 		}
 	}
 

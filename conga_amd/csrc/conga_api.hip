@@ -85,6 +85,8 @@ int conga_release_staging(conga_ctx *ctx)
 		return CONGA_OK;
 	if (hipSetDevice(ctx->device) != hipSuccess)
 		return CONGA_ERR_HIP;
+	if (ctx->bz_copy2)
+		(void) hipStreamSynchronize(ctx->bz_copy2);
 	if (ctx->bz_copy)
 		(void) hipStreamSynchronize(ctx->bz_copy); // (every piece has long gone up: conga_reads_bgzf* returns behind its checks)
 	uint8_t *ring = ctx->h_bz_ring;
@@ -172,6 +174,8 @@ conga_ctx *conga_create(int device, const conga_opts *opts, int *status)
 	ctx->sched.cfg.no_ahead = knobs.bgzf_no_ahead;
 	if (knobs.bgzf_trace)
 		bz::trace_on().store(true);
+	if (knobs.bgzf_ahead_follow)
+		ctx->sched.cfg.ahead_wait_factor = 0;
 	ctx->sched.cfg.timing = knobs.timing;
 	ctx->opts.struct_size = sizeof(conga_opts);
 	ctx->opts.mq_threshold = -1;
@@ -357,6 +361,10 @@ void conga_destroy(conga_ctx *ctx)
 	for (hipEvent_t e : ctx->ev_bz_kernel)
 		if (e)
 			(void) hipEventDestroy(e);
+	if (ctx->bz_copy2)
+		(void) hipStreamDestroy(ctx->bz_copy2);
+	if (ctx->ev_bz_copy2)
+		(void) hipEventDestroy(ctx->ev_bz_copy2);
 	if (ctx->bz_copy)
 		(void) hipStreamDestroy(ctx->bz_copy);
 	if (ctx->bz_third_maker.joinable())
@@ -584,7 +592,9 @@ int conga_sample_begin(conga_ctx *ctx)
 {
 	if (!ctx)
 		return CONGA_ERR_INVALID;
+	bz::trace("conga_sample_begin");
 	TRY(drop_reads(ctx, "conga_sample_begin"));
+	bz::trace("conga_sample_begin: the reads are dropped");
 	ctx->read_target = 0;
 	return CONGA_OK;
 }

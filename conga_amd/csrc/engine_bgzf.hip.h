@@ -126,6 +126,9 @@ void make_bz_ring(conga_ctx *ctx)
 	if (ok && ctx->bz_copy) // (the ring was given back, conga_release_staging: streams and events are still there)
 		return;
 	ok = ok && hipStreamCreateWithPriority(&ctx->bz_copy, hipStreamNonBlocking, prio ? prio_high : 0) == hipSuccess;
+	if (ok && ctx->knobs.bgzf_copy_streams > 1)
+		ok = hipStreamCreateWithPriority(&ctx->bz_copy2, hipStreamNonBlocking, prio ? prio_high : 0) == hipSuccess
+				&& hipEventCreateWithFlags(&ctx->ev_bz_copy2, hipEventDisableTiming) == hipSuccess;
 	for (int k = 0; ok && k < bz_slots(); k++)
 		ok = hipEventCreateWithFlags(&ctx->ev_bz_slot[k], hipEventDisableTiming) == hipSuccess;
 	// The inflate launches need streams BELOW the copy stream's priority (equal priorities: the pieces go up at 22 GB/s beside
@@ -181,7 +184,22 @@ struct HipMachine final : bz::Machine {
 	explicit HipMachine(conga_ctx *c) : ctx(c) {}
 	bool bind() override { return hipSetDevice(ctx->device) == hipSuccess; }
 	uint8_t *ring_slot(int slot) override { return ctx->h_bz_ring + (size_t) slot * kBzPiece; }
-	bool slot_wait(int slot) override { return hipEventSynchronize(ctx->ev_bz_slot[slot]) == hipSuccess; }
+	bool slot_wait(int slot) override
+	{
+		if (!ctx->knobs.bgzf_slot_spin)
+			return hipEventSynchronize(ctx->ev_bz_slot[slot]) == hipSuccess;
+		for (;;) { // (measurement switch)
+			const hipError_t e = hipEventQuery(ctx->ev_bz_slot[slot]);
+			if (e == hipSuccess)
+				return true;
+			if (e != hipErrorNotReady) {
+				(void) hipGetLastError();
+				return false;
+			}
+			for (int k = 0; k < 64; k++)
+				__builtin_ia32_pause();
+		}
+	}
 	uint8_t *up_buffer(int which, size_t bytes) override
 	{ // (grown only: a cohort's samples are of a size)
 		if (ctx->bz_up_cap[which] < bytes) {
@@ -206,10 +224,16 @@ struct HipMachine final : bz::Machine {
 	void event_destroy(void *ev) override { (void) hipEventDestroy((hipEvent_t) ev); }
 	bool copy_up(uint8_t *dst, int slot, size_t len) override
 	{
-		return hipMemcpyAsync(dst, ring_slot(slot), len, hipMemcpyHostToDevice, ctx->bz_copy) == hipSuccess
-				&& hipEventRecord(ctx->ev_bz_slot[slot], ctx->bz_copy) == hipSuccess;
+		hipStream_t cs = (ctx->bz_copy2 && (slot & 1)) ? ctx->bz_copy2 : ctx->bz_copy;
+		return hipMemcpyAsync(dst, ring_slot(slot), len, hipMemcpyHostToDevice, cs) == hipSuccess && hipEventRecord(ctx->ev_bz_slot[slot], cs) == hipSuccess;
 	}
-	bool event_record(void *ev) override { return hipEventRecord((hipEvent_t) ev, ctx->bz_copy) == hipSuccess; }
+	bool event_record(void *ev) override
+	{
+		if (ctx->bz_copy2 // (what the event says -- every piece so far is up -- holds for both streams)
+				&& (hipEventRecord(ctx->ev_bz_copy2, ctx->bz_copy2) != hipSuccess || hipStreamWaitEvent(ctx->bz_copy, ctx->ev_bz_copy2, 0) != hipSuccess))
+			return false;
+		return hipEventRecord((hipEvent_t) ev, ctx->bz_copy) == hipSuccess;
+	}
 	// inflating ahead: when a call of this context has inflated something (the CRC tables are on the device), no chromosome holds
 	// reference text (split reads are mapped on the inflated stream where it lies: no spare set) and the kernel is the usual one
 	bool ahead_possible() override
@@ -218,8 +242,14 @@ struct HipMachine final : bz::Machine {
 	}
 	bool spare_reserve(size_t n_blocks, uint64_t out_bytes) override
 	{
+		const bool grows = n_blocks * sizeof(conga_bgzf_block) > ctx->d_bz_blocks2.cap || n_blocks * 8 > ctx->d_bz_off2.cap
+				|| (size_t) out_bytes + 64 > ctx->d_bz_out2.cap || n_blocks > ctx->d_bz_status2.cap;
+		if (grows)
+			bz::trace("the spare output set grows: %zu blocks, %.0f MB of output (it holds %.0f MB)", n_blocks, (double) out_bytes / 1e6, (double) ctx->d_bz_out2.cap / 1e6);
 		bool ok = quiet_ensure(ctx->d_bz_blocks2, n_blocks * sizeof(conga_bgzf_block)) && quiet_ensure(ctx->d_bz_off2, n_blocks * 8)
 				&& quiet_ensure(ctx->d_bz_out2, (size_t) out_bytes + 64) && quiet_ensure(ctx->d_bz_status2, n_blocks);
+		if (grows)
+			bz::trace("the spare output set has grown");
 		if (ok && !ctx->bz_ahead[0]) { // the launch streams of the inflate ahead (lowest priority), made by its first thread
 			int lo = 0, hi = 0;
 			ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
@@ -234,7 +264,7 @@ struct HipMachine final : bz::Machine {
 	bool ahead_launch(void *batch_event, const uint8_t *d_bytes, const conga_bgzf_block *blocks, const uint64_t *out_off, size_t first, size_t n,
 			int launch) override
 	{
-		hipStream_t ks = ctx->bz_ahead[launch % 2];
+		hipStream_t ks = ctx->bz_ahead[ctx->knobs.bgzf_ahead_one_stream ? 0 : launch % 2];
 		// A launch ahead is up to a whole sample's blocks on every wave slot of the machine, resident until its last block is through
 		// (27-30 ms of a 1x genome), and the compute of the sample in front is a CHAIN of small launches: once these waves are in, the
 		// chain's next link finds no slot and that compute -- 0.3 ms of work -- ends when the inflate does (a run at 41 ms per sample
@@ -244,6 +274,7 @@ struct HipMachine final : bz::Machine {
 			(void) hipGetLastError();
 			return false;
 		}
+		bz::trace("launch ahead %d: its tables go up", launch);
 		bool ok = hipMemcpyAsync(ptr<conga_bgzf_block>(ctx->d_bz_blocks2) + first, blocks + first, n * sizeof(conga_bgzf_block), hipMemcpyHostToDevice, ks)
 						== hipSuccess
 				&& hipMemcpyAsync(ptr<uint64_t>(ctx->d_bz_off2) + first, out_off + first, n * 8, hipMemcpyHostToDevice, ks) == hipSuccess
@@ -609,6 +640,14 @@ int conga_reads_bgzf_next_table(conga_ctx *ctx, uint64_t ticket, const conga_bgz
 	return CONGA_OK;
 }
 
+int conga_reads_bgzf_next_go(conga_ctx *ctx, uint64_t ticket)
+{
+	if (!ctx)
+		return CONGA_ERR_INVALID;
+	ctx->sched.go(ticket);
+	return CONGA_OK;
+}
+
 int conga_reads_bgzf_forget(conga_ctx *ctx, uint64_t ticket)
 {
 	if (!ctx)
@@ -630,6 +669,7 @@ int reads_bgzf_from(conga_ctx *ctx, const ByteSource &src, size_t n_bytes, const
 		return fail(ctx, CONGA_ERR_INVALID, "conga_reads_bgzf: no chromosome open");
 	if (ctx->staging_cur >= 0)
 		return fail(ctx, CONGA_ERR_INVALID, "conga_reads_bgzf: a staging buffer is handed out and not committed");
+	bz::trace("call: entered");
 	const int n_chrom = (int) ctx->slots.size();
 	const int first_chrom = segments[0].chrom;
 	if (first_chrom < 0 || first_chrom >= n_chrom)
@@ -688,10 +728,25 @@ int reads_bgzf_from(conga_ctx *ctx, const ByteSource &src, size_t n_bytes, const
 	const bool overlapped = !lane_kernel_asked(ctx) && in_order && (ctx->knobs.bgzf_overlap >= 0 ? ctx->knobs.bgzf_overlap != 0 : n_bytes >= ((size_t) 96 << 20));
 	if (!overlapped) // (the overlapped form has device buffers of its own for the compressed bytes: the upload jobs')
 		TRY(ensure(ctx, ctx->d_bz_in, n_bytes + 512)); // (the decoders read ahead of their position: up to 64 dwords)
-	TRY(ensure(ctx, ctx->d_bz_blocks, n_blocks * sizeof(conga_bgzf_block)));
-	TRY(ensure(ctx, ctx->d_bz_off, n_blocks * 8));
-	TRY(ensure(ctx, ctx->d_bz_out, (size_t) (base + total) + 64, base > 0));
-	TRY(ensure(ctx, ctx->d_bz_status, n_blocks));
+	// A cohort's pipeline swaps this output set with the spare one sample by sample: sized for THIS sample alone it is too small for
+	// the bound the next job is given room for (a quarter more than the largest ratio seen, bz_prewarm_start) and was grown -- 6.5 GB
+	// allocated and 5.2 GB freed by the job's inflating thread, with every other thread's HIP call waiting behind the runtime's lock:
+	// 0.1 - 0.65 s in which a cohort's second or third sample stood still (profiles/r04j_cohort_first_samples.log).  With
+	// CONGA_FLAG_EXPECT_COHORT the set is the spare's size from the start.
+	size_t room_blocks = n_blocks, room_out = (size_t) (base + total) + 64;
+	if ((ctx->opts.flags & CONGA_FLAG_EXPECT_COHORT) && overlapped && base == 0 && !ctx->sr_layout.load() && !ctx->knobs.bgzf_no_inflate_ahead) {
+		double ratio;
+		{
+			std::lock_guard<std::mutex> g(ctx->sched.mu);
+			ratio = ctx->sched.ratio;
+		}
+		room_blocks = std::max(room_blocks, n_bytes / 4096 + 65536);
+		room_out = std::max(room_out, (size_t) ((double) n_bytes * ratio * 1.25) + ((size_t) 64 << 20) + 64);
+	}
+	TRY(ensure(ctx, ctx->d_bz_blocks, room_blocks * sizeof(conga_bgzf_block)));
+	TRY(ensure(ctx, ctx->d_bz_off, room_blocks * 8));
+	TRY(ensure(ctx, ctx->d_bz_out, room_out, base > 0));
+	TRY(ensure(ctx, ctx->d_bz_status, room_blocks));
 	TRY(ensure(ctx, ctx->d_bz_seg, n_segments * sizeof(conga_bam_segment)));
 	TRY(ensure(ctx, ctx->d_bz_cnt, n_segments * 4));
 	TRY(ensure(ctx, ctx->d_bz_first, n_segments * 8));

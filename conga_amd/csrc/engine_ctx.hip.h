@@ -124,6 +124,8 @@ struct conga_ctx {
 	hipEvent_t ev_bz_slot[12] = {};
 	bool bz_ring_failed = false;
 	hipStream_t bz_copy = nullptr, bz_kernel[3] = {};
+	hipStream_t bz_copy2 = nullptr;   // (measurement switch CONGA_BGZF_COPY_STREAMS=2: the ring's odd slots go up on a stream of their own)
+	hipEvent_t ev_bz_copy2 = nullptr;
 	hipEvent_t ev_bz_kernel[3] = {};
 	bool bz_shared = false; // the inflate launches go to `stream2` and `stream` (made with the lowest priority for that)
 	int n_bz_streams = 0;

@@ -46,6 +46,10 @@ struct Knobs {
 	int tuple_blocks_per_cu = 0;      // CONGA_TUPLE_BLOCKS_PER_CU
 	int depth_tiles_per_block = 0;    // CONGA_DEPTH_TILES_PER_BLOCK
 	int bgzf_groups_per_cu = 8;       // CONGA_BGZF_GROUPS_PER_CU: workgroups (of four waves) an inflate launch puts on a CU, 1 .. 8
+	int bgzf_ahead_follow = 0;        // CONGA_BGZF_AHEAD_FOLLOW: launches ahead follow the batches whatever the upload's rate (bz::Config::ahead_wait_factor = 0)
+	bool bgzf_ahead_one_stream = false; // CONGA_BGZF_AHEAD_ONE_STREAM: every launch ahead on the first of the two streams
+	int bgzf_copy_streams = 1;        // CONGA_BGZF_COPY_STREAMS: 2 = the ring's odd slots go up on a second copy stream
+	bool bgzf_slot_spin = false;      // CONGA_BGZF_SLOT_SPIN: a copying thread polls its slot's event (hipEventQuery) instead of hipEventSynchronize
 	bool bgzf_trace = false;          // CONGA_BGZF_TRACE: the upload pipeline's events with a clock, on stderr (bz::trace)
 	int split_flags = 0;              // CONGA_SPLIT_FLAGS: 1 = split_map_kernel does not ask the presence bitmaps, 2 = plain unit order
 };
@@ -90,6 +94,10 @@ inline Knobs read_knobs()
 	k.tuple_blocks_per_cu = num("CONGA_TUPLE_BLOCKS_PER_CU", 0);
 	k.depth_tiles_per_block = num("CONGA_DEPTH_TILES_PER_BLOCK", 0);
 	k.bgzf_trace = getenv("CONGA_BGZF_TRACE") != nullptr;
+	k.bgzf_slot_spin = getenv("CONGA_BGZF_SLOT_SPIN") != nullptr;
+	k.bgzf_copy_streams = std::max(1, std::min(num("CONGA_BGZF_COPY_STREAMS", 1), 2));
+	k.bgzf_ahead_follow = num("CONGA_BGZF_AHEAD_FOLLOW", 0);
+	k.bgzf_ahead_one_stream = getenv("CONGA_BGZF_AHEAD_ONE_STREAM") != nullptr;
 	k.bgzf_groups_per_cu = std::max(1, std::min(num("CONGA_BGZF_GROUPS_PER_CU", 8), 8));
 	k.split_flags = num("CONGA_SPLIT_FLAGS", 0);
 	return k;

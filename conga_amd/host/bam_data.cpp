@@ -303,8 +303,9 @@ std::vector<std::pair<int, int>> select_chromosomes(const parameters *params, co
 }
 
 // engine: a context that will be given this input next (a cohort's kept one), or nullptr
+// front_begun: set once the call in front of this input's own has begun (nullptr: there is none) -- see conga_reads_bgzf_next_go
 std::unique_ptr<planned_input> plan_input(const parameters *params, const sonic *this_sonic, const std::string &path, conga_ctx *engine = nullptr,
-		std::atomic<bool> *named = nullptr, std::atomic<uint64_t> *ticket_out = nullptr)
+		std::atomic<bool> *named = nullptr, std::atomic<uint64_t> *ticket_out = nullptr, const std::atomic<bool> *front_begun = nullptr)
 {
 	std::unique_ptr<planned_input> p(new planned_input);
 	std::string err;
@@ -322,10 +323,16 @@ std::unique_ptr<planned_input> plan_input(const parameters *params, const sonic 
 	plan_hooks hooks;
 	bool engine_table = false;
 	if (engine) {
-		hooks.named = [raw, engine, named, ticket_out](const file_piece &bytes, const std::vector<uint64_t> &known_starts, uint64_t stop_at) {
+		hooks.named = [raw, engine, named, ticket_out, front_begun](const file_piece &bytes, const std::vector<uint64_t> &known_starts, uint64_t stop_at) {
 			if (bytes.data == nullptr && bytes.fd >= 0)
 				(void) conga_reads_bgzf_next_fd(engine, bytes.fd, bytes.file_off, bytes.size, known_starts.data(), known_starts.size(), stop_at,
 						&raw->ahead_ticket);
+			// Named between two calls, the bytes wait for the next call to begin (it may bring other bytes: the sample in front).  When
+			// that sample's call HAS begun -- it may even be over: a sample that was inflated ahead is six milliseconds of call -- the
+			// next call is this input's own, and the thread of the calls is about to wait for this plan: the bytes must go now.  (Read
+			// AFTER the naming: a call that begins later finds the bytes named and takes them along.)
+			if (raw->ahead_ticket && front_begun && front_begun->load())
+				(void) conga_reads_bgzf_next_go(engine, raw->ahead_ticket);
 			if (ticket_out)
 				ticket_out->store(raw->ahead_ticket);
 			if (named)
@@ -357,6 +364,8 @@ struct kept_engine {
 	bool last_sample = false; // no BAM behind this one: the pinned staging can go while the context computes
 	bool expect_cohort = false; // three samples or more: their bytes will be named ahead (read_bam_cohort)
 	std::atomic<conga_ctx *> early_ctx{nullptr}; // the context as soon as it exists (the first sample's run makes it on a thread of its own)
+	std::atomic<bool> *call_begins = nullptr; // raised right in front of this sample's conga_reads_bgzf* call (or when its reads are in
+	                                          // without one): from then on the NEXT sample's bytes need not wait for a call (plan_input)
 	bed_index dels_bed, dups_bed, map_bed; // --dels / --dups / --mappability as parsed for the first sample
 	bool beds_loaded = false;
 	// the producer of the packed hand-over and its pinned buffers (hand_over_packed: further samples from the host decoders)
@@ -624,6 +633,8 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 			if (knobs().timing)
 				fprintf(stderr, "\n[timing] block table + start points %.1f ms, chromosomes opened (GC tracks, intervals, tracks) %.1f ms\n",
 						ms_plan, ms_since(t_open));
+			if (keep && keep->call_begins)
+				keep->call_begins->store(true);
 			const int rc = bytes.data ? conga_reads_bgzf(ctx, bytes.data, bytes.size, blocks.data(), blocks.size(), segments.data(), segments.size(),
 					gpu_counts.data())
 					: conga_reads_bgzf_fd(ctx, bytes.fd, bytes.file_off, bytes.size, blocks.data(), blocks.size(), segments.data(), segments.size(),
@@ -701,6 +712,8 @@ void run_worker(const parameters *params, const sonic *this_sonic, read_source *
 		job->staged = true;
 	}
 	wt->ms_reads = ms_since(t_loop);
+	if (keep && keep->call_begins)
+		keep->call_begins->store(true); // (a sample that went another way: its reads are in)
 
 	// ---- calc_mean_per_chr + find_depths for every chromosome of this context at once
 	if (!mine.empty()) {
@@ -838,6 +851,9 @@ int cohort_pipeline(parameters *params, sonic *this_sonic, const std::vector<std
 	std::unique_ptr<std::atomic<uint64_t>[]> tickets(new std::atomic<uint64_t>[n_samples]); // conga_reads_bgzf_next_fd's, 0: not named
 	for (size_t j = 0; j < n_samples; j++)
 		tickets[j] = 0;
+	std::unique_ptr<std::atomic<bool>[]> begun(new std::atomic<bool>[n_samples]); // sample j's run (and with it its call) has begun
+	for (size_t j = 0; j < n_samples; j++)
+		begun[j] = false;
 	std::atomic<bool> first_sample_done{false};
 	auto launch = [&](size_t j, conga_ctx *engine_now, size_t ahead_of, bool wait_for_engine = false) { // ahead_of: the sample right behind the one on the GPU
 		if (j >= n_samples || planners[j].joinable() || plans[j])
@@ -856,7 +872,7 @@ int cohort_pipeline(parameters *params, sonic *this_sonic, const std::vector<std
 			// (... and only behind NAMED bytes, or behind the sample on the GPU: a sample whose bytes the engine was not told about
 			// brings them with its call, and a call must not find two named stretches in front of its own)
 			conga_ctx *tell = engine && (j <= ahead_of || tickets[j - 1].load() != 0) ? engine : nullptr;
-			plans[j] = plan_input(params, this_sonic, samples[j].first, tell, &named[j], &tickets[j]);
+			plans[j] = plan_input(params, this_sonic, samples[j].first, tell, &named[j], &tickets[j], j > 0 ? &begun[j - 1] : nullptr);
 			named[j] = true;
 		});
 	};
@@ -898,6 +914,7 @@ int cohort_pipeline(parameters *params, sonic *this_sonic, const std::vector<std
 		keep.last_sample = k + 1 == n_samples;
 		fprintf(stderr, "\n[CONGA] sample %zu of %zu: %s\n", k + 1, n_samples, params->bam_file.c_str());
 		host_trace("begins", k + 1);
+		keep.call_begins = &begun[k]; // (raised by run_worker right in front of the sample's call)
 		// several contexts (--gpus N) are made per sample; one context is kept from sample to sample
 		const int rc = read_bam_with(params, this_sonic, params->n_gpus == 1 ? &keep : nullptr, mine_now.get());
 		first_sample_done = true;

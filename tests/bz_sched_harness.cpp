@@ -303,8 +303,9 @@ void cohort(const char *dir, unsigned seed, size_t piece, int copy_threads, int 
 	std::vector<std::vector<conga_bgzf_block>> tables((size_t) n_samples);
 	std::unique_ptr<std::atomic<bool>[]> named(new std::atomic<bool>[(size_t) n_samples]);
 	std::unique_ptr<std::atomic<uint64_t>[]> tickets(new std::atomic<uint64_t>[(size_t) n_samples]);
+	std::unique_ptr<std::atomic<bool>[]> begun(new std::atomic<bool>[(size_t) n_samples]); // sample j's call is about to begin (bam_data.cpp: call_begins)
 	for (int j = 0; j < n_samples; j++)
-		named[j] = false, tickets[j] = 0;
+		named[j] = false, tickets[j] = 0, begun[j] = false;
 	auto launch = [&](int j, int ahead_of) {
 		if (j >= n_samples || planners[(size_t) j].joinable() || named[j].load())
 			return;
@@ -318,6 +319,8 @@ void cohort(const char *dir, unsigned seed, size_t piece, int copy_threads, int 
 				const std::vector<uint64_t> known = caller_tables ? std::vector<uint64_t>() : known_of(samples[(size_t) j], prng);
 				t = r.sched.name_next(samples[(size_t) j].fd, 0, samples[(size_t) j].file.size(), known.data(), known.size(), 0, true);
 			}
+			if (t && begun[j - 1].load())
+				r.sched.go(t); // (the call in front has begun -- or is over: the next one is this sample's own, and it waits for this thread)
 			tickets[j] = t;
 			named[j] = true;
 			tables[(size_t) j] = samples[(size_t) j].blocks; // (what walking the file gives)
@@ -345,6 +348,7 @@ void cohort(const char *dir, unsigned seed, size_t piece, int copy_threads, int 
 			launch(k + 1, k + 1);
 		if (depth >= 2 && k > 0)
 			launch(k + 2, k + 1);
+		begun[k] = true;
 		how += one_call(r, samples[(size_t) k], tables[(size_t) k]);
 		if (tickets[k].load())
 			r.sched.forget(tickets[k].load()); // (a no-op for a ticket taken up)
@@ -408,6 +412,27 @@ void give_ups(const char *dir, unsigned seed)
 	// ... and the wrong table for the bytes: the call finds the spare set is not its own and inflates by itself
 	if (one_call(r, s[1], std::vector<conga_bgzf_block>(s[1].blocks.begin(), s[1].blocks.end() - 1)) == 'a')
 		fail("a call with another table took the stream inflated ahead");
+	// named between two calls, and the table asked for before any call begins -- a cohort's thread of the calls waits for the next
+	// sample's plan, the plan for the table, the table for the bytes, and the bytes (named between calls) for a call: told to go,
+	// they start by themselves and the table is there long before wait_table's 400 ms are over
+	known = known_of(s[3], rng);
+	t = r.sched.name_next(s[3].fd, 0, s[3].file.size(), known.data(), known.size(), 0, true);
+	r.sched.go(t);
+	r.sched.go(t); // (twice, and for a ticket nobody holds: nothing happens)
+	r.sched.go(12345);
+	{
+		const auto t0 = std::chrono::steady_clock::now();
+		const conga_bgzf_block *b = nullptr;
+		size_t n = 0;
+		r.sched.wait_table(t, &b, &n);
+		const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+		if (n != s[3].blocks.size() || memcmp(b, s[3].blocks.data(), n * sizeof(conga_bgzf_block)) != 0)
+			fail("bytes told to go: no table, or not the file's");
+		if (ms > 300.0)
+			fail("bytes told to go waited for a call all the same");
+	}
+	one_call(r, s[3], s[3].blocks);
+	r.sched.forget(t);
 	// the context ends with jobs named and one inflating ahead
 	known = known_of(s[2], rng);
 	(void) r.sched.name_next(s[2].fd, 0, s[2].file.size(), known.data(), known.size(), 0, true);

@@ -45,6 +45,8 @@ try:
         dt, err = e2e_bench.run_conga(["--cohort", "list.txt", "--out", "x", "--ref", "r.fa", "--sonic", "a.cga", "--dels", "dels.bed"], d, env)
     done = [float(x) for x in re.findall(r"cohort: sample \d+ of \d+ is done ([0-9.]+) ms", err)]
     print("wall %.3f s; sample ends (ms): %s" % (dt, " ".join("%.0f" % x for x in done)))
+    for ln in [ln for ln in err.splitlines() if "overlapped upload: named ahead" in ln][-3:]:
+        print("   " + ln[:330])
     lines = [ln for ln in err.splitlines() if ln.startswith("[bz ")]
     t0 = None
     show = False
