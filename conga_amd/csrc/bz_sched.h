@@ -506,6 +506,20 @@ public:
 		cv.notify_all();
 	}
 
+	// A call that launches its job's inflates itself (nothing was inflated ahead) keeps the spare set out of the reach of the jobs
+	// behind until ITS sample's compute is enqueued as well (spare_free), like a call that swapped the set in: the walks, the layout
+	// and the compute of the sample in front are a few milliseconds of launches and, the first time, dozens of allocations -- and an
+	// allocation beside a launch that holds every wave slot for 28 ms waits for it (a cohort's first sample: "walks + checks 537 ms").
+	// false: a job is inflating into the set already.
+	bool hold_spare(const JobPtr &job)
+	{
+		std::lock_guard<std::mutex> g(mu);
+		if (spare_owner)
+			return false;
+		spare_owner = job;
+		return true;
+	}
+
 	// the spare output set is nobody's again (when it was this job's)
 	void spare_free(const JobPtr &job)
 	{

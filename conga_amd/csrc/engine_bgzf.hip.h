@@ -202,6 +202,7 @@ struct HipMachine final : bz::Machine {
 	}
 	uint8_t *up_buffer(int which, size_t bytes) override
 	{ // (grown only: a cohort's samples are of a size)
+		std::lock_guard<std::mutex> g(ctx->prewarm_mu); // (bz_prealloc, on the caller's thread, may be at the same buffers)
 		if (ctx->bz_up_cap[which] < bytes) {
 			if (ctx->bz_up_buf[which])
 				(void) hipFree(ctx->bz_up_buf[which]);
@@ -321,6 +322,44 @@ struct HipMachine final : bz::Machine {
 // for compressed bytes and the spare output set, ~3.6 bytes of HBM per byte of file -- is allocated by a thread of its own
 // while the first sample is inflated, indexed and computed: 45 GB take the runtime 1.3 s, which the second and third sample
 // would otherwise wait for (profiles/r03e_cohort_depth.log).
+constexpr double kSetRoom = 1.25 * 1.1; // an output set of the pipeline: what a job asks for (1.25 x ratio x bytes), for bytes a tenth more than the first input's
+
+// ... or rather, since round 4's last day, by the first call itself BEFORE anything of it is on the device: hipMalloc is a
+// millisecond for gigabytes on an idle device and hundreds of milliseconds beside running kernels and copies, with every launch
+// of the process queued behind it meanwhile -- the thread below made a cohort's FIRST sample 0.45 s longer than a sample that
+// is alone in its process (its own call: "upload + inflate 624 ms" instead of 38), which was most of `fixed_cost_ms`
+// (profiles/r04j_cohort_first_samples.log).  The thread stays for a context whose first call was not told its size this way.
+void bz_prealloc(conga_ctx *ctx, size_t n_bytes, double ratio)
+{
+	if (ctx->bz_prewarmed || !(ctx->opts.flags & CONGA_FLAG_EXPECT_COHORT) || ctx->knobs.bgzf_no_inflate_ahead)
+		return;
+	ctx->bz_prewarmed = true;
+	const auto t0 = std::chrono::steady_clock::now();
+	{
+		std::lock_guard<std::mutex> g(ctx->prewarm_mu);
+		const size_t want = n_bytes + n_bytes / 10 + n_bytes / 16 + 512;
+		for (int which = 0; which < 2; which++)
+			if (ctx->bz_up_cap[which] < want) {
+				uint8_t *p = nullptr;
+				if (hipMalloc((void **) &p, want) == hipSuccess) {
+					if (ctx->bz_up_buf[which])
+						(void) hipFree(ctx->bz_up_buf[which]);
+					ctx->bz_up_buf[which] = p;
+					ctx->bz_up_cap[which] = want;
+				} else
+					(void) hipGetLastError();
+			}
+	}
+	if (!ctx->sr_layout.load()) { // (split reads: named bytes are brought up ahead, not inflated ahead -- no spare output set)
+		const size_t cap_blocks = (n_bytes + n_bytes / 10) / 4096 + 65536;
+		const uint64_t cap_out = (uint64_t) ((double) n_bytes * ratio * kSetRoom) + ((uint64_t) 64 << 20);
+		(void) (quiet_ensure(ctx->d_bz_blocks2, cap_blocks * sizeof(conga_bgzf_block)) && quiet_ensure(ctx->d_bz_off2, cap_blocks * 8)
+				&& quiet_ensure(ctx->d_bz_out2, (size_t) cap_out + 64) && quiet_ensure(ctx->d_bz_status2, cap_blocks));
+	}
+	bz::trace("the pipeline's buffers (the second one for compressed bytes, the spare output set) in %.1f ms, before the first piece goes up",
+			std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+}
+
 void bz_prewarm_start(conga_ctx *ctx, size_t n_bytes)
 {
 	if (ctx->bz_prewarmed || !(ctx->opts.flags & CONGA_FLAG_EXPECT_COHORT) || ctx->knobs.bgzf_no_inflate_ahead)
@@ -349,8 +388,10 @@ void bz_prewarm_start(conga_ctx *ctx, size_t n_bytes)
 		}
 		if (ctx->sr_layout.load()) // (split reads: named bytes are brought up ahead, not inflated ahead -- no spare output set)
 			return;
-		const size_t cap_blocks = n_bytes / 4096 + 65536;
-		const uint64_t cap_out = (uint64_t) ((double) n_bytes * ratio * 1.25) + ((uint64_t) 64 << 20);
+		// (a job asks for room for 1.25 x the largest ratio seen x ITS bytes: the set holds a tenth more than the first input would
+		// ask for, so that a sample a few per cent larger than the first -- another individual at the same depth -- does not make it grow)
+		const size_t cap_blocks = (n_bytes + n_bytes / 10) / 4096 + 65536;
+		const uint64_t cap_out = (uint64_t) ((double) n_bytes * ratio * kSetRoom) + ((uint64_t) 64 << 20);
 		(void) (quiet_ensure(ctx->d_bz_blocks2, cap_blocks * sizeof(conga_bgzf_block)) && quiet_ensure(ctx->d_bz_off2, cap_blocks * 8)
 				&& quiet_ensure(ctx->d_bz_out2, (size_t) cap_out + 64) && quiet_ensure(ctx->d_bz_status2, cap_blocks));
 	});
@@ -473,6 +514,10 @@ int upload_and_inflate_overlapped(conga_ctx *ctx, const ByteSource &src, size_t 
 		}
 		else if (took < 0)
 			sched.spare_free(job);
+		else if (ctx->machine->ahead_possible() && sched.hold_spare(job)) { // (bz_sched.h: hold_spare)
+			std::lock_guard<std::mutex> g(ctx->spare_mu);
+			ctx->spare_held = job;
+		}
 	}
 	sched.enqueue_later();
 	if (inflated_ahead) {
@@ -734,25 +779,36 @@ int reads_bgzf_from(conga_ctx *ctx, const ByteSource &src, size_t n_bytes, const
 	// 0.1 - 0.65 s in which a cohort's second or third sample stood still (profiles/r04j_cohort_first_samples.log).  With
 	// CONGA_FLAG_EXPECT_COHORT the set is the spare's size from the start.
 	size_t room_blocks = n_blocks, room_out = (size_t) (base + total) + 64;
-	if ((ctx->opts.flags & CONGA_FLAG_EXPECT_COHORT) && overlapped && base == 0 && !ctx->sr_layout.load() && !ctx->knobs.bgzf_no_inflate_ahead) {
+	if ((ctx->opts.flags & CONGA_FLAG_EXPECT_COHORT) && overlapped && base == 0 && !ctx->sr_layout.load() && !ctx->knobs.bgzf_no_inflate_ahead
+			&& ctx->d_bz_out.cap == 0) { // (the first sizing: later a set is grown for what a sample needs, not for what the next one may)
 		double ratio;
 		{
 			std::lock_guard<std::mutex> g(ctx->sched.mu);
 			ratio = ctx->sched.ratio;
 		}
-		room_blocks = std::max(room_blocks, n_bytes / 4096 + 65536);
-		room_out = std::max(room_out, (size_t) ((double) n_bytes * ratio * 1.25) + ((size_t) 64 << 20) + 64);
+		room_blocks = std::max(room_blocks, (n_bytes + n_bytes / 10) / 4096 + 65536);
+		room_out = std::max(room_out, (size_t) ((double) n_bytes * ratio * kSetRoom) + ((size_t) 64 << 20) + 64);
+	}
+	if (overlapped && base == 0) {
+		double ratio;
+		{
+			std::lock_guard<std::mutex> g(ctx->sched.mu);
+			ratio = ctx->sched.ratio;
+		}
+		bz_prealloc(ctx, n_bytes, ratio); // (the device is idle: see there)
 	}
 	TRY(ensure(ctx, ctx->d_bz_blocks, room_blocks * sizeof(conga_bgzf_block)));
 	TRY(ensure(ctx, ctx->d_bz_off, room_blocks * 8));
 	TRY(ensure(ctx, ctx->d_bz_out, room_out, base > 0));
 	TRY(ensure(ctx, ctx->d_bz_status, room_blocks));
-	TRY(ensure(ctx, ctx->d_bz_seg, n_segments * sizeof(conga_bam_segment)));
-	TRY(ensure(ctx, ctx->d_bz_cnt, n_segments * 4));
-	TRY(ensure(ctx, ctx->d_bz_first, n_segments * 8));
-	TRY(ensure(ctx, ctx->d_bz_stop, n_segments * 8));
-	TRY(ensure(ctx, ctx->d_bz_bad, n_segments));
-	TRY(ensure(ctx, ctx->d_bz_at, n_segments * 8));
+	// (a cohort: room for a sample with an eighth more start points than the first -- growing beside the pipeline's launches waits for them)
+	const size_t seg_room = ctx->d_bz_seg.cap == 0 && (ctx->opts.flags & CONGA_FLAG_EXPECT_COHORT) ? n_segments + n_segments / 8 : n_segments;
+	TRY(ensure(ctx, ctx->d_bz_seg, seg_room * sizeof(conga_bam_segment)));
+	TRY(ensure(ctx, ctx->d_bz_cnt, seg_room * 4));
+	TRY(ensure(ctx, ctx->d_bz_first, seg_room * 8));
+	TRY(ensure(ctx, ctx->d_bz_stop, seg_room * 8));
+	TRY(ensure(ctx, ctx->d_bz_bad, seg_room));
+	TRY(ensure(ctx, ctx->d_bz_at, seg_room * 8));
 	TRY(ensure(ctx, ctx->d_bz_flag, 4));
 	TRY(ensure_crc_table(ctx));
 	const double ms_buffers = ms_since(t_begin);
@@ -843,7 +899,8 @@ int reads_bgzf_from(conga_ctx *ctx, const ByteSource &src, size_t n_bytes, const
 	if (n_new) {
 		const size_t total_reads = (size_t) ctx->n_reads_total + (size_t) n_new;
 		if (total_reads * 4 > ctx->d_pos.cap || total_reads > ctx->d_mapq.cap) {
-			const size_t want = std::max(total_reads, (size_t) 1 << 22);
+			// (a cohort's samples differ a little: the next one must not make these grow beside the pipeline's launches -- bz_prealloc)
+			const size_t want = std::max(total_reads + ((ctx->opts.flags & CONGA_FLAG_EXPECT_COHORT) ? total_reads / 8 : 0), (size_t) 1 << 22);
 			TRY(ensure(ctx, ctx->d_pos, want * 4, true));
 			TRY(ensure(ctx, ctx->d_mapq, want, true));
 		}

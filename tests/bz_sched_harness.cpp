@@ -233,6 +233,7 @@ char one_call(Run &r, const Sample &s, const std::vector<conga_bgzf_block> &bloc
 		r.machine.spare_done();
 		r.sched.spare_free(job);
 	}
+	const bool held = took == 0 && r.sched.hold_spare(job); // (upload_and_inflate_overlapped: until the sample's compute is enqueued)
 	r.sched.enqueue_later();
 	bool failed = false;
 	if (how == 'c') {
@@ -266,6 +267,8 @@ char one_call(Run &r, const Sample &s, const std::vector<conga_bgzf_block> &bloc
 		failed = job->failed;
 	}
 	r.sched.job_kept = job;
+	if (held)
+		r.sched.spare_free(job); // ("conga_chrom_compute")
 	r.sched.end_call();
 	g_progress++;
 	if (failed != expect_failure)

@@ -834,6 +834,36 @@ def test_cli_cohort_that_stood_still_on_round_3s_last_day(tmp_path, piece_kb, ah
 
 
 @pytest.mark.gpu
+def test_cli_cohort_pipeline_neither_grows_its_spare_set_nor_waits_for_a_call_that_waits_for_it(tmp_path):
+    """Round 4's last day, from the pipeline's event trace (profiles/r04j_cohort_first_samples.log).  (1) The first sample's output set is
+    the spare set after the first swap: sized for that sample alone it was grown by the next job's inflating thread -- gigabytes allocated
+    and freed behind the runtime's lock, 0.1-0.65 s of a whole-genome cohort; with CONGA_FLAG_EXPECT_COHORT it has the spare's size from
+    the start.  (2) Bytes named between two calls waited for a call to begin while the thread of the calls waited for their plan:
+    conga_reads_bgzf_next_table's 0.4 s, one run in three; the executable now says conga_reads_bgzf_next_go.  Six samples of one size,
+    the trace on: no growth, no sample-to-sample gap of 0.35 s, every sample's files those of a run of its own."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import re
+    import soak
+    d = str(tmp_path)
+    args = soak.bam_case(np.random.default_rng([81, 11_000_000 + 38]), d)
+    with open(os.path.join(d, "list.txt"), "w") as f:
+        f.write("".join("r.bam\tc%d\n" % k for k in range(6)))
+    env = dict(os.environ, CONGA_GPU_BAM="1", CONGA_BGZF_OVERLAP="1", CONGA_TIMING="1", CONGA_BGZF_PIECE_KB="16", CONGA_DEBUG="1", CONGA_BGZF_TRACE="1")
+    for rep in range(3):   # (the circle of waits was a race: a few runs)
+        r = subprocess.run([CONGA, "--cohort", "list.txt", "--out", "co"] + args[2:], cwd=d, capture_output=True, text=True, timeout=60, env=env)
+        assert r.returncode == 0 and "decoding on the host" not in r.stderr, r.stderr[-3000:]
+        assert "the spare output set grows" not in r.stderr, [ln for ln in r.stderr.splitlines() if "spare output set" in ln][:6]
+        done = [float(x) for x in re.findall(r"cohort: sample \d+ of \d+ is done ([0-9.]+) ms", r.stderr)]
+        assert len(done) == 6 and max(b - a for a, b in zip(done[1:], done[2:])) < 350.0, done
+        assert r.stderr.count("inflated ahead: the output sets change places") >= 2, r.stderr[-3000:]   # (the pipeline was on)
+    one = subprocess.run([CONGA] + args + ["--out", "one"], cwd=d, capture_output=True, text=True, timeout=60, env=dict(os.environ, CONGA_GPU_BAM="1"))
+    assert one.returncode == 0, one.stderr[-2000:]
+    for k in range(6):
+        for kind in ("svs", "dels", "dups"):
+            assert open(os.path.join(d, "c%d_%s.bed" % (k, kind)), "rb").read() == open(os.path.join(d, "one_%s.bed" % kind), "rb").read(), (k, kind)
+
+
+@pytest.mark.gpu
 def test_cli_damaged_bam_records_gpu_and_host_decoders_agree():
     """Records with a damaged block_size, refID, pos, l_read_name, n_cigar, l_seq or flag, and random bytes, in a BAM whose
     blocks still check out (tools/bam_fuzz.py): the run that decodes on the GPU ends the way the run on the host decoders
