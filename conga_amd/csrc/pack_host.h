@@ -18,6 +18,8 @@
 #if defined(__linux__)
 #include <pthread.h>
 #include <sched.h>
+#include <stdio.h>
+#include <sys/syscall.h>
 #include <unistd.h>
 #endif
 #if defined(__x86_64__)
@@ -277,12 +279,68 @@ inline void cpu_relax()
 #endif
 }
 
+// how long a worker looks for the next sample before it sleeps, in pauses (measurement switch: CONGA_DEBUG=1 CONGA_PACK_SPIN=n)
+inline int spin_limit()
+{
+	static const int n = [] {
+		const char *d = getenv("CONGA_DEBUG"), *e = getenv("CONGA_PACK_SPIN");
+		return d && atoi(d) != 0 && e ? atoi(e) : 20000;
+	}();
+	return n;
+}
+
+#if defined(__linux__)
+// The memory node a page lies on (move_pages in its query form: no page moves), -1: not known (not resident yet, no such call here).
+inline int node_of(const void *p)
+{
+	void *page = reinterpret_cast<void *>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t) 4095);
+	int status = -1;
+	const long rc = syscall(SYS_move_pages, 0, 1UL, &page, nullptr, &status, 0);
+	return rc == 0 && status >= 0 ? status : -1;
+}
+// the CPUs of a memory node (/sys/devices/system/node/nodeN/cpulist: "0-63,128-191")
+inline bool node_cpus(int node, cpu_set_t *set)
+{
+	char path[96], text[4096];
+	snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+	FILE *f = fopen(path, "r");
+	if (!f)
+		return false;
+	const size_t n = fread(text, 1, sizeof text - 1, f);
+	fclose(f);
+	text[n] = 0;
+	CPU_ZERO(set);
+	int any = 0;
+	for (const char *q = text; *q;) {
+		char *end;
+		const long a = strtol(q, &end, 10);
+		if (end == q)
+			break;
+		long b = a;
+		if (*end == '-')
+			b = strtol(end + 1, &end, 10);
+		for (long c = a; c <= b && c < CPU_SETSIZE; c++) {
+			CPU_SET((int) c, set);
+			any = 1;
+		}
+		q = *end == ',' ? end + 1 : end;
+		if (*end != ',')
+			break;
+	}
+	return any != 0;
+}
+#endif
+
 class Packer {
 public:
 	// spread > 0: worker t pins itself to CPU (t * spread) mod the CPUs of the machine -- one worker per L3 domain reads through
 	// that domain's own link to memory instead of eight sharing one (tools/packbench --spread)
 	explicit Packer(int n_threads, int spread = 0) : n_threads_(std::max(1, n_threads))
 	{
+#if defined(__linux__)
+		have_allowed_ = sched_getaffinity(0, sizeof allowed_, &allowed_) == 0;
+		follow_node_ = spread == 0 && !(getenv("CONGA_DEBUG") && getenv("CONGA_PACK_NO_NUMA")); // (measurement switch)
+#endif
 		for (int t = 0; t < n_threads_; t++)
 			threads_.emplace_back([this, t, spread] {
 #if defined(__linux__)
@@ -349,6 +407,22 @@ private:
 				// integer; only elements of the chromosome's own index range are ever read through it)
 				fbase.push_back(chrom_pos ? reinterpret_cast<const int32_t *>(reinterpret_cast<uintptr_t>(chrom_pos[c]) - (uintptr_t) (4 * chrom_off[c])) : pos);
 			}
+#if defined(__linux__)
+		// The workers stay on the memory node the positions lie on: a process that may run anywhere on a two-socket host (a GPU box
+		// grants 16 CPUs' worth of time on all 256) otherwise has some of them read across the sockets' link -- the same encode,
+		// fourteen threads: 0.92-0.95 ms inside one node, 0.92-1.30 anywhere (tools/packbench under taskset, profiles/r04k_packbench_numa.log).
+		if (follow_node_ && have_allowed_ && n) {
+			const int32_t *first = pos; // the sample's first read
+			for (int c = 0; chrom_pos && c < n_chrom && first == nullptr; c++)
+				if (chrom_off[c + 1] > chrom_off[c])
+					first = chrom_pos[c];
+			int node = first ? node_of(first) : -1;
+			if (node < 0)
+				node = node_of(out);
+			if (node >= 0)
+				want_node_.store(node, std::memory_order_relaxed);
+		}
+#endif
 		{
 			// (a thread that slept through the sample before wakes up whenever it likes, finds nothing left and goes back to sleep: it
 			// reads these fields meanwhile -- they change under the lock, with no thread inside its loop)
@@ -415,11 +489,26 @@ private:
 	void loop()
 	{
 		uint64_t seen = 0;
+		int my_node = -1;
 		for (;;) {
+#if defined(__linux__)
+			{
+				const int want = want_node_.load(std::memory_order_relaxed);
+				if (want != my_node && want >= 0) { // (once per packer, as a rule)
+					cpu_set_t on_node, mine;
+					if (node_cpus(want, &on_node)) {
+						CPU_AND(&mine, &on_node, &allowed_);
+						if (CPU_COUNT(&mine) > 0)
+							(void) pthread_setaffinity_np(pthread_self(), sizeof mine, &mine);
+					}
+					my_node = want;
+				}
+			}
+#endif
 			// (a caller that packs sample after sample -- a cohort, bench.py's step -- starts the next one within a millisecond: a
 			// thread that goes to sleep at once pays a wake-up, and a core that idled its clock ramp, on every sample.  Look for the
 			// next sample for that long before sleeping.)
-			for (int spin = 0; spin < 20000 && generation_hint_.load(std::memory_order_acquire) == seen && !quit_hint_.load(std::memory_order_relaxed); spin++)
+			for (int spin = 0; spin < spin_limit() && generation_hint_.load(std::memory_order_acquire) == seen && !quit_hint_.load(std::memory_order_relaxed); spin++)
 				cpu_relax();
 			{
 				std::unique_lock<std::mutex> lk(mu_);
@@ -454,6 +543,11 @@ private:
 	}
 
 	const int n_threads_;
+#if defined(__linux__)
+	cpu_set_t allowed_;
+	bool have_allowed_ = false, follow_node_ = false;
+#endif
+	std::atomic<int> want_node_{-1}; // the memory node the workers keep to (-1: wherever the scheduler puts them)
 	std::vector<std::thread> threads_;
 	std::mutex mu_;
 	std::condition_variable cv_, done_cv_;

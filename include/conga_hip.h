@@ -88,12 +88,14 @@ typedef enum conga_status {
 #define CONGA_FLAG_EXPECT_BGZF 0x20u   /* conga_reads_bgzf() will be called: conga_create() gets its pinned staging ring (96 MB,
                                           ~50 ms) instead of the first such call */
 
-#define CONGA_FLAG_EXPECT_COHORT 0x40u /* conga_reads_bgzf_next_fd() will be called for further inputs of the size of the first: the
-                                          second device buffer for compressed bytes and the spare output set (~3.6 bytes of HBM per byte
-                                          of file) are allocated by a thread of the engine's while the first input is on, not when
-                                          the second one is named (45 GB take the runtime 1.3 s).  A context that holds reference
-                                          text (conga_reference: split reads are mapped on the inflated stream in place) brings named
-                                          bytes up ahead without inflating them ahead: only the second buffer for compressed bytes */
+#define CONGA_FLAG_EXPECT_COHORT 0x40u /* conga_reads_bgzf_next_fd() will be called for further inputs of about the size of the first
+                                          (a tenth more fits): the second device buffer for compressed bytes and the spare output set
+                                          (~3.6 bytes of HBM per byte of file) are allocated by the first conga_reads_bgzf* call before
+                                          its first byte goes up -- an allocation is half a millisecond on an idle device and waits for
+                                          whatever runs on a busy one --, the first input's own output set gets the spare's size (the two
+                                          change places input by input), per-input buffers an eighth of room.  A context that holds
+                                          reference text (conga_reference: split reads are mapped on the inflated stream in place) brings
+                                          named bytes up ahead without inflating them ahead: only the second buffer for compressed bytes */
 
 /* SV types, as the reference's DELETION / DUPLICATION (common.h:12-13) */
 #define CONGA_DELETION 'D'
