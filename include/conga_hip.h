@@ -276,7 +276,8 @@ int conga_sample_reads_packed(conga_ctx *ctx, const uint8_t *bits, int width, co
  * there are and how many bytes of `out` go over the link: hand (out, *width, NULL, NULL, *n_esc) to conga_sample_reads_packed.
  * `out` holds conga_pack_bound(n_reads, max_esc) bytes for up to max_esc exceptions at any width (CONGA_ERR_NOMEM from start / finish:
  * it does not); pos[] and out[] must stay as they are between start and finish.  One sample at a time per packer; every all-ones
- * difference gets its entry (the contract conga_sample_reads_packed relies on). */
+ * difference gets its entry (the contract conga_sample_reads_packed relies on).  On Linux the packer's threads keep to the CPUs of the
+ * memory node the positions lie on (a two-socket host: reading across the sockets' link costs the encode a third of its rate). */
 typedef struct conga_packer conga_packer;
 conga_packer *conga_packer_create(int n_threads);
 void conga_packer_destroy(conga_packer *p);
