@@ -6,7 +6,11 @@
 // for positions that already lie in an array -- the CLI's host decoders and tuple containers leave them so, and bench.py's
 // timed step starts from such an array --: a pool of threads of the packer's own encodes runs of 8 192 reads (eight
 // differences are W whole bytes, so every run starts on a byte) and collects the exceptions run by run; the caller's thread
-// goes on with something else between start() and finish().  Rounds 3's encoder was numpy in the test binding, outside
+// goes on with something else between start() and finish().  The producer is bound by the host's memory, so what it does with
+// memory is the design: a run is put together in a buffer of the thread's own and leaves the core with non-temporal stores (the
+// pinned buffer's lines are never read, and are in memory -- not modified in some core's cache -- when the copy engine asks),
+// a thread takes eight runs in a row and asks for its positions 8 KB ahead (bench.py's step with the producer inside:
+// 0.99-1.03 ms -> 0.68-0.71 on one box, the same differences encoded beforehand 0.62; tools/packprobe_bench.sh).  Rounds 3's encoder was numpy in the test binding, outside
 // anything timed ("what's weak" 3).
 //
 // Host-only on purpose: tests/test_pack_host.py builds it with g++ (also under -fsanitize=thread) without the HIP runtime.
@@ -36,6 +40,15 @@
 namespace conga_pack {
 
 constexpr uint64_t kRun = 8192; // reads per unit of work (a multiple of 8)
+// runs a worker takes at a time (measurement switch: CONGA_DEBUG=1 CONGA_PACK_BATCH=n)
+inline size_t batch_runs()
+{
+	static const size_t n = [] {
+		const char *d = getenv("CONGA_DEBUG"), *e = getenv("CONGA_PACK_BATCH");
+		return (size_t) (d && atoi(d) != 0 && e ? std::max(1, atoi(e)) : 0); // 0: by the sample's size
+	}();
+	return n;
+}
 
 // bytes `out` must hold for any width and up to max_esc exceptions: differences, padding, the two lists, the 64 bytes of slack the
 // expansion's last 16-byte load may touch
@@ -90,32 +103,57 @@ template <int W> inline void encode_groups(const int32_t *pos, uint64_t i0, uint
 // subtract, the clamp to all-ones a `min`, the exceptions a compare + movemask that is zero for all but one group in a few
 // hundred, and the bits squeezed together by two `pext` -- a dozen instructions per eight reads where the scalar loop has sixty.
 // What is left is the read of the positions themselves: 4 bytes per read from host memory.
-template <int W> __attribute__((target("avx2,bmi2"))) inline void encode_groups_avx2(const int32_t *pos, uint64_t i0, uint64_t i1, uint8_t *out, std::vector<Exc> &exc)
+// how far in front of the load the positions are asked for, in reads (CONGA_DEBUG=1 CONGA_PACK_PREFETCH=n; 0: no prefetch).  A core
+// of a two-socket host waits ~120 ns for a line and has a few dozen lines in flight: one sequential stream per thread gets 8-10 GB/s
+// from the hardware's own prefetcher, which also stops at every 4 KB page; asking 8 KB ahead keeps more lines under way
+// (tools/packprobe.sh, three samples in turn on a GPU box: 0.84-0.90 ms against 0.95-1.17 without; 256 ... 4096 reads ahead tried).
+inline int prefetch_reads()
+{
+	static const int n = [] {
+		const char *d = getenv("CONGA_DEBUG"), *e = getenv("CONGA_PACK_PREFETCH");
+		return d && atoi(d) != 0 && e ? std::max(0, atoi(e)) : 2048;
+	}();
+	return n;
+}
+
+template <int W> __attribute__((target("avx2,bmi2"))) inline void encode_group_avx2(const int32_t *pos, uint64_t i, uint8_t *out, std::vector<Exc> &exc)
 {
 	constexpr uint32_t kTop = (1u << W) - 1u;
 	constexpr uint64_t kMask = (uint64_t) kTop * 0x0001000100010001ull;
 	const __m256i top = _mm256_set1_epi32((int) kTop);
-	for (uint64_t i = i0; i < i1; i += 8) {
-		const __m256i cur = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(pos + i));
-		const __m256i prev = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(pos + i - 1));
-		const __m256i v = _mm256_min_epu32(_mm256_sub_epi32(cur, prev), top); // (a position in front of its predecessor: huge, clamped)
-		const int esc = _mm256_movemask_ps(_mm256_castsi256_ps(_mm256_cmpeq_epi32(v, top)));
-		if (esc)
-			for (int k = 0; k < 8; k++)
-				if (esc >> k & 1)
-					exc.push_back(Exc{(uint32_t) (i + (uint64_t) k), pos[i + (uint64_t) k]});
-		const __m256i p16 = _mm256_packus_epi32(v, v); // 16 bits each: v0..v3 in the low lane's first quadword, v4..v7 in the high lane's
-		const uint64_t lo = _pext_u64((uint64_t) _mm256_extract_epi64(p16, 0), kMask), hi = _pext_u64((uint64_t) _mm256_extract_epi64(p16, 2), kMask);
-		uint64_t w[2];
-		if (W == 16) {
-			w[0] = lo;
-			w[1] = hi;
-		} else {
-			w[0] = lo | hi << (4 * W);
-			w[1] = hi >> (64 - 4 * W);
-		}
-		memcpy(out + (i >> 3) * W, w, W);
+	const __m256i cur = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(pos + i));
+	const __m256i prev = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(pos + i - 1));
+	const __m256i v = _mm256_min_epu32(_mm256_sub_epi32(cur, prev), top); // (a position in front of its predecessor: huge, clamped)
+	const int esc = _mm256_movemask_ps(_mm256_castsi256_ps(_mm256_cmpeq_epi32(v, top)));
+	if (__builtin_expect(esc != 0, 0))
+		for (int k = 0; k < 8; k++)
+			if (esc >> k & 1)
+				exc.push_back(Exc{(uint32_t) (i + (uint64_t) k), pos[i + (uint64_t) k]});
+	const __m256i p16 = _mm256_packus_epi32(v, v); // 16 bits each: v0..v3 in the low lane's first quadword, v4..v7 in the high lane's
+	const uint64_t lo = _pext_u64((uint64_t) _mm256_extract_epi64(p16, 0), kMask), hi = _pext_u64((uint64_t) _mm256_extract_epi64(p16, 2), kMask);
+	uint64_t w[2];
+	if (W == 16) {
+		w[0] = lo;
+		w[1] = hi;
+	} else {
+		w[0] = lo | hi << (4 * W);
+		w[1] = hi >> (64 - 4 * W);
 	}
+	memcpy(out + (i >> 3) * W, w, W);
+}
+
+template <int W> __attribute__((target("avx2,bmi2"))) inline void encode_groups_avx2(const int32_t *pos, uint64_t i0, uint64_t i1, uint8_t *out, std::vector<Exc> &exc)
+{
+	const uint64_t ahead = (uint64_t) prefetch_reads();
+	uint64_t i = i0;
+	if (ahead)
+		for (; i + 16 <= i1; i += 16) { // sixteen reads are one line of positions
+			_mm_prefetch(reinterpret_cast<const char *>(pos + i + ahead), _MM_HINT_T0);
+			encode_group_avx2<W>(pos, i, out, exc);
+			encode_group_avx2<W>(pos, i + 8, out, exc);
+		}
+	for (; i < i1; i += 8)
+		encode_group_avx2<W>(pos, i, out, exc);
 }
 
 inline bool have_avx2_bmi2()
@@ -167,7 +205,7 @@ template <int W> inline void encode_group_slow(const int32_t *&pos, uint64_t i, 
 // one run [r0, r1) of the sample (r0 a multiple of 8; r1 one too, or the sample's end) at width W; `forced` = indices in [r0, r1)
 // that are a chromosome's first read (ascending); `pos`: the array of read r0 (see encode_group_slow)
 template <int W>
-inline void encode_run(const int32_t *pos, uint64_t r0, uint64_t r1, const uint64_t *forced, const int32_t *const *fbase, size_t n_forced, uint8_t *out,
+inline void encode_run_to(const int32_t *pos, uint64_t r0, uint64_t r1, const uint64_t *forced, const int32_t *const *fbase, size_t n_forced, uint8_t *out,
 		std::vector<Exc> &exc)
 {
 	size_t f = 0;
@@ -190,6 +228,45 @@ inline void encode_run(const int32_t *pos, uint64_t r0, uint64_t r1, const uint6
 	}
 	if (cur < r1)
 		encode_group_slow<W>(pos, cur, r1, forced, fbase, n_forced, &f, out, exc);
+}
+
+#if defined(__x86_64__)
+// The run's bytes leave the core with non-temporal stores (CONGA_DEBUG=1 CONGA_PACK_NO_STREAM=1: plain ones): `out` is the pinned
+// buffer the link reads next and nobody else -- written the plain way every line of it is first READ from memory (a quarter more
+// traffic for a producer that is bound by memory) and then sits modified in some core's cache when the copy engine asks for it
+// (engine_bgzf: the pinned ring goes up at 50 GB/s filled this way, at 43-44 filled by plain stores).
+inline bool stream_out()
+{
+	static const bool yes = !(getenv("CONGA_DEBUG") && atoi(getenv("CONGA_DEBUG")) != 0 && getenv("CONGA_PACK_NO_STREAM"));
+	return yes;
+}
+inline void stream_copy(uint8_t *dst, const uint8_t *src, size_t n) // src 16-byte aligned
+{
+	size_t k = 0;
+	if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)
+		for (; k + 16 <= n; k += 16)
+			_mm_stream_si128(reinterpret_cast<__m128i *>(dst + k), _mm_load_si128(reinterpret_cast<const __m128i *>(src + k)));
+	memcpy(dst + k, src + k, n - k);
+}
+#endif
+
+template <int W>
+inline void encode_run(const int32_t *pos, uint64_t r0, uint64_t r1, const uint64_t *forced, const int32_t *const *fbase, size_t n_forced, uint8_t *out,
+		std::vector<Exc> &exc)
+{
+#if defined(__x86_64__)
+	if (stream_out() && r1 - r0 <= kRun) {
+		// the run is put together in a buffer of the thread's own (10 KB at ten bits: it stays in L1) ...
+		alignas(64) uint8_t own[kRun / 8 * 16 + 64];
+		const size_t at = (size_t) (r0 >> 3) * W, n_bytes = (size_t) ((r1 - r0 + 7) / 8) * W;
+		// (the encoder addresses group g at base + g * W: a base computed as an integer, only the run's own bytes are written through it)
+		uint8_t *base = reinterpret_cast<uint8_t *>(reinterpret_cast<uintptr_t>(own) - (uintptr_t) at);
+		encode_run_to<W>(pos, r0, r1, forced, fbase, n_forced, base, exc);
+		stream_copy(out + at, own, n_bytes); // ... and leaves it in one piece (run r begins r * 1024 * W bytes in: a multiple of 16)
+		return;
+	}
+#endif
+	encode_run_to<W>(pos, r0, r1, forced, fbase, n_forced, out, exc);
 }
 
 inline void encode_run_any(int width, const int32_t *pos, uint64_t r0, uint64_t r1, const uint64_t *forced, const int32_t *const *fbase, size_t n_forced,
@@ -520,18 +597,27 @@ private:
 			}
 			size_t mine = 0;
 			for (;;) {
-				const size_t r = next_.fetch_add(1, std::memory_order_relaxed);
-				if (r >= n_runs_)
+				// (eight runs in a row per turn: a thread reads 256 KB of positions as one stream -- the hardware's prefetcher and the
+				// requests made ahead in encode_groups_avx2 both start anew wherever a thread jumps)
+				// (... as long as every thread still gets eight turns or so: a rank's share of a genome on eight GPUs is 390 runs)
+				const size_t kBatch = batch_runs() ? batch_runs() : std::max<size_t>(1, std::min<size_t>(8, n_runs_ / (8 * (size_t) n_threads_)));
+				const size_t b = next_.fetch_add(1, std::memory_order_relaxed);
+				if (b * kBatch >= n_runs_)
 					break;
-				const uint64_t r0 = (uint64_t) r * kRun, r1 = std::min(n_, r0 + kRun);
-				const auto f0 = std::lower_bound(forced_.begin(), forced_.end(), r0), f1 = std::lower_bound(f0, forced_.end(), r1);
-				const size_t k0 = (size_t) (f0 - forced_.begin());
-				// the array read r0 lies in: that of the last chromosome that begins at or before it (forced_[0] == 0 whenever there are reads)
-				const int32_t *at_r0 = fbase_[(f0 != forced_.end() && *f0 == r0) ? k0 : k0 - 1];
-				exc_[r].clear();
-				encode_run_any(width_, at_r0, r0, r1, forced_.data() + k0, gather_ ? fbase_.data() + k0 : nullptr, (size_t) (f1 - f0), out_, exc_[r]);
-				mine++;
+				for (size_t r = b * kBatch; r < std::min(n_runs_, (b + 1) * kBatch); r++) {
+					const uint64_t r0 = (uint64_t) r * kRun, r1 = std::min(n_, r0 + kRun);
+					const auto f0 = std::lower_bound(forced_.begin(), forced_.end(), r0), f1 = std::lower_bound(f0, forced_.end(), r1);
+					const size_t k0 = (size_t) (f0 - forced_.begin());
+					// the array read r0 lies in: that of the last chromosome that begins at or before it (forced_[0] == 0 whenever there are reads)
+					const int32_t *at_r0 = fbase_[(f0 != forced_.end() && *f0 == r0) ? k0 : k0 - 1];
+					exc_[r].clear();
+					encode_run_any(width_, at_r0, r0, r1, forced_.data() + k0, gather_ ? fbase_.data() + k0 : nullptr, (size_t) (f1 - f0), out_, exc_[r]);
+					mine++;
+				}
 			}
+#if defined(__x86_64__)
+			_mm_sfence(); // the non-temporal stores of this thread's runs are in memory before finish() says so
+#endif
 			{
 				std::lock_guard<std::mutex> g(mu_);
 				left_ -= mine;

@@ -6,41 +6,60 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 int main(int argc, char **argv)
 {
+	// --rotate R: R samples of 25.6 M positions taken in turn, as bench.py's step does (three: 307 MB between two encodes of one
+	// sample, more than a socket's L3 -- one sample encoded again and again is partly read from cache)
 	const uint64_t n = 25600000;
-	std::vector<int32_t> pos(n);
+	int rotate = 1;
+	for (int a = 1; a + 1 < argc; a++)
+		if (strcmp(argv[a], "--rotate") == 0)
+			rotate = std::max(1, atoi(argv[a + 1]));
+	std::vector<std::vector<int32_t>> samples((size_t) rotate, std::vector<int32_t>(n));
 	uint64_t x = 88172645463325252ull;
-	int32_t p = 0;
-	for (uint64_t i = 0; i < n; i++) {
-		x ^= x << 13, x ^= x >> 7, x ^= x << 17;
-		if (i == n / 2)
-			p = 0;
-		p += (int32_t) (x % 199u) + ((x >> 40) % 4000u == 0 ? 30000 : 0);
-		pos[i] = p;
+	for (auto &pos : samples) {
+		int32_t p = 0;
+		for (uint64_t i = 0; i < n; i++) {
+			x ^= x << 13, x ^= x >> 7, x ^= x << 17;
+			if (i == n / 2)
+				p = 0;
+			p += (int32_t) (x % 199u) + ((x >> 40) % 4000u == 0 ? 30000 : 0);
+			pos[i] = p;
+		}
 	}
 	const uint64_t off[3] = {0, n / 2, n};
-	std::vector<uint8_t> out(conga_pack::bound(n, n / 16));
+	std::vector<std::vector<uint8_t>> outs((size_t) rotate, std::vector<uint8_t>(conga_pack::bound(n, n / 16)));
 	int spread = 0;
-	for (int a = 1; a < (argc > 1 ? argc : 2); a++) {
-		if (argc > 1 && strcmp(argv[a], "--spread") == 0 && a + 1 < argc) {
+	bool any = false;
+	for (int a = 1; a < argc || !any; a++) {
+		if (a < argc && strcmp(argv[a], "--spread") == 0 && a + 1 < argc) {
 			spread = atoi(argv[++a]);
 			continue;
 		}
-		const int nt = argc > 1 ? atoi(argv[a]) : 8;
+		if (a < argc && strcmp(argv[a], "--rotate") == 0 && a + 1 < argc) {
+			a++;
+			continue;
+		}
+		any = true;
+		const int nt = a < argc ? atoi(argv[a]) : 8;
 		conga_pack::Packer pk(nt, spread);
-		double best = 1e30;
+		std::vector<double> ms;
 		int w = 0;
 		size_t ne = 0, nb = 0;
-		for (int rep = 0; rep < 12; rep++) {
+		const int reps = 12 * rotate;
+		for (int rep = 0; rep < reps; rep++) {
 			const auto t0 = std::chrono::steady_clock::now();
-			if (pk.start(pos.data(), off, 2, 0, out.data(), out.size()) != 0 || pk.finish(&w, &ne, &nb) != 0)
+			std::vector<uint8_t> &out = outs[(size_t) (rep % rotate)];
+			if (pk.start(samples[(size_t) (rep % rotate)].data(), off, 2, 0, out.data(), out.size()) != 0 || pk.finish(&w, &ne, &nb) != 0)
 				return 1;
-			best = std::min(best, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+			ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
 		}
-		printf("%2d threads (spread %d): %.3f ms best of 12 (width %d, %zu exceptions, %zu bytes) = %.1f GB/s of positions read, %s\n", nt, spread, best, w, ne, nb,
-				4.0 * n / best / 1e6, conga_pack::have_avx2_bmi2() ? "avx2+bmi2" : "scalar");
+		std::sort(ms.begin() + rotate, ms.end()); // (the first turn touches the pages)
+		const double best = ms[(size_t) rotate], median = ms[(size_t) rotate + (ms.size() - (size_t) rotate) / 2];
+		printf("%2d threads (spread %d, rotate %d): %.3f ms best, %.3f median of %d (width %d, %zu exceptions, %zu bytes) = %.1f GB/s of positions read, %s\n", nt, spread,
+				rotate, best, median, reps - rotate, w, ne, nb, 4.0 * n / best / 1e6, conga_pack::have_avx2_bmi2() ? "avx2+bmi2" : "scalar");
 	}
 	return 0;
 }
