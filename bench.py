@@ -135,6 +135,16 @@ def cpus_granted():
     return max(1, n)
 
 
+def cpu_throttled():
+    """(times, milliseconds) the cgroup's CPU quota has held this process back so far -- a producer with as many busy threads as
+    the quota has CPUs runs into it."""
+    try:
+        st = dict(line.split() for line in open("/sys/fs/cgroup/cpu.stat"))
+        return int(st.get("nr_throttled", 0)), int(st.get("throttled_usec", 0)) / 1e3
+    except (OSError, ValueError):
+        return 0, 0.0
+
+
 def open_layout(ctx, mine):
     """The part of a cohort job that is handed over once: chromosomes, GC arrays, intervals, tracks."""
     for i, u in enumerate(mine):
@@ -404,6 +414,7 @@ class Leg:
                 c.compute()
                 phases = os.environ.get("CONGA_BENCH_PHASES")   # (measurement switch: where the host thread's time goes, on stderr)
                 t_ph = [0.0] * 5
+                thr0 = cpu_throttled()
                 for k in range(1, n):
                     if phases:
                         t0 = time.perf_counter()
@@ -429,7 +440,9 @@ class Leg:
                     c.compute()
                 if phases and n > 1:
                     print("[phases] per step over %d steps: wait for the encode %.3f ms, hand over %.3f, start the next encode %.3f, fetch %.3f, "
-                          "compute (enqueue) %.3f" % ((n - 1,) + tuple(1e3 * x / (n - 1) for x in t_ph)), file=sys.stderr, flush=True)
+                          "compute (enqueue) %.3f; the cgroup held the process back %d times, %.1f ms in all"
+                          % ((n - 1,) + tuple(1e3 * x / (n - 1) for x in t_ph) + tuple(b - a for a, b in zip(thr0, cpu_throttled()))),
+                          file=sys.stderr, flush=True)
                 self.finish(n - 1, c)
             else:
                 self.reads(c, 0)
