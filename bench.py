@@ -356,20 +356,26 @@ class Leg:
             self.reads(c, k % N_ROTATE)               # pinned host -> HBM, asynchronous
         c.compute()                                   # the whole hot path for this rank's chromosomes, asynchronous
 
-    def finish(self, k, c=None):
+    def finish(self, k, c=None, previous=False):
         """The records of step k: into host memory (N = 1), or into the RCCL gather towards rank 0 (N > 1) -- c: the context that
-        computed the step (the one-context loop passes its only one)."""
+        computed the step (the one-context loop passes its only one); previous: step k + 1 has been computed ahead
+        (conga_chrom_compute_ahead) and step k's results are those of the compute before the latest one."""
         j = k % N_ROTATE
         if c is None:
             c = self.ctxs[j]
         if not self.env["dist_on"]:
-            c.sample_fetch(self.out[j], self.E[j])    # waits for the kernels; records into host memory
+            # waits for the kernels of step k; records into host memory
+            (c.sample_fetch_previous if previous else c.sample_fetch)(self.out[j], self.E[j])
             return
         import torch
         import torch.distributed as dist
         env = self.env
-        c.sync()                                      # (settles the wrap guard before the records are read on the device)
-        c.results_copy(self.packed[j].data_ptr(), self.n_iv_mine * self.rec)
+        if previous:
+            c.sync_previous()                         # (settles the wrap guard before the records are read on the device)
+            c.results_copy_previous(self.packed[j].data_ptr(), self.n_iv_mine * self.rec)
+        else:
+            c.sync()
+            c.results_copy(self.packed[j].data_ptr(), self.n_iv_mine * self.rec)
         if env["rehearsal"]:                          # one GPU, gloo: host tensors
             c.sync()
             dist.gather(self.packed[j].cpu(), self.recv[j], dst=0)
@@ -406,6 +412,10 @@ class Leg:
             # (N = 1) or gathered (N > 1: finish(k) copies them into send buffer k % 3 on the context's stream and gathers on a stream
             # of the gather's own).  With hand_over = "packed+encode" the library's producer encodes sample k + 1 meanwhile.
             c = self.ctxs[0]
+            # Two computes in flight (ABI v9): step k + 1 is handed over AND enqueued before step k is waited for, so that the GPU
+            # goes from one step's last launch to the next one's first without waiting for the host's wake-up, its fetch and its
+            # launches (CONGA_BENCH_NO_AHEAD=1: round 4's order, hand over (k + 1) -> fetch (k) -> compute (k + 1)).
+            ahead = not os.environ.get("CONGA_BENCH_NO_AHEAD")
             if self.hand_over == "packed+encode":
                 self.encode_start(0)
                 self.encode_finish_and_hand_over(c, 0)
@@ -416,28 +426,31 @@ class Leg:
                 t_ph = [0.0] * 5
                 thr0 = cpu_throttled()
                 for k in range(1, n):
-                    if phases:
-                        t0 = time.perf_counter()
-                        width, n_esc, _nb = self.packer.finish()
-                        t1 = time.perf_counter()
-                        _pos, mapq, off = self.samples[k % N_ROTATE][:3]
-                        c.sample_reads_packed(self.enc[k % 3], width, n_esc, None, mapq, off)
-                        t2 = time.perf_counter()
-                        if k + 1 < n:
-                            self.encode_start(k + 1)
-                        t3 = time.perf_counter()
+                    t0 = time.perf_counter()
+                    width, n_esc, _nb = self.packer.finish()
+                    t1 = time.perf_counter()
+                    _pos, mapq, off = self.samples[k % N_ROTATE][:3]
+                    c.sample_reads_packed(self.enc[k % 3], width, n_esc, None, mapq, off)
+                    t2 = time.perf_counter()
+                    if k + 1 < n:
+                        self.encode_start(k + 1)
+                    t3 = time.perf_counter()
+                    if ahead:
+                        c.compute_ahead()
+                        t4 = time.perf_counter()
+                        self.finish(k - 1, c, previous=True)
+                        t5 = time.perf_counter()
+                        t_ph[3] += t5 - t4
+                        t_ph[4] += t4 - t3
+                    else:
                         self.finish(k - 1, c)
                         t4 = time.perf_counter()
                         c.compute()
                         t5 = time.perf_counter()
-                        for i, (a, b) in enumerate(((t0, t1), (t1, t2), (t2, t3), (t3, t4), (t4, t5))):
-                            t_ph[i] += b - a
-                        continue
-                    self.encode_finish_and_hand_over(c, k)
-                    if k + 1 < n:
-                        self.encode_start(k + 1)
-                    self.finish(k - 1, c)
-                    c.compute()
+                        t_ph[3] += t4 - t3
+                        t_ph[4] += t5 - t4
+                    for i, (a, b) in enumerate(((t0, t1), (t1, t2), (t2, t3))):
+                        t_ph[i] += b - a
                 if phases and n > 1:
                     print("[phases] per step over %d steps: wait for the encode %.3f ms, hand over %.3f, start the next encode %.3f, fetch %.3f, "
                           "compute (enqueue) %.3f; the cgroup held the process back %d times, %.1f ms in all"
@@ -449,8 +462,12 @@ class Leg:
                 c.compute()
                 for k in range(1, n):
                     self.reads(c, k % N_ROTATE)
-                    self.finish(k - 1, c)
-                    c.compute()
+                    if ahead:
+                        c.compute_ahead()
+                        self.finish(k - 1, c, previous=True)
+                    else:
+                        self.finish(k - 1, c)
+                        c.compute()
                 self.finish(n - 1, c)
             self.drain()
             return

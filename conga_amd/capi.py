@@ -39,7 +39,8 @@ EXPORTS = (
     "conga_create", "conga_destroy", "conga_strerror", "conga_last_error", "conga_abi_version",
     "conga_device_count", "conga_reset", "conga_chrom_count", "conga_chrom_select", "conga_chrom_begin", "conga_reads_staging", "conga_reads_commit",
     "conga_reads_bgzf", "conga_reads_bgzf_fd", "conga_reads_bgzf_next_fd", "conga_reads_bgzf_next_table", "conga_reads_bgzf_next_blocks", "conga_reads_bgzf_next_go", "conga_reads_bgzf_forget", "conga_release_staging", "conga_inflate_blocks", "conga_host_alloc", "conga_host_free", "conga_sample_reads", "conga_sample_reads_d16", "conga_sample_reads_packed", "conga_packer_create", "conga_packer_destroy", "conga_packer_threads", "conga_pack_bound", "conga_packer_start", "conga_packer_start_v", "conga_packer_finish", "conga_sample_begin",
-    "conga_sample_chrom", "conga_sample_fetch",
+    "conga_sample_chrom", "conga_sample_fetch", "conga_chrom_compute_ahead", "conga_sample_fetch_previous", "conga_sync_previous",
+    "conga_results_copy_previous",
     "conga_mappability", "conga_intervals", "conga_reference", "conga_satellites", "conga_split_reads_staging",
     "conga_split_reads_commit", "conga_split_support", "conga_chrom_compute",
     "conga_chrom_fetch", "conga_chrom_finish", "conga_results_device", "conga_results_copy",
@@ -300,6 +301,14 @@ def load():
     L.conga_sample_chrom.argtypes = [vp, C.c_int]
     L.conga_sample_fetch.restype = C.c_int
     L.conga_sample_fetch.argtypes = [vp, vp, sz, vp, C.POINTER(ChromStats)]
+    L.conga_sample_fetch_previous.restype = C.c_int
+    L.conga_sample_fetch_previous.argtypes = [vp, vp, sz, vp, C.POINTER(ChromStats)]
+    L.conga_chrom_compute_ahead.restype = C.c_int
+    L.conga_chrom_compute_ahead.argtypes = [vp]
+    L.conga_sync_previous.restype = C.c_int
+    L.conga_sync_previous.argtypes = [vp]
+    L.conga_results_copy_previous.restype = C.c_int
+    L.conga_results_copy_previous.argtypes = [vp, vp, sz]
     L.conga_mappability.restype = C.c_int
     L.conga_mappability.argtypes = [vp, vp, vp, vp, sz]
     L.conga_intervals.restype = C.c_int
@@ -504,6 +513,17 @@ class Context:
         self._check(self._lib.conga_sample_fetch(self._h, records.ctypes.data if n else None, n, expected.ctypes.data, st))
         return records, expected, st
 
+    def sample_fetch_previous(self, records=None, expected=None, want_stats=False):
+        """conga_sample_fetch_previous: the same for the compute BEFORE the latest one (compute_ahead)."""
+        n, nc = self.n_records, len(self._meta)
+        if records is None:
+            records = np.zeros(n, dtype=RESULT_DTYPE)
+        if expected is None:
+            expected = np.zeros((nc, 101), dtype=np.float32)
+        st = (ChromStats * nc)() if want_stats else None
+        self._check(self._lib.conga_sample_fetch_previous(self._h, records.ctypes.data if n else None, n, expected.ctypes.data, st))
+        return records, expected, st
+
     def release_staging(self):
         """conga_release_staging: the pinned ring of conga_reads_bgzf back to the system (made again when needed)."""
         self._check(self._lib.conga_release_staging(self._h))
@@ -620,6 +640,17 @@ class Context:
 
     def compute(self):
         self._check(self._lib.conga_chrom_compute(self._h))
+
+    def compute_ahead(self):
+        """conga_chrom_compute_ahead: behind the last compute, whose results stay fetchable (sample_fetch_previous, sync_previous,
+        results_copy_previous)."""
+        self._check(self._lib.conga_chrom_compute_ahead(self._h))
+
+    def sync_previous(self):
+        self._check(self._lib.conga_sync_previous(self._h))
+
+    def results_copy_previous(self, dst_ptr, dst_bytes):
+        self._check(self._lib.conga_results_copy_previous(self._h, C.c_void_p(dst_ptr), dst_bytes))
 
     def fetch(self):
         """-> (dels RESULT_DTYPE[n_dels], dups RESULT_DTYPE[n_dups], E float32[101], ChromStats)"""

@@ -257,6 +257,8 @@ conga_ctx *conga_create(int device, const conga_opts *opts, int *status)
 	if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_low) != hipSuccess)
 		return bail(CONGA_ERR_HIP);
 	if (hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming) != hipSuccess
+			|| hipEventCreateWithFlags(&ctx->ev_set, hipEventDisableTiming) != hipSuccess
+			|| hipEventCreateWithFlags(&ctx->ev_set_prev, hipEventDisableTiming) != hipSuccess
 			|| hipEventCreateWithFlags(&ctx->ev_head, hipEventDisableTiming) != hipSuccess)
 		return bail(CONGA_ERR_HIP);
 	if (hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_low) != hipSuccess
@@ -313,7 +315,7 @@ void conga_destroy(conga_ctx *ctx)
 			&ctx->d_map_val, &ctx->d_iv_start, &ctx->d_iv_end, &ctx->d_iv_type, &ctx->d_iv_slot, &ctx->d_iv_has_map,
 			&ctx->d_order, &ctx->d_bz_in, &ctx->d_bz_blocks, &ctx->d_bz_off, &ctx->d_bz_out, &ctx->d_bz_status, &ctx->d_bz_out2, &ctx->d_bz_blocks2, &ctx->d_bz_off2, &ctx->d_bz_status2, &ctx->d_bz_scratch,
 			&ctx->d_bz_crc, &ctx->d_bz_x2n, &ctx->d_bz_ticket, &ctx->d_bz_seg, &ctx->d_bz_cnt, &ctx->d_bz_first, &ctx->d_bz_stop, &ctx->d_bz_bad, &ctx->d_bz_at, &ctx->d_bz_flag, &ctx->d_expected, &ctx->d_item_off, &ctx->d_item_len, &ctx->d_item_iv,
-			&ctx->d_item_has_map, &ctx->d_item_first, &ctx->d_map_part, &ctx->d_support, &ctx->d_results,
+			&ctx->d_item_has_map, &ctx->d_item_first, &ctx->d_map_part, &ctx->d_support, &ctx->d_results, &ctx->d_results_prev,
 			&ctx->d_bases, &ctx->d_row_tile, &ctx->d_depth_blocks, &ctx->d_support_base, &ctx->d_ref, &ctx->d_sat_start, &ctx->d_sat_end,
 			&ctx->d_sr_pos, &ctx->d_sr_mapq, &ctx->d_sr_flag, &ctx->d_sr_lq, &ctx->d_sr_off, &ctx->d_sr_data,
 			&ctx->d_sr_recoff, &ctx->d_refn, &ctx->d_kmer_keys, &ctx->d_kmer_sorted, &ctx->d_kmer_tmp, &ctx->d_kmer_offset, &ctx->d_kmer_pos, &ctx->d_kmer_pres};
@@ -336,6 +338,10 @@ void conga_destroy(conga_ctx *ctx)
 	}
 	if (ctx->h_small)
 		(void) hipHostFree(ctx->h_small);
+	if (ctx->h_small_prev)
+		(void) hipHostFree(ctx->h_small_prev);
+	if (ctx->h_results_prev)
+		(void) hipHostFree(ctx->h_results_prev);
 	if (ctx->h_head)
 		(void) hipHostFree(ctx->h_head);
 	hand_spare_on(ctx);
@@ -384,6 +390,10 @@ void conga_destroy(conga_ctx *ctx)
 		(void) hipHostFree(ctx->h_results);
 	if (ctx->ev_done)
 		(void) hipEventDestroy(ctx->ev_done);
+	if (ctx->ev_set)
+		(void) hipEventDestroy(ctx->ev_set);
+	if (ctx->ev_set_prev)
+		(void) hipEventDestroy(ctx->ev_set_prev);
 	for (int k = 0; k < CONGA_K_COUNT; k++) {
 		if (ctx->ev_k0[k])
 			(void) hipEventDestroy(ctx->ev_k0[k]);
@@ -557,6 +567,8 @@ int drop_reads(conga_ctx *ctx, const char *who, bool keep_computed = false)
 		return fail(ctx, CONGA_ERR_INVALID, std::string(who) + ": no chromosome open");
 	if (ctx->staging_cur >= 0)
 		return fail(ctx, CONGA_ERR_INVALID, std::string(who) + ": a staging buffer is handed out and not committed");
+	// (two computes in flight, conga_chrom_compute_ahead: the older one's tuples are about to be given up -- its guard first)
+	TRY(settle_previous(ctx));
 	for (HostSlot &h : ctx->slots) {
 		h.read_off = 0;
 		h.n_reads = 0;

@@ -3,12 +3,29 @@
 // guard's second compute, and the device-side access used by the multi-GPU gather.  Part of conga_api.hip's one translation unit.
 #pragma once
 
-extern "C" {
+namespace {
 
-int conga_chrom_compute(conga_ctx *ctx)
+int settle_previous(conga_ctx *ctx);
+
+// the set of the latest compute <-> the set of the one before (engine_ctx.hip.h)
+void swap_result_sets(conga_ctx *ctx)
 {
-	if (!ctx)
-		return CONGA_ERR_INVALID;
+	std::swap(ctx->ev_set, ctx->ev_set_prev);
+	std::swap(ctx->h_small, ctx->h_small_prev);
+	std::swap(ctx->h_small_cap, ctx->h_small_prev_cap);
+	std::swap(ctx->h_results, ctx->h_results_prev);
+	std::swap(ctx->h_results_cap, ctx->h_results_prev_cap);
+	std::swap(ctx->d_results, ctx->d_results_prev);
+	std::swap(ctx->host_results_by_order, ctx->prev_by_order);
+	std::swap(ctx->host_results_valid, ctx->prev_valid);
+	std::swap(ctx->depth_resident, ctx->prev_depth_resident);
+	ctx->computed_reads.swap(ctx->prev_computed_reads);
+	std::swap(ctx->computed_total, ctx->prev_computed_total);
+}
+
+// every launch of a step into the queues (conga_chrom_compute, conga_chrom_compute_ahead, the wrap guard's second compute)
+int compute_step(conga_ctx *ctx)
+{
 	if (ctx->slots.empty())
 		return fail(ctx, CONGA_ERR_INVALID, "conga_chrom_compute: no chromosome open");
 	if (ctx->staging_cur >= 0)
@@ -115,6 +132,7 @@ int conga_chrom_compute(conga_ctx *ctx)
 	ctx->depth_resident = dense;
 	ctx->small_cur = ctx->small_cur_next; // the arena the chain launch has just cleared, if it did
 	HIP_TRY(ctx, hipEventRecord(ctx->ev_done, st));
+	HIP_TRY(ctx, hipEventRecord(ctx->ev_set, st));
 	ctx->computed_once.store(true, std::memory_order_release);
 	HIP_TRY(ctx, hipEventRecord(ctx->ev_pair[ctx->pos_buf], st));
 	ctx->used_recorded[ctx->pos_buf] = true;
@@ -127,6 +145,67 @@ int conga_chrom_compute(conga_ctx *ctx)
 	ctx->computed = true;
 	bz::trace("compute: enqueued");
 	hand_spare_on(ctx); // (this sample's launches are in the queues: the next sample's inflates may follow them -- engine_bgzf.hip.h)
+	return CONGA_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int conga_chrom_compute(conga_ctx *ctx)
+{
+	if (!ctx)
+		return CONGA_ERR_INVALID;
+	ctx->have_previous = false; // (what the compute before the last one left is out of reach from here on)
+	return compute_step(ctx);
+}
+
+// The step's launches go into the queues BEHIND the last compute's, whose results stay where they are until
+// conga_sample_fetch_previous / conga_sync_previous / conga_results_copy_previous have had them: hand over sample k + 1, compute it
+// ahead, fetch sample k -- the GPU goes from one sample's last launch to the next one's first while the host is still waking up.
+// Without a compute whose results could be kept (none yet, or the layout has changed since) this is conga_chrom_compute.
+int conga_chrom_compute_ahead(conga_ctx *ctx)
+{
+	if (!ctx)
+		return CONGA_ERR_INVALID;
+	// (a layout that only has to be laid out for the other formulation -- the sample before needed the dense kernels -- keeps its
+	// chromosomes, intervals and their order: the older records stay what they were)
+	if (!ctx->computed || ctx->layout_dirty || (ctx->opts.flags & CONGA_FLAG_PROFILE) != 0 || ctx->n_sr_total != 0 || ctx->bz_keep_bytes != 0)
+		return conga_chrom_compute(ctx);
+	if (ctx->staging_cur >= 0)
+		return fail(ctx, CONGA_ERR_INVALID, "conga_chrom_compute_ahead: a staging buffer is handed out and not committed");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	// (the set before the last one -- if there is one -- is given up: its guard is looked at first, an error of its own is the caller's
+	// who never fetched it)
+	TRY(settle_previous(ctx));
+	// the spare set as large as the one in use (first time: two pinned blocks and the records' buffer; nothing is in flight on them)
+	if (ctx->h_small_prev_cap < ctx->h_small_cap) {
+		if (ctx->h_small_prev)
+			(void) hipHostFree(ctx->h_small_prev);
+		ctx->h_small_prev = nullptr;
+		ctx->h_small_prev_cap = 0;
+		HIP_TRY(ctx, hipHostMalloc((void **) &ctx->h_small_prev, ctx->h_small_cap * sizeof(Small), hipHostMallocDefault));
+		ctx->h_small_prev_cap = ctx->h_small_cap;
+	}
+	if (ctx->h_results_prev_cap < ctx->h_results_cap) {
+		if (ctx->h_results_prev)
+			(void) hipHostFree(ctx->h_results_prev);
+		ctx->h_results_prev = nullptr;
+		ctx->h_results_prev_cap = 0;
+		HIP_TRY(ctx, hipHostMalloc((void **) &ctx->h_results_prev, ctx->h_results_cap * sizeof(conga_result), hipHostMallocDefault));
+		ctx->h_results_prev_cap = ctx->h_results_cap;
+	}
+	TRY(ensure(ctx, ctx->d_results_prev, ctx->d_results.cap));
+	drop_graph(ctx); // (a captured step has the other set's addresses in it)
+	swap_result_sets(ctx);
+	const int rc = compute_step(ctx);
+	if (rc != CONGA_OK) {
+		swap_result_sets(ctx);
+		ctx->have_previous = false;
+		return rc;
+	}
+	ctx->have_previous = true;
+	ctx->previous_settled = false;
 	return CONGA_OK;
 }
 
@@ -431,7 +510,7 @@ int enqueue_compute(conga_ctx *ctx, bool dense)
 			c.score = sa;
 			const bool to_host = (ctx->opts.flags & CONGA_FLAG_RESULTS_ON_DEVICE) == 0;
 			c.out_host = to_host ? ctx->h_results : nullptr;
-			ctx->host_results_by_order = fused_score && to_host;
+			ctx->host_results_by_order = false; // (the chain kernel writes the host copy in interval order too: the fetch is a plain copy)
 			ctx->host_results_valid = to_host;
 			c.start = ptr<int32_t>(ctx->d_iv_start);
 			c.end = ptr<int32_t>(ctx->d_iv_end);
@@ -502,8 +581,8 @@ int settle_wrap_risk(conga_ctx *ctx)
 		return CONGA_OK;
 	if (!ctx->reads_ahead) {
 		ctx->wrap_risk = true;
-		TRY(conga_chrom_compute(ctx));
-		HIP_TRY(ctx, hipEventSynchronize(ctx->ev_done));
+		TRY(compute_step(ctx));
+		HIP_TRY(ctx, hipEventSynchronize(ctx->ev_set));
 		return CONGA_OK;
 	}
 	// The next sample's tuples are already on their way (conga_sample_reads beside this compute): the sample that has to be
@@ -525,8 +604,8 @@ int settle_wrap_risk(conga_ctx *ctx)
 	ctx->reads_on_stream2 = false; // (this compute reads the OLD pair: nothing to wait for)
 	ctx->wrap_risk = true;
 	ctx->sample_dirty = true;
-	int rc = conga_chrom_compute(ctx);
-	if (rc == CONGA_OK && hipEventSynchronize(ctx->ev_done) != hipSuccess)
+	int rc = compute_step(ctx);
+	if (rc == CONGA_OK && hipEventSynchronize(ctx->ev_set) != hipSuccess)
 		rc = fail(ctx, CONGA_ERR_HIP, "settle_wrap_risk: waiting for the second compute failed");
 	for (size_t c = 0; c < ctx->slots.size(); c++) {
 		ctx->slots[c].read_off = next_reads[c].first;
@@ -544,6 +623,31 @@ int settle_wrap_risk(conga_ctx *ctx)
 	return rc;
 }
 
+// The same for the compute BEFORE the latest one (conga_chrom_compute_ahead): its tuples lie in the other pair of buffers as long
+// as no further sample has been handed over -- every path that hands one over comes through here first.  With the sets swapped the
+// case is settle_wrap_risk's own "the next sample is already there": the HostSlots describe a newer sample (here: one that has even
+// been computed) than the set being looked at.
+int settle_previous(conga_ctx *ctx)
+{
+	if (!ctx->have_previous || ctx->previous_settled)
+		return CONGA_OK;
+	if (!ctx->computed) { // (the reads were dropped or the layout touched since: the older results went with the latest ones)
+		ctx->have_previous = false;
+		return CONGA_OK;
+	}
+	ctx->previous_settled = true;
+	swap_result_sets(ctx);
+	int rc = hipEventSynchronize(ctx->ev_set) == hipSuccess ? CONGA_OK : fail(ctx, CONGA_ERR_HIP, "settle_previous: waiting for the compute failed");
+	if (rc == CONGA_OK) {
+		const bool keep = ctx->reads_ahead;
+		ctx->reads_ahead = true;
+		rc = settle_wrap_risk(ctx);
+		ctx->reads_ahead = keep;
+	}
+	swap_result_sets(ctx);
+	return rc;
+}
+
 } // namespace
 
 extern "C" {
@@ -558,9 +662,12 @@ int conga_chrom_fetch(conga_ctx *ctx, conga_result *dels, conga_result *dups, fl
 	HostSlot *h = current(ctx);
 	if (!h)
 		return fail(ctx, CONGA_ERR_INVALID, "conga_chrom_fetch: no chromosome selected");
+	const auto tf0 = std::chrono::steady_clock::now();
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
-	HIP_TRY(ctx, hipEventSynchronize(ctx->ev_done));
+	HIP_TRY(ctx, hipEventSynchronize(ctx->ev_set));
+	const auto tf1 = std::chrono::steady_clock::now();
 	TRY(settle_wrap_risk(ctx));
+	const auto tf2 = std::chrono::steady_clock::now();
 	const Small &sb = ctx->h_small[ctx->cur];
 	if (sb.status & kStatusUnsorted)
 		return fail(ctx, CONGA_ERR_UNSORTED,
@@ -581,13 +688,29 @@ int conga_chrom_fetch(conga_ctx *ctx, conga_result *dels, conga_result *dups, fl
 		if (nu)
 			memcpy(dups, ctx->h_results + h->iv0 + nd, nu * sizeof(conga_result));
 	} else { // the chain kernel wrote the host copy in its own processing order
+		const conga_result *src = ctx->h_results;
 		for (size_t i = 0; i < nd; i++)
-			dels[i] = ctx->h_results[ctx->order_pos[(size_t) h->iv0 + i]];
+			dels[i] = src[ctx->order_pos[(size_t) h->iv0 + i]];
 		for (size_t i = 0; i < nu; i++)
-			dups[i] = ctx->h_results[ctx->order_pos[(size_t) h->iv0 + nd + i]];
+			dups[i] = src[ctx->order_pos[(size_t) h->iv0 + nd + i]];
 	}
+	const auto tf3 = std::chrono::steady_clock::now();
 	if (expected_rd)
 		memcpy(expected_rd, sb.E, kGcBins * sizeof(float));
+	if (ctx->knobs.timing) { // (measurement switch CONGA_DEBUG=1 CONGA_TIMING=1: where a fetch's time goes, every 64th call)
+		static thread_local double acc[4] = {0, 0, 0, 0};
+		static thread_local int calls = 0;
+		const auto tf4 = std::chrono::steady_clock::now();
+		acc[0] += std::chrono::duration<double, std::micro>(tf1 - tf0).count();
+		acc[1] += std::chrono::duration<double, std::micro>(tf2 - tf1).count();
+		acc[2] += std::chrono::duration<double, std::micro>(tf3 - tf2).count();
+		acc[3] += std::chrono::duration<double, std::micro>(tf4 - tf3).count();
+		if (++calls % 64 == 0) {
+			fprintf(stderr, "[timing] conga_chrom_fetch x64: the wait %.1f us, the guard %.1f, the records %.1f, the table %.1f (per call)\n", acc[0] / 64, acc[1] / 64,
+					acc[2] / 64, acc[3] / 64);
+			acc[0] = acc[1] = acc[2] = acc[3] = 0;
+		}
+	}
 	if (stats) {
 		memset(stats, 0, sizeof *stats);
 		stats->reads_committed = (size_t) ctx->cur < ctx->computed_reads.size() ? ctx->computed_reads[(size_t) ctx->cur].second : h->n_reads;
@@ -706,6 +829,51 @@ int conga_sync(conga_ctx *ctx)
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2)); // (the copies of a conga_sample_reads that no compute has taken up yet)
 	TRY(settle_wrap_risk(ctx));
 	return CONGA_OK;
+}
+
+// ---- the results of the compute BEFORE the latest one (conga_chrom_compute_ahead).  Each call changes the two sets over, does
+// what its namesake does, and changes them back: nothing else of the context notices.
+namespace {
+int previous_or_fail(conga_ctx *ctx, const char *who)
+{
+	if (!ctx->have_previous || !ctx->computed)
+		return fail(ctx, CONGA_ERR_INVALID, std::string(who) + ": no compute before the latest one whose results are kept (conga_chrom_compute_ahead)");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	return settle_previous(ctx);
+}
+} // namespace
+
+int conga_sample_fetch_previous(conga_ctx *ctx, conga_result *records, size_t n_records, float *expected_rd, conga_chrom_stats *stats)
+{
+	if (!ctx)
+		return CONGA_ERR_INVALID;
+	TRY(previous_or_fail(ctx, "conga_sample_fetch_previous"));
+	swap_result_sets(ctx);
+	const bool keep = ctx->reads_ahead;
+	ctx->reads_ahead = true; // (the HostSlots describe a newer sample; the guard has been settled: nothing is computed again)
+	const int rc = conga_sample_fetch(ctx, records, n_records, expected_rd, stats);
+	ctx->reads_ahead = keep;
+	swap_result_sets(ctx);
+	return rc;
+}
+
+int conga_sync_previous(conga_ctx *ctx)
+{
+	if (!ctx)
+		return CONGA_ERR_INVALID;
+	return previous_or_fail(ctx, "conga_sync_previous"); // (settle_previous waits for that compute's last launch)
+}
+
+int conga_results_copy_previous(conga_ctx *ctx, void *dst_device, size_t dst_bytes)
+{
+	if (!ctx)
+		return CONGA_ERR_INVALID;
+	if (!ctx->have_previous || !ctx->computed)
+		return fail(ctx, CONGA_ERR_INVALID, "conga_results_copy_previous: no compute before the latest one whose results are kept");
+	swap_result_sets(ctx);
+	const int rc = conga_results_copy(ctx, dst_device, dst_bytes); // (on the context's stream: behind the launches of BOTH computes)
+	swap_result_sets(ctx);
+	return rc;
 }
 
 int conga_copy_read_depth(conga_ctx *ctx, int16_t *out, int64_t n)

@@ -191,7 +191,23 @@ struct conga_ctx {
 	hipGraphExec_t graph_exec = nullptr; // the captured step; dropped whenever the layout changes
 	bool graph_dense = false;
 	int computes_on_layout = 0;          // computes since the layout last changed
-	hipEvent_t ev_done = nullptr;
+	hipEvent_t ev_done = nullptr;      // the end of the LATEST compute (also waited for by the inflate-ahead thread on its streams)
+	// conga_chrom_compute_ahead: TWO computes in flight.  What a compute leaves for its fetch -- the pinned read-back blocks, the
+	// records in HBM, the event behind its last launch, what it ran on -- exists twice; the set of the compute BEFORE the latest
+	// one is the `_prev` half, and the two change places (swap_result_sets) whenever the previous compute's results are asked for
+	// or a compute goes ahead.  A small step's time is mostly the host's (the wait's wake-up, the fetch, the next step's launches:
+	// 0.27 ms against 0.12 ms of kernels on one chromosome); with the next compute already in the queue the GPU does not wait for it.
+	hipEvent_t ev_set = nullptr, ev_set_prev = nullptr; // the end of the compute whose results the set holds
+	Small *h_small_prev = nullptr;
+	size_t h_small_prev_cap = 0;
+	conga_result *h_results_prev = nullptr;
+	size_t h_results_prev_cap = 0;
+	DevBuf d_results_prev;
+	bool prev_by_order = false, prev_valid = false, prev_depth_resident = false;
+	std::vector<std::pair<int64_t, int64_t>> prev_computed_reads;
+	int64_t prev_computed_total = 0;
+	bool have_previous = false;    // the `_prev` half holds the results of the compute before the latest one (same layout)
+	bool previous_settled = false; // ... and its wrap guard has been looked at (settle_previous)
 	hipEvent_t ev_k0[CONGA_K_COUNT] = {}, ev_k1[CONGA_K_COUNT] = {};
 	bool ev_used[CONGA_K_COUNT] = {};
 };
@@ -206,6 +222,7 @@ int fail(conga_ctx *ctx, int status, const std::string &msg)
 }
 
 int enqueue_compute(conga_ctx *ctx, bool dense);
+int settle_previous(conga_ctx *ctx); // (engine_compute.hip.h: the wrap guard of the compute before the latest one)
 
 // Formulation: tuple / row space unless the arrays were asked for, the reads may be unsorted, or a `short` may wrap.
 bool dense_formulation(const conga_ctx *ctx)

@@ -1487,8 +1487,10 @@ struct ChainArgs {
 	float *expected; // [n_iv]
 	int32_t fused_score;   // 1: score each interval as its chain ends (score.observed etc. are final already)
 	ScoreArgs score;
-	conga_result *out_host; // pinned host copy of the records (may be null), in the order of order[]: what one wave
-	                        // writes is contiguous; the host un-permutes at fetch
+	conga_result *out_host; // pinned host copy of the records (may be null), in INTERVAL order like score.out: a record is one
+	                        // 64-byte line wherever it goes (tools/hostwrite.hip: stores into pinned host memory run at the link's
+	                        // rate whatever their shape), and the host's fetch is a plain copy -- in processing order, un-permuted by
+	                        // the host, 40 000 records cost the fetch 0.25-0.4 ms a step (round 4's last day)
 	int32_t table_blocks;   // > 0: that many trailing workgroups do expected_table_kernel's job (one chromosome each)
 	Small *host_small;      // its pinned host copy (may be null)
 	int32_t zero_blocks;    // > 0: that many workgroups in front of those clear the OTHER accumulator arena (the
@@ -1510,8 +1512,9 @@ __device__ __forceinline__ void chain_emit(const ChainArgs &a, int32_t iv, int64
 		const conga_result r = score_interval(a.score, iv, expected);
 		a.score.out[iv] = r;
 		if (a.out_host)
-			a.out_host[order_pos] = r;
+			a.out_host[iv] = r;
 	}
+	(void) order_pos;
 }
 
 // Inclusive prefix sum over a lane group through DPP (no LDS crossbar): row_shr 1/2/4/8 inside each
@@ -1995,9 +1998,9 @@ template <bool LDS_TABLES> __device__ __forceinline__ void chain_serial_lanes(co
 			chain_emit(a, ci.iv, first + idx, s);
 		return;
 	}
-	// Scored here, and the pinned host copy written as one contiguous 4 KiB run per wave: every lane parks its record
-	// in LDS, then four neighbouring lanes write one record's four 16-byte quarters, sixteen records (1 KiB) per
-	// instruction.
+	// Scored here, and the pinned host copy written a whole 64-byte record at a time: every lane parks its record in LDS,
+	// then four neighbouring lanes write one record's four 16-byte quarters, sixteen records per instruction, each to its
+	// interval's place.
 	const int lane = threadIdx.x & (kWave - 1);
 	uint4 *my_stage = stage + (size_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x / kWave)) * kWave * 4; // this wave's 64 records
 	if (have) {
@@ -2008,13 +2011,14 @@ template <bool LDS_TABLES> __device__ __forceinline__ void chain_serial_lanes(co
 	}
 
 	__builtin_amdgcn_wave_barrier(); // written and read by lanes of the same wave: LDS ops stay in order
+	const int32_t my_iv = have ? ci.iv : -1;
 #pragma unroll
 	for (int t = 0; t < 4; t++) {
 		const int src = t * 16 + (lane >> 2);
-		const int64_t pos_src = first + idx - lane + src; // lanes of a wave hold consecutive entries of order[]
+		const int32_t iv_src = __shfl(my_iv, src, kWave); // the interval whose record lane `src` parked
 		const uint4 v = my_stage[src * 4 + (lane & 3)];
-		if (pos_src < first + count)
-			reinterpret_cast<uint4 *>(a.out_host + pos_src)[lane & 3] = v;
+		if (iv_src >= 0)
+			reinterpret_cast<uint4 *>(a.out_host + iv_src)[lane & 3] = v;
 	}
 }
 

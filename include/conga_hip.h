@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define CONGA_ABI_VERSION 8
+#define CONGA_ABI_VERSION 9
 
 typedef struct conga_ctx conga_ctx;
 
@@ -297,6 +297,24 @@ int conga_sample_chrom(conga_ctx *ctx, int index);
  * n_records must be the total; expected_rd (may be NULL) receives 101 floats per chromosome, stats (may be NULL) one
  * entry per chromosome. */
 int conga_sample_fetch(conga_ctx *ctx, conga_result *records, size_t n_records, float *expected_rd, conga_chrom_stats *stats);
+
+/* ---- two computes in flight (ABI v9) -------------------------------------------------------------------------
+ * The reference handles one sample per process, one chromosome after the other (bam_data.c:269-339): nothing of sample k + 1
+ * depends on sample k.  With the loop above the GPU still waits for the host between two samples -- for the wait on sample k
+ * to return, for its records to be taken out, for the launches of sample k + 1 to arrive: 0.27 ms a step where the kernels take
+ * 0.12 (one chromosome of a 1x genome, the share of a rank on eight GPUs).  conga_chrom_compute_ahead() enqueues a compute
+ * BEHIND the last one and keeps that one's results (pinned read-back blocks, records in HBM, statistics) where they are:
+ *     conga_sample_reads(k + 1);  conga_chrom_compute_ahead();  conga_sample_fetch_previous(k);
+ * The `_previous` calls are their namesakes for the compute before the latest one; the plain calls keep addressing the latest
+ * (the last sample of a loop is fetched with conga_sample_fetch).  The wrap guard of the older compute is settled inside them --
+ * out of the pair of tuple buffers that no copy is writing: the next conga_sample_reads* / conga_sample_begin settles it first if
+ * the caller has not (and then waits for that compute) --, a second compute in the dense formulation is enqueued behind the
+ * latest one's launches.  conga_chrom_compute() gives up whatever an older compute left; conga_chrom_compute_ahead() is
+ * conga_chrom_compute() when there is nothing to keep (no compute yet, a changed layout, split reads, CONGA_FLAG_PROFILE). */
+int conga_chrom_compute_ahead(conga_ctx *ctx);
+int conga_sample_fetch_previous(conga_ctx *ctx, conga_result *records, size_t n_records, float *expected_rd, conga_chrom_stats *stats);
+int conga_sync_previous(conga_ctx *ctx);   /* waits for that compute alone (the latest one may still run) and settles its guard */
+int conga_results_copy_previous(conga_ctx *ctx, void *dst_device, size_t dst_bytes); /* conga_results_copy of its records, on the context's stream */
 
 /* ---- count_reads_bam with the BAM decode on the device -------------------------------------------------------
  * Instead of decoded tuples the caller hands over a stretch of the BAM file exactly as it is on disk, the table of

@@ -26,7 +26,7 @@ def test_header_symbols_are_exported(capi):
 
 def test_abi_version_and_struct_sizes(capi):
     lib = capi.load()
-    assert lib.conga_abi_version() == 8
+    assert lib.conga_abi_version() == 9
     assert capi.RESULT_DTYPE.itemsize == 64
     assert ctypes.sizeof(capi.Opts) == 32
     assert ctypes.sizeof(capi.BgzfBlock) == 24 and ctypes.sizeof(capi.BamSegment) == 24

@@ -223,6 +223,122 @@ def test_next_sample_handed_over_beside_the_compute_one_context(capi, oracle, fo
         check_against_oracle(oracle, chroms, samples[3], recs, E, False)
 
 
+def test_two_computes_in_flight_one_context(capi, oracle, formulation):
+    """conga_chrom_compute_ahead (ABI v9): sample k + 1 is handed over AND computed before sample k is fetched -- the results of the
+    compute before the latest one stay where they are (conga_sample_fetch_previous) -- and every sample's records are still its own,
+    whether its positions came as 32-bit numbers or as packed differences.  Two of the samples wrap a `short` (40 000 reads on one
+    base): the older compute's guard is settled with the sets changed over, out of the pair of tuple buffers no copy is writing,
+    behind the launches of the compute ahead."""
+    chroms = layout(False)
+    covs = [1.0, 2.0, 0.5, 1.5, 0.8, 1.2]
+    samples = [sample_reads_of(chroms, 40 + k, covs[k]) for k in range(len(covs))]
+    hot = int(chroms[1][1][3]) + 17
+    for k in (1, 4):
+        p, m = samples[k][1]
+        p = np.sort(np.concatenate([p, np.full(40_000, hot, np.int32)])).astype(np.int32)
+        samples[k][1] = (p, np.full(len(p), 60, np.uint8))
+    n = len(samples)
+    with capi.Context(device=0, flags=capi.FLAG_BATCH) as ctx:
+        open_layout(ctx, chroms, False)
+        pinned = [pinned_sample(ctx, r) for r in samples]
+        packed = {}                                        # (the arrays of a hand-over stay as they are until its compute has been waited for)
+
+        def hand_over(k):
+            pos, mapq, off = pinned[k]
+            if k % 2 == 0:
+                ctx.sample_reads(pos, mapq, off)
+            else:                                          # (the packed hand-over's expansion runs in the compute that goes ahead)
+                if k not in packed:
+                    bits, w, ei, ep = capi.encode_packed(pos[:int(off[-1])], off, None)
+                    packed[k] = (capi.pack_inline(bits, ei, ep), w, len(ei))
+                ctx.sample_reads_packed(packed[k][0], packed[k][1], packed[k][2], None, mapq, off)
+
+        def check(k, got):
+            recs, E, st = got
+            check_against_oracle(oracle, chroms, samples[k], recs, E, False)
+            assert [s.reads_committed for s in st] == [len(r[0]) for r in samples[k]], k
+            assert st[1].depth_materialized == (1 if (k in (1, 4) or formulation == "dense") else 0), k
+
+        with pytest.raises(capi.CongaError):
+            ctx.sample_fetch_previous()                    # nothing computed, nothing kept
+        hand_over(0)
+        ctx.compute_ahead()                                # (nothing to keep yet: a plain compute)
+        with pytest.raises(capi.CongaError):
+            ctx.sample_fetch_previous()
+        for k in range(n):
+            if k + 1 < n:
+                hand_over(k + 1)
+                ctx.compute_ahead()                        # behind compute k, which nobody has waited for
+                check(k, ctx.sample_fetch_previous(want_stats=True))
+            else:
+                check(k, ctx.sample_fetch(want_stats=True))
+        # a caller that hands the NEXT sample over before it has fetched the older one: the hand-over settles that one's guard
+        # first (it is sample 4's pair of buffers the copy goes into), the records are fetched afterwards all the same
+        hand_over(4)
+        ctx.compute()
+        hand_over(2)
+        ctx.compute_ahead()
+        hand_over(3)                                       # sample 4 (it wraps) has not been fetched
+        check(4, ctx.sample_fetch_previous(want_stats=True))
+        ctx.compute_ahead()                                # keeps sample 2, computes sample 3
+        check(2, ctx.sample_fetch_previous(want_stats=True))
+        check(3, ctx.sample_fetch(want_stats=True))
+        # a plain compute gives the older results up
+        hand_over(0)
+        ctx.compute()
+        with pytest.raises(capi.CongaError):
+            ctx.sample_fetch_previous()
+        check(0, ctx.sample_fetch(want_stats=True))
+
+
+def test_records_of_the_compute_before_the_latest_on_the_device(capi, oracle):
+    """conga_sync_previous + conga_results_copy_previous (the multi-GPU loop's half of ABI v9): with CONGA_FLAG_RESULTS_ON_DEVICE the
+    older compute's records are copied device to device while the latest compute's launches are in the queues."""
+    import ctypes
+    chroms = layout(False)
+    samples = [sample_reads_of(chroms, 50 + k, 1.0 + 0.5 * k) for k in range(3)]
+    with capi.Context(device=0, flags=capi.FLAG_BATCH) as plain:
+        open_layout(plain, chroms, False)
+        want = []
+        for r in samples:
+            plain.sample_reads(*pinned_sample(plain, r))
+            plain.compute()
+            want.append(plain.sample_fetch()[0].tobytes())
+    # device buffers from the HIP runtime the library is linked against (torch ships another and wants a process of its own)
+    paths = sorted({line.split()[-1] for line in open("/proc/self/maps") if "libamdhip64" in line}, key=lambda q: ("/opt/rocm" not in q, q))
+    hip = ctypes.CDLL(paths[0])
+    nbytes = len(want[0])
+    bufs = []
+    for _ in samples:
+        p = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(nbytes)) == 0
+        assert hip.hipMemset(p, 0, ctypes.c_size_t(nbytes)) == 0
+        bufs.append(p)
+    try:
+        with capi.Context(device=0, flags=capi.FLAG_BATCH | capi.FLAG_RESULTS_ON_DEVICE) as ctx:
+            open_layout(ctx, chroms, False)
+            pinned = [pinned_sample(ctx, r) for r in samples]
+            ctx.sample_reads(*pinned[0])
+            ctx.compute()
+            for k in range(len(samples)):
+                if k + 1 < len(samples):
+                    ctx.sample_reads(*pinned[k + 1])
+                    ctx.compute_ahead()
+                    ctx.sync_previous()
+                    ctx.results_copy_previous(bufs[k].value, nbytes)
+                else:
+                    ctx.sync()
+                    ctx.results_copy(bufs[k].value, nbytes)
+            ctx.sync()
+            for k in range(len(samples)):
+                got = np.zeros(nbytes, np.uint8)
+                assert hip.hipMemcpy(ctypes.c_void_p(got.ctypes.data), bufs[k], ctypes.c_size_t(nbytes), 2) == 0   # hipMemcpyDeviceToHost
+                assert got.tobytes() == want[k], k
+    finally:
+        for p in bufs:
+            hip.hipFree(p)
+
+
 def test_positions_as_16_bit_differences_give_the_same_records(capi, oracle, formulation):
     """conga_sample_reads_d16: the same samples handed over as differences + exceptions (a gap of 65 535 bases and more, one of
     exactly 65 534 and 65 535, equal neighbours, a chromosome without reads, a chromosome of one read, chunk borders of the scan
