@@ -130,6 +130,7 @@ int compute_step(conga_ctx *ctx)
 		HIP_TRY(ctx, hipGraphLaunch(ctx->graph_exec, st));
 	}
 	ctx->depth_resident = dense;
+	ctx->rd_clobbered = false;
 	ctx->small_cur = ctx->small_cur_next; // the arena the chain launch has just cleared, if it did
 	HIP_TRY(ctx, hipEventRecord(ctx->ev_done, st));
 	HIP_TRY(ctx, hipEventRecord(ctx->ev_set, st));
@@ -639,10 +640,16 @@ int settle_previous(conga_ctx *ctx)
 	swap_result_sets(ctx);
 	int rc = hipEventSynchronize(ctx->ev_set) == hipSuccess ? CONGA_OK : fail(ctx, CONGA_ERR_HIP, "settle_previous: waiting for the compute failed");
 	if (rc == CONGA_OK) {
-		const bool keep = ctx->reads_ahead;
+		// (wrap_risk is what the host knows about the LATEST sample -- set, for one, when that sample's own guard has just sent it to
+		// the dense kernels; it says nothing about the older one)
+		const bool keep = ctx->reads_ahead, keep_risk = ctx->wrap_risk, was_dense = ctx->depth_resident;
 		ctx->reads_ahead = true;
+		ctx->wrap_risk = false;
 		rc = settle_wrap_risk(ctx);
 		ctx->reads_ahead = keep;
+		ctx->wrap_risk = keep_risk;
+		if (!was_dense && ctx->depth_resident && ctx->prev_depth_resident)
+			ctx->rd_clobbered = true; // read_depth[] in HBM is the older sample's now: conga_copy_read_depth builds the latest one's again
 	}
 	swap_result_sets(ctx);
 	return rc;
@@ -884,7 +891,7 @@ int conga_copy_read_depth(conga_ctx *ctx, int16_t *out, int64_t n)
 	if (ctx->reads_ahead)
 		return fail(ctx, CONGA_ERR_INVALID, "conga_copy_read_depth: the reads have been replaced since the compute");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
-	if (!ctx->depth_resident) {
+	if (!ctx->depth_resident || ctx->rd_clobbered) {
 		// tuple-space compute: build read_depth[] now; its by-products go to a scratch block, not into the results
 		const size_t bytes = ctx->slots.size() * sizeof(Small);
 		TRY(ensure(ctx, ctx->d_small_scratch, bytes));
@@ -892,6 +899,7 @@ int conga_copy_read_depth(conga_ctx *ctx, int16_t *out, int64_t n)
 		TRY(launch_dense_depth(ctx, ptr<Small>(ctx->d_small_scratch), false));
 		HIP_TRY(ctx, hipGetLastError());
 		ctx->depth_resident = true;
+		ctx->rd_clobbered = false;
 	}
 	HIP_TRY(ctx, hipMemcpyAsync(out, ptr<int16_t>(ctx->d_rd) + h->rd_off, (size_t) n * 2, hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

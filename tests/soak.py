@@ -230,6 +230,10 @@ def main():
     ap.add_argument("--packed", action="store_true",
                     help="cohort hand-overs: random samples behind random layouts through conga_sample_reads and through "
                          "conga_sample_reads_packed at every width (exceptions separate and inline, beside the previous compute): same records")
+    ap.add_argument("--ahead", action="store_true",
+                    help="two computes in flight (ABI v9): random layouts, random sequences of samples (pile-ups that wrap a `short`, empty "
+                         "chromosomes, 32-bit and packed hand-overs) through conga_chrom_compute_ahead / conga_sample_fetch_previous in "
+                         "random call orders: every sample's records == the records of that sample computed alone")
     ap.add_argument("--bam-rp", action="store_true",
                     help="`conga --rp` on random BAMs with sequences: records mapped in place after the decode on the GPU (one call, and "
                          "one per chromosome) against the host decoders handing them over -- same files, same split-read counts")
@@ -356,6 +360,119 @@ def main():
             if a.seconds and time.time() - t0 > a.seconds:
                 break
         print("soak: %d layouts: conga_sample_reads_packed at every width == conga_sample_reads (seed %d, %.0f s)" % (done, a.seed, time.time() - t0))
+        return
+    if a.ahead:
+        from conga_amd import synth
+        wraps = 0
+        for i in range(a.first_case, a.first_case + a.cases):
+            rng = np.random.default_rng([a.seed, 16_000_000 + i])
+            n_chr = int(rng.integers(1, 5))
+            chroms = []
+            for k in range(n_chr):
+                L = int(rng.choice([rng.integers(5_000, 100_000), rng.integers(100_000, 2_000_000)]))
+                c = synth.make_chrom(str(k + 1), L, cov=0.0, n_dels=int(rng.integers(1, 40)), n_dups=int(rng.integers(0, 10)), gaps=bool(rng.integers(0, 2)),
+                                     seed=int(rng.integers(1, 1 << 30)))
+                chroms.append((c, *synth.kept_sorted(c.del_start, c.del_end), *synth.kept_sorted(c.dup_start, c.dup_end)))
+            n_smp = int(rng.integers(2, 8))
+            samples = []
+            for smp in range(n_smp):
+                reads = []
+                for c, *_r in chroms:
+                    cov = float(rng.choice([0.0, 0.02, 0.5, 1.0, 4.0]))
+                    p, m = synth.make_reads(c.length, c.gc, c.step, cov, 100, rng) if cov else (np.zeros(0, np.int32), np.zeros(0, np.uint8))
+                    if rng.random() < 0.25:                   # a pile-up that wraps the reference's `short` (or stays just below the guard)
+                        p = np.sort(np.concatenate([p, np.full(int(rng.choice([20_000, 33_000, 40_000, 70_000])), int(rng.integers(0, c.length)), np.int32)])).astype(np.int32)
+                        m = np.full(len(p), 60, np.uint8)
+                    reads.append((p, m))
+                n = sum(len(p) for p, _ in reads)
+                pos = np.concatenate([p for p, _ in reads] + [np.zeros(1, np.int32)]).astype(np.int32)
+                mapq = np.concatenate([m for _, m in reads] + [np.zeros(1, np.uint8)]).astype(np.uint8)
+                off = np.concatenate([[0], np.cumsum([len(p) for p, _ in reads])]).astype(np.uint64)
+                kind = str(rng.choice(["int32", "packed", "inline"]))
+                bits, w, ei, ep = capi.encode_packed(pos[:n], off, None if rng.random() < 0.5 else int(rng.integers(5, 17)))
+                samples.append(dict(pos=pos, mapq=mapq, off=off, kind=kind, bits=np.concatenate([bits, np.zeros(32, np.uint8)]), w=w, ei=ei, ep=ep,
+                                    inline=capi.pack_inline(bits, ei, ep)))
+
+            def lay_out(ctx):
+                for c, ds, de, us, ue in chroms:
+                    ctx.chrom_begin(c.length, c.gc)
+                    ctx.intervals("D", ds, de)
+                    ctx.intervals("E", us, ue)
+
+            def hand_over(ctx, sm):
+                if sm["kind"] == "int32":
+                    ctx.sample_reads(sm["pos"], sm["mapq"], sm["off"])
+                elif sm["kind"] == "packed":
+                    ctx.sample_reads_packed(sm["bits"], sm["w"], sm["ei"], sm["ep"], sm["mapq"], sm["off"])
+                else:
+                    ctx.sample_reads_packed(sm["inline"], sm["w"], len(sm["ei"]), None, sm["mapq"], sm["off"])
+
+            mq = int(rng.choice([-1, -1, 0, 30]))
+            want, wrapping = [], []
+            with capi.Context(device=0, mq_threshold=mq, flags=capi.FLAG_BATCH) as ctx:   # every sample alone, one after the other
+                lay_out(ctx)
+                for sm in samples:
+                    ctx.sample_reads(sm["pos"], sm["mapq"], sm["off"])
+                    ctx.compute()
+                    r, E, st = ctx.sample_fetch(want_stats=True)
+                    wraps += int(any(x.depth_materialized for x in st))
+                    wrapping.append(int(any(x.depth_materialized for x in st)))
+                    want.append((r.tobytes(), E.tobytes()))
+            with capi.Context(device=0, mq_threshold=mq, flags=capi.FLAG_BATCH) as ctx:
+                lay_out(ctx)
+                got = {}
+                calls = []
+
+                def take(k, previous):
+                    r, E, _ = ctx.sample_fetch_previous() if previous else ctx.sample_fetch()
+                    got.setdefault(k, []).append((r.tobytes(), E.tobytes()))
+                    calls.append("fetch%s(%d)" % ("_previous" if previous else "", k))
+
+                hand_over(ctx, samples[0])
+                ctx.compute()
+                for k in range(n_smp):
+                    if k + 1 == n_smp:
+                        take(k, False)
+                        break
+                    order = int(rng.integers(0, 5))
+                    calls.append("[order %d]" % order)
+                    if order == 4:                            # round 4's order now and then: hand over, fetch, compute
+                        hand_over(ctx, samples[k + 1])
+                        take(k, False)
+                        ctx.compute()
+                        continue
+                    hand_over(ctx, samples[k + 1])
+                    ctx.compute_ahead()
+                    if order == 1:
+                        take(k + 1, False)                    # the latest one first (it is fetched again in its own turn)
+                    if order == 2:
+                        ctx.sync_previous()
+                    if order == 3 and k + 2 < n_smp:
+                        # the next sample handed over BEFORE the older one is fetched: the hand-over settles its guard; the sample
+                        # handed over is dropped again by the hand-over of the next turn (two without a compute: the later one counts)
+                        hand_over(ctx, samples[k + 2])
+                        take(k, True)
+                        hand_over(ctx, samples[k + 1])
+                        ctx.compute()                         # (sample k + 1 once more: a plain compute, the older results are given up)
+                        continue
+                    take(k, True)
+                for k in range(n_smp):
+                    for g in got.get(k, []):
+                        if g != want[k]:
+                            print("FAILED ahead case %d (seed %d): sample %d of %d (%s), %d chromosomes; records %s, tables %s; samples that wrap: %s; %s"
+                                  % (i, a.seed, k, n_smp, samples[k]["kind"], n_chr, "differ" if g[0] != want[k][0] else "equal", "differ" if g[1] != want[k][1] else "equal",
+                                     wrapping, " ".join(calls)), flush=True)
+                            raise SystemExit(1)
+                    if k not in got:
+                        print("FAILED ahead case %d (seed %d): sample %d was never fetched" % (i, a.seed, k), flush=True)
+                        raise SystemExit(1)
+            done += 1
+            if i % 10 == 9:
+                print("%d ahead cases ok, %.0f s" % (done, time.time() - t0), flush=True)
+            if a.seconds and time.time() - t0 > a.seconds:
+                break
+        print("soak: %d layouts, two computes in flight in random call orders == every sample computed alone (%d samples needed the dense kernels) (seed %d, %.0f s)"
+              % (done, wraps, a.seed, time.time() - t0))
         return
     if a.bam_rp:
         import re

@@ -283,6 +283,16 @@ def test_two_computes_in_flight_one_context(capi, oracle, formulation):
         ctx.compute_ahead()                                # keeps sample 2, computes sample 3
         check(2, ctx.sample_fetch_previous(want_stats=True))
         check(3, ctx.sample_fetch(want_stats=True))
+        # both computes in flight wrap, and the LATEST one is fetched first: its guard sends it to the dense kernels and leaves the
+        # context knowing that its sample wraps -- which says nothing about the older one (tests/soak.py --ahead, seed 901 case 11:
+        # the older sample's records came back as tuple space had them)
+        hand_over(1)
+        ctx.compute()
+        hand_over(4)
+        ctx.compute_ahead()
+        check(4, ctx.sample_fetch(want_stats=True))
+        check(1, ctx.sample_fetch_previous(want_stats=True))
+        check(4, ctx.sample_fetch(want_stats=True))
         # a plain compute gives the older results up
         hand_over(0)
         ctx.compute()
