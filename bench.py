@@ -300,6 +300,8 @@ class Leg:
             c.sync()
         if env["dist_on"]:
             self._dist_setup()
+            if os.environ.get("CONGA_BENCH_PHASES"):
+                self._finish_phases = [0.0] * 6
 
     def _dist_setup(self):
         import torch
@@ -370,6 +372,8 @@ class Leg:
         import torch
         import torch.distributed as dist
         env = self.env
+        ph = getattr(self, "_finish_phases", None)    # (CONGA_BENCH_PHASES=1: where the multi-rank finish's host time goes)
+        t0 = time.perf_counter()
         if previous:
             c.sync_previous()                         # (settles the wrap guard before the records are read on the device)
             c.results_copy_previous(self.packed[j].data_ptr(), self.n_iv_mine * self.rec)
@@ -380,25 +384,42 @@ class Leg:
             c.sync()
             dist.gather(self.packed[j].cpu(), self.recv[j], dst=0)
             return
-        prev = self.in_flight[(k - 1) % N_ROTATE] if k > 0 else None
+        t1 = time.perf_counter()
+        # the gathered records of the step before the last one are in (pinned) host memory before this step's go into the send
+        # buffer that step's successor will use (three buffers: steps k - 1 and k may be in flight).  Waiting for step k - 1 here --
+        # round 4's loop -- is waiting for the compute in front of its copy: 0.09 ms of every 0.17 ms step with little to copy.
+        prev = self.in_flight[(k - 2) % N_ROTATE] if k > 1 else None
         if prev is not None:
-            prev.synchronize()                        # the previous step's gathered records are in (pinned) host memory
-            self.in_flight[(k - 1) % N_ROTATE] = None
+            prev.synchronize()
+            self.in_flight[(k - 2) % N_ROTATE] = None
+        t2 = time.perf_counter()
         # RCCL over xGMI on a stream of the gather's own, ordered behind the copy on the context's stream by an event: the context's
         # stream goes on with the next compute while the records travel (send buffer j is not written again before step k + 3)
         ext = self.ext[self.ctxs.index(c)]
         copied = torch.cuda.Event()
         copied.record(ext)
         self.gstream.wait_event(copied)
+        t3 = time.perf_counter()
         with torch.cuda.stream(self.gstream):
             dist.gather(self.packed[j], self.recv[j], dst=0)
+            t4 = time.perf_counter()
             if env["rank"] == 0:
                 self.host_recv[j].copy_(self.recv_all[j], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.gstream)
             self.in_flight[j] = ev
+        if ph is not None:
+            t5 = time.perf_counter()
+            for i, (a, b) in enumerate(((t0, t1), (t1, t2), (t2, t3), (t3, t4), (t4, t5))):
+                ph[i] += b - a
+            ph[5] += 1
 
     def drain(self):
+        ph = getattr(self, "_finish_phases", None)
+        if ph is not None and ph[5] > 20:
+            print("[phases] finish over %d steps (ms each): sync + copy of the records %.3f, wait for the gather before %.3f, events %.3f, dist.gather %.3f, "
+                  "copy to the host + event %.3f" % ((int(ph[5]),) + tuple(1e3 * x / ph[5] for x in ph[:5])), file=sys.stderr, flush=True)
+            self._finish_phases = [0.0] * 6
         if self.env["dist_on"] and not self.env["rehearsal"]:
             for j, ev in enumerate(self.in_flight):
                 if ev is not None:
