@@ -7,7 +7,8 @@
 // sent as all ones plus an entry (index, position) of a short exception list.  Here the differences become positions again:
 // a segmented inclusive scan (an exception restarts the sum) in four launches -- where every chunk's exceptions begin in the list,
 // per-chunk aggregates, one workgroup's scan over them, the chunks' local scans with their carry -- writing the int32 array every kernel of the path reads.  25.6 M reads:
-// 51 MB (16 bits) or 32 MB (10 bits) over the link instead of 102, and ~40 us of HBM-bound work that hides under the next sample's copy.
+// 51 MB (16 bits) or 32 MB (10 bits) over the link instead of 102, and ~70 us of launches (6 + 21 + 15 + 27: the differences are read
+// twice, the positions written once) that hide under the next sample's copy.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -141,28 +142,38 @@ template <int W> __global__ __launch_bounds__(256) void delta_aggregate_kernel(c
 		agg[blockIdx.x] = make_int2(all.v, (int) all.f);
 }
 
-// launch 2 (one workgroup): exclusive scan over the chunks' aggregates -> what each chunk starts from
+// launch 2 (one workgroup): exclusive scan over the chunks' aggregates -> what each chunk starts from.  Every thread takes a run of
+// consecutive chunks (13 of a 1x genome's 12 500), folds it, ONE scan over the 1 024 runs gives each its start, and the run is walked
+// once more to write the carries: one barrier (a scan per 1 024 chunks, thirteen of them one after the other, was 27 us of the
+// expansion's 82 -- as long as the launch that writes the positions, profiles/r04n_kernel_stats.csv; 70 us in all now).
 __global__ __launch_bounds__(1024) void delta_carry_kernel(const int2 *__restrict__ agg, uint32_t n_chunks, int32_t *__restrict__ carry)
 {
 	__shared__ SegVal s_wave[16];
-	__shared__ SegVal s_all;
-	SegVal running = {0, 0u};
-	for (uint32_t base = 0; base < n_chunks; base += 1024) {
-		const uint32_t c = base + threadIdx.x;
-		SegVal mine = {0, 0u};
-		if (c < n_chunks) {
-			const int2 a = agg[c];
-			mine = SegVal{a.x, (uint32_t) a.y};
+	const uint32_t per = (n_chunks + 1023u) / 1024u;
+	const uint32_t c0 = min(threadIdx.x * per, n_chunks), c1 = min(c0 + per, n_chunks);
+	SegVal mine = {0, 0u};
+	// (eight aggregates -- one 64-byte line of the thread's own -- asked for before the first is used: a run is two trips to L2, not thirteen)
+	for (uint32_t c = c0; c < c1; c += 8) {
+		int2 a[8];
+#pragma unroll
+		for (int j = 0; j < 8; j++)
+			a[j] = c + j < c1 ? agg[c + j] : make_int2(0, 0);
+#pragma unroll
+		for (int j = 0; j < 8; j++)
+			mine = seg_combine(mine, SegVal{a[j].x, (uint32_t) a[j].y});
+	}
+	SegVal running = delta_block_exclusive<16>(mine, s_wave, nullptr); // of the runs in front of this one
+	for (uint32_t c = c0; c < c1; c += 8) {
+		int2 a[8];
+#pragma unroll
+		for (int j = 0; j < 8; j++)
+			a[j] = c + j < c1 ? agg[c + j] : make_int2(0, 0);
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			if (c + j < c1)
+				carry[c + j] = running.v;
+			running = seg_combine(running, SegVal{a[j].x, (uint32_t) a[j].y});
 		}
-		SegVal all;
-		const SegVal ex = delta_block_exclusive<16>(mine, s_wave, &all);
-		if (c < n_chunks)
-			carry[c] = seg_combine(running, ex).v;
-		if (threadIdx.x == 0)
-			s_all = all;
-		__syncthreads();
-		running = seg_combine(running, s_all);
-		__syncthreads();
 	}
 }
 
