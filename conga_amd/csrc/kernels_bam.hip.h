@@ -102,6 +102,9 @@ template <bool WRITE> __global__ __launch_bounds__(64) void bam_walk_kernel(BamW
 	uint64_t at = sg.start, first = kNone, stop = kNone;
 	uint32_t n = 0;
 	uint64_t w = WRITE ? a.write_at[k] : 0;
+	int32_t hp0 = 0, hp1 = 0, hp2 = 0; // WRITE: the tuples held back for the next 16-byte store (named: nothing indexed by a variable)
+	uint32_t hm = 0;
+	int held = 0;
 	uint8_t bad = 0;
 	for (;;) {
 		if (at + 12 > a.stream_len)
@@ -158,14 +161,40 @@ template <bool WRITE> __global__ __launch_bounds__(64) void bam_walk_kernel(BamW
 			}
 		}
 		if (WRITE) {
-			a.pos[w] = p;
-			a.mapq[w] = (uint8_t) ((uint32_t) load_i32(r + 12) >> 8); // l_read_name, MAPQ, bin: the byte at 13
+			// A lane's tuples go out four at a time -- a 16-byte store of positions and a 4-byte store of MAPQ bytes once the
+			// lane's place is a multiple of four: sixty-four lanes store to sixty-four different lines, and a 4-byte piece of a
+			// line is a read-modify-write of all of it for the memory (the writing walk took 1.6 ms of a 1x genome where the
+			// counting one takes 0.67).
+			const uint32_t mq = ((uint32_t) load_i32(r + 12) >> 8) & 0xFFu; // l_read_name, MAPQ, bin: the byte at 13
 			if (a.rec_off)
-				a.rec_off[w] = a.rec_base + here;
-			w++;
+				a.rec_off[w + held] = a.rec_base + here;
+			if (held == 0 && (w & 3u) != 0) { // (up to three in front of the first whole group)
+				a.pos[w] = p;
+				a.mapq[w] = (uint8_t) mq;
+				w++;
+			} else {
+				hm |= mq << (8 * held);
+				if (held == 3) {
+					*reinterpret_cast<int4 *>(a.pos + w) = make_int4(hp0, hp1, hp2, p);
+					*reinterpret_cast<uint32_t *>(a.mapq + w) = hm;
+					w += 4;
+					held = 0;
+					hm = 0;
+				} else {
+					hp2 = held == 2 ? p : hp2;
+					hp1 = held == 1 ? p : hp1;
+					hp0 = held == 0 ? p : hp0;
+					held++;
+				}
+			}
 		}
 		n++;
 	}
+	if (WRITE)
+		for (int j = 0; j < held; j++) { // (what is left of the last group)
+			a.pos[w + j] = j == 0 ? hp0 : j == 1 ? hp1 : hp2;
+			a.mapq[w + j] = (uint8_t) (hm >> (8 * j));
+		}
 	if (!WRITE) {
 		a.count[k] = n;
 		a.v_first[k] = first;
