@@ -340,6 +340,8 @@ void conga_destroy(conga_ctx *ctx)
 		(void) hipHostFree(ctx->h_small);
 	if (ctx->h_small_prev)
 		(void) hipHostFree(ctx->h_small_prev);
+	if (ctx->h_walk)
+		(void) hipHostFree(ctx->h_walk);
 	if (ctx->h_results_prev)
 		(void) hipHostFree(ctx->h_results_prev);
 	if (ctx->h_head)

@@ -208,6 +208,8 @@ struct conga_ctx {
 	int64_t prev_computed_total = 0;
 	bool have_previous = false;    // the `_prev` half holds the results of the compute before the latest one (same layout)
 	bool previous_settled = false; // ... and its wrap guard has been looked at (settle_previous)
+	void *h_walk = nullptr;        // pinned: what the counting walk of conga_reads_bgzf* found, and the places of the writing one
+	size_t h_walk_cap = 0;
 	bool rd_clobbered = false;     // d_rd holds the depth of an OLDER sample than the latest compute's (settle_previous computed it again)
 	hipEvent_t ev_k0[CONGA_K_COUNT] = {}, ev_k1[CONGA_K_COUNT] = {};
 	bool ev_used[CONGA_K_COUNT] = {};
