@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <sys/mman.h>
 
 int main(int argc, char **argv)
 {
@@ -17,9 +18,24 @@ int main(int argc, char **argv)
 	for (int a = 1; a + 1 < argc; a++)
 		if (strcmp(argv[a], "--rotate") == 0)
 			rotate = std::max(1, atoi(argv[a + 1]));
-	std::vector<std::vector<int32_t>> samples((size_t) rotate, std::vector<int32_t>(n));
+	// --huge 1 / 0: the positions in memory the kernel is asked to back with 2 MB pages / with 4 KB pages (madvise); default: as malloc gives it
+	int huge = -1;
+	for (int a = 1; a + 1 < argc; a++)
+		if (strcmp(argv[a], "--huge") == 0)
+			huge = atoi(argv[a + 1]);
+	std::vector<int32_t *> samples;
+	for (int r = 0; r < rotate; r++) {
+		const size_t bytes = ((n * 4 + (2u << 20) - 1) / (2u << 20) + 1) * (2u << 20);
+		char *m = (char *) mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+		if (m == MAP_FAILED)
+			return 2;
+		char *al = (char *) (((uintptr_t) m + (2u << 20) - 1) & ~(uintptr_t) ((2u << 20) - 1));
+		if (huge >= 0)
+			madvise(al, bytes - (2u << 20), huge ? MADV_HUGEPAGE : MADV_NOHUGEPAGE);
+		samples.push_back((int32_t *) al);
+	}
 	uint64_t x = 88172645463325252ull;
-	for (auto &pos : samples) {
+	for (int32_t *pos : samples) {
 		int32_t p = 0;
 		for (uint64_t i = 0; i < n; i++) {
 			x ^= x << 13, x ^= x >> 7, x ^= x << 17;
@@ -38,7 +54,7 @@ int main(int argc, char **argv)
 			spread = atoi(argv[++a]);
 			continue;
 		}
-		if (a < argc && strcmp(argv[a], "--rotate") == 0 && a + 1 < argc) {
+		if (a < argc && (strcmp(argv[a], "--rotate") == 0 || strcmp(argv[a], "--huge") == 0) && a + 1 < argc) {
 			a++;
 			continue;
 		}
@@ -52,14 +68,14 @@ int main(int argc, char **argv)
 		for (int rep = 0; rep < reps; rep++) {
 			const auto t0 = std::chrono::steady_clock::now();
 			std::vector<uint8_t> &out = outs[(size_t) (rep % rotate)];
-			if (pk.start(samples[(size_t) (rep % rotate)].data(), off, 2, 0, out.data(), out.size()) != 0 || pk.finish(&w, &ne, &nb) != 0)
+			if (pk.start(samples[(size_t) (rep % rotate)], off, 2, 0, out.data(), out.size()) != 0 || pk.finish(&w, &ne, &nb) != 0)
 				return 1;
 			ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
 		}
 		std::sort(ms.begin() + rotate, ms.end()); // (the first turn touches the pages)
 		const double best = ms[(size_t) rotate], median = ms[(size_t) rotate + (ms.size() - (size_t) rotate) / 2];
-		printf("%2d threads (spread %d, rotate %d): %.3f ms best, %.3f median of %d (width %d, %zu exceptions, %zu bytes) = %.1f GB/s of positions read, %s\n", nt, spread,
-				rotate, best, median, reps - rotate, w, ne, nb, 4.0 * n / best / 1e6, conga_pack::have_avx2_bmi2() ? "avx2+bmi2" : "scalar");
+		printf("%2d threads (spread %d, rotate %d, huge %d): %.3f ms best, %.3f median of %d (width %d, %zu exceptions, %zu bytes) = %.1f GB/s of positions read, %s\n", nt, spread,
+				rotate, huge, best, median, reps - rotate, w, ne, nb, 4.0 * n / best / 1e6, conga_pack::have_avx2_bmi2() ? "avx2+bmi2" : "scalar");
 	}
 	return 0;
 }
