@@ -252,7 +252,9 @@ struct Job {
 	};
 	bool build_table = false;
 	std::vector<uint64_t> known; // piece-relative offsets of block headers, ascending
-	uint64_t stop_at = 0;        // 0, or: the table ends with the first block that starts at or behind this offset
+	uint64_t stop_at = 0;        // 0, or one more than an offset: the table ends with the first block that starts at or behind that offset
+	                             // (one more: a next target that begins in the stretch's FIRST block is offset 0 -- which read as "none"
+	                             // and left the engine's table longer than the file's, tests/soak.py --bam seed 3001 case 362)
 	std::vector<PieceTable> piece_tables;
 	uint64_t expect = 0;         // where the chain goes on (upload thread)
 	bool table_failed = false, table_stopped = false; // (upload thread; published with the counters below)
@@ -345,7 +347,7 @@ inline void join_piece(Job &job, size_t c, const uint8_t *buf, uint64_t begin, s
 		job.out_off.push_back(job.total_out);
 		job.blocks.push_back(b);
 		job.total_out += b.inflated_len;
-		if (job.stop_at && b.data_off - 18 >= job.stop_at)
+		if (job.stop_at && b.data_off - 18 + 1 >= job.stop_at)
 			job.table_stopped = true; // (the block in which the next target begins is in: enough)
 	};
 	if (pt.bad) {

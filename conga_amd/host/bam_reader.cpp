@@ -624,7 +624,7 @@ public:
 			std::vector<uint64_t> rel{0};
 			for (uint64_t v : starts)
 				rel.push_back(v - c_lo);
-			hooks->named(*bytes, rel, c_end ? c_end - c_lo : 0);
+			hooks->named(*bytes, rel, c_end ? c_end - c_lo + 1 : 0); // (one more than the offset: 0 says "none", include/conga_hip.h)
 		}
 		// ---- block table.  A BGZF file is a chain (every header says where the next block starts), but the index knows
 		// thousands of block starts along it: the stretch is cut at some of them and every part is walked by its own thread;

@@ -372,8 +372,9 @@ int conga_reads_bgzf_fd(conga_ctx *ctx, int fd, uint64_t file_off, size_t n_byte
  * offsets, ascending, the first one 0.  The engine then reads the block table off the bytes while they pass through its pinned
  * ring (every copying thread follows the chain of headers inside its piece from the first known start on; what straddles two
  * pieces is read from the file), publishes it batch by batch, and -- once a call of this context has shown how much such a
- * file inflates to -- inflates the batches ahead as well, into a spare output buffer.  stop_at (0: none): the table ends with
- * the first block that begins at or behind this offset.  conga_reads_bgzf_next_table() waits for the table (n_blocks 0: none
+ * file inflates to -- inflates the batches ahead as well, into a spare output buffer.  stop_at (0: none; otherwise ONE MORE than an
+ * offset inside the stretch -- offset 0, the stretch's first block, is an offset like any other): the table ends with the first block
+ * that begins at or behind that offset.  conga_reads_bgzf_next_table() waits for the table (n_blocks 0: none
  * -- a header of an unusual form, a chain that does not arrive at a known start: the caller walks the file itself); the
  * conga_reads_bgzf_fd call that brings the SAME table finds the stream inflated and goes straight to its record walks, any
  * other table makes it inflate as usual.  The pointer stays valid until that call has returned or the ticket is forgotten.

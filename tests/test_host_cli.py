@@ -834,6 +834,31 @@ def test_cli_cohort_that_stood_still_on_round_3s_last_day(tmp_path, piece_kb, ah
 
 
 @pytest.mark.gpu
+def test_cli_cohort_whose_next_target_begins_in_the_stretchs_first_block(tmp_path):
+    """tests/soak.py --bam, seed 3001, case 362, as a fixture (round 4's last hours): a file so small that the target behind the last
+    one wanted begins in the FIRST block of the stretch named to the engine.  `stop_at` -- where the engine's block table may end --
+    was that block's offset inside the stretch, 0, which also said "none": the engine's table had every block of the stretch (4),
+    the planner's own walk stopped after the first, and CONGA_BGZF_CHECK_TABLE=1 (which wants the two alike) aborted the run.
+    stop_at is one more than the offset now."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import soak
+    d = str(tmp_path)
+    args = soak.bam_case(np.random.default_rng([3001, 11_000_000 + 362]), d)
+    assert "--gpus" not in args
+    with open(os.path.join(d, "list.txt"), "w") as f:
+        f.write("".join("r.bam\tc%d\n" % k for k in range(4)))
+    env = dict(os.environ, CONGA_GPU_BAM="1", CONGA_BGZF_OVERLAP="1", CONGA_BGZF_CHECK_TABLE="1", CONGA_TIMING="1", CONGA_BGZF_PIECE_KB="512")
+    r = subprocess.run([CONGA, "--cohort", "list.txt", "--out", "co"] + args[2:], cwd=d, capture_output=True, text=True, timeout=60, env=env)
+    assert r.returncode == 0 and "decoding on the host" not in r.stderr and "is not the one read from the file" not in r.stderr, r.stderr[-3000:]
+    assert "the engine's and the file's agree" in r.stderr, r.stderr[-3000:]
+    one = subprocess.run([CONGA] + args + ["--out", "one"], cwd=d, capture_output=True, text=True, timeout=60, env=dict(os.environ, CONGA_GPU_BAM="1"))
+    assert one.returncode == 0, one.stderr[-2000:]
+    for k in range(4):
+        for kind in ("svs", "dels", "dups"):
+            assert open(os.path.join(d, "c%d_%s.bed" % (k, kind)), "rb").read() == open(os.path.join(d, "one_%s.bed" % kind), "rb").read(), (k, kind)
+
+
+@pytest.mark.gpu
 def test_cli_cohort_pipeline_neither_grows_its_spare_set_nor_waits_for_a_call_that_waits_for_it(tmp_path):
     """Round 4's last day, from the pipeline's event trace (profiles/r04j_cohort_first_samples.log).  (1) The first sample's output set is
     the spare set after the first swap: sized for that sample alone it was grown by the next job's inflating thread -- gigabytes allocated
