@@ -109,6 +109,31 @@ def test_c_producer_writes_what_the_numpy_encoder_writes(threads):
             assert pk.finish() == (w, n_esc, nbytes) and np.array_equal(out_v[:nbytes], out[:nbytes])   # (the same width from the same reads)
 
 
+def test_c_producer_into_a_buffer_at_any_address():
+    """The producer's runs leave the core with non-temporal 16-byte stores when the destination allows it and with plain ones when it
+    does not (pack_host.h: stream_copy): a buffer that starts 1, 3, 8 or 15 bytes behind a 16-byte boundary gets the same bytes, and
+    nothing in front of it or behind what the bound promises is touched."""
+    rng = np.random.default_rng(11)
+    with capi.Packer(3) as pk:
+        pos, off = _case(rng, 4, 110.0, 30000)
+        n = len(pos)
+        assert n > 3 * 8192                                              # (several whole runs and a ragged one)
+        for width in (5, 10, 16, 0):
+            base = np.full(pk.bound(n, n) + 64, 0xAB, np.uint8)
+            a0 = (-base.ctypes.data) % 16                                 # first 16-byte boundary inside `base`
+            pk.start(pos, off, base[a0:], width)
+            w, n_esc, nbytes = pk.finish()
+            want = base[a0:a0 + nbytes].copy()
+            for shift in (1, 3, 8, 15):
+                buf = np.full(len(base), 0xAB, np.uint8)
+                out = buf[a0 + shift:]
+                assert out.ctypes.data % 16 == shift
+                pk.start(pos, off, out, w)
+                assert pk.finish() == (w, n_esc, nbytes)
+                assert np.array_equal(out[:nbytes], want), (width, shift)
+                assert (buf[:a0 + shift] == 0xAB).all() and (out[pk.bound(n, n):] == 0xAB).all(), (width, shift)
+
+
 def test_c_producer_picks_the_bench_widths_and_refuses_what_does_not_fit():
     rng = np.random.default_rng(7)
     with capi.Packer(2) as pk:
